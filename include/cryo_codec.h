@@ -1,0 +1,160 @@
+/*
+ * cryo_codec.h -- C ABI of the MI355X-native cryo-block codec.
+ *
+ * This is the drop-in boundary underneath pg_cryogen's compression.h
+ * (reference compression.h:7-24).  The reference reaches its codec through
+ * six third-party calls; each entry point below names the call (file:line in
+ * /root/reference) it replaces.  Plain C, plain pointers and sizes, no HIP or
+ * torch types.  Nothing here ever calls elog()/exit()/throws: every function
+ * returns a cryo_status (0 = ok, negative = error) so that the PG-side C shim
+ * (pg_cryogen_amd/shim/compression.c) can raise ereport(ERROR) itself without a
+ * longjmp crossing C++ frames.
+ *
+ * Process model: a cryo_codec handle is bound to one GPU and one HIP stream and
+ * is used by one thread at a time (a PostgreSQL backend is single-threaded;
+ * reference pg_cryogen.c:603-663).  HIP is initialised lazily by
+ * cryo_codec_open(), never at library load, so loading the library in the
+ * postmaster before fork() is safe.
+ *
+ * There is NO CPU fallback in this library: without a usable GPU,
+ * cryo_codec_open() fails with CRYO_E_NODEV and nothing else can be called.
+ */
+#ifndef CRYO_CODEC_H
+#define CRYO_CODEC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* numeric values are an on-disk contract: CryoFirstPageHeader.compression_method
+ * (reference compression.h:7-11, storage.h:64, cache.c:133) */
+enum { CRYO_METHOD_LZ4 = 0, CRYO_METHOD_ZSTD = 1 };
+
+typedef enum {
+    CRYO_OK = 0,
+    CRYO_E_ARG = -1,         /* bad argument (null pointer, unknown method, size 0 ...) */
+    CRYO_E_HIP = -2,         /* HIP runtime call failed (see cryo_codec_last_error)     */
+    CRYO_E_NODEV = -3,       /* no usable gfx950 device                                 */
+    CRYO_E_CORRUPT = -4,     /* malformed compressed block, or decoded size != block_size */
+    CRYO_E_DSTSIZE = -5,     /* destination capacity below cryo_codec_bound()           */
+    CRYO_E_UNSUPPORTED = -6, /* valid request this build has no kernel for              */
+    CRYO_E_NOMEM = -7
+} cryo_status;
+
+typedef struct cryo_codec cryo_codec; /* opaque: device id, stream, workspace */
+
+/* ---- library / device ---- */
+
+/* "cryo-codec X.Y (lz4 block format as liblz4 1.9.3; zstd as libzstd 1.4.9)" */
+const char *cryo_codec_version(void);
+/* number of visible HIP devices, or a negative cryo_status */
+int cryo_codec_device_count(void);
+/* bind a handle to `device`; creates its stream.  Lazy HIP init happens here. */
+int cryo_codec_open(int device, cryo_codec **out);
+void cryo_codec_close(cryo_codec *c);
+/* text of the last HIP error seen by this handle ("" if none) */
+const char *cryo_codec_last_error(const cryo_codec *c);
+/* the handle's HIP stream as an opaque pointer (hipStream_t) for profilers/interop */
+void *cryo_codec_stream(cryo_codec *c);
+/* wait for everything queued on the handle's stream */
+int cryo_codec_sync(cryo_codec *c);
+
+/* ---- sizes ---- */
+
+/* replaces LZ4_compressBound (compression.c:67) / ZSTD_compressBound (compression.c:99):
+ * identical values (131602 / 131584 at 128 KiB, 1052704 / 1052672 at 1 MiB). 0 on bad args. */
+size_t cryo_codec_bound(int method, size_t block_size);
+
+/* ---- device memory plumbing (plain hipMalloc/hipMemcpy wrappers so that C
+ *      callers and ctypes need no HIP headers) ---- */
+int cryo_dev_alloc(cryo_codec *c, size_t bytes, void **d_ptr);
+int cryo_dev_free(cryo_codec *c, void *d_ptr);
+int cryo_dev_upload(cryo_codec *c, void *d_dst, const void *h_src, size_t bytes);   /* sync */
+int cryo_dev_download(cryo_codec *c, void *h_dst, const void *d_src, size_t bytes); /* sync */
+int cryo_dev_memset(cryo_codec *c, void *d_dst, int value, size_t bytes);           /* async */
+
+/* ---- batch codec on DEVICE-RESIDENT buffers (the hot path) ----
+ *
+ * One wavefront per cryo block; blocks are independent (the reference uses the
+ * stateless one-shot APIs, compression.c:70-72,102-104).  All calls are
+ * asynchronous on the handle's stream; per-block results land in the device
+ * arrays d_out_size / d_status (cryo_status values).
+ */
+
+/*
+ * Compress n_blocks blocks of block_size bytes.  Block i is read at
+ * d_src + i*src_stride and written at d_dst + i*dst_stride
+ * (dst_stride >= cryo_codec_bound(method, block_size)).
+ *   method LZ4 : replaces LZ4_compress_fast(src,dst,B,LZ4_compressBound(B),accel)
+ *                (compression.c:70-72); param = lz4_acceleration_guc (0..50);
+ *                output bytes identical to liblz4 1.9.3.
+ *   method ZSTD: replaces ZSTD_compress(dst,bound,src,B,level) (compression.c:102-104);
+ *                param = zstd_compression_level_guc (-5..22).
+ */
+int cryo_codec_compress_batch(cryo_codec *c, int method, int param,
+                              const void *d_src, uint64_t src_stride,
+                              uint32_t block_size, uint64_t n_blocks,
+                              void *d_dst, uint64_t dst_stride,
+                              uint32_t *d_out_size, int32_t *d_status);
+
+/*
+ * Decompress n_blocks blocks.  Compressed block i is the d_src_size[i] bytes at
+ * d_src + d_src_off[i]; it must decode to exactly block_size bytes, written at
+ * d_dst + i*dst_stride.  d_status[i] = CRYO_OK or CRYO_E_CORRUPT.
+ *   method LZ4 : replaces LZ4_decompress_safe(src,dst,csize,B) (compression.c:84)
+ *   method ZSTD: replaces ZSTD_decompress(dst,B,src,csize)     (compression.c:116)
+ * A stream that decodes to fewer than block_size bytes is reported as
+ * CRYO_E_CORRUPT (the reference only Assert()s this, compression.c:88,120).
+ */
+int cryo_codec_decompress_batch(cryo_codec *c, int method,
+                                const void *d_src, const uint64_t *d_src_off,
+                                const uint32_t *d_src_size,
+                                void *d_dst, uint64_t dst_stride,
+                                uint32_t block_size, uint64_t n_blocks,
+                                int32_t *d_status);
+
+/* ---- single block, HOST buffers: what cryo_compress()/cryo_decompress()
+ *      (compression.c:125-159) call.  Synchronous: H2D, kernel, D2H. ---- */
+int cryo_codec_compress_block(cryo_codec *c, int method, int param,
+                              const void *h_src, size_t block_size,
+                              void *h_dst, size_t dst_cap, size_t *out_size);
+int cryo_codec_decompress_block(cryo_codec *c, int method,
+                                const void *h_src, size_t src_size,
+                                void *h_dst, size_t block_size);
+
+/* ---- batch helpers used by staging, tests and the benchmark ---- */
+
+/* synthetic cryo blocks (include/cryo_synth.h) first_block .. first_block+n-1, on device */
+int cryo_codec_synth_batch(cryo_codec *c, uint64_t seed, uint64_t first_block, uint64_t n_blocks,
+                           uint32_t block_size, int dist, void *d_dst, uint64_t dst_stride);
+/* per-block 64-bit checksum (same function as cryo_checksum64() below) */
+int cryo_codec_checksum_batch(cryo_codec *c, const void *d_src, uint64_t src_stride,
+                              const uint32_t *d_sizes /* or NULL: fixed_size */, uint32_t fixed_size,
+                              uint64_t n_blocks, uint64_t *d_sums);
+/* number of blocks whose bytes differ between two batches -> *d_mismatch (device u64, accumulated) */
+int cryo_codec_compare_batch(cryo_codec *c, const void *d_a, uint64_t a_stride,
+                             const void *d_b, uint64_t b_stride, uint32_t block_size,
+                             uint64_t n_blocks, uint64_t *d_mismatch);
+/* host-side reference of the checksum, for tests */
+uint64_t cryo_checksum64(const void *p, size_t n);
+
+/* ---- timing on the handle's stream (HIP events) ---- */
+int cryo_codec_timer_start(cryo_codec *c);
+/* records the end event, waits for it, returns elapsed milliseconds */
+int cryo_codec_timer_stop(cryo_codec *c, float *ms);
+
+/* ---- counters (SURVEY.md section 5 "metrics") ---- */
+typedef struct {
+    uint64_t blocks_compressed, blocks_decompressed;
+    uint64_t bytes_in, bytes_out;   /* uncompressed bytes through compress / decompress */
+    uint64_t launches;
+} cryo_codec_counters;
+int cryo_codec_get_counters(const cryo_codec *c, cryo_codec_counters *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRYO_CODEC_H */

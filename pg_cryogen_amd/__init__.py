@@ -1,0 +1,11 @@
+"""pg_cryogen_amd -- MI355X-native cryo-block codec (the hot path of adjust/pg_cryogen).
+
+Layout (only what the path needs):
+  csrc/      gfx950 HIP kernels + the C-ABI host code  -> libcryo_codec.so
+  shim/      C mirror of the reference's compression.h over the C ABI
+  staging/   page-chain write/read staging and the decompressed-block cache (C)
+  codec.py   ctypes binding used by tests/ and bench.py
+The public contract is include/cryo_codec.h.
+"""
+from .codec import (Codec, CryoError, METHOD_LZ4, METHOD_ZSTD, bound, checksum64,  # noqa: F401
+                    device_count, version, DIST_NAMES)

@@ -1,0 +1,359 @@
+/*
+ * cryo_codec.cpp -- host side of the C ABI declared in include/cryo_codec.h.
+ *
+ * Thin by design: argument checks, HIP plumbing (stream, events, buffers) and
+ * kernel launches.  All codec arithmetic is in the .hip kernels.  No CPU codec
+ * exists in this library: if HIP or the device is unavailable every entry
+ * point fails with CRYO_E_NODEV / CRYO_E_HIP.
+ */
+#include "cryo_codec.h"
+#include "kernels.h"
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+struct cryo_codec {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    char err[256] = {0};
+    cryo_codec_counters ctr = {};
+    /* scratch for the single-block host API */
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    size_t in_cap = 0, out_cap = 0;
+    uint64_t *d_off = nullptr;
+    uint32_t *d_size = nullptr;
+    int32_t *d_status = nullptr;
+    /* zstd decode workspace */
+    void *d_ws = nullptr;
+    size_t ws_cap = 0;
+};
+
+namespace {
+
+int fail(cryo_codec *c, hipError_t e, const char *what)
+{
+    if (c) snprintf(c->err, sizeof c->err, "%s: %s", what, hipGetErrorString(e));
+    return CRYO_E_HIP;
+}
+
+#define HIP_TRY(c, call)                                                                           \
+    do {                                                                                           \
+        hipError_t e_ = (call);                                                                    \
+        if (e_ != hipSuccess) return fail((c), e_, #call);                                         \
+    } while (0)
+
+bool method_ok(int m) { return m == CRYO_METHOD_LZ4 || m == CRYO_METHOD_ZSTD; }
+
+int ensure(cryo_codec *c, uint8_t **p, size_t *cap, size_t need)
+{
+    if (*cap >= need) return CRYO_OK;
+    if (*p) { HIP_TRY(c, hipFree(*p)); *p = nullptr; *cap = 0; }
+    HIP_TRY(c, hipMalloc((void **)p, need));
+    *cap = need;
+    return CRYO_OK;
+}
+
+int ensure_ws(cryo_codec *c, size_t need)
+{
+    if (c->ws_cap >= need) return CRYO_OK;
+    if (c->d_ws) { HIP_TRY(c, hipFree(c->d_ws)); c->d_ws = nullptr; c->ws_cap = 0; }
+    HIP_TRY(c, hipMalloc(&c->d_ws, need));
+    c->ws_cap = need;
+    return CRYO_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *cryo_codec_version(void)
+{
+    return "cryo-codec 0.1 gfx950 (lz4 block format as liblz4 1.9.3; zstd frames as libzstd 1.4.9)";
+}
+
+int cryo_codec_device_count(void)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) return CRYO_E_NODEV;
+    return n;
+}
+
+int cryo_codec_open(int device, cryo_codec **out)
+{
+    if (!out) return CRYO_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return CRYO_E_NODEV;
+    if (device < 0 || device >= n) return CRYO_E_ARG;
+    cryo_codec *c = new (std::nothrow) cryo_codec;
+    if (!c) return CRYO_E_NOMEM;
+    c->device = device;
+    hipError_t e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_off, sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_size, sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_status, sizeof(int32_t));
+    if (e != hipSuccess) {
+        cryo_codec_close(c);
+        return CRYO_E_HIP;
+    }
+    *out = c;
+    return CRYO_OK;
+}
+
+void cryo_codec_close(cryo_codec *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->d_in) (void)hipFree(c->d_in);
+    if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_off) (void)hipFree(c->d_off);
+    if (c->d_size) (void)hipFree(c->d_size);
+    if (c->d_status) (void)hipFree(c->d_status);
+    if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *cryo_codec_last_error(const cryo_codec *c) { return c ? c->err : ""; }
+void *cryo_codec_stream(cryo_codec *c) { return c ? (void *)c->stream : nullptr; }
+
+int cryo_codec_sync(cryo_codec *c)
+{
+    if (!c) return CRYO_E_ARG;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CRYO_OK;
+}
+
+size_t cryo_codec_bound(int method, size_t n)
+{
+    if (method == CRYO_METHOD_LZ4) {
+        /* LZ4_compressBound: n + n/255 + 16, 0 above LZ4_MAX_INPUT_SIZE */
+        return n > 0x7E000000u ? 0 : n + n / 255 + 16;
+    }
+    if (method == CRYO_METHOD_ZSTD) {
+        /* ZSTD_COMPRESSBOUND: n + n/256 + (n < 128 KiB ? (128 KiB - n) >> 11 : 0) */
+        return n + (n >> 8) + (n < (128u << 10) ? ((128u << 10) - n) >> 11 : 0);
+    }
+    return 0;
+}
+
+/* ---- device memory plumbing ---- */
+int cryo_dev_alloc(cryo_codec *c, size_t bytes, void **d_ptr)
+{
+    if (!c || !d_ptr) return CRYO_E_ARG;
+    *d_ptr = nullptr;
+    HIP_TRY(c, hipSetDevice(c->device));
+    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return CRYO_E_NOMEM; }
+    if (e != hipSuccess) return fail(c, e, "hipMalloc");
+    return CRYO_OK;
+}
+int cryo_dev_free(cryo_codec *c, void *d_ptr)
+{
+    if (!c) return CRYO_E_ARG;
+    if (!d_ptr) return CRYO_OK;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipFree(d_ptr));
+    return CRYO_OK;
+}
+int cryo_dev_upload(cryo_codec *c, void *d_dst, const void *h_src, size_t bytes)
+{
+    if (!c || (bytes && (!d_dst || !h_src))) return CRYO_E_ARG;
+    if (!bytes) return CRYO_OK;
+    HIP_TRY(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CRYO_OK;
+}
+int cryo_dev_download(cryo_codec *c, void *h_dst, const void *d_src, size_t bytes)
+{
+    if (!c || (bytes && (!h_dst || !d_src))) return CRYO_E_ARG;
+    if (!bytes) return CRYO_OK;
+    HIP_TRY(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CRYO_OK;
+}
+int cryo_dev_memset(cryo_codec *c, void *d_dst, int value, size_t bytes)
+{
+    if (!c || (bytes && !d_dst)) return CRYO_E_ARG;
+    if (!bytes) return CRYO_OK;
+    HIP_TRY(c, hipMemsetAsync(d_dst, value, bytes, c->stream));
+    return CRYO_OK;
+}
+
+/* ---- batch codec ---- */
+int cryo_codec_compress_batch(cryo_codec *c, int method, int param, const void *d_src,
+                              uint64_t src_stride, uint32_t block_size, uint64_t n_blocks,
+                              void *d_dst, uint64_t dst_stride, uint32_t *d_out_size,
+                              int32_t *d_status)
+{
+    if (!c || !method_ok(method) || block_size == 0) return CRYO_E_ARG;
+    if (n_blocks == 0) return CRYO_OK;
+    if (!d_src || !d_dst || !d_out_size || !d_status || src_stride < block_size) return CRYO_E_ARG;
+    if (dst_stride < cryo_codec_bound(method, block_size)) return CRYO_E_DSTSIZE;
+    if (method == CRYO_METHOD_LZ4) {
+        HIP_TRY(c, cryo::launch_lz4_compress(c->stream, (const uint8_t *)d_src, src_stride, block_size,
+                                             n_blocks, (uint8_t *)d_dst, dst_stride, param,
+                                             d_out_size, d_status));
+    } else {
+        return CRYO_E_UNSUPPORTED; /* zstd encode kernel: not in this build yet */
+    }
+    c->ctr.blocks_compressed += n_blocks;
+    c->ctr.bytes_in += n_blocks * (uint64_t)block_size;
+    c->ctr.launches++;
+    return CRYO_OK;
+}
+
+int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
+                                const uint64_t *d_src_off, const uint32_t *d_src_size, void *d_dst,
+                                uint64_t dst_stride, uint32_t block_size, uint64_t n_blocks,
+                                int32_t *d_status)
+{
+    if (!c || !method_ok(method) || block_size == 0) return CRYO_E_ARG;
+    if (n_blocks == 0) return CRYO_OK;
+    if (!d_src || !d_src_off || !d_src_size || !d_dst || !d_status || dst_stride < block_size)
+        return CRYO_E_ARG;
+    if (method == CRYO_METHOD_LZ4) {
+        HIP_TRY(c, cryo::launch_lz4_decompress(c->stream, (const uint8_t *)d_src, d_src_off, d_src_size,
+                                               (uint8_t *)d_dst, dst_stride, block_size, n_blocks,
+                                               d_status));
+    } else {
+        const size_t need = cryo::zstd_decompress_workspace(n_blocks, block_size);
+        int rc = ensure_ws(c, need);
+        if (rc != CRYO_OK) return rc;
+        HIP_TRY(c, cryo::launch_zstd_decompress(c->stream, (const uint8_t *)d_src, d_src_off, d_src_size,
+                                                (uint8_t *)d_dst, dst_stride, block_size, n_blocks,
+                                                d_status, c->d_ws, c->ws_cap));
+    }
+    c->ctr.blocks_decompressed += n_blocks;
+    c->ctr.bytes_out += n_blocks * (uint64_t)block_size;
+    c->ctr.launches++;
+    return CRYO_OK;
+}
+
+/* ---- single block, host buffers ---- */
+int cryo_codec_compress_block(cryo_codec *c, int method, int param, const void *h_src,
+                              size_t block_size, void *h_dst, size_t dst_cap, size_t *out_size)
+{
+    if (!c || !h_src || !h_dst || !out_size || !method_ok(method)) return CRYO_E_ARG;
+    if (block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
+    const size_t bound = cryo_codec_bound(method, block_size);
+    if (dst_cap < bound) return CRYO_E_DSTSIZE;
+    int rc;
+    if ((rc = ensure(c, &c->d_in, &c->in_cap, block_size)) != CRYO_OK) return rc;
+    if ((rc = ensure(c, &c->d_out, &c->out_cap, bound)) != CRYO_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->d_in, h_src, block_size, hipMemcpyHostToDevice, c->stream));
+    rc = cryo_codec_compress_batch(c, method, param, c->d_in, block_size, (uint32_t)block_size, 1,
+                                   c->d_out, bound, c->d_size, c->d_status);
+    if (rc != CRYO_OK) return rc;
+    uint32_t csize = 0;
+    int32_t st = 0;
+    HIP_TRY(c, hipMemcpyAsync(&csize, c->d_size, sizeof csize, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(&st, c->d_status, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (st != CRYO_OK) return st;
+    if (csize == 0 || csize > bound) return CRYO_E_HIP;
+    HIP_TRY(c, hipMemcpyAsync(h_dst, c->d_out, csize, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    *out_size = csize;
+    return CRYO_OK;
+}
+
+int cryo_codec_decompress_block(cryo_codec *c, int method, const void *h_src, size_t src_size,
+                                void *h_dst, size_t block_size)
+{
+    if (!c || !h_src || !h_dst || !method_ok(method)) return CRYO_E_ARG;
+    if (block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
+    if (src_size == 0 || src_size > 0xFFFFFFFFu) return CRYO_E_CORRUPT;
+    int rc;
+    if ((rc = ensure(c, &c->d_in, &c->in_cap, src_size)) != CRYO_OK) return rc;
+    if ((rc = ensure(c, &c->d_out, &c->out_cap, block_size)) != CRYO_OK) return rc;
+    const uint64_t off = 0;
+    const uint32_t sz = (uint32_t)src_size;
+    HIP_TRY(c, hipMemcpyAsync(c->d_in, h_src, src_size, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_off, &off, sizeof off, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_size, &sz, sizeof sz, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream)); /* off/sz are stack variables */
+    rc = cryo_codec_decompress_batch(c, method, c->d_in, c->d_off, c->d_size, c->d_out, block_size,
+                                     (uint32_t)block_size, 1, c->d_status);
+    if (rc != CRYO_OK) return rc;
+    int32_t st = 0;
+    HIP_TRY(c, hipMemcpyAsync(&st, c->d_status, sizeof st, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (st != CRYO_OK) return st;
+    HIP_TRY(c, hipMemcpyAsync(h_dst, c->d_out, block_size, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CRYO_OK;
+}
+
+/* ---- helpers ---- */
+int cryo_codec_synth_batch(cryo_codec *c, uint64_t seed, uint64_t first_block, uint64_t n_blocks,
+                           uint32_t block_size, int dist, void *d_dst, uint64_t dst_stride)
+{
+    if (!c || block_size < 64 || dist < 0 || dist > 4) return CRYO_E_ARG;
+    if (n_blocks == 0) return CRYO_OK;
+    if (!d_dst || dst_stride < block_size) return CRYO_E_ARG;
+    HIP_TRY(c, cryo::launch_synth(c->stream, seed, first_block, n_blocks, block_size, dist,
+                                  (uint8_t *)d_dst, dst_stride));
+    c->ctr.launches++;
+    return CRYO_OK;
+}
+
+int cryo_codec_checksum_batch(cryo_codec *c, const void *d_src, uint64_t src_stride,
+                              const uint32_t *d_sizes, uint32_t fixed_size, uint64_t n_blocks,
+                              uint64_t *d_sums)
+{
+    if (!c) return CRYO_E_ARG;
+    if (n_blocks == 0) return CRYO_OK;
+    if (!d_src || !d_sums) return CRYO_E_ARG;
+    HIP_TRY(c, cryo::launch_checksum(c->stream, (const uint8_t *)d_src, src_stride, d_sizes, fixed_size,
+                                     n_blocks, d_sums));
+    c->ctr.launches++;
+    return CRYO_OK;
+}
+
+int cryo_codec_compare_batch(cryo_codec *c, const void *d_a, uint64_t a_stride, const void *d_b,
+                             uint64_t b_stride, uint32_t block_size, uint64_t n_blocks,
+                             uint64_t *d_mismatch)
+{
+    if (!c) return CRYO_E_ARG;
+    if (n_blocks == 0) return CRYO_OK;
+    if (!d_a || !d_b || !d_mismatch) return CRYO_E_ARG;
+    HIP_TRY(c, cryo::launch_compare(c->stream, (const uint8_t *)d_a, a_stride, (const uint8_t *)d_b,
+                                    b_stride, block_size, n_blocks, d_mismatch));
+    c->ctr.launches++;
+    return CRYO_OK;
+}
+
+/* ---- timing ---- */
+int cryo_codec_timer_start(cryo_codec *c)
+{
+    if (!c) return CRYO_E_ARG;
+    HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
+    return CRYO_OK;
+}
+int cryo_codec_timer_stop(cryo_codec *c, float *ms)
+{
+    if (!c || !ms) return CRYO_E_ARG;
+    HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(c->ev1));
+    HIP_TRY(c, hipEventElapsedTime(ms, c->ev0, c->ev1));
+    return CRYO_OK;
+}
+
+int cryo_codec_get_counters(const cryo_codec *c, cryo_codec_counters *out)
+{
+    if (!c || !out) return CRYO_E_ARG;
+    *out = c->ctr;
+    return CRYO_OK;
+}
+
+} /* extern "C" */

@@ -1,0 +1,49 @@
+/*
+ * kernels.h -- internal launcher interface between the C-ABI host code
+ * (cryo_codec.cpp) and the gfx950 kernels.  Not installed; the public surface
+ * is include/cryo_codec.h.
+ */
+#ifndef CRYO_KERNELS_H
+#define CRYO_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cryo {
+
+/* synthetic cryo blocks, include/cryo_synth.h */
+hipError_t launch_synth(hipStream_t s, uint64_t seed, uint64_t first_block, uint64_t n_blocks,
+                        uint32_t block_size, int dist, uint8_t *d_dst, uint64_t dst_stride);
+
+hipError_t launch_checksum(hipStream_t s, const uint8_t *d_src, uint64_t src_stride,
+                           const uint32_t *d_sizes, uint32_t fixed_size, uint64_t n_blocks,
+                           uint64_t *d_sums);
+
+hipError_t launch_compare(hipStream_t s, const uint8_t *d_a, uint64_t a_stride, const uint8_t *d_b,
+                          uint64_t b_stride, uint32_t block_size, uint64_t n_blocks,
+                          uint64_t *d_mismatch);
+
+/* LZ4 block format */
+hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
+                                 const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
+                                 uint32_t block_size, uint64_t n_blocks, int32_t *d_status);
+
+hipError_t launch_lz4_compress(hipStream_t s, const uint8_t *d_src, uint64_t src_stride,
+                               uint32_t block_size, uint64_t n_blocks, uint8_t *d_dst,
+                               uint64_t dst_stride, int accel, uint32_t *d_out_size,
+                               int32_t *d_status);
+
+/* zstd frames */
+hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
+                                  const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
+                                  uint32_t block_size, uint64_t n_blocks, int32_t *d_status,
+                                  void *d_workspace, size_t workspace_bytes);
+size_t zstd_decompress_workspace(uint64_t n_blocks, uint32_t block_size);
+
+} // namespace cryo
+
+#define CRYO_WAVE 64
+#define CRYO_ST_OK 0
+#define CRYO_ST_CORRUPT (-4)
+
+#endif
