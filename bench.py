@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the cryo-block codec hot path on MI355X.
+
+Metric (BASELINE.json): uncompressed GB/s of LZ4 decompress over a batch of
+synthetic 128 KiB cryo blocks resident in HBM (configs[1]: 64k x 128 KiB on one
+GPU; weak scaling: every rank decodes its own 64k blocks, block i of the job
+belongs to rank i mod N, no collective on the data path).
+
+A "step" = one decode pass over the rank's whole batch (one kernel launch).
+Setup (untimed): blocks are generated on the device, compressed on the device
+by the bit-exact HIP LZ4 encoder, and a strided sample is verified against the
+CPU oracle; after the timed region every decoded block is compared on the
+device with its original.
+
+Prints ONE JSON line on rank 0 (see the driver contract in the task).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--blocks", type=int, default=65536, help="cryo blocks per GPU")
+    ap.add_argument("--block-size", type=int, default=131072)
+    ap.add_argument("--dist", default="wide", choices=["wide", "narrow", "int4", "random", "zeros"])
+    ap.add_argument("--accel", type=int, default=1, help="lz4 acceleration used to produce the inputs")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(comps, B, budget_s):
+    """Time the CPU oracle (kind 'port', 1 thread) and, if present, the stock liblz4 the
+    reference links (compression.c:84 call shape) on the same sample of compressed blocks."""
+    import oracle_lib
+    ora = oracle_lib.Oracle()
+    out = np.empty(B, np.uint8)
+    fn = ora.L.cryo_oracle_lz4_decompress
+    ptrs = [(c.ctypes.data, c.nbytes) for c in comps]
+    # oracle, single thread, bounded by budget/2
+    t0 = time.perf_counter()
+    done = 0
+    reps = 0
+    while True:
+        for p, n in ptrs:
+            r = fn(p, n, out.ctypes.data, B)
+            assert r == B
+        done += len(ptrs)
+        reps += 1
+        if time.perf_counter() - t0 > budget_s * 0.5:
+            break
+    dt = time.perf_counter() - t0
+    res = {"value": round(done * B / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+           "sample": "%d distinct compressed blocks x %d passes (%.1f s), oracle/lz4_oracle.c decoder, 1 thread"
+                     % (len(ptrs), reps, dt)}
+    stock = oracle_lib.StockLibs()
+    if stock.lz4 is not None:
+        f = stock.lz4.LZ4_decompress_safe
+        t0 = time.perf_counter()
+        done = 0
+        while time.perf_counter() - t0 < budget_s * 0.2:
+            for p, n in ptrs:
+                f(p, out.ctypes.data, n, B)
+            done += len(ptrs)
+        dt1 = time.perf_counter() - t0
+        one = done * B / dt1 / 1e9
+        # all cores: thread t decodes blocks i = t mod T into a private buffer (ctypes drops the GIL)
+        T = max(1, min(os.cpu_count() or 1, 64))
+        counts = [0] * T
+        stop_at = time.perf_counter() + budget_s * 0.3
+
+        def work(t):
+            o = np.empty(B, np.uint8)
+            mine = ptrs[t::T] or ptrs
+            k = 0
+            while time.perf_counter() < stop_at:
+                for p, n in mine:
+                    f(p, o.ctypes.data, n, B)
+                k += len(mine)
+            counts[t] = k
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+        [x.start() for x in th]
+        [x.join() for x in th]
+        dtT = time.perf_counter() - t0
+        res["stock_liblz4"] = {"version": stock.lz4_version, "call": "LZ4_decompress_safe(src,dst,csize,B)",
+                               "GBps_1_thread": round(one, 3),
+                               "GBps_%d_threads" % T: round(sum(counts) * B / dtT / 1e9, 3), "threads": T}
+    return res
+
+
+def main():
+    a = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus and world > 1:
+        a.gpus = world
+
+    import torch  # plumbing only: process group + device sync; loaded first so ONE HIP runtime is shared
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    have_cuda = torch.cuda.is_available()
+    if have_cuda:
+        torch.cuda.set_device(local_rank)
+
+    from pg_cryogen_amd import Codec, METHOD_LZ4, bound
+    from pg_cryogen_amd.codec import DIST_NAMES
+    import oracle_lib
+
+    def barrier():
+        if have_cuda:
+            torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    B, n = a.block_size, a.blocks
+    dist_id = DIST_NAMES.index(a.dist)
+    codec = Codec(local_rank)
+    stride = (bound(METHOD_LZ4, B) + 15) & ~15
+
+    # ---------------- setup (untimed) ----------------
+    d_raw = codec.alloc(n * B)
+    d_comp = codec.alloc(n * stride)
+    d_out = codec.alloc(n * B)
+    d_sizes, d_status = codec.alloc(4 * n), codec.alloc(4 * n)
+    d_off = codec.alloc(8 * n)
+    d_mis = codec.alloc(8)
+    # block i of the job lives on rank i mod N: this rank's k-th block is job block k*N + rank.
+    # (the generator takes a contiguous index range, so rank r uses indices [r*n, (r+1)*n) of seed 0;
+    #  all blocks of the job are distinct either way)
+    first = rank * n
+    codec.synth_batch(0, first, n, B, dist_id, d_raw)
+    codec.timer_start()
+    codec.compress_batch(METHOD_LZ4, a.accel, d_raw, B, B, n, d_comp, stride, d_sizes, d_status)
+    enc_ms = codec.timer_stop()
+    st = d_status.download(dtype=np.int32)
+    assert (st == 0).all(), "lz4 encode status"
+    sizes = d_sizes.download(dtype=np.uint32)
+    d_off.upload(np.arange(n, dtype=np.uint64) * np.uint64(stride))
+    comp_bytes = int(sizes.astype(np.uint64).sum())
+
+    # spot check vs the CPU oracle: strided sample of the device-encoded blocks
+    ora = oracle_lib.Oracle()
+    sample_idx = sorted(set(list(range(0, n, max(1, n // 16)))[:16] + [n - 1]))
+    sample_comps = []
+    for i in sample_idx:
+        c = d_comp.download(int(sizes[i]), offset=i * stride)
+        raw = ora.synth(0, first + i, B, dist_id)
+        exp = ora.lz4_compress(raw, a.accel)
+        assert np.array_equal(c, exp), "device lz4 encode differs from oracle at block %d" % i
+        sample_comps.append(c)
+
+    def step():
+        codec.decompress_batch(METHOD_LZ4, d_comp, d_off, d_sizes, d_out, B, B, n, d_status)
+
+    for _ in range(a.warmup):
+        step()
+    codec.sync()
+
+    # ---------------- timed region ----------------
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = []
+    for _ in range(a.steps):
+        codec.timer_start()          # HIP events on the codec's own stream
+        step()
+        kernel_ms.append(codec.timer_stop())
+    codec.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    # ---------------- verification (untimed) ----------------
+    st = d_status.download(dtype=np.int32)
+    assert (st == 0).all(), "lz4 decode status"
+    d_mis.memset(0)
+    codec.compare_batch(d_raw, B, d_out, B, B, n, d_mis)
+    codec.sync()
+    mismatch = int(d_mis.download(dtype=np.uint64)[0])
+    assert mismatch == 0, "decoded blocks differ from originals: %d" % mismatch
+
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t[0])
+
+    if rank == 0:
+        total_blocks = n * world
+        value = total_blocks * B * a.steps / elapsed / 1e9
+        avg_ms = float(np.mean(kernel_ms))
+        algo_bytes = comp_bytes + n * B        # per launch: compressed bytes read + B written per block
+        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+        out = {
+            "metric": "lz4_decompress_uncompressed_GBps", "value": round(value, 2), "unit": "GB/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "LZ4 decompress %d x %d KiB synthetic cryo blocks per GPU" % (n, B // 1024),
+                       "distribution": a.dist, "lz4_acceleration": a.accel, "block_size": B,
+                       "blocks_per_gpu": n, "sharding": "block i -> rank i mod N, no collective",
+                       "compression_ratio": round(n * B / comp_bytes, 3),
+                       "bit_exact": "encode == oracle on %d sampled blocks; decode == original on all %d blocks"
+                                    % (len(sample_idx), n),
+                       "setup_lz4_encode_GBps": round(n * B / (enc_ms * 1e-3) / 1e9, 2)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "kernel": "k_lz4_dec", "avg_launch_ms": round(avg_ms, 4),
+                         "algorithmic_bytes_per_launch": algo_bytes},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(sample_comps, B, a.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    for b in (d_raw, d_comp, d_out, d_sizes, d_status, d_off, d_mis):
+        b.free()
+    codec.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -198,7 +198,8 @@ long cryo_oracle_lz4_decompress(const uint8_t *src, size_t csize, uint8_t *dst, 
         if (off > op) return -1;
         if (op + len + LASTLITERALS > cap) return -1;
         if (off == 0) { memset(dst + op, 0, len); op += len; continue; }
-        for (i = 0; i < len; i++) dst[op + i] = dst[op + i - off];
+        if (off >= len) memcpy(dst + op, dst + op - off, len);
+        else for (i = 0; i < len; i++) dst[op + i] = dst[op + i - off];
         op += len;
     }
 }

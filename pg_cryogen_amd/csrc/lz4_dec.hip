@@ -8,100 +8,585 @@
  * bounds-checked decoder applies them (see oracle/lz4_oracle.c for the list);
  * additionally a block must decode to exactly block_size bytes.
  *
- * Structure of one wave: the sequence chain (token -> literal run -> offset ->
- * match) is inherently serial, so the parse is wave-uniform and the 64 lanes
- * co-operate on the two copies of each sequence:
- *   literals : lanes stride over the run, compressed stream -> output
- *   match    : lanes stride over the match, output -> output.  A match whose
- *              offset is smaller than its length (RLE-style, e.g. the zero gap
- *              of a cryo block: one ~110 KB match) is periodic with period
- *              `offset`, so every lane reads from the already-written prefix
- *              [op-off, op) and no lane depends on another lane of the same pass.
- * Vector memory operations of one wave are executed in order and the CU's L1
- * is coherent for its own stores, so a match may read bytes the same wave
- * stored in an earlier instruction without a fence.
+ * Data movement of one wave (k_lz4_dec_ring):
+ *
+ *   HBM --16 B/lane, 1 KiB per wave-instruction--> s_in  (2 KiB input ring, LDS)
+ *   s_in --one byte per lane--> `win`: a 64-byte look-ahead window in VGPRs
+ *        lane 0 holds the token, the following lanes already hold the
+ *        literals, the 2 offset bytes and the length-extension bytes, so one
+ *        LDS read serves the whole parse of a typical sequence (v_readlane)
+ *        and the literal copy needs no second read.
+ *   win / s_ring --> s_ring  (output ring in LDS, the last R bytes produced):
+ *        literals are written from the window registers; a match reads its
+ *        source from the ring (LDS round trip instead of a global one).  LDS
+ *        operations of one wave execute in order, so a match may read bytes
+ *        written by the instruction before it.
+ *   s_ring --16 B/lane--> HBM: every completed 1 KiB of output is flushed with
+ *        one ds_read_b128 + one global_store_dwordx4 per lane.
+ *
+ * A match whose offset exceeds the ring reads its source back from the output
+ * in HBM/L2 (already flushed, and vector memory operations of one wave are
+ * executed in order).  Overlapping matches (offset < length, e.g. the zero gap
+ * of a cryo block is a single ~110 KB match) are periodic: the first 64 bytes
+ * use lane % offset, later pieces use a multiple of the offset >= 64.
+ *
+ * Two parse engines share this data movement:
+ *
+ *  BATCH (lz4_batch): the CU has ONE scalar unit (1 SALU instruction per cycle for
+ *  all its waves) and a wave-uniform token parse saturates it (measured: 69 SALU per
+ *  sequence, profiles/r01_v2_scalar_parse_pmc.json).  So the parse is done by the
+ *  lanes instead: for a window of W compressed bytes every lane computes, for "its"
+ *  byte positions, the distance d1 to the next token *if* a token started there;
+ *  two doubling passes give d2, d4; a 16-hop chase over d4 plus a 2-step fill puts
+ *  the start of sequence i into lane i.  Each lane then decodes one sequence's
+ *  (literal length, offset, match length); a wave scan turns lengths into output
+ *  positions; and the copy runs one output byte per lane, 64 bytes per step: a bitmap
+ *  of sequence starts + mbcnt gives every byte its sequence, the byte's source is
+ *  either the input ring (literal) or the output ring (match).  Chunks are produced
+ *  in order, so only sources inside the current 64-byte chunk can be unready; those
+ *  are resolved in extra rounds guarded by a ballot of finished lanes.
+ *
+ *  GENERAL (one sequence, wave-uniform parse): anything the batch does not take --
+ *  length fields with 255-runs, literal runs > 58, overlapping or far matches, the
+ *  first/last bytes of a block, malformed input.  It implements every accept/reject
+ *  rule; the batch only ever accepts sequences that pass all of them.
  */
 #include "kernels.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace cryo {
 
-__device__ static inline uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+namespace {
 
-__global__ void __launch_bounds__(256)
-k_lz4_dec(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
-          const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
-          uint64_t n_blocks, int32_t *__restrict__ status)
+constexpr uint32_t kInRing = 2048, kInMask = kInRing - 1; /* >= kWMax + 256 + 72 + kChunk */
+constexpr uint32_t kChunk = 1024; /* bytes per refill / flush: 64 lanes x 16 B */
+
+__device__ inline uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+/* NOTE: never rebuild a pointer from integers (it becomes a FLAT pointer and every access then
+ * also counts on lgkmcnt, serialising LDS traffic behind HBM traffic); make the OFFSET uniform. */
+__device__ inline uint64_t uni64(uint64_t v)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t blk = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (blk >= n_blocks) return;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ inline uint32_t lane_get(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ inline uint32_t ctz64(unsigned long long m) { return (uint32_t)__builtin_ctzll(m); }
 
-    const uint8_t *__restrict__ src = src_base + src_off[blk];
-    const uint32_t csize = src_size[blk];
-    uint8_t *dst = dst_base + blk * dst_stride;
+template <uint32_t R>
+struct Wave {
+    /* LDS */
+    uint8_t *ring; /* R bytes   */
+    uint8_t *in;   /* kInRing   */
+    /* stream */
+    const uint8_t *abase; /* 16-byte aligned address at or below the block's first byte */
+    uint32_t delta;       /* first byte = abase + delta                                */
+    uint32_t vend;        /* delta + csize: end of stream in "virtual" positions       */
+    uint32_t in_hi;       /* virtual position staged up to (multiple of kChunk)        */
+    uint4 pre;            /* prefetched next chunk                                     */
+    /* output */
+    uint8_t *dst;
+    uint32_t op;      /* bytes produced      */
+    uint32_t flushed; /* bytes stored to HBM (multiple of kChunk) */
+    bool dst_aligned;
+    uint32_t lane;
 
-    uint32_t ip = 0, op = 0;
-    bool bad = (csize == 0);
+    __device__ inline void prefetch()
+    {
+        const uint32_t o = in_hi + lane * 16u;
+        pre = make_uint4(0, 0, 0, 0);
+        if (o < vend) pre = *reinterpret_cast<const uint4 *>(abase + o);
+    }
+    /* write the prefetched chunk into the input ring, start fetching the one after */
+    __device__ inline void refill()
+    {
+        *reinterpret_cast<uint4 *>(in + ((in_hi + lane * 16u) & kInMask)) = pre;
+        in_hi += kChunk;
+        prefetch();
+    }
+    /* keep at least 128 staged bytes ahead of virtual position vp (the chunk after that is
+     * already on its way in `pre`) */
+    __device__ inline void need(uint32_t vp)
+    {
+        while (in_hi < vend && vp + 128u > in_hi) refill();
+    }
+    /* 64-byte window at virtual position vp: lane l holds byte vp + l */
+    __device__ inline uint32_t window(uint32_t vp) const { return in[(vp + lane) & kInMask]; }
 
-    while (!bad) {
-        const uint32_t token = uni(src[ip]);
-        ip++;
-        uint32_t len = token >> 4;
-        if (len == 15u) {
-            if (ip + 15u >= csize) { bad = true; break; }
-            uint32_t s;
-            do {
-                s = uni(src[ip]);
-                ip++;
-                len += s;
-                if (ip + 15u >= csize) break;
-            } while (s == 255u);
+    /* store completed 1 KiB output chunks */
+    __device__ inline void flush()
+    {
+        while (op - flushed >= kChunk) {
+            if (dst_aligned) {
+                const uint4 x = *reinterpret_cast<const uint4 *>(ring + ((flushed + lane * 16u) & (R - 1)));
+                *reinterpret_cast<uint4 *>(dst + flushed + lane * 16u) = x;
+            } else {
+                for (uint32_t i = lane; i < kChunk; i += 64u) dst[flushed + i] = ring[(flushed + i) & (R - 1)];
+            }
+            flushed += kChunk;
         }
-        /* literal run: must be the final one if it comes near either end */
-        const bool last = (op + len + 12u > B) || (ip + len + 8u > csize);
-        if (last && (ip + len != csize || op + len > B)) { bad = true; break; }
-        for (uint32_t i = lane; i < len; i += 64u) dst[op + i] = src[ip + i];
-        ip += len;
-        op += len;
-        if (last) break;
+    }
+    __device__ inline void flush_tail()
+    {
+        for (uint32_t i = flushed + lane; i < op; i += 64u) dst[i] = ring[i & (R - 1)];
+        flushed = op;
+    }
+};
 
-        const uint32_t off = uni((uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8));
-        ip += 2;
-        len = token & 15u;
-        if (len == 15u) {
-            uint32_t s;
-            do {
-                s = uni(src[ip]);
-                ip++;
-                len += s;
-                if (ip + 4u >= csize) { bad = true; break; }
-            } while (s == 255u);
-            if (bad) break;
+/* lane % m for lane < 64, 0 < m < 64 */
+__device__ inline uint32_t lane_mod(uint32_t lane, uint32_t m)
+{
+    const uint32_t q = (uint32_t)((float)lane * __frcp_rn((float)m));
+    int32_t r = (int32_t)(lane - q * m);
+    if (r < 0) r += (int32_t)m;
+    if (r >= (int32_t)m) r -= (int32_t)m;
+    return (uint32_t)r;
+}
+
+} // namespace
+
+/* ---- batch engine constants ---- */
+constexpr uint32_t kWMax = 512;   /* sequences of a batch start at window offsets < W <= kWMax */
+constexpr uint32_t kD1N = kWMax + 256; /* d1 domain [0, W+256): d2 lookups reach < W+128+63     */
+constexpr uint32_t kD2N = kWMax + 128; /* d2 domain [0, W+128): d4 lookups reach < W+126        */
+constexpr uint32_t kDMax = 63;    /* longest token-to-token distance the batch handles          */
+constexpr uint32_t kTMax = 1024;  /* output bytes per batch (16 chunks of 64)                   */
+constexpr uint32_t kNCh = kTMax / 64;
+
+template <uint32_t R>
+struct __attribute__((aligned(16))) WaveLds {
+    uint8_t ring[R];
+    uint8_t in[kInRing];
+    uint8_t d1[kD1N];
+    uint8_t d2[kD2N];
+    uint8_t d4[kWMax];
+    uint32_t bm[kTMax / 32];     /* bit q set: a sequence starts at batch output offset q */
+    unsigned long long meta[64]; /* per sequence: ostart | ll<<16 | litidx<<32 | off<<48  */
+};
+
+struct Stats { uint32_t batches, batch_seqs, general_seqs, chunks, rounds, zero_batches; };
+
+/*
+ * Decode up to 64 "simple" sequences starting at virtual position vp; `W` (multiple of 64,
+ * <= kWMax) is the span of compressed bytes searched for sequence starts.
+ * Returns the number of sequences consumed (0 = none; caller runs the general path) and the
+ * compressed bytes consumed in *used.
+ *
+ * Offsets: a match source is "near" (off < kNear, still in the LDS ring while the batch
+ * writes up to kTMax new bytes) or "far" (off >= kNear: older than anything the batch
+ * produces and already flushed, so it is read back from the output buffer in HBM/L2; all
+ * far bytes of a batch are requested up front and cost one memory latency per batch).
+ */
+template <uint32_t R>
+__device__ inline uint32_t lz4_batch(Wave<R> &w, WaveLds<R> &L, uint32_t &vp, const uint32_t B,
+                                     const uint32_t W, uint32_t *used, Stats &st)
+{
+    static_assert(R >= 4096, "ring must hold kTMax new bytes plus the near window");
+    constexpr uint32_t kNear = R - kTMax - 64u;
+    const uint32_t lane = w.lane;
+    const uint32_t vend = w.vend;
+    *used = 0;
+    if (vend < 32u || B < 32u) return 0;
+    const uint32_t vsafe = vend - 16u;
+    if (vp + 64u > vsafe || w.op + 64u > B) return 0;
+
+    /* stage the window (no refill happens while the batch runs) */
+    while (w.in_hi < vend && w.in_hi < vp + W + 256u + 72u) w.refill();
+
+    /* ---- phase 1: d1 for every window offset, then d2, d4 ---- */
+    for (uint32_t j = lane; j < W + 256u; j += 64u) {
+        const uint32_t pos = vp + j;
+        const uint32_t t = L.in[pos & kInMask];
+        const uint32_t e1 = L.in[(pos + 1u) & kInMask];
+        const uint32_t hi = t >> 4;
+        uint32_t d = hi + 3u + ((t & 15u) == 15u ? 1u : 0u);
+        if (hi == 15u) d += e1 + 1u;
+        if (d > kDMax) d = 0; /* 0 marks "not batchable from here" */
+        L.d1[j] = (uint8_t)d;
+    }
+    for (uint32_t j = lane; j < W + 128u; j += 64u) {
+        const uint32_t a = L.d1[j];
+        const uint32_t b = L.d1[j + a];
+        L.d2[j] = (uint8_t)((a != 0u && b != 0u) ? a + b : 0u);
+    }
+    for (uint32_t j = lane; j < W; j += 64u) {
+        const uint32_t a = L.d2[j];
+        const uint32_t b = L.d2[j + a];
+        L.d4[j] = (uint8_t)((a != 0u && b != 0u) ? a + b : 0u);
+    }
+
+    /* ---- chase: start of every 4th sequence into lanes 0,4,8,... ---- */
+    uint32_t sl = 0;   /* window offset of this lane's sequence */
+    uint32_t ngrp = 0;
+    {
+        uint32_t s0 = 0;
+        for (uint32_t k = 0; k < 16u; k++) {
+            if (s0 >= W) break;
+            const uint32_t dd = uni(L.d4[s0]);
+            if (dd == 0u) break;
+            if ((lane >> 2) == k) sl = s0;
+            s0 += dd;
+            ngrp++;
         }
-        len += 4u;
-        if (off > op || op + len + 5u > B) { bad = true; break; }
+    }
+    if (ngrp == 0u) return 0;
+    const uint32_t ncand = ngrp * 4u;
+    /* fill: lanes 4k+1..4k+3 walk 1..3 tokens from the group start */
+    if (lane & 2u) sl += L.d2[sl];
+    if (lane & 1u) sl += L.d1[sl];
 
-        if (off == 0u) {
-            /* liblz4 1.9.3 does not reject offset 0; it reproduces as zero bytes */
-            for (uint32_t i = lane; i < len; i += 64u) dst[op + i] = 0;
-        } else if (off >= 64u || off >= len) {
-            /* each pass reads only bytes written by earlier passes or earlier sequences */
-            for (uint32_t i = lane; i < len; i += 64u) dst[op + i] = dst[op + i - off];
-        } else {
-            /* overlapping match: periodic with period off, source is the prefix [op-off, op) */
-            const uint8_t *pat = dst + op - off;
-            uint32_t ph = lane % off;
-            const uint32_t adv = 64u % off;
-            for (uint32_t i = lane; i < len; i += 64u) {
-                dst[op + i] = pat[ph];
-                ph += adv;
-                if (ph >= off) ph -= off;
+    /* ---- phase 2: one sequence per lane ---- */
+    const uint32_t pos = vp + sl;
+    const uint32_t t = L.in[pos & kInMask];
+    const uint32_t e1 = L.in[(pos + 1u) & kInMask];
+    uint32_t ll = t >> 4;
+    uint32_t k = 1u;
+    if (ll == 15u) { ll += e1; k = 2u; }
+    const uint32_t q = pos + k + ll; /* offset field */
+    const uint32_t off = (uint32_t)L.in[q & kInMask] | ((uint32_t)L.in[(q + 1u) & kInMask] << 8);
+    const uint32_t e2 = L.in[(q + 2u) & kInMask];
+    uint32_t ml = (t & 15u) + 4u;
+    uint32_t dlen = k + ll + 2u;
+    const bool hasM = (t & 15u) == 15u;
+    if (hasM) { ml += e2; dlen += 1u; }
+    const bool cand = lane < ncand;
+    const uint32_t outlen = cand ? ll + ml : 0u;
+    /* inclusive scan of output lengths */
+    uint32_t oend = outlen;
+#pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) {
+        const uint32_t y = __shfl_up(oend, d, 64);
+        if (lane >= d) oend += y;
+    }
+    const uint32_t ostart = oend - outlen;
+    const uint32_t mabs = w.op + ostart + ll; /* absolute output position of the match */
+    const bool ok = cand && !(hasM && e2 == 255u) && off >= ml && off <= mabs &&
+                    pos + dlen <= vsafe && oend <= kTMax && w.op + oend + 16u <= B;
+    const unsigned long long badmask = __ballot(!ok);
+    const uint32_t nseq = badmask ? ctz64(badmask) : 64u;
+    if (nseq == 0u) return 0;
+    const uint32_t T = lane_get(oend, nseq - 1u);
+    *used = lane_get(sl + dlen, nseq - 1u);
+
+    /* ---- phase 3: bitmap of sequence starts + metadata ---- */
+    if (lane < kTMax / 32u) L.bm[lane] = 0u;
+    if (lane < nseq) {
+        L.meta[lane] = (unsigned long long)ostart | ((unsigned long long)ll << 16) |
+                       ((unsigned long long)((pos + k) & kInMask) << 32) | ((unsigned long long)off << 48);
+        atomicOr(&L.bm[ostart >> 5], 1u << (ostart & 31u));
+    }
+    const uint32_t bm_lo = L.bm[(lane & (kNCh - 1u)) * 2u], bm_hi = L.bm[(lane & (kNCh - 1u)) * 2u + 1u];
+    uint32_t basev = (uint32_t)(__popc(bm_lo) + __popc(bm_hi)); /* lanes 0..kNCh-1: starts in chunk `lane` */
+    {
+        uint32_t incl = basev;
+#pragma unroll
+        for (uint32_t d = 1; d < kNCh; d <<= 1) {
+            const uint32_t y = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += y;
+        }
+        basev = incl - basev; /* exclusive: starts before this chunk */
+    }
+    const uint32_t op0 = w.op;
+    st.batches++;
+    st.batch_seqs += nseq;
+
+    /* ---- pass A: bytes that do not depend on this batch: literals (input ring -> ring) and
+     *      far matches (requested now from the output buffer, written in pass B) ---- */
+    uint32_t mlo[kNCh], mhi[kNCh];
+    uint32_t xfar[kNCh];
+#pragma unroll
+    for (uint32_t c = 0; c < kNCh; c++) {
+        mlo[c] = 0; mhi[c] = 0; xfar[c] = 0;
+        if (c * 64u < T) {
+            const uint32_t wlo = lane_get(bm_lo, c), whi = lane_get(bm_hi, c);
+            const uint32_t bc = lane_get(basev, c);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
+            const uint32_t own = ((lane < 32u ? wlo >> lane : whi >> (lane - 32u)) & 1u);
+            const uint32_t idx = bc + below + own - 1u;
+            const unsigned long long m = L.meta[idx & 63u];
+            mlo[c] = (uint32_t)m;
+            mhi[c] = (uint32_t)(m >> 32);
+            const uint32_t qo = c * 64u + lane; /* batch output offset of this lane's byte */
+            const uint32_t dd = qo - (mlo[c] & 0xffffu);
+            const uint32_t mll = mlo[c] >> 16;
+            const uint32_t moff = mhi[c] >> 16;
+            const bool active = qo < T;
+            if (active && dd < mll) L.ring[(op0 + qo) & (R - 1)] = L.in[((mhi[c] & 0xffffu) + dd) & kInMask];
+            if (active && dd >= mll && moff >= kNear) xfar[c] = w.dst[op0 + qo - moff];
+        }
+    }
+    /* ---- pass B: chunks in order; far bytes land first, then near matches read the ring.
+     *      Only a source inside the current chunk can be unready: extra rounds guarded by
+     *      a ballot of finished lanes ---- */
+#pragma unroll
+    for (uint32_t c = 0; c < kNCh; c++) {
+        if (c * 64u < T) {
+            st.chunks++;
+            const uint32_t qo = c * 64u + lane;
+            const uint32_t dd = qo - (mlo[c] & 0xffffu);
+            const uint32_t mll = mlo[c] >> 16;
+            const uint32_t moff = mhi[c] >> 16;
+            const bool isMatch = qo < T && dd >= mll;
+            uint8_t *dstp = &L.ring[(op0 + qo) & (R - 1)];
+            if (isMatch && moff >= kNear) *dstp = (uint8_t)xfar[c];
+            const bool near = isMatch && moff < kNear;
+            const uint8_t *srcp = &L.ring[(op0 + qo - moff) & (R - 1)];
+            const bool inchunk = moff <= lane; /* source byte belongs to this very chunk */
+            if (near && !inchunk) *dstp = *srcp;
+            bool pend = near && inchunk;
+            unsigned long long donem = __ballot(!pend);
+            while (__ballot(pend) != 0ull) {
+                st.rounds++;
+                const bool rdy = pend && ((donem >> ((lane - moff) & 63u)) & 1ull);
+                if (rdy) *dstp = *srcp;
+                donem |= __ballot(rdy);
+                pend = pend && !rdy;
             }
         }
-        op += len;
     }
-    if (!bad && op != B) bad = true;
+    w.op = op0 + T;
+    vp += *used;
+    w.flush();
+    return nseq;
+}
+
+template <uint32_t R, bool STATS>
+__global__ void __launch_bounds__(256)
+k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
+               const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
+               uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats)
+{
+    Stats st = {0, 0, 0, 0, 0, 0};
+    __shared__ WaveLds<R> s_lds[4];
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wid = uni(threadIdx.x >> 6);
+    const uint64_t blk = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid;
+    if (blk >= n_blocks) return;
+
+    /* wave-uniform values are forced into SGPRs so the parse runs on the scalar unit */
+    const uint8_t *base = src_base + uni64(src_off[blk]);
+    const uint32_t csize = uni(src_size[blk]);
+
+    Wave<R> w;
+    WaveLds<R> &L = s_lds[wid];
+    w.ring = L.ring;
+    w.in = L.in;
+    w.lane = lane;
+    w.delta = (uint32_t)(reinterpret_cast<uintptr_t>(base) & 15u);
+    w.abase = base - w.delta;
+    w.vend = w.delta + csize;
+    w.in_hi = 0;
+    w.dst = dst_base + uni64(blk * dst_stride);
+    w.dst_aligned = (reinterpret_cast<uintptr_t>(w.dst) & 15u) == 0;
+    w.op = 0;
+    w.flushed = 0;
+
+    /* all stream positions below are "virtual": vp = delta + offset in the compressed block */
+    const uint32_t vend = w.vend;
+    uint32_t vp = w.delta;
+    bool bad = (csize == 0);
+    bool done = bad;
+    uint32_t skip = 0;
+    uint32_t W = kWMax;
+
+    if (!bad) {
+        w.prefetch();
+        w.refill();
+        if (w.in_hi < vend) w.refill();
+    }
+    uint32_t win = bad ? 0u : w.window(vp);
+
+    while (!done) {
+        /* =====================  BATCH PATH  =====================
+         * The window W follows the compressed bytes a batch actually consumed (long matches
+         * make a batch hit kTMax output bytes after few tokens). */
+        if (skip == 0u) {
+            uint32_t n, used;
+            do {
+                n = lz4_batch<R>(w, L, vp, B, W, &used, st);
+                if (n == 0u) st.zero_batches++;
+                uint32_t want = (used + used / 2u + 63u) & ~63u;
+                if (n == 64u || used + 64u > W) want = W * 2u;  /* ran out of lanes / window */
+                W = want < 128u ? 128u : (want > kWMax ? kWMax : want);
+            } while (n >= 24u);
+            if (n < 8u) skip = 8u; /* poor yield: stay on the general path for a while */
+        } else {
+            skip--;
+        }
+
+        /* =====================  GENERAL PATH: one sequence  ===================== */
+        st.general_seqs++;
+        w.flush();
+        w.need(vp);
+        win = w.window(vp);
+
+        /* ---- token and literal length (window lane 0 = token) ---- */
+        const uint32_t token = lane_get(win, 0);
+        uint32_t ll = token >> 4;
+        uint32_t k = 1; /* window lane of the first byte after the literal-length field */
+        if (ll == 15u) {
+            /* extension bytes: 255 ... 255 x ; find the terminating byte with a ballot */
+            uint32_t wbase = vp;
+            for (;;) {
+                const unsigned long long m = __ballot(win != 255u) & ~((1ull << k) - 1ull);
+                if (m != 0ull) {
+                    const uint32_t f = ctz64(m);
+                    ll += (f - k) * 255u + lane_get(win, f);
+                    k = f + 1u;
+                    break;
+                }
+                /* a 255 at position q is only legal while q + 16 < csize */
+                if (wbase + 63u + 16u >= vend) { bad = true; break; }
+                ll += (64u - k) * 255u;
+                wbase += 64u;
+                w.need(wbase);
+                win = w.window(wbase);
+                k = 0;
+            }
+            if (bad) break;
+            /* terminating byte at position pe must satisfy pe + 15 < csize */
+            if (wbase + (k - 1u) + 15u >= vend) { bad = true; break; }
+            vp = wbase; /* lane k of the current window is the byte after the field */
+        }
+        const uint32_t lp = vp + k; /* virtual position of the first literal */
+
+        /* ---- literal run ---- */
+        const bool last = (w.op + ll + 12u > B) || (lp + ll + 8u > vend);
+        if (last && (lp + ll != vend || w.op + ll > B)) { bad = true; break; }
+        {
+            /* first piece straight from the window registers */
+            uint32_t n0 = 64u - k;
+            if (n0 > ll) n0 = ll;
+            if (lane >= k && lane < k + n0) w.ring[(w.op + lane - k) & (R - 1)] = (uint8_t)win;
+            w.op += n0;
+            uint32_t rem = ll - n0;
+            uint32_t p = lp + n0;
+            while (rem) {
+                w.flush();
+                w.need(p);
+                const uint32_t x = w.window(p);
+                const uint32_t n = rem < 64u ? rem : 64u;
+                if (lane < n) w.ring[(w.op + lane) & (R - 1)] = (uint8_t)x;
+                w.op += n;
+                p += n;
+                rem -= n;
+            }
+            if (last) { done = true; break; }
+            /* keep the 2 offset bytes and the first length byte inside the window */
+            if (p - vp > 61u) {
+                vp = p;
+                w.need(vp);
+                win = w.window(vp);
+            }
+            k = p - vp; /* window lane of the offset's low byte */
+        }
+
+        /* ---- offset and match length ---- */
+        const uint32_t off = lane_get(win, k) | (lane_get(win, k + 1u) << 8);
+        uint32_t ml = token & 15u;
+        k += 2u;
+        if (ml == 15u) {
+            uint32_t wbase = vp;
+            for (;;) {
+                const unsigned long long m = (k < 64u) ? (__ballot(win != 255u) & ~((1ull << k) - 1ull)) : 0ull;
+                if (m != 0ull) {
+                    const uint32_t f = ctz64(m);
+                    ml += (f - k) * 255u + lane_get(win, f);
+                    k = f + 1u;
+                    break;
+                }
+                /* every extension byte at position q needs q + 5 < csize */
+                if (wbase + 63u + 5u >= vend) { bad = true; break; }
+                ml += (64u - k) * 255u;
+                wbase += 64u;
+                w.need(wbase);
+                win = w.window(wbase);
+                k = 0;
+            }
+            if (bad) break;
+            if (wbase + (k - 1u) + 5u >= vend) { bad = true; break; }
+            vp = wbase;
+        }
+        ml += 4u;
+        if (off > w.op || w.op + ml + 5u > B) { bad = true; break; }
+
+        /* ---- next window: issue its LDS read before the match copy so the two overlap ---- */
+        vp += k;
+        w.need(vp);
+        win = w.window(vp);
+
+        /* ---- match copy ---- */
+        {
+            uint32_t rem = ml;
+            if (off == 0u) {
+                /* liblz4 1.9.3 does not reject offset 0: it reproduces as zero bytes */
+                while (rem) {
+                    w.flush();
+                    const uint32_t n = rem < 64u ? rem : 64u;
+                    if (lane < n) w.ring[(w.op + lane) & (R - 1)] = 0;
+                    w.op += n;
+                    rem -= n;
+                }
+            } else if (off <= R - 128u) {
+                /* source inside the LDS ring */
+                uint32_t eff = off; /* distance used by pieces after the first */
+                uint32_t sidx;      /* ring index this lane reads for the first piece */
+                if (off < 64u && ml > off) {
+                    sidx = w.op - off + lane_mod(lane, off);
+                    /* smallest multiple of the period >= 64: out[i] = out[i - eff] holds for every
+                     * i >= op + 64 only while eff <= 64 + off */
+                    eff = (uint32_t)(64.0f * __frcp_rn((float)off)) * off;
+                    if (eff >= 64u + off) eff -= off;
+                    if (eff < 64u) eff += off;
+                } else {
+                    sidx = w.op - off + lane;
+                }
+                {
+                    const uint32_t n = rem < 64u ? rem : 64u;
+                    const uint8_t x = w.ring[sidx & (R - 1)];
+                    if (lane < n) w.ring[(w.op + lane) & (R - 1)] = x;
+                    w.op += n;
+                    rem -= n;
+                }
+                while (rem) {
+                    w.flush();
+                    const uint32_t n = rem < 64u ? rem : 64u;
+                    const uint8_t x = w.ring[(w.op - eff + lane) & (R - 1)];
+                    if (lane < n) w.ring[(w.op + lane) & (R - 1)] = x;
+                    w.op += n;
+                    rem -= n;
+                }
+            } else {
+                /* far match: source already flushed to the output buffer (off > R-128 >= 1088+) */
+                while (rem) {
+                    w.flush();
+                    const uint32_t n = rem < 64u ? rem : 64u;
+                    uint8_t x = 0;
+                    if (lane < n) x = w.dst[w.op - off + lane];
+                    if (lane < n) w.ring[(w.op + lane) & (R - 1)] = x;
+                    w.op += n;
+                    rem -= n;
+                }
+            }
+        }
+    }
+
+    if (!bad && w.op != B) bad = true;
+    if (!bad) {
+        w.flush();
+        w.flush_tail();
+    }
     if (lane == 0) status[blk] = bad ? CRYO_ST_CORRUPT : CRYO_ST_OK;
+    if (STATS && lane == 0) {
+        atomicAdd(&stats[0], (unsigned long long)st.batches);
+        atomicAdd(&stats[1], (unsigned long long)st.batch_seqs);
+        atomicAdd(&stats[2], (unsigned long long)st.general_seqs);
+        atomicAdd(&stats[3], (unsigned long long)st.chunks);
+        atomicAdd(&stats[4], (unsigned long long)st.rounds);
+        atomicAdd(&stats[5], (unsigned long long)st.zero_batches);
+    }
 }
 
 hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
@@ -111,8 +596,32 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
     if (n_blocks == 0) return hipSuccess;
     const uint64_t grid = (n_blocks + 3) / 4;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_lz4_dec, dim3((uint32_t)grid), dim3(256), 0, s, d_src, d_src_off,
-                       d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status);
+    /* output ring size per wave: 4 KiB default (24 waves/CU); CRYO_LZ4_RING=4096|8192 for tuning */
+    static const int ring = [] {
+        const char *e = getenv("CRYO_LZ4_RING");
+        return e ? atoi(e) : 4096;
+    }();
+    const dim3 g((uint32_t)grid), b(256);
+    static const bool want_stats = getenv("CRYO_LZ4_STATS") != nullptr; /* debugging aid */
+    if (want_stats) {
+        unsigned long long *d_st = nullptr, h_st[6];
+        if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
+        hipLaunchKernelGGL((k_lz4_dec_ring<4096, true>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
+                           block_size, n_blocks, d_status, d_st);
+        (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(d_st);
+        fprintf(stderr, "[lz4 stats] batches %llu batch_seqs %llu general_seqs %llu chunks %llu rounds %llu zero_batches %llu\n",
+                h_st[0], h_st[1], h_st[2], h_st[3], h_st[4], h_st[5]);
+        return hipGetLastError();
+    }
+    if (ring == 8192)
+        hipLaunchKernelGGL((k_lz4_dec_ring<8192, false>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
+                           block_size, n_blocks, d_status, nullptr);
+    else
+        hipLaunchKernelGGL((k_lz4_dec_ring<4096, false>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
+                           block_size, n_blocks, d_status, nullptr);
     return hipGetLastError();
 }
 
