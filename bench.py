@@ -42,6 +42,7 @@ def parse_args():
     ap.add_argument("--accel", type=int, default=1, help="lz4 acceleration used to produce the inputs")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="diagnostic ablation runs only: result is not valid")
     return ap.parse_args()
 
 
@@ -190,12 +191,12 @@ def main():
 
     # ---------------- verification (untimed) ----------------
     st = d_status.download(dtype=np.int32)
-    assert (st == 0).all(), "lz4 decode status"
+    assert a.no_verify or (st == 0).all(), "lz4 decode status"
     d_mis.memset(0)
     codec.compare_batch(d_raw, B, d_out, B, B, n, d_mis)
     codec.sync()
     mismatch = int(d_mis.download(dtype=np.uint64)[0])
-    assert mismatch == 0, "decoded blocks differ from originals: %d" % mismatch
+    assert a.no_verify or mismatch == 0, "decoded blocks differ from originals: %d" % mismatch
 
     t = torch.tensor([elapsed], dtype=torch.float64)
     if world > 1:

@@ -134,6 +134,30 @@ struct Wave {
     }
 };
 
+/* wave64 inclusive add-scan on the DPP cross-lane network (no LDS round trips):
+ * Hillis-Steele inside each row of 16 (row_shr 1,2,4,8; out-of-row sources read 0), then
+ * row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3. */
+template <int CTRL, int ROW_MASK>
+__device__ inline uint32_t dpp_add(uint32_t x)
+{
+    return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
+}
+__device__ inline uint32_t scan16_incl(uint32_t x) /* independent scan in every row of 16 lanes */
+{
+    x = dpp_add<0x111, 0xf>(x);
+    x = dpp_add<0x112, 0xf>(x);
+    x = dpp_add<0x114, 0xf>(x);
+    x = dpp_add<0x118, 0xf>(x);
+    return x;
+}
+__device__ inline uint32_t scan64_incl(uint32_t x)
+{
+    x = scan16_incl(x);
+    x = dpp_add<0x142, 0xa>(x);
+    x = dpp_add<0x143, 0xc>(x);
+    return x;
+}
+
 /* lane % m for lane < 64, 0 < m < 64 */
 __device__ inline uint32_t lane_mod(uint32_t lane, uint32_t m)
 {
@@ -154,22 +178,26 @@ constexpr uint32_t kDMax = 63;    /* longest token-to-token distance the batch h
 constexpr uint32_t kTMax = 1024;  /* output bytes per batch (16 chunks of 64)                   */
 constexpr uint32_t kNCh = kTMax / 64;
 
+/* Per-wave LDS regions.  They are separate __shared__ objects on purpose: the compiler can
+ * then prove that e.g. a byte store into the output ring does not alias the parse tables,
+ * and hoists the next group's LDS reads above it (otherwise every group costs a full LDS
+ * round trip and the batch is latency bound). */
 template <uint32_t R>
-struct __attribute__((aligned(16))) WaveLds {
-    uint8_t ring[R];
-    uint8_t in[kInRing];
-    uint8_t d1[kD1N];
-    uint8_t d2[kD2N];
-    uint8_t d4[kWMax];
-    uint32_t bm[kTMax / 32];     /* bit q set: a sequence starts at batch output offset q */
-    unsigned long long meta[64]; /* per sequence: ostart | ll<<16 | litidx<<32 | off<<48  */
+struct WaveLds {
+    uint8_t *__restrict__ ring;            /* R        output ring                       */
+    uint8_t *__restrict__ in;              /* kInRing  input ring                        */
+    uint8_t *__restrict__ d1;              /* kD1N                                        */
+    uint8_t *__restrict__ d2;              /* kD2N                                        */
+    uint8_t *__restrict__ d4;              /* kWMax                                       */
+    unsigned long long *__restrict__ meta; /* 64: ostart | ll<<16 | litidx<<32 | off<<48 */
+    uint32_t *__restrict__ bm;             /* kTMax/32: bit q = a sequence starts at q    */
 };
 
-struct Stats { uint32_t batches, batch_seqs, general_seqs, chunks, rounds, zero_batches; };
+struct Stats { uint32_t batches, batch_seqs, general_seqs, chunks, rounds, zero_batches; uint32_t ablate; };
 
 /*
- * Decode up to 64 "simple" sequences starting at virtual position vp; `W` (multiple of 64,
- * <= kWMax) is the span of compressed bytes searched for sequence starts.
+ * Decode up to 64 "simple" sequences starting at virtual position vp; NG*64 (<= kWMax) is the
+ * span of compressed bytes searched for sequence starts.
  * Returns the number of sequences consumed (0 = none; caller runs the general path) and the
  * compressed bytes consumed in *used.
  *
@@ -177,13 +205,19 @@ struct Stats { uint32_t batches, batch_seqs, general_seqs, chunks, rounds, zero_
  * writes up to kTMax new bytes) or "far" (off >= kNear: older than anything the batch
  * produces and already flushed, so it is read back from the output buffer in HBM/L2; all
  * far bytes of a batch are requested up front and cost one memory latency per batch).
+ *
+ * Every phase is written "all loads, then all arithmetic, then all stores" over fully
+ * unrolled register arrays so that a phase costs ~one LDS round trip, not one per group.
  */
-template <uint32_t R>
-__device__ inline uint32_t lz4_batch(Wave<R> &w, WaveLds<R> &L, uint32_t &vp, const uint32_t B,
-                                     const uint32_t W, uint32_t *used, Stats &st)
+template <uint32_t R, uint32_t NG>
+__device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &vp, const uint32_t B,
+                                     uint32_t *used, Stats &st)
 {
     static_assert(R >= 4096, "ring must hold kTMax new bytes plus the near window");
+    static_assert(NG * 64u <= kWMax, "window too large");
     constexpr uint32_t kNear = R - kTMax - 64u;
+    constexpr uint32_t W = NG * 64u;
+    constexpr uint32_t G1 = NG + 4u, G2 = NG + 2u; /* groups of 64 in the d1 / d2 domains */
     const uint32_t lane = w.lane;
     const uint32_t vend = w.vend;
     *used = 0;
@@ -195,25 +229,42 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, WaveLds<R> &L, uint32_t &vp, co
     while (w.in_hi < vend && w.in_hi < vp + W + 256u + 72u) w.refill();
 
     /* ---- phase 1: d1 for every window offset, then d2, d4 ---- */
-    for (uint32_t j = lane; j < W + 256u; j += 64u) {
-        const uint32_t pos = vp + j;
-        const uint32_t t = L.in[pos & kInMask];
-        const uint32_t e1 = L.in[(pos + 1u) & kInMask];
-        const uint32_t hi = t >> 4;
-        uint32_t d = hi + 3u + ((t & 15u) == 15u ? 1u : 0u);
-        if (hi == 15u) d += e1 + 1u;
-        if (d > kDMax) d = 0; /* 0 marks "not batchable from here" */
-        L.d1[j] = (uint8_t)d;
+    uint32_t a1[G1], a2[G2];
+    {
+        uint32_t t[G1], e1[G1];
+#pragma unroll
+        for (uint32_t g = 0; g < G1; g++) {
+            const uint32_t pos = vp + g * 64u + lane;
+            t[g] = L.in[pos & kInMask];
+            e1[g] = L.in[(pos + 1u) & kInMask];
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < G1; g++) {
+            const uint32_t hi = t[g] >> 4;
+            uint32_t d = hi + 3u + ((t[g] & 15u) == 15u ? 1u : 0u);
+            if (hi == 15u) d += e1[g] + 1u;
+            if (d > kDMax) d = 0; /* 0 marks "not batchable from here" */
+            a1[g] = d;
+        }
+#pragma unroll
+        for (uint32_t g = 0; g < G1; g++) L.d1[g * 64u + lane] = (uint8_t)a1[g];
     }
-    for (uint32_t j = lane; j < W + 128u; j += 64u) {
-        const uint32_t a = L.d1[j];
-        const uint32_t b = L.d1[j + a];
-        L.d2[j] = (uint8_t)((a != 0u && b != 0u) ? a + b : 0u);
+    {
+        uint32_t b[G2];
+#pragma unroll
+        for (uint32_t g = 0; g < G2; g++) b[g] = L.d1[g * 64u + lane + a1[g]];
+#pragma unroll
+        for (uint32_t g = 0; g < G2; g++) a2[g] = (a1[g] != 0u && b[g] != 0u) ? a1[g] + b[g] : 0u;
+#pragma unroll
+        for (uint32_t g = 0; g < G2; g++) L.d2[g * 64u + lane] = (uint8_t)a2[g];
     }
-    for (uint32_t j = lane; j < W; j += 64u) {
-        const uint32_t a = L.d2[j];
-        const uint32_t b = L.d2[j + a];
-        L.d4[j] = (uint8_t)((a != 0u && b != 0u) ? a + b : 0u);
+    {
+        uint32_t b[NG];
+#pragma unroll
+        for (uint32_t g = 0; g < NG; g++) b[g] = L.d2[g * 64u + lane + a2[g]];
+#pragma unroll
+        for (uint32_t g = 0; g < NG; g++)
+            L.d4[g * 64u + lane] = (uint8_t)((a2[g] != 0u && b[g] != 0u) ? a2[g] + b[g] : 0u);
     }
 
     /* ---- chase: start of every 4th sequence into lanes 0,4,8,... ---- */
@@ -252,13 +303,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, WaveLds<R> &L, uint32_t &vp, co
     if (hasM) { ml += e2; dlen += 1u; }
     const bool cand = lane < ncand;
     const uint32_t outlen = cand ? ll + ml : 0u;
-    /* inclusive scan of output lengths */
-    uint32_t oend = outlen;
-#pragma unroll
-    for (uint32_t d = 1; d < 64u; d <<= 1) {
-        const uint32_t y = __shfl_up(oend, d, 64);
-        if (lane >= d) oend += y;
-    }
+    const uint32_t oend = scan64_incl(outlen);
     const uint32_t ostart = oend - outlen;
     const uint32_t mabs = w.op + ostart + ll; /* absolute output position of the match */
     const bool ok = cand && !(hasM && e2 == 255u) && off >= ml && off <= mabs &&
@@ -278,15 +323,8 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, WaveLds<R> &L, uint32_t &vp, co
     }
     const uint32_t bm_lo = L.bm[(lane & (kNCh - 1u)) * 2u], bm_hi = L.bm[(lane & (kNCh - 1u)) * 2u + 1u];
     uint32_t basev = (uint32_t)(__popc(bm_lo) + __popc(bm_hi)); /* lanes 0..kNCh-1: starts in chunk `lane` */
-    {
-        uint32_t incl = basev;
-#pragma unroll
-        for (uint32_t d = 1; d < kNCh; d <<= 1) {
-            const uint32_t y = __shfl_up(incl, d, 64);
-            if (lane >= d) incl += y;
-        }
-        basev = incl - basev; /* exclusive: starts before this chunk */
-    }
+    static_assert(kNCh == 16, "chunk-count scan uses one DPP row");
+    basev = scan16_incl(basev) - basev; /* exclusive: starts before this chunk */
     const uint32_t op0 = w.op;
     st.batches++;
     st.batch_seqs += nseq;
@@ -295,25 +333,38 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, WaveLds<R> &L, uint32_t &vp, co
      *      far matches (requested now from the output buffer, written in pass B) ---- */
     uint32_t mlo[kNCh], mhi[kNCh];
     uint32_t xfar[kNCh];
+    {
+        uint32_t idx[kNCh];
 #pragma unroll
-    for (uint32_t c = 0; c < kNCh; c++) {
-        mlo[c] = 0; mhi[c] = 0; xfar[c] = 0;
-        if (c * 64u < T) {
+        for (uint32_t c = 0; c < kNCh; c++) {
             const uint32_t wlo = lane_get(bm_lo, c), whi = lane_get(bm_hi, c);
             const uint32_t bc = lane_get(basev, c);
             const uint32_t below = __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
             const uint32_t own = ((lane < 32u ? wlo >> lane : whi >> (lane - 32u)) & 1u);
-            const uint32_t idx = bc + below + own - 1u;
-            const unsigned long long m = L.meta[idx & 63u];
+            idx[c] = (bc + below + own - 1u) & 63u;
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < kNCh; c++) {
+            const unsigned long long m = L.meta[idx[c]];
             mlo[c] = (uint32_t)m;
             mhi[c] = (uint32_t)(m >> 32);
+        }
+        uint32_t lit[kNCh];
+#pragma unroll
+        for (uint32_t c = 0; c < kNCh; c++) {
             const uint32_t qo = c * 64u + lane; /* batch output offset of this lane's byte */
             const uint32_t dd = qo - (mlo[c] & 0xffffu);
-            const uint32_t mll = mlo[c] >> 16;
             const uint32_t moff = mhi[c] >> 16;
-            const bool active = qo < T;
-            if (active && dd < mll) L.ring[(op0 + qo) & (R - 1)] = L.in[((mhi[c] & 0xffffu) + dd) & kInMask];
-            if (active && dd >= mll && moff >= kNear) xfar[c] = w.dst[op0 + qo - moff];
+            const bool isMatch = qo < T && dd >= (mlo[c] >> 16);
+            lit[c] = L.in[((mhi[c] & 0xffffu) + dd) & kInMask];
+            xfar[c] = 0;
+            if (isMatch && moff >= kNear && !(st.ablate & 1u)) xfar[c] = w.dst[op0 + qo - moff];
+        }
+#pragma unroll
+        for (uint32_t c = 0; c < kNCh; c++) {
+            const uint32_t qo = c * 64u + lane;
+            const uint32_t dd = qo - (mlo[c] & 0xffffu);
+            if (qo < T && dd < (mlo[c] >> 16) && !(st.ablate & 4u)) L.ring[(op0 + qo) & (R - 1)] = (uint8_t)lit[c];
         }
     }
     /* ---- pass B: chunks in order; far bytes land first, then near matches read the ring.
@@ -321,7 +372,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, WaveLds<R> &L, uint32_t &vp, co
      *      a ballot of finished lanes ---- */
 #pragma unroll
     for (uint32_t c = 0; c < kNCh; c++) {
-        if (c * 64u < T) {
+        if (c * 64u < T && !(st.ablate & 2u)) {
             st.chunks++;
             const uint32_t qo = c * 64u + lane;
             const uint32_t dd = qo - (mlo[c] & 0xffffu);
@@ -357,8 +408,15 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
                const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
                uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats)
 {
-    Stats st = {0, 0, 0, 0, 0, 0};
-    __shared__ WaveLds<R> s_lds[4];
+    Stats st = {0, 0, 0, 0, 0, 0, 0};
+    if (STATS) st.ablate = (uint32_t)stats[7];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][R];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[4][kInRing];
+    __shared__ uint8_t s_d1[4][kD1N];
+    __shared__ uint8_t s_d2[4][kD2N];
+    __shared__ uint8_t s_d4[4][kWMax];
+    __shared__ unsigned long long s_meta[4][64];
+    __shared__ uint32_t s_bm[4][kTMax / 32];
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = uni(threadIdx.x >> 6);
@@ -370,7 +428,7 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     const uint32_t csize = uni(src_size[blk]);
 
     Wave<R> w;
-    WaveLds<R> &L = s_lds[wid];
+    const WaveLds<R> L = {s_ring[wid], s_in[wid], s_d1[wid], s_d2[wid], s_d4[wid], s_meta[wid], s_bm[wid]};
     w.ring = L.ring;
     w.in = L.in;
     w.lane = lane;
@@ -389,7 +447,7 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     bool bad = (csize == 0);
     bool done = bad;
     uint32_t skip = 0;
-    uint32_t W = kWMax;
+    bool small = false;
 
     if (!bad) {
         w.prefetch();
@@ -405,13 +463,13 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
         if (skip == 0u) {
             uint32_t n, used;
             do {
-                n = lz4_batch<R>(w, L, vp, B, W, &used, st);
+                n = small ? lz4_batch<R, 2>(w, L, vp, B, &used, st) : lz4_batch<R, 8>(w, L, vp, B, &used, st);
                 if (n == 0u) st.zero_batches++;
-                uint32_t want = (used + used / 2u + 63u) & ~63u;
-                if (n == 64u || used + 64u > W) want = W * 2u;  /* ran out of lanes / window */
-                W = want < 128u ? 128u : (want > kWMax ? kWMax : want);
-            } while (n >= 24u);
-            if (n < 8u) skip = 8u; /* poor yield: stay on the general path for a while */
+                /* long matches fill kTMax output bytes after few tokens: then a 128-byte window
+                 * is enough and the table passes shrink 3x */
+                small = (n != 0u && n < 64u && used < 96u);
+            } while (n >= 24u || (n >= 4u && small));
+            if (n < 4u) skip = 8u; /* poor yield: stay on the general path for a while */
         } else {
             skip--;
         }
@@ -604,15 +662,17 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
     const dim3 g((uint32_t)grid), b(256);
     static const bool want_stats = getenv("CRYO_LZ4_STATS") != nullptr; /* debugging aid */
     if (want_stats) {
-        unsigned long long *d_st = nullptr, h_st[6];
+        unsigned long long *d_st = nullptr, h_st[8];
+        static const unsigned long long abl = getenv("CRYO_LZ4_ABLATE") ? strtoull(getenv("CRYO_LZ4_ABLATE"), nullptr, 0) : 0ull;
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
+        (void)hipMemcpyAsync(d_st + 7, &abl, sizeof abl, hipMemcpyHostToDevice, s);
         hipLaunchKernelGGL((k_lz4_dec_ring<4096, true>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
                            block_size, n_blocks, d_status, d_st);
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
         (void)hipFree(d_st);
-        fprintf(stderr, "[lz4 stats] batches %llu batch_seqs %llu general_seqs %llu chunks %llu rounds %llu zero_batches %llu\n",
+        if (!getenv("CRYO_LZ4_QUIET")) fprintf(stderr, "[lz4 stats] batches %llu batch_seqs %llu general_seqs %llu chunks %llu rounds %llu zero_batches %llu\n",
                 h_st[0], h_st[1], h_st[2], h_st[3], h_st[4], h_st[5]);
         return hipGetLastError();
     }
