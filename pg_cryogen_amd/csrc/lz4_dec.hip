@@ -5,7 +5,15 @@
  * (reference compression.c:84) for a batch of independent blocks.
  *
  * Accept/reject rules are those of the LZ4 block format as liblz4 1.9.3's
- * bounds-checked decoder applies them (see oracle/lz4_oracle.c for the list);
+ * bounds-checked decoder applies them (csize = compressed size, B = block size):
+ *   - a literal run reaching within 12 bytes of B or within 8 bytes of csize must be
+ *     the final one: it has to end the input exactly and fit the output;
+ *   - a literal-length extension byte at position q needs q + 15 < csize (terminator)
+ *     and q + 16 < csize (a 255 that continues);
+ *   - a match-length extension byte at position q needs q + 5 < csize;
+ *   - the offset may not reach before the start of the output; offset 0 is not
+ *     rejected by liblz4 1.9.3, it reproduces as zero bytes;
+ *   - a match must end at least 5 bytes before B;
  * additionally a block must decode to exactly block_size bytes.
  *
  * Data movement of one wave (k_lz4_dec_ring):
@@ -54,6 +62,10 @@
 #include "kernels.h"
 #include <cstdio>
 #include <cstdlib>
+
+#ifndef LZ4_WAVES_PER_SIMD
+#define LZ4_WAVES_PER_SIMD 5
+#endif
 
 namespace cryo {
 
@@ -186,10 +198,10 @@ template <uint32_t R>
 struct WaveLds {
     uint8_t *__restrict__ ring;            /* R        output ring                       */
     uint8_t *__restrict__ in;              /* kInRing  input ring                        */
-    uint8_t *__restrict__ d1;              /* kD1N                                        */
+    uint8_t *d1;                           /* kD1N  (phase 3 reuses it as `meta`)         */
     uint8_t *__restrict__ d2;              /* kD2N                                        */
     uint8_t *__restrict__ d4;              /* kWMax                                       */
-    unsigned long long *__restrict__ meta; /* 64: ostart | ll<<16 | litidx<<32 | off<<48 */
+    unsigned long long *meta;              /* 64: ostart | ll<<16 | litidx<<32 | off<<48 */
     uint32_t *__restrict__ bm;             /* kTMax/32: bit q = a sequence starts at q    */
 };
 
@@ -329,70 +341,77 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     st.batches++;
     st.batch_seqs += nseq;
 
-    /* ---- pass A: bytes that do not depend on this batch: literals (input ring -> ring) and
-     *      far matches (requested now from the output buffer, written in pass B) ---- */
-    uint32_t mlo[kNCh], mhi[kNCh];
-    uint32_t xfar[kNCh];
-    {
-        uint32_t idx[kNCh];
+    /* Two halves of 8 chunks (keeps the register arrays at 8 entries).  Per half:
+     * pass A: bytes that do not depend on this batch: literals (input ring -> ring) and far
+     *         matches (requested now from the output buffer, written in pass B);
+     * pass B: chunks in order; far bytes land first, then near matches read the ring.  Only a
+     *         source inside the current chunk can be unready: extra rounds guarded by a
+     *         ballot of finished lanes. */
+    constexpr uint32_t kHalf = kNCh / 2u;
 #pragma unroll
-        for (uint32_t c = 0; c < kNCh; c++) {
-            const uint32_t wlo = lane_get(bm_lo, c), whi = lane_get(bm_hi, c);
-            const uint32_t bc = lane_get(basev, c);
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
-            const uint32_t own = ((lane < 32u ? wlo >> lane : whi >> (lane - 32u)) & 1u);
-            idx[c] = (bc + below + own - 1u) & 63u;
+    for (uint32_t h = 0; h < 2u; h++) {
+        if (h * kHalf * 64u >= T) break;
+        uint32_t mlo[kHalf], mhi[kHalf], xfar[kHalf];
+        {
+            uint32_t idx[kHalf];
+#pragma unroll
+            for (uint32_t i = 0; i < kHalf; i++) {
+                const uint32_t c = h * kHalf + i;
+                const uint32_t wlo = lane_get(bm_lo, c), whi = lane_get(bm_hi, c);
+                const uint32_t bc = lane_get(basev, c);
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
+                const uint32_t own = ((lane < 32u ? wlo >> lane : whi >> (lane - 32u)) & 1u);
+                idx[i] = (bc + below + own - 1u) & 63u;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < kHalf; i++) {
+                const unsigned long long m = L.meta[idx[i]];
+                mlo[i] = (uint32_t)m;
+                mhi[i] = (uint32_t)(m >> 32);
+            }
+            uint32_t lit[kHalf];
+#pragma unroll
+            for (uint32_t i = 0; i < kHalf; i++) {
+                const uint32_t qo = (h * kHalf + i) * 64u + lane; /* batch output offset of this lane's byte */
+                const uint32_t dd = qo - (mlo[i] & 0xffffu);
+                const uint32_t moff = mhi[i] >> 16;
+                const bool isMatch = qo < T && dd >= (mlo[i] >> 16);
+                lit[i] = L.in[((mhi[i] & 0xffffu) + dd) & kInMask];
+                xfar[i] = 0;
+                if (isMatch && moff >= kNear && !(st.ablate & 1u)) xfar[i] = w.dst[op0 + qo - moff];
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < kHalf; i++) {
+                const uint32_t qo = (h * kHalf + i) * 64u + lane;
+                const uint32_t dd = qo - (mlo[i] & 0xffffu);
+                if (qo < T && dd < (mlo[i] >> 16)) L.ring[(op0 + qo) & (R - 1)] = (uint8_t)lit[i];
+            }
         }
 #pragma unroll
-        for (uint32_t c = 0; c < kNCh; c++) {
-            const unsigned long long m = L.meta[idx[c]];
-            mlo[c] = (uint32_t)m;
-            mhi[c] = (uint32_t)(m >> 32);
-        }
-        uint32_t lit[kNCh];
-#pragma unroll
-        for (uint32_t c = 0; c < kNCh; c++) {
-            const uint32_t qo = c * 64u + lane; /* batch output offset of this lane's byte */
-            const uint32_t dd = qo - (mlo[c] & 0xffffu);
-            const uint32_t moff = mhi[c] >> 16;
-            const bool isMatch = qo < T && dd >= (mlo[c] >> 16);
-            lit[c] = L.in[((mhi[c] & 0xffffu) + dd) & kInMask];
-            xfar[c] = 0;
-            if (isMatch && moff >= kNear && !(st.ablate & 1u)) xfar[c] = w.dst[op0 + qo - moff];
-        }
-#pragma unroll
-        for (uint32_t c = 0; c < kNCh; c++) {
-            const uint32_t qo = c * 64u + lane;
-            const uint32_t dd = qo - (mlo[c] & 0xffffu);
-            if (qo < T && dd < (mlo[c] >> 16) && !(st.ablate & 4u)) L.ring[(op0 + qo) & (R - 1)] = (uint8_t)lit[c];
-        }
-    }
-    /* ---- pass B: chunks in order; far bytes land first, then near matches read the ring.
-     *      Only a source inside the current chunk can be unready: extra rounds guarded by
-     *      a ballot of finished lanes ---- */
-#pragma unroll
-    for (uint32_t c = 0; c < kNCh; c++) {
-        if (c * 64u < T && !(st.ablate & 2u)) {
-            st.chunks++;
-            const uint32_t qo = c * 64u + lane;
-            const uint32_t dd = qo - (mlo[c] & 0xffffu);
-            const uint32_t mll = mlo[c] >> 16;
-            const uint32_t moff = mhi[c] >> 16;
-            const bool isMatch = qo < T && dd >= mll;
-            uint8_t *dstp = &L.ring[(op0 + qo) & (R - 1)];
-            if (isMatch && moff >= kNear) *dstp = (uint8_t)xfar[c];
-            const bool near = isMatch && moff < kNear;
-            const uint8_t *srcp = &L.ring[(op0 + qo - moff) & (R - 1)];
-            const bool inchunk = moff <= lane; /* source byte belongs to this very chunk */
-            if (near && !inchunk) *dstp = *srcp;
-            bool pend = near && inchunk;
-            unsigned long long donem = __ballot(!pend);
-            while (__ballot(pend) != 0ull) {
-                st.rounds++;
-                const bool rdy = pend && ((donem >> ((lane - moff) & 63u)) & 1ull);
-                if (rdy) *dstp = *srcp;
-                donem |= __ballot(rdy);
-                pend = pend && !rdy;
+        for (uint32_t i = 0; i < kHalf; i++) {
+            const uint32_t c = h * kHalf + i;
+            if (c * 64u < T && !(st.ablate & 2u)) {
+                st.chunks++;
+                const uint32_t qo = c * 64u + lane;
+                const uint32_t dd = qo - (mlo[i] & 0xffffu);
+                const uint32_t mll = mlo[i] >> 16;
+                const uint32_t moff = mhi[i] >> 16;
+                const bool isMatch = qo < T && dd >= mll;
+                uint8_t *dstp = &L.ring[(op0 + qo) & (R - 1)];
+                if (isMatch && moff >= kNear) *dstp = (uint8_t)xfar[i];
+                const bool near = isMatch && moff < kNear;
+                const uint8_t *srcp = &L.ring[(op0 + qo - moff) & (R - 1)];
+                const bool inchunk = moff <= lane; /* source byte belongs to this very chunk */
+                if (near && !inchunk) *dstp = *srcp;
+                bool pend = near && inchunk;
+                unsigned long long donem = __ballot(!pend);
+                while (__ballot(pend) != 0ull) {
+                    st.rounds++;
+                    const bool rdy = pend && ((donem >> ((lane - moff) & 63u)) & 1ull);
+                    if (rdy) *dstp = *srcp;
+                    donem |= __ballot(rdy);
+                    pend = pend && !rdy;
+                }
             }
         }
     }
@@ -403,7 +422,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
 }
 
 template <uint32_t R, bool STATS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, LZ4_WAVES_PER_SIMD) /* VGPR cap matching what the LDS budget admits */
 k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
                uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats)
@@ -412,10 +431,9 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     if (STATS) st.ablate = (uint32_t)stats[7];
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][R];
     __shared__ __attribute__((aligned(16))) uint8_t s_in[4][kInRing];
-    __shared__ uint8_t s_d1[4][kD1N];
+    __shared__ __attribute__((aligned(16))) uint8_t s_d1[4][kD1N]; /* also holds meta[64] in phase 3 */
     __shared__ uint8_t s_d2[4][kD2N];
     __shared__ uint8_t s_d4[4][kWMax];
-    __shared__ unsigned long long s_meta[4][64];
     __shared__ uint32_t s_bm[4][kTMax / 32];
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -428,7 +446,8 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     const uint32_t csize = uni(src_size[blk]);
 
     Wave<R> w;
-    const WaveLds<R> L = {s_ring[wid], s_in[wid], s_d1[wid], s_d2[wid], s_d4[wid], s_meta[wid], s_bm[wid]};
+    const WaveLds<R> L = {s_ring[wid], s_in[wid], s_d1[wid], s_d2[wid], s_d4[wid],
+                          reinterpret_cast<unsigned long long *>(s_d1[wid]), s_bm[wid]};
     w.ring = L.ring;
     w.in = L.in;
     w.lane = lane;

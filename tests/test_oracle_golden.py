@@ -1,0 +1,150 @@
+"""CPU tests: pin the oracle (oracle/*.c) to the golden vectors produced by the real
+liblz4 1.9.3 / libzstd 1.4.x (tests/golden/make_golden.py), and to the live libraries
+where they can be dlopen'ed.  No GPU needed."""
+import base64
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _load(name):
+    with open(os.path.join(G, name)) as f:
+        return json.load(f)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+VEC = _load("vectors.json")
+STREAMS = _load("streams.json")
+ADV = _load("adversarial.json")
+
+
+def test_golden_header():
+    assert VEC["lz4_version"] == "1.9.3"
+    assert VEC["zstd_version"] in ("1.4.8", "1.4.9")
+
+
+def test_synth_generator_pinned(oracle):
+    seen = {}
+    for c in VEC["cells"]:
+        key = (c["B"], c["dist"], c["block"])
+        if key in seen:
+            assert seen[key] == c["raw_sha256"]
+            continue
+        seen[key] = c["raw_sha256"]
+        if c["B"] > 131072 and c["block"] > 1:
+            continue  # keep the CPU suite short: the generator is per-byte
+        assert sha(oracle.synth(VEC["seed"], c["block"], c["B"], c["dist"])) == c["raw_sha256"], key
+
+
+def test_lz4_encoder_oracle_matches_liblz4_golden(oracle):
+    n = 0
+    for c in VEC["cells"]:
+        if c["method"] != "lz4" or (c["B"] > 131072 and c["block"] > 0):
+            continue
+        raw = oracle.synth(VEC["seed"], c["block"], c["B"], c["dist"])
+        comp = oracle.lz4_compress(raw, c["param"])
+        assert len(comp) == c["csize"], c
+        assert sha(comp) == c["comp_sha256"], c
+        n += 1
+    assert n >= 100
+
+
+def test_lz4_decoder_oracle_on_golden_streams(oracle):
+    n = 0
+    for s in STREAMS["streams"]:
+        if s["method"] != "lz4":
+            continue
+        comp = np.frombuffer(base64.b64decode(s["data"]), np.uint8)
+        r, out = oracle.lz4_decompress(comp, s["B"])
+        assert r == s["B"]
+        assert sha(out) == s["raw_sha256"], s["dist"]
+        n += 1
+    assert n >= 10
+
+
+def test_lz4_decoder_oracle_adversarial(oracle):
+    """accept (exactly B bytes) / reject verdict and decoded bytes as liblz4 1.9.3 gave them"""
+    n_ok = n_bad = 0
+    for c in ADV["cases"]:
+        if c["method"] != "lz4":
+            continue
+        m = np.frombuffer(base64.b64decode(c["data"]), np.uint8)
+        if len(m) == 0:
+            continue
+        r, out = oracle.lz4_decompress(m, c["B"], fill=0xA5)
+        assert (r == c["B"]) == c["ok"], c["name"]
+        if c["ok"]:
+            assert sha(out) == c["out_sha256"], c["name"]
+            n_ok += 1
+        else:
+            n_bad += 1
+    assert n_ok > 5 and n_bad > 20
+
+
+def test_bounds_match_libraries(oracle):
+    # LZ4_compressBound / ZSTD_compressBound values quoted in SURVEY.md 8a-3/8a-5
+    assert oracle.lz4_bound(131072) == 131602 and oracle.lz4_bound(1 << 20) == 1052704
+    from pg_cryogen_amd import bound, METHOD_LZ4, METHOD_ZSTD
+    assert bound(METHOD_LZ4, 131072) == 131602 and bound(METHOD_LZ4, 1 << 20) == 1052704
+    assert bound(METHOD_ZSTD, 131072) == 131584 and bound(METHOD_ZSTD, 1 << 20) == 1052672
+
+
+# ---------------- live libraries (skipped where they cannot be loaded) ----------------
+@pytest.fixture(scope="module")
+def stock():
+    s = oracle_lib.StockLibs()
+    if s.lz4 is None:
+        pytest.skip("liblz4.so.1 not loadable")
+    return s
+
+
+@pytest.mark.parametrize("B", [131072, 4096, 65546, 65547, 13, 12, 1])
+def test_lz4_oracle_vs_live_liblz4(oracle, stock, B):
+    for dist in range(5):
+        raw = oracle.synth(3, 11, B, dist) if B >= 64 else (np.arange(B, dtype=np.uint8) * 7)
+        for accel in (0, 1, 3, 50):
+            exp = stock.lz4_compress(raw, accel)
+            got = oracle.lz4_compress(raw, accel)
+            assert np.array_equal(got, exp), (B, dist, accel)
+            r, out = oracle.lz4_decompress(exp, B)
+            assert r == B and np.array_equal(out, raw)
+
+
+def test_lz4_oracle_fuzz_vs_live_liblz4(oracle, stock):
+    rng = np.random.default_rng(7)
+    B = 4096
+    checked = 0
+    for dist in (0, 1, 3):
+        c = stock.lz4_compress(oracle.synth(0, 1, B, dist), 1)
+        for it in range(600):
+            m = c.copy()
+            k = it % 4
+            if k == 0:
+                for _ in range(int(rng.integers(1, 4))):
+                    m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+            elif k == 1:
+                m = m[:int(rng.integers(1, len(m)))].copy()
+            elif k == 2:
+                m = np.concatenate([m, rng.integers(0, 256, int(rng.integers(1, 20))).astype(np.uint8)])
+            else:
+                p = int(rng.integers(0, len(m) - 1))
+                m[p] = 0
+                m[p + 1] = 0
+            r1, o1 = stock.lz4_decompress(m, B, fill=0xA5)
+            r2, o2 = oracle.lz4_decompress(m, B, fill=0xA5)
+            # contract of this repo: success == exactly B bytes decoded (compression.c:88 Assert)
+            assert (r1 == B) == (r2 == B), (dist, it)
+            if r1 == B:
+                assert np.array_equal(o1, o2), (dist, it)
+                checked += 1
+    assert checked > 100
