@@ -148,3 +148,94 @@ def test_lz4_oracle_fuzz_vs_live_liblz4(oracle, stock):
                 assert np.array_equal(o1, o2), (dist, it)
                 checked += 1
     assert checked > 100
+
+
+# ---------------- zstd decoder oracle ----------------
+def test_zstd_decoder_oracle_on_golden_streams(oracle):
+    n = 0
+    for s in STREAMS["streams"]:
+        if s["method"] != "zstd":
+            continue
+        comp = np.frombuffer(base64.b64decode(s["data"]), np.uint8)
+        r, out = oracle.zstd_decompress(comp, s["B"])
+        assert r == s["B"], (s["B"], s["dist"], s["param"])
+        assert sha(out) == s["raw_sha256"], (s["B"], s["dist"], s["param"])
+        n += 1
+    assert n >= 20
+
+
+def _zstd_malformed_rule(lib_ok, lib_out_sha, r, out, B, tag):
+    """malformed-input contract (oracle/zstd_dec_oracle.c header):
+    we accept => library accepts and bytes are identical; library rejects => we reject."""
+    ours_ok = (r == B)
+    if ours_ok:
+        assert lib_ok, tag
+        assert sha(out) == lib_out_sha, tag
+    if not lib_ok:
+        assert not ours_ok, tag
+    return ours_ok
+
+
+def test_zstd_decoder_oracle_adversarial(oracle):
+    n_ok = n_lib_ok = n = 0
+    for c in ADV["cases"]:
+        if c["method"] != "zstd":
+            continue
+        m = np.frombuffer(base64.b64decode(c["data"]), np.uint8)
+        if len(m) == 0:
+            continue
+        r, out = oracle.zstd_decompress(m, c["B"], fill=0xA5)
+        n_ok += _zstd_malformed_rule(c["ok"], c["out_sha256"], r, out, c["B"], c["name"])
+        n_lib_ok += c["ok"]
+        n += 1
+        if c["name"] == "valid":
+            assert r == c["B"]
+    assert n > 100 and n_ok >= 3
+    # strictness (exact bitstream consumption) may only drop a small share of library-accepted cases
+    assert n_lib_ok - n_ok <= max(3, n // 20), (n_lib_ok, n_ok)
+
+
+@pytest.mark.parametrize("B", [131072, 4096, 65546, 300, 17])
+def test_zstd_oracle_decodes_live_libzstd_all_levels(oracle, B):
+    stock = oracle_lib.StockLibs()
+    if stock.zstd is None:
+        pytest.skip("libzstd.so.1 not loadable")
+    for dist in range(5):
+        raw = oracle.synth(4, 2, B, dist) if B >= 64 else (np.arange(B, dtype=np.uint8) * 3)
+        for lvl in (-5, -1, 1, 2, 3, 4, 5, 7, 9, 12, 16, 19, 22):
+            if B == 131072 and lvl > 16 and dist in (0, 3):
+                continue
+            c = stock.zstd_compress(raw, lvl)
+            r, out = oracle.zstd_decompress(c, B)
+            assert r == B and np.array_equal(out, raw), (B, dist, lvl)
+
+
+def test_zstd_oracle_fuzz_vs_live_libzstd(oracle):
+    stock = oracle_lib.StockLibs()
+    if stock.zstd is None:
+        pytest.skip("libzstd.so.1 not loadable")
+    rng = np.random.default_rng(11)
+    B = 4096
+    n = n_ok = n_lib = 0
+    for dist in (0, 1, 3):
+        for lvl in (1, 3, 19):
+            c = stock.zstd_compress(oracle.synth(0, 1, B, dist), lvl)
+            for it in range(300):
+                m = c.copy()
+                k = it % 4
+                if k == 0:
+                    for _ in range(int(rng.integers(1, 4))):
+                        m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+                elif k == 1:
+                    m = m[:int(rng.integers(1, len(m)))].copy()
+                elif k == 2:
+                    m = np.concatenate([m, rng.integers(0, 256, int(rng.integers(1, 20))).astype(np.uint8)])
+                else:
+                    p = int(rng.integers(0, len(m)))
+                    m[p] ^= 1 << int(rng.integers(0, 8))
+                r1, o1 = stock.zstd_decompress(m, B, fill=0xA5)
+                r2, o2 = oracle.zstd_decompress(m, B, fill=0xA5)
+                n_ok += _zstd_malformed_rule(r1 == B, sha(o1), r2, o2, B, (dist, lvl, it))
+                n_lib += (r1 == B)
+                n += 1
+    assert n_lib - n_ok <= n // 20, (n_lib, n_ok)
