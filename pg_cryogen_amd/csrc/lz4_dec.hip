@@ -59,7 +59,7 @@
  *  first/last bytes of a block, malformed input.  It implements every accept/reject
  *  rule; the batch only ever accepts sequences that pass all of them.
  */
-#include "kernels.h"
+#include "lz_common.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -70,116 +70,6 @@
 namespace cryo {
 
 namespace {
-
-constexpr uint32_t kInRing = 2048, kInMask = kInRing - 1; /* >= kWMax + 256 + 72 + kChunk */
-constexpr uint32_t kChunk = 1024; /* bytes per refill / flush: 64 lanes x 16 B */
-
-__device__ inline uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
-/* NOTE: never rebuild a pointer from integers (it becomes a FLAT pointer and every access then
- * also counts on lgkmcnt, serialising LDS traffic behind HBM traffic); make the OFFSET uniform. */
-__device__ inline uint64_t uni64(uint64_t v)
-{
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-__device__ inline uint32_t lane_get(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ inline uint32_t ctz64(unsigned long long m) { return (uint32_t)__builtin_ctzll(m); }
-
-template <uint32_t R>
-struct Wave {
-    /* LDS */
-    uint8_t *ring; /* R bytes   */
-    uint8_t *in;   /* kInRing   */
-    /* stream */
-    const uint8_t *abase; /* 16-byte aligned address at or below the block's first byte */
-    uint32_t delta;       /* first byte = abase + delta                                */
-    uint32_t vend;        /* delta + csize: end of stream in "virtual" positions       */
-    uint32_t in_hi;       /* virtual position staged up to (multiple of kChunk)        */
-    uint4 pre;            /* prefetched next chunk                                     */
-    /* output */
-    uint8_t *dst;
-    uint32_t op;      /* bytes produced      */
-    uint32_t flushed; /* bytes stored to HBM (multiple of kChunk) */
-    bool dst_aligned;
-    uint32_t lane;
-
-    __device__ inline void prefetch()
-    {
-        const uint32_t o = in_hi + lane * 16u;
-        pre = make_uint4(0, 0, 0, 0);
-        if (o < vend) pre = *reinterpret_cast<const uint4 *>(abase + o);
-    }
-    /* write the prefetched chunk into the input ring, start fetching the one after */
-    __device__ inline void refill()
-    {
-        *reinterpret_cast<uint4 *>(in + ((in_hi + lane * 16u) & kInMask)) = pre;
-        in_hi += kChunk;
-        prefetch();
-    }
-    /* keep at least 128 staged bytes ahead of virtual position vp (the chunk after that is
-     * already on its way in `pre`) */
-    __device__ inline void need(uint32_t vp)
-    {
-        while (in_hi < vend && vp + 128u > in_hi) refill();
-    }
-    /* 64-byte window at virtual position vp: lane l holds byte vp + l */
-    __device__ inline uint32_t window(uint32_t vp) const { return in[(vp + lane) & kInMask]; }
-
-    /* store completed 1 KiB output chunks */
-    __device__ inline void flush()
-    {
-        while (op - flushed >= kChunk) {
-            if (dst_aligned) {
-                const uint4 x = *reinterpret_cast<const uint4 *>(ring + ((flushed + lane * 16u) & (R - 1)));
-                *reinterpret_cast<uint4 *>(dst + flushed + lane * 16u) = x;
-            } else {
-                for (uint32_t i = lane; i < kChunk; i += 64u) dst[flushed + i] = ring[(flushed + i) & (R - 1)];
-            }
-            flushed += kChunk;
-        }
-    }
-    __device__ inline void flush_tail()
-    {
-        for (uint32_t i = flushed + lane; i < op; i += 64u) dst[i] = ring[i & (R - 1)];
-        flushed = op;
-    }
-};
-
-/* wave64 inclusive add-scan on the DPP cross-lane network (no LDS round trips):
- * Hillis-Steele inside each row of 16 (row_shr 1,2,4,8; out-of-row sources read 0), then
- * row_bcast:15 into rows 1,3 and row_bcast:31 into rows 2,3. */
-template <int CTRL, int ROW_MASK>
-__device__ inline uint32_t dpp_add(uint32_t x)
-{
-    return x + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROW_MASK, 0xf, false);
-}
-__device__ inline uint32_t scan16_incl(uint32_t x) /* independent scan in every row of 16 lanes */
-{
-    x = dpp_add<0x111, 0xf>(x);
-    x = dpp_add<0x112, 0xf>(x);
-    x = dpp_add<0x114, 0xf>(x);
-    x = dpp_add<0x118, 0xf>(x);
-    return x;
-}
-__device__ inline uint32_t scan64_incl(uint32_t x)
-{
-    x = scan16_incl(x);
-    x = dpp_add<0x142, 0xa>(x);
-    x = dpp_add<0x143, 0xc>(x);
-    return x;
-}
-
-/* lane % m for lane < 64, 0 < m < 64 */
-__device__ inline uint32_t lane_mod(uint32_t lane, uint32_t m)
-{
-    const uint32_t q = (uint32_t)((float)lane * __frcp_rn((float)m));
-    int32_t r = (int32_t)(lane - q * m);
-    if (r < 0) r += (int32_t)m;
-    if (r >= (int32_t)m) r -= (int32_t)m;
-    return (uint32_t)r;
-}
-
 } // namespace
 
 /* ---- batch engine constants ---- */

@@ -1,0 +1,128 @@
+"""GPU parity tests for the zstd decode path: HIP kernel through the C ABI vs the CPU oracle
+and the golden streams produced by libzstd 1.4.8.
+
+Reference call shape: compression.c:116 ZSTD_decompress(out, B, src, csize).  Bar: bit-exact.
+"""
+import base64
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from pg_cryogen_amd import METHOD_ZSTD
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_zstd_decode_golden_streams(codec):
+    streams = json.load(open(os.path.join(G, "streams.json")))["streams"]
+    by_B = {}
+    for s in streams:
+        if s["method"] == "zstd":
+            by_B.setdefault(s["B"], []).append(s)
+    assert by_B
+    for B, lst in by_B.items():
+        comps = [np.frombuffer(base64.b64decode(s["data"]), np.uint8) for s in lst]
+        outs, st = codec.decompress_blocks(METHOD_ZSTD, comps, B)
+        assert (st == 0).all(), (B, st)
+        for s, o in zip(lst, outs):
+            assert sha(o) == s["raw_sha256"], (B, s["dist"], s["param"])
+
+
+def test_zstd_decode_adversarial_matches_oracle(codec, oracle):
+    """malformed streams: the kernel's verdict and bytes equal the oracle's (which is pinned to
+    libzstd by tests/test_oracle_golden.py)"""
+    adv = json.load(open(os.path.join(G, "adversarial.json")))["cases"]
+    cases = [c for c in adv if c["method"] == "zstd" and len(c["data"]) > 0]
+    B = cases[0]["B"]
+    comps = [np.frombuffer(base64.b64decode(c["data"]), np.uint8) for c in cases]
+    outs, st = codec.decompress_blocks(METHOD_ZSTD, comps, B)
+    n_ok = 0
+    for c, m, o, s in zip(cases, comps, outs, st):
+        r, exp = oracle.zstd_decompress(m, B, fill=0xA5)
+        if r == B:
+            assert s == 0, c["name"]
+            assert np.array_equal(o, exp), c["name"]
+            n_ok += 1
+        else:
+            assert s != 0, c["name"]
+    assert n_ok >= 3
+
+
+@pytest.mark.parametrize("B", [131072, 1 << 20, 4096, 65546, 300])
+def test_zstd_decode_all_levels_live_library(codec, oracle, B):
+    stock = oracle_lib.StockLibs()
+    if stock.zstd is None:
+        pytest.skip("libzstd.so.1 not loadable")
+    blocks, comps = [], []
+    for dist in range(5):
+        raw = oracle.synth(9, dist, B, dist)
+        for lvl in (-5, 1, 2, 3, 5, 9, 16, 19, 22):
+            if B >= 131072 and lvl > 9 and dist in (0, 3):
+                continue
+            if B == (1 << 20) and lvl > 5:
+                continue
+            blocks.append(raw)
+            comps.append(stock.zstd_compress(raw, lvl))
+    outs, st = codec.decompress_blocks(METHOD_ZSTD, comps, B)
+    assert (st == 0).all(), st
+    for raw, o in zip(blocks, outs):
+        assert np.array_equal(o, raw)
+
+
+def test_zstd_decode_fuzz_matches_oracle(codec, oracle):
+    stock = oracle_lib.StockLibs()
+    if stock.zstd is None:
+        pytest.skip("libzstd.so.1 not loadable")
+    rng = np.random.default_rng(21)
+    B = 4096
+    comps, expect = [], []
+    for dist in (0, 1, 3):
+        for lvl in (1, 3, 19):
+            c = stock.zstd_compress(oracle.synth(0, 1, B, dist), lvl)
+            for it in range(200):
+                m = c.copy()
+                k = it % 4
+                if k == 0:
+                    for _ in range(int(rng.integers(1, 4))):
+                        m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+                elif k == 1:
+                    m = m[:int(rng.integers(1, len(m)))].copy()
+                elif k == 2:
+                    m = np.concatenate([m, rng.integers(0, 256, int(rng.integers(1, 20))).astype(np.uint8)])
+                else:
+                    p = int(rng.integers(0, len(m)))
+                    m[p] ^= 1 << int(rng.integers(0, 8))
+                r, out = oracle.zstd_decompress(m, B, fill=0xA5)
+                comps.append(m)
+                expect.append(out.copy() if r == B else None)
+    outs, st = codec.decompress_blocks(METHOD_ZSTD, comps, B)
+    n_ok = 0
+    for i, e in enumerate(expect):
+        if e is None:
+            assert st[i] != 0, i
+        else:
+            assert st[i] == 0, i
+            assert np.array_equal(outs[i], e), i
+            n_ok += 1
+    assert n_ok > 30
+
+
+def test_zstd_single_block_host_api(codec, oracle):
+    stock = oracle_lib.StockLibs()
+    if stock.zstd is None:
+        pytest.skip("libzstd.so.1 not loadable")
+    B = 131072
+    raw = oracle.synth(2, 9, B, 0)
+    c = stock.zstd_compress(raw, 1)
+    out = codec.decompress_block(METHOD_ZSTD, c, B)
+    assert np.array_equal(out, raw)
+    assert codec.decompress_block(METHOD_ZSTD, c[:-3], B) is None
