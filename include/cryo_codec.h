@@ -125,6 +125,20 @@ int cryo_codec_decompress_block(cryo_codec *c, int method,
                                 const void *h_src, size_t src_size,
                                 void *h_dst, size_t block_size);
 
+/* ---- K blocks at once, HOST buffers: what the batch write/read staging calls
+ *      (write-behind of K full blocks from multi_insert, read-ahead of K block chains;
+ *      reference one-at-a-time equivalents: pg_cryogen.c:726 and cache.c:178).
+ *      Synchronous: one H2D, one kernel launch, one D2H for the whole batch. ---- */
+/* block i: h_src + i*block_size  ->  h_dst + i*dst_stride, size in h_out_size[i] */
+int cryo_codec_compress_blocks(cryo_codec *c, int method, int param,
+                               const void *h_src, size_t block_size, size_t n_blocks,
+                               void *h_dst, size_t dst_stride, uint32_t *h_out_size);
+/* block i: h_src[i] (h_src_size[i] bytes) -> h_dst + i*block_size; h_status[i] = CRYO_OK / CRYO_E_CORRUPT.
+ * Returns CRYO_OK when the batch ran, even if some blocks are corrupt. */
+int cryo_codec_decompress_blocks(cryo_codec *c, int method,
+                                 const void *const *h_src, const uint32_t *h_src_size, size_t n_blocks,
+                                 void *h_dst, size_t block_size, int32_t *h_status);
+
 /* ---- batch helpers used by staging, tests and the benchmark ---- */
 
 /* synthetic cryo blocks (include/cryo_synth.h) first_block .. first_block+n-1, on device */

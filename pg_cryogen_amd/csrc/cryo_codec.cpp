@@ -10,6 +10,7 @@
 #include "kernels.h"
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -292,6 +293,106 @@ int cryo_codec_decompress_block(cryo_codec *c, int method, const void *h_src, si
     HIP_TRY(c, hipMemcpyAsync(h_dst, c->d_out, block_size, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return CRYO_OK;
+}
+
+/* ---- K blocks, host buffers ---- */
+int cryo_codec_compress_blocks(cryo_codec *c, int method, int param, const void *h_src, size_t block_size,
+                               size_t n, void *h_dst, size_t dst_stride, uint32_t *h_out_size)
+{
+    if (!c || !method_ok(method) || block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
+    if (n == 0) return CRYO_OK;
+    if (!h_src || !h_dst || !h_out_size) return CRYO_E_ARG;
+    const size_t bound = cryo_codec_bound(method, block_size);
+    if (dst_stride < bound) return CRYO_E_DSTSIZE;
+    const size_t dstride = (bound + 15) & ~(size_t)15;
+    uint8_t *d_src = nullptr, *d_dst = nullptr;
+    uint32_t *d_sz = nullptr;
+    int32_t *d_st = nullptr;
+    int rc = CRYO_OK;
+    hipError_t e = hipMalloc((void **)&d_src, n * block_size);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_dst, n * dstride);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_sz, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_st, n * sizeof(int32_t));
+    int32_t *h_st = (int32_t *)malloc(n * sizeof(int32_t));
+    if (e != hipSuccess || !h_st) rc = (e == hipSuccess || e == hipErrorOutOfMemory) ? CRYO_E_NOMEM : fail(c, e, "hipMalloc");
+    if (rc == CRYO_OK && (e = hipMemcpyAsync(d_src, h_src, n * block_size, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
+        rc = fail(c, e, "hipMemcpyAsync");
+    if (rc == CRYO_OK)
+        rc = cryo_codec_compress_batch(c, method, param, d_src, block_size, (uint32_t)block_size, n, d_dst, dstride, d_sz, d_st);
+    if (rc == CRYO_OK) {
+        e = hipMemcpyAsync(h_out_size, d_sz, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_st, d_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, e, "compress_blocks D2H");
+    }
+    for (size_t i = 0; rc == CRYO_OK && i < n; i++) {
+        if (h_st[i] != CRYO_OK) { rc = h_st[i]; break; }
+        if (h_out_size[i] == 0 || h_out_size[i] > bound) { rc = CRYO_E_HIP; break; }
+        e = hipMemcpyAsync((uint8_t *)h_dst + i * dst_stride, d_dst + i * dstride, h_out_size[i], hipMemcpyDeviceToHost, c->stream);
+        if (e != hipSuccess) rc = fail(c, e, "compress_blocks D2H");
+    }
+    if (rc == CRYO_OK && (e = hipStreamSynchronize(c->stream)) != hipSuccess) rc = fail(c, e, "hipStreamSynchronize");
+    (void)hipStreamSynchronize(c->stream);
+    free(h_st);
+    if (d_src) (void)hipFree(d_src);
+    if (d_dst) (void)hipFree(d_dst);
+    if (d_sz) (void)hipFree(d_sz);
+    if (d_st) (void)hipFree(d_st);
+    return rc;
+}
+
+int cryo_codec_decompress_blocks(cryo_codec *c, int method, const void *const *h_src, const uint32_t *h_src_size,
+                                 size_t n, void *h_dst, size_t block_size, int32_t *h_status)
+{
+    if (!c || !method_ok(method) || block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
+    if (n == 0) return CRYO_OK;
+    if (!h_src || !h_src_size || !h_dst || !h_status) return CRYO_E_ARG;
+    uint64_t *h_off = (uint64_t *)malloc(n * sizeof(uint64_t));
+    if (!h_off) return CRYO_E_NOMEM;
+    size_t total = 0;
+    for (size_t i = 0; i < n; i++) {
+        h_off[i] = total;
+        total += ((size_t)h_src_size[i] + 15) & ~(size_t)15;
+    }
+    if (total == 0) total = 16;
+    uint8_t *d_src = nullptr, *d_dst = nullptr;
+    uint64_t *d_off = nullptr;
+    uint32_t *d_sz = nullptr;
+    int32_t *d_st = nullptr;
+    int rc = CRYO_OK;
+    hipError_t e = hipMalloc((void **)&d_src, total);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_dst, n * block_size);
+    if (e == hipSuccess) e = hipMalloc((void **)&d_off, n * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_sz, n * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc((void **)&d_st, n * sizeof(int32_t));
+    if (e != hipSuccess) rc = (e == hipErrorOutOfMemory) ? CRYO_E_NOMEM : fail(c, e, "hipMalloc");
+    for (size_t i = 0; rc == CRYO_OK && i < n; i++) {
+        if (h_src_size[i] == 0) continue;
+        if (!h_src[i]) { rc = CRYO_E_ARG; break; }
+        e = hipMemcpyAsync(d_src + h_off[i], h_src[i], h_src_size[i], hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) rc = fail(c, e, "hipMemcpyAsync");
+    }
+    if (rc == CRYO_OK) {
+        e = hipMemcpyAsync(d_off, h_off, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_sz, h_src_size, n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) rc = fail(c, e, "hipMemcpyAsync");
+    }
+    if (rc == CRYO_OK)
+        rc = cryo_codec_decompress_batch(c, method, d_src, d_off, d_sz, d_dst, block_size, (uint32_t)block_size, n, d_st);
+    if (rc == CRYO_OK) {
+        e = hipMemcpyAsync(h_status, d_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(h_dst, d_dst, n * block_size, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) rc = fail(c, e, "decompress_blocks D2H");
+    }
+    (void)hipStreamSynchronize(c->stream);
+    free(h_off);
+    if (d_src) (void)hipFree(d_src);
+    if (d_dst) (void)hipFree(d_dst);
+    if (d_off) (void)hipFree(d_off);
+    if (d_sz) (void)hipFree(d_sz);
+    if (d_st) (void)hipFree(d_st);
+    return rc;
 }
 
 /* ---- helpers ---- */

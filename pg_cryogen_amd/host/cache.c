@@ -1,0 +1,215 @@
+/* cache.c -- see cache.h */
+#include "cache.h"
+
+typedef struct
+{
+    Oid relid;
+    BlockNumber blockno;
+    bool pinned;     /* insert buffer: cannot be evicted */
+    uint64 ts;       /* 0 = free; otherwise last-use tick (LRU) */
+    uint32 nblocks;  /* PostgreSQL pages of the chain */
+    TransactionId xid;
+    BlockNumber *blocks;
+    char *data;      /* cryo_blcksz bytes */
+} Slot;
+
+static Slot *slots;
+static int nslots;
+static uint32 max_chain;
+static uint64 tick, n_hits, n_misses, n_codec_calls;
+
+void cryo_cache_shutdown(void)
+{
+    int i;
+    for (i = 0; i < nslots; i++) { free(slots[i].data); free(slots[i].blocks); }
+    free(slots);
+    slots = NULL;
+    nslots = 0;
+}
+
+int cryo_cache_configure(int n)
+{
+    const CryoCodecOps *ops = cryo_host_codec_ops();
+    Size worst = cryo_blcksz + cryo_blcksz / 255 + 16; /* >= either codec's bound */
+    int i;
+    if (ops) { Size a = ops->bound(COMP_LZ4, cryo_blcksz), b = ops->bound(COMP_ZSTD, cryo_blcksz); worst = a > b ? a : b; }
+    cryo_cache_shutdown();
+    if (n < 1) return -1;
+    slots = calloc((size_t)n, sizeof *slots);
+    if (!slots) return -1;
+    max_chain = (uint32)cryo_pages_needed(worst);
+    for (i = 0; i < n; i++) {
+        slots[i].data = malloc(cryo_blcksz);
+        slots[i].blocks = malloc(max_chain * sizeof(BlockNumber));
+        if (!slots[i].data || !slots[i].blocks) { nslots = i + 1; cryo_cache_shutdown(); return -1; }
+    }
+    nslots = n;
+    tick = n_hits = n_misses = n_codec_calls = 0;
+    return 0;
+}
+
+void cryo_init_cache(void) { (void)cryo_cache_configure(16); }
+
+static int find_slot(Oid relid, BlockNumber blockno)
+{
+    int i;
+    for (i = 0; i < nslots; i++)
+        if (slots[i].ts != 0 && slots[i].relid == relid && slots[i].blockno == blockno) return i;
+    return InvalidCacheEntry;
+}
+
+/* a free slot, else the least recently used unpinned one; InvalidCacheEntry if all pinned */
+static int allocate_slot(void)
+{
+    int i, victim = InvalidCacheEntry;
+    uint64 min_ts = ~(uint64)0;
+    for (i = 0; i < nslots; i++) {
+        if (slots[i].pinned) continue;
+        if (slots[i].ts == 0) return i;
+        if (slots[i].ts < min_ts) { min_ts = slots[i].ts; victim = i; }
+    }
+    if (victim != InvalidCacheEntry)
+        elog(DEBUG1, "pg_cryogen: evicted cache entry for (%u, %u)", slots[victim].relid, slots[victim].blockno);
+    return victim;
+}
+
+static CryoError load_blocks(CryoRel *rel, const BlockNumber *blocks, int k, CacheEntry *results, CryoError *errors)
+{
+    /* gather the chains of every missing block, then ONE decompress call per method */
+    const CryoCodecOps *ops = cryo_host_codec_ops();
+    char **comp = calloc((size_t)k, sizeof *comp);
+    uint32_t *csz = calloc((size_t)k, sizeof *csz);
+    int *slot_of = malloc((size_t)k * sizeof *slot_of);
+    CompressionMethod *meth = calloc((size_t)k, sizeof *meth);
+    CryoError first_err = CRYO_ERR_SUCCESS;
+    int i, m;
+    if (!comp || !csz || !slot_of || !meth) { free(comp); free(csz); free(slot_of); free(meth); return CRYO_ERR_CACHE_IS_FULL; }
+
+    for (i = 0; i < k; i++) {
+        int s;
+        slot_of[i] = InvalidCacheEntry;
+        errors[i] = CRYO_ERR_SUCCESS;
+        if (rel->ops->nblocks(rel->handle) <= blocks[i] || blocks[i] == CRYO_META_PAGE) {
+            errors[i] = CRYO_ERR_WRONG_STARTING_BLOCK; results[i] = InvalidCacheEntry; continue;
+        }
+        s = find_slot(rel->relid, blocks[i]);
+        if (s != InvalidCacheEntry) { n_hits++; slots[s].ts = ++tick; results[i] = s; continue; }
+        n_misses++;
+        s = allocate_slot();
+        if (s == InvalidCacheEntry) { errors[i] = CRYO_ERR_CACHE_IS_FULL; results[i] = InvalidCacheEntry; continue; }
+        {
+            Size cs = 0;
+            Slot *sl = &slots[s];
+            sl->nblocks = 0;
+            errors[i] = cryo_stage_read_chain(rel, blocks[i], &comp[i], &cs, &meth[i], &sl->xid, sl->blocks,
+                                              max_chain, &sl->nblocks);
+            if (errors[i] != CRYO_ERR_SUCCESS) { results[i] = InvalidCacheEntry; continue; }
+            csz[i] = (uint32_t)cs;
+            /* claim the slot now (pinned for the duration of the batch so a later miss cannot evict it) */
+            sl->relid = rel->relid; sl->blockno = blocks[i]; sl->ts = ++tick; sl->pinned = true;
+            slot_of[i] = s;
+            results[i] = s;
+        }
+    }
+    for (m = COMP_LZ4; m <= COMP_ZSTD; m++) {
+        int cnt = 0, j = 0;
+        for (i = 0; i < k; i++) if (slot_of[i] != InvalidCacheEntry && (int)meth[i] == m) cnt++;
+        if (!cnt) continue;
+        {
+            const void **srcs = malloc((size_t)cnt * sizeof *srcs);
+            uint32_t *sz = malloc((size_t)cnt * sizeof *sz);
+            int32_t *st = calloc((size_t)cnt, sizeof *st);
+            int *idx = malloc((size_t)cnt * sizeof *idx);
+            char *out = malloc((size_t)cnt * cryo_blcksz);
+            int rc = -1;
+            if (srcs && sz && st && idx && out && ops) {
+                for (i = 0; i < k; i++)
+                    if (slot_of[i] != InvalidCacheEntry && (int)meth[i] == m) { srcs[j] = comp[i]; sz[j] = csz[i]; idx[j] = i; j++; }
+                rc = ops->decompress_blocks(ops->ctx, m, srcs, sz, (size_t)cnt, out, cryo_blcksz, st);
+                n_codec_calls++;
+            }
+            for (j = 0; j < cnt; j++) {
+                const int bi = idx ? idx[j] : 0;
+                Slot *sl = &slots[slot_of[bi]];
+                if (rc == 0 && st[j] == 0) memcpy(sl->data, out + (size_t)j * cryo_blcksz, cryo_blcksz);
+                else { errors[bi] = CRYO_ERR_DECOMPRESSION_FAILED; results[bi] = InvalidCacheEntry; sl->ts = 0; }
+            }
+            free(srcs); free(sz); free(st); free(idx); free(out);
+        }
+    }
+    for (i = 0; i < k; i++) {
+        if (slot_of[i] != InvalidCacheEntry) slots[slot_of[i]].pinned = false;
+        free(comp[i]);
+        if (errors[i] != CRYO_ERR_SUCCESS && first_err == CRYO_ERR_SUCCESS) first_err = errors[i];
+    }
+    free(comp); free(csz); free(slot_of); free(meth);
+    return first_err;
+}
+
+CryoError cryo_read_data_batch(CryoRel *rel, const BlockNumber *blocks, int k, CacheEntry *results, CryoError *errors)
+{
+    if (k <= 0) return CRYO_ERR_SUCCESS;
+    return load_blocks(rel, blocks, k, results, errors);
+}
+
+CryoError cryo_read_data(CryoRel *rel, void *iter, BlockNumber block, CacheEntry *result)
+{
+    CryoError err = CRYO_ERR_SUCCESS;
+    (void)iter; /* the seq-scan iterator bookkeeping (cache.c:235-242,290-292) stays with the table AM */
+    *result = InvalidCacheEntry;
+    (void)load_blocks(rel, &block, 1, result, &err);
+    return err;
+}
+
+CacheEntry cryo_cache_allocate(CryoRel *rel, BlockNumber blockno)
+{
+    int s = find_slot(rel->relid, blockno);
+    if (s == InvalidCacheEntry) {
+        s = allocate_slot();
+        if (s == InvalidCacheEntry) {
+            elog(ERROR, "pg_cryogen: %s", cryo_cache_err(CRYO_ERR_CACHE_IS_FULL));
+            return InvalidCacheEntry;
+        }
+    }
+    slots[s].relid = rel->relid;
+    slots[s].blockno = blockno;
+    slots[s].ts = ++tick;
+    slots[s].pinned = true;
+    slots[s].nblocks = 0;
+    return s;
+}
+
+void cryo_cache_release(CacheEntry entry)
+{
+    if (entry < 0 || entry >= nslots) { elog(ERROR, "pg_cryogen: invalid cache entry"); return; }
+    if (!slots[entry].pinned) { elog(ERROR, "pg_cryogen: trying to release read-only cache entry"); return; }
+    slots[entry].ts = 0;
+    slots[entry].pinned = false;
+}
+
+void cryo_cache_invalidate_relation(Oid relid)
+{
+    int i;
+    for (i = 0; i < nslots; i++)
+        if (slots[i].relid == relid && !slots[i].pinned) slots[i].ts = 0;
+}
+
+uint32 cryo_cache_get_pg_nblocks(CacheEntry entry) { return slots[entry].nblocks; }
+char *cryo_cache_get_data(CacheEntry entry) { slots[entry].ts = ++tick; return slots[entry].data; }
+TransactionId cryo_cache_get_xid(CacheEntry entry) { return slots[entry].xid; }
+
+const char *cryo_cache_err(CryoError err)
+{
+    switch (err) {
+    case CRYO_ERR_SUCCESS: return "success";
+    case CRYO_ERR_WRONG_STARTING_BLOCK: return "wrong starting block number";
+    case CRYO_ERR_DECOMPRESSION_FAILED: return "decompression failed";
+    case CRYO_ERR_EMPTY_BLOCK: return "empty block";
+    case CRYO_ERR_CACHE_IS_FULL: return "cannot allocate cache slot; all slots are locked for modification";
+    default: return "unknown error";
+    }
+}
+
+uint64 cryo_cache_hits(void) { return n_hits; }
+uint64 cryo_cache_misses(void) { return n_misses; }
+uint64 cryo_cache_codec_calls(void) { return n_codec_calls; }

@@ -1,0 +1,158 @@
+/*
+ * compression.c -- cryo_compress / cryo_decompress over the MI355X codec C ABI.
+ *
+ * Mirrors reference compression.c:16-159: the three GUCs with the same names, ranges and
+ * defaults (compression.c:24-58), palloc(bound) output owned by the caller
+ * (pg_cryogen.c:826 pfrees it), elog(ERROR, "pg_cryogen: compression failed") on failure
+ * (compression.c:73-74,105-106), `false` from cryo_decompress on malformed input
+ * (compression.c:85-86,117-118), elog(ERROR) on an unknown method (compression.c:137,157).
+ * Differences, all invisible to valid data: a block that decodes to fewer than CRYO_BLCKSZ
+ * bytes returns false (the reference only Assert()s, compression.c:88,120).
+ *
+ * The GPU codec is opened lazily on first use, never in _PG_init: a library preloaded by the
+ * postmaster must not create a HIP context before fork().  The C ABI never
+ * longjmps; elog(ERROR) is raised here, in C, after the call returned.
+ */
+#include "compression.h"
+#include "cryo_codec.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+
+int compression_method_guc = COMP_ZSTD;
+int lz4_acceleration_guc = 1;
+int zstd_compression_level_guc = 1;
+int cryo_gpu_device_guc = 0;
+Size cryo_blcksz = (Size)1 << 20; /* CRYO_BLCKSZ, reference storage.h:18 */
+
+/* ---------------- codec binding ---------------- */
+static cryo_codec *hip_codec;
+static char codec_err[320];
+
+static size_t hip_bound(int method, size_t n) { return cryo_codec_bound(method, n); }
+static int hip_compress_blocks(void *ctx, int method, int param, const void *src, size_t bs, size_t n, void *dst,
+                               size_t stride, uint32_t *out)
+{
+    return cryo_codec_compress_blocks((cryo_codec *)ctx, method, param, src, bs, n, dst, stride, out);
+}
+static int hip_decompress_blocks(void *ctx, int method, const void *const *src, const uint32_t *sz, size_t n,
+                                 void *dst, size_t bs, int32_t *st)
+{
+    return cryo_codec_decompress_blocks((cryo_codec *)ctx, method, src, sz, n, dst, bs, st);
+}
+
+static CryoCodecOps hip_ops = {hip_bound, hip_compress_blocks, hip_decompress_blocks, NULL};
+static const CryoCodecOps *bound_ops; /* test double, if any */
+
+void cryo_host_set_codec_ops(const CryoCodecOps *ops) { bound_ops = ops; }
+const char *cryo_host_codec_error(void) { return codec_err; }
+
+const CryoCodecOps *cryo_host_codec_ops(void)
+{
+    if (bound_ops) return bound_ops;
+    if (!hip_codec) {
+        int rc = cryo_codec_open(cryo_gpu_device_guc, &hip_codec);
+        if (rc != CRYO_OK) {
+            snprintf(codec_err, sizeof codec_err, "cryo_codec_open(%d) failed with %d (no CPU fallback)",
+                     cryo_gpu_device_guc, rc);
+            hip_codec = NULL;
+            return NULL;
+        }
+        hip_ops.ctx = hip_codec;
+    }
+    return &hip_ops;
+}
+
+/* ---------------- GUCs ---------------- */
+void cryo_define_compression_gucs(void)
+{
+#ifdef CRYO_HAVE_POSTGRES
+    static const struct config_enum_entry compression_method_options[] = {
+        {"lz4", COMP_LZ4, false}, {"zstd", COMP_ZSTD, false}, {NULL, 0, false}};
+    DefineCustomEnumVariable("pg_cryogen.compression_method", "Possible values are lz4 and zstd.", NULL,
+                             &compression_method_guc, COMP_ZSTD, compression_method_options, PGC_USERSET, 0,
+                             NULL, NULL, NULL);
+    DefineCustomIntVariable("pg_cryogen.lz4_acceleration", "Sets lz4 acceleration.", NULL,
+                            &lz4_acceleration_guc, 1, 0, 50, PGC_USERSET, 0, NULL, NULL, NULL);
+    DefineCustomIntVariable("pg_cryogen.zstd_compression_level", "Sets zstd compression level.", NULL,
+                            &zstd_compression_level_guc, 1, -5, 22, PGC_USERSET, 0, NULL, NULL, NULL);
+    DefineCustomIntVariable("pg_cryogen.gpu_device", "GPU used by this backend.", NULL, &cryo_gpu_device_guc, 0,
+                            0, 63, PGC_USERSET, 0, NULL, NULL, NULL);
+#else
+    /* no GUC machinery without PostgreSQL: the variables keep the reference's defaults */
+    compression_method_guc = COMP_ZSTD;
+    lz4_acceleration_guc = 1;
+    zstd_compression_level_guc = 1;
+#endif
+}
+
+/* ---------------- the two calls ---------------- */
+static int method_param(CompressionMethod method)
+{
+    return method == COMP_LZ4 ? lz4_acceleration_guc : zstd_compression_level_guc;
+}
+
+char *cryo_compress(CompressionMethod method, const char *data, Size *compressed_size)
+{
+    const CryoCodecOps *ops;
+    Size estimate;
+    char *compressed;
+    uint32_t csize = 0;
+    int rc;
+
+    if (method != COMP_LZ4 && method != COMP_ZSTD)
+        elog(ERROR, "pg_cryogen: unknown compression method");
+    ops = cryo_host_codec_ops();
+    if (!ops)
+        elog(ERROR, "pg_cryogen: compression failed (%s)", codec_err);
+    estimate = ops->bound((int)method, cryo_blcksz);
+    compressed = palloc(estimate);
+    rc = ops->compress_blocks(ops->ctx, (int)method, method_param(method), data, cryo_blcksz, 1, compressed,
+                              estimate, &csize);
+    if (rc != 0 || csize == 0) {
+        pfree(compressed);
+        elog(ERROR, "pg_cryogen: compression failed");
+        return NULL;
+    }
+    *compressed_size = csize;
+    return compressed;
+}
+
+bool cryo_decompress(CompressionMethod method, const char *compressed, Size compressed_size, char *out)
+{
+    const CryoCodecOps *ops;
+    const void *srcs[1];
+    uint32_t sizes[1];
+    int32_t status[1] = {0};
+    int rc;
+
+    if (method != COMP_LZ4 && method != COMP_ZSTD)
+        elog(ERROR, "pg_cryogen: unknown compression method");
+    if (compressed_size == 0 || compressed_size > 0xFFFFFFFFu)
+        return false;
+    ops = cryo_host_codec_ops();
+    if (!ops)
+        elog(ERROR, "pg_cryogen: decompression unavailable (%s)", codec_err);
+    srcs[0] = compressed;
+    sizes[0] = (uint32_t)compressed_size;
+    rc = ops->decompress_blocks(ops->ctx, (int)method, srcs, sizes, 1, out, cryo_blcksz, status);
+    if (rc != 0)
+        elog(ERROR, "pg_cryogen: decompression failed to run (%d)", rc);
+    return status[0] == 0;
+}
+
+#ifndef CRYO_HAVE_POSTGRES
+/* ---------------- pg_compat: elog ---------------- */
+static cryo_error_handler err_handler;
+void cryo_compat_set_error_handler(cryo_error_handler h) { err_handler = h; }
+void cryo_compat_elog(int elevel, const char *fmt, ...)
+{
+    char msg[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(msg, sizeof msg, fmt, ap);
+    va_end(ap);
+    if (err_handler) { err_handler(elevel, msg); return; }
+    if (elevel >= ERROR) { fprintf(stderr, "ERROR: %s\n", msg); abort(); }
+}
+#endif

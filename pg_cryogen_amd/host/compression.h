@@ -1,0 +1,60 @@
+/*
+ * compression.h -- host-side mirror of the reference's codec boundary
+ * (reference compression.h:7-24): same type, same three GUC variables, same three
+ * functions with the same argument meaning, ownership and error behaviour
+ * (SURVEY.md section 8b).  pg_cryogen.c:726 and cache.c:178 call it unchanged.
+ *
+ * Underneath, instead of liblz4/libzstd, it drives the MI355X codec through the C ABI
+ * (include/cryo_codec.h).
+ */
+#ifndef __COMPRESSION_H__
+#define __COMPRESSION_H__
+
+#ifdef CRYO_HAVE_POSTGRES
+#include "postgres.h"
+#else
+#include "pg_compat.h"
+#endif
+
+typedef enum
+{
+    COMP_LZ4 = 0,
+    COMP_ZSTD
+} CompressionMethod;
+
+extern int compression_method_guc;
+extern int lz4_acceleration_guc;
+extern int zstd_compression_level_guc;
+
+extern char *cryo_compress(CompressionMethod method,
+                           const char *data,
+                           Size *compressed_size);
+extern bool cryo_decompress(CompressionMethod method,
+                            const char *compressed,
+                            Size compressed_size,
+                            char *out);
+extern void cryo_define_compression_gucs(void);
+
+/* ---- additions (not in the reference) ---- */
+
+/* the reference hard-codes CRYO_BLCKSZ = 1 MiB (storage.h:18); here it is a run-time value
+ * with the same default so the benchmark's 128 KiB blocks use the same code */
+extern Size cryo_blcksz;
+/* GPU used by this backend (additive GUC pg_cryogen.gpu_device, default 0) */
+extern int cryo_gpu_device_guc;
+
+/* the codec entry points the host side calls; production binds them to libcryo_codec.so
+ * (include/cryo_codec.h), CPU-only plumbing tests may bind a test double */
+typedef struct CryoCodecOps {
+    size_t (*bound)(int method, size_t block_size);
+    int (*compress_blocks)(void *ctx, int method, int param, const void *src, size_t block_size, size_t n,
+                           void *dst, size_t dst_stride, uint32_t *out_size);
+    int (*decompress_blocks)(void *ctx, int method, const void *const *src, const uint32_t *src_size, size_t n,
+                             void *dst, size_t block_size, int32_t *status);
+    void *ctx;
+} CryoCodecOps;
+void cryo_host_set_codec_ops(const CryoCodecOps *ops); /* NULL restores the HIP binding */
+const CryoCodecOps *cryo_host_codec_ops(void);         /* lazily opens the GPU codec */
+const char *cryo_host_codec_error(void);
+
+#endif /* __COMPRESSION_H__ */
