@@ -19,7 +19,6 @@ import ctypes
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -40,69 +39,50 @@ def parse_args():
     ap.add_argument("--block-size", type=int, default=131072)
     ap.add_argument("--dist", default="wide", choices=["wide", "narrow", "int4", "random", "zeros"])
     ap.add_argument("--accel", type=int, default=1, help="lz4 acceleration used to produce the inputs")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="diagnostic ablation runs only: result is not valid")
     return ap.parse_args()
 
 
-def cpu_baseline(comps, B, budget_s):
-    """Time the CPU oracle (kind 'port', 1 thread) and, if present, the stock liblz4 the
-    reference links (compression.c:84 call shape) on the same sample of compressed blocks."""
+def cpu_baseline(comps, B, budget_s, method=0):
+    """cpu_baseline leg: the oracle ("port", 1 thread) and -- reported beside it -- the stock library the
+    reference links (reference compression.c:84/116 call shape), 1 thread and all cores, timed by
+    oracle/cpu_bench.c on this machine's host cores over the same sample of compressed blocks."""
     import oracle_lib
     ora = oracle_lib.Oracle()
-    out = np.empty(B, np.uint8)
-    fn = ora.L.cryo_oracle_lz4_decompress
-    ptrs = [(c.ctypes.data, c.nbytes) for c in comps]
-    # oracle, single thread, bounded by budget/2
-    t0 = time.perf_counter()
-    done = 0
-    reps = 0
-    while True:
-        for p, n in ptrs:
-            r = fn(p, n, out.ctypes.data, B)
-            assert r == B
-        done += len(ptrs)
-        reps += 1
-        if time.perf_counter() - t0 > budget_s * 0.5:
-            break
-    dt = time.perf_counter() - t0
-    res = {"value": round(done * B / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
-           "sample": "%d distinct compressed blocks x %d passes (%.1f s), oracle/lz4_oracle.c decoder, 1 thread"
-                     % (len(ptrs), reps, dt)}
-    stock = oracle_lib.StockLibs()
-    if stock.lz4 is not None:
-        f = stock.lz4.LZ4_decompress_safe
-        t0 = time.perf_counter()
-        done = 0
-        while time.perf_counter() - t0 < budget_s * 0.2:
-            for p, n in ptrs:
-                f(p, out.ctypes.data, n, B)
-            done += len(ptrs)
-        dt1 = time.perf_counter() - t0
-        one = done * B / dt1 / 1e9
-        # all cores: thread t decodes blocks i = t mod T into a private buffer (ctypes drops the GIL)
-        T = max(1, min(os.cpu_count() or 1, 64))
-        counts = [0] * T
-        stop_at = time.perf_counter() + budget_s * 0.3
+    fn = ora.L.cryo_oracle_cpu_decode_bench
+    fn.restype = ctypes.c_double
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
+                   ctypes.c_uint32, ctypes.c_int, ctypes.c_double, ctypes.c_char_p, ctypes.c_size_t]
+    offs = np.zeros(len(comps), np.uint64)
+    pos = 0
+    for i, c in enumerate(comps):
+        offs[i] = pos
+        pos += (len(c) + 63) & ~63
+    packed = np.zeros(pos + 64, np.uint8)
+    for i, c in enumerate(comps):
+        packed[int(offs[i]):int(offs[i]) + len(c)] = c
+    sizes = np.array([len(c) for c in comps], np.uint32)
+    ver = ctypes.create_string_buffer(64)
 
-        def work(t):
-            o = np.empty(B, np.uint8)
-            mine = ptrs[t::T] or ptrs
-            k = 0
-            while time.perf_counter() < stop_at:
-                for p, n in mine:
-                    f(p, o.ctypes.data, n, B)
-                k += len(mine)
-            counts[t] = k
-        t0 = time.perf_counter()
-        th = [threading.Thread(target=work, args=(t,)) for t in range(T)]
-        [x.start() for x in th]
-        [x.join() for x in th]
-        dtT = time.perf_counter() - t0
-        res["stock_liblz4"] = {"version": stock.lz4_version, "call": "LZ4_decompress_safe(src,dst,csize,B)",
-                               "GBps_1_thread": round(one, 3),
-                               "GBps_%d_threads" % T: round(sum(counts) * B / dtT / 1e9, 3), "threads": T}
+    def run(stock, threads, secs):
+        return fn(method, stock, packed.ctypes.data, offs.ctypes.data, sizes.ctypes.data, len(comps), B, threads,
+                  secs, ver, 64)
+    name = "lz4" if method == 0 else "zstd"
+    v = run(0, 1, budget_s * 0.4)
+    res = {"value": round(v, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+           "sample": "%d distinct compressed blocks (%.1f MiB uncompressed) decoded repeatedly for %.1f s by "
+                     "oracle/%s, 1 thread" % (len(comps), len(comps) * B / 2**20, budget_s * 0.4,
+                                              "lz4_oracle.c" if method == 0 else "zstd_dec_oracle.c")}
+    T = os.cpu_count() or 1
+    one = run(1, 1, budget_s * 0.25)
+    if one > 0:
+        allc = run(1, T, budget_s * 0.35)
+        res["stock_lib%s" % name] = {"version": ver.value.decode(),
+                                     "call": "LZ4_decompress_safe(src,dst,csize,B)" if method == 0
+                                     else "ZSTD_decompress(dst,B,src,csize)",
+                                     "GBps_1_thread": round(one, 3), "GBps_all_threads": round(allc, 3), "threads": T}
     return res
 
 
@@ -145,11 +125,10 @@ def main():
     d_sizes, d_status = codec.alloc(4 * n), codec.alloc(4 * n)
     d_off = codec.alloc(8 * n)
     d_mis = codec.alloc(8)
-    # block i of the job lives on rank i mod N: this rank's k-th block is job block k*N + rank.
-    # (the generator takes a contiguous index range, so rank r uses indices [r*n, (r+1)*n) of seed 0;
-    #  all blocks of the job are distinct either way)
-    first = rank * n
-    codec.synth_batch(0, first, n, B, dist_id, d_raw)
+    # block i of the job lives on rank i mod N: this rank's k-th block is job block rank + k*N
+    # (pg_cryogen_amd/shard.py); every block of the job is distinct
+    job_block = lambda k: rank + k * world
+    codec.synth_batch(0, rank, n, B, dist_id, d_raw, block_step=world)
     codec.timer_start()
     codec.compress_batch(METHOD_LZ4, a.accel, d_raw, B, B, n, d_comp, stride, d_sizes, d_status)
     enc_ms = codec.timer_stop()
@@ -165,10 +144,13 @@ def main():
     sample_comps = []
     for i in sample_idx:
         c = d_comp.download(int(sizes[i]), offset=i * stride)
-        raw = ora.synth(0, first + i, B, dist_id)
+        raw = ora.synth(0, job_block(i), B, dist_id)
         exp = ora.lz4_compress(raw, a.accel)
         assert np.array_equal(c, exp), "device lz4 encode differs from oracle at block %d" % i
         sample_comps.append(c)
+    # cpu_baseline sample: 512 device-encoded blocks (64 MiB uncompressed), enough for every host thread
+    cpu_idx = list(range(0, n, max(1, n // 512)))[:512]
+    cpu_comps = [d_comp.download(int(sizes[i]), offset=i * stride) for i in cpu_idx] if (world == 1 and not a.no_cpu_baseline) else []
 
     def step():
         codec.decompress_batch(METHOD_LZ4, d_comp, d_off, d_sizes, d_out, B, B, n, d_status)
@@ -227,7 +209,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sample_comps, B, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(cpu_comps, B, a.cpu_seconds)
         print(json.dumps(out), flush=True)
 
     for b in (d_raw, d_comp, d_out, d_sizes, d_status, d_off, d_mis):

@@ -141,9 +141,10 @@ int cryo_codec_decompress_blocks(cryo_codec *c, int method,
 
 /* ---- batch helpers used by staging, tests and the benchmark ---- */
 
-/* synthetic cryo blocks (include/cryo_synth.h) first_block .. first_block+n-1, on device */
-int cryo_codec_synth_batch(cryo_codec *c, uint64_t seed, uint64_t first_block, uint64_t n_blocks,
-                           uint32_t block_size, int dist, void *d_dst, uint64_t dst_stride);
+/* synthetic cryo blocks (include/cryo_synth.h) on device: slot k holds job block
+ * first_block + k*block_step (block_step = N, first_block = rank gives rank's round-robin share) */
+int cryo_codec_synth_batch(cryo_codec *c, uint64_t seed, uint64_t first_block, uint64_t block_step,
+                           uint64_t n_blocks, uint32_t block_size, int dist, void *d_dst, uint64_t dst_stride);
 /* per-block 64-bit checksum (same function as cryo_checksum64() below) */
 int cryo_codec_checksum_batch(cryo_codec *c, const void *d_src, uint64_t src_stride,
                               const uint32_t *d_sizes /* or NULL: fixed_size */, uint32_t fixed_size,

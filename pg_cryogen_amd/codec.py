@@ -80,7 +80,7 @@ def lib():
     L.cryo_codec_decompress_block.argtypes = [vp, i32, vp, sz, vp, sz]
     L.cryo_codec_compress_blocks.argtypes = [vp, i32, i32, vp, sz, sz, vp, sz, vp]
     L.cryo_codec_decompress_blocks.argtypes = [vp, i32, vp, vp, sz, vp, sz, vp]
-    L.cryo_codec_synth_batch.argtypes = [vp, u64, u64, u64, u32, i32, vp, u64]
+    L.cryo_codec_synth_batch.argtypes = [vp, u64, u64, u64, u64, u32, i32, vp, u64]
     L.cryo_codec_checksum_batch.argtypes = [vp, vp, u64, vp, u32, u64, vp]
     L.cryo_codec_compare_batch.argtypes = [vp, vp, u64, vp, u64, u32, u64, vp]
     L.cryo_checksum64.argtypes = [vp, sz]
@@ -190,9 +190,10 @@ class Codec:
         return {f: getattr(c, f) for f, _ in Counters._fields_}
 
     # -- device-resident batches (async on the handle's stream) --
-    def synth_batch(self, seed, first_block, n, block_size, dist, d_dst, stride=None):
+    def synth_batch(self, seed, first_block, n, block_size, dist, d_dst, stride=None, block_step=1):
         stride = block_size if stride is None else stride
-        self._chk(self.L.cryo_codec_synth_batch(self.h, seed, first_block, n, block_size, dist, d_dst.ptr, stride),
+        self._chk(self.L.cryo_codec_synth_batch(self.h, seed, first_block, block_step, n, block_size, dist,
+                                                d_dst.ptr, stride),
                   "synth_batch")
 
     def compress_batch(self, method, param, d_src, src_stride, block_size, n, d_dst, dst_stride, d_sizes, d_status):

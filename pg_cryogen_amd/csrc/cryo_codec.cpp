@@ -396,13 +396,13 @@ int cryo_codec_decompress_blocks(cryo_codec *c, int method, const void *const *h
 }
 
 /* ---- helpers ---- */
-int cryo_codec_synth_batch(cryo_codec *c, uint64_t seed, uint64_t first_block, uint64_t n_blocks,
-                           uint32_t block_size, int dist, void *d_dst, uint64_t dst_stride)
+int cryo_codec_synth_batch(cryo_codec *c, uint64_t seed, uint64_t first_block, uint64_t block_step,
+                           uint64_t n_blocks, uint32_t block_size, int dist, void *d_dst, uint64_t dst_stride)
 {
     if (!c || block_size < 64 || dist < 0 || dist > 4) return CRYO_E_ARG;
     if (n_blocks == 0) return CRYO_OK;
     if (!d_dst || dst_stride < block_size) return CRYO_E_ARG;
-    HIP_TRY(c, cryo::launch_synth(c->stream, seed, first_block, n_blocks, block_size, dist,
+    HIP_TRY(c, cryo::launch_synth(c->stream, seed, first_block, block_step ? block_step : 1, n_blocks, block_size, dist,
                                   (uint8_t *)d_dst, dst_stride));
     c->ctr.launches++;
     return CRYO_OK;

@@ -12,7 +12,7 @@
 namespace cryo {
 
 /* synthetic cryo blocks, include/cryo_synth.h */
-hipError_t launch_synth(hipStream_t s, uint64_t seed, uint64_t first_block, uint64_t n_blocks,
+hipError_t launch_synth(hipStream_t s, uint64_t seed, uint64_t first_block, uint64_t block_step, uint64_t n_blocks,
                         uint32_t block_size, int dist, uint8_t *d_dst, uint64_t dst_stride);
 
 hipError_t launch_checksum(hipStream_t s, const uint8_t *d_src, uint64_t src_stride,

@@ -12,7 +12,7 @@ namespace cryo {
 
 /* ---------------- synthetic blocks ---------------- */
 __global__ void __launch_bounds__(256)
-k_synth(uint64_t seed, uint64_t first_block, uint64_t n_blocks, uint32_t B, int dist,
+k_synth(uint64_t seed, uint64_t first_block, uint64_t block_step, uint64_t n_blocks, uint32_t B, int dist,
         uint8_t *__restrict__ dst, uint64_t dst_stride, uint32_t chunks_per_block)
 {
     const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -22,7 +22,7 @@ k_synth(uint64_t seed, uint64_t first_block, uint64_t n_blocks, uint32_t B, int 
     const uint32_t off0 = chunk * 16u;
     const cryo_synth_geom g = cryo_synth_geometry(B, dist);
     uint8_t *out = dst + blk * dst_stride;
-    const uint64_t bi = first_block + blk;
+    const uint64_t bi = first_block + blk * block_step;
     if (off0 + 16u <= B && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0)) {
         uint32_t w[4];
 #pragma unroll
@@ -40,7 +40,7 @@ k_synth(uint64_t seed, uint64_t first_block, uint64_t n_blocks, uint32_t B, int 
     }
 }
 
-hipError_t launch_synth(hipStream_t s, uint64_t seed, uint64_t first_block, uint64_t n_blocks,
+hipError_t launch_synth(hipStream_t s, uint64_t seed, uint64_t first_block, uint64_t block_step, uint64_t n_blocks,
                         uint32_t block_size, int dist, uint8_t *d_dst, uint64_t dst_stride)
 {
     if (n_blocks == 0 || block_size == 0) return hipSuccess;
@@ -48,7 +48,7 @@ hipError_t launch_synth(hipStream_t s, uint64_t seed, uint64_t first_block, uint
     const uint64_t threads = n_blocks * cpb;
     const uint64_t grid = (threads + 255) / 256;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_synth, dim3((uint32_t)grid), dim3(256), 0, s, seed, first_block, n_blocks,
+    hipLaunchKernelGGL(k_synth, dim3((uint32_t)grid), dim3(256), 0, s, seed, first_block, block_step, n_blocks,
                        block_size, dist, d_dst, dst_stride, cpb);
     return hipGetLastError();
 }
