@@ -191,6 +191,18 @@ def main():
         avg_ms = float(np.mean(kernel_ms))
         algo_bytes = comp_bytes + n * B        # per launch: compressed bytes read + B written per block
         achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+        traffic = None   # HBM bytes per launch from the PMC passes of the same workload (profiles/)
+        try:
+            for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+                if fn.endswith("_hbm_traffic.json"):
+                    t = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                    wl = t.get("workload", {})
+                    if (wl.get("blocks_per_gpu"), wl.get("block_size"), wl.get("distribution"),
+                            wl.get("lz4_acceleration")) == (n, B, a.dist, a.accel):
+                        traffic = t["traffic_bytes_per_launch"]
+                        break
+        except OSError:
+            pass
         out = {
             "metric": "lz4_decompress_uncompressed_GBps", "value": round(value, 2), "unit": "GB/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -204,7 +216,7 @@ def main():
                                     % (len(sample_idx), n),
                        "setup_lz4_encode_GBps": round(n * B / (enc_ms * 1e-3) / 1e9, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "kernel": "k_lz4_dec", "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
