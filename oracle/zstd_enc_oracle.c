@@ -1,0 +1,953 @@
+/*
+ * zstd_enc_oracle.c -- CPU ORACLE (test infrastructure, see cryo_oracle.h).
+ *
+ * Restates ZSTD_compress(dst, ZSTD_compressBound(B), src, B, level) as libzstd 1.4.8 runs it
+ * for the reference's call shape (compression.c:102-104), for the levels whose strategy is
+ * `fast` (levels -5 .. 2 at cryo block sizes; the reference's default
+ * level 1 is one of them).  Output bytes are identical to the library's; pinned by
+ * tests/golden/vectors.json (libzstd 1.4.8 == 1.4.9) and by a live differential test.
+ *
+ * Pipeline restated (all integer arithmetic):
+ *   parameters by level and size -> frame header -> per 128 KiB block:
+ *     greedy 2-position hash-table match finder with repeat-offset checks ("fast" strategy)
+ *     -> sequences (literal length, match length, offset code) + literal bytes
+ *     -> literals: raw / RLE / Huffman (length-limited tree, FSE-compressed or raw weights,
+ *        1 or 4 backward bitstreams), with the library's "worth it" heuristics
+ *     -> sequences: per-field encoding type (predefined / RLE / FSE) by the `fast`-strategy
+ *        heuristic, FSE table normalisation + description, interleaved backward bitstream
+ *     -> raw block fallback when the gain is below srcSize/64 + 2; RLE block for constant
+ *        non-first blocks
+ */
+#include "cryo_oracle.h"
+#include <string.h>
+
+#define ZBLOCK_MAX (128u * 1024u)
+#define MINMATCH 3
+#define REP_MOVE 2
+#define HASH_READ 8
+#define MaxLL 35
+#define MaxML 52
+#define MaxOff 31
+#define DefaultMaxOff 28
+#define LLFSELog 9
+#define MLFSELog 9
+#define OffFSELog 8
+#define HUF_LOG_MAX 12
+#define HUF_LOG_DEFAULT 11
+
+static int hb(uint32_t v) { int r = 0; while (v >>= 1) r++; return r; }
+static uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+static uint64_t rd64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+/* ------------------------------------------------------------ forward LSB-first bit writer */
+typedef struct { uint8_t *p; uint64_t acc; int n; size_t len; } bitw;
+static void bw_init(bitw *b, uint8_t *p) { b->p = p; b->acc = 0; b->n = 0; b->len = 0; }
+static void bw_add(bitw *b, uint64_t v, int nb)
+{
+    if (nb == 0) return;
+    b->acc |= (v & ((nb >= 64) ? ~0ull : ((1ull << nb) - 1))) << b->n;
+    b->n += nb;
+    while (b->n >= 8) { b->p[b->len++] = (uint8_t)b->acc; b->acc >>= 8; b->n -= 8; }
+}
+/* end mark + padding, as BIT_closeCStream */
+static size_t bw_close(bitw *b)
+{
+    bw_add(b, 1, 1);
+    if (b->n > 0) { b->p[b->len++] = (uint8_t)b->acc; b->n = 0; b->acc = 0; }
+    return b->len;
+}
+/* flush without end mark (FSE table descriptions) */
+static size_t bw_flush(bitw *b)
+{
+    if (b->n > 0) { b->p[b->len++] = (uint8_t)b->acc; b->n = 0; b->acc = 0; }
+    return b->len;
+}
+
+/* ------------------------------------------------------------ FSE (compression side) */
+typedef struct { int delta_find; uint32_t delta_nb; } fse_sym;
+typedef struct {
+    int log;
+    uint16_t state[1 << 9];   /* table sizes here are <= 512 */
+    fse_sym sym[256];
+} fse_ct;
+
+static int fse_min_log(size_t n, uint32_t max_sym)
+{
+    int a = hb((uint32_t)n) + 1, b = hb(max_sym) + 2;
+    return a < b ? a : b;
+}
+static int fse_optimal_log(int max_log, size_t n, uint32_t max_sym, int minus)
+{
+    int max_src = hb((uint32_t)(n - 1)) - minus;
+    int log = max_log, min_bits = fse_min_log(n, max_sym);
+    if (log == 0) log = 11;
+    if (max_src < log) log = max_src;
+    if (min_bits > log) log = min_bits;
+    if (log < 5) log = 5;
+    if (log > 12) log = 12;
+    return log;
+}
+
+/* secondary normalisation (rare corner case of FSE_normalizeCount) */
+static int fse_norm_m2(int16_t *norm, int log, const uint32_t *count, size_t total, uint32_t max_sym, int16_t low_prob)
+{
+    const int16_t NYA = -2;
+    uint32_t s, distributed = 0, to_dist;
+    const uint32_t low_thr = (uint32_t)(total >> log);
+    uint32_t low_one = (uint32_t)((total * 3) >> (log + 1));
+    for (s = 0; s <= max_sym; s++) {
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= low_thr) { norm[s] = low_prob; distributed++; total -= count[s]; continue; }
+        if (count[s] <= low_one) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+        norm[s] = NYA;
+    }
+    to_dist = (1u << log) - distributed;
+    if (to_dist == 0) return 0;
+    if ((total / to_dist) > low_one) {
+        low_one = (uint32_t)((total * 3) / (to_dist * 2));
+        for (s = 0; s <= max_sym; s++)
+            if (norm[s] == NYA && count[s] <= low_one) { norm[s] = 1; distributed++; total -= count[s]; }
+        to_dist = (1u << log) - distributed;
+    }
+    if (distributed == max_sym + 1) {
+        uint32_t mv = 0, mc = 0;
+        for (s = 0; s <= max_sym; s++) if (count[s] > mc) { mv = s; mc = count[s]; }
+        norm[mv] += (int16_t)to_dist;
+        return 0;
+    }
+    if (total == 0) {
+        for (s = 0; to_dist > 0; s = (s + 1) % (max_sym + 1)) if (norm[s] > 0) { to_dist--; norm[s]++; }
+        return 0;
+    }
+    {
+        const uint64_t vlog = 62 - (uint64_t)log, mid = (1ull << (vlog - 1)) - 1;
+        const uint64_t rstep = (((1ull << vlog) * to_dist) + mid) / total;
+        uint64_t tmp = mid;
+        for (s = 0; s <= max_sym; s++) {
+            if (norm[s] == NYA) {
+                const uint64_t end = tmp + (uint64_t)count[s] * rstep;
+                const uint32_t w = (uint32_t)(end >> vlog) - (uint32_t)(tmp >> vlog);
+                if (w < 1) return -1;
+                norm[s] = (int16_t)w;
+                tmp = end;
+            }
+        }
+    }
+    return 0;
+}
+
+/* FSE_normalizeCount; returns table log, 0 for the RLE special case, <0 on error.
+ * use_low_prob: symbols at or below total >> log get the "less than one" probability -1
+ * (sequence tables with >= 2048 sequences) or a plain 1 (Huffman weights, short sequence tables) */
+static int fse_normalize(int16_t *norm, int log, const uint32_t *count, size_t total, uint32_t max_sym, int use_low_prob)
+{
+    const int16_t low_prob = use_low_prob ? -1 : 1;
+    static const uint32_t rtb[] = {0, 473195, 504333, 520860, 550000, 700000, 750000, 830000};
+    const uint64_t scale = 62 - (uint64_t)log, step = (1ull << 62) / total, vstep = 1ull << (scale - 20);
+    int still = 1 << log;
+    uint32_t s, largest = 0;
+    int16_t largest_p = 0;
+    const uint32_t low_thr = (uint32_t)(total >> log);
+    if (log < fse_min_log(total, max_sym)) return -1;
+    for (s = 0; s <= max_sym; s++) {
+        if (count[s] == total) return 0;
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= low_thr) { norm[s] = low_prob; still--; }
+        else {
+            int16_t proba = (int16_t)(((uint64_t)count[s] * step) >> scale);
+            if (proba < 8) {
+                const uint64_t rest = vstep * rtb[proba];
+                proba += ((uint64_t)count[s] * step) - ((uint64_t)proba << scale) > rest;
+            }
+            if (proba > largest_p) { largest_p = proba; largest = s; }
+            norm[s] = proba;
+            still -= proba;
+        }
+    }
+    if (-still >= (norm[largest] >> 1)) { if (fse_norm_m2(norm, log, count, total, max_sym, low_prob)) return -1; }
+    else norm[largest] += (int16_t)still;
+    return log;
+}
+
+/* FSE_writeNCount; returns bytes written */
+static size_t fse_write_ncount(uint8_t *dst, const int16_t *norm, uint32_t max_sym, int log)
+{
+    bitw b;
+    const int table_size = 1 << log;
+    int remaining = table_size + 1, threshold = table_size, nb = log + 1, prev0 = 0;
+    uint32_t sym = 0;
+    const uint32_t alpha = max_sym + 1;
+    bw_init(&b, dst);
+    bw_add(&b, (uint64_t)(log - 5), 4);
+    while (sym < alpha && remaining > 1) {
+        if (prev0) {
+            uint32_t start = sym;
+            while (sym < alpha && !norm[sym]) sym++;
+            if (sym == alpha) break;
+            while (sym >= start + 24) { start += 24; bw_add(&b, 0xFFFF, 16); }
+            while (sym >= start + 3) { start += 3; bw_add(&b, 3, 2); }
+            bw_add(&b, sym - start, 2);
+        }
+        {
+            int count = norm[sym++];
+            const int max = (2 * threshold - 1) - remaining;
+            remaining -= count < 0 ? -count : count;
+            count++;
+            if (count >= threshold) count += max;
+            bw_add(&b, (uint64_t)count, nb - (count < max));
+            prev0 = (count == 1);
+            if (remaining < 1) return 0;
+            while (remaining < threshold) { nb--; threshold >>= 1; }
+        }
+    }
+    if (remaining != 1) return 0;
+    return bw_flush(&b);
+}
+
+static void fse_build_ct(fse_ct *ct, const int16_t *norm, uint32_t max_sym, int log)
+{
+    const uint32_t size = 1u << log, mask = size - 1, step = (size >> 1) + (size >> 3) + 3;
+    uint8_t cell[1 << 9];
+    uint32_t cumul[258];
+    uint32_t high = size - 1, pos = 0, u;
+    ct->log = log;
+    cumul[0] = 0;
+    for (u = 1; u <= max_sym + 1; u++) {
+        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; cell[high--] = (uint8_t)(u - 1); }
+        else cumul[u] = cumul[u - 1] + (uint32_t)norm[u - 1];
+    }
+    cumul[max_sym + 1] = size + 1;
+    for (u = 0; u <= max_sym; u++) {
+        int i;
+        for (i = 0; i < norm[u]; i++) {
+            cell[pos] = (uint8_t)u;
+            pos = (pos + step) & mask;
+            while (pos > high) pos = (pos + step) & mask;
+        }
+    }
+    for (u = 0; u < size; u++) { const uint8_t s = cell[u]; ct->state[cumul[s]++] = (uint16_t)(size + u); }
+    {
+        uint32_t total = 0, s;
+        for (s = 0; s <= max_sym; s++) {
+            switch (norm[s]) {
+            case 0: ct->sym[s].delta_nb = ((uint32_t)(log + 1) << 16) - (1u << log); ct->sym[s].delta_find = 0; break;
+            case -1:
+            case 1:
+                ct->sym[s].delta_nb = ((uint32_t)log << 16) - (1u << log);
+                ct->sym[s].delta_find = (int)total - 1;
+                total++;
+                break;
+            default: {
+                const uint32_t max_out = (uint32_t)log - (uint32_t)hb((uint32_t)norm[s] - 1);
+                const uint32_t min_plus = (uint32_t)norm[s] << max_out;
+                ct->sym[s].delta_nb = (max_out << 16) - min_plus;
+                ct->sym[s].delta_find = (int)total - norm[s];
+                total += (uint32_t)norm[s];
+            }
+            }
+        }
+    }
+}
+static void fse_build_ct_rle(fse_ct *ct, uint32_t sym)
+{
+    ct->log = 0;
+    ct->state[0] = 0; ct->state[1] = 0;
+    ct->sym[sym].delta_nb = 0; ct->sym[sym].delta_find = 0;
+}
+static uint32_t fse_init_state(const fse_ct *ct, uint32_t sym)
+{
+    const fse_sym t = ct->sym[sym];
+    const uint32_t nb = (t.delta_nb + (1u << 15)) >> 16;
+    const uint32_t v = (nb << 16) - t.delta_nb;
+    return ct->state[(int)(v >> nb) + t.delta_find];
+}
+static uint32_t fse_encode(bitw *b, const fse_ct *ct, uint32_t state, uint32_t sym)
+{
+    const fse_sym t = ct->sym[sym];
+    const uint32_t nb = (state + t.delta_nb) >> 16;
+    bw_add(b, state, (int)nb);
+    return ct->state[(int)(state >> nb) + t.delta_find];
+}
+
+/* ------------------------------------------------------------ Huffman (compression side) */
+typedef struct { uint16_t val; uint8_t nb; } huf_elt;
+typedef struct { uint32_t count; uint16_t parent; uint8_t byte; uint8_t nb; } huf_node;
+
+static uint32_t huf_set_max_height(huf_node *node, uint32_t last, uint32_t max_nb)
+{
+    const uint32_t largest = node[last].nb;
+    if (largest <= max_nb) return largest;
+    {
+        int total = 0, n = (int)last;
+        const uint32_t base = 1u << (largest - max_nb);
+        while (node[n].nb > max_nb) { total += (int)(base - (1u << (largest - node[n].nb))); node[n].nb = (uint8_t)max_nb; n--; }
+        while (node[n].nb == max_nb) n--;
+        total >>= (largest - max_nb);
+        {
+            const uint32_t none = 0xF0F0F0F0u;
+            uint32_t rank_last[HUF_LOG_MAX + 2];
+            int pos;
+            uint32_t cur = max_nb;
+            for (pos = 0; pos < HUF_LOG_MAX + 2; pos++) rank_last[pos] = none;
+            for (pos = n; pos >= 0; pos--) {
+                if (node[pos].nb >= cur) continue;
+                cur = node[pos].nb;
+                rank_last[max_nb - cur] = (uint32_t)pos;
+            }
+            while (total > 0) {
+                uint32_t dec = (uint32_t)hb((uint32_t)total) + 1;
+                for (; dec > 1; dec--) {
+                    const uint32_t hp = rank_last[dec], lp = rank_last[dec - 1];
+                    if (hp == none) continue;
+                    if (lp == none) break;
+                    if (node[hp].count <= 2 * node[lp].count) break;
+                }
+                while (dec <= HUF_LOG_MAX && rank_last[dec] == none) dec++;
+                total -= 1 << (dec - 1);
+                if (rank_last[dec - 1] == none) rank_last[dec - 1] = rank_last[dec];
+                node[rank_last[dec]].nb++;
+                if (rank_last[dec] == 0) rank_last[dec] = none;
+                else {
+                    rank_last[dec]--;
+                    if (node[rank_last[dec]].nb != max_nb - dec) rank_last[dec] = none;
+                }
+            }
+            while (total < 0) {
+                if (rank_last[1] == none) {
+                    while (node[n].nb == max_nb) n--;
+                    node[n + 1].nb--;
+                    rank_last[1] = (uint32_t)(n + 1);
+                    total++;
+                    continue;
+                }
+                node[rank_last[1] + 1].nb--;
+                rank_last[1]++;
+                total++;
+            }
+        }
+    }
+    return max_nb;
+}
+
+/* HUF_buildCTable: returns max code length */
+static uint32_t huf_build(huf_elt *tree, const uint32_t *count, uint32_t max_sym, uint32_t max_nb)
+{
+    huf_node node0[2 * 256 + 2];
+    huf_node *node = node0 + 1;
+    int n, non_null, low_s, low_n, node_nb = 256, node_root;
+    memset(node0, 0, sizeof node0);
+    /* sort by decreasing count, ties by increasing symbol (bucketed insertion sort) */
+    {
+        uint32_t base[33], cur[33];
+        memset(base, 0, sizeof base);
+        for (n = 0; n <= (int)max_sym; n++) base[hb(count[n] + 1)]++;
+        for (n = 30; n > 0; n--) base[n - 1] += base[n];
+        for (n = 0; n < 32; n++) cur[n] = base[n];
+        for (n = 0; n <= (int)max_sym; n++) {
+            const uint32_t c = count[n], r = (uint32_t)hb(c + 1) + 1;
+            uint32_t pos = cur[r]++;
+            while (pos > base[r] && c > node[pos - 1].count) { node[pos] = node[pos - 1]; pos--; }
+            node[pos].count = c;
+            node[pos].byte = (uint8_t)n;
+        }
+    }
+    non_null = (int)max_sym;
+    while (node[non_null].count == 0) non_null--;
+    low_s = non_null; node_root = node_nb + low_s - 1; low_n = node_nb;
+    node[node_nb].count = node[low_s].count + node[low_s - 1].count;
+    node[low_s].parent = node[low_s - 1].parent = (uint16_t)node_nb;
+    node_nb++; low_s -= 2;
+    for (n = node_nb; n <= node_root; n++) node[n].count = 1u << 30;
+    node0[0].count = 1u << 31;
+    while (node_nb <= node_root) {
+        const int n1 = (node[low_s].count < node[low_n].count) ? low_s-- : low_n++;
+        const int n2 = (node[low_s].count < node[low_n].count) ? low_s-- : low_n++;
+        node[node_nb].count = node[n1].count + node[n2].count;
+        node[n1].parent = node[n2].parent = (uint16_t)node_nb;
+        node_nb++;
+    }
+    node[node_root].nb = 0;
+    for (n = node_root - 1; n >= 256; n--) node[n].nb = (uint8_t)(node[node[n].parent].nb + 1);
+    for (n = 0; n <= non_null; n++) node[n].nb = (uint8_t)(node[node[n].parent].nb + 1);
+    max_nb = huf_set_max_height(node, (uint32_t)non_null, max_nb);
+    {
+        uint16_t per_rank[HUF_LOG_MAX + 2], val_rank[HUF_LOG_MAX + 2];
+        const int alpha = (int)max_sym + 1;
+        memset(per_rank, 0, sizeof per_rank);
+        memset(val_rank, 0, sizeof val_rank);
+        for (n = 0; n <= non_null; n++) per_rank[node[n].nb]++;
+        {
+            uint16_t min = 0;
+            for (n = (int)max_nb; n > 0; n--) { val_rank[n] = min; min = (uint16_t)(min + per_rank[n]); min >>= 1; }
+        }
+        for (n = 0; n < alpha; n++) tree[node[n].byte].nb = node[n].nb;
+        for (n = 0; n < alpha; n++) tree[n].val = val_rank[tree[n].nb]++;
+    }
+    return max_nb;
+}
+
+/* FSE-compress the Huffman weights (HUF_compressWeights); 0 = not compressible, 1 = RLE */
+static size_t huf_compress_weights(uint8_t *dst, const uint8_t *w, size_t n)
+{
+    uint32_t count[HUF_LOG_MAX + 1], max_sym = HUF_LOG_MAX, max_count = 0, s;
+    int16_t norm[HUF_LOG_MAX + 1];
+    fse_ct ct;
+    int log;
+    size_t hsz, i;
+    bitw b;
+    uint32_t s1, s2;
+    if (n <= 1) return 0;
+    memset(count, 0, sizeof count);
+    for (i = 0; i < n; i++) count[w[i]]++;
+    while (!count[max_sym]) max_sym--;
+    for (s = 0; s <= max_sym; s++) if (count[s] > max_count) max_count = count[s];
+    if (max_count == n) return 1;
+    if (max_count == 1) return 0;
+    log = fse_optimal_log(6, n, max_sym, 2);
+    if (fse_normalize(norm, log, count, n, max_sym, 0) <= 0) return 0;
+    hsz = fse_write_ncount(dst, norm, max_sym, log);
+    if (!hsz) return 0;
+    fse_build_ct(&ct, norm, max_sym, log);
+    /* FSE_compress_usingCTable: symbols from the end, even index -> state 1, odd -> state 2 */
+    if (n <= 2) return 0;
+    bw_init(&b, dst + hsz);
+    {
+        size_t ip = n;
+        if (n & 1) {
+            s1 = fse_init_state(&ct, w[--ip]);
+            s2 = fse_init_state(&ct, w[--ip]);
+            s1 = fse_encode(&b, &ct, s1, w[--ip]);
+        } else {
+            s2 = fse_init_state(&ct, w[--ip]);
+            s1 = fse_init_state(&ct, w[--ip]);
+        }
+        while (ip > 0) {
+            s2 = fse_encode(&b, &ct, s2, w[--ip]);
+            s1 = fse_encode(&b, &ct, s1, w[--ip]);
+        }
+        bw_add(&b, s2, ct.log);
+        bw_add(&b, s1, ct.log);
+    }
+    return hsz + bw_close(&b);
+}
+
+static size_t huf_write_table(uint8_t *dst, const huf_elt *tree, uint32_t max_sym, uint32_t log)
+{
+    uint8_t bits2w[HUF_LOG_MAX + 2], w[256];
+    uint32_t n;
+    size_t hsz;
+    bits2w[0] = 0;
+    for (n = 1; n < log + 1; n++) bits2w[n] = (uint8_t)(log + 1 - n);
+    for (n = 0; n < max_sym; n++) w[n] = bits2w[tree[n].nb];
+    hsz = huf_compress_weights(dst + 1, w, max_sym);
+    if (hsz > 1 && hsz < max_sym / 2) { dst[0] = (uint8_t)hsz; return hsz + 1; }
+    if (max_sym > 128) return 0; /* library returns an error: literals stay uncompressed */
+    dst[0] = (uint8_t)(128 + (max_sym - 1));
+    w[max_sym] = 0;
+    for (n = 0; n < max_sym; n += 2) dst[n / 2 + 1] = (uint8_t)((w[n] << 4) + w[n + 1]);
+    return (max_sym + 1) / 2 + 1;
+}
+
+static size_t huf_encode_1x(uint8_t *dst, const uint8_t *src, size_t n, const huf_elt *t)
+{
+    bitw b;
+    size_t i;
+    bw_init(&b, dst);
+    for (i = n; i > 0; i--) bw_add(&b, t[src[i - 1]].val, t[src[i - 1]].nb);
+    return bw_close(&b);
+}
+
+/* encode with a given table, 1 or 4 streams (HUF_compressCTable_internal); 0 = not compressible */
+static size_t huf_encode_streams(uint8_t *dst, size_t hsz, const uint8_t *src, size_t n, const huf_elt *tree, int single)
+{
+    size_t op = hsz;
+    if (single) {
+        op += huf_encode_1x(dst + op, src, n, tree);
+    } else {
+        const size_t seg = (n + 3) / 4;
+        size_t k, ip = 0;
+        if (n < 12) return 0;
+        op += 6;
+        for (k = 0; k < 3; k++) {
+            const size_t c = huf_encode_1x(dst + op, src + ip, seg, tree);
+            dst[hsz + 2 * k] = (uint8_t)c;
+            dst[hsz + 2 * k + 1] = (uint8_t)(c >> 8);
+            ip += seg; op += c;
+        }
+        op += huf_encode_1x(dst + op, src + ip, n - ip, tree);
+    }
+    if (op >= n - 1) return 0;
+    return op;
+}
+
+/* Huffman table state carried from block to block (ZSTD_hufCTables_t): mode 0 = none,
+ * 1 = "check" (a table exists and may be reused if it covers the symbols and is cheaper) */
+typedef struct { int mode; huf_elt tree[256]; } huf_state;
+
+/* HUF_compress{1X,4X}_repeat; returns compressed size (incl. table), 0 = not compressible,
+ * 1 = RLE; *reused = 1 when the previous table was used (treeless literals) */
+static size_t huf_compress(uint8_t *dst, const uint8_t *src, size_t n, int single, huf_state *st, int prefer_repeat,
+                           int *reused)
+{
+    uint32_t count[256], max_sym = 255, largest = 0, s, log;
+    huf_elt tree[256];
+    size_t i, hsz;
+    int mode = st->mode;
+    *reused = 0;
+    memset(count, 0, sizeof count);
+    for (i = 0; i < n; i++) count[src[i]]++;
+    while (!count[max_sym]) max_sym--;
+    for (s = 0; s <= max_sym; s++) if (count[s] > largest) largest = count[s];
+    if (largest == n) { dst[0] = src[0]; return 1; }
+    if (largest <= (n >> 7) + 4) return 0;
+    if (mode == 1) { /* HUF_validateCTable */
+        int bad = 0;
+        for (s = 0; s <= max_sym; s++) bad |= (count[s] != 0) & (st->tree[s].nb == 0);
+        if (bad) mode = 0;
+    }
+    if (prefer_repeat && mode != 0) { *reused = 1; return huf_encode_streams(dst, 0, src, n, st->tree, single); }
+    log = (uint32_t)fse_optimal_log(HUF_LOG_DEFAULT, n, max_sym, 1);
+    memset(tree, 0, sizeof tree);
+    log = huf_build(tree, count, max_sym, log);
+    hsz = huf_write_table(dst, tree, max_sym, log);
+    if (hsz == 0) return 0;
+    if (mode != 0) {
+        size_t old_bits = 0, new_bits = 0;
+        for (s = 0; s <= max_sym; s++) { old_bits += (size_t)st->tree[s].nb * count[s]; new_bits += (size_t)tree[s].nb * count[s]; }
+        if ((old_bits >> 3) <= hsz + (new_bits >> 3) || hsz + 12 >= n) {
+            *reused = 1;
+            return huf_encode_streams(dst, 0, src, n, st->tree, single);
+        }
+    }
+    if (hsz + 12 >= n) return 0;
+    st->mode = 0; /* *repeat = HUF_repeat_none: the new table replaces the old one */
+    memcpy(st->tree, tree, sizeof tree);
+    return huf_encode_streams(dst, hsz, src, n, tree, single);
+}
+
+/* ------------------------------------------------------------ literals section */
+static size_t min_gain(size_t n) { return (n >> 6) + 2; } /* strategies below btultra */
+
+static size_t lit_raw(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    const size_t fl = 1 + (n > 31) + (n > 4095);
+    if (fl == 1) dst[0] = (uint8_t)(0 + (n << 3));
+    else if (fl == 2) { const uint32_t h = (uint32_t)(0 + (1 << 2) + (n << 4)); dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); }
+    else { const uint32_t h = (uint32_t)(0 + (3 << 2) + (n << 4)); dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16); }
+    memcpy(dst + fl, src, n);
+    return fl + n;
+}
+static size_t lit_rle(uint8_t *dst, const uint8_t *src, size_t n)
+{
+    const size_t fl = 1 + (n > 31) + (n > 4095);
+    if (fl == 1) dst[0] = (uint8_t)(1 + (n << 3));
+    else if (fl == 2) { const uint32_t h = (uint32_t)(1 + (1 << 2) + (n << 4)); dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); }
+    else { const uint32_t h = (uint32_t)(1 + (3 << 2) + (n << 4)); dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16); }
+    dst[fl] = src[0];
+    return fl + 1;
+}
+
+/* ZSTD_compressLiterals: `prev` is the confirmed table state, `next` receives the state this
+ * block would leave behind (committed by the caller only if the block is emitted compressed) */
+static size_t compress_literals(uint8_t *dst, const uint8_t *src, size_t n, const huf_state *prev, huf_state *next,
+                                int disable)
+{
+    const size_t lh = 3 + (n >= 1024) + (n >= 16384);
+    const int single = n < 256;
+    int reused = 0;
+    uint32_t htype = 2;
+    size_t c;
+    *next = *prev;
+    /* ZSTD_disableLiteralsCompression: strategy fast with targetLength > 0 (negative levels) */
+    if (disable) return lit_raw(dst, src, n);
+    if (n <= 63) return lit_raw(dst, src, n);
+    c = huf_compress(dst + lh, src, n, single, next, n <= 1024, &reused);
+    if (reused) htype = 3;
+    if (c == 0 || c >= n - min_gain(n)) { *next = *prev; return lit_raw(dst, src, n); }
+    if (c == 1) { *next = *prev; return lit_rle(dst, src, n); }
+    if (htype == 2) next->mode = 1; /* a freshly built table is "check" for the next block */
+    if (lh == 3) {
+        const uint32_t h = htype + ((uint32_t)(!single) << 2) + ((uint32_t)n << 4) + ((uint32_t)c << 14);
+        dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16);
+    } else if (lh == 4) {
+        const uint32_t h = htype + (2u << 2) + ((uint32_t)n << 4) + ((uint32_t)c << 18);
+        dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16); dst[3] = (uint8_t)(h >> 24);
+    } else {
+        const uint32_t h = htype + (3u << 2) + ((uint32_t)n << 4) + ((uint32_t)c << 22);
+        dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16); dst[3] = (uint8_t)(h >> 24);
+        dst[4] = (uint8_t)(c >> 10);
+    }
+    return lh + c;
+}
+
+/* ------------------------------------------------------------ sequences */
+typedef struct { uint32_t off; uint16_t ll, ml; } seq_t; /* off = offCode + 1, ml = matchLength - 3 */
+
+static const uint8_t LL_bits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6,
+    7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+static const uint8_t ML_bits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+    0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+static const int16_t LL_def[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3,
+    2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+static const int16_t ML_def[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+    1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+static const int16_t OF_def[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1,
+    -1, -1, -1};
+
+static uint32_t ll_code(uint32_t ll)
+{
+    static const uint8_t c[64] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 16, 17, 17, 18, 18, 19,
+        19, 20, 20, 20, 20, 21, 21, 21, 21, 22, 22, 22, 22, 22, 22, 22, 22, 23, 23, 23, 23, 23, 23, 23, 23, 24, 24,
+        24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24};
+    return ll > 63 ? (uint32_t)hb(ll) + 19 : c[ll];
+}
+static uint32_t ml_code(uint32_t mb)
+{
+    static const uint8_t c[128] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22,
+        23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 32, 33, 33, 34, 34, 35, 35, 36, 36, 36, 36, 37, 37, 37, 37, 38, 38,
+        38, 38, 38, 38, 38, 38, 39, 39, 39, 39, 39, 39, 39, 39, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40,
+        40, 40, 40, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 42, 42, 42, 42, 42, 42, 42, 42,
+        42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42};
+    return mb > 127 ? (uint32_t)hb(mb) + 36 : c[mb];
+}
+
+enum { SET_BASIC = 0, SET_RLE = 1, SET_COMPRESSED = 2, SET_REPEAT = 3 };
+
+/* ZSTD_selectEncodingType for strategy `fast` (no dictionary: repeat mode is never "valid") */
+static int select_type(uint32_t max, size_t most, size_t nseq, int def_log, int def_allowed)
+{
+    (void)max;
+    if (most == nseq) return (def_allowed && nseq <= 2) ? SET_BASIC : SET_RLE;
+    if (def_allowed) {
+        const size_t mult = 10 - 1; /* strategy fast == 1 */
+        const size_t dyn_min = (((size_t)1 << def_log) * mult) >> 3;
+        if (nseq < dyn_min || most < (nseq >> (def_log - 1))) return SET_BASIC;
+    }
+    return SET_COMPRESSED;
+}
+
+/* ZSTD_buildCTable; returns bytes written to dst (table description) or (size_t)-1 on error */
+static size_t build_ctable(uint8_t *dst, fse_ct *ct, int fse_log, int type, uint32_t *count, uint32_t max,
+                           const uint8_t *codes, size_t nseq, const int16_t *def_norm, int def_log, uint32_t def_max)
+{
+    if (type == SET_RLE) { fse_build_ct_rle(ct, max); dst[0] = codes[0]; return 1; }
+    if (type == SET_BASIC) { fse_build_ct(ct, def_norm, def_max, def_log); return 0; }
+    {
+        int16_t norm[MaxML + 1];
+        size_t n1 = nseq, sz;
+        const int log = fse_optimal_log(fse_log, nseq, max, 2);
+        if (count[codes[nseq - 1]] > 1) { count[codes[nseq - 1]]--; n1--; }
+        if (fse_normalize(norm, log, count, n1, max, n1 >= 2048) <= 0) return (size_t)-1;
+        sz = fse_write_ncount(dst, norm, max, log);
+        if (!sz) return (size_t)-1;
+        fse_build_ct(ct, norm, max, log);
+        return sz;
+    }
+}
+
+/* literals + sequences of one block -> compressed block body; 0 = emit a raw block */
+static size_t compress_sequences(uint8_t *dst, const seq_t *seqs, size_t nseq, const uint8_t *lits, size_t nlit,
+                                 size_t src_size, int long_pos, int long_kind, const huf_state *hprev, huf_state *hnext,
+                                 int disable_lit)
+{
+    static uint8_t llc[ZBLOCK_MAX / 3 + 8], mlc[ZBLOCK_MAX / 3 + 8], ofc[ZBLOCK_MAX / 3 + 8];
+    static fse_ct ct_ll, ct_of, ct_ml;
+    uint32_t count[MaxML + 1], max, s;
+    size_t op, i, most;
+    uint8_t *seq_head, *last_ncount = NULL;
+    int tll, tof, tml;
+    op = compress_literals(dst, lits, nlit, hprev, hnext, disable_lit);
+    if (nseq < 128) dst[op++] = (uint8_t)nseq;
+    else if (nseq < 0x7F00) { dst[op] = (uint8_t)((nseq >> 8) + 0x80); dst[op + 1] = (uint8_t)nseq; op += 2; }
+    else { dst[op] = 0xFF; dst[op + 1] = (uint8_t)(nseq - 0x7F00); dst[op + 2] = (uint8_t)((nseq - 0x7F00) >> 8); op += 3; }
+    if (nseq == 0) goto check;
+    seq_head = dst + op++;
+    for (i = 0; i < nseq; i++) {
+        llc[i] = (uint8_t)ll_code(seqs[i].ll);
+        ofc[i] = (uint8_t)hb(seqs[i].off);
+        mlc[i] = (uint8_t)ml_code(seqs[i].ml);
+    }
+    if (long_kind == 1) llc[long_pos] = MaxLL;
+    if (long_kind == 2) mlc[long_pos] = MaxML;
+#define HIST(codes, maxv)                                                                                 \
+    do {                                                                                                  \
+        memset(count, 0, sizeof count);                                                                   \
+        for (i = 0; i < nseq; i++) count[codes[i]]++;                                                     \
+        max = (maxv);                                                                                     \
+        while (!count[max]) max--;                                                                        \
+        most = 0;                                                                                         \
+        for (s = 0; s <= max; s++) if (count[s] > most) most = count[s];                                  \
+    } while (0)
+    {
+        size_t sz;
+        HIST(llc, MaxLL);
+        tll = select_type(max, most, nseq, 6, 1);
+        sz = build_ctable(dst + op, &ct_ll, LLFSELog, tll, count, max, llc, nseq, LL_def, 6, MaxLL);
+        if (sz == (size_t)-1) return 0;
+        if (tll == SET_COMPRESSED) last_ncount = dst + op;
+        op += sz;
+        HIST(ofc, MaxOff);
+        tof = select_type(max, most, nseq, 5, max <= DefaultMaxOff);
+        sz = build_ctable(dst + op, &ct_of, OffFSELog, tof, count, max, ofc, nseq, OF_def, 5, DefaultMaxOff);
+        if (sz == (size_t)-1) return 0;
+        if (tof == SET_COMPRESSED) last_ncount = dst + op;
+        op += sz;
+        HIST(mlc, MaxML);
+        tml = select_type(max, most, nseq, 6, 1);
+        sz = build_ctable(dst + op, &ct_ml, MLFSELog, tml, count, max, mlc, nseq, ML_def, 6, MaxML);
+        if (sz == (size_t)-1) return 0;
+        if (tml == SET_COMPRESSED) last_ncount = dst + op;
+        op += sz;
+    }
+#undef HIST
+    *seq_head = (uint8_t)((tll << 6) + (tof << 4) + (tml << 2));
+    {
+        bitw b;
+        uint32_t sm, so, sl;
+        size_t n = nseq - 1, bs;
+        bw_init(&b, dst + op);
+        sm = fse_init_state(&ct_ml, mlc[n]);
+        so = fse_init_state(&ct_of, ofc[n]);
+        sl = fse_init_state(&ct_ll, llc[n]);
+        bw_add(&b, seqs[n].ll, LL_bits[llc[n]]);
+        bw_add(&b, seqs[n].ml, ML_bits[mlc[n]]);
+        bw_add(&b, seqs[n].off, ofc[n]);
+        while (n-- > 0) {
+            so = fse_encode(&b, &ct_of, so, ofc[n]);
+            sm = fse_encode(&b, &ct_ml, sm, mlc[n]);
+            sl = fse_encode(&b, &ct_ll, sl, llc[n]);
+            bw_add(&b, seqs[n].ll, LL_bits[llc[n]]);
+            bw_add(&b, seqs[n].ml, ML_bits[mlc[n]]);
+            bw_add(&b, seqs[n].off, ofc[n]);
+        }
+        bw_add(&b, sm, ct_ml.log);
+        bw_add(&b, so, ct_of.log);
+        bw_add(&b, sl, ct_ll.log);
+        bs = bw_close(&b);
+        op += bs;
+        if (last_ncount && (size_t)(dst + op - last_ncount) < 4) return 0;
+    }
+check:
+    if (op >= src_size - min_gain(src_size)) return 0;
+    return op;
+}
+
+/* ------------------------------------------------------------ match finder: strategy `fast` */
+typedef struct { int wlog, hlog, mml, tlen; } cpar;
+
+static uint32_t hash_ptr(const uint8_t *p, int hlog, int mls)
+{
+    switch (mls) {
+    default:
+    case 4: return (rd32(p) * 2654435761u) >> (32 - hlog);
+    case 5: return (uint32_t)(((rd64(p) << 24) * 889523592379ull) >> (64 - hlog));
+    case 6: return (uint32_t)(((rd64(p) << 16) * 227718039650203ull) >> (64 - hlog));
+    case 7: return (uint32_t)(((rd64(p) << 8) * 58295818150454627ull) >> (64 - hlog));
+    }
+}
+static size_t count_match(const uint8_t *a, const uint8_t *b, const uint8_t *end)
+{
+    const uint8_t *s = a;
+    while (a < end && *a == *b) { a++; b++; }
+    return (size_t)(a - s);
+}
+
+typedef struct {
+    seq_t *seqs; size_t nseq;
+    uint8_t *lits; size_t nlit;
+    int long_pos, long_kind;
+} seqstore;
+
+static void store_seq(seqstore *ss, size_t ll, const uint8_t *lit, uint32_t offcode, size_t mlbase)
+{
+    memcpy(ss->lits + ss->nlit, lit, ll);
+    ss->nlit += ll;
+    if (ll > 0xFFFF) { ss->long_kind = 1; ss->long_pos = (int)ss->nseq; }
+    if (mlbase > 0xFFFF) { ss->long_kind = 2; ss->long_pos = (int)ss->nseq; }
+    ss->seqs[ss->nseq].ll = (uint16_t)ll;
+    ss->seqs[ss->nseq].off = offcode + 1;
+    ss->seqs[ss->nseq].ml = (uint16_t)mlbase;
+    ss->nseq++;
+}
+
+/* base = src - 1 (the library gives the first input byte index 1) */
+static size_t block_fast(uint32_t *table, const cpar *cp, const uint8_t *base, const uint8_t *istart, size_t n,
+                         uint32_t rep[3], seqstore *ss, uint32_t dict_limit)
+{
+    const int hlog = cp->hlog, mls = cp->mml < 4 ? 4 : (cp->mml > 7 ? 7 : cp->mml);
+    const size_t step_size = (size_t)cp->tlen + !cp->tlen + 1;
+    const uint8_t *ip0 = istart, *ip1, *anchor = istart;
+    const uint32_t end_index = (uint32_t)(istart - base) + (uint32_t)n;
+    const uint32_t max_dist = 1u << cp->wlog;
+    const uint32_t prefix_idx = (end_index - dict_limit > max_dist) ? end_index - max_dist : dict_limit;
+    const uint8_t *prefix = base + prefix_idx;
+    const uint8_t *iend = istart + n, *ilimit = iend - HASH_READ;
+    uint32_t off1 = rep[0], off2 = rep[1], saved = 0;
+
+    ip0 += (ip0 == prefix);
+    ip1 = ip0 + 1;
+    {
+        const uint32_t cur = (uint32_t)(ip0 - base);
+        const uint32_t wlow = (cur - dict_limit > max_dist) ? cur - max_dist : dict_limit;
+        const uint32_t max_rep = cur - wlow;
+        if (off2 > max_rep) { saved = off2; off2 = 0; }
+        if (off1 > max_rep) { saved = off1; off1 = 0; }
+    }
+    while (ip1 < ilimit) {
+        size_t mlen;
+        const uint8_t *ip2 = ip0 + 2;
+        const uint32_t h0 = hash_ptr(ip0, hlog, mls), h1 = hash_ptr(ip1, hlog, mls);
+        const uint32_t v0 = rd32(ip0), v1 = rd32(ip1);
+        const uint32_t cur0 = (uint32_t)(ip0 - base), cur1 = (uint32_t)(ip1 - base);
+        const uint32_t mi0 = table[h0], mi1 = table[h1];
+        const uint8_t *rep_m = ip2 - off1;
+        const uint8_t *m0 = base + mi0, *m1 = base + mi1;
+        uint32_t offcode;
+        table[h0] = cur0;
+        table[h1] = cur1;
+        if ((off1 > 0) && rd32(rep_m) == rd32(ip2)) {
+            mlen = (ip2[-1] == rep_m[-1]) ? 1 : 0;
+            ip0 = ip2 - mlen;
+            m0 = rep_m - mlen;
+            mlen += 4;
+            offcode = 0;
+            goto match;
+        }
+        if (mi0 > prefix_idx && rd32(m0) == v0) goto offset;
+        if (mi1 > prefix_idx && rd32(m1) == v1) { ip0 = ip1; m0 = m1; goto offset; }
+        {
+            const size_t step = ((size_t)(ip0 - anchor) >> (8 - 1)) + step_size;
+            ip0 += step;
+            ip1 += step;
+            continue;
+        }
+    offset:
+        off2 = off1;
+        off1 = (uint32_t)(ip0 - m0);
+        offcode = off1 + REP_MOVE;
+        mlen = 4;
+        while ((ip0 > anchor) && (m0 > prefix) && ip0[-1] == m0[-1]) { ip0--; m0--; mlen++; }
+    match:
+        mlen += count_match(ip0 + mlen, m0 + mlen, iend);
+        store_seq(ss, (size_t)(ip0 - anchor), anchor, offcode, mlen - MINMATCH);
+        ip0 += mlen;
+        anchor = ip0;
+        if (ip0 <= ilimit) {
+            table[hash_ptr(base + cur0 + 2, hlog, mls)] = cur0 + 2;
+            table[hash_ptr(ip0 - 2, hlog, mls)] = (uint32_t)(ip0 - 2 - base);
+            if (off2 > 0) {
+                while (ip0 <= ilimit && rd32(ip0) == rd32(ip0 - off2)) {
+                    const size_t rlen = count_match(ip0 + 4, ip0 + 4 - off2, iend) + 4;
+                    const uint32_t t = off2; off2 = off1; off1 = t;
+                    table[hash_ptr(ip0, hlog, mls)] = (uint32_t)(ip0 - base);
+                    ip0 += rlen;
+                    store_seq(ss, 0, anchor, 0, rlen - MINMATCH);
+                    anchor = ip0;
+                }
+            }
+        }
+        ip1 = ip0 + 1;
+    }
+    rep[0] = off1 ? off1 : saved;
+    rep[1] = off2 ? off2 : saved;
+    return (size_t)(iend - anchor);
+}
+
+/* ------------------------------------------------------------ parameters (ZSTD_getCParams) */
+static int get_cpar(int level, size_t n, cpar *cp)
+{
+    /* rows: level 0(base for negatives),1,2 of the library's tables for the two size classes the
+     * cryo path uses; validated against ZSTD_getCParams by the tests */
+    static const int big[3][4] = {{19, 12, 13, 6}, {19, 13, 14, 7}, {20, 15, 16, 6}};   /* n > 256 KiB */
+    static const int k128[3][4] = {{17, 12, 12, 5}, {17, 12, 13, 6}, {17, 13, 15, 5}};  /* 16 KiB < n <= 128 KiB */
+    const int (*t)[4];
+    int row, srclog;
+    if (level == 0) level = 3;
+    if (level > 2 || level < -131072) return -1; /* other levels: not `fast` */
+    if (n > 256u * 1024u) t = big;
+    else if (n > 16u * 1024u && n <= 128u * 1024u) t = k128;
+    else return -1;
+    row = level < 0 ? 0 : level;
+    cp->wlog = t[row][0]; cp->hlog = t[row][2]; cp->mml = t[row][3];
+    cp->tlen = level < 0 ? -level : 0;
+    /* ZSTD_adjustCParams_internal: shrink the window (and hash) to the source size */
+    srclog = (n < 64) ? 6 : hb((uint32_t)(n - 1)) + 1;
+    if (cp->wlog > srclog) cp->wlog = srclog;
+    if (cp->hlog > cp->wlog + 1) cp->hlog = cp->wlog + 1;
+    if (cp->wlog < 10) cp->wlog = 10;
+    return 0;
+}
+
+/* ------------------------------------------------------------ frame */
+size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int level)
+{
+    static uint32_t table[1 << 16];
+    static seq_t seqs[ZBLOCK_MAX / 3 + 8];
+    static uint8_t lits[ZBLOCK_MAX + 8];
+    cpar cp;
+    size_t op = 0, ip = 0;
+    uint32_t rep[3] = {1, 4, 8};
+    uint32_t dict_limit = 1;
+    const uint8_t *base = src - 1;
+    int first = 1;
+    static huf_state hprev, hnext;
+    hprev.mode = 0;
+    if (get_cpar(level, n, &cp) || cap < cryo_oracle_zstd_bound(n)) return 0;
+    memset(table, 0, sizeof(uint32_t) << cp.hlog);
+    /* frame header: content size always, no checksum, no dictionary id */
+    {
+        const uint64_t wsize = 1ull << cp.wlog;
+        const int single = wsize >= n;
+        const int fcs = (n >= 256) + (n >= 65536 + 256) + (n >= 0xFFFFFFFFu);
+        dst[0] = 0x28; dst[1] = 0xB5; dst[2] = 0x2F; dst[3] = 0xFD;
+        dst[4] = (uint8_t)((single << 5) + (fcs << 6));
+        op = 5;
+        if (!single) dst[op++] = (uint8_t)((cp.wlog - 10) << 3);
+        if (fcs == 0) { if (single) dst[op++] = (uint8_t)n; }
+        else if (fcs == 1) { dst[op++] = (uint8_t)(n - 256); dst[op++] = (uint8_t)((n - 256) >> 8); }
+        else { dst[op++] = (uint8_t)n; dst[op++] = (uint8_t)(n >> 8); dst[op++] = (uint8_t)(n >> 16); dst[op++] = (uint8_t)(n >> 24); }
+    }
+    if (n == 0) { dst[op++] = 1; dst[op++] = 0; dst[op++] = 0; return op; }
+    while (ip < n) {
+        const size_t bs = (n - ip < ZBLOCK_MAX) ? n - ip : ZBLOCK_MAX;
+        const int last = (ip + bs == n);
+        size_t csize = 0;
+        /* the window's low limit follows the block end (ZSTD_window_enforceMaxDist) */
+        {
+            const uint32_t end_idx = (uint32_t)(ip + bs) + 1;
+            const uint32_t max_dist = 1u << cp.wlog;
+            if (end_idx > max_dist && dict_limit < end_idx - max_dist) dict_limit = end_idx - max_dist;
+        }
+        if (bs >= 3 + 3 + 1) {
+            seqstore ss;
+            uint32_t nrep[3];
+            size_t last_ll;
+            ss.seqs = seqs; ss.nseq = 0; ss.lits = lits; ss.nlit = 0; ss.long_pos = 0; ss.long_kind = 0;
+            nrep[0] = rep[0]; nrep[1] = rep[1]; nrep[2] = rep[2];
+            last_ll = block_fast(table, &cp, base, src + ip, bs, nrep, &ss, dict_limit);
+            memcpy(lits + ss.nlit, src + ip + bs - last_ll, last_ll);
+            ss.nlit += last_ll;
+            csize = compress_sequences(dst + op + 3, seqs, ss.nseq, lits, ss.nlit, bs, ss.long_pos, ss.long_kind, &hprev, &hnext, cp.tlen > 0);
+            if (!first && csize < 25) { /* RLE block for constant non-first blocks */
+                size_t k = 1;
+                while (k < bs && src[ip + k] == src[ip]) k++;
+                if (k == bs) { csize = 1; dst[op + 3] = src[ip]; }
+            }
+            if (csize > 1) { rep[0] = nrep[0]; rep[1] = nrep[1]; rep[2] = nrep[2]; hprev = hnext; }
+        }
+        if (csize == 0) {
+            const uint32_t h = (uint32_t)last + (0u << 1) + ((uint32_t)bs << 3);
+            dst[op] = (uint8_t)h; dst[op + 1] = (uint8_t)(h >> 8); dst[op + 2] = (uint8_t)(h >> 16);
+            memcpy(dst + op + 3, src + ip, bs);
+            op += 3 + bs;
+        } else {
+            const uint32_t h = csize == 1 ? (uint32_t)last + (1u << 1) + ((uint32_t)bs << 3)
+                                          : (uint32_t)last + (2u << 1) + ((uint32_t)csize << 3);
+            dst[op] = (uint8_t)h; dst[op + 1] = (uint8_t)(h >> 8); dst[op + 2] = (uint8_t)(h >> 16);
+            op += 3 + csize;
+        }
+        ip += bs;
+        first = 0;
+    }
+    return op;
+}

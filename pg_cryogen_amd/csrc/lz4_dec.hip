@@ -95,7 +95,22 @@ struct WaveLds {
     uint32_t *__restrict__ bm;             /* kTMax/32: bit q = a sequence starts at q    */
 };
 
-struct Stats { uint32_t batches, batch_seqs, general_seqs, chunks, rounds, zero_batches; uint32_t ablate; };
+struct Stats {
+    uint32_t batches, batch_seqs, general_seqs, chunks, rounds, zero_batches;
+    uint32_t ablate;
+    unsigned long long t[8]; /* cycle stamps per phase (diagnostic build only) */
+    unsigned long long t0;
+    bool on;
+};
+/* phase stamp: adds the cycles since the previous stamp to bucket k (STATS build only) */
+__device__ inline void stamp(Stats &st, int k)
+{
+    if (st.on) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        st.t[k] += now - st.t0;
+        st.t0 = now;
+    }
+}
 
 /*
  * Decode up to 64 "simple" sequences starting at virtual position vp; NG*64 (<= kWMax) is the
@@ -127,8 +142,10 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     const uint32_t vsafe = vend - 16u;
     if (vp + 64u > vsafe || w.op + 64u > B) return 0;
 
+    stamp(st, 7);
     /* stage the window (no refill happens while the batch runs) */
     while (w.in_hi < vend && w.in_hi < vp + W + 256u + 72u) w.refill();
+    stamp(st, 0);
 
     /* ---- phase 1: d1 for every window offset, then d2, d4 ---- */
     uint32_t a1[G1], a2[G2];
@@ -169,6 +186,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
             L.d4[g * 64u + lane] = (uint8_t)((a2[g] != 0u && b[g] != 0u) ? a2[g] + b[g] : 0u);
     }
 
+    stamp(st, 1);
     /* ---- chase: start of every 4th sequence into lanes 0,4,8,... ---- */
     uint32_t sl = 0;   /* window offset of this lane's sequence */
     uint32_t ngrp = 0;
@@ -189,6 +207,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     if (lane & 2u) sl += L.d2[sl];
     if (lane & 1u) sl += L.d1[sl];
 
+    stamp(st, 2);
     /* ---- phase 2: one sequence per lane ---- */
     const uint32_t pos = vp + sl;
     const uint32_t t = L.in[pos & kInMask];
@@ -216,6 +235,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     const uint32_t T = lane_get(oend, nseq - 1u);
     *used = lane_get(sl + dlen, nseq - 1u);
 
+    stamp(st, 3);
     /* ---- phase 3: bitmap of sequence starts + metadata ---- */
     if (lane < kTMax / 32u) L.bm[lane] = 0u;
     if (lane < nseq) {
@@ -241,6 +261,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
 #pragma unroll
     for (uint32_t h = 0; h < 2u; h++) {
         if (h * kHalf * 64u >= T) break;
+        stamp(st, 4);
         uint32_t mlo[kHalf], mhi[kHalf], xfar[kHalf];
         {
             uint32_t idx[kHalf];
@@ -277,6 +298,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
                 if (qo < T && dd < (mlo[i] >> 16)) L.ring[(op0 + qo) & (R - 1)] = (uint8_t)lit[i];
             }
         }
+        stamp(st, 5);
 #pragma unroll
         for (uint32_t i = 0; i < kHalf; i++) {
             const uint32_t c = h * kHalf + i;
@@ -305,9 +327,11 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
             }
         }
     }
+    stamp(st, 6);
     w.op = op0 + T;
     vp += *used;
     w.flush();
+    stamp(st, 0);
     return nseq;
 }
 
@@ -317,8 +341,9 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
                const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
                uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats)
 {
-    Stats st = {0, 0, 0, 0, 0, 0, 0};
-    if (STATS) st.ablate = (uint32_t)stats[7];
+    Stats st = {};
+    st.on = STATS;
+    if (STATS) { st.ablate = (uint32_t)stats[7]; st.t0 = __builtin_amdgcn_s_memtime(); }
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][R];
     __shared__ __attribute__((aligned(16))) uint8_t s_in[4][kInRing];
     __shared__ __attribute__((aligned(16))) uint8_t s_d1[4][kD1N]; /* also holds meta[64] in phase 3 */
@@ -553,6 +578,8 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
         atomicAdd(&stats[3], (unsigned long long)st.chunks);
         atomicAdd(&stats[4], (unsigned long long)st.rounds);
         atomicAdd(&stats[5], (unsigned long long)st.zero_batches);
+        stamp(st, 7);
+        for (int k = 0; k < 8; k++) atomicAdd(&stats[8 + k], st.t[k]);
     }
 }
 
@@ -571,7 +598,7 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
     const dim3 g((uint32_t)grid), b(256);
     static const bool want_stats = getenv("CRYO_LZ4_STATS") != nullptr; /* debugging aid */
     if (want_stats) {
-        unsigned long long *d_st = nullptr, h_st[8];
+        unsigned long long *d_st = nullptr, h_st[16];
         static const unsigned long long abl = getenv("CRYO_LZ4_ABLATE") ? strtoull(getenv("CRYO_LZ4_ABLATE"), nullptr, 0) : 0ull;
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
@@ -583,6 +610,12 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
         (void)hipFree(d_st);
         if (!getenv("CRYO_LZ4_QUIET")) fprintf(stderr, "[lz4 stats] batches %llu batch_seqs %llu general_seqs %llu chunks %llu rounds %llu zero_batches %llu\n",
                 h_st[0], h_st[1], h_st[2], h_st[3], h_st[4], h_st[5]);
+        if (!getenv("CRYO_LZ4_QUIET")) {
+            unsigned long long tot = 0;
+            for (int k = 0; k < 8; k++) tot += h_st[8 + k];
+            static const char *nm[8] = {"stage+flush", "phase1 tables", "chase+fill", "phase2 meta", "phase3 bitmap", "passA", "passB", "general+other"};
+            for (int k = 0; k < 8; k++) fprintf(stderr, "[lz4 cycles] %-14s %5.1f%%\n", nm[k], 100.0 * (double)h_st[8 + k] / (double)(tot ? tot : 1));
+        }
         return hipGetLastError();
     }
     if (ring == 8192)

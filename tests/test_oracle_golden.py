@@ -239,3 +239,39 @@ def test_zstd_oracle_fuzz_vs_live_libzstd(oracle):
                 n_lib += (r1 == B)
                 n += 1
     assert n_lib - n_ok <= n // 20, (n_lib, n_ok)
+
+
+# ---------------- zstd encoder oracle (strategy `fast`: levels -5..2) ----------------
+def test_zstd_encoder_oracle_matches_libzstd_golden(oracle):
+    n = 0
+    for c in VEC["cells"]:
+        if c["method"] != "zstd" or c["param"] > 2 or c["B"] < 20000 or (c["B"] > 131072 and c["block"] > 0):
+            continue
+        raw = oracle.synth(VEC["seed"], c["block"], c["B"], c["dist"])
+        comp = oracle.zstd_compress(raw, c["param"])
+        assert len(comp) == c["csize"], c
+        assert sha(comp) == c["comp_sha256"], c
+        n += 1
+    assert n >= 80
+
+
+@pytest.mark.parametrize("B", [131072, 1 << 20, 65546, 20000])
+def test_zstd_encoder_oracle_vs_live_libzstd(oracle, B):
+    stock = oracle_lib.StockLibs()
+    if stock.zstd is None:
+        pytest.skip("libzstd.so.1 not loadable")
+    for dist in range(5):
+        for blk in (7, 8):
+            raw = oracle.synth(6, blk, B, dist)
+            for lvl in (-5, -3, -1, 1, 2):
+                exp = stock.zstd_compress(raw, lvl)
+                got = oracle.zstd_compress(raw, lvl)
+                assert np.array_equal(got, exp), (B, dist, blk, lvl, len(got), len(exp))
+                r, out = oracle.zstd_decompress(got, B)
+                assert r == B and np.array_equal(out, raw)
+
+
+def test_zstd_encoder_oracle_unsupported_levels_return_empty(oracle):
+    raw = oracle.synth(0, 0, 131072, 1)
+    assert len(oracle.zstd_compress(raw, 3)) == 0      # dfast and above: not restated
+    assert len(oracle.zstd_compress(raw, 22)) == 0
