@@ -205,7 +205,14 @@ int cryo_codec_compress_batch(cryo_codec *c, int method, int param, const void *
                                              n_blocks, (uint8_t *)d_dst, dst_stride, param,
                                              d_out_size, d_status));
     } else {
-        return CRYO_E_UNSUPPORTED; /* zstd encode kernel: not in this build yet */
+        /* levels whose strategy is `fast` (-5..2 at cryo block sizes); others: no kernel yet */
+        if (!cryo::zstd_compress_supported(param, block_size)) return CRYO_E_UNSUPPORTED;
+        const size_t need = cryo::zstd_compress_workspace(n_blocks);
+        int rc = ensure_ws(c, need);
+        if (rc != CRYO_OK) return rc;
+        HIP_TRY(c, cryo::launch_zstd_compress(c->stream, (const uint8_t *)d_src, src_stride, block_size, n_blocks,
+                                              (uint8_t *)d_dst, dst_stride, param, d_out_size, d_status, c->d_ws,
+                                              c->ws_cap));
     }
     c->ctr.blocks_compressed += n_blocks;
     c->ctr.bytes_in += n_blocks * (uint64_t)block_size;

@@ -1,0 +1,1014 @@
+/*
+ * zstd_enc.hip -- Zstandard frame encode, one wavefront per cryo block, output bytes identical
+ * to libzstd 1.4.8 for the levels whose strategy is `fast` (levels -5 .. 2 at cryo block
+ * sizes; the reference's default zstd_compression_level_guc = 1 is one of them).
+ *
+ * Replaces ZSTD_compress(dst, ZSTD_compressBound(B), src, B, level)
+ * (reference compression.c:102-104).
+ *
+ * Pipeline per 128 KiB zstd block (a 1 MiB cryo block is a frame of 8 dependent blocks):
+ *   match finder  : the `fast` strategy's 2-positions-per-step hash probe with repeat-offset
+ *                   checks.  A serial recurrence over one hash table, so it runs wave-uniform;
+ *                   lanes co-operate on match extension (64 bytes/step, ballot + ctz) and on
+ *                   copying literal runs into the block's literal buffer.
+ *   literals      : histogram by LDS atomics (all lanes), length-limited Huffman tree
+ *                   (serial, <= 256 symbols), weights FSE-compressed or raw, then the 4
+ *                   backward bitstreams encoded by lanes 0..3 in parallel at offsets known
+ *                   from a first pass that only sums code lengths.
+ *   sequences     : codes + histograms lane-parallel; encoding-type choice, FSE normalisation,
+ *                   table description and the interleaved LL/OF/ML bitstream are serial.
+ *   block         : raw fallback when the gain is below size/64 + 2, RLE block for constant
+ *                   non-first blocks, repeat offsets / Huffman table state carried over only
+ *                   by blocks emitted compressed.
+ * Hash table: LDS when hashLog <= 13 (level 1 at 128 KiB), else a per-workgroup global table.
+ * Sequences, literals and codes of the block live in a per-workgroup global workspace.
+ */
+#include "lz_common.h"
+
+namespace cryo {
+
+namespace {
+
+constexpr uint32_t kZBlk = 128u << 10;
+constexpr uint32_t kMaxSeq = kZBlk / 3u + 8u;
+constexpr uint32_t kMaxLL = 35, kMaxML = 52, kMaxOff = 31, kDefMaxOff = 28;
+constexpr int kHufLogMaxE = 12;
+
+/* per-workgroup global workspace layout */
+constexpr size_t kWsSeq = 0;                                   /* uint2 {off, ll | ml<<16} x kMaxSeq */
+constexpr size_t kWsLit = kWsSeq + (size_t)kMaxSeq * 8u;        /* literals                          */
+constexpr size_t kWsLlc = kWsLit + kZBlk + 64u;                 /* LL / OF / ML codes                */
+constexpr size_t kWsOfc = kWsLlc + kMaxSeq;
+constexpr size_t kWsMlc = kWsOfc + kMaxSeq;
+constexpr size_t kWsHash = (kWsMlc + kMaxSeq + 255u) & ~(size_t)255u; /* u32 x 65536 (hashLog <= 16) */
+constexpr size_t kWsBytes = kWsHash + 65536u * 4u;
+
+struct FseCt {
+    uint16_t state[512];
+    int32_t dfind[64];
+    uint32_t dnb[64];
+    int log;
+};
+
+struct EncLds {
+    uint32_t hash[8192];       /* match-finder table when hashLog <= 13 */
+    uint32_t hist[256];
+    /* Huffman tree nodes; huffNode[i] of the library lives at index i+1, its "fake entry" at 0 */
+    uint32_t ncount[516];
+    uint16_t nparent[516];
+    uint8_t nbyte[516];
+    uint8_t nnb[516];
+    uint16_t hval[256];        /* code table built for this block */
+    uint8_t hnb[256];
+    uint16_t pval[256];        /* table confirmed by the previous compressed block ("check" mode) */
+    uint8_t pnb[256];
+    uint8_t wts[256];
+    int16_t norm[64];
+    uint32_t cumul[66];
+    uint8_t cell[512];
+    uint32_t seg_bits[4];
+    FseCt ll, of, ml, wt;
+};
+
+__device__ inline uint32_t hbit(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+__device__ inline uint32_t ld32u(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return uni(v); }
+__device__ inline uint64_t ld64u(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return uni64(v); }
+
+/* forward LSB-first bit writer into global memory (one lane's view) */
+struct BitW {
+    uint8_t *p;
+    uint64_t acc;
+    uint32_t n;
+    uint32_t len;
+    __device__ inline void init(uint8_t *dst) { p = dst; acc = 0; n = 0; len = 0; }
+    __device__ inline void add(uint64_t v, uint32_t nb)
+    {
+        if (nb == 0u) return;
+        acc |= (v & ((1ull << nb) - 1ull)) << n;
+        n += nb;
+        while (n >= 8u) { p[len++] = (uint8_t)acc; acc >>= 8; n -= 8u; }
+    }
+    __device__ inline uint32_t flush() { if (n > 0u) { p[len++] = (uint8_t)acc; n = 0; acc = 0; } return len; }
+    __device__ inline uint32_t close() { add(1, 1); return flush(); }
+};
+
+/* ------------------------------------------------------------ FSE (compression side); wave-uniform */
+__device__ inline int fse_min_log(uint32_t n, uint32_t max_sym)
+{
+    const int a = (int)hbit(n) + 1, b = (int)hbit(max_sym) + 2;
+    return a < b ? a : b;
+}
+__device__ inline int fse_optimal_log(int max_log, uint32_t n, uint32_t max_sym, int minus)
+{
+    const int max_src = (int)hbit(n - 1u) - minus;
+    int log = max_log;
+    const int min_bits = fse_min_log(n, max_sym);
+    if (max_src < log) log = max_src;
+    if (min_bits > log) log = min_bits;
+    if (log < 5) log = 5;
+    if (log > 12) log = 12;
+    return log;
+}
+
+__device__ int fse_norm_m2(int16_t *norm, int log, const uint32_t *count, uint32_t total_in, uint32_t max_sym,
+                           int16_t low_prob)
+{
+    const int16_t NYA = -2;
+    uint64_t total = total_in;
+    uint32_t distributed = 0;
+    const uint32_t low_thr = (uint32_t)(total >> log);
+    uint32_t low_one = (uint32_t)((total * 3u) >> (log + 1));
+    for (uint32_t s = 0; s <= max_sym; s++) {
+        const uint32_t c = count[s];
+        if (c == 0u) { norm[s] = 0; continue; }
+        if (c <= low_thr) { norm[s] = low_prob; distributed++; total -= c; continue; }
+        if (c <= low_one) { norm[s] = 1; distributed++; total -= c; continue; }
+        norm[s] = NYA;
+    }
+    uint32_t to_dist = (1u << log) - distributed;
+    if (to_dist == 0u) return 0;
+    if ((total / to_dist) > low_one) {
+        low_one = (uint32_t)((total * 3u) / (to_dist * 2u));
+        for (uint32_t s = 0; s <= max_sym; s++)
+            if (norm[s] == NYA && count[s] <= low_one) { norm[s] = 1; distributed++; total -= count[s]; }
+        to_dist = (1u << log) - distributed;
+    }
+    if (distributed == max_sym + 1u) {
+        uint32_t mv = 0, mc = 0;
+        for (uint32_t s = 0; s <= max_sym; s++) if (count[s] > mc) { mv = s; mc = count[s]; }
+        norm[mv] = (int16_t)(norm[mv] + (int16_t)to_dist);
+        return 0;
+    }
+    if (total == 0u) {
+        for (uint32_t s = 0; to_dist > 0u; s = (s + 1u) % (max_sym + 1u))
+            if (norm[s] > 0) { to_dist--; norm[s] = (int16_t)(norm[s] + 1); }
+        return 0;
+    }
+    {
+        const uint64_t vlog = 62u - (uint64_t)log, mid = (1ull << (vlog - 1u)) - 1u;
+        const uint64_t rstep = (((1ull << vlog) * to_dist) + mid) / total;
+        uint64_t tmp = mid;
+        for (uint32_t s = 0; s <= max_sym; s++) {
+            if (norm[s] == NYA) {
+                const uint64_t end = tmp + (uint64_t)count[s] * rstep;
+                const uint32_t w = (uint32_t)(end >> vlog) - (uint32_t)(tmp >> vlog);
+                if (w < 1u) return -1;
+                norm[s] = (int16_t)w;
+                tmp = end;
+            }
+        }
+    }
+    return 0;
+}
+
+/* FSE_normalizeCount (libzstd 1.4.8: low-probability symbols get -1 only when use_low_prob) */
+__device__ int fse_normalize(int16_t *norm, int log, const uint32_t *count, uint32_t total, uint32_t max_sym,
+                             bool use_low_prob)
+{
+    const uint32_t rtb[8] = {0, 473195, 504333, 520860, 550000, 700000, 750000, 830000};
+    const int16_t low_prob = use_low_prob ? -1 : 1;
+    const uint64_t scale = 62u - (uint64_t)log, step = (1ull << 62) / total, vstep = 1ull << (scale - 20u);
+    int still = 1 << log;
+    uint32_t largest = 0;
+    int16_t largest_p = 0;
+    const uint32_t low_thr = total >> log;
+    if (log < fse_min_log(total, max_sym)) return -1;
+    for (uint32_t s = 0; s <= max_sym; s++) {
+        const uint32_t c = count[s];
+        if (c == total) return 0;
+        if (c == 0u) { norm[s] = 0; continue; }
+        if (c <= low_thr) { norm[s] = low_prob; still--; }
+        else {
+            int16_t proba = (int16_t)(((uint64_t)c * step) >> scale);
+            if (proba < 8) {
+                const uint64_t rest = vstep * rtb[proba];
+                proba = (int16_t)(proba + ((((uint64_t)c * step) - ((uint64_t)proba << scale)) > rest ? 1 : 0));
+            }
+            if (proba > largest_p) { largest_p = proba; largest = s; }
+            norm[s] = proba;
+            still -= proba;
+        }
+    }
+    if (-still >= (norm[largest] >> 1)) { if (fse_norm_m2(norm, log, count, total, max_sym, low_prob)) return -1; }
+    else norm[largest] = (int16_t)(norm[largest] + (int16_t)still);
+    return log;
+}
+
+__device__ uint32_t fse_write_ncount(uint8_t *dst, const int16_t *norm, uint32_t max_sym, int log)
+{
+    BitW b;
+    b.init(dst);
+    const int table_size = 1 << log;
+    int remaining = table_size + 1, threshold = table_size, nb = log + 1;
+    bool prev0 = false;
+    uint32_t sym = 0;
+    const uint32_t alpha = max_sym + 1u;
+    b.add((uint64_t)(log - 5), 4);
+    while (sym < alpha && remaining > 1) {
+        if (prev0) {
+            uint32_t start = sym;
+            while (sym < alpha && !norm[sym]) sym++;
+            if (sym == alpha) break;
+            while (sym >= start + 24u) { start += 24u; b.add(0xFFFF, 16); }
+            while (sym >= start + 3u) { start += 3u; b.add(3, 2); }
+            b.add(sym - start, 2);
+        }
+        int count = norm[sym++];
+        const int max = (2 * threshold - 1) - remaining;
+        remaining -= count < 0 ? -count : count;
+        count++;
+        if (count >= threshold) count += max;
+        b.add((uint64_t)count, (uint32_t)(nb - (count < max ? 1 : 0)));
+        prev0 = (count == 1);
+        if (remaining < 1) return 0;
+        while (remaining < threshold) { nb--; threshold >>= 1; }
+    }
+    if (remaining != 1) return 0;
+    return b.flush();
+}
+
+__device__ void fse_build_ct(FseCt &ct, const int16_t *norm, uint32_t max_sym, int log, uint32_t *cumul, uint8_t *cell)
+{
+    const uint32_t size = 1u << log, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
+    uint32_t high = size - 1u, pos = 0;
+    ct.log = log;
+    cumul[0] = 0;
+    for (uint32_t u = 1; u <= max_sym + 1u; u++) {
+        const int c = norm[u - 1u];
+        if (c == -1) { cumul[u] = cumul[u - 1u] + 1u; cell[high--] = (uint8_t)(u - 1u); }
+        else cumul[u] = cumul[u - 1u] + (uint32_t)c;
+    }
+    cumul[max_sym + 1u] = size + 1u;
+    for (uint32_t u = 0; u <= max_sym; u++) {
+        const int c = norm[u];
+        for (int i = 0; i < c; i++) {
+            cell[pos] = (uint8_t)u;
+            pos = (pos + step) & mask;
+            while (pos > high) pos = (pos + step) & mask;
+        }
+    }
+    for (uint32_t u = 0; u < size; u++) {
+        const uint32_t s = cell[u];
+        const uint32_t k = cumul[s];
+        cumul[s] = k + 1u;
+        ct.state[k] = (uint16_t)(size + u);
+    }
+    uint32_t total = 0;
+    for (uint32_t s = 0; s <= max_sym; s++) {
+        const int c = norm[s];
+        if (c == 0) { ct.dnb[s] = ((uint32_t)(log + 1) << 16) - (1u << log); ct.dfind[s] = 0; }
+        else if (c == -1 || c == 1) { ct.dnb[s] = ((uint32_t)log << 16) - (1u << log); ct.dfind[s] = (int32_t)total - 1; total++; }
+        else {
+            const uint32_t max_out = (uint32_t)log - hbit((uint32_t)c - 1u);
+            ct.dnb[s] = (max_out << 16) - ((uint32_t)c << max_out);
+            ct.dfind[s] = (int32_t)total - c;
+            total += (uint32_t)c;
+        }
+    }
+}
+__device__ inline void fse_build_ct_rle(FseCt &ct, uint32_t sym)
+{
+    ct.log = 0;
+    ct.state[0] = 0; ct.state[1] = 0;
+    ct.dnb[sym] = 0; ct.dfind[sym] = 0;
+}
+__device__ inline uint32_t fse_init_state(const FseCt &ct, uint32_t sym)
+{
+    const uint32_t dnb = ct.dnb[sym];
+    const uint32_t nb = (dnb + (1u << 15)) >> 16;
+    const uint32_t v = (nb << 16) - dnb;
+    return ct.state[(int32_t)(v >> nb) + ct.dfind[sym]];
+}
+__device__ inline uint32_t fse_encode(BitW &b, const FseCt &ct, uint32_t state, uint32_t sym)
+{
+    const uint32_t nb = (state + ct.dnb[sym]) >> 16;
+    b.add(state, nb);
+    return ct.state[(int32_t)(state >> nb) + ct.dfind[sym]];
+}
+
+/* ------------------------------------------------------------ Huffman (compression side); wave-uniform */
+#define HN(i) ((i) + 1) /* library index -> LDS index */
+
+__device__ uint32_t huf_set_max_height(EncLds &L, uint32_t last, uint32_t max_nb)
+{
+    const uint32_t largest = L.nnb[HN(last)];
+    if (largest <= max_nb) return largest;
+    int total = 0, n = (int)last;
+    const uint32_t base = 1u << (largest - max_nb);
+    while (L.nnb[HN(n)] > max_nb) { total += (int)(base - (1u << (largest - L.nnb[HN(n)]))); L.nnb[HN(n)] = (uint8_t)max_nb; n--; }
+    while (L.nnb[HN(n)] == max_nb) n--;
+    total >>= (largest - max_nb);
+    const uint32_t none = 0xF0F0F0F0u;
+    uint32_t *rank_last = L.cumul; /* scratch: kHufLogMaxE + 2 entries */
+    for (int k = 0; k < kHufLogMaxE + 2; k++) rank_last[k] = none;
+    {
+        uint32_t cur = max_nb;
+        for (int pos = n; pos >= 0; pos--) {
+            const uint32_t nb = L.nnb[HN(pos)];
+            if (nb >= cur) continue;
+            cur = nb;
+            rank_last[max_nb - cur] = (uint32_t)pos;
+        }
+    }
+    while (total > 0) {
+        uint32_t dec = hbit((uint32_t)total) + 1u;
+        for (; dec > 1u; dec--) {
+            const uint32_t hp = rank_last[dec], lp = rank_last[dec - 1u];
+            if (hp == none) continue;
+            if (lp == none) break;
+            if (L.ncount[HN(hp)] <= 2u * L.ncount[HN(lp)]) break;
+        }
+        while (dec <= (uint32_t)kHufLogMaxE && rank_last[dec] == none) dec++;
+        total -= 1 << (dec - 1u);
+        if (rank_last[dec - 1u] == none) rank_last[dec - 1u] = rank_last[dec];
+        L.nnb[HN(rank_last[dec])] = (uint8_t)(L.nnb[HN(rank_last[dec])] + 1);
+        if (rank_last[dec] == 0u) rank_last[dec] = none;
+        else {
+            rank_last[dec] = rank_last[dec] - 1u;
+            if (L.nnb[HN(rank_last[dec])] != max_nb - dec) rank_last[dec] = none;
+        }
+    }
+    while (total < 0) {
+        if (rank_last[1] == none) {
+            while (L.nnb[HN(n)] == max_nb) n--;
+            L.nnb[HN(n + 1)] = (uint8_t)(L.nnb[HN(n + 1)] - 1);
+            rank_last[1] = (uint32_t)(n + 1);
+            total++;
+            continue;
+        }
+        L.nnb[HN(rank_last[1] + 1u)] = (uint8_t)(L.nnb[HN(rank_last[1] + 1u)] - 1);
+        rank_last[1] = rank_last[1] + 1u;
+        total++;
+    }
+    return max_nb;
+}
+
+/* HUF_buildCTable from L.hist[0..max_sym] into L.hval / L.hnb; returns the longest code length */
+__device__ uint32_t huf_build(EncLds &L, uint32_t max_sym, uint32_t max_nb, uint32_t lane)
+{
+    for (uint32_t i = lane; i < 516u; i += 64u) { L.ncount[i] = 0; L.nparent[i] = 0; L.nbyte[i] = 0; L.nnb[i] = 0; }
+    __builtin_amdgcn_wave_barrier();
+    /* sort by decreasing count, ties by increasing symbol (bucketed insertion sort) */
+    {
+        uint32_t *base = L.cumul;        /* 33 entries */
+        uint32_t *cur = L.cumul + 33;    /* 33 entries */
+        for (int k = 0; k < 33; k++) base[k] = 0;
+        for (uint32_t n = 0; n <= max_sym; n++) { const uint32_t r = hbit(L.hist[n] + 1u); base[r] = base[r] + 1u; }
+        for (int k = 30; k > 0; k--) base[k - 1] = base[k - 1] + base[k];
+        for (int k = 0; k < 32; k++) cur[k] = base[k];
+        for (uint32_t n = 0; n <= max_sym; n++) {
+            const uint32_t c = L.hist[n], r = hbit(c + 1u) + 1u;
+            uint32_t pos = cur[r];
+            cur[r] = pos + 1u;
+            while (pos > base[r] && c > L.ncount[HN(pos - 1u)]) {
+                L.ncount[HN(pos)] = L.ncount[HN(pos - 1u)];
+                L.nbyte[HN(pos)] = L.nbyte[HN(pos - 1u)];
+                pos--;
+            }
+            L.ncount[HN(pos)] = c;
+            L.nbyte[HN(pos)] = (uint8_t)n;
+        }
+    }
+    int non_null = (int)max_sym;
+    while (L.ncount[HN(non_null)] == 0u) non_null--;
+    int low_s = non_null, node_nb = 256, low_n = 256;
+    const int node_root = node_nb + low_s - 1;
+    L.ncount[HN(node_nb)] = L.ncount[HN(low_s)] + L.ncount[HN(low_s - 1)];
+    L.nparent[HN(low_s)] = (uint16_t)node_nb;
+    L.nparent[HN(low_s - 1)] = (uint16_t)node_nb;
+    node_nb++; low_s -= 2;
+    for (int n = node_nb; n <= node_root; n++) L.ncount[HN(n)] = 1u << 30;
+    L.ncount[0] = 1u << 31; /* fake entry, strong barrier (library index -1) */
+    while (node_nb <= node_root) {
+        const int n1 = (L.ncount[HN(low_s)] < L.ncount[HN(low_n)]) ? low_s-- : low_n++;
+        const int n2 = (L.ncount[HN(low_s)] < L.ncount[HN(low_n)]) ? low_s-- : low_n++;
+        L.ncount[HN(node_nb)] = L.ncount[HN(n1)] + L.ncount[HN(n2)];
+        L.nparent[HN(n1)] = (uint16_t)node_nb;
+        L.nparent[HN(n2)] = (uint16_t)node_nb;
+        node_nb++;
+    }
+    L.nnb[HN(node_root)] = 0;
+    for (int n = node_root - 1; n >= 256; n--) L.nnb[HN(n)] = (uint8_t)(L.nnb[HN(L.nparent[HN(n)])] + 1);
+    for (int n = 0; n <= non_null; n++) L.nnb[HN(n)] = (uint8_t)(L.nnb[HN(L.nparent[HN(n)])] + 1);
+    max_nb = huf_set_max_height(L, (uint32_t)non_null, max_nb);
+    {
+        uint32_t *per_rank = L.cumul;       /* 14 entries */
+        uint32_t *val_rank = L.cumul + 16;  /* 14 entries */
+        for (int k = 0; k < 14; k++) { per_rank[k] = 0; val_rank[k] = 0; }
+        for (int n = 0; n <= non_null; n++) { const uint32_t nb = L.nnb[HN(n)]; per_rank[nb] = per_rank[nb] + 1u; }
+        {
+            uint32_t min = 0;
+            for (int n = (int)max_nb; n > 0; n--) { val_rank[n] = min; min = (min + per_rank[n]) & 0xFFFFu; min >>= 1; }
+        }
+        for (uint32_t i = lane; i < 256u; i += 64u) { L.hval[i] = 0; L.hnb[i] = 0; }
+        __builtin_amdgcn_wave_barrier();
+        const int alpha = (int)max_sym + 1;
+        for (int n = 0; n < alpha; n++) L.hnb[L.nbyte[HN(n)]] = L.nnb[HN(n)];
+        for (int n = 0; n < alpha; n++) { const uint32_t nb = L.hnb[n]; const uint32_t v = val_rank[nb]; val_rank[nb] = v + 1u; L.hval[n] = (uint16_t)v; }
+    }
+    return max_nb;
+}
+
+/* HUF_compressWeights: 0 = not compressible, 1 = RLE, else size */
+__device__ uint32_t huf_compress_weights(EncLds &L, uint8_t *dst, uint32_t n)
+{
+    uint32_t *count = L.cumul + 40; /* 13 entries */
+    uint32_t max_sym = (uint32_t)kHufLogMaxE, max_count = 0;
+    if (n <= 1u) return 0;
+    for (uint32_t s = 0; s <= (uint32_t)kHufLogMaxE; s++) count[s] = 0;
+    for (uint32_t i = 0; i < n; i++) { const uint32_t wv = L.wts[i]; count[wv] = count[wv] + 1u; }
+    while (!count[max_sym]) max_sym--;
+    for (uint32_t s = 0; s <= max_sym; s++) if (count[s] > max_count) max_count = count[s];
+    if (max_count == n) return 1;
+    if (max_count == 1u) return 0;
+    const int log = fse_optimal_log(6, n, max_sym, 2);
+    if (fse_normalize(L.norm, log, count, n, max_sym, false) <= 0) return 0;
+    const uint32_t hsz = fse_write_ncount(dst, L.norm, max_sym, log);
+    if (!hsz) return 0;
+    fse_build_ct(L.wt, L.norm, max_sym, log, L.cumul, L.cell);
+    if (n <= 2u) return 0;
+    BitW b;
+    b.init(dst + hsz);
+    uint32_t ip = n, s1, s2;
+    if (n & 1u) {
+        s1 = fse_init_state(L.wt, L.wts[--ip]);
+        s2 = fse_init_state(L.wt, L.wts[--ip]);
+        s1 = fse_encode(b, L.wt, s1, L.wts[--ip]);
+    } else {
+        s2 = fse_init_state(L.wt, L.wts[--ip]);
+        s1 = fse_init_state(L.wt, L.wts[--ip]);
+    }
+    while (ip > 0u) {
+        s2 = fse_encode(b, L.wt, s2, L.wts[--ip]);
+        s1 = fse_encode(b, L.wt, s1, L.wts[--ip]);
+    }
+    b.add(s2, (uint32_t)L.wt.log);
+    b.add(s1, (uint32_t)L.wt.log);
+    return hsz + b.close();
+}
+
+/* HUF_writeCTable for L.hval/L.hnb; 0 = cannot be described (literals stay raw) */
+__device__ uint32_t huf_write_table(EncLds &L, uint8_t *dst, uint32_t max_sym, uint32_t log, uint32_t lane)
+{
+    for (uint32_t n = lane; n < max_sym; n += 64u) { const uint32_t nb = L.hnb[n]; L.wts[n] = (uint8_t)(nb ? log + 1u - nb : 0u); }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t hsz = huf_compress_weights(L, dst + 1, max_sym);
+    if (hsz > 1u && hsz < max_sym / 2u) { if (lane == 0) dst[0] = (uint8_t)hsz; return hsz + 1u; }
+    if (max_sym > 128u) return 0;
+    if (lane == 0) {
+        dst[0] = (uint8_t)(128u + (max_sym - 1u));
+        L.wts[max_sym] = 0;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t n = lane * 2u; n < max_sym; n += 128u) dst[n / 2u + 1u] = (uint8_t)((L.wts[n] << 4) + L.wts[n + 1u]);
+    return (max_sym + 1u) / 2u + 1u;
+}
+
+/* encode literals with the table (val, nb): 1 stream (lane 0) or 4 streams (lanes 0..3).
+ * Returns the total size written at dst+hsz (jump table included) + hsz, 0 = not compressible */
+__device__ uint32_t huf_encode_streams(EncLds &L, uint8_t *dst, uint32_t hsz, const uint8_t *src, uint32_t n,
+                                       const uint16_t *val, const uint8_t *nbt, bool single, uint32_t lane)
+{
+    const uint32_t nstreams = single ? 1u : 4u;
+    const uint32_t seg = single ? n : (n + 3u) / 4u;
+    if (!single && n < 12u) return 0;
+    /* pass 1: bit length of every stream, so each lane knows where its stream starts */
+    const uint32_t me = lane < nstreams ? lane : 0u;
+    const uint32_t beg = me * seg;
+    const uint32_t end = (me + 1u == nstreams) ? n : beg + seg;
+    uint32_t bits = 0;
+    if (lane < nstreams) for (uint32_t i = beg; i < end; i++) bits += nbt[src[i]];
+    const uint32_t bytes = (bits + 1u + 7u) >> 3; /* + end mark */
+    const uint32_t b0 = lane_get(bytes, 0), b1 = lane_get(bytes, 1), b2 = lane_get(bytes, 2), b3 = lane_get(bytes, 3);
+    uint32_t op = hsz;
+    uint32_t my_off;
+    if (single) { my_off = op; op += b0; }
+    else {
+        if (lane == 0) {
+            dst[hsz + 0] = (uint8_t)b0; dst[hsz + 1] = (uint8_t)(b0 >> 8);
+            dst[hsz + 2] = (uint8_t)b1; dst[hsz + 3] = (uint8_t)(b1 >> 8);
+            dst[hsz + 4] = (uint8_t)b2; dst[hsz + 5] = (uint8_t)(b2 >> 8);
+        }
+        op += 6u;
+        my_off = op + (me > 0u ? b0 : 0u) + (me > 1u ? b1 : 0u) + (me > 2u ? b2 : 0u);
+        op += b0 + b1 + b2 + b3;
+    }
+    /* pass 2: symbols from the end of the segment backwards, LSB-first packing */
+    if (lane < nstreams) {
+        BitW b;
+        b.init(dst + my_off);
+        for (uint32_t i = end; i > beg; i--) { const uint32_t c = src[i - 1u]; b.add(val[c], nbt[c]); }
+        b.close();
+    }
+    if (op >= n - 1u) return 0;
+    return op;
+}
+
+struct HufState { bool prev_valid; bool next_new; };
+
+/* ZSTD_compressLiterals; returns the literals-section size.  Updates hs.next_new. */
+__device__ uint32_t compress_literals(EncLds &L, uint8_t *dst, const uint8_t *src, uint32_t n, HufState &hs,
+                                      bool disable, uint32_t lane)
+{
+    hs.next_new = false;
+    const uint32_t fl = 1u + (n > 31u) + (n > 4095u);
+    auto raw = [&]() {
+        if (lane == 0) {
+            if (fl == 1u) dst[0] = (uint8_t)(0u + (n << 3));
+            else if (fl == 2u) { const uint32_t h = 0u + (1u << 2) + (n << 4); dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); }
+            else { const uint32_t h = 0u + (3u << 2) + (n << 4); dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16); }
+        }
+        for (uint32_t i = lane; i < n; i += 64u) dst[fl + i] = src[i];
+        return fl + n;
+    };
+    if (disable || n <= 63u) return raw();
+    const uint32_t lh = 3u + (n >= 1024u) + (n >= 16384u);
+    const bool single = n < 256u;
+    /* histogram */
+    for (uint32_t i = lane; i < 256u; i += 64u) L.hist[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < n; i += 64u) atomicAdd(&L.hist[src[i]], 1u);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t max_sym = 255, largest = 0;
+    while (!L.hist[max_sym]) max_sym--;
+    for (uint32_t s = 0; s <= max_sym; s++) { const uint32_t c = L.hist[s]; if (c > largest) largest = c; }
+    max_sym = uni(max_sym);
+    largest = uni(largest);
+    uint32_t c = 0;
+    bool reused = false;
+    if (largest == n) c = 1; /* RLE */
+    else if (largest <= (n >> 7) + 4u) c = 0;
+    else {
+        bool mode = hs.prev_valid;
+        if (mode) { /* HUF_validateCTable */
+            bool bad = false;
+            for (uint32_t s = 0; s <= max_sym; s++) bad |= (L.hist[s] != 0u) && (L.pnb[s] == 0u);
+            if (bad) mode = false;
+        }
+        if (n <= 1024u && mode) { reused = true; c = huf_encode_streams(L, dst + lh, 0, src, n, L.pval, L.pnb, single, lane); }
+        else {
+            uint32_t log = (uint32_t)fse_optimal_log(11, n, max_sym, 1);
+            log = huf_build(L, max_sym, log, lane);
+            __builtin_amdgcn_wave_barrier();
+            const uint32_t hsz = huf_write_table(L, dst + lh, max_sym, log, lane);
+            if (hsz == 0u) c = 0;
+            else {
+                bool use_old = false;
+                if (mode) {
+                    uint32_t old_bits = 0, new_bits = 0;
+                    for (uint32_t s = 0; s <= max_sym; s++) { const uint32_t k = L.hist[s]; old_bits += L.pnb[s] * k; new_bits += L.hnb[s] * k; }
+                    use_old = ((old_bits >> 3) <= hsz + (new_bits >> 3)) || (hsz + 12u >= n);
+                }
+                if (use_old) { reused = true; c = huf_encode_streams(L, dst + lh, 0, src, n, L.pval, L.pnb, single, lane); }
+                else if (hsz + 12u >= n) c = 0;
+                else { hs.next_new = true; c = huf_encode_streams(L, dst + lh, hsz, src, n, L.hval, L.hnb, single, lane); }
+            }
+        }
+    }
+    const uint32_t gain = (n >> 6) + 2u;
+    if (c == 0u || c >= n - gain) { hs.next_new = false; return raw(); }
+    if (c == 1u) {
+        hs.next_new = false;
+        if (lane == 0) {
+            if (fl == 1u) dst[0] = (uint8_t)(1u + (n << 3));
+            else if (fl == 2u) { const uint32_t h = 1u + (1u << 2) + (n << 4); dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); }
+            else { const uint32_t h = 1u + (3u << 2) + (n << 4); dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16); }
+            dst[fl] = src[0];
+        }
+        return fl + 1u;
+    }
+    if (lane == 0) {
+        const uint32_t ht = reused ? 3u : 2u;
+        if (lh == 3u) { const uint32_t h = ht + ((single ? 0u : 1u) << 2) + (n << 4) + (c << 14); dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16); }
+        else if (lh == 4u) { const uint32_t h = ht + (2u << 2) + (n << 4) + (c << 18); dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16); dst[3] = (uint8_t)(h >> 24); }
+        else { const uint32_t h = ht + (3u << 2) + (n << 4) + (c << 22); dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16); dst[3] = (uint8_t)(h >> 24); dst[4] = (uint8_t)(c >> 10); }
+    }
+    return lh + c;
+}
+
+/* ------------------------------------------------------------ sequences */
+__constant__ uint8_t kELLBits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6,
+    7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__constant__ uint8_t kEMLBits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+    0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__constant__ int16_t kELLDef[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3,
+    2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__constant__ int16_t kEMLDef[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
+    1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+__constant__ int16_t kEOFDef[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1,
+    -1, -1, -1};
+__constant__ uint8_t kLLCode[64] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 16, 17, 17, 18, 18, 19,
+    19, 20, 20, 20, 20, 21, 21, 21, 21, 22, 22, 22, 22, 22, 22, 22, 22, 23, 23, 23, 23, 23, 23, 23, 23, 24, 24,
+    24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24};
+__constant__ uint8_t kMLCode[128] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22,
+    23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 32, 33, 33, 34, 34, 35, 35, 36, 36, 36, 36, 37, 37, 37, 37, 38, 38,
+    38, 38, 38, 38, 38, 38, 39, 39, 39, 39, 39, 39, 39, 39, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40, 40,
+    40, 40, 40, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 42, 42, 42, 42, 42, 42, 42, 42,
+    42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42};
+
+enum { SET_BASIC = 0, SET_RLE = 1, SET_COMPRESSED = 2 };
+
+__device__ inline int select_type(uint32_t most, uint32_t nseq, int def_log, bool def_allowed)
+{
+    if (most == nseq) return (def_allowed && nseq <= 2u) ? SET_BASIC : SET_RLE;
+    if (def_allowed) {
+        const uint32_t dyn_min = ((1u << def_log) * 9u) >> 3; /* strategy fast: mult = 10 - 1 */
+        if (nseq < dyn_min || most < (nseq >> (def_log - 1))) return SET_BASIC;
+    }
+    return SET_COMPRESSED;
+}
+
+/* histogram of `codes` into L.hist (lane-parallel); returns max symbol and most frequent count */
+__device__ void hist_codes(EncLds &L, const uint8_t *codes, uint32_t nseq, uint32_t max_in, uint32_t *max_out,
+                           uint32_t *most_out, uint32_t lane)
+{
+    for (uint32_t i = lane; i < 64u; i += 64u) L.hist[i] = 0;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i = lane; i < nseq; i += 64u) atomicAdd(&L.hist[codes[i]], 1u);
+    __builtin_amdgcn_wave_barrier();
+    uint32_t max = max_in, most = 0;
+    while (!L.hist[max]) max--;
+    for (uint32_t s = 0; s <= max; s++) { const uint32_t c = L.hist[s]; if (c > most) most = c; }
+    *max_out = uni(max);
+    *most_out = uni(most);
+}
+
+/* ZSTD_buildCTable; returns bytes of table description, 0xFFFFFFFF on error */
+__device__ uint32_t build_ctable(EncLds &L, uint8_t *dst, FseCt &ct, int fse_log, int type, uint32_t max,
+                                 const uint8_t *codes, uint32_t nseq, const int16_t *def_norm, int def_log,
+                                 uint32_t def_max, uint32_t lane)
+{
+    if (type == SET_RLE) { fse_build_ct_rle(ct, max); if (lane == 0) dst[0] = codes[0]; return 1; }
+    if (type == SET_BASIC) {
+        for (uint32_t i = 0; i <= def_max; i++) L.norm[i] = def_norm[i];
+        fse_build_ct(ct, L.norm, def_max, def_log, L.cumul, L.cell);
+        return 0;
+    }
+    uint32_t n1 = nseq;
+    const int log = fse_optimal_log(fse_log, nseq, max, 2);
+    const uint32_t lastc = uni(codes[nseq - 1u]);
+    if (L.hist[lastc] > 1u) { L.hist[lastc] = L.hist[lastc] - 1u; n1--; }
+    if (fse_normalize(L.norm, log, L.hist, n1, max, n1 >= 2048u) <= 0) return 0xFFFFFFFFu;
+    const uint32_t sz = fse_write_ncount(dst, L.norm, max, log);
+    if (!sz) return 0xFFFFFFFFu;
+    fse_build_ct(ct, L.norm, max, log, L.cumul, L.cell);
+    return sz;
+}
+
+/* literals + sequences -> compressed block body at dst; 0 = emit a raw block */
+__device__ uint32_t compress_sequences(EncLds &L, uint8_t *dst, uint8_t *ws, uint32_t nseq, uint32_t nlit,
+                                       uint32_t src_size, uint32_t long_pos, uint32_t long_kind, HufState &hs,
+                                       bool disable_lit, uint32_t lane)
+{
+    const uint2 *seqs = reinterpret_cast<const uint2 *>(ws + kWsSeq);
+    const uint8_t *lits = ws + kWsLit;
+    uint8_t *llc = ws + kWsLlc, *ofc = ws + kWsOfc, *mlc = ws + kWsMlc;
+    uint32_t op = compress_literals(L, dst, lits, nlit, hs, disable_lit, lane);
+    if (lane == 0) {
+        if (nseq < 128u) dst[op] = (uint8_t)nseq;
+        else if (nseq < 0x7F00u) { dst[op] = (uint8_t)((nseq >> 8) + 0x80u); dst[op + 1] = (uint8_t)nseq; }
+        else { dst[op] = 0xFF; dst[op + 1] = (uint8_t)(nseq - 0x7F00u); dst[op + 2] = (uint8_t)((nseq - 0x7F00u) >> 8); }
+    }
+    op += nseq < 128u ? 1u : (nseq < 0x7F00u ? 2u : 3u);
+    const uint32_t gain = (src_size >> 6) + 2u;
+    if (nseq == 0u) return (op >= src_size - gain) ? 0u : op;
+    const uint32_t seq_head = op++;
+    for (uint32_t i = lane; i < nseq; i += 64u) {
+        const uint2 q = seqs[i];
+        const uint32_t ll = q.y & 0xFFFFu, mlb = q.y >> 16;
+        llc[i] = (uint8_t)(ll > 63u ? hbit(ll) + 19u : kLLCode[ll]);
+        ofc[i] = (uint8_t)hbit(q.x);
+        mlc[i] = (uint8_t)(mlb > 127u ? hbit(mlb) + 36u : kMLCode[mlb]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    if (lane == 0) {
+        if (long_kind == 1u) llc[long_pos] = (uint8_t)kMaxLL;
+        if (long_kind == 2u) mlc[long_pos] = (uint8_t)kMaxML;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    uint32_t max, most, last_ncount = 0xFFFFFFFFu;
+    hist_codes(L, llc, nseq, kMaxLL, &max, &most, lane);
+    const int tll = select_type(most, nseq, 6, true);
+    uint32_t sz = build_ctable(L, dst + op, L.ll, 9, tll, max, llc, nseq, kELLDef, 6, kMaxLL, lane);
+    if (sz == 0xFFFFFFFFu) return 0;
+    if (tll == SET_COMPRESSED) last_ncount = op;
+    op += sz;
+    hist_codes(L, ofc, nseq, kMaxOff, &max, &most, lane);
+    const int tof = select_type(most, nseq, 5, max <= kDefMaxOff);
+    sz = build_ctable(L, dst + op, L.of, 8, tof, max, ofc, nseq, kEOFDef, 5, kDefMaxOff, lane);
+    if (sz == 0xFFFFFFFFu) return 0;
+    if (tof == SET_COMPRESSED) last_ncount = op;
+    op += sz;
+    hist_codes(L, mlc, nseq, kMaxML, &max, &most, lane);
+    const int tml = select_type(most, nseq, 6, true);
+    sz = build_ctable(L, dst + op, L.ml, 9, tml, max, mlc, nseq, kEMLDef, 6, kMaxML, lane);
+    if (sz == 0xFFFFFFFFu) return 0;
+    if (tml == SET_COMPRESSED) last_ncount = op;
+    op += sz;
+    if (lane == 0) dst[seq_head] = (uint8_t)((tll << 6) + (tof << 4) + (tml << 2));
+    __builtin_amdgcn_wave_barrier();
+    /* interleaved bitstream, last sequence first (wave-uniform) */
+    {
+        BitW b;
+        b.init(dst + op);
+        uint32_t n = nseq - 1u;
+        uint32_t lc = uni(llc[n]), oc = uni(ofc[n]), mc = uni(mlc[n]);
+        uint2 q = seqs[n];
+        uint32_t sm = fse_init_state(L.ml, mc), so = fse_init_state(L.of, oc), sl = fse_init_state(L.ll, lc);
+        b.add(uni(q.y) & 0xFFFFu, kELLBits[lc]);
+        b.add(uni(q.y) >> 16, kEMLBits[mc]);
+        b.add(uni(q.x), oc);
+        while (n-- > 0u) {
+            lc = uni(llc[n]); oc = uni(ofc[n]); mc = uni(mlc[n]);
+            q = seqs[n];
+            so = fse_encode(b, L.of, so, oc);
+            sm = fse_encode(b, L.ml, sm, mc);
+            sl = fse_encode(b, L.ll, sl, lc);
+            b.add(uni(q.y) & 0xFFFFu, kELLBits[lc]);
+            b.add(uni(q.y) >> 16, kEMLBits[mc]);
+            b.add(uni(q.x), oc);
+        }
+        b.add(sm, (uint32_t)L.ml.log);
+        b.add(so, (uint32_t)L.of.log);
+        b.add(sl, (uint32_t)L.ll.log);
+        op += b.close();
+        if (last_ncount != 0xFFFFFFFFu && op - last_ncount < 4u) return 0;
+    }
+    if (op >= src_size - gain) return 0;
+    return op;
+}
+
+/* ------------------------------------------------------------ match finder: strategy `fast` */
+struct CPar { int wlog, hlog, mml, tlen; };
+
+__device__ inline uint32_t hash_ptr(const uint8_t *p, int hlog, int mls)
+{
+    switch (mls) {
+    default:
+    case 4: return (ld32u(p) * 2654435761u) >> (32 - hlog);
+    case 5: return (uint32_t)(((ld64u(p) << 24) * 889523592379ull) >> (64 - hlog));
+    case 6: return (uint32_t)(((ld64u(p) << 16) * 227718039650203ull) >> (64 - hlog));
+    case 7: return (uint32_t)(((ld64u(p) << 8) * 58295818150454627ull) >> (64 - hlog));
+    }
+}
+
+/* bytes equal from a/b forward, limited by end (64 bytes per step) */
+__device__ inline uint32_t count_match(const uint8_t *a, const uint8_t *b, const uint8_t *end, uint32_t lane)
+{
+    uint32_t done = 0;
+    for (;;) {
+        const bool inb = a + done + lane < end;
+        const bool eq = inb && a[done + lane] == b[done + lane];
+        const unsigned long long neq = __ballot(!eq);
+        if (neq != 0ull) return done + ctz64(neq);
+        done += 64u;
+    }
+}
+
+struct SeqStore { uint32_t nseq, nlit, long_pos, long_kind; };
+
+__device__ inline void store_seq(uint8_t *ws, SeqStore &ss, uint32_t ll, const uint8_t *lit, uint32_t offcode,
+                                 uint32_t mlbase, uint32_t lane)
+{
+    uint8_t *lits = ws + kWsLit;
+    for (uint32_t i = lane; i < ll; i += 64u) lits[ss.nlit + i] = lit[i];
+    ss.nlit += ll;
+    if (ll > 0xFFFFu) { ss.long_kind = 1; ss.long_pos = ss.nseq; }
+    if (mlbase > 0xFFFFu) { ss.long_kind = 2; ss.long_pos = ss.nseq; }
+    if (lane == 0) reinterpret_cast<uint2 *>(ws + kWsSeq)[ss.nseq] = make_uint2(offcode + 1u, (ll & 0xFFFFu) | (mlbase << 16));
+    ss.nseq++;
+}
+
+/* ZSTD_compressBlock_fast; `table` is a generic pointer (LDS or global).  base = src - 1. */
+__device__ uint32_t block_fast(uint32_t *table, const CPar &cp, const uint8_t *base, const uint8_t *istart,
+                               uint32_t n, uint32_t *rep, uint8_t *ws, SeqStore &ss, uint32_t dict_limit,
+                               uint32_t lane)
+{
+    const int hlog = cp.hlog, mls = cp.mml < 4 ? 4 : (cp.mml > 7 ? 7 : cp.mml);
+    const uint32_t step_size = (uint32_t)cp.tlen + (cp.tlen ? 0u : 1u) + 1u;
+    const uint8_t *ip0 = istart, *ip1, *anchor = istart;
+    const uint32_t end_index = (uint32_t)(istart - base) + n;
+    const uint32_t max_dist = 1u << cp.wlog;
+    const uint32_t prefix_idx = (end_index - dict_limit > max_dist) ? end_index - max_dist : dict_limit;
+    const uint8_t *prefix = base + prefix_idx;
+    const uint8_t *iend = istart + n, *ilimit = iend - 8;
+    uint32_t off1 = rep[0], off2 = rep[1], saved = 0;
+    if (ip0 == prefix) ip0++;
+    ip1 = ip0 + 1;
+    {
+        const uint32_t cur = (uint32_t)(ip0 - base);
+        const uint32_t wlow = (cur - dict_limit > max_dist) ? cur - max_dist : dict_limit;
+        const uint32_t max_rep = cur - wlow;
+        if (off2 > max_rep) { saved = off2; off2 = 0; }
+        if (off1 > max_rep) { saved = off1; off1 = 0; }
+    }
+    while (ip1 < ilimit) {
+        uint32_t mlen, offcode;
+        const uint8_t *ip2 = ip0 + 2;
+        const uint32_t h0 = hash_ptr(ip0, hlog, mls), h1 = hash_ptr(ip1, hlog, mls);
+        const uint32_t v0 = ld32u(ip0), v1 = ld32u(ip1);
+        const uint32_t cur0 = (uint32_t)(ip0 - base), cur1 = (uint32_t)(ip1 - base);
+        const uint32_t mi0 = uni(table[h0]);
+        const uint32_t mi1 = uni(table[h1]);   /* read before either store, as the library does */
+        const uint8_t *m0 = base + mi0, *m1 = base + mi1;
+        table[h0] = cur0;
+        table[h1] = cur1;
+        bool have = false;
+        if (off1 > 0u && ld32u(ip2 - off1) == ld32u(ip2)) {
+            const uint8_t *rep_m = ip2 - off1;
+            mlen = (uni(ip2[-1]) == uni(rep_m[-1])) ? 1u : 0u;
+            ip0 = ip2 - mlen;
+            m0 = rep_m - mlen;
+            mlen += 4u;
+            offcode = 0;
+            have = true;
+        } else {
+            bool found = false;
+            if (mi0 > prefix_idx && ld32u(m0) == v0) found = true;
+            else if (mi1 > prefix_idx && ld32u(m1) == v1) { ip0 = ip1; m0 = m1; found = true; }
+            if (found) {
+                off2 = off1;
+                off1 = (uint32_t)(ip0 - m0);
+                offcode = off1 + 2u;
+                mlen = 4u;
+                while (ip0 > anchor && m0 > prefix && uni(ip0[-1]) == uni(m0[-1])) { ip0--; m0--; mlen++; }
+                have = true;
+            }
+        }
+        if (!have) {
+            const uint32_t step = ((uint32_t)(ip0 - anchor) >> 7) + step_size;
+            ip0 += step;
+            ip1 += step;
+            continue;
+        }
+        mlen += count_match(ip0 + mlen, m0 + mlen, iend, lane);
+        store_seq(ws, ss, (uint32_t)(ip0 - anchor), anchor, offcode, mlen - 3u, lane);
+        ip0 += mlen;
+        anchor = ip0;
+        if (ip0 <= ilimit) {
+            table[hash_ptr(base + cur0 + 2u, hlog, mls)] = cur0 + 2u;
+            table[hash_ptr(ip0 - 2, hlog, mls)] = (uint32_t)(ip0 - 2 - base);
+            if (off2 > 0u) {
+                while (ip0 <= ilimit && ld32u(ip0) == ld32u(ip0 - off2)) {
+                    const uint32_t rlen = count_match(ip0 + 4, ip0 + 4 - off2, iend, lane) + 4u;
+                    const uint32_t t = off2; off2 = off1; off1 = t;
+                    table[hash_ptr(ip0, hlog, mls)] = (uint32_t)(ip0 - base);
+                    ip0 += rlen;
+                    store_seq(ws, ss, 0, anchor, 0, rlen - 3u, lane);
+                    anchor = ip0;
+                }
+            }
+        }
+        ip1 = ip0 + 1;
+    }
+    rep[0] = off1 ? off1 : saved;
+    rep[1] = off2 ? off2 : saved;
+    return (uint32_t)(iend - anchor);
+}
+
+} // namespace
+
+__global__ void __launch_bounds__(64)
+k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t n_blocks,
+           uint8_t *__restrict__ dst_base, uint64_t dst_stride, int wlog, int hlog, int mml, int tlen,
+           uint32_t *__restrict__ out_size, int32_t *__restrict__ status, uint8_t *workspace)
+{
+    __shared__ EncLds L;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint8_t *ws = workspace + (uint64_t)blockIdx.x * kWsBytes;
+    CPar cp;
+    cp.wlog = wlog; cp.hlog = hlog; cp.mml = mml; cp.tlen = tlen;
+    uint32_t *table = (hlog <= 13) ? L.hash : reinterpret_cast<uint32_t *>(ws + kWsHash);
+
+    for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint8_t *src = src_base + blk * src_stride;
+        uint8_t *dst = dst_base + blk * dst_stride;
+        for (uint32_t i = lane; i < (1u << hlog); i += 64u) table[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint32_t op;
+        {
+            const uint64_t wsize = 1ull << wlog;
+            const uint32_t single = wsize >= n ? 1u : 0u;
+            const uint32_t fcs = (n >= 256u) + (n >= 65536u + 256u);
+            if (lane == 0) {
+                dst[0] = 0x28; dst[1] = 0xB5; dst[2] = 0x2F; dst[3] = 0xFD;
+                dst[4] = (uint8_t)((single << 5) + (fcs << 6));
+            }
+            op = 5;
+            if (!single) { if (lane == 0) dst[op] = (uint8_t)((wlog - 10) << 3); op++; }
+            if (fcs == 0u) { if (single) { if (lane == 0) dst[op] = (uint8_t)n; op++; } }
+            else if (fcs == 1u) { if (lane == 0) { dst[op] = (uint8_t)(n - 256u); dst[op + 1] = (uint8_t)((n - 256u) >> 8); } op += 2; }
+            else { if (lane == 0) { dst[op] = (uint8_t)n; dst[op + 1] = (uint8_t)(n >> 8); dst[op + 2] = (uint8_t)(n >> 16); dst[op + 3] = (uint8_t)(n >> 24); } op += 4; }
+        }
+        uint32_t rep[3] = {1, 4, 8};
+        uint32_t dict_limit = 1;
+        const uint8_t *base = src - 1;
+        bool first = true;
+        HufState hs;
+        hs.prev_valid = false; hs.next_new = false;
+        uint32_t ip = 0;
+        while (ip < n) {
+            const uint32_t bs = (n - ip < kZBlk) ? n - ip : kZBlk;
+            const uint32_t last = (ip + bs == n) ? 1u : 0u;
+            uint32_t csize = 0;
+            {
+                const uint32_t end_idx = ip + bs + 1u;
+                const uint32_t max_dist = 1u << wlog;
+                if (end_idx > max_dist && dict_limit < end_idx - max_dist) dict_limit = end_idx - max_dist;
+            }
+            if (bs >= 7u) {
+                SeqStore ss;
+                ss.nseq = 0; ss.nlit = 0; ss.long_pos = 0; ss.long_kind = 0;
+                uint32_t nrep[3] = {rep[0], rep[1], rep[2]};
+                const uint32_t last_ll = block_fast(table, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane);
+                for (uint32_t i = lane; i < last_ll; i += 64u) (ws + kWsLit)[ss.nlit + i] = src[ip + bs - last_ll + i];
+                ss.nlit += last_ll;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                csize = compress_sequences(L, dst + op + 3, ws, ss.nseq, ss.nlit, bs, ss.long_pos, ss.long_kind, hs,
+                                           tlen > 0, lane);
+                if (!first && csize < 25u) { /* RLE block for constant non-first blocks */
+                    const uint32_t b0 = uni(src[ip]);
+                    bool diff = false;
+                    for (uint32_t i = lane; i < bs; i += 64u) diff |= (src[ip + i] != b0);
+                    if (__ballot(diff) == 0ull) { csize = 1; if (lane == 0) dst[op + 3] = (uint8_t)b0; }
+                }
+                if (csize > 1u) {
+                    rep[0] = nrep[0]; rep[1] = nrep[1]; rep[2] = nrep[2];
+                    if (hs.next_new) {
+                        for (uint32_t i = lane; i < 256u; i += 64u) { L.pval[i] = L.hval[i]; L.pnb[i] = L.hnb[i]; }
+                        hs.prev_valid = true;
+                    }
+                }
+            }
+            if (csize == 0u) {
+                const uint32_t h = last + (0u << 1) + (bs << 3);
+                if (lane == 0) { dst[op] = (uint8_t)h; dst[op + 1] = (uint8_t)(h >> 8); dst[op + 2] = (uint8_t)(h >> 16); }
+                for (uint32_t i = lane; i < bs; i += 64u) dst[op + 3u + i] = src[ip + i];
+                op += 3u + bs;
+            } else {
+                const uint32_t h = csize == 1u ? last + (1u << 1) + (bs << 3) : last + (2u << 1) + (csize << 3);
+                if (lane == 0) { dst[op] = (uint8_t)h; dst[op + 1] = (uint8_t)(h >> 8); dst[op + 2] = (uint8_t)(h >> 16); }
+                op += 3u + csize;
+            }
+            ip += bs;
+            first = false;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane == 0) { out_size[blk] = op; status[blk] = CRYO_ST_OK; }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+/* ZSTD_getCParams + ZSTD_adjustCParams for the `fast` levels at cryo block sizes (oracle-checked) */
+static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *mml, int *tlen)
+{
+    static const int big[3][3] = {{19, 13, 6}, {19, 14, 7}, {20, 16, 6}};   /* n > 256 KiB: wlog, hlog, mml */
+    static const int k128[3][3] = {{17, 12, 5}, {17, 13, 6}, {17, 15, 5}};  /* 16 KiB < n <= 128 KiB       */
+    const int (*t)[3];
+    if (level == 0) level = 3;
+    if (level > 2 || level < -131072) return false;
+    if (n > 256u * 1024u) t = big;
+    else if (n > 16u * 1024u && n <= 128u * 1024u) t = k128;
+    else return false;
+    const int row = level < 0 ? 0 : level;
+    *wlog = t[row][0]; *hlog = t[row][1]; *mml = t[row][2];
+    *tlen = level < 0 ? -level : 0;
+    int srclog = 0;
+    for (uint32_t v = n - 1u; v; v >>= 1) srclog++;
+    if (n < 64u) srclog = 6;
+    if (*wlog > srclog) *wlog = srclog;
+    if (*hlog > *wlog + 1) *hlog = *wlog + 1;
+    if (*wlog < 10) *wlog = 10;
+    return true;
+}
+
+static uint32_t zstd_enc_grid(uint64_t n_blocks)
+{
+    const uint64_t cap = 256u * 2u; /* 2 workgroups per CU (LDS ~56 KiB each) */
+    return (uint32_t)(n_blocks < cap ? n_blocks : cap);
+}
+
+size_t zstd_compress_workspace(uint64_t n_blocks) { return (size_t)zstd_enc_grid(n_blocks) * kWsBytes + 256; }
+
+bool zstd_compress_supported(int level, uint32_t block_size)
+{
+    int a, b, c, d;
+    return zstd_fast_cparams(level, block_size, &a, &b, &c, &d);
+}
+
+hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t src_stride, uint32_t block_size,
+                                uint64_t n_blocks, uint8_t *d_dst, uint64_t dst_stride, int level,
+                                uint32_t *d_out_size, int32_t *d_status, void *d_workspace, size_t workspace_bytes)
+{
+    if (n_blocks == 0) return hipSuccess;
+    int wlog, hlog, mml, tlen;
+    if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen)) return hipErrorNotSupported;
+    const uint32_t grid = zstd_enc_grid(n_blocks);
+    if (workspace_bytes < (size_t)grid * kWsBytes) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_zstd_enc, dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst,
+                       dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status, (uint8_t *)d_workspace);
+    return hipGetLastError();
+}
+
+} // namespace cryo

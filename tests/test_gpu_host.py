@@ -107,6 +107,14 @@ def test_gpu_compression_h_surface(HG, oracle):
     assert np.array_equal(out, raw)
     assert L.cryo_decompress(host.COMP_LZ4, comp.ctypes.data, len(comp) - 9, out.ctypes.data) is False
     assert not errors
-    # zstd encode kernel is not in this build: the shim raises the reference's error, it does not fall back
+    # zstd at the reference's default level 1 (compression.c:18): bytes identical to libzstd 1.4.8
+    p = L.cryo_compress(host.COMP_ZSTD, raw.ctypes.data, C.byref(n))
+    zc = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value,)).copy()
+    assert np.array_equal(zc, oracle.zstd_compress(raw, 1))
+    assert L.cryo_decompress(host.COMP_ZSTD, zc.ctypes.data, len(zc), out.ctypes.data) is True
+    assert np.array_equal(out, raw) and not errors
+    # levels above 2 (dfast .. btultra2) have no kernel: the reference's error is raised, no CPU fallback
+    host.set_int("zstd_compression_level_guc", 9)
     L.cryo_compress(host.COMP_ZSTD, raw.ctypes.data, C.byref(n))
     assert errors and errors[-1][1].startswith("pg_cryogen: compression failed")
+    host.set_int("zstd_compression_level_guc", 1)

@@ -126,3 +126,42 @@ def test_zstd_single_block_host_api(codec, oracle):
     out = codec.decompress_block(METHOD_ZSTD, c, B)
     assert np.array_equal(out, raw)
     assert codec.decompress_block(METHOD_ZSTD, c[:-3], B) is None
+
+
+# ---------------- zstd encode (strategy `fast`: levels -5..2), reference compression.c:102-104 ----------------
+@pytest.mark.parametrize("B", [131072, 1 << 20, 65546, 20000])
+def test_zstd_encode_bit_exact(codec, oracle, B):
+    blocks = [oracle.synth(3, blk, B, dist) for dist in range(5) for blk in range(2)]
+    for lvl in (-5, -1, 1, 2):
+        got = codec.compress_blocks(METHOD_ZSTD, lvl, blocks)
+        for i, b in enumerate(blocks):
+            exp = oracle.zstd_compress(b, lvl)
+            assert len(exp) > 0
+            assert len(got[i]) == len(exp), (B, lvl, i, len(got[i]), len(exp))
+            assert np.array_equal(got[i], exp), (B, lvl, i)
+
+
+def test_zstd_encode_matches_golden_vectors(codec, oracle):
+    cells = [c for c in json.load(open(os.path.join(G, "vectors.json")))["cells"]
+             if c["method"] == "zstd" and c["param"] <= 2 and c["B"] == 131072]
+    assert len(cells) >= 40
+    for lvl in sorted(set(c["param"] for c in cells)):
+        sub = [c for c in cells if c["param"] == lvl]
+        blocks = [oracle.synth(0, c["block"], c["B"], c["dist"]) for c in sub]
+        got = codec.compress_blocks(METHOD_ZSTD, lvl, blocks)
+        for c, g in zip(sub, got):
+            assert len(g) == c["csize"] and sha(g) == c["comp_sha256"], c
+
+
+def test_zstd_roundtrip_on_device_and_unsupported_levels(codec, oracle):
+    from pg_cryogen_amd.codec import CryoError, E_UNSUPPORTED
+    B = 131072
+    blocks = [oracle.synth(8, i, B, i % 5) for i in range(10)]
+    comps = codec.compress_blocks(METHOD_ZSTD, 1, blocks)
+    outs, st = codec.decompress_blocks(METHOD_ZSTD, comps, B)
+    assert (st == 0).all()
+    for b, o in zip(blocks, outs):
+        assert np.array_equal(b, o)
+    with pytest.raises(CryoError) as e:
+        codec.compress_blocks(METHOD_ZSTD, 3, blocks[:1])      # dfast and above: no kernel (no CPU fallback)
+    assert e.value.code == E_UNSUPPORTED
