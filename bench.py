@@ -42,6 +42,10 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="diagnostic ablation runs only: result is not valid")
+    ap.add_argument("--workload", default="lz4_decode", choices=["lz4_decode", "zstd", "lz4"],
+                    help="lz4_decode = headline (BASELINE configs[1]); zstd / lz4 = compress+decompress of the same "
+                         "batch (configs[2] shape), a secondary measurement")
+    ap.add_argument("--level", type=int, default=1, help="zstd level for --workload zstd")
     return ap.parse_args()
 
 
@@ -86,6 +90,76 @@ def cpu_baseline(comps, B, budget_s, method=0):
     return res
 
 
+def bench_roundtrip(a, codec, rank, world, barrier, torch, dist):
+    """secondary workload: compress + decompress of the rank's batch (BASELINE configs[2] shape)"""
+    from pg_cryogen_amd import METHOD_LZ4, METHOD_ZSTD, bound
+    from pg_cryogen_amd.codec import DIST_NAMES
+    import oracle_lib
+    method = METHOD_ZSTD if a.workload == "zstd" else METHOD_LZ4
+    param = a.level if method == METHOD_ZSTD else a.accel
+    B, n = a.block_size, a.blocks
+    dist_id = DIST_NAMES.index(a.dist)
+    stride = (bound(method, B) + 15) & ~15
+    d_raw, d_comp, d_out = codec.alloc(n * B), codec.alloc(n * stride), codec.alloc(n * B)
+    d_sizes, d_status, d_off, d_mis = codec.alloc(4 * n), codec.alloc(4 * n), codec.alloc(8 * n), codec.alloc(8)
+    codec.synth_batch(0, rank, n, B, dist_id, d_raw, block_step=world)
+    d_off.upload(np.arange(n, dtype=np.uint64) * np.uint64(stride))
+    enc_ms, dec_ms = [], []
+
+    def step(timed):
+        codec.timer_start()
+        codec.compress_batch(method, param, d_raw, B, B, n, d_comp, stride, d_sizes, d_status)
+        t1 = codec.timer_stop()
+        codec.timer_start()
+        codec.decompress_batch(method, d_comp, d_off, d_sizes, d_out, B, B, n, d_status)
+        t2 = codec.timer_stop()
+        if timed:
+            enc_ms.append(t1)
+            dec_ms.append(t2)
+    for _ in range(a.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step(True)
+    codec.sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    assert (d_status.download(dtype=np.int32) == 0).all()
+    d_mis.memset(0)
+    codec.compare_batch(d_raw, B, d_out, B, B, n, d_mis)
+    codec.sync()
+    assert int(d_mis.download(dtype=np.uint64)[0]) == 0, "round trip mismatch"
+    sizes = d_sizes.download(dtype=np.uint32)
+    ora = oracle_lib.Oracle()
+    for i in sorted(set(list(range(0, n, max(1, n // 8)))[:8] + [n - 1])):
+        c = d_comp.download(int(sizes[i]), offset=i * stride)
+        raw = ora.synth(0, rank + i * world, B, dist_id)
+        exp = ora.zstd_compress(raw, param) if method == METHOD_ZSTD else ora.lz4_compress(raw, param)
+        assert np.array_equal(c, exp), "device encode differs from oracle at block %d" % i
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        comp_bytes = int(sizes.astype(np.uint64).sum())
+        e, d = float(np.mean(enc_ms)), float(np.mean(dec_ms))
+        algo = 2 * (n * B + comp_bytes)
+        print(json.dumps({
+            "metric": "%s_compress_plus_decompress_uncompressed_GBps" % a.workload,
+            "value": round(2 * n * world * B * a.steps / float(t[0]) / 1e9, 2), "unit": "GB/s", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(float(t[0]) / a.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "%s param %d: compress + decompress %d x %d KiB synthetic cryo blocks per GPU"
+                                   % (a.workload, param, n, B // 1024), "distribution": a.dist,
+                       "compression_ratio": round(n * B / comp_bytes, 3),
+                       "encode_GBps": round(n * B / (e * 1e-3) / 1e9, 2), "decode_GBps": round(n * B / (d * 1e-3) / 1e9, 2),
+                       "bit_exact": "encode == oracle (libzstd 1.4.8 / liblz4 1.9.3 pinned) on sampled blocks; "
+                                    "decode == original on all blocks"},
+            "roofline": {"bound": "hbm", "achieved": round(algo / ((e + d) * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
+                         "unit": "GB/s", "frac": round(algo / ((e + d) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                         "traffic": None, "kernel": "encode+decode pair"}}), flush=True)
+
+
 def main():
     a = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -116,6 +190,12 @@ def main():
     B, n = a.block_size, a.blocks
     dist_id = DIST_NAMES.index(a.dist)
     codec = Codec(local_rank)
+    if a.workload != "lz4_decode":
+        bench_roundtrip(a, codec, rank, world, barrier, torch, dist)
+        codec.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
     stride = (bound(METHOD_LZ4, B) + 15) & ~15
 
     # ---------------- setup (untimed) ----------------
