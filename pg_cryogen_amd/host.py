@@ -88,6 +88,17 @@ def lib():
     L.cryo_cache_shutdown.restype = None
     L.cryo_read_data.argtypes = [C.POINTER(CryoRel), vp, u32, C.POINTER(i32)]
     L.cryo_read_data_batch.argtypes = [C.POINTER(CryoRel), C.POINTER(u32), i32, C.POINTER(i32), C.POINTER(i32)]
+    L.cryo_scan_next_batch.argtypes = [C.POINTER(CryoRel), vp, i32, C.POINTER(u32), C.POINTER(i32), C.POINTER(i32)]
+    L.cryo_seqscan_iter_create.restype = vp
+    L.cryo_seqscan_iter_free.argtypes = [vp]
+    L.cryo_seqscan_iter_free.restype = None
+    L.cryo_seqscan_iter_next.argtypes = [vp]
+    L.cryo_seqscan_iter_next.restype = u32
+    L.cryo_seqscan_iter_exclude.argtypes = [vp, u32, C.c_bool]
+    L.cryo_seqscan_iter_exclude.restype = C.c_bool
+    L.cryo_seqscan_iter_reset.argtypes = [vp]
+    L.cryo_seqscan_iter_reset.restype = None
+    L.cryo_seqscan_iter_nranges.argtypes = [vp]
     L.cryo_cache_allocate.argtypes = [C.POINTER(CryoRel), u32]
     L.cryo_cache_release.argtypes = [i32]
     L.cryo_cache_release.restype = None

@@ -1,5 +1,6 @@
 /* cache.c -- see cache.h */
 #include "cache.h"
+#include "scan_iterator.h"
 
 typedef struct
 {
@@ -73,7 +74,8 @@ static int allocate_slot(void)
     return victim;
 }
 
-static CryoError load_blocks(CryoRel *rel, const BlockNumber *blocks, int k, CacheEntry *results, CryoError *errors)
+static CryoError load_blocks(CryoRel *rel, SeqScanIterator *iter, const BlockNumber *blocks, int k,
+                             CacheEntry *results, CryoError *errors)
 {
     /* gather the chains of every missing block, then ONE decompress call per method */
     const CryoCodecOps *ops = cryo_host_codec_ops();
@@ -93,7 +95,13 @@ static CryoError load_blocks(CryoRel *rel, const BlockNumber *blocks, int k, Cac
             errors[i] = CRYO_ERR_WRONG_STARTING_BLOCK; results[i] = InvalidCacheEntry; continue;
         }
         s = find_slot(rel->relid, blocks[i]);
-        if (s != InvalidCacheEntry) { n_hits++; slots[s].ts = ++tick; results[i] = s; continue; }
+        if (s != InvalidCacheEntry) {
+            uint32 j;
+            n_hits++; slots[s].ts = ++tick; results[i] = s;
+            /* the cached block's pages must not be handed out again (cache.c:235-242,290-292) */
+            for (j = 0; j < slots[s].nblocks; j++) cryo_seqscan_iter_exclude(iter, slots[s].blocks[j], true);
+            continue;
+        }
         n_misses++;
         s = allocate_slot();
         if (s == InvalidCacheEntry) { errors[i] = CRYO_ERR_CACHE_IS_FULL; results[i] = InvalidCacheEntry; continue; }
@@ -104,6 +112,14 @@ static CryoError load_blocks(CryoRel *rel, const BlockNumber *blocks, int k, Cac
             errors[i] = cryo_stage_read_chain(rel, blocks[i], &comp[i], &cs, &meth[i], &sl->xid, sl->blocks,
                                               max_chain, &sl->nblocks);
             if (errors[i] != CRYO_ERR_SUCCESS) { results[i] = InvalidCacheEntry; continue; }
+            {
+                /* continuation pages are not block starts (cache.c:174).  miss_ok: the reference
+                 * passes false here and its regression output pins the resulting internal error
+                 * (expected/pg_cryogen.out:166); a page the iterator already handed out is
+                 * harmless (it reads as WRONG_STARTING_BLOCK), so it is tolerated here */
+                uint32 j;
+                for (j = 1; j < sl->nblocks; j++) cryo_seqscan_iter_exclude(iter, sl->blocks[j], true);
+            }
             csz[i] = (uint32_t)cs;
             /* claim the slot now (pinned for the duration of the batch so a later miss cannot evict it) */
             sl->relid = rel->relid; sl->blockno = blocks[i]; sl->ts = ++tick; sl->pinned = true;
@@ -149,16 +165,62 @@ static CryoError load_blocks(CryoRel *rel, const BlockNumber *blocks, int k, Cac
 CryoError cryo_read_data_batch(CryoRel *rel, const BlockNumber *blocks, int k, CacheEntry *results, CryoError *errors)
 {
     if (k <= 0) return CRYO_ERR_SUCCESS;
-    return load_blocks(rel, blocks, k, results, errors);
+    return load_blocks(rel, NULL, blocks, k, results, errors);
 }
 
 CryoError cryo_read_data(CryoRel *rel, void *iter, BlockNumber block, CacheEntry *result)
 {
     CryoError err = CRYO_ERR_SUCCESS;
-    (void)iter; /* the seq-scan iterator bookkeeping (cache.c:235-242,290-292) stays with the table AM */
     *result = InvalidCacheEntry;
-    (void)load_blocks(rel, &block, 1, result, &err);
+    (void)load_blocks(rel, (SeqScanIterator *)iter, &block, 1, result, &err);
     return err;
+}
+
+/*
+ * Read-ahead for a sequential scan: pop block starts from the iterator in the reference's
+ * order (lowest unread first), skip pages that are not block starts or are empty, gather up
+ * to k chains and decode them with one codec call per method.  Returns the number of blocks
+ * delivered in starts[]/entries[] (0 = end of relation).
+ */
+int cryo_scan_next_batch(CryoRel *rel, void *iter_, int k, BlockNumber *starts, CacheEntry *entries,
+                         CryoError *errors)
+{
+    SeqScanIterator *iter = iter_;
+    BlockNumber *cand = malloc((size_t)k * sizeof *cand);
+    CacheEntry *res = malloc((size_t)k * sizeof *res);
+    CryoError *errs = malloc((size_t)k * sizeof *errs);
+    int got = 0;
+    if (!cand || !res || !errs || k <= 0) { free(cand); free(res); free(errs); return 0; }
+    while (got < k) {
+        int want = k - got, nc = 0, i;
+        /* candidates whose first page really starts a chain (cheap header look, no decode) */
+        while (nc < want) {
+            const BlockNumber b = cryo_seqscan_iter_next(iter);
+            const CryoPageHeader *pg;
+            if (!BlockNumberIsValid(b) || b >= rel->ops->nblocks(rel->handle)) { want = nc; break; }
+            pg = (const CryoPageHeader *)rel->ops->read_page(rel->handle, b);
+            if (!pg || pg->base.pd_upper == 0 || pg->first != b) continue; /* empty page / continuation page */
+            {
+                /* exclude this chain's continuation pages now so they are not offered as candidates */
+                const CryoPageHeader *q = pg;
+                BlockNumber nb = q->next;
+                uint32 guard = 0;
+                while (BlockNumberIsValid(nb) && nb < rel->ops->nblocks(rel->handle) && guard++ < max_chain) {
+                    cryo_seqscan_iter_exclude(iter, nb, true);
+                    q = (const CryoPageHeader *)rel->ops->read_page(rel->handle, nb);
+                    if (!q || q->first != b) break;
+                    nb = q->next;
+                }
+            }
+            cand[nc++] = b;
+        }
+        if (nc == 0) break;
+        (void)load_blocks(rel, iter, cand, nc, res, errs);
+        for (i = 0; i < nc; i++) { starts[got] = cand[i]; entries[got] = res[i]; errors[got] = errs[i]; got++; }
+        if (want < k - (got - nc)) break; /* hit the end of the relation */
+    }
+    free(cand); free(res); free(errs);
+    return got;
 }
 
 CacheEntry cryo_cache_allocate(CryoRel *rel, BlockNumber blockno)

@@ -26,6 +26,9 @@ void cryo_cache_shutdown(void);
 CryoError cryo_read_data(CryoRel *rel, void *iter, BlockNumber block, CacheEntry *result);
 CryoError cryo_read_data_batch(CryoRel *rel, const BlockNumber *blocks, int k, CacheEntry *results,
                                CryoError *errors);
+/* read-ahead in seq-scan order (iter = SeqScanIterator*, scan_iterator.h); returns blocks delivered */
+int cryo_scan_next_batch(CryoRel *rel, void *iter, int k, BlockNumber *starts, CacheEntry *entries,
+                         CryoError *errors);
 CacheEntry cryo_cache_allocate(CryoRel *rel, BlockNumber blockno);
 void cryo_cache_release(CacheEntry entry);
 void cryo_cache_invalidate_relation(Oid relid);

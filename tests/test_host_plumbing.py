@@ -277,3 +277,66 @@ def test_compression_h_surface(H):
     L.cryo_decompress(7, comp.ctypes.data, len(comp), out.ctypes.data)
     assert errors and errors[-1][1] == "pg_cryogen: unknown compression method"
     host.set_int("lz4_acceleration_guc", 1)
+
+
+def test_scan_iterator_semantics(H):
+    """reference scan_iterator.c:45-127"""
+    L, _, errors = H
+    it = L.cryo_seqscan_iter_create()
+    assert [L.cryo_seqscan_iter_next(it) for _ in range(3)] == [1, 2, 3]     # starts at block 1 (0 = metapage)
+    assert L.cryo_seqscan_iter_exclude(it, 5, False) and L.cryo_seqscan_iter_nranges(it) == 2   # split
+    assert L.cryo_seqscan_iter_exclude(it, 4, False) and L.cryo_seqscan_iter_nranges(it) == 1   # range [4,4] vanishes
+    assert L.cryo_seqscan_iter_next(it) == 6
+    assert L.cryo_seqscan_iter_exclude(it, 7, False)                                             # start of a range
+    assert L.cryo_seqscan_iter_next(it) == 8
+    assert not L.cryo_seqscan_iter_exclude(it, 2, True) and not errors                           # miss_ok
+    L.cryo_seqscan_iter_exclude(it, 2, False)
+    assert errors and "block 2 is not the part of seqscan iterator" in errors[-1][1]
+    L.cryo_seqscan_iter_reset(it)
+    assert L.cryo_seqscan_iter_next(it) == 1
+    L.cryo_seqscan_iter_free(it)
+
+
+def test_seqscan_read_ahead_in_iterator_order(H):
+    """multi-page chains interleaved with single-page ones: the read-ahead pops block starts in the
+    reference's order, never offers continuation pages, and decodes K chains per codec call"""
+    L, dbl, errors = H
+    host.set_block_size(131072)
+    L.cryo_cache_configure(32)
+    rng = np.random.default_rng(2)
+    mem = L.cryo_memrel_create()
+    rel = host.CryoRel()
+    L.cryo_memrel_bind(mem, 7, C.byref(rel))
+    all_rows, firsts = [], []
+    for b in range(9):
+        if b % 2:   # incompressible rows -> ~15-page chain
+            rows = [struct.pack("<i", 1000 * b + i) + rng.integers(0, 256, 400, dtype=np.uint8).tobytes() for i in range(290)]
+        else:
+            rows = [struct.pack("<i", 1000 * b + i) for i in range(290)]
+        blk = pack_rows(L, rows, 2 if b % 2 else 1, 131072)
+        assert len(blk) == 1
+        fb = (C.c_uint32 * 1)(L.cryo_memrel_reserve(mem))
+        assert L.cryo_stage_write_batch(C.byref(rel), blk[0], 1, host.COMP_LZ4, 5, fb) == 0
+        if b == 4:
+            L.cryo_memrel_reserve(mem)          # a reserved-but-unwritten page in the middle (EMPTY_BLOCK)
+        all_rows.append(rows)
+        firsts.append(fb[0])
+    it = L.cryo_seqscan_iter_create()
+    before = dbl.decompress_calls
+    got_rows, got_starts = [], []
+    while True:
+        K = 4
+        starts, ents, errs = (C.c_uint32 * K)(), (C.c_int * K)(), (C.c_int * K)()
+        n = L.cryo_scan_next_batch(C.byref(rel), it, K, starts, ents, errs)
+        if n == 0:
+            break
+        for i in range(n):
+            assert errs[i] == 0
+            got_starts.append(starts[i])
+            got_rows.append(fetch_rows(L, L.cryo_cache_get_data(ents[i])))
+    assert got_starts == firsts                       # block starts only, in increasing order
+    assert got_rows == all_rows
+    assert dbl.decompress_calls - before == 3         # 9 chains, K = 4 -> 3 codec calls
+    assert not errors
+    L.cryo_seqscan_iter_free(it)
+    L.cryo_memrel_destroy(mem)
