@@ -91,7 +91,8 @@ struct WaveLds {
     uint8_t *d1;                           /* kD1N  (phase 3 reuses it as `meta`)         */
     uint8_t *__restrict__ d2;              /* kD2N                                        */
     uint8_t *__restrict__ d4;              /* kWMax                                       */
-    unsigned long long *meta;              /* 64: ostart | ll<<16 | litidx<<32 | off<<48 */
+    uint16_t *__restrict__ d16;            /* kWMax (0 = not batchable within 16 tokens)  */
+    unsigned long long *meta;              /* 64: litend | off<<16 | (litidx - ostart)<<32 */
     uint32_t *__restrict__ bm;             /* kTMax/32: bit q = a sequence starts at q    */
 };
 
@@ -177,29 +178,68 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
 #pragma unroll
         for (uint32_t g = 0; g < G2; g++) L.d2[g * 64u + lane] = (uint8_t)a2[g];
     }
+    uint32_t a4[NG];
     {
         uint32_t b[NG];
 #pragma unroll
         for (uint32_t g = 0; g < NG; g++) b[g] = L.d2[g * 64u + lane + a2[g]];
 #pragma unroll
-        for (uint32_t g = 0; g < NG; g++)
-            L.d4[g * 64u + lane] = (uint8_t)((a2[g] != 0u && b[g] != 0u) ? a2[g] + b[g] : 0u);
+        for (uint32_t g = 0; g < NG; g++) a4[g] = (a2[g] != 0u && b[g] != 0u) ? a2[g] + b[g] : 0u;
+#pragma unroll
+        for (uint32_t g = 0; g < NG; g++) L.d4[g * 64u + lane] = (uint8_t)a4[g];
     }
-
+    /* d8 and d16 only for window offsets whose 16-token span stays inside the d4 domain; a span
+     * that leaves it reads 0 ("stop") from the guard below */
+    {
+        uint32_t a8[NG], b[NG];
+#pragma unroll
+        for (uint32_t g = 0; g < NG; g++) { const uint32_t j = g * 64u + lane + a4[g]; b[g] = j < W ? L.d4[j] : 0u; }
+#pragma unroll
+        for (uint32_t g = 0; g < NG; g++) a8[g] = (a4[g] != 0u && b[g] != 0u) ? a4[g] + b[g] : 0u;
+        /* d16 needs d8 at another offset: publish d8 through the d16 array first */
+#pragma unroll
+        for (uint32_t g = 0; g < NG; g++) L.d16[g * 64u + lane] = (uint16_t)a8[g];
+#pragma unroll
+        for (uint32_t g = 0; g < NG; g++) { const uint32_t j = g * 64u + lane + a8[g]; b[g] = j < W ? L.d16[j] : 0u; }
+        /* all d8 reads are done before any lane overwrites an entry with d16 (same wave, in order) */
+#pragma unroll
+        for (uint32_t g = 0; g < NG; g++) L.d16[g * 64u + lane] = (uint16_t)((a8[g] != 0u && b[g] != 0u) ? a8[g] + b[g] : 0u);
+    }
     stamp(st, 1);
     /* ---- chase: start of every 4th sequence into lanes 0,4,8,... ---- */
     uint32_t sl = 0;   /* window offset of this lane's sequence */
-    uint32_t ngrp = 0;
+    uint32_t ngrp = 0; /* groups of 4 sequences found */
     {
-        uint32_t s0 = 0;
-        for (uint32_t k = 0; k < 16u; k++) {
-            if (s0 >= W) break;
-            const uint32_t dd = uni(L.d4[s0]);
-            if (dd == 0u) break;
-            if ((lane >> 2) == k) sl = s0;
-            s0 += dd;
-            ngrp++;
+        /* starts of sequences 0,16,32,48 by serial hops over d16 (0 = fewer than 16 simple tokens left) */
+        uint32_t s16[4] = {0, 0, 0, 0};
+        uint32_t n16 = 0;
+        {
+            uint32_t s0 = 0;
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++) {
+                s16[k] = s0;
+                if (n16 == k && s0 < W) {
+                    const uint32_t dd = uni(L.d16[s0]);
+                    if (dd != 0u) { s0 += dd; n16 = k + 1u; }
+                }
+            }
         }
+        /* lane 4a (a = 0..15) walks (a & 3) d4-hops from the start of its 16-group; a group of 4 is
+         * valid while its own d4 is non-zero and it starts inside the window */
+        const uint32_t a = lane >> 2;
+        uint32_t s4 = (a >> 2) == 0u ? s16[0] : ((a >> 2) == 1u ? s16[1] : ((a >> 2) == 2u ? s16[2] : s16[3]));
+        bool alive = (a >> 2) <= n16; /* the 16-group's start is known */
+#pragma unroll
+        for (uint32_t h = 0; h < 3u; h++) {
+            const uint32_t dd = (alive && s4 < W) ? L.d4[s4] : 0u;
+            if ((a & 3u) > h) { alive = alive && dd != 0u; s4 += dd; }
+        }
+        const uint32_t dlast = (alive && s4 < W) ? L.d4[s4] : 0u;
+        alive = alive && dlast != 0u;
+        /* groups are usable up to the first dead one */
+        const unsigned long long dead = __ballot(!alive);
+        ngrp = dead ? (ctz64(dead) >> 2) : 16u;
+        sl = s4;
     }
     if (ngrp == 0u) return 0;
     const uint32_t ncand = ngrp * 4u;
@@ -239,8 +279,10 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     /* ---- phase 3: bitmap of sequence starts + metadata ---- */
     if (lane < kTMax / 32u) L.bm[lane] = 0u;
     if (lane < nseq) {
-        L.meta[lane] = (unsigned long long)ostart | ((unsigned long long)ll << 16) |
-                       ((unsigned long long)((pos + k) & kInMask) << 32) | ((unsigned long long)off << 48);
+        /* per sequence: lo = litend | off << 16; hi = (first literal's input-ring index) - ostart, so
+         * that a literal byte at batch offset qo sits at input-ring index (qo + hi) & kInMask */
+        L.meta[lane] = (unsigned long long)(ostart + ll) | ((unsigned long long)off << 16) |
+                       ((unsigned long long)(uint32_t)((pos + k) - ostart) << 32);
         atomicOr(&L.bm[ostart >> 5], 1u << (ostart & 31u));
     }
     const uint32_t bm_lo = L.bm[(lane & (kNCh - 1u)) * 2u], bm_hi = L.bm[(lane & (kNCh - 1u)) * 2u + 1u];
@@ -262,65 +304,61 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     for (uint32_t h = 0; h < 2u; h++) {
         if (h * kHalf * 64u >= T) break;
         stamp(st, 4);
-        uint32_t mlo[kHalf], mhi[kHalf], xfar[kHalf];
+        /* pass A: per output byte, find its sequence, classify it (literal / near match / far match)
+         * and compute the LDS address of its source once; far bytes are requested from HBM now */
+        const uint8_t *sp[kHalf]; /* LDS source of the byte (input ring or output ring) */
+        uint32_t fl[kHalf];       /* bit0 active, bit1 far, bit2 source inside this chunk, bits 8.. offset */
+        uint32_t xfar[kHalf];
         {
             uint32_t idx[kHalf];
+            unsigned long long m[kHalf];
 #pragma unroll
             for (uint32_t i = 0; i < kHalf; i++) {
                 const uint32_t c = h * kHalf + i;
                 const uint32_t wlo = lane_get(bm_lo, c), whi = lane_get(bm_hi, c);
                 const uint32_t bc = lane_get(basev, c);
                 const uint32_t below = __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
-                const uint32_t own = ((lane < 32u ? wlo >> lane : whi >> (lane - 32u)) & 1u);
+                const uint32_t own = (uint32_t)(((((unsigned long long)whi << 32) | wlo) >> lane) & 1ull);
                 idx[i] = (bc + below + own - 1u) & 63u;
             }
 #pragma unroll
-            for (uint32_t i = 0; i < kHalf; i++) {
-                const unsigned long long m = L.meta[idx[i]];
-                mlo[i] = (uint32_t)m;
-                mhi[i] = (uint32_t)(m >> 32);
-            }
-            uint32_t lit[kHalf];
+            for (uint32_t i = 0; i < kHalf; i++) m[i] = L.meta[idx[i]];
 #pragma unroll
             for (uint32_t i = 0; i < kHalf; i++) {
                 const uint32_t qo = (h * kHalf + i) * 64u + lane; /* batch output offset of this lane's byte */
-                const uint32_t dd = qo - (mlo[i] & 0xffffu);
-                const uint32_t moff = mhi[i] >> 16;
-                const bool isMatch = qo < T && dd >= (mlo[i] >> 16);
-                lit[i] = L.in[((mhi[i] & 0xffffu) + dd) & kInMask];
-                xfar[i] = 0;
-                if (isMatch && moff >= kNear && !(st.ablate & 1u)) xfar[i] = w.dst[op0 + qo - moff];
-            }
-#pragma unroll
-            for (uint32_t i = 0; i < kHalf; i++) {
-                const uint32_t qo = (h * kHalf + i) * 64u + lane;
-                const uint32_t dd = qo - (mlo[i] & 0xffffu);
-                if (qo < T && dd < (mlo[i] >> 16)) L.ring[(op0 + qo) & (R - 1)] = (uint8_t)lit[i];
+                const uint32_t mlo = (uint32_t)m[i], mhi = (uint32_t)(m[i] >> 32);
+                const uint32_t moff = mlo >> 16;
+                const bool active = qo < T;
+                const bool isLit = qo < (mlo & 0xffffu);
+                const bool isFar = !isLit && moff >= kNear;
+                const bool inch = !isLit && moff <= lane; /* near source inside this very chunk */
+                sp[i] = isLit ? &L.in[(qo + mhi) & kInMask] : &L.ring[(op0 + qo - moff) & (R - 1)];
+                fl[i] = (active ? 1u : 0u) | (isFar ? 2u : 0u) | (inch ? 4u : 0u) | (moff << 8);
+                /* unconditional load: lanes without a far byte read the first byte of the block */
+                const uint32_t goff = (active && isFar && !(st.ablate & 1u)) ? op0 + qo - moff : 0u;
+                xfar[i] = w.dst[goff];
             }
         }
         stamp(st, 5);
+        /* pass B: chunks in order.  Every byte whose source is not inside the chunk itself is final
+         * after one LDS read; sources inside the chunk are resolved in rounds guarded by a ballot
+         * of finished lanes. */
 #pragma unroll
         for (uint32_t i = 0; i < kHalf; i++) {
             const uint32_t c = h * kHalf + i;
             if (c * 64u < T && !(st.ablate & 2u)) {
                 st.chunks++;
-                const uint32_t qo = c * 64u + lane;
-                const uint32_t dd = qo - (mlo[i] & 0xffffu);
-                const uint32_t mll = mlo[i] >> 16;
-                const uint32_t moff = mhi[i] >> 16;
-                const bool isMatch = qo < T && dd >= mll;
-                uint8_t *dstp = &L.ring[(op0 + qo) & (R - 1)];
-                if (isMatch && moff >= kNear) *dstp = (uint8_t)xfar[i];
-                const bool near = isMatch && moff < kNear;
-                const uint8_t *srcp = &L.ring[(op0 + qo - moff) & (R - 1)];
-                const bool inchunk = moff <= lane; /* source byte belongs to this very chunk */
-                if (near && !inchunk) *dstp = *srcp;
-                bool pend = near && inchunk;
+                const uint32_t f = fl[i];
+                uint8_t *dstp = &L.ring[(op0 + c * 64u + lane) & (R - 1)];
+                uint32_t x = *sp[i];
+                if (f & 2u) x = xfar[i];
+                bool pend = (f & 5u) == 5u;
+                if ((f & 5u) == 1u) *dstp = (uint8_t)x;
                 unsigned long long donem = __ballot(!pend);
                 while (__ballot(pend) != 0ull) {
                     st.rounds++;
-                    const bool rdy = pend && ((donem >> ((lane - moff) & 63u)) & 1ull);
-                    if (rdy) *dstp = *srcp;
+                    const bool rdy = pend && ((donem >> ((lane - (f >> 8)) & 63u)) & 1ull);
+                    if (rdy) *dstp = *sp[i];
                     donem |= __ballot(rdy);
                     pend = pend && !rdy;
                 }
@@ -349,6 +387,7 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     __shared__ __attribute__((aligned(16))) uint8_t s_d1[4][kD1N]; /* also holds meta[64] in phase 3 */
     __shared__ uint8_t s_d2[4][kD2N];
     __shared__ uint8_t s_d4[4][kWMax];
+    __shared__ uint16_t s_d16[4][kWMax];
     __shared__ uint32_t s_bm[4][kTMax / 32];
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -361,7 +400,7 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     const uint32_t csize = uni(src_size[blk]);
 
     Wave<R> w;
-    const WaveLds<R> L = {s_ring[wid], s_in[wid], s_d1[wid], s_d2[wid], s_d4[wid],
+    const WaveLds<R> L = {s_ring[wid], s_in[wid], s_d1[wid], s_d2[wid], s_d4[wid], s_d16[wid],
                           reinterpret_cast<unsigned long long *>(s_d1[wid]), s_bm[wid]};
     w.ring = L.ring;
     w.in = L.in;
