@@ -66,6 +66,9 @@
 #ifndef LZ4_WAVES_PER_SIMD
 #define LZ4_WAVES_PER_SIMD 5
 #endif
+#ifndef LZ4_HALVES
+#define LZ4_HALVES 2   /* copy passes work on kNCh / LZ4_HALVES chunks at a time (register arrays) */
+#endif
 
 namespace cryo {
 
@@ -89,9 +92,8 @@ struct WaveLds {
     uint8_t *__restrict__ ring;            /* R        output ring                       */
     uint8_t *__restrict__ in;              /* kInRing  input ring                        */
     uint8_t *d1;                           /* kD1N  (phase 3 reuses it as `meta`)         */
-    uint8_t *__restrict__ d2;              /* kD2N                                        */
+    uint8_t *__restrict__ d2;              /* kD2N; after d4 is built the same bytes hold d8 (kWMax) */
     uint8_t *__restrict__ d4;              /* kWMax                                       */
-    uint16_t *__restrict__ d16;            /* kWMax (0 = not batchable within 16 tokens)  */
     unsigned long long *meta;              /* 64: litend | off<<16 | (litidx - ostart)<<32 */
     uint32_t *__restrict__ bm;             /* kTMax/32: bit q = a sequence starts at q    */
 };
@@ -188,64 +190,62 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
 #pragma unroll
         for (uint32_t g = 0; g < NG; g++) L.d4[g * 64u + lane] = (uint8_t)a4[g];
     }
-    /* d8 and d16 only for window offsets whose 16-token span stays inside the d4 domain; a span
-     * that leaves it reads 0 ("stop") from the guard below */
+    /* d8 for window offsets whose 8-token span stays inside the d4 domain (else 0 = "stop"; also 0
+     * when the span exceeds 255 bytes).  d2 is dead once d4 exists, so d8 reuses its storage. */
     {
-        uint32_t a8[NG], b[NG];
+        uint32_t b[NG];
 #pragma unroll
         for (uint32_t g = 0; g < NG; g++) { const uint32_t j = g * 64u + lane + a4[g]; b[g] = j < W ? L.d4[j] : 0u; }
 #pragma unroll
-        for (uint32_t g = 0; g < NG; g++) a8[g] = (a4[g] != 0u && b[g] != 0u) ? a4[g] + b[g] : 0u;
-        /* d16 needs d8 at another offset: publish d8 through the d16 array first */
-#pragma unroll
-        for (uint32_t g = 0; g < NG; g++) L.d16[g * 64u + lane] = (uint16_t)a8[g];
-#pragma unroll
-        for (uint32_t g = 0; g < NG; g++) { const uint32_t j = g * 64u + lane + a8[g]; b[g] = j < W ? L.d16[j] : 0u; }
-        /* all d8 reads are done before any lane overwrites an entry with d16 (same wave, in order) */
-#pragma unroll
-        for (uint32_t g = 0; g < NG; g++) L.d16[g * 64u + lane] = (uint16_t)((a8[g] != 0u && b[g] != 0u) ? a8[g] + b[g] : 0u);
+        for (uint32_t g = 0; g < NG; g++) {
+            const uint32_t d8 = (a4[g] != 0u && b[g] != 0u) ? a4[g] + b[g] : 0u;
+            L.d2[g * 64u + lane] = (uint8_t)(d8 > 255u ? 0u : d8);
+        }
     }
     stamp(st, 1);
     /* ---- chase: start of every 4th sequence into lanes 0,4,8,... ---- */
     uint32_t sl = 0;   /* window offset of this lane's sequence */
     uint32_t ngrp = 0; /* groups of 4 sequences found */
     {
-        /* starts of sequences 0,16,32,48 by serial hops over d16 (0 = fewer than 16 simple tokens left) */
-        uint32_t s16[4] = {0, 0, 0, 0};
-        uint32_t n16 = 0;
+        /* starts of sequences 0,8,16,..,56 by serial hops over d8 (0 = fewer than 8 simple tokens left) */
+        uint32_t s8[8];
+        uint32_t n8 = 0;
         {
             uint32_t s0 = 0;
 #pragma unroll
-            for (uint32_t k = 0; k < 4u; k++) {
-                s16[k] = s0;
-                if (n16 == k && s0 < W) {
-                    const uint32_t dd = uni(L.d16[s0]);
-                    if (dd != 0u) { s0 += dd; n16 = k + 1u; }
+            for (uint32_t k = 0; k < 8u; k++) {
+                s8[k] = s0;
+                if (n8 == k && s0 < W) {
+                    const uint32_t dd = uni(L.d2[s0]);
+                    if (dd != 0u) { s0 += dd; n8 = k + 1u; }
                 }
             }
         }
-        /* lane 4a (a = 0..15) walks (a & 3) d4-hops from the start of its 16-group; a group of 4 is
-         * valid while its own d4 is non-zero and it starts inside the window */
-        const uint32_t a = lane >> 2;
-        uint32_t s4 = (a >> 2) == 0u ? s16[0] : ((a >> 2) == 1u ? s16[1] : ((a >> 2) == 2u ? s16[2] : s16[3]));
-        bool alive = (a >> 2) <= n16; /* the 16-group's start is known */
+        /* lanes 4a..4a+3 (a = 0..15): start of 4-group a = start of 8-group a>>1, plus one d4 hop for odd a;
+         * a 4-group is usable while its own d4 is non-zero and it starts inside the window */
+        const uint32_t a = lane >> 2, g8 = a >> 1;
+        uint32_t s4 = s8[0];
 #pragma unroll
-        for (uint32_t h = 0; h < 3u; h++) {
+        for (uint32_t k = 1; k < 8u; k++) if (g8 == k) s4 = s8[k];
+        bool alive = g8 <= n8;
+        {
             const uint32_t dd = (alive && s4 < W) ? L.d4[s4] : 0u;
-            if ((a & 3u) > h) { alive = alive && dd != 0u; s4 += dd; }
+            if (a & 1u) { alive = alive && dd != 0u; s4 += dd; }
         }
         const uint32_t dlast = (alive && s4 < W) ? L.d4[s4] : 0u;
         alive = alive && dlast != 0u;
-        /* groups are usable up to the first dead one */
         const unsigned long long dead = __ballot(!alive);
         ngrp = dead ? (ctz64(dead) >> 2) : 16u;
         sl = s4;
     }
     if (ngrp == 0u) return 0;
     const uint32_t ncand = ngrp * 4u;
-    /* fill: lanes 4k+1..4k+3 walk 1..3 tokens from the group start */
-    if (lane & 2u) sl += L.d2[sl];
-    if (lane & 1u) sl += L.d1[sl];
+    /* fill: lanes 4a+r walk r tokens from the group start */
+#pragma unroll
+    for (uint32_t hp = 0; hp < 3u; hp++) {
+        const uint32_t dd = L.d1[sl];
+        if ((lane & 3u) > hp) sl += dd;
+    }
 
     stamp(st, 2);
     /* ---- phase 2: one sequence per lane ---- */
@@ -299,9 +299,9 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
      * pass B: chunks in order; far bytes land first, then near matches read the ring.  Only a
      *         source inside the current chunk can be unready: extra rounds guarded by a
      *         ballot of finished lanes. */
-    constexpr uint32_t kHalf = kNCh / 2u;
+    constexpr uint32_t kHalf = kNCh / LZ4_HALVES;
 #pragma unroll
-    for (uint32_t h = 0; h < 2u; h++) {
+    for (uint32_t h = 0; h < (uint32_t)LZ4_HALVES; h++) {
         if (h * kHalf * 64u >= T) break;
         stamp(st, 4);
         /* pass A: per output byte, find its sequence, classify it (literal / near match / far match)
@@ -387,7 +387,6 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     __shared__ __attribute__((aligned(16))) uint8_t s_d1[4][kD1N]; /* also holds meta[64] in phase 3 */
     __shared__ uint8_t s_d2[4][kD2N];
     __shared__ uint8_t s_d4[4][kWMax];
-    __shared__ uint16_t s_d16[4][kWMax];
     __shared__ uint32_t s_bm[4][kTMax / 32];
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -400,7 +399,7 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     const uint32_t csize = uni(src_size[blk]);
 
     Wave<R> w;
-    const WaveLds<R> L = {s_ring[wid], s_in[wid], s_d1[wid], s_d2[wid], s_d4[wid], s_d16[wid],
+    const WaveLds<R> L = {s_ring[wid], s_in[wid], s_d1[wid], s_d2[wid], s_d4[wid],
                           reinterpret_cast<unsigned long long *>(s_d1[wid]), s_bm[wid]};
     w.ring = L.ring;
     w.in = L.in;
