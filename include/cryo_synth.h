@@ -102,15 +102,14 @@ CRYO_HD cryo_synth_geom cryo_synth_geometry(uint32_t B, int dist)
  * anything else is literal.  The template is the field pattern below repeated
  * and cut to the text length, so it is computable per byte.
  */
-#define CRYO_SYNTH_PERIOD 104u
+#define CRYO_SYNTH_PERIOD 126u
 CRYO_HD uint8_t cryo_synth_tmpl(uint32_t j)
 {
-    /* 104-byte period: four fields of 26 bytes */
+    /* 126-byte period: three fields of 42 bytes, each "<key>": "<32 value chars>", */
     const char *p =
-        "\"ka\": \"################\", "   /* 26: hex16 */
-        "\"kb\": \"$$$$$$$$-@@@@@@@\", "   /* 26: word + decimal */
-        "\"kc\": \"%%%%%%%%%%%%%%%%\", "   /* 26: base64-like 16 */
-        "\"kd\": \"2026-10-@@T@@:@@\", ";  /* 26: timestamp-like */
+        "\"ka\": \"################################\", "   /* 42: 32 hex (md5/uuid-like)     */
+        "\"kb\": \"$$$$$$$$-@@@@@@@-###############\", "    /* 42: word, decimal id, 15 hex   */
+        "\"kc\": \"################################\", ";  /* 42: 32 hex                      */
     return (uint8_t)p[j % CRYO_SYNTH_PERIOD];
 }
 
@@ -146,11 +145,11 @@ CRYO_HD uint8_t cryo_synth_text_byte(uint64_t seed, uint64_t block, uint32_t tup
         return (uint8_t)('0' + (d * 10u >> 8));
     }
     if (c == '$') {
-        /* position within the 8-byte word hole: the hole spans period offsets 33..40 */
-        uint32_t q = (j - 1u) % CRYO_SYNTH_PERIOD;       /* 33..40 */
+        /* position within the 8-byte word hole: the hole spans period offsets 49..56 */
+        uint32_t q = (j - 1u) % CRYO_SYNTH_PERIOD;       /* 49..56 */
         uint32_t rep = (j - 1u) / CRYO_SYNTH_PERIOD;
         uint64_t r = cryo_rng(seed, block, tup, 0x20000u + rep);
-        return cryo_synth_word((uint32_t)(r >> 17), q - 33u);
+        return cryo_synth_word((uint32_t)(r >> 17), q - 49u);
     }
     return c;
 }

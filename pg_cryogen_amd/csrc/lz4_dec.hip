@@ -76,7 +76,7 @@ namespace {
 } // namespace
 
 /* ---- batch engine constants ---- */
-constexpr uint32_t kWMax = 512;   /* sequences of a batch start at window offsets < W <= kWMax */
+constexpr uint32_t kWMax = 1024;  /* sequences of a batch start at window offsets < W <= kWMax */
 constexpr uint32_t kD1N = kWMax + 256; /* d1 domain [0, W+256): d2 lookups reach < W+128+63     */
 constexpr uint32_t kD2N = kWMax + 128; /* d2 domain [0, W+128): d4 lookups reach < W+126        */
 constexpr uint32_t kDMax = 63;    /* longest token-to-token distance the batch handles          */
@@ -419,7 +419,7 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     bool bad = (csize == 0);
     bool done = bad;
     uint32_t skip = 0;
-    bool small = false;
+    uint32_t wmode = 1u; /* parse window: 0 = 128 B, 1 = 512 B, 2 = 1 KiB */
 
     if (!bad) {
         w.prefetch();
@@ -435,12 +435,17 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
         if (skip == 0u) {
             uint32_t n, used;
             do {
-                n = small ? lz4_batch<R, 2>(w, L, vp, B, &used, st) : lz4_batch<R, 8>(w, L, vp, B, &used, st);
+                n = wmode == 0u ? lz4_batch<R, 2>(w, L, vp, B, &used, st)
+                  : (wmode == 1u ? lz4_batch<R, 8>(w, L, vp, B, &used, st) : lz4_batch<R, 16>(w, L, vp, B, &used, st));
                 if (n == 0u) st.zero_batches++;
-                /* long matches fill kTMax output bytes after few tokens: then a 128-byte window
-                 * is enough and the table passes shrink 3x */
-                small = (n != 0u && n < 64u && used < 96u);
-            } while (n >= 24u || (n >= 4u && small));
+                /* the window follows the data: long matches fill kTMax output bytes after few tokens
+                 * (128 bytes of input suffice), literal-heavy blocks need 1 KiB of input for 64 tokens */
+                const uint32_t wbytes = wmode == 0u ? 128u : (wmode == 1u ? 512u : 1024u);
+                if (n != 0u && n < 64u && used < 96u) wmode = 0u;
+                else if (n != 0u && n < 56u && used + 64u > wbytes && wmode < 2u) wmode++;
+                else if (wmode == 2u && used < 400u) wmode = 1u;
+                else if (wmode == 0u && used >= 96u) wmode = 1u;
+            } while (n >= 24u || (n >= 4u && wmode == 0u));
             if (n < 4u) skip = 8u; /* poor yield: stay on the general path for a while */
         } else {
             skip--;

@@ -17,7 +17,8 @@ namespace {
 
 
 constexpr uint32_t kInRing = 2048, kInMask = kInRing - 1; /* >= kWMax + 256 + 72 + kChunk */
-constexpr uint32_t kChunk = 1024; /* bytes per refill / flush: 64 lanes x 16 B */
+constexpr uint32_t kChunk = 1024;   /* bytes per output flush: 64 lanes x 16 B */
+constexpr uint32_t kInChunk = 512;  /* bytes per input refill: 64 lanes x 8 B (leaves room for a 1 KiB parse window) */
 
 __device__ inline uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 /* NOTE: never rebuild a pointer from integers (it becomes a FLAT pointer and every access then
@@ -40,8 +41,8 @@ struct Wave {
     const uint8_t *abase; /* 16-byte aligned address at or below the block's first byte */
     uint32_t delta;       /* first byte = abase + delta                                */
     uint32_t vend;        /* delta + csize: end of stream in "virtual" positions       */
-    uint32_t in_hi;       /* virtual position staged up to (multiple of kChunk)        */
-    uint4 pre;            /* prefetched next chunk                                     */
+    uint32_t in_hi;       /* virtual position staged up to (multiple of kInChunk)      */
+    uint2 pre;            /* prefetched next chunk                                     */
     /* output */
     uint8_t *dst;
     uint32_t op;      /* bytes produced      */
@@ -51,15 +52,15 @@ struct Wave {
 
     __device__ inline void prefetch()
     {
-        const uint32_t o = in_hi + lane * 16u;
-        pre = make_uint4(0, 0, 0, 0);
-        if (o < vend) pre = *reinterpret_cast<const uint4 *>(abase + o);
+        const uint32_t o = in_hi + lane * 8u;
+        pre = make_uint2(0, 0);
+        if (o < vend) pre = *reinterpret_cast<const uint2 *>(abase + o);
     }
     /* write the prefetched chunk into the input ring, start fetching the one after */
     __device__ inline void refill()
     {
-        *reinterpret_cast<uint4 *>(in + ((in_hi + lane * 16u) & kInMask)) = pre;
-        in_hi += kChunk;
+        *reinterpret_cast<uint2 *>(in + ((in_hi + lane * 8u) & kInMask)) = pre;
+        in_hi += kInChunk;
         prefetch();
     }
     /* keep at least 128 staged bytes ahead of virtual position vp (the chunk after that is
