@@ -80,8 +80,6 @@ constexpr uint32_t kWMax = 1024;  /* sequences of a batch start at window offset
 constexpr uint32_t kD1N = kWMax + 256; /* d1 domain [0, W+256): d2 lookups reach < W+128+63     */
 constexpr uint32_t kD2N = kWMax + 128; /* d2 domain [0, W+128): d4 lookups reach < W+126        */
 constexpr uint32_t kDMax = 63;    /* longest token-to-token distance the batch handles          */
-constexpr uint32_t kTMax = 1024;  /* output bytes per batch (16 chunks of 64)                   */
-constexpr uint32_t kNCh = kTMax / 64;
 
 /* Per-wave LDS regions.  They are separate __shared__ objects on purpose: the compiler can
  * then prove that e.g. a byte store into the output ring does not alias the parse tables,
@@ -97,23 +95,6 @@ struct WaveLds {
     unsigned long long *meta;              /* 64: litend | off<<16 | (litidx - ostart)<<32 */
     uint32_t *__restrict__ bm;             /* kTMax/32: bit q = a sequence starts at q    */
 };
-
-struct Stats {
-    uint32_t batches, batch_seqs, general_seqs, chunks, rounds, zero_batches;
-    uint32_t ablate;
-    unsigned long long t[8]; /* cycle stamps per phase (diagnostic build only) */
-    unsigned long long t0;
-    bool on;
-};
-/* phase stamp: adds the cycles since the previous stamp to bucket k (STATS build only) */
-__device__ inline void stamp(Stats &st, int k)
-{
-    if (st.on) {
-        const unsigned long long now = __builtin_amdgcn_s_memtime();
-        st.t[k] += now - st.t0;
-        st.t0 = now;
-    }
-}
 
 /*
  * Decode up to 64 "simple" sequences starting at virtual position vp; NG*64 (<= kWMax) is the
@@ -276,99 +257,8 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     *used = lane_get(sl + dlen, nseq - 1u);
 
     stamp(st, 3);
-    /* ---- phase 3: bitmap of sequence starts + metadata ---- */
-    if (lane < kTMax / 32u) L.bm[lane] = 0u;
-    if (lane < nseq) {
-        /* per sequence: lo = litend | off << 16; hi = (first literal's input-ring index) - ostart, so
-         * that a literal byte at batch offset qo sits at input-ring index (qo + hi) & kInMask */
-        L.meta[lane] = (unsigned long long)(ostart + ll) | ((unsigned long long)off << 16) |
-                       ((unsigned long long)(uint32_t)((pos + k) - ostart) << 32);
-        atomicOr(&L.bm[ostart >> 5], 1u << (ostart & 31u));
-    }
-    const uint32_t bm_lo = L.bm[(lane & (kNCh - 1u)) * 2u], bm_hi = L.bm[(lane & (kNCh - 1u)) * 2u + 1u];
-    uint32_t basev = (uint32_t)(__popc(bm_lo) + __popc(bm_hi)); /* lanes 0..kNCh-1: starts in chunk `lane` */
-    static_assert(kNCh == 16, "chunk-count scan uses one DPP row");
-    basev = scan16_incl(basev) - basev; /* exclusive: starts before this chunk */
-    const uint32_t op0 = w.op;
-    st.batches++;
-    st.batch_seqs += nseq;
-
-    /* Two halves of 8 chunks (keeps the register arrays at 8 entries).  Per half:
-     * pass A: bytes that do not depend on this batch: literals (input ring -> ring) and far
-     *         matches (requested now from the output buffer, written in pass B);
-     * pass B: chunks in order; far bytes land first, then near matches read the ring.  Only a
-     *         source inside the current chunk can be unready: extra rounds guarded by a
-     *         ballot of finished lanes. */
-    constexpr uint32_t kHalf = kNCh / LZ4_HALVES;
-#pragma unroll
-    for (uint32_t h = 0; h < (uint32_t)LZ4_HALVES; h++) {
-        if (h * kHalf * 64u >= T) break;
-        stamp(st, 4);
-        /* pass A: per output byte, find its sequence, classify it (literal / near match / far match)
-         * and compute the LDS address of its source once; far bytes are requested from HBM now */
-        const uint8_t *sp[kHalf]; /* LDS source of the byte (input ring or output ring) */
-        uint32_t fl[kHalf];       /* bit0 active, bit1 far, bit2 source inside this chunk, bits 8.. offset */
-        uint32_t xfar[kHalf];
-        {
-            uint32_t idx[kHalf];
-            unsigned long long m[kHalf];
-#pragma unroll
-            for (uint32_t i = 0; i < kHalf; i++) {
-                const uint32_t c = h * kHalf + i;
-                const uint32_t wlo = lane_get(bm_lo, c), whi = lane_get(bm_hi, c);
-                const uint32_t bc = lane_get(basev, c);
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
-                const uint32_t own = (uint32_t)(((((unsigned long long)whi << 32) | wlo) >> lane) & 1ull);
-                idx[i] = (bc + below + own - 1u) & 63u;
-            }
-#pragma unroll
-            for (uint32_t i = 0; i < kHalf; i++) m[i] = L.meta[idx[i]];
-#pragma unroll
-            for (uint32_t i = 0; i < kHalf; i++) {
-                const uint32_t qo = (h * kHalf + i) * 64u + lane; /* batch output offset of this lane's byte */
-                const uint32_t mlo = (uint32_t)m[i], mhi = (uint32_t)(m[i] >> 32);
-                const uint32_t moff = mlo >> 16;
-                const bool active = qo < T;
-                const bool isLit = qo < (mlo & 0xffffu);
-                const bool isFar = !isLit && moff >= kNear;
-                const bool inch = !isLit && moff <= lane; /* near source inside this very chunk */
-                sp[i] = isLit ? &L.in[(qo + mhi) & kInMask] : &L.ring[(op0 + qo - moff) & (R - 1)];
-                fl[i] = (active ? 1u : 0u) | (isFar ? 2u : 0u) | (inch ? 4u : 0u) | (moff << 8);
-                /* unconditional load: lanes without a far byte read the first byte of the block */
-                const uint32_t goff = (active && isFar && !(st.ablate & 1u)) ? op0 + qo - moff : 0u;
-                xfar[i] = w.dst[goff];
-            }
-        }
-        stamp(st, 5);
-        /* pass B: chunks in order.  Every byte whose source is not inside the chunk itself is final
-         * after one LDS read; sources inside the chunk are resolved in rounds guarded by a ballot
-         * of finished lanes. */
-#pragma unroll
-        for (uint32_t i = 0; i < kHalf; i++) {
-            const uint32_t c = h * kHalf + i;
-            if (c * 64u < T && !(st.ablate & 2u)) {
-                st.chunks++;
-                const uint32_t f = fl[i];
-                uint8_t *dstp = &L.ring[(op0 + c * 64u + lane) & (R - 1)];
-                uint32_t x = *sp[i];
-                if (f & 2u) x = xfar[i];
-                bool pend = (f & 5u) == 5u;
-                if ((f & 5u) == 1u) *dstp = (uint8_t)x;
-                unsigned long long donem = __ballot(!pend);
-                while (__ballot(pend) != 0ull) {
-                    st.rounds++;
-                    const bool rdy = pend && ((donem >> ((lane - (f >> 8)) & 63u)) & 1ull);
-                    if (rdy) *dstp = *sp[i];
-                    donem |= __ballot(rdy);
-                    pend = pend && !rdy;
-                }
-            }
-        }
-    }
-    stamp(st, 6);
-    w.op = op0 + T;
+    batch_copy<R>(w, L.in, L.meta, L.bm, nseq, ostart, ll, off, (pos + k) - ostart, T, st);
     vp += *used;
-    w.flush();
     stamp(st, 0);
     return nseq;
 }

@@ -10,6 +10,10 @@
 #ifndef CRYO_LZ_COMMON_H
 #define CRYO_LZ_COMMON_H
 
+#ifndef LZ4_HALVES
+#define LZ4_HALVES 2   /* copy passes work on kNCh / LZ4_HALVES chunks at a time (register arrays) */
+#endif
+
 #include "kernels.h"
 
 namespace cryo {
@@ -206,6 +210,146 @@ __device__ inline void wave_copy_match(Wave<R> &w, uint32_t off, uint32_t ml)
             rem -= n;
         }
     }
+}
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Batch copy: execute up to 64 non-overlapping LZ sequences (one per lane) one output byte per lane.
+ *
+ *   lane i < nseq holds sequence i: ostart = its first output byte (offset inside the batch),
+ *   ll literal bytes followed by a match at distance `off` (off >= match length), its literals at
+ *   input-ring index (ostart + lit_rel + j) & kInMask; T = total output bytes (<= kTMax).
+ *
+ * A bitmap of sequence starts + mbcnt maps every output byte to its sequence.  Pass A classifies
+ * each byte (literal / near match / far match), computes its LDS source address once and requests
+ * every far-match byte of the batch from the already flushed output in HBM/L2 (one memory latency
+ * per batch).  Pass B walks the 64-byte chunks in order: a byte whose source is not inside the
+ * chunk itself is final after one LDS read; sources inside the chunk are resolved in rounds guarded
+ * by a ballot of finished lanes.  Used by the LZ4 and the zstd block decoders.
+ * --------------------------------------------------------------------------------------------- */
+constexpr uint32_t kTMax = 1024;  /* output bytes per batch (16 chunks of 64) */
+constexpr uint32_t kNCh = kTMax / 64;
+
+struct Stats {
+    uint32_t batches, batch_seqs, general_seqs, chunks, rounds, zero_batches;
+    uint32_t ablate;
+    unsigned long long t[8]; /* cycle stamps per phase (diagnostic build only) */
+    unsigned long long t0;
+    bool on;
+};
+/* phase stamp: adds the cycles since the previous stamp to bucket k (STATS build only) */
+__device__ inline void stamp(Stats &st, int k)
+{
+    if (st.on) {
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        st.t[k] += now - st.t0;
+        st.t0 = now;
+    }
+}
+
+
+template <uint32_t R>
+__device__ inline void batch_copy(Wave<R> &w, const uint8_t *__restrict__ in, unsigned long long *meta,
+                                  uint32_t *__restrict__ bm, const uint32_t nseq, const uint32_t ostart,
+                                  const uint32_t ll, const uint32_t off, const uint32_t lit_rel, const uint32_t T,
+                                  Stats &st)
+{
+    static_assert(R >= 4096, "ring must hold kTMax new bytes plus the near window");
+    constexpr uint32_t kNear = R - kTMax - 64u;
+    const uint32_t lane = w.lane;
+    st.batches++;
+    st.batch_seqs += nseq;
+    if (lane < kTMax / 32u) bm[lane] = 0u;
+    if (lane < nseq) {
+        /* per sequence: lo = litend (11 bits, <= kTMax) | off << 11 (21 bits: zstd windows up to 2 MiB); hi = (first literal's input-ring index) - ostart, so
+         * that a literal byte at batch offset qo sits at input-ring index (qo + hi) & kInMask */
+        meta[lane] = (unsigned long long)(ostart + ll) | ((unsigned long long)off << 11) |
+                       ((unsigned long long)lit_rel << 32);
+        atomicOr(&bm[ostart >> 5], 1u << (ostart & 31u));
+    }
+    const uint32_t bm_lo = bm[(lane & (kNCh - 1u)) * 2u], bm_hi = bm[(lane & (kNCh - 1u)) * 2u + 1u];
+    uint32_t basev = (uint32_t)(__popc(bm_lo) + __popc(bm_hi)); /* lanes 0..kNCh-1: starts in chunk `lane` */
+    static_assert(kNCh == 16, "chunk-count scan uses one DPP row");
+    basev = scan16_incl(basev) - basev; /* exclusive: starts before this chunk */
+    const uint32_t op0 = w.op;
+    st.batches++;
+    st.batch_seqs += nseq;
+
+    /* Two halves of 8 chunks (keeps the register arrays at 8 entries).  Per half:
+     * pass A: bytes that do not depend on this batch: literals (input ring -> ring) and far
+     *         matches (requested now from the output buffer, written in pass B);
+     * pass B: chunks in order; far bytes land first, then near matches read the ring.  Only a
+     *         source inside the current chunk can be unready: extra rounds guarded by a
+     *         ballot of finished lanes. */
+    constexpr uint32_t kHalf = kNCh / LZ4_HALVES;
+#pragma unroll
+    for (uint32_t h = 0; h < (uint32_t)LZ4_HALVES; h++) {
+        if (h * kHalf * 64u >= T) break;
+        stamp(st, 4);
+        /* pass A: per output byte, find its sequence, classify it (literal / near match / far match)
+         * and compute the LDS address of its source once; far bytes are requested from HBM now */
+        const uint8_t *sp[kHalf]; /* LDS source of the byte (input ring or output ring) */
+        uint32_t fl[kHalf];       /* bit0 active, bit1 far, bit2 source inside this chunk, bits 8.. offset */
+        uint32_t xfar[kHalf];
+        {
+            uint32_t idx[kHalf];
+            unsigned long long m[kHalf];
+#pragma unroll
+            for (uint32_t i = 0; i < kHalf; i++) {
+                const uint32_t c = h * kHalf + i;
+                const uint32_t wlo = lane_get(bm_lo, c), whi = lane_get(bm_hi, c);
+                const uint32_t bc = lane_get(basev, c);
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
+                const uint32_t own = (uint32_t)(((((unsigned long long)whi << 32) | wlo) >> lane) & 1ull);
+                idx[i] = (bc + below + own - 1u) & 63u;
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < kHalf; i++) m[i] = meta[idx[i]];
+#pragma unroll
+            for (uint32_t i = 0; i < kHalf; i++) {
+                const uint32_t qo = (h * kHalf + i) * 64u + lane; /* batch output offset of this lane's byte */
+                const uint32_t mlo = (uint32_t)m[i], mhi = (uint32_t)(m[i] >> 32);
+                const uint32_t moff = mlo >> 11;
+                const bool active = qo < T;
+                const bool isLit = qo < (mlo & 0x7ffu);
+                const bool isFar = !isLit && moff >= kNear;
+                const bool inch = !isLit && moff <= lane; /* near source inside this very chunk */
+                sp[i] = isLit ? &in[(qo + mhi) & kInMask] : &w.ring[(op0 + qo - moff) & (R - 1)];
+                fl[i] = (active ? 1u : 0u) | (isFar ? 2u : 0u) | (inch ? 4u : 0u) | (moff << 8);
+                /* unconditional load: lanes without a far byte read the first byte of the block */
+                const uint32_t goff = (active && isFar && !(st.ablate & 1u)) ? op0 + qo - moff : 0u;
+                xfar[i] = w.dst[goff];
+            }
+        }
+        stamp(st, 5);
+        /* pass B: chunks in order.  Every byte whose source is not inside the chunk itself is final
+         * after one LDS read; sources inside the chunk are resolved in rounds guarded by a ballot
+         * of finished lanes. */
+#pragma unroll
+        for (uint32_t i = 0; i < kHalf; i++) {
+            const uint32_t c = h * kHalf + i;
+            if (c * 64u < T && !(st.ablate & 2u)) {
+                st.chunks++;
+                const uint32_t f = fl[i];
+                uint8_t *dstp = &w.ring[(op0 + c * 64u + lane) & (R - 1)];
+                uint32_t x = *sp[i];
+                if (f & 2u) x = xfar[i];
+                bool pend = (f & 5u) == 5u;
+                if ((f & 5u) == 1u) *dstp = (uint8_t)x;
+                unsigned long long donem = __ballot(!pend);
+                while (__ballot(pend) != 0ull) {
+                    st.rounds++;
+                    const bool rdy = pend && ((donem >> ((lane - (f >> 8)) & 63u)) & 1ull);
+                    if (rdy) *dstp = *sp[i];
+                    donem |= __ballot(rdy);
+                    pend = pend && !rdy;
+                }
+            }
+        }
+    }
+    stamp(st, 6);
+    w.op = op0 + T;
+    w.flush();
 }
 
 } // namespace

@@ -34,40 +34,52 @@ constexpr uint32_t kZBlockMax = 128u << 10;
 constexpr uint32_t kLitBuf = kZBlockMax + 64u; /* per-workgroup literal buffer in global memory */
 constexpr int kHufLogMax = 12;
 
-/* ---- backward bit reader over global memory (per lane) ---- */
+/* ---- backward bit reader over global memory (per lane) ----
+ * `cont` holds stream bits [cbase, cbase+64); `ahead` is the prefetched 64 bits just below it, so a
+ * refill is a register funnel shift plus ONE new load that is not waited for until the next refill. */
 struct BitRd {
     const uint8_t *p;
     uint32_t n;
     int32_t pos;   /* unread bits */
-    int32_t cbase; /* bit index of cont bit 0 */
-    uint64_t cont;
+    int32_t cbase; /* bit index of cont bit 0 (multiple of 8) */
+    uint64_t cont, ahead; /* ahead = bits [cbase-64, cbase) (zero below the stream start) */
     bool over;
 
-    __device__ inline uint64_t load(uint32_t bi) const
+    __device__ inline uint64_t load(int32_t bi) const /* 8 bytes at byte index bi (may be negative / past the end) */
     {
         uint64_t v = 0;
-        if (bi + 8u <= n) {
+        if (bi >= 0 && (uint32_t)bi + 8u <= n) {
             __builtin_memcpy(&v, p + bi, 8);
         } else {
-            for (uint32_t k = 0; bi + k < n && k < 8u; k++) v |= (uint64_t)p[bi + k] << (8u * k);
+            for (int32_t k = 0; k < 8; k++) {
+                const int32_t q = bi + k;
+                if (q >= 0 && (uint32_t)q < n) v |= (uint64_t)p[q] << (8 * k);
+            }
         }
         return v;
     }
     __device__ inline void refill()
     {
-        int32_t bi = (pos >> 3) - 7;
-        if (bi < 0) bi = 0;
-        cbase = bi * 8;
-        cont = load((uint32_t)bi);
+        int32_t nb = ((pos >> 3) - 7) * 8;
+        if (nb < 0) nb = 0;
+        const int32_t sh = cbase - nb; /* 0..64, multiple of 8 */
+        if (sh >= 64) cont = ahead;
+        else if (sh > 0) cont = (cont << sh) | (ahead >> (64 - sh));
+        cbase = nb;
+        ahead = load((nb >> 3) - 8);
     }
     __device__ inline bool init(const uint8_t *src, uint32_t len)
     {
-        p = src; n = len; over = false; pos = 0; cbase = 0; cont = 0;
+        p = src; n = len; over = false; pos = 0; cbase = 0; cont = 0; ahead = 0;
         if (len < 1u) return false;
         const uint32_t last = src[len - 1u];
         if (last == 0u) return false;
         pos = (int32_t)(len - 1u) * 8 + (31 - __builtin_clz(last));
-        refill();
+        int32_t bi = (pos >> 3) - 7;
+        if (bi < 0) bi = 0;
+        cbase = bi * 8;
+        cont = load(bi);
+        ahead = load(bi - 8);
         return true;
     }
     /* next nb (<= 32) bits, MSB first, zero extended past the start of the stream */
@@ -94,6 +106,8 @@ struct ZLds {
     uint32_t wdt[64]; /* FSE table of the Huffman weights */
     uint8_t wts[256];
     uint8_t cell[512];
+    unsigned long long meta[64]; /* batch copy: per-sequence metadata */
+    uint32_t bm[kTMax / 32];     /* batch copy: bitmap of sequence starts */
 };
 
 __device__ inline uint32_t hb32(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
@@ -526,43 +540,88 @@ __device__ bool decode_block(ZLds &L, Wave<ZR> &w, FrameState &fs, const uint8_t
         uint32_t sl = uni(b.read((uint32_t)fs.ll_log));
         uint32_t so = uni(b.read((uint32_t)fs.of_log));
         uint32_t sm = uni(b.read((uint32_t)fs.ml_log));
-        for (uint32_t i = 0; i < nseq; i++) {
-            const uint32_t el = L.ll[sl], eo = L.of[so], em = L.ml[sm];
-            const uint32_t lsym = el >> 14, osym = eo >> 14, msym = em >> 14;
-            const uint32_t llbase = kLLBase[lsym], llbits = kLLBits[lsym];
-            const uint32_t mlbase = kMLBase[msym], mlbits = kMLBits[msym];
-            const bool ll0 = (llbase == 0u);
-            uint32_t offset;
-            if (osym > 1u) {
-                offset = ((1u << osym) - 3u) + uni(b.read(osym));
-                fs.rep2 = fs.rep1; fs.rep1 = fs.rep0; fs.rep0 = offset;
-            } else if (osym == 0u) {
-                if (!ll0) offset = fs.rep0;
-                else { offset = fs.rep1; fs.rep1 = fs.rep0; fs.rep0 = offset; }
+        /* Decoded sequences wait in a 64-entry queue held one-per-lane (q_ll, q_ml, q_off); its head
+         * prefix of "simple" sequences is executed as ONE batch by the shared copy engine. */
+        uint32_t q_ll = 0, q_ml = 0, q_off = 0;
+        uint32_t qn = 0, decoded = 0;
+        Stats st = {};
+        for (;;) {
+            /* ---- refill the queue: serial FSE decode (one adaptive bitstream) ---- */
+            while (qn < 64u && decoded < nseq) {
+                const uint32_t el = L.ll[sl], eo = L.of[so], em = L.ml[sm];
+                const uint32_t lsym = uni(el >> 14), osym = uni(eo >> 14), msym = uni(em >> 14);
+                const uint32_t llbase = kLLBase[lsym], llbits = kLLBits[lsym];
+                const uint32_t mlbase = kMLBase[msym], mlbits = kMLBits[msym];
+                const bool ll0 = (llbase == 0u);
+                uint32_t offset;
+                if (osym > 1u) {
+                    offset = ((1u << osym) - 3u) + uni(b.read(osym));
+                    fs.rep2 = fs.rep1; fs.rep1 = fs.rep0; fs.rep0 = offset;
+                } else if (osym == 0u) {
+                    if (!ll0) offset = fs.rep0;
+                    else { offset = fs.rep1; fs.rep1 = fs.rep0; fs.rep0 = offset; }
+                } else {
+                    const uint32_t idx = 1u + (ll0 ? 1u : 0u) + uni(b.read(1u));
+                    uint32_t tmp = (idx == 3u) ? fs.rep0 - 1u : (idx == 1u ? fs.rep1 : fs.rep2);
+                    if (tmp == 0u) tmp = 1u; /* 0 is not valid: forced to 1 like the library */
+                    if (idx != 1u) fs.rep2 = fs.rep1;
+                    fs.rep1 = fs.rep0;
+                    fs.rep0 = offset = tmp;
+                }
+                const uint32_t mlen = mlbase + (mlbits ? uni(b.read(mlbits)) : 0u);
+                const uint32_t llen = llbase + (llbits ? uni(b.read(llbits)) : 0u);
+                decoded++;
+                if (decoded < nseq) { /* state updates: LL, ML, OF */
+                    sl = uni((el & 1023u) + b.read((el >> 10) & 15u));
+                    sm = uni((em & 1023u) + b.read((em >> 10) & 15u));
+                    so = uni((eo & 1023u) + b.read((eo >> 10) & 15u));
+                }
+                if (lane == qn) { q_ll = llen; q_ml = mlen; q_off = offset; }
+                qn++;
+            }
+            if (qn == 0u) break;
+
+            /* ---- head prefix of the queue that the batch engine can take ---- */
+            const bool inq = lane < qn;
+            const uint32_t outlen = inq ? q_ll + q_ml : 0u;
+            const uint32_t oend = scan64_incl(outlen);
+            const uint32_t ostart = oend - outlen;
+            const uint32_t litend = scan64_incl(inq ? q_ll : 0u); /* literals consumed up to and incl. this sequence */
+            const uint32_t mabs = w.op + ostart + q_ll;
+            const bool ok = inq && lit_mode == 0 && q_ml <= q_off && q_off <= mabs && q_off < (1u << 21) &&
+                            litend <= regen - lit_pos && oend <= kTMax && (uint64_t)w.op + oend <= cap;
+            const unsigned long long badmask = __ballot(!ok);
+            const uint32_t nb = badmask ? ctz64(badmask) : 64u;
+            if (nb > 0u) {
+                const uint32_t T = lane_get(oend, nb - 1u);
+                const uint32_t lits = lane_get(litend, nb - 1u);
+                /* stage the literals of the whole batch (<= kTMax bytes) in the input ring */
+                while (w.in_hi < w.vend && w.in_hi < lvp + lits + 8u) w.refill();
+                batch_copy<ZR>(w, L.in, L.meta, L.bm, nb, ostart, q_ll, q_off, (lvp + (litend - q_ll)) - ostart, T, st);
+                lvp += lits;
+                lit_pos += lits;
+                /* drop the executed prefix from the queue */
+                q_ll = __shfl(q_ll, (int)((lane + nb) & 63u), 64);
+                q_ml = __shfl(q_ml, (int)((lane + nb) & 63u), 64);
+                q_off = __shfl(q_off, (int)((lane + nb) & 63u), 64);
+                qn -= nb;
             } else {
-                const uint32_t idx = 1u + (ll0 ? 1u : 0u) + uni(b.read(1u));
-                uint32_t tmp = (idx == 3u) ? fs.rep0 - 1u : (idx == 1u ? fs.rep1 : fs.rep2);
-                if (tmp == 0u) tmp = 1u; /* 0 is not valid: forced to 1 like the library */
-                if (idx != 1u) fs.rep2 = fs.rep1;
-                fs.rep1 = fs.rep0;
-                fs.rep0 = offset = tmp;
+                /* the head sequence is not batchable (overlapping or very long match, RLE literals,
+                 * or malformed): execute it alone, with every check */
+                const uint32_t llen = lane_get(q_ll, 0), mlen = lane_get(q_ml, 0), offset = lane_get(q_off, 0);
+                if (llen > regen - lit_pos) return false;
+                if ((uint64_t)llen + mlen > (uint64_t)(cap - w.op)) return false;
+                if (lit_mode == 0) lvp = wave_copy_literals(w, lvp, llen);
+                else wave_fill(w, rle_byte, llen);
+                lit_pos += llen;
+                if (offset > w.op) return false;
+                wave_copy_match(w, offset, mlen);
+                w.flush();
+                q_ll = __shfl(q_ll, (int)((lane + 1u) & 63u), 64);
+                q_ml = __shfl(q_ml, (int)((lane + 1u) & 63u), 64);
+                q_off = __shfl(q_off, (int)((lane + 1u) & 63u), 64);
+                qn -= 1u;
             }
-            const uint32_t mlen = mlbase + (mlbits ? uni(b.read(mlbits)) : 0u);
-            const uint32_t llen = llbase + (llbits ? uni(b.read(llbits)) : 0u);
-            if (i + 1u < nseq) { /* state updates: LL, ML, OF */
-                sl = (el & 1023u) + uni(b.read((el >> 10) & 15u));
-                sm = (em & 1023u) + uni(b.read((em >> 10) & 15u));
-                so = (eo & 1023u) + uni(b.read((eo >> 10) & 15u));
-            }
-            /* execute */
-            if (llen > regen - lit_pos) return false;
-            if ((uint64_t)llen + mlen > (uint64_t)(cap - w.op)) return false;
-            if (lit_mode == 0) lvp = wave_copy_literals(w, lvp, llen);
-            else wave_fill(w, rle_byte, llen);
-            lit_pos += llen;
-            if (offset > w.op) return false;
-            wave_copy_match(w, offset, mlen);
-            w.flush();
         }
         if (b.over || b.pos != 0) return false; /* the bitstream must be consumed exactly */
     }
