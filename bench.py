@@ -174,8 +174,12 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     have_cuda = torch.cuda.is_available()
+    ndev = torch.cuda.device_count() if have_cuda else 0
+    # one process per GPU; if a node exposes fewer devices than ranks (functional tests of the N>1
+    # path on a 1-GPU box) ranks share devices round-robin
+    dev = local_rank % ndev if ndev else local_rank
     if have_cuda:
-        torch.cuda.set_device(local_rank)
+        torch.cuda.set_device(dev)
 
     from pg_cryogen_amd import Codec, METHOD_LZ4, bound
     from pg_cryogen_amd.codec import DIST_NAMES
@@ -189,7 +193,7 @@ def main():
 
     B, n = a.block_size, a.blocks
     dist_id = DIST_NAMES.index(a.dist)
-    codec = Codec(local_rank)
+    codec = Codec(dev)
     if a.workload != "lz4_decode":
         bench_roundtrip(a, codec, rank, world, barrier, torch, dist)
         codec.close()
