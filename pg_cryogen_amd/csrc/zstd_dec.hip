@@ -24,6 +24,8 @@
  *     matches read back from the flushed output, 1 KiB coalesced flushes to HBM.
  */
 #include "lz_common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace cryo {
 
@@ -457,8 +459,9 @@ struct FrameState {
 
 /* one compressed block; returns false on malformed input */
 __device__ bool decode_block(ZLds &L, Wave<ZR> &w, FrameState &fs, const uint8_t *src, uint32_t n, uint8_t *litbuf,
-                             uint32_t cap, uint32_t lane)
+                             uint32_t cap, uint32_t lane, Stats &st)
 {
+    stamp(st, 7);
     /* ---------------- literals section ---------------- */
     if (n < 3u) return false;
     const uint32_t b0 = uni(src[0]);
@@ -497,7 +500,9 @@ __device__ bool decode_block(ZLds &L, Wave<ZR> &w, FrameState &fs, const uint8_t
             fs.huf_valid = true;
             p += t; left -= (uint32_t)t;
         }
+        stamp(st, 0); /* literal header + huffman table */
         if (!huf_decode_streams(L, fs.huf_log, litbuf, regen, p, left, single, lane)) return false;
+        stamp(st, 1); /* huffman streams */
         lit_mode = 0; lit_ptr = litbuf; used = hdr + csize;
     }
     /* make the decoded literals visible to the staging loads (same wave, in-order memory ops) */
@@ -544,8 +549,9 @@ __device__ bool decode_block(ZLds &L, Wave<ZR> &w, FrameState &fs, const uint8_t
          * prefix of "simple" sequences is executed as ONE batch by the shared copy engine. */
         uint32_t q_ll = 0, q_ml = 0, q_off = 0;
         uint32_t qn = 0, decoded = 0;
-        Stats st = {};
+        stamp(st, 2); /* sequence tables */
         for (;;) {
+            stamp(st, 5);
             /* ---- refill the queue: serial FSE decode (one adaptive bitstream) ---- */
             while (qn < 64u && decoded < nseq) {
                 const uint32_t el = L.ll[sl], eo = L.of[so], em = L.ml[sm];
@@ -580,6 +586,7 @@ __device__ bool decode_block(ZLds &L, Wave<ZR> &w, FrameState &fs, const uint8_t
                 qn++;
             }
             if (qn == 0u) break;
+            stamp(st, 3); /* FSE sequence decode */
 
             /* ---- head prefix of the queue that the batch engine can take ---- */
             const bool inq = lane < qn;
@@ -639,10 +646,13 @@ __device__ bool decode_block(ZLds &L, Wave<ZR> &w, FrameState &fs, const uint8_t
 __global__ void __launch_bounds__(64)
 k_zstd_dec(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
            const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
-           uint64_t n_blocks, int32_t *__restrict__ status, uint8_t *workspace)
+           uint64_t n_blocks, int32_t *__restrict__ status, uint8_t *workspace, unsigned long long *stats)
 {
     __shared__ __attribute__((aligned(16))) ZLds L;
     const uint32_t lane = threadIdx.x & 63u;
+    Stats st = {};
+    st.on = stats != nullptr; /* diagnostic phase stamps (CRYO_ZSTD_STATS) */
+    if (st.on) st.t0 = __builtin_amdgcn_s_memtime();
     uint8_t *litbuf = workspace + (uint64_t)blockIdx.x * kLitBuf;
 
     for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
@@ -720,7 +730,7 @@ k_zstd_dec(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ sr
                         w.flush();
                     } else {
                         if (bsize >= kZBlockMax) { bad = true; break; }
-                        if (!decode_block(L, w, fs, src + ip, bsize, litbuf, B, lane)) { bad = true; break; }
+                        if (!decode_block(L, w, fs, src + ip, bsize, litbuf, B, lane, st)) { bad = true; break; }
                     }
                     ip += bsize;
                 }
@@ -745,6 +755,10 @@ k_zstd_dec(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ sr
         if (lane == 0) status[blk] = bad ? CRYO_ST_CORRUPT : CRYO_ST_OK;
         __builtin_amdgcn_wave_barrier();
     }
+    if (st.on && lane == 0) {
+        stamp(st, 7);
+        for (int k = 0; k < 8; k++) atomicAdd(&stats[k], st.t[k]);
+    }
 }
 
 static uint32_t zstd_grid(uint64_t n_blocks)
@@ -766,8 +780,24 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
     if (n_blocks == 0) return hipSuccess;
     const uint32_t grid = zstd_grid(n_blocks);
     if (workspace_bytes < (size_t)grid * kLitBuf) return hipErrorInvalidValue;
+    static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
+    unsigned long long *d_st = nullptr, h_st[8];
+    if (want_stats) {
+        if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
+    }
     hipLaunchKernelGGL(k_zstd_dec, dim3(grid), dim3(64), 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
-                       block_size, n_blocks, d_status, (uint8_t *)d_workspace);
+                       block_size, n_blocks, d_status, (uint8_t *)d_workspace, d_st);
+    if (want_stats) {
+        (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(d_st);
+        unsigned long long tot = 0;
+        for (int k = 0; k < 8; k++) tot += h_st[k];
+        static const char *nm[8] = {"lit hdr+huf table", "huffman streams", "seq tables", "FSE seq decode", "batch passA",
+                                    "batch setup/general", "batch passB+flush", "frame/other"};
+        for (int k = 0; k < 8; k++) fprintf(stderr, "[zstd cycles] %-20s %5.1f%%\n", nm[k], 100.0 * (double)h_st[k] / (double)(tot ? tot : 1));
+    }
     return hipGetLastError();
 }
 

@@ -99,3 +99,64 @@ def test_lz4_single_block_host_api(codec, oracle):
     out = codec.decompress_block(METHOD_LZ4, c, B)
     assert np.array_equal(out, b)
     assert codec.decompress_block(METHOD_LZ4, c[:-3], B) is None
+
+
+def test_lz4_decode_unaligned_inputs_and_edge_statuses(codec, oracle):
+    """compressed blocks packed at odd byte offsets; empty / absurd inputs are reported, never crash"""
+    from pg_cryogen_amd import METHOD_LZ4
+    B = 131072
+    blocks = [oracle.synth(11, i, B, i % 5) for i in range(7)]
+    comps = [oracle.lz4_compress(b, 1) for b in blocks]
+    comps.append(np.zeros(0, np.uint8))                       # empty stream -> corrupt
+    comps.append(np.array([0x00], np.uint8))                  # valid stream of an EMPTY block -> wrong size
+    n = len(comps)
+    offs, pos = [], 3
+    for c in comps:
+        offs.append(pos)
+        pos += len(c) + 1 + (len(c) % 7)                       # odd, irregular gaps
+    packed = np.full(pos + 64, 0xEE, np.uint8)
+    for o, c in zip(offs, comps):
+        packed[o:o + len(c)] = c
+    d_src, d_off, d_sz = codec.alloc(packed.nbytes), codec.alloc(8 * n), codec.alloc(4 * n)
+    d_dst, d_st = codec.alloc(n * (B + 5)), codec.alloc(4 * n)
+    d_src.upload(packed)
+    d_off.upload(np.array(offs, np.uint64))
+    d_sz.upload(np.array([len(c) for c in comps], np.uint32))
+    d_dst.memset(0x5A)
+    codec.decompress_batch(METHOD_LZ4, d_src, d_off, d_sz, d_dst, B + 5, B, n, d_st)   # odd dst stride too
+    codec.sync()
+    st = d_st.download(dtype=np.int32)
+    raw = d_dst.download()
+    for i, b in enumerate(blocks):
+        assert st[i] == 0
+        assert np.array_equal(raw[i * (B + 5):i * (B + 5) + B], b), i
+        assert (raw[i * (B + 5) + B:(i + 1) * (B + 5)] == 0x5A).all()          # nothing written past the block
+    assert st[7] != 0 and st[8] != 0
+    for x in (d_src, d_off, d_sz, d_dst, d_st):
+        x.free()
+
+
+def test_lz4_checksum_of_checksums_property(codec, oracle):
+    """size-independent property at a larger batch: per-block checksums of decode(encode(x)) equal those of x"""
+    from pg_cryogen_amd import METHOD_LZ4, bound
+    B, n = 131072, 2048
+    stride = (bound(METHOD_LZ4, B) + 15) & ~15
+    d_raw, d_comp, d_out = codec.alloc(n * B), codec.alloc(n * stride), codec.alloc(n * B)
+    d_sz, d_st, d_off = codec.alloc(4 * n), codec.alloc(4 * n), codec.alloc(8 * n)
+    d_s1, d_s2 = codec.alloc(8 * n), codec.alloc(8 * n)
+    for dist in (0, 1):
+        codec.synth_batch(5, 1000, n, B, dist, d_raw)
+        codec.compress_batch(METHOD_LZ4, 1, d_raw, B, B, n, d_comp, stride, d_sz, d_st)
+        d_off.upload(np.arange(n, dtype=np.uint64) * np.uint64(stride))
+        codec.decompress_batch(METHOD_LZ4, d_comp, d_off, d_sz, d_out, B, B, n, d_st)
+        codec.checksum_batch(d_raw, B, n, d_s1, fixed_size=B)
+        codec.checksum_batch(d_out, B, n, d_s2, fixed_size=B)
+        codec.sync()
+        assert (d_st.download(dtype=np.int32) == 0).all()
+        s1, s2 = d_s1.download(dtype=np.uint64), d_s2.download(dtype=np.uint64)
+        assert np.array_equal(s1, s2)
+        # the device checksum equals the host reference of the C ABI on a sampled block
+        from pg_cryogen_amd import checksum64
+        assert int(s1[17]) == checksum64(oracle.synth(5, 1017, B, dist))
+    for x in (d_raw, d_comp, d_out, d_sz, d_st, d_off, d_s1, d_s2):
+        x.free()

@@ -1,0 +1,37 @@
+"""Property tests (hypothesis) of the CPU oracle: decode(encode(x)) == x on arbitrary bytes, and the
+decoders never write outside their output on arbitrary (mostly malformed) input."""
+import numpy as np
+from hypothesis import given, settings, strategies as st
+
+import oracle_lib
+
+ORA = oracle_lib.Oracle()
+
+
+@settings(max_examples=150, deadline=None)
+@given(st.binary(min_size=0, max_size=3000), st.integers(0, 50))
+def test_lz4_oracle_roundtrip_arbitrary_bytes(data, accel):
+    a = np.frombuffer(data, np.uint8)
+    c = ORA.lz4_compress(a, accel)
+    r, out = ORA.lz4_decompress(c, len(a))
+    assert r == len(a) and bytes(out[:len(a)]) == data
+
+
+@settings(max_examples=150, deadline=None)
+@given(st.binary(min_size=1, max_size=400), st.integers(1, 512))
+def test_decoders_stay_inside_output_on_garbage(data, cap):
+    a = np.frombuffer(data, np.uint8)
+    for fn in (ORA.L.cryo_oracle_lz4_decompress, ORA.L.cryo_oracle_zstd_decompress):
+        out = np.full(cap + 64, 0xC3, np.uint8)
+        r = fn(a.ctypes.data, a.nbytes, out.ctypes.data, cap)
+        assert r <= cap
+        assert (out[cap:] == 0xC3).all()
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.integers(0, 2**32), st.integers(0, 4), st.sampled_from([-5, -1, 1, 2]))
+def test_zstd_oracle_roundtrip_synthetic(seed, dist, level):
+    raw = ORA.synth(seed, seed % 977, 20000, dist)
+    c = ORA.zstd_compress(raw, level)
+    r, out = ORA.zstd_decompress(c, 20000)
+    assert r == 20000 and np.array_equal(out, raw)
