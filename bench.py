@@ -42,8 +42,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="diagnostic ablation runs only: result is not valid")
-    ap.add_argument("--workload", default="lz4_decode", choices=["lz4_decode", "zstd", "lz4"],
-                    help="lz4_decode = headline (BASELINE configs[1]); zstd / lz4 = compress+decompress of the same "
+    ap.add_argument("--workload", default="lz4_decode", choices=["lz4_decode", "zstd_decode", "zstd", "lz4"],
+                    help="lz4_decode = headline (BASELINE configs[1]); zstd_decode = same shape for the zstd method; zstd / lz4 = compress+decompress of the same "
                          "batch (configs[2] shape), a secondary measurement")
     ap.add_argument("--level", type=int, default=1, help="zstd level for --workload zstd")
     return ap.parse_args()
@@ -194,13 +194,16 @@ def main():
     B, n = a.block_size, a.blocks
     dist_id = DIST_NAMES.index(a.dist)
     codec = Codec(dev)
-    if a.workload != "lz4_decode":
+    if not a.workload.endswith("_decode"):
         bench_roundtrip(a, codec, rank, world, barrier, torch, dist)
         codec.close()
         if world > 1:
             dist.destroy_process_group()
         return
-    stride = (bound(METHOD_LZ4, B) + 15) & ~15
+    from pg_cryogen_amd import METHOD_ZSTD
+    is_lz4 = a.workload == "lz4_decode"
+    method, param, mname = (METHOD_LZ4, a.accel, "lz4") if is_lz4 else (METHOD_ZSTD, a.level, "zstd")
+    stride = (bound(method, B) + 15) & ~15
 
     # ---------------- setup (untimed) ----------------
     d_raw = codec.alloc(n * B)
@@ -214,10 +217,10 @@ def main():
     job_block = lambda k: rank + k * world
     codec.synth_batch(0, rank, n, B, dist_id, d_raw, block_step=world)
     codec.timer_start()
-    codec.compress_batch(METHOD_LZ4, a.accel, d_raw, B, B, n, d_comp, stride, d_sizes, d_status)
+    codec.compress_batch(method, param, d_raw, B, B, n, d_comp, stride, d_sizes, d_status)
     enc_ms = codec.timer_stop()
     st = d_status.download(dtype=np.int32)
-    assert (st == 0).all(), "lz4 encode status"
+    assert (st == 0).all(), "encode status"
     sizes = d_sizes.download(dtype=np.uint32)
     d_off.upload(np.arange(n, dtype=np.uint64) * np.uint64(stride))
     comp_bytes = int(sizes.astype(np.uint64).sum())
@@ -229,15 +232,15 @@ def main():
     for i in sample_idx:
         c = d_comp.download(int(sizes[i]), offset=i * stride)
         raw = ora.synth(0, job_block(i), B, dist_id)
-        exp = ora.lz4_compress(raw, a.accel)
-        assert np.array_equal(c, exp), "device lz4 encode differs from oracle at block %d" % i
+        exp = ora.lz4_compress(raw, param) if is_lz4 else ora.zstd_compress(raw, param)
+        assert np.array_equal(c, exp), "device encode differs from oracle at block %d" % i
         sample_comps.append(c)
     # cpu_baseline sample: 512 device-encoded blocks (64 MiB uncompressed), enough for every host thread
     cpu_idx = list(range(0, n, max(1, n // 512)))[:512]
     cpu_comps = [d_comp.download(int(sizes[i]), offset=i * stride) for i in cpu_idx] if (world == 1 and not a.no_cpu_baseline) else []
 
     def step():
-        codec.decompress_batch(METHOD_LZ4, d_comp, d_off, d_sizes, d_out, B, B, n, d_status)
+        codec.decompress_batch(method, d_comp, d_off, d_sizes, d_out, B, B, n, d_status)
 
     for _ in range(a.warmup):
         step()
@@ -257,7 +260,7 @@ def main():
 
     # ---------------- verification (untimed) ----------------
     st = d_status.download(dtype=np.int32)
-    assert a.no_verify or (st == 0).all(), "lz4 decode status"
+    assert a.no_verify or (st == 0).all(), "decode status"
     d_mis.memset(0)
     codec.compare_batch(d_raw, B, d_out, B, B, n, d_mis)
     codec.sync()
@@ -281,31 +284,32 @@ def main():
                 if fn.endswith("_hbm_traffic.json"):
                     t = json.load(open(os.path.join(ROOT, "profiles", fn)))
                     wl = t.get("workload", {})
-                    if (wl.get("blocks_per_gpu"), wl.get("block_size"), wl.get("distribution"),
-                            wl.get("lz4_acceleration")) == (n, B, a.dist, a.accel):
+                    if (wl.get("method", "lz4"), wl.get("blocks_per_gpu"), wl.get("block_size"), wl.get("distribution"),
+                            wl.get("param", wl.get("lz4_acceleration"))) == (mname, n, B, a.dist, param):
                         traffic = t["traffic_bytes_per_launch"]
                         break
         except OSError:
             pass
         out = {
-            "metric": "lz4_decompress_uncompressed_GBps", "value": round(value, 2), "unit": "GB/s",
+            "metric": "%s_decompress_uncompressed_GBps" % mname, "value": round(value, 2), "unit": "GB/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "LZ4 decompress %d x %d KiB synthetic cryo blocks per GPU" % (n, B // 1024),
-                       "distribution": a.dist, "lz4_acceleration": a.accel, "block_size": B,
+            "config": {"workload": "%s decompress %d x %d KiB synthetic cryo blocks per GPU" % (mname.upper(), n, B // 1024),
+                       "distribution": a.dist, "method": mname, "param": param, "block_size": B,
                        "blocks_per_gpu": n, "sharding": "block i -> rank i mod N, no collective",
                        "compression_ratio": round(n * B / comp_bytes, 3),
                        "bit_exact": "encode == oracle on %d sampled blocks; decode == original on all %d blocks"
                                     % (len(sample_idx), n),
-                       "setup_lz4_encode_GBps": round(n * B / (enc_ms * 1e-3) / 1e9, 2)},
+                       "setup_encode_GBps": round(n * B / (enc_ms * 1e-3) / 1e9, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "k_lz4_dec", "avg_launch_ms": round(avg_ms, 4),
+                         "kernel": "k_lz4_dec_ring" if is_lz4 else "k_zplan+k_zhuf+k_zseq+k_zexec (one decode call)",
+                         "avg_launch_ms": round(avg_ms, 4),
                          "algorithmic_bytes_per_launch": algo_bytes},
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cpu_comps, B, a.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(cpu_comps, B, a.cpu_seconds, 0 if is_lz4 else 1)
         print(json.dumps(out), flush=True)
 
     for b in (d_raw, d_comp, d_out, d_sizes, d_status, d_off, d_mis):

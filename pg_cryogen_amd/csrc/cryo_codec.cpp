@@ -29,6 +29,9 @@ struct cryo_codec {
     /* zstd decode workspace */
     void *d_ws = nullptr;
     size_t ws_cap = 0;
+    /* side streams of the zstd batch pipeline (created on first use) */
+    cryo::ZstdAux aux = {};
+    bool have_aux = false;
 };
 
 namespace {
@@ -118,6 +121,11 @@ void cryo_codec_close(cryo_codec *c)
     if (c->d_size) (void)hipFree(c->d_size);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_ws) (void)hipFree(c->d_ws);
+    for (int l = 0; l < 2; l++) {
+        if (c->aux.lane[l]) { (void)hipStreamSynchronize(c->aux.lane[l]); (void)hipStreamDestroy(c->aux.lane[l]); }
+        if (c->aux.join[l]) (void)hipEventDestroy(c->aux.join[l]);
+    }
+    if (c->aux.fork) (void)hipEventDestroy(c->aux.fork);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -237,9 +245,18 @@ int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
         const size_t need = cryo::zstd_decompress_workspace(n_blocks, block_size);
         int rc = ensure_ws(c, need);
         if (rc != CRYO_OK) return rc;
+        if (!c->have_aux) {
+            HIP_TRY(c, hipSetDevice(c->device));
+            for (int l = 0; l < 2; l++) {
+                HIP_TRY(c, hipStreamCreateWithFlags(&c->aux.lane[l], hipStreamNonBlocking));
+                HIP_TRY(c, hipEventCreateWithFlags(&c->aux.join[l], hipEventDisableTiming));
+            }
+            HIP_TRY(c, hipEventCreateWithFlags(&c->aux.fork, hipEventDisableTiming));
+            c->have_aux = true;
+        }
         HIP_TRY(c, cryo::launch_zstd_decompress(c->stream, (const uint8_t *)d_src, d_src_off, d_src_size,
                                                 (uint8_t *)d_dst, dst_stride, block_size, n_blocks,
-                                                d_status, c->d_ws, c->ws_cap));
+                                                d_status, c->d_ws, c->ws_cap, &c->aux));
     }
     c->ctr.blocks_decompressed += n_blocks;
     c->ctr.bytes_out += n_blocks * (uint64_t)block_size;

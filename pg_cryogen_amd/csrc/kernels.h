@@ -33,11 +33,16 @@ hipError_t launch_lz4_compress(hipStream_t s, const uint8_t *d_src, uint64_t src
                                uint64_t dst_stride, int accel, uint32_t *d_out_size,
                                int32_t *d_status);
 
-/* zstd frames */
+/* zstd frames.  `aux` (optional): two side streams + events the batch pipeline alternates its tiles on;
+ * the work is ordered after everything already queued on `s`, and `s` waits for it before returning. */
+struct ZstdAux {
+    hipStream_t lane[2];
+    hipEvent_t fork, join[2];
+};
 hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                   const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                   uint32_t block_size, uint64_t n_blocks, int32_t *d_status,
-                                  void *d_workspace, size_t workspace_bytes);
+                                  void *d_workspace, size_t workspace_bytes, const ZstdAux *aux);
 size_t zstd_decompress_workspace(uint64_t n_blocks, uint32_t block_size);
 /* fused one-wave-per-frame decoder (zstd_dec.hip): small batches, and the pipeline's irregular frames
  * (d_list != nullptr: decode blocks list_base + d_list[0 .. *d_list_n), n_blocks only sizes the grid) */

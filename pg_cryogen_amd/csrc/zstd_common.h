@@ -78,6 +78,138 @@ struct BitRd {
     __device__ inline uint32_t read(uint32_t nb) { const uint32_t v = peek(nb); skip(nb); return v; }
 };
 
+/* ---- per-lane backward bit reader fed through a private LDS ring ----
+ * For kernels that run one bitstream PER LANE (zstd_pipe.hip: Huffman streams, FSE sequences).  A lane
+ * that refills its container straight from global memory stalls the whole wave (s_waitcnt counts are per
+ * wave, and the lanes refill at different times), so here the global loads happen at fixed program points
+ * (`tick<J>`, J = static slot 0..3, one 16-byte block per lane per tick at most, consumed four ticks
+ * later), land in a 128-byte per-lane ring in LDS (rows 0..31 of a [36][NL] dword array: mirror of the
+ * address bits 0..6, transposed so lane l only touches bank l; rows 32..35 take the idle slots' stores), and the container is rebuilt from the ring with three aligned ds_reads.
+ *
+ * Contract: at most 12 bytes consumed between two ticks, at most 57 bits between two fills.  With one
+ * block issued per tick while less than 112 bytes are reserved below the read position, at least 36
+ * staged bytes are always ahead of the reader (zstd decode).  Bits below the stream start read
+ * as zero, as in BitRd.  NL = lanes sharing the ring array.
+ * Loads are whole aligned 16-byte blocks: up to 15 bytes after the stream end and down to the frame's
+ * first byte rounded down to 16 are touched. */
+template <int NL>
+struct LaneBits {
+    uint32_t *ring;        /* this lane's column: dword d is ring[d * NL] */
+    const uint8_t *origin; /* the frame's first byte rounded down to 16; every position below is an offset from it
+                              (a pointer rebuilt from an integer would turn the loads into FLAT accesses) */
+    int32_t o_start, o_top; /* stream byte 0; 16-aligned end: block b = [o_top - 16(b+1), o_top - 16b) */
+    int32_t pos;            /* unread bits */
+    uint32_t issued, written, pend;
+    bool alive;
+    uint64_t c; /* container, left aligned */
+    uint4 t0, t1, t2, t3;
+
+    __device__ inline uint4 load_block(uint32_t idx) const
+    {
+        const int32_t a = o_top - 16 * (int32_t)(idx + 1u);
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (a >= 0) v = *reinterpret_cast<const uint4 *>(origin + a);
+        return v;
+    }
+    __device__ inline void write_block(uint4 v, uint32_t idx)
+    {
+        const int32_t a = o_top - 16 * (int32_t)(idx + 1u);
+        if (a < o_start) { /* zero the bytes below the stream start */
+            const int32_t k = o_start - a > 16 ? 16 : o_start - a;
+            auto m = [&](int32_t q) { const int32_t nz = k - 4 * q; return nz >= 4 ? 0u : (nz <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * nz)); };
+            v.x &= m(0); v.y &= m(1); v.z &= m(2); v.w &= m(3);
+        }
+        const uint32_t d0 = (uint32_t)(a >> 2) & 31u;
+        ring[(d0 + 0u) * NL] = v.x;
+        ring[(d0 + 1u) * NL] = v.y;
+        ring[(d0 + 2u) * NL] = v.z;
+        ring[(d0 + 3u) * NL] = v.w;
+    }
+    /* open the stream frame_src[off .. off+len) (false: empty or no end mark); primes the ring with its top 112 bytes */
+    __device__ inline bool init(uint32_t *ring_col, const uint8_t *frame_src, uint32_t off, uint32_t len, bool on)
+    {
+        ring = ring_col;
+        const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(frame_src) & 15u);
+        origin = frame_src - mis;
+        o_start = (int32_t)(off + mis);
+        o_top = (int32_t)((off + mis + len + 15u) & ~15u);
+        pos = 0; issued = written = pend = 0; c = 0;
+        t0 = t1 = t2 = t3 = make_uint4(0, 0, 0, 0);
+        alive = on && len >= 1u;
+        uint32_t last = 0;
+        if (alive) last = frame_src[off + len - 1u];
+        if (last == 0u) alive = false;
+        if (!alive) { o_start = 16; o_top = 16; } /* idle ticks re-read origin[0..16) */
+        if (alive) {
+            pos = (int32_t)(len - 1u) * 8 + (31 - __builtin_clz(last));
+            const uint4 a = load_block(0), b = load_block(1), c4 = load_block(2), d = load_block(3);
+            const uint4 e = load_block(4), f = load_block(5), g = load_block(6);
+            write_block(a, 0); write_block(b, 1); write_block(c4, 2); write_block(d, 3);
+            write_block(e, 4); write_block(f, 5); write_block(g, 6);
+            issued = written = 7;
+        }
+        return alive;
+    }
+    template <int J>
+    __device__ inline uint4 &slot() { if constexpr (J == 0) return t0; else if constexpr (J == 1) return t1; else if constexpr (J == 2) return t2; else return t3; }
+    /* fixed-cadence ring maintenance: retire the block loaded four ticks ago, maybe start another.
+     * Branch-free around the memory operations -- exactly one global load and four LDS stores per tick,
+     * whether or not the lane needs them (an idle slot re-reads the previous block and lands in the trash
+     * rows 32..35) -- so the compiler can count the loads in flight (s_waitcnt vmcnt(3)) instead of draining. */
+    template <int J>
+    __device__ inline void tick()
+    {
+        {
+            const bool pending = (pend >> J) & 1u;
+            uint4 v = slot<J>();
+            const int32_t a = o_top - 16 * (int32_t)(written + 1u);
+            if (a < o_start) { /* zero the bytes below the stream start */
+                const int32_t k = o_start - a > 16 ? 16 : o_start - a;
+                auto m = [&](int32_t q) { const int32_t nz = k - 4 * q; return nz >= 4 ? 0u : (nz <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * nz)); };
+                v.x &= m(0); v.y &= m(1); v.z &= m(2); v.w &= m(3);
+            }
+            const uint32_t d0 = pending ? (uint32_t)(a >> 2) & 31u : 32u;
+            ring[(d0 + 0u) * NL] = v.x;
+            ring[(d0 + 1u) * NL] = v.y;
+            ring[(d0 + 2u) * NL] = v.z;
+            ring[(d0 + 3u) * NL] = v.w;
+            written += pending ? 1u : 0u;
+        }
+        const int32_t t = o_start + (pos > 0 ? (pos - 1) >> 3 : 0);
+        const int32_t low = o_top - 16 * (int32_t)issued;
+        const bool want = alive && t - low < 112 && low > o_start - 8;
+        const uint32_t b = want ? issued : (issued ? issued - 1u : 0u);
+        int32_t off = o_top - 16 * (int32_t)(b + 1u);
+        off = off < 0 ? 0 : off; /* blocks below the origin lie wholly below the stream start: masked to zero above */
+        slot<J>() = *reinterpret_cast<const uint4 *>(origin + off);
+        issued += want ? 1u : 0u;
+        pend = (pend & ~(1u << J)) | ((want ? 1u : 0u) << J);
+    }
+    /* rebuild the container: >= 57 valid bits (or all that are left) */
+    __device__ inline void fill()
+    {
+        c = 0;
+        if (pos > 0) {
+            const int32_t lowoff = o_start + ((pos - 1) >> 3) - 7;
+            const uint32_t d0 = (uint32_t)(lowoff >> 2), s = (uint32_t)lowoff & 3u;
+            const uint32_t w0 = ring[(d0 & 31u) * NL], w1 = ring[((d0 + 1u) & 31u) * NL], w2 = ring[((d0 + 2u) & 31u) * NL];
+            const uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, s), hi = __builtin_amdgcn_alignbyte(w2, w1, s);
+            c = (((uint64_t)hi << 32) | lo) << (7u - ((uint32_t)(pos - 1) & 7u));
+        }
+    }
+    __device__ inline uint32_t peek(uint32_t nb) const { return (uint32_t)((c >> 1) >> (63u - nb)); } /* nb 0..32 */
+    __device__ inline uint32_t peek_nz(uint32_t nb) const { return (uint32_t)(c >> 32) >> (32u - nb); } /* nb 1..32 */
+    __device__ inline void skip(uint32_t nb) { c <<= nb; pos -= (int32_t)nb; }
+    __device__ inline uint32_t read(uint32_t nb) { const uint32_t v = peek(nb); skip(nb); return v; }
+};
+
+__device__ inline uint32_t wave_max(uint32_t v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)v, o, 64); v = x > v ? x : v; }
+    return uni(v);
+}
+
 __device__ inline uint32_t hb32(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
 
 /* ---- FSE table description (forward, LSB-first bits); wave-uniform.  Returns bytes used or -1. */

@@ -22,7 +22,8 @@
  * skippable frames, malformed headers, pool exhaustion) is put on an irregular list and decoded by the
  * fused kernel afterwards, so coverage and error behaviour are exactly the fused decoder's.
  *
- * The batch is processed in tiles of F frames so the workspace stays bounded (~4 GiB).
+ * The batch is processed in tiles of F <= 7680 frames (one full round of K2 and of K3 on 256 CUs) so the
+ * workspace stays bounded (~2.3 GiB for 128 KiB blocks).
  */
 #include "zstd_common.h"
 #include "kernels.h"
@@ -101,6 +102,17 @@ struct PlanState {
 __device__ inline void copy_words(uint32_t *dst, const uint32_t *src, uint32_t n, uint32_t lane)
 {
     for (uint32_t i = lane; i < n; i += 64u) dst[i] = src[i];
+}
+
+/* sequence decoding table -> workspace, with the symbol's extra-bit count folded in at bits 20..24 (K3 needs
+ * the bit counts, not the base values, to find the next state: one LDS round trip less on its critical path) */
+__device__ inline void copy_seq_table(uint32_t *dst, const uint32_t *src, uint32_t n, int kind, uint32_t lane)
+{
+    for (uint32_t i = lane; i < n; i += 64u) {
+        const uint32_t e = src[i], sym = e >> 14;
+        const uint32_t xb = kind == 0 ? kLLBits[sym] : (kind == 1 ? sym : kMLBits[sym]);
+        dst[i] = e | (xb << 20);
+    }
 }
 
 /* K1: one compressed block's section headers -> descriptor + tables.  false = not plannable. */
@@ -209,7 +221,7 @@ __device__ bool plan_block(PlanLds &L, const ZPipe &P, PlanState &ps, const uint
                 ip += u; left -= (uint32_t)u;
                 if (mode != 3) {
                     __builtin_amdgcn_wave_barrier();
-                    copy_words(gt + goff, lt, 1u << lg, lane);
+                    copy_seq_table(gt + goff, lt, 1u << lg, kind, lane);
                     __builtin_amdgcn_wave_barrier();
                     ps.slot[kind] = k;
                     ps.log[kind] = (uint32_t)lg;
@@ -241,7 +253,7 @@ __global__ void __launch_bounds__(64) k_zplan(ZPipe P)
             uint32_t *lt = kind == 0 ? L.ll : (kind == 1 ? L.of : L.ml);
             (void)read_seq_table(L, lt, &lg, kind, 0, nullptr, 0, false);
             __builtin_amdgcn_wave_barrier();
-            copy_words(P.predef + (kind == 0 ? 0u : (kind == 1 ? 1024u : 512u)), lt, 1u << lg, lane);
+            copy_seq_table(P.predef + (kind == 0 ? 0u : (kind == 1 ? 1024u : 512u)), lt, 1u << lg, kind, lane);
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -330,7 +342,16 @@ __global__ void __launch_bounds__(64) k_zplan(ZPipe P)
         }
         if (regular) {
             for (uint32_t k = 0; k < nblk; k++)
-                if (bd[k].type == 2u && bd[k].lit_mode == 2u) P.hitems[atomicAdd(&P.counters[1], 1u)] = f * P.nbmax + k;
+                if (bd[k].type == 2u && bd[k].lit_mode == 2u) {
+                    P.hitems[atomicAdd(&P.counters[1], 1u)] = f * P.nbmax + k;
+                    atomicAdd(&P.counters[4 + (bd[k].huf_log & 15u)], 1u); /* histogram of table logs (diagnostics) */
+                }
+            for (uint32_t k = 0; k < nblk; k++)
+                if (bd[k].type == 2u && bd[k].nseq) {
+                    atomicAdd(&P.counters[20 + (bd[k].logs & 15u)], 1u);
+                    atomicAdd(&P.counters[32 + ((bd[k].logs >> 8) & 15u)], 1u);
+                    atomicAdd(&P.counters[44 + ((bd[k].logs >> 16) & 15u)], 1u);
+                }
         } else {
             fr.flags = F_IRREG;
             P.irregular[atomicAdd(&P.counters[2], 1u)] = f;
@@ -342,38 +363,109 @@ __global__ void __launch_bounds__(64) k_zplan(ZPipe P)
 
 /* ------------------------------------------------------------------------------------------------ K2 */
 constexpr uint32_t kHufPerWave = 16; /* blocks per wave: 16 x 4 streams = 64 lanes */
-constexpr uint32_t kHufLdsLog = 11;  /* tables up to 2^11 entries sit in LDS; 2^12 ones are read from L2 */
+constexpr uint32_t kHufL1 = 11;      /* table in LDS: 2^11 entries (4 KiB) per block -- every table libzstd's encoder emits */
+
+constexpr uint32_t kHufL2 = 128;     /* second-level entries per block */
+
+/* LDS capacity bounds this kernel (streams in flight per CU = LDS / table bytes per stream; the lookup
+ * latency per symbol is fixed).  A table of 2^12 entries (legal, never produced by libzstd) is kept as two
+ * levels: the first indexed by the next 11 bits; prefixes under which 12-bit codes live carry nbits = 0 and
+ * the number of a 2-entry sub-table (255: no room, resolved in the full table in global memory).
+ * A two-level table with a 9-bit first level was measured: 2.5x the waves per CU but twice the time per
+ * symbol (the escape test serialises each lookup), a net loss at 11 bits. */
+struct HufLds {
+    uint16_t tbl[kHufPerWave << kHufL1];
+    uint16_t sub[kHufPerWave * kHufL2];
+    uint32_t ring[36][64];
+};
+
+struct HufTab {
+    const uint16_t *t, *t2, *gt;
+    uint32_t l1, hlog, sh;
+};
+
+template <bool TWO>
+__device__ inline uint32_t huf_symbol(LaneBits<64> &lb, const HufTab &h)
+{
+    uint32_t e = h.t[lb.peek_nz(h.l1)];
+    if (TWO && (e >> 8) == 0u) { /* long code */
+        const uint32_t full = lb.peek_nz(h.hlog), s = e & 255u;
+        if (s != 255u) e = h.t2[(s << h.sh) | (full & ((1u << h.sh) - 1u))];
+        else {
+            e = h.gt[full];
+            asm volatile("" : "+v"(e)); /* take the load's wait here, not at the join every lane passes */
+        }
+    }
+    lb.skip(e >> 8);
+    return e & 255u;
+}
+
+/* eight symbols -> one 8-byte store; two container fills (4 x 12 bits <= 57) */
+template <int J, bool TWO>
+__device__ inline void huf_octet(LaneBits<64> &lb, const HufTab &h, uint8_t *o, uint32_t r, uint32_t n8)
+{
+    lb.tick<J>();
+    if (r + J < n8) {
+        uint64_t acc = 0;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            lb.fill();
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc |= (uint64_t)huf_symbol<TWO>(lb, h) << (8 * (4 * half + q));
+        }
+        __builtin_memcpy(o + (size_t)(r + J) * 8u, &acc, 8);
+    }
+}
 
 __global__ void __launch_bounds__(64) k_zhuf(ZPipe P)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t tbl[kHufPerWave << kHufLdsLog];
+    __shared__ __attribute__((aligned(16))) HufLds L;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nitems = uni(P.counters[1]);
     const uint32_t base = blockIdx.x * kHufPerWave;
     if (base >= nitems) return;
 
-    /* stage the 16 tables: 4 KiB each, 16 bytes per lane per step */
+    /* stage the 16 first-level tables */
     for (uint32_t j = 0; j < kHufPerWave && base + j < nitems; j++) {
         const uint32_t it = uni(P.hitems[base + j]);
         const ZBlk *d = P.blks + it;
         const uint32_t f = it / P.nbmax;
         const uint32_t hlog = uni(d->huf_log);
-        if (hlog > kHufLdsLog) continue;
-        const uint4 *g = reinterpret_cast<const uint4 *>(P.huf + ((uint64_t)f * P.nbmax + uni(d->huf_slot)) * kHufTblWords);
-        uint4 *l = reinterpret_cast<uint4 *>(tbl + (j << kHufLdsLog));
-        const uint32_t n16 = ((2u << hlog) + 15u) >> 4;
-        for (uint32_t i = lane; i < n16; i += 64u) l[i] = g[i];
+        const uint16_t *g = P.huf + ((uint64_t)f * P.nbmax + uni(d->huf_slot)) * kHufTblWords;
+        uint16_t *l = L.tbl + (j << kHufL1);
+        if (hlog <= kHufL1) {
+            for (uint32_t i = lane; i < (1u << hlog); i += 64u) l[i] = g[i];
+        } else {
+            const uint32_t sh = hlog - kHufL1, cap = kHufL2 >> sh;
+            uint16_t *l2 = L.sub + j * kHufL2;
+            uint32_t running = 0;
+            for (uint32_t i = lane; i < (1u << kHufL1); i += 64u) {
+                uint32_t e = g[i << sh];
+                const bool lng = (e >> 8) > kHufL1;
+                const unsigned long long m = __ballot(lng);
+                if (lng) {
+                    const uint32_t rank = running + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (rank < cap) {
+                        for (uint32_t k = 0; k < (1u << sh); k++) l2[(rank << sh) + k] = g[(i << sh) + k];
+                        e = rank;
+                    } else e = 255u;
+                }
+                l[i] = (uint16_t)e;
+                running += (uint32_t)__builtin_popcountll(m);
+            }
+        }
     }
     __builtin_amdgcn_wave_barrier();
 
     const uint32_t j = lane >> 2, sid = lane & 3u;
-    if (base + j >= nitems) return;
-    const uint32_t it = P.hitems[base + j];
+    bool have = base + j < nitems;
+    const uint32_t it = have ? P.hitems[base + j] : P.hitems[base];
     const ZBlk *d = P.blks + it;
     const uint32_t f = it / P.nbmax;
     const uint32_t nstreams = d->nstreams;
-    if (sid >= nstreams) return;
+    have = have && sid < nstreams;
     const uint32_t regen = d->regen, hlog = d->huf_log;
+    const uint32_t l1 = hlog < kHufL1 ? hlog : kHufL1;
     const uint32_t seg = (regen + 3u) / 4u;
     uint32_t cnt, oofs;
     if (nstreams == 1u) { cnt = regen; oofs = 0; }
@@ -381,101 +473,195 @@ __global__ void __launch_bounds__(64) k_zhuf(ZPipe P)
     const uint64_t blk = P.first + f;
     const uint8_t *src = P.src_base + P.src_off[blk];
     uint8_t *o = P.lits + (uint64_t)f * P.litcap + d->lit_src + oofs;
+    const uint32_t soff = d->hs_off[sid], slen = d->hs_len[sid];
+    const uint16_t *gt = P.huf + ((uint64_t)f * P.nbmax + d->huf_slot) * kHufTblWords;
 
-    BitRd b;
-    bool ok = b.init(src + d->hs_off[sid], d->hs_len[sid]);
-    if (ok) {
-        uint32_t i = 0;
-        if (hlog <= kHufLdsLog) {
-            const uint16_t *t = tbl + (j << kHufLdsLog);
-            for (; i + 8u <= cnt; i += 8u) { /* 8 symbols -> one 8-byte store */
-                uint64_t acc = 0;
-#pragma unroll
-                for (int q = 0; q < 8; q++) {
-                    const uint32_t e = t[b.peek(hlog)];
-                    acc |= (uint64_t)(e & 255u) << (8 * q);
-                    b.skip(e >> 8);
-                }
-                __builtin_memcpy(o + i, &acc, 8);
-            }
-            for (; i < cnt; i++) {
-                const uint32_t e = t[b.peek(hlog)];
-                o[i] = (uint8_t)e;
-                b.skip(e >> 8);
-            }
-        } else {
-            const uint16_t *t = P.huf + ((uint64_t)f * P.nbmax + d->huf_slot) * kHufTblWords;
-            for (; i < cnt; i++) {
-                const uint32_t e = t[b.peek(hlog)];
-                o[i] = (uint8_t)e;
-                b.skip(e >> 8);
-            }
+    bool ok = true;
+    LaneBits<64> lb;
+    const bool opened = lb.init(&L.ring[0][lane], src, soff, slen, have);
+    if (have && !opened) ok = false;
+    HufTab h;
+    h.t = L.tbl + (j << kHufL1);
+    h.t2 = L.sub + j * kHufL2;
+    h.gt = gt;
+    h.l1 = l1; h.hlog = hlog; h.sh = hlog > kHufL1 ? hlog - kHufL1 : 0u;
+    const uint32_t n8 = opened ? cnt >> 3 : 0u;
+    const uint32_t maxn8 = wave_max(n8);
+    if (wave_max(hlog) <= kHufL1) {
+        for (uint32_t r = 0; r < maxn8; r += 4u) {
+            huf_octet<0, false>(lb, h, o, r, n8);
+            huf_octet<1, false>(lb, h, o, r, n8);
+            huf_octet<2, false>(lb, h, o, r, n8);
+            huf_octet<3, false>(lb, h, o, r, n8);
         }
-        ok = (b.pos == 0) && !b.over; /* must end exactly */
+    } else {
+        for (uint32_t r = 0; r < maxn8; r += 4u) {
+            huf_octet<0, true>(lb, h, o, r, n8);
+            huf_octet<1, true>(lb, h, o, r, n8);
+            huf_octet<2, true>(lb, h, o, r, n8);
+            huf_octet<3, true>(lb, h, o, r, n8);
+        }
     }
-    if (!ok) atomicOr(&P.frames[f].flags, F_BAD);
+    if (opened) { /* the last cnt % 8 symbols */
+        uint32_t i = n8 * 8u;
+        lb.fill();
+        for (uint32_t q = 0; q < 4u && i < cnt; q++, i++) o[i] = (uint8_t)huf_symbol<true>(lb, h);
+        lb.fill();
+        for (; i < cnt; i++) o[i] = (uint8_t)huf_symbol<true>(lb, h);
+        ok = lb.pos == 0; /* must end exactly */
+    }
+    if (have && !ok) atomicOr(&P.frames[f].flags, F_BAD);
 }
 
 /* ------------------------------------------------------------------------------------------------ K3 */
+constexpr uint32_t kSeqPerWave = 15; /* frames per wave: 15 x 5 KiB of decoding tables in LDS, 2 workgroups per CU */
+
+struct SeqLds {
+    uint32_t tab[kSeqPerWave][kSeqTblWords];
+    uint32_t ring[36][16];
+    uint32_t cur[kSeqPerWave][4];
+    uint32_t llx[36], mlx[53]; /* base value | extra bits << 24 (LDS copies: a constant-memory load in the loop
+                                  would wait on the ring's in-flight global loads as well) */
+};
+
+struct SeqState {
+    uint32_t sl, so, sm, rep0, rep1, rep2;
+};
+
+/* nb <= 31 bits off the top of the container */
+__device__ inline uint32_t seq_bits(LaneBits<16> &lb, uint32_t nb)
+{
+    const uint32_t v = __builtin_amdgcn_ubfe((uint32_t)(lb.c >> 32), 32u - nb, nb);
+    lb.skip(nb);
+    return v;
+}
+
+struct SeqPre { uint32_t el, eo, em; }; /* table entries of the next sequence, already on their way from LDS */
+
+/* One sequence.  Entry: next-state base (10 bits) | state bits (4) | symbol (6) | extra bits (5).
+ * The serial chain is entries -> bit counts -> state bits -> next states -> next entries; the entry reads
+ * and the container fill for sequence i+1 are issued as soon as the states are known, and everything else
+ * (base values, repeat offsets, the record store, the ring tick) runs while they are in flight.
+ * Bit budget after a fill is >= 57: offset code <= 31 bits, length extras <= 32, state updates <= 26 -- one
+ * fill covers the usual sequence, two more are taken only by the lanes that need them. */
+template <int J>
+__device__ inline void seq_step(LaneBits<16> &lb, const uint32_t *tab, const uint32_t *llx, const uint32_t *mlx, SeqState &z,
+                                SeqPre &pre, uint4 *out, uint32_t i, uint32_t nseq)
+{
+    if (i + J < nseq) {
+        const uint32_t el = pre.el, eo = pre.eo, em = pre.em;
+        const uint32_t lsym = (el >> 14) & 63u, osym = (eo >> 14) & 63u, msym = (em >> 14) & 63u;
+        const uint32_t llbits = (el >> 20) & 31u, mlbits = (em >> 20) & 31u;
+        int32_t avail = 57;
+        /* offset code: osym extra bits (the 1-bit repeat index when osym == 1, none when 0) */
+        const uint32_t extra = seq_bits(lb, osym);
+        avail -= (int32_t)osym;
+        if (avail < (int32_t)(mlbits + llbits)) { lb.fill(); avail = 57; }
+        const uint32_t mlv = seq_bits(lb, mlbits);
+        const uint32_t llv = seq_bits(lb, llbits);
+        avail -= (int32_t)(mlbits + llbits);
+        if (i + J + 1u < nseq) { /* state updates: LL, ML, OF; then start fetching the next sequence */
+            const uint32_t nl = (el >> 10) & 15u, nm = (em >> 10) & 15u, no = (eo >> 10) & 15u;
+            if (avail < (int32_t)(nl + nm + no)) lb.fill();
+            z.sl = (el & 1023u) + seq_bits(lb, nl);
+            z.sm = (em & 1023u) + seq_bits(lb, nm);
+            z.so = (eo & 1023u) + seq_bits(lb, no);
+            pre.el = tab[z.sl]; pre.eo = tab[1024u + z.so]; pre.em = tab[512u + z.sm];
+            lb.fill();
+        }
+        const uint32_t llbase = llx[lsym] & 0xFFFFFFu, mlbase = mlx[msym] & 0xFFFFFFu;
+        const uint32_t ll0 = lsym == 0u ? 1u : 0u; /* literal length 0 <=> code 0 */
+        const bool fresh = osym > 1u;
+        const uint32_t idx = (osym == 1u ? 1u + extra : 0u) + ll0; /* repeat-offset index 0..3 (unused when fresh) */
+        uint32_t cand = idx == 0u ? z.rep0 : (idx == 1u ? z.rep1 : (idx == 2u ? z.rep2 : z.rep0 - 1u));
+        if (cand == 0u) cand = 1u; /* 0 is not valid: forced to 1 like the library */
+        const uint32_t offset = fresh ? ((1u << osym) - 3u) + extra : cand;
+        const uint32_t r0 = z.rep0, r1 = z.rep1;
+        z.rep0 = offset;
+        z.rep1 = (!fresh && idx == 0u) ? r1 : r0;
+        z.rep2 = (fresh || idx >= 2u) ? r1 : z.rep2;
+        out[i + J] = make_uint4(llbase + llv, mlbase + mlv, offset, 0u);
+    }
+    lb.tick<J>();
+}
+
 __global__ void __launch_bounds__(64) k_zseq(ZPipe P)
 {
-    const uint32_t f = blockIdx.x * 64u + (threadIdx.x & 63u);
-    if (f >= P.F) return;
-    const uint32_t flags = P.frames[f].flags;
-    if (flags & (F_BAD | F_IRREG)) return;
-    const uint32_t nblk = P.frames[f].nblk;
-    const uint64_t blk = P.first + f;
-    const uint8_t *src = P.src_base + P.src_off[blk];
-    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;
+    __shared__ __attribute__((aligned(16))) SeqLds L;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t f0 = blockIdx.x * kSeqPerWave;
+    const uint32_t f = f0 + lane;
+    bool mine = lane < kSeqPerWave && f < P.F;
+    uint32_t nblk = 0;
+    if (mine) {
+        const uint32_t flags = P.frames[f].flags;
+        if (flags & (F_BAD | F_IRREG)) mine = false;
+        else nblk = P.frames[f].nblk;
+    }
+    const uint32_t max_nblk = wave_max(nblk);
+    if (max_nblk == 0u) return;
+    if (lane < kSeqPerWave * 4u) (&L.cur[0][0])[lane] = 0xFFFFFFFFu;
+    if (lane < 36u) L.llx[lane] = kLLBase[lane] | ((uint32_t)kLLBits[lane] << 24);
+    if (lane < 53u) L.mlx[lane] = kMLBase[lane] | ((uint32_t)kMLBits[lane] << 24);
+    __builtin_amdgcn_wave_barrier();
+    const uint8_t *src = mine ? P.src_base + P.src_off[P.first + f] : P.src_base;
+    SeqState z;
+    z.rep0 = 1; z.rep1 = 4; z.rep2 = 8;
+    z.sl = z.so = z.sm = 0;
     bool bad = false;
-    for (uint32_t k = 0; k < nblk && !bad; k++) {
-        const ZBlk *d = P.blks + (uint64_t)f * P.nbmax + k;
-        if (d->type != 2u) continue;
-        const uint32_t nseq = d->nseq;
-        if (nseq == 0u) continue;
-        const uint32_t slots = d->slots, logs = d->logs;
-        const uint32_t ll_log = logs & 255u, of_log = (logs >> 8) & 255u, ml_log = (logs >> 16) & 255u;
-        auto tab = [&](uint32_t slot, uint32_t goff) -> const uint32_t * {
-            return (slot == kPredefSlot ? P.predef : P.seqt + ((uint64_t)f * P.nbmax + slot) * kSeqTblWords) + goff;
-        };
-        const uint32_t *tl = tab(slots & 255u, 0u), *to = tab((slots >> 8) & 255u, 1024u), *tm = tab((slots >> 16) & 255u, 512u);
-        uint4 *out = P.seqs + d->seq_base;
-        BitRd b;
-        if (!b.init(src + d->sq_off, d->sq_len)) { bad = true; break; }
-        uint32_t sl = b.read(ll_log);
-        uint32_t so = b.read(of_log);
-        uint32_t sm = b.read(ml_log);
-        for (uint32_t i = 0; i < nseq; i++) {
-            const uint32_t el = tl[sl], eo = to[so], em = tm[sm];
-            const uint32_t lsym = el >> 14, osym = eo >> 14, msym = em >> 14;
-            const uint32_t llbase = kLLBase[lsym], llbits = kLLBits[lsym];
-            const uint32_t mlbase = kMLBase[msym], mlbits = kMLBits[msym];
-            const bool ll0 = (llbase == 0u);
-            uint32_t offset;
-            if (osym > 1u) {
-                offset = ((1u << osym) - 3u) + b.read(osym);
-                rep2 = rep1; rep1 = rep0; rep0 = offset;
-            } else if (osym == 0u) {
-                if (!ll0) offset = rep0;
-                else { offset = rep1; rep1 = rep0; rep0 = offset; }
-            } else {
-                const uint32_t idx = 1u + (ll0 ? 1u : 0u) + b.read(1u);
-                uint32_t tmp = (idx == 3u) ? rep0 - 1u : (idx == 1u ? rep1 : rep2);
-                if (tmp == 0u) tmp = 1u;
-                if (idx != 1u) rep2 = rep1;
-                rep1 = rep0;
-                rep0 = offset = tmp;
+
+    for (uint32_t k = 0; k < max_nblk; k++) {
+        /* ---- stage the tables block k of each frame uses (skipped when the slot is already resident) ---- */
+        for (uint32_t j = 0; j < kSeqPerWave && f0 + j < P.F; j++) {
+            const uint32_t fj = f0 + j;
+            const uint32_t fl = uni(P.frames[fj].flags);
+            if ((fl & (F_BAD | F_IRREG)) || k >= uni(P.frames[fj].nblk)) continue;
+            const ZBlk *d = P.blks + (uint64_t)fj * P.nbmax + k;
+            if (uni(d->type) != 2u || uni(d->nseq) == 0u) continue;
+            const uint32_t slots = uni(d->slots), logs = uni(d->logs);
+#pragma unroll
+            for (int kind = 0; kind < 3; kind++) {
+                const uint32_t slot = (slots >> (8 * kind)) & 255u, lg = (logs >> (8 * kind)) & 255u;
+                if (uni(L.cur[j][kind]) == slot) continue;
+                const uint32_t goff = kind == 0 ? 0u : (kind == 1 ? 1024u : 512u);
+                const uint32_t *g = (slot == kPredefSlot ? P.predef : P.seqt + ((uint64_t)fj * P.nbmax + slot) * kSeqTblWords) + goff;
+                copy_words(&L.tab[j][goff], g, 1u << lg, lane);
+                __builtin_amdgcn_wave_barrier();
+                if (lane == 0) L.cur[j][kind] = slot;
             }
-            const uint32_t mlen = mlbase + (mlbits ? b.read(mlbits) : 0u);
-            const uint32_t llen = llbase + (llbits ? b.read(llbits) : 0u);
-            if (i + 1u < nseq) {
-                sl = (el & 1023u) + b.read((el >> 10) & 15u);
-                sm = (em & 1023u) + b.read((em >> 10) & 15u);
-                so = (eo & 1023u) + b.read((eo >> 10) & 15u);
-            }
-            out[i] = make_uint4(llen, mlen, offset, 0u);
         }
-        if (b.over || b.pos != 0) bad = true; /* the bitstream must be consumed exactly */
+        __builtin_amdgcn_wave_barrier();
+
+        /* ---- lanes 0..14: block k of their frame ---- */
+        const ZBlk *d = P.blks + (uint64_t)(mine ? f : 0u) * P.nbmax + k;
+        bool act = mine && !bad && k < nblk;
+        uint32_t nseq = 0, logs = 0;
+        if (act) { act = d->type == 2u; }
+        if (act) { nseq = d->nseq; logs = d->logs; act = nseq != 0u; }
+        LaneBits<16> lb;
+        const bool opened = lb.init(&L.ring[0][lane & 15u], src, act ? d->sq_off : 0u, act ? d->sq_len : 0u, act);
+        if (act && !opened) { bad = true; }
+        if (!opened) nseq = 0;
+        const uint32_t *tab = L.tab[lane < kSeqPerWave ? lane : 0u];
+        uint4 *out = P.seqs + (opened ? d->seq_base : 0u);
+        SeqPre pre = {0, 0, 0};
+        if (opened) {
+            lb.fill();
+            z.sl = lb.read(logs & 255u);
+            z.so = lb.read((logs >> 8) & 255u);
+            z.sm = lb.read((logs >> 16) & 255u);
+            pre.el = tab[z.sl]; pre.eo = tab[1024u + z.so]; pre.em = tab[512u + z.sm];
+            lb.fill();
+        }
+        const uint32_t maxn = wave_max(nseq);
+        for (uint32_t i = 0; i < maxn; i += 4u) {
+            seq_step<0>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq);
+            seq_step<1>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq);
+            seq_step<2>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq);
+            seq_step<3>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq);
+        }
+        if (opened && lb.pos != 0) bad = true; /* the bitstream must be consumed exactly */
+        __builtin_amdgcn_wave_barrier();
     }
     if (bad) atomicOr(&P.frames[f].flags, F_BAD);
 }
@@ -653,11 +839,14 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     y.litcap = ((B + 15u) & ~15u) + 16u * y.nbmax;
     const size_t per_frame = sizeof(ZFrame) + (size_t)y.nbmax * (sizeof(ZBlk) + kHufTblWords * 2u + kSeqTblWords * 4u + 4u) +
                              y.litcap + (size_t)B /* sequence pool share: B/16 records */ + 4u;
-    const size_t budget = (size_t)4 << 30;
+    /* Tile size.  K2 and K3 are bound by LDS capacity (two workgroups per CU, 512 per chip): 7680 frames
+     * = 512 x 15 (K3) = 480 x 16 (K2) fill exactly one round of each; the workspace budget may force less. */
+    const size_t budget = (size_t)5 << 29; /* 2.5 GiB per tile in flight */
     uint64_t F = budget / per_frame;
-    if (F < 64u) F = 64u;
+    if (F > 7680u) F = 7680u;
+    if (F >= 240u) F -= F % 240u;
+    else if (F < 16u) F = 16u;
     if (F > n_blocks) F = n_blocks;
-    if (F > (1u << 20)) F = 1u << 20;
     y.F = (uint32_t)F;
     uint64_t seqcap = (uint64_t)y.F * (B / 16u) + 4096u;
     if (seqcap > 0xFFFF0000ull) seqcap = 0xFFFF0000ull;
@@ -670,12 +859,18 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     y.o_predef = o; o = al256(o + kSeqTblWords * 4u);
     y.o_lits = o; o = al256(o + (size_t)y.F * y.litcap + 64u);
     y.o_seqs = o; o = al256(o + (size_t)y.seqcap * sizeof(uint4));
-    y.o_cnt = o; o = al256(o + 64u);
+    y.o_cnt = o; o = al256(o + 256u);
     y.o_hitems = o; o = al256(o + (size_t)y.F * y.nbmax * 4u);
     y.o_irreg = o; o = al256(o + (size_t)y.F * 4u);
     y.o_fused = o; o = al256(o + zstd_fused_workspace(kFusedGridForIrregular));
     y.total = o;
     return y;
+}
+
+bool two_lanes()
+{
+    static const bool on = getenv("CRYO_ZSTD_LANES") && getenv("CRYO_ZSTD_LANES")[0] == '2';
+    return on;
 }
 
 bool use_pipeline(uint64_t n_blocks)
@@ -691,51 +886,89 @@ bool use_pipeline(uint64_t n_blocks)
 size_t zstd_decompress_workspace(uint64_t n_blocks, uint32_t block_size)
 {
     if (!use_pipeline(n_blocks)) return zstd_fused_workspace(n_blocks);
-    return make_layout(n_blocks, block_size).total + 256;
+    return (two_lanes() ? 2u : 1u) * make_layout(n_blocks, block_size).total + 256;
 }
 
 hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                   const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                   uint32_t block_size, uint64_t n_blocks, int32_t *d_status,
-                                  void *d_workspace, size_t workspace_bytes)
+                                  void *d_workspace, size_t workspace_bytes, const ZstdAux *aux)
 {
     if (n_blocks == 0) return hipSuccess;
     if (!use_pipeline(n_blocks))
         return launch_zstd_fused(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status,
                                  d_workspace, workspace_bytes, nullptr, nullptr, 0);
     const Layout y = make_layout(n_blocks, block_size);
-    if (workspace_bytes < y.total) return hipErrorInvalidValue;
-    uint8_t *ws = (uint8_t *)(((uintptr_t)d_workspace + 255u) & ~(uintptr_t)255u);
-    ZPipe P;
-    P.src_base = d_src; P.src_off = d_src_off; P.src_size = d_src_size;
-    P.dst_base = d_dst; P.dst_stride = dst_stride; P.B = block_size;
-    P.nbmax = y.nbmax; P.litcap = y.litcap; P.seqcap = y.seqcap;
-    P.status = d_status;
-    P.frames = (ZFrame *)(ws + y.o_frames);
-    P.blks = (ZBlk *)(ws + y.o_blks);
-    P.huf = (uint16_t *)(ws + y.o_huf);
-    P.seqt = (uint32_t *)(ws + y.o_seqt);
-    P.predef = (uint32_t *)(ws + y.o_predef);
-    P.lits = ws + y.o_lits;
-    P.seqs = (uint4 *)(ws + y.o_seqs);
-    P.counters = (uint32_t *)(ws + y.o_cnt);
-    P.hitems = (uint32_t *)(ws + y.o_hitems);
-    P.irregular = (uint32_t *)(ws + y.o_irreg);
-    for (uint64_t first = 0; first < n_blocks; first += y.F) {
+    if (workspace_bytes < (two_lanes() ? 2u : 1u) * y.total) return hipErrorInvalidValue;
+    uint8_t *ws0 = (uint8_t *)(((uintptr_t)d_workspace + 255u) & ~(uintptr_t)255u);
+    /* Optional (CRYO_ZSTD_LANES=2): tiles alternate between two side streams with a workspace each, so that
+     * K2/K3 of one tile (LDS-capacity bound) could overlap K1/K4 of the other (issue bound).  Measured: no
+     * gain yet -- K2/K3 leave < 8 KB of LDS per CU free, so K1/K4 workgroups cannot co-reside. */
+    const uint64_t ntiles = (n_blocks + y.F - 1u) / y.F;
+    const int nl = (aux && ntiles > 1u && two_lanes()) ? 2 : 1;
+    hipError_t e;
+    if (nl == 2) {
+        if ((e = hipEventRecord(aux->fork, s)) != hipSuccess) return e;
+        for (int l = 0; l < 2; l++)
+            if ((e = hipStreamWaitEvent(aux->lane[l], aux->fork, 0)) != hipSuccess) return e;
+    }
+    static const uint32_t huf_pad = getenv("CRYO_ZHUF_PAD") ? (uint32_t)atoi(getenv("CRYO_ZHUF_PAD")) : 0u; /* tuning aid: extra LDS to cap occupancy */
+    static const uint32_t seq_pad = getenv("CRYO_ZSEQ_PAD") ? (uint32_t)atoi(getenv("CRYO_ZSEQ_PAD")) : 0u;
+    static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
+    uint64_t t = 0;
+    for (uint64_t first = 0; first < n_blocks; first += y.F, t++) {
+        const int l = (int)(t % (uint64_t)nl);
+        hipStream_t st = nl == 2 ? aux->lane[l] : s;
+        uint8_t *ws = ws0 + (size_t)l * y.total;
+        ZPipe P;
+        P.src_base = d_src; P.src_off = d_src_off; P.src_size = d_src_size;
+        P.dst_base = d_dst; P.dst_stride = dst_stride; P.B = block_size;
+        P.nbmax = y.nbmax; P.litcap = y.litcap; P.seqcap = y.seqcap;
+        P.status = d_status;
+        P.frames = (ZFrame *)(ws + y.o_frames);
+        P.blks = (ZBlk *)(ws + y.o_blks);
+        P.huf = (uint16_t *)(ws + y.o_huf);
+        P.seqt = (uint32_t *)(ws + y.o_seqt);
+        P.predef = (uint32_t *)(ws + y.o_predef);
+        P.lits = ws + y.o_lits;
+        P.seqs = (uint4 *)(ws + y.o_seqs);
+        P.counters = (uint32_t *)(ws + y.o_cnt);
+        P.hitems = (uint32_t *)(ws + y.o_hitems);
+        P.irregular = (uint32_t *)(ws + y.o_irreg);
         const uint64_t left = n_blocks - first;
         P.first = first;
         P.F = (uint32_t)(left < y.F ? left : y.F);
-        hipError_t e = hipMemsetAsync(P.counters, 0, 64, s);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k_zplan, dim3(P.F), dim3(64), 0, s, P);
-        hipLaunchKernelGGL(k_zhuf, dim3((P.F * P.nbmax + kHufPerWave - 1u) / kHufPerWave), dim3(64), 0, s, P);
-        hipLaunchKernelGGL(k_zseq, dim3((P.F + 63u) / 64u), dim3(64), 0, s, P);
-        hipLaunchKernelGGL(k_zexec, dim3(P.F), dim3(64), 0, s, P);
+        if ((e = hipMemsetAsync(P.counters, 0, 256, st)) != hipSuccess) return e;
+        hipLaunchKernelGGL(k_zplan, dim3(P.F), dim3(64), 0, st, P);
+        hipLaunchKernelGGL(k_zhuf, dim3((P.F * P.nbmax + kHufPerWave - 1u) / kHufPerWave), dim3(64), huf_pad, st, P);
+        hipLaunchKernelGGL(k_zseq, dim3((P.F + kSeqPerWave - 1u) / kSeqPerWave), dim3(64), seq_pad, st, P);
+        hipLaunchKernelGGL(k_zexec, dim3(P.F), dim3(64), 0, st, P);
         const uint64_t fg = P.F < kFusedGridForIrregular ? P.F : kFusedGridForIrregular;
-        e = launch_zstd_fused(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, fg, d_status,
+        e = launch_zstd_fused(st, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, fg, d_status,
                               ws + y.o_fused, zstd_fused_workspace(kFusedGridForIrregular), P.irregular,
                               P.counters + 2, first);
         if (e != hipSuccess) return e;
+        if (want_stats) {
+            uint32_t h[64];
+            (void)hipMemcpyAsync(h, P.counters, sizeof h, hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            fprintf(stderr, "[zstd pipe] tile %llu: frames %u seqs %u huf items %u irregular %u | huf log histogram:",
+                    (unsigned long long)first, P.F, h[0], h[1], h[2]);
+            for (int k = 1; k <= 12; k++) fprintf(stderr, " %d:%u", k, h[4 + k]);
+            fprintf(stderr, " | LL log:");
+            for (int k = 0; k <= 9; k++) fprintf(stderr, " %d:%u", k, h[20 + k]);
+            fprintf(stderr, " | OF log:");
+            for (int k = 0; k <= 9; k++) fprintf(stderr, " %d:%u", k, h[32 + k]);
+            fprintf(stderr, " | ML log:");
+            for (int k = 0; k <= 9; k++) fprintf(stderr, " %d:%u", k, h[44 + k]);
+            fprintf(stderr, "\n");
+        }
+    }
+    if (nl == 2) {
+        for (int l = 0; l < 2; l++) {
+            if ((e = hipEventRecord(aux->join[l], aux->lane[l])) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(s, aux->join[l], 0)) != hipSuccess) return e;
+        }
     }
     return hipGetLastError();
 }

@@ -165,3 +165,63 @@ def test_zstd_roundtrip_on_device_and_unsupported_levels(codec, oracle):
     with pytest.raises(CryoError) as e:
         codec.compress_blocks(METHOD_ZSTD, 3, blocks[:1])      # dfast and above: no kernel (no CPU fallback)
     assert e.value.code == E_UNSUPPORTED
+
+
+def test_zstd_decode_huffman_log12_crafted(codec, oracle):
+    """2^12-entry Huffman table: fused decoder (small batch) and batch pipeline (two-level lookup)"""
+    import zstd_craft
+    for streams in (1, 4):
+        frame, lits = zstd_craft.huf12_frame(n=700, streams=streams, seed=10 + streams)
+        r, exp = oracle.zstd_decompress(frame, len(lits))
+        assert r == len(lits) and np.array_equal(exp, lits)
+        for n in (1, 40):   # 40 >= the pipeline threshold
+            outs, st = codec.decompress_blocks(METHOD_ZSTD, [frame] * n, len(lits))
+            assert (st == 0).all(), (streams, n, st)
+            for o in outs:
+                assert np.array_equal(o, lits), (streams, n)
+        bad = frame.copy()
+        bad[len(bad) // 2] ^= 0x10
+        rb, _ = oracle.zstd_decompress(bad, len(lits))
+        _, stb = codec.decompress_blocks(METHOD_ZSTD, [bad] * 40, len(lits))
+        assert ((stb == 0).all() and rb == len(lits)) or ((stb != 0).all() and rb != len(lits))
+
+
+def test_zstd_pipeline_many_frames_across_tiles(codec, oracle):
+    """> 7680 frames: the batch pipeline runs two tiles; irregular inputs (concatenated frames, skippable
+    frames, garbage, truncation) are sprinkled in and must get the fused decoder's verdicts"""
+    B, n = 4096, 9000
+    rng = np.random.default_rng(5)
+    raws = [oracle.synth(3, i, B, i % 5) for i in range(40)]
+    stock = oracle_lib.StockLibs()
+    if stock.zstd is None:
+        pytest.skip("needs the stock libzstd to produce 4 KiB frames (the oracle encoder mirrors the device's sizes)")
+    comps = [stock.zstd_compress(r, 1 + (i % 5)) for i, r in enumerate(raws)]
+    half = [stock.zstd_compress(r[:B // 2], 1) for r in raws[:4]]
+    skippable = np.frombuffer((0x184D2A50).to_bytes(4, "little") + (5).to_bytes(4, "little") + b"hello", np.uint8)
+    items, expect = [], []
+    for i in range(n):
+        k = int(rng.integers(0, 40))
+        sel = i % 97
+        if sel == 13:      # two concatenated frames decoding to B bytes
+            a, b = int(rng.integers(0, 4)), int(rng.integers(0, 4))
+            items.append(np.concatenate([half[a], half[b]]))
+            expect.append(np.concatenate([raws[a][:B // 2], raws[b][:B // 2]]))
+        elif sel == 29:    # skippable frame in front
+            items.append(np.concatenate([skippable, comps[k]]))
+            expect.append(raws[k])
+        elif sel == 41:    # truncated
+            items.append(comps[k][:len(comps[k]) - 3].copy())
+            expect.append(None)
+        elif sel == 59:    # garbage
+            items.append(rng.integers(0, 256, 100, dtype=np.uint8))
+            expect.append(None)
+        else:
+            items.append(comps[k])
+            expect.append(raws[k])
+    outs, st = codec.decompress_blocks(METHOD_ZSTD, items, B)
+    for i in range(n):
+        if expect[i] is None:
+            assert st[i] != 0, i
+        else:
+            assert st[i] == 0, i
+            assert np.array_equal(outs[i], expect[i]), i

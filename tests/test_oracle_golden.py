@@ -275,3 +275,16 @@ def test_zstd_encoder_oracle_unsupported_levels_return_empty(oracle):
     raw = oracle.synth(0, 0, 131072, 1)
     assert len(oracle.zstd_compress(raw, 3)) == 0      # dfast and above: not restated
     assert len(oracle.zstd_compress(raw, 22)) == 0
+
+
+def test_zstd_oracle_huffman_log12_crafted(oracle):
+    """a Huffman table of log 12 (legal, never emitted by libzstd's encoder): oracle == expected == stock lib"""
+    import zstd_craft
+    stock = oracle_lib.StockLibs()
+    for streams in (1, 4):
+        frame, lits = zstd_craft.huf12_frame(n=700, streams=streams, seed=streams)
+        r, out = oracle.zstd_decompress(frame, len(lits))
+        assert r == len(lits) and np.array_equal(out, lits)
+        if stock.zstd is not None:
+            r2, out2 = stock.zstd_decompress(frame, len(lits))
+            assert r2 == len(lits) and np.array_equal(out2, lits)
