@@ -33,6 +33,10 @@ hipError_t launch_lz4_compress(hipStream_t s, const uint8_t *d_src, uint64_t src
                                uint64_t dst_stride, int accel, uint32_t *d_out_size,
                                int32_t *d_status);
 
+hipError_t launch_lz4_compress_batch64(hipStream_t s, const uint8_t *d_src, uint64_t src_stride,
+                                       uint32_t block_size, uint64_t n_blocks, uint8_t *d_dst,
+                                       uint64_t dst_stride, int accel, uint32_t *d_out_size, int32_t *d_status);
+
 /* zstd frames.  `aux` (optional): two side streams + events the batch pipeline alternates its tiles on;
  * the work is ordered after everything already queued on `s`, and `s` waits for it before returning. */
 struct ZstdAux {

@@ -15,6 +15,7 @@
  *   - literal copies into the output.
  */
 #include "kernels.h"
+#include <cstdlib>
 
 namespace cryo {
 
@@ -181,6 +182,11 @@ hipError_t launch_lz4_compress(hipStream_t s, const uint8_t *d_src, uint64_t src
                                int32_t *d_status)
 {
     if (n_blocks == 0) return hipSuccess;
+    /* liblz4's byU32 table mode, positions below 2^24: the 64-probes-per-step kernel (lz4_enc2.hip) */
+    static const bool serial_only = getenv("CRYO_LZ4_ENC") && getenv("CRYO_LZ4_ENC")[0] == '1'; /* testing aid */
+    if (!serial_only && block_size >= kLimit64k && block_size <= (16u << 20))
+        return launch_lz4_compress_batch64(s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride, accel,
+                                           d_out_size, d_status);
     const uint64_t grid = (n_blocks + 3) / 4;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_lz4_enc, dim3((uint32_t)grid), dim3(256), 0, s, d_src, src_stride,

@@ -160,3 +160,34 @@ def test_lz4_checksum_of_checksums_property(codec, oracle):
         assert int(s1[17]) == checksum64(oracle.synth(5, 1017, B, dist))
     for x in (d_raw, d_comp, d_out, d_sz, d_st, d_off, d_s1, d_s2):
         x.free()
+
+
+def test_lz4_encode_batch_kernel_corners(codec, oracle):
+    """the 64-probes-per-step encoder (blocks >= 65547 bytes): odd sizes around its lower bound, data whose
+    search steps outgrow the LDS ring (incompressible, large acceleration), far matches (beyond the ring,
+    up to and past the 65535 limit), long runs, and mixtures"""
+    rng = np.random.default_rng(11)
+    blocks = []
+    for n in (65547, 65548, 70001, 131072 + 13, 262144 + 1):
+        blocks.append(rng.integers(0, 256, n, dtype=np.uint8))                       # incompressible
+        a = rng.integers(0, 256, n, dtype=np.uint8)
+        chunk = a[:3000].copy()
+        for off in (4000, 4000 + 2047, 40000, 40000 + 65535, 40000 + 65536, n - 3100):  # repeats at many distances
+            if off + 3000 <= n:
+                a[off:off + 3000] = chunk
+        blocks.append(a)
+        z = np.zeros(n, np.uint8)
+        z[n // 3:n // 3 + 100] = rng.integers(0, 256, 100, dtype=np.uint8)
+        blocks.append(z)                                                               # very long matches
+        t = np.frombuffer((b"abcdefghij" * (n // 10 + 1))[:n], np.uint8).copy()
+        t[::997] = rng.integers(0, 256, len(t[::997]), dtype=np.uint8)
+        blocks.append(t)                                                               # periodic with noise
+    by_len = {}
+    for b in blocks:
+        by_len.setdefault(len(b), []).append(b)
+    for n, lst in by_len.items():
+        for accel in (1, 3, 50, 5000, 65537):
+            got = codec.compress_blocks(METHOD_LZ4, accel, lst)
+            for i, b in enumerate(lst):
+                exp = oracle.lz4_compress(b, accel)
+                assert np.array_equal(got[i], exp), (n, accel, i, len(got[i]), len(exp))
