@@ -24,6 +24,8 @@
  * Sequences, literals and codes of the block live in a per-workgroup global workspace.
  */
 #include "lz_common.h"
+#include <cstdio>
+#include <cstdlib>
 
 namespace cryo {
 
@@ -871,9 +873,11 @@ __device__ uint32_t block_fast(uint32_t *table, const CPar &cp, const uint8_t *b
 __global__ void __launch_bounds__(64)
 k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t n_blocks,
            uint8_t *__restrict__ dst_base, uint64_t dst_stride, int wlog, int hlog, int mml, int tlen,
-           uint32_t *__restrict__ out_size, int32_t *__restrict__ status, uint8_t *workspace)
+           uint32_t *__restrict__ out_size, int32_t *__restrict__ status, uint8_t *workspace,
+           unsigned long long *stats)
 {
     __shared__ EncLds L;
+    unsigned long long t_mf = 0, t_en = 0, t_other = 0, t_prev = stats ? __builtin_amdgcn_s_memtime() : 0; /* CRYO_ZSTD_STATS */
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *ws = workspace + (uint64_t)blockIdx.x * kWsBytes;
     CPar cp;
@@ -921,12 +925,15 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 SeqStore ss;
                 ss.nseq = 0; ss.nlit = 0; ss.long_pos = 0; ss.long_kind = 0;
                 uint32_t nrep[3] = {rep[0], rep[1], rep[2]};
+                if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_other += t - t_prev; t_prev = t; }
                 const uint32_t last_ll = block_fast(table, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane);
+                if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mf += t - t_prev; t_prev = t; }
                 for (uint32_t i = lane; i < last_ll; i += 64u) (ws + kWsLit)[ss.nlit + i] = src[ip + bs - last_ll + i];
                 ss.nlit += last_ll;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 csize = compress_sequences(L, dst + op + 3, ws, ss.nseq, ss.nlit, bs, ss.long_pos, ss.long_kind, hs,
                                            tlen > 0, lane);
+                if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_en += t - t_prev; t_prev = t; }
                 if (!first && csize < 25u) { /* RLE block for constant non-first blocks */
                     const uint32_t b0 = uni(src[ip]);
                     bool diff = false;
@@ -957,6 +964,10 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         }
         if (lane == 0) { out_size[blk] = op; status[blk] = CRYO_ST_OK; }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (stats && lane == 0) {
+        t_other += __builtin_amdgcn_s_memtime() - t_prev;
+        atomicAdd(&stats[0], t_mf); atomicAdd(&stats[1], t_en); atomicAdd(&stats[2], t_other);
     }
 }
 
@@ -1006,8 +1017,22 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
     if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen)) return hipErrorNotSupported;
     const uint32_t grid = zstd_enc_grid(n_blocks);
     if (workspace_bytes < (size_t)grid * kWsBytes) return hipErrorInvalidValue;
+    static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
+    unsigned long long *d_st = nullptr, h_st[3] = {0, 0, 0};
+    if (want_stats) {
+        if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
+    }
     hipLaunchKernelGGL(k_zstd_enc, dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst,
-                       dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status, (uint8_t *)d_workspace);
+                       dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status, (uint8_t *)d_workspace, d_st);
+    if (want_stats) {
+        (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(d_st);
+        const double tot = (double)(h_st[0] + h_st[1] + h_st[2]);
+        fprintf(stderr, "[zstd enc cycles] match finder %.1f%%  entropy stage %.1f%%  other %.1f%%\n",
+                100.0 * h_st[0] / tot, 100.0 * h_st[1] / tot, 100.0 * h_st[2] / tot);
+    }
     return hipGetLastError();
 }
 
