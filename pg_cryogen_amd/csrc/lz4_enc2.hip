@@ -26,7 +26,7 @@
  * per CU, i.e. LDS per wave: the position table is 4096 x (u16 low | u8 high) = 12 KiB and the ring only
  * 2 KiB (measured on 64k x 128 KiB "wide" blocks: 64 KiB ring 8.6 GB/s, 16 KiB 19, 8 KiB 25.6, 2 KiB 29).
  */
-#include "lz_common.h"
+#include "enc_ring.h"
 #include "kernels.h"
 #include <cstdlib>
 
@@ -34,7 +34,6 @@ namespace cryo {
 
 namespace {
 
-constexpr uint32_t kStage = 1024;
 constexpr uint32_t kMfLimit = 12, kLastLiterals = 5, kMinLength = 13, kMaxDist = 65535, kSkipTrigger = 6;
 
 template <uint32_t kW>
@@ -45,68 +44,17 @@ struct EncLds {
 };
 
 template <uint32_t kW>
-struct Enc {
-    static constexpr uint32_t kWM = kW - 1u;
+struct Enc : RingIn<kW> {
     EncLds<kW> *L;
-    const uint8_t *src;
     uint8_t *dst;
-    uint32_t n, hi, lane, op;
-    uint4 pre;
-
-    __device__ inline void prefetch()
-    {
-        const uint32_t o = hi + lane * 16u;
-        pre = make_uint4(0, 0, 0, 0);
-        if (o + 16u <= n) __builtin_memcpy(&pre, src + o, 16);
-        else if (o < n) { /* the block's last, partial 16 bytes: never read past its end */
-            uint32_t w0 = 0, w1 = 0, w2 = 0, w3 = 0;
-#pragma unroll
-            for (uint32_t k = 0; k < 16u; k++) {
-                const uint32_t b = o + k < n ? (uint32_t)src[o + k] << (8u * (k & 3u)) : 0u;
-                if (k < 4u) w0 |= b; else if (k < 8u) w1 |= b; else if (k < 12u) w2 |= b; else w3 |= b;
-            }
-            pre = make_uint4(w0, w1, w2, w3);
-        }
-    }
-    /* stage until position `upto` (exclusive) is in the ring */
-    __device__ inline void ensure(uint32_t upto)
-    {
-        while (hi < n && hi < upto) {
-            *reinterpret_cast<uint4 *>(L->win + ((hi + lane * 16u) & kWM)) = pre;
-            hi += kStage;
-            prefetch();
-        }
-    }
-    __device__ inline uint32_t lo_pos() const { return hi > kW ? hi - kW : 0u; }
-
-    /* the two dwords that hold bytes p .. p+4 */
-    __device__ inline void rd2(uint32_t p, uint32_t &d0, uint32_t &d1) const
-    {
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(L->win);
-        d0 = w[(p >> 2) & (kW / 4 - 1)];
-        d1 = w[((p >> 2) + 1u) & (kW / 4 - 1)];
-    }
-    __device__ inline uint32_t rd32(uint32_t p) const
-    {
-        uint32_t d0, d1;
-        rd2(p, d0, d1);
-        return __builtin_amdgcn_alignbyte(d1, d0, p & 3u);
-    }
-    /* 4 bytes at any position of the block: ring if still there, global memory otherwise */
-    __device__ inline uint32_t rd32_any(uint32_t p) const
-    {
-        if (p >= lo_pos()) return rd32(p);
-        uint32_t v;
-        __builtin_memcpy(&v, src + p, 4);
-        return v;
-    }
-    __device__ inline uint32_t byte_any(uint32_t p) const { return p >= lo_pos() ? (uint32_t)L->win[p & kWM] : (uint32_t)src[p]; }
+    uint32_t op;
+    using RingIn<kW>::lane;
+    using RingIn<kW>::dw;
 
     /* LZ4_hash5 of the bytes at p (table log 12): ((v << 24) * 889523592379) >> 52, in 32-bit pieces */
     __device__ inline uint32_t hash(uint32_t p, uint32_t &first4) const
     {
-        uint32_t d0, d1;
-        rd2(p, d0, d1);
+        const uint32_t d0 = dw(p, 0), d1 = dw(p, 1);
         const uint32_t s = p & 3u;
         const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, s);
         const uint32_t b4 = __builtin_amdgcn_ubfe(d1, 8u * s, 8u);
@@ -119,7 +67,7 @@ struct Enc {
     __device__ inline uint32_t tab_get(uint32_t h) const { return (uint32_t)L->tlo[h] | ((uint32_t)L->thi[h] << 16); }
     __device__ inline void tab_put(uint32_t h, uint32_t v) { L->tlo[h] = (uint16_t)v; L->thi[h] = (uint8_t)(v >> 16); }
 
-    /* 255-run length code; returns the new output position */
+    /* 255-run length code */
     __device__ inline void put_len(uint32_t len)
     {
         const uint32_t n255 = len / 255u;
@@ -129,7 +77,7 @@ struct Enc {
     }
     __device__ inline void put_literals(uint32_t from, uint32_t lit)
     {
-        for (uint32_t i = lane; i < lit; i += 64u) dst[op + i] = (uint8_t)byte_any(from + i);
+        for (uint32_t i = lane; i < lit; i += 64u) dst[op + i] = (uint8_t)this->byte_any(from + i);
         op += lit;
     }
 };
@@ -149,15 +97,14 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
 
     Enc<kW> e;
     e.L = &L;
-    e.src = src_base + uni64(blk * src_stride);
     e.dst = dst_base + uni64(blk * dst_stride);
-    e.n = n; e.hi = 0; e.lane = lane; e.op = 0;
+    e.op = 0;
     const uint32_t accel = accel_in < 1 ? 1u : (accel_in > 65537 ? 65537u : (uint32_t)accel_in);
 
     for (uint32_t i = lane; i < 512u; i += 64u) reinterpret_cast<uint4 *>(L.tlo)[i] = make_uint4(0, 0, 0, 0);
     for (uint32_t i = lane; i < 256u; i += 64u) reinterpret_cast<uint4 *>(L.thi)[i] = make_uint4(0, 0, 0, 0);
-    e.prefetch();
-    e.ensure(2u * kStage);
+    e.open(L.win, src_base + uni64(blk * src_stride), n, lane);
+    e.ensure(2u * kEncStage);
     __builtin_amdgcn_wave_barrier();
 
     const unsigned long long lt_mask = lane ? (~0ull >> (64u - lane)) : 0ull; /* lanes below this one */
@@ -187,7 +134,7 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                  * grow), and only as far as the ring can hold next to the first position */
                 const bool ends = !(lane < sh || nxt <= mflimit_p1);
                 const uint32_t base = pre ? ip - 2u : fwd;
-                const bool fits = cur + 9u <= base + (kW - kStage);
+                const bool fits = cur + 9u <= base + (kW - kEncStage);
                 const unsigned long long stopm = __ballot(ends || !fits);
                 const uint32_t T = stopm ? ctz64(stopm) : 64u; /* lanes 0 .. T-1 take part */
                 const bool at_end = T < 64u && ((__ballot(ends) >> T) & 1ull); /* stopped by the block's end, not the ring */

@@ -23,7 +23,7 @@
  * Hash table: LDS when hashLog <= 13 (level 1 at 128 KiB), else a per-workgroup global table.
  * Sequences, literals and codes of the block live in a per-workgroup global workspace.
  */
-#include "lz_common.h"
+#include "enc_ring.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -53,7 +53,6 @@ struct FseCt {
 };
 
 struct EncLds {
-    uint32_t hash[8192];       /* match-finder table when hashLog <= 13 */
     uint32_t hist[256];
     /* Huffman tree nodes; huffNode[i] of the library lives at index i+1, its "fake entry" at 0 */
     uint32_t ncount[516];
@@ -868,8 +867,254 @@ __device__ uint32_t block_fast(uint32_t *table, const CPar &cp, const uint8_t *b
     return (uint32_t)(iend - anchor);
 }
 
+
+/* ------------------------------------------------------------------------------------------------
+ * ZSTD_compressBlock_fast, 64 iterations per step (same idea as lz4_enc2.hip): the iterations of the
+ * search loop whose step is the same -- (ip0 - anchor) >> 7 unchanged -- are taken by the lanes at once.
+ * Each iteration reads its two table slots and then writes them; a lane reads what the latest earlier
+ * lane wrote to the same slot, found by marking the slots' high bytes with the lane number.  The first
+ * iteration that finds anything (repeat offset at ip0+2, then ip0, then ip0+1, the library's order) ends
+ * the batch, and only the iterations up to it are committed.  Input comes from the LDS ring (enc_ring.h),
+ * positions are byte offsets in the frame's input, table entries are index = position + 1 as in the
+ * library (base = src - 1), kept as u16 low | u8 high.
+ */
+constexpr uint32_t kZW = 2048; /* input ring */
+
+struct PosTab {
+    uint16_t *lo;
+    uint8_t *hi;
+    __device__ inline uint32_t get(uint32_t h) const { return (uint32_t)lo[h] | ((uint32_t)hi[h] << 16); }
+    __device__ inline void put(uint32_t h, uint32_t v) const { lo[h] = (uint16_t)v; hi[h] = (uint8_t)(v >> 16); }
+};
+
+/* ZSTD_hashPtr on the 8 bytes (lo, hi) read at a position */
+__device__ inline uint32_t hash_v(uint32_t lo, uint32_t hi, int hlog, int mls)
+{
+    if (mls == 4) return (lo * 2654435761u) >> (32 - hlog);
+    uint32_t x_lo, x_hi, c_lo, c_hi;
+    if (mls == 5) { x_lo = lo << 24; x_hi = (lo >> 8) | (hi << 24); c_lo = 0x1BBCDCBBu; c_hi = 0xCFu; }
+    else if (mls == 6) { x_lo = lo << 16; x_hi = (lo >> 16) | (hi << 16); c_lo = 0xBCDCBF9Bu; c_hi = 0xCF1Bu; }
+    else { x_lo = lo << 8; x_hi = (lo >> 24) | (hi << 8); c_lo = 0xDCBFA563u; c_hi = 0xCF1BBCu; }
+    const uint32_t top = __umulhi(x_lo, c_lo) + x_lo * c_hi + x_hi * c_lo;
+    return top >> (32 - hlog);
+}
+
+template <uint32_t kW>
+__device__ inline void rd64_any(const RingIn<kW> &r, uint32_t p, uint32_t &lo, uint32_t &hi)
+{
+    if (p >= r.lo_pos()) {
+        const uint32_t d0 = r.dw(p, 0), d1 = r.dw(p, 1), d2 = r.dw(p, 2), s = p & 3u;
+        lo = __builtin_amdgcn_alignbyte(d1, d0, s);
+        hi = __builtin_amdgcn_alignbyte(d2, d1, s);
+    } else {
+        uint64_t v;
+        __builtin_memcpy(&v, r.src + p, 8);
+        lo = (uint32_t)v; hi = (uint32_t)(v >> 32);
+    }
+}
+
+/* bytes equal from positions a / b forward, a limited by end (64 bytes per step) */
+template <uint32_t kW>
+__device__ inline uint32_t count_match_r(RingIn<kW> &r, uint32_t a, uint32_t b, uint32_t end, uint32_t lane)
+{
+    uint32_t done = 0;
+    for (;;) {
+        r.ensure(a + done + 64u);
+        const bool inb = a + done + lane < end;
+        const bool eq = inb && r.byte_any(a + done + lane) == r.byte_any(b + done + lane);
+        const unsigned long long neq = __ballot(!eq);
+        if (neq != 0ull) return done + ctz64(neq);
+        done += 64u;
+    }
+}
+
+template <uint32_t kW>
+__device__ inline void store_seq_r(const RingIn<kW> &r, uint8_t *ws, SeqStore &ss, uint32_t ll, uint32_t lit_pos, uint32_t offcode,
+                                   uint32_t mlbase, uint32_t lane)
+{
+    uint8_t *lits = ws + kWsLit;
+    for (uint32_t i = lane; i < ll; i += 64u) lits[ss.nlit + i] = (uint8_t)r.byte_any(lit_pos + i);
+    ss.nlit += ll;
+    if (ll > 0xFFFFu) { ss.long_kind = 1; ss.long_pos = ss.nseq; }
+    if (mlbase > 0xFFFFu) { ss.long_kind = 2; ss.long_pos = ss.nseq; }
+    if (lane == 0) reinterpret_cast<uint2 *>(ws + kWsSeq)[ss.nseq] = make_uint2(offcode + 1u, (ll & 0xFFFFu) | (mlbase << 16));
+    ss.nseq++;
+}
+
+/* istart, n: the zstd block inside the frame's input (positions); returns the length of the last literals */
+template <uint32_t kW>
+__device__ uint32_t block_fast_batch(RingIn<kW> &r, const PosTab &tab, const CPar &cp, uint32_t istart, uint32_t n,
+                                     uint32_t *rep, uint8_t *ws, SeqStore &ss, uint32_t dict_limit, uint32_t lane)
+{
+    const int hlog = cp.hlog, mls = cp.mml < 4 ? 4 : (cp.mml > 7 ? 7 : cp.mml);
+    const uint32_t step_size = (uint32_t)cp.tlen + (cp.tlen ? 0u : 1u) + 1u;
+    const uint32_t end_index = istart + 1u + n;
+    const uint32_t max_dist = 1u << cp.wlog;
+    const uint32_t prefix_idx = (end_index - dict_limit > max_dist) ? end_index - max_dist : dict_limit;
+    const uint32_t prefix_pos = prefix_idx - 1u;
+    const uint32_t iend = istart + n, ilimit = iend - 8u;
+    const unsigned long long lt_mask = lane ? (~0ull >> (64u - lane)) : 0ull;
+    uint32_t ip0 = istart, anchor = istart;
+    uint32_t off1 = rep[0], off2 = rep[1], saved = 0;
+    if (ip0 == prefix_pos) ip0++;
+    {
+        const uint32_t cur = ip0 + 1u;
+        const uint32_t wlow = (cur - dict_limit > max_dist) ? cur - max_dist : dict_limit;
+        const uint32_t max_rep = cur - wlow;
+        if (off2 > max_rep) { saved = off2; off2 = 0; }
+        if (off1 > max_rep) { saved = off1; off1 = 0; }
+    }
+    while (ip0 + 1u < ilimit) {
+        /* ---------------- one batch: iterations k = 0 .. T-1 at ip0 + k * st ---------------- */
+        const uint32_t c = (ip0 - anchor) >> 7;
+        const uint32_t st = c + step_size;
+        const uint32_t p0 = ip0 + lane * st;
+        const bool stop = (((p0 - anchor) >> 7) != c) || !(p0 + 1u < ilimit) || !(p0 + 16u <= ip0 + (kW - kEncStage));
+        const unsigned long long stopm = __ballot(stop);
+        const uint32_t T = stopm ? ctz64(stopm) : 64u; /* >= 1: lane 0 never stops */
+        const bool valid = lane < T;
+        r.ensure(ip0 + (T - 1u) * st + 12u);
+        uint32_t lo = 0, hi = 0, h0 = 0, h1 = 0, mi0 = 0, mi1 = 0;
+        if (valid) {
+            const uint32_t d0 = r.dw(p0, 0), d1 = r.dw(p0, 1), d2 = r.dw(p0, 2), s = p0 & 3u;
+            lo = __builtin_amdgcn_alignbyte(d1, d0, s);
+            hi = __builtin_amdgcn_alignbyte(d2, d1, s);
+            h0 = hash_v(lo, hi, hlog, mls);
+            h1 = hash_v((lo >> 8) | (hi << 24), hi >> 8, hlog, mls);
+            mi0 = tab.get(h0);
+            mi1 = tab.get(h1); /* both read before either store, as the library does */
+            tab.hi[h0] = (uint8_t)lane; /* owner marks; the real high bytes are in mi0 / mi1 and come back below */
+            tab.hi[h1] = (uint8_t)lane;
+        }
+        const uint32_t v0 = lo, v1 = (lo >> 8) | (hi << 24), v2 = (lo >> 16) | (hi << 16);
+        unsigned long long grouped = 0ull;
+        {
+            asm volatile("" ::: "memory"); /* the read-back must see what the WAVE wrote */
+            bool lost0 = valid && tab.hi[h0] != (uint8_t)lane;
+            bool lost1 = valid && tab.hi[h1] != (uint8_t)lane;
+            asm volatile("" ::: "memory");
+            if (valid) { tab.hi[h0] = (uint8_t)(mi0 >> 16); tab.hi[h1] = (uint8_t)(mi1 >> 16); }
+            unsigned long long losers = __ballot(lost0 || lost1);
+            while (losers) {
+                const uint32_t j = ctz64(losers);
+                const uint32_t hv = lane_get(lost0 ? h0 : h1, j);
+                const unsigned long long G0 = __ballot(valid && h0 == hv), G1 = __ballot(valid && h1 == hv);
+                const unsigned long long GE = G0 | G1;
+                const unsigned long long below = GE & lt_mask;
+                const uint32_t pj = below ? 63u - (uint32_t)__builtin_clzll(below) : lane;
+                /* the latest earlier iteration that wrote this slot: its ip1 store comes after its ip0 store */
+                const uint32_t val = ip0 + pj * st + 1u + (uint32_t)((G1 >> pj) & 1ull);
+                if (valid && below) {
+                    if (h0 == hv) mi0 = val;
+                    if (h1 == hv) mi1 = val;
+                }
+                if (h0 == hv) lost0 = false;
+                if (h1 == hv) lost1 = false;
+                grouped |= GE;
+                losers = __ballot(lost0 || lost1);
+            }
+        }
+        /* ---- what each iteration finds: repeat offset at ip0+2, match at ip0, match at ip0+1 ---- */
+        const uint32_t aR = p0 + 2u - off1, aA = mi0 - 1u, aB = mi1 - 1u;
+        const bool cR = valid && off1 > 0u, cA = valid && mi0 > prefix_idx, cB = valid && mi1 > prefix_idx;
+        const uint32_t lop = r.lo_pos();
+        const bool nR = aR >= lop, nA = aA >= lop, nB = aB >= lop;
+        bool hR = cR && nR && r.rd32(aR) == v2;
+        bool hA = cA && nA && r.rd32(aA) == v0;
+        bool hB = cB && nB && r.rd32(aB) == v1;
+        {
+            const unsigned long long hm_near = __ballot(hR || hA || hB);
+            const uint32_t first = hm_near ? ctz64(hm_near) : 64u;
+            const bool anyfar = (cR && !nR) || (cA && !nA) || (cB && !nB);
+            const unsigned long long far = __ballot(anyfar) & (first >= 63u ? ~0ull : ((2ull << first) - 1ull));
+            if (far) { /* older than the ring: global memory, only for iterations that can still come first */
+                if ((far >> lane) & 1ull) {
+                    uint32_t v;
+                    if (cR && !nR) { __builtin_memcpy(&v, r.src + aR, 4); hR = v == v2; }
+                    if (cA && !nA) { __builtin_memcpy(&v, r.src + aA, 4); hA = v == v0; }
+                    if (cB && !nB) { __builtin_memcpy(&v, r.src + aB, 4); hB = v == v1; }
+                }
+            }
+        }
+        const unsigned long long hm = __ballot(hR || hA || hB);
+        const uint32_t K = hm ? ctz64(hm) + 1u : T;
+        /* commit iterations 0 .. K-1 (ip0 store, then ip1 store); colliding ones one by one, ascending */
+        if (lane < K && !((grouped >> lane) & 1ull)) { tab.put(h0, p0 + 1u); tab.put(h1, p0 + 2u); }
+        {
+            unsigned long long g = grouped & (K >= 64u ? ~0ull : ((1ull << K) - 1ull));
+            while (g) {
+                const uint32_t j = ctz64(g);
+                if (lane == j) { tab.put(h0, p0 + 1u); tab.put(h1, p0 + 2u); }
+                g &= g - 1ull;
+            }
+        }
+        if (!hm) { ip0 += T * st; continue; }
+
+        /* ---------------- the match of iteration m = K-1 ---------------- */
+        const uint32_t m = K - 1u;
+        const uint32_t P0 = ip0 + m * st;
+        const bool kR = lane_get((uint32_t)hR, m) != 0u, kA = lane_get((uint32_t)hA, m) != 0u;
+        uint32_t mpos, mlen, offcode;
+        if (kR) {
+            const uint32_t ip2 = P0 + 2u, rp = ip2 - off1;
+            mlen = (uni(r.byte_any(ip2 - 1u)) == uni(r.byte_any(rp - 1u))) ? 1u : 0u;
+            ip0 = ip2 - mlen;
+            mpos = rp - mlen;
+            mlen += 4u;
+            offcode = 0;
+        } else {
+            if (kA) { ip0 = P0; mpos = lane_get(mi0, m) - 1u; }
+            else { ip0 = P0 + 1u; mpos = lane_get(mi1, m) - 1u; }
+            off2 = off1;
+            off1 = ip0 - mpos;
+            offcode = off1 + 2u;
+            mlen = 4u;
+            uint32_t room = ip0 - anchor < mpos - prefix_pos ? ip0 - anchor : mpos - prefix_pos;
+            while (room) { /* backwards, 64 bytes per step */
+                const bool in = lane < room;
+                const bool eq = in && r.byte_any(ip0 - 1u - lane) == r.byte_any(mpos - 1u - lane);
+                const unsigned long long neq = __ballot(!eq);
+                const uint32_t cb = neq ? ctz64(neq) : 64u;
+                ip0 -= cb; mpos -= cb; mlen += cb;
+                if (cb < 64u) break;
+                room -= 64u;
+            }
+        }
+        mlen += count_match_r(r, ip0 + mlen, mpos + mlen, iend, lane);
+        store_seq_r(r, ws, ss, ip0 - anchor, anchor, offcode, mlen - 3u, lane);
+        ip0 += mlen;
+        anchor = ip0;
+        if (ip0 <= ilimit) {
+            r.ensure(ip0 + 12u);
+            uint32_t a_lo, a_hi, b_lo, b_hi;
+            rd64_any(r, P0 + 2u, a_lo, a_hi);
+            tab.put(uni(hash_v(a_lo, a_hi, hlog, mls)), P0 + 3u);          /* base + current0 + 2 */
+            rd64_any(r, ip0 - 2u, b_lo, b_hi);
+            tab.put(uni(hash_v(b_lo, b_hi, hlog, mls)), ip0 - 1u);         /* ip0 - 2 */
+            if (off2 > 0u) {
+                while (ip0 <= ilimit) {
+                    r.ensure(ip0 + 12u);
+                    uint32_t c_lo, c_hi;
+                    rd64_any(r, ip0, c_lo, c_hi);
+                    if (uni(c_lo) != uni(r.rd32_any(ip0 - off2))) break;
+                    const uint32_t rlen = count_match_r(r, ip0 + 4u, ip0 + 4u - off2, iend, lane) + 4u;
+                    const uint32_t t = off2; off2 = off1; off1 = t;
+                    tab.put(uni(hash_v(c_lo, c_hi, hlog, mls)), ip0 + 1u);
+                    ip0 += rlen;
+                    store_seq_r(r, ws, ss, 0, anchor, 0, rlen - 3u, lane);
+                    anchor = ip0;
+                }
+            }
+        }
+    }
+    rep[0] = off1 ? off1 : saved;
+    rep[1] = off2 ? off2 : saved;
+    return iend - anchor;
+}
+
 } // namespace
 
+template <bool BATCH>
 __global__ void __launch_bounds__(64)
 k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t n_blocks,
            uint8_t *__restrict__ dst_base, uint64_t dst_stride, int wlog, int hlog, int mml, int tlen,
@@ -882,12 +1127,30 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
     uint8_t *ws = workspace + (uint64_t)blockIdx.x * kWsBytes;
     CPar cp;
     cp.wlog = wlog; cp.hlog = hlog; cp.mml = mml; cp.tlen = tlen;
-    uint32_t *table = (hlog <= 13) ? L.hash : reinterpret_cast<uint32_t *>(ws + kWsHash);
+    /* match-finder table: BATCH: u16 | u8 entries in dynamic LDS behind the input ring (hashLog <= 14);
+     * serial: u32 in LDS when hashLog <= 13, else in the workgroup's workspace */
+    uint32_t *table = nullptr;
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
+    PosTab ptab = {nullptr, nullptr};
+    if constexpr (BATCH) {
+        ptab.lo = reinterpret_cast<uint16_t *>(dyn_lds + kZW);
+        ptab.hi = dyn_lds + kZW + (2u << hlog);
+    } else {
+        __shared__ uint32_t hash_lds[8192];
+        table = (hlog <= 13) ? hash_lds : reinterpret_cast<uint32_t *>(ws + kWsHash);
+    }
 
     for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         const uint8_t *src = src_base + blk * src_stride;
         uint8_t *dst = dst_base + blk * dst_stride;
-        for (uint32_t i = lane; i < (1u << hlog); i += 64u) table[i] = 0;
+        RingIn<kZW> ring;
+        if constexpr (BATCH) {
+            for (uint32_t i = lane; i < (3u << hlog) / 16u; i += 64u) reinterpret_cast<uint4 *>(dyn_lds + kZW)[i] = make_uint4(0, 0, 0, 0);
+            ring.open(dyn_lds, src, n, lane);
+            ring.ensure(kZW);
+        } else {
+            for (uint32_t i = lane; i < (1u << hlog); i += 64u) table[i] = 0;
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         uint32_t op;
@@ -926,7 +1189,9 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 ss.nseq = 0; ss.nlit = 0; ss.long_pos = 0; ss.long_kind = 0;
                 uint32_t nrep[3] = {rep[0], rep[1], rep[2]};
                 if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_other += t - t_prev; t_prev = t; }
-                const uint32_t last_ll = block_fast(table, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane);
+                uint32_t last_ll;
+                if constexpr (BATCH) last_ll = block_fast_batch(ring, ptab, cp, ip, bs, nrep, ws, ss, dict_limit, lane);
+                else last_ll = block_fast(table, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane);
                 if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mf += t - t_prev; t_prev = t; }
                 for (uint32_t i = lane; i < last_ll; i += 64u) (ws + kWsLit)[ss.nlit + i] = src[ip + bs - last_ll + i];
                 ss.nlit += last_ll;
@@ -994,13 +1259,26 @@ static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *
     return true;
 }
 
-static uint32_t zstd_enc_grid(uint64_t n_blocks)
+static bool zstd_enc_batch(int hlog)
 {
-    const uint64_t cap = 256u * 2u; /* 2 workgroups per CU (LDS ~56 KiB each) */
+    static const bool serial_only = getenv("CRYO_ZSTD_ENC") && getenv("CRYO_ZSTD_ENC")[0] == '1'; /* testing aid */
+    return !serial_only && hlog <= 14;
+}
+
+static uint32_t zstd_enc_grid(uint64_t n_blocks, bool batch, int hlog)
+{
+    /* workgroups per CU by LDS: serial 2 (~47 KiB); batch: 14 KiB + ring + 3 bytes per table entry */
+    uint64_t per_cu = 2;
+    if (batch) {
+        per_cu = (160u * 1024u) / (sizeof(EncLds) + kZW + (3u << hlog));
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 8) per_cu = 8;
+    }
+    const uint64_t cap = 256u * per_cu;
     return (uint32_t)(n_blocks < cap ? n_blocks : cap);
 }
 
-size_t zstd_compress_workspace(uint64_t n_blocks) { return (size_t)zstd_enc_grid(n_blocks) * kWsBytes + 256; }
+size_t zstd_compress_workspace(uint64_t n_blocks) { return (size_t)zstd_enc_grid(n_blocks, true, 10) * kWsBytes + 256; }
 
 bool zstd_compress_supported(int level, uint32_t block_size)
 {
@@ -1015,7 +1293,8 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
     if (n_blocks == 0) return hipSuccess;
     int wlog, hlog, mml, tlen;
     if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen)) return hipErrorNotSupported;
-    const uint32_t grid = zstd_enc_grid(n_blocks);
+    const bool batch = zstd_enc_batch(hlog);
+    const uint32_t grid = zstd_enc_grid(n_blocks, batch, hlog);
     if (workspace_bytes < (size_t)grid * kWsBytes) return hipErrorInvalidValue;
     static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
     unsigned long long *d_st = nullptr, h_st[3] = {0, 0, 0};
@@ -1023,8 +1302,13 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
     }
-    hipLaunchKernelGGL(k_zstd_enc, dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst,
-                       dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status, (uint8_t *)d_workspace, d_st);
+    if (batch)
+        hipLaunchKernelGGL(k_zstd_enc<true>, dim3(grid), dim3(64), kZW + (3u << hlog), s, d_src, src_stride, block_size,
+                           n_blocks, d_dst, dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status,
+                           (uint8_t *)d_workspace, d_st);
+    else
+        hipLaunchKernelGGL(k_zstd_enc<false>, dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst,
+                           dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status, (uint8_t *)d_workspace, d_st);
     if (want_stats) {
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);

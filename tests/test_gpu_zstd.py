@@ -225,3 +225,36 @@ def test_zstd_pipeline_many_frames_across_tiles(codec, oracle):
         else:
             assert st[i] == 0, i
             assert np.array_equal(outs[i], expect[i]), i
+
+
+def test_zstd_encode_batch_match_finder_corners(codec, oracle):
+    """the 64-iterations-per-step match finder: incompressible data (growing steps), repeats at distances
+    beyond the LDS ring and the window, long runs (repeat-offset loop), periodic data with noise;
+    block sizes at the edges of the supported ranges; every fast level.  Bar: bytes == oracle (== libzstd)."""
+    rng = np.random.default_rng(21)
+    stock = oracle_lib.StockLibs()
+    for n in (16385, 20000, 131072, 262145, 300000 + 7):
+        blocks = [rng.integers(0, 256, n, dtype=np.uint8)]
+        a = rng.integers(0, 256, n, dtype=np.uint8)
+        chunk = a[:3000].copy()
+        for off in (4000, 4000 + 2047, 12000, n // 2, n - 3100):
+            if off + 3000 <= n:
+                a[off:off + 3000] = chunk
+        blocks.append(a)
+        z = np.zeros(n, np.uint8)
+        z[n // 3:n // 3 + 100] = rng.integers(0, 256, 100, dtype=np.uint8)
+        blocks.append(z)
+        t = np.frombuffer((b"abcdefghij" * (n // 10 + 1))[:n], np.uint8).copy()
+        t[::997] = rng.integers(0, 256, len(t[::997]), dtype=np.uint8)
+        blocks.append(t)
+        w = np.frombuffer((b"the quick brown fox jumps over the lazy dog, " * (n // 45 + 1))[:n], np.uint8).copy()
+        w[rng.integers(0, n, n // 50)] = 0x5A
+        blocks.append(w)
+        for level in (-5, -1, 1, 2):
+            got = codec.compress_blocks(METHOD_ZSTD, level, blocks)
+            for i, b in enumerate(blocks):
+                exp = oracle.zstd_compress(b, level)
+                assert len(exp) > 0
+                assert np.array_equal(got[i], exp), (n, level, i, len(got[i]), len(exp))
+                if stock.zstd is not None and level > 0:
+                    assert np.array_equal(stock.zstd_compress(b, level), exp), (n, level, i)
