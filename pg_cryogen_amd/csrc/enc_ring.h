@@ -18,11 +18,12 @@ struct RingIn {
     uint8_t *win; /* LDS, kW bytes, 16-byte aligned */
     const uint8_t *src;
     uint32_t n, hi, lane;
+    uint32_t floor; /* lowest position the ring may hold (after reopen(): what was staged before is gone) */
     uint4 pre;
 
     __device__ inline void open(uint8_t *lds, const uint8_t *s, uint32_t len, uint32_t ln)
     {
-        win = lds; src = s; n = len; hi = 0; lane = ln;
+        win = lds; src = s; n = len; hi = 0; lane = ln; floor = 0;
         prefetch();
     }
     __device__ inline void prefetch()
@@ -49,7 +50,18 @@ struct RingIn {
             prefetch();
         }
     }
-    __device__ inline uint32_t lo_pos() const { return hi > kW ? hi - kW : 0u; }
+    /* the LDS behind the ring was used for something else: start staging again at the chunk that holds `pos` */
+    __device__ inline void reopen(uint32_t pos)
+    {
+        hi = pos & ~(kEncStage - 1u);
+        floor = hi;
+        prefetch();
+    }
+    __device__ inline uint32_t lo_pos() const
+    {
+        const uint32_t l = hi > kW ? hi - kW : 0u;
+        return l > floor ? l : floor;
+    }
 
     /* dword i (0, 1, 2) of the aligned group that holds bytes p .. p+11 */
     __device__ inline uint32_t dw(uint32_t p, uint32_t i) const

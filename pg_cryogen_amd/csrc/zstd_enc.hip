@@ -43,7 +43,8 @@ constexpr size_t kWsLlc = kWsLit + kZBlk + 64u;                 /* LL / OF / ML 
 constexpr size_t kWsOfc = kWsLlc + kMaxSeq;
 constexpr size_t kWsMlc = kWsOfc + kMaxSeq;
 constexpr size_t kWsHash = (kWsMlc + kMaxSeq + 255u) & ~(size_t)255u; /* u32 x 65536 (hashLog <= 16) */
-constexpr size_t kWsBytes = kWsHash + 65536u * 4u;
+constexpr size_t kWsPrev = kWsHash + 65536u * 4u;                 /* previous block's Huffman table (batch kernel) */
+constexpr size_t kWsBytes = kWsPrev + 1024u;
 
 struct FseCt {
     uint16_t state[512];
@@ -87,9 +88,14 @@ struct BitW {
         if (nb == 0u) return;
         acc |= (v & ((1ull << nb) - 1ull)) << n;
         n += nb;
-        while (n >= 8u) { p[len++] = (uint8_t)acc; acc >>= 8; n -= 8u; }
+        if (n >= 32u) { const uint32_t w = (uint32_t)acc; __builtin_memcpy(p + len, &w, 4); len += 4u; acc >>= 32; n -= 32u; }
     }
-    __device__ inline uint32_t flush() { if (n > 0u) { p[len++] = (uint8_t)acc; n = 0; acc = 0; } return len; }
+    __device__ inline uint32_t flush()
+    {
+        while (n > 0u) { p[len++] = (uint8_t)acc; acc >>= 8; n = n > 8u ? n - 8u : 0u; }
+        acc = 0;
+        return len;
+    }
     __device__ inline uint32_t close() { add(1, 1); return flush(); }
 };
 
@@ -465,7 +471,64 @@ __device__ uint32_t huf_write_table(EncLds &L, uint8_t *dst, uint32_t max_sym, u
     return (max_sym + 1u) / 2u + 1u;
 }
 
-/* encode literals with the table (val, nb): 1 stream (lane 0) or 4 streams (lanes 0..3).
+/* ---- Huffman literal streams, all 64 lanes per stream ----
+ * A stream is the concatenation of its symbols' codes, last symbol first.  The lanes split it into 64
+ * runs of consecutive symbols, count their bits (pass 1), scan the counts into bit offsets, and then each
+ * lane packs its run at its offset (pass 2): whole dwords it owns are stored, the first and last (shared
+ * with the neighbours, the jump table or the previous stream) are OR-ed in atomically into the zeroed
+ * output.  Symbols are fetched 16 at a time. */
+__device__ inline uint32_t huf_run_bits(const uint8_t *src, uint32_t top, uint32_t cnt, const uint8_t *nbt)
+{
+    uint32_t bits = 0, i = 0;
+    for (; i + 16u <= cnt; i += 16u) {
+        uint4 v;
+        __builtin_memcpy(&v, src + top - i - 16u, 16);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) bits += nbt[(w[k >> 2] >> (8 * (k & 3))) & 255u];
+    }
+    for (; i < cnt; i++) bits += nbt[src[top - 1u - i]];
+    return bits;
+}
+
+struct OrW { /* bit packer over dwords: first and last dword OR-ed atomically, the ones between stored */
+    uint32_t *a;
+    uint64_t acc;
+    uint32_t nacc;
+    bool first;
+    __device__ inline void init(uint32_t *base, uint32_t bitpos) { a = base + (bitpos >> 5); acc = 0; nacc = bitpos & 31u; first = true; }
+    __device__ inline void add(uint32_t v, uint32_t nb)
+    {
+        acc |= (uint64_t)v << nacc;
+        nacc += nb;
+        if (nacc >= 32u) {
+            if (first) atomicOr(a, (uint32_t)acc); else *a = (uint32_t)acc;
+            first = false;
+            a++;
+            acc >>= 32;
+            nacc -= 32u;
+        }
+    }
+    __device__ inline void finish() { if (nacc) atomicOr(a, (uint32_t)acc); }
+};
+
+__device__ inline void huf_run_emit(OrW &o, const uint8_t *src, uint32_t top, uint32_t cnt, const uint16_t *val, const uint8_t *nbt)
+{
+    uint32_t i = 0;
+    for (; i + 16u <= cnt; i += 16u) {
+        uint4 v;
+        __builtin_memcpy(&v, src + top - i - 16u, 16);
+        const uint32_t w[4] = {v.w, v.z, v.y, v.x}; /* highest address first */
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const uint32_t c = (w[k >> 2] >> (8 * (3 - (k & 3)))) & 255u;
+            o.add(val[c], nbt[c]);
+        }
+    }
+    for (; i < cnt; i++) { const uint32_t c = src[top - 1u - i]; o.add(val[c], nbt[c]); }
+}
+
+/* HUF_compress1X / 4X body: the n symbols at src with code table (val, nbt) -> dst + hsz.
  * Returns the total size written at dst+hsz (jump table included) + hsz, 0 = not compressible */
 __device__ uint32_t huf_encode_streams(EncLds &L, uint8_t *dst, uint32_t hsz, const uint8_t *src, uint32_t n,
                                        const uint16_t *val, const uint8_t *nbt, bool single, uint32_t lane)
@@ -473,39 +536,78 @@ __device__ uint32_t huf_encode_streams(EncLds &L, uint8_t *dst, uint32_t hsz, co
     const uint32_t nstreams = single ? 1u : 4u;
     const uint32_t seg = single ? n : (n + 3u) / 4u;
     if (!single && n < 12u) return 0;
-    /* pass 1: bit length of every stream, so each lane knows where its stream starts */
-    const uint32_t me = lane < nstreams ? lane : 0u;
-    const uint32_t beg = me * seg;
-    const uint32_t end = (me + 1u == nstreams) ? n : beg + seg;
-    uint32_t bits = 0;
-    if (lane < nstreams) for (uint32_t i = beg; i < end; i++) bits += nbt[src[i]];
-    const uint32_t bytes = (bits + 1u + 7u) >> 3; /* + end mark */
-    const uint32_t b0 = lane_get(bytes, 0), b1 = lane_get(bytes, 1), b2 = lane_get(bytes, 2), b3 = lane_get(bytes, 3);
-    uint32_t op = hsz;
-    uint32_t my_off;
-    if (single) { my_off = op; op += b0; }
-    else {
-        if (lane == 0) {
-            dst[hsz + 0] = (uint8_t)b0; dst[hsz + 1] = (uint8_t)(b0 >> 8);
-            dst[hsz + 2] = (uint8_t)b1; dst[hsz + 3] = (uint8_t)(b1 >> 8);
-            dst[hsz + 4] = (uint8_t)b2; dst[hsz + 5] = (uint8_t)(b2 >> 8);
+    /* pass 1: every lane's run in every stream; bit offsets by scan */
+    uint32_t off[4] = {0, 0, 0, 0}, bytes[4] = {0, 0, 0, 0}, tot[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (uint32_t s4 = 0; s4 < 4u; s4++) {
+        if (s4 < nstreams) {
+            const uint32_t beg = s4 * seg, end = (s4 + 1u == nstreams) ? n : beg + seg;
+            const uint32_t m = end - beg, q = (m + 63u) >> 6;
+            const uint32_t r0 = lane * q < m ? lane * q : m, r1 = r0 + q < m ? r0 + q : m;
+            const uint32_t bits = huf_run_bits(src, end - r0, r1 - r0, nbt);
+            const uint32_t inc = scan64_incl(bits);
+            off[s4] = inc - bits;
+            tot[s4] = lane_get(inc, 63u);
+            bytes[s4] = (tot[s4] + 1u + 7u) >> 3; /* + end mark */
         }
-        op += 6u;
-        my_off = op + (me > 0u ? b0 : 0u) + (me > 1u ? b1 : 0u) + (me > 2u ? b2 : 0u);
-        op += b0 + b1 + b2 + b3;
     }
-    /* pass 2: symbols from the end of the segment backwards, LSB-first packing */
-    if (lane < nstreams) {
-        BitW b;
-        b.init(dst + my_off);
-        for (uint32_t i = end; i > beg; i--) { const uint32_t c = src[i - 1u]; b.add(val[c], nbt[c]); }
-        b.close();
+    uint32_t op = hsz + (single ? 0u : 6u);
+    const uint32_t total = bytes[0] + bytes[1] + bytes[2] + bytes[3];
+    if (op + total >= n - 1u) return 0; /* not compressible (same verdict as after writing, without the writes) */
+    /* zero the output range (the bytes up to the next dword boundary one by one: the dword before holds
+     * the header) */
+    {
+        uint8_t *z0 = dst + hsz;
+        const uint32_t len = (single ? 0u : 6u) + total;
+        const uint32_t head = (4u - (uint32_t)(reinterpret_cast<uintptr_t>(z0) & 3u)) & 3u;
+        if (lane < head && lane < len) z0[lane] = 0;
+        if (len > head) {
+            uint32_t *zw = reinterpret_cast<uint32_t *>(z0 + head);
+            const uint32_t nw = (len - head + 3u) >> 2;
+            for (uint32_t i = lane; i < nw; i += 64u) zw[i] = 0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_s_waitcnt(0);
     }
+    if (!single && lane == 0) {
+        dst[hsz + 0] = (uint8_t)bytes[0]; dst[hsz + 1] = (uint8_t)(bytes[0] >> 8);
+        dst[hsz + 2] = (uint8_t)bytes[1]; dst[hsz + 3] = (uint8_t)(bytes[1] >> 8);
+        dst[hsz + 4] = (uint8_t)bytes[2]; dst[hsz + 5] = (uint8_t)(bytes[2] >> 8);
+    }
+    /* pass 2 */
+    uint32_t sofs = op;
+#pragma unroll
+    for (uint32_t s4 = 0; s4 < 4u; s4++) {
+        if (s4 < nstreams) {
+            const uint32_t beg = s4 * seg, end = (s4 + 1u == nstreams) ? n : beg + seg;
+            const uint32_t m = end - beg, q = (m + 63u) >> 6;
+            const uint32_t r0 = lane * q < m ? lane * q : m, r1 = r0 + q < m ? r0 + q : m;
+            uint8_t *sp = dst + sofs;
+            const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(sp) & 3u);
+            uint32_t *base = reinterpret_cast<uint32_t *>(sp - mis);
+            OrW o;
+            o.init(base, 8u * mis + off[s4]);
+            huf_run_emit(o, src, end - r0, r1 - r0, val, nbt);
+            o.finish();
+            if (lane == 0) { /* end mark */
+                const uint32_t bp = 8u * mis + tot[s4];
+                atomicOr(base + (bp >> 5), 1u << (bp & 31u));
+            }
+            sofs += bytes[s4];
+        }
+    }
+    op += total;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (op >= n - 1u) return 0;
     return op;
 }
 
-struct HufState { bool prev_valid; bool next_new; };
+struct HufState { bool prev_valid; bool next_new; unsigned long long *prof; unsigned long long t; };
+/* diagnostic phase stamps (CRYO_ZSTD_STATS): bucket k gets the cycles since the previous stamp */
+__device__ inline void zprof(HufState &hs, int k)
+{
+    if (hs.prof) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&hs.prof[k], now - hs.t); hs.t = now; }
+}
 
 /* ZSTD_compressLiterals; returns the literals-section size.  Updates hs.next_new. */
 __device__ uint32_t compress_literals(EncLds &L, uint8_t *dst, const uint8_t *src, uint32_t n, HufState &hs,
@@ -549,9 +651,11 @@ __device__ uint32_t compress_literals(EncLds &L, uint8_t *dst, const uint8_t *sr
         if (n <= 1024u && mode) { reused = true; c = huf_encode_streams(L, dst + lh, 0, src, n, L.pval, L.pnb, single, lane); }
         else {
             uint32_t log = (uint32_t)fse_optimal_log(11, n, max_sym, 1);
+            zprof(hs, 3);
             log = huf_build(L, max_sym, log, lane);
             __builtin_amdgcn_wave_barrier();
             const uint32_t hsz = huf_write_table(L, dst + lh, max_sym, log, lane);
+            zprof(hs, 4);
             if (hsz == 0u) c = 0;
             else {
                 bool use_old = false;
@@ -566,6 +670,7 @@ __device__ uint32_t compress_literals(EncLds &L, uint8_t *dst, const uint8_t *sr
             }
         }
     }
+    zprof(hs, 5);
     const uint32_t gain = (n >> 6) + 2u;
     if (c == 0u || c >= n - gain) { hs.next_new = false; return raw(); }
     if (c == 1u) {
@@ -708,31 +813,54 @@ __device__ uint32_t compress_sequences(EncLds &L, uint8_t *dst, uint8_t *ws, uin
     op += sz;
     if (lane == 0) dst[seq_head] = (uint8_t)((tll << 6) + (tof << 4) + (tml << 2));
     __builtin_amdgcn_wave_barrier();
-    /* interleaved bitstream, last sequence first (wave-uniform) */
+    zprof(hs, 6);
+    /* interleaved bitstream, last sequence first.  The state recurrences are serial, but nothing in the loop
+     * touches memory except the three state tables in LDS: the lanes fetch 64 sequences at a time (codes,
+     * values, per-symbol table entries) and the loop reads them with v_readlane. */
     {
         BitW b;
         b.init(dst + op);
-        uint32_t n = nseq - 1u;
-        uint32_t lc = uni(llc[n]), oc = uni(ofc[n]), mc = uni(mlc[n]);
-        uint2 q = seqs[n];
-        uint32_t sm = fse_init_state(L.ml, mc), so = fse_init_state(L.of, oc), sl = fse_init_state(L.ll, lc);
-        b.add(uni(q.y) & 0xFFFFu, kELLBits[lc]);
-        b.add(uni(q.y) >> 16, kEMLBits[mc]);
-        b.add(uni(q.x), oc);
-        while (n-- > 0u) {
-            lc = uni(llc[n]); oc = uni(ofc[n]); mc = uni(mlc[n]);
-            q = seqs[n];
-            so = fse_encode(b, L.of, so, oc);
-            sm = fse_encode(b, L.ml, sm, mc);
-            sl = fse_encode(b, L.ll, sl, lc);
-            b.add(uni(q.y) & 0xFFFFu, kELLBits[lc]);
-            b.add(uni(q.y) >> 16, kEMLBits[mc]);
-            b.add(uni(q.x), oc);
+        uint32_t sm = 0, so = 0, sl = 0;
+        for (uint32_t c1 = nseq; c1 > 0u;) {
+            const uint32_t cnt = c1 < 64u ? c1 : 64u;
+            const uint32_t idx = lane < cnt ? c1 - 1u - lane : 0u; /* lane j holds sequence c1-1-j */
+            const uint32_t lc = llc[idx], oc = ofc[idx], mc = mlc[idx];
+            const uint2 q = seqs[idx];
+            const uint32_t llv = q.y & 0xFFFFu, mlv = q.y >> 16, ofv = q.x;
+            const uint32_t llb = kELLBits[lc], mlb = kEMLBits[mc];
+            const uint32_t l_dnb = L.ll.dnb[lc], o_dnb = L.of.dnb[oc], m_dnb = L.ml.dnb[mc];
+            const int32_t l_df = L.ll.dfind[lc], o_df = L.of.dfind[oc], m_df = L.ml.dfind[mc];
+            uint32_t j = 0;
+            if (c1 == nseq) { /* the last sequence starts the states */
+                sm = fse_init_state(L.ml, lane_get(mc, 0));
+                so = fse_init_state(L.of, lane_get(oc, 0));
+                sl = fse_init_state(L.ll, lane_get(lc, 0));
+                b.add(lane_get(llv, 0), lane_get(llb, 0));
+                b.add(lane_get(mlv, 0), lane_get(mlb, 0));
+                b.add(lane_get(ofv, 0), lane_get(oc, 0));
+                j = 1;
+            }
+            for (; j < cnt; j++) {
+                uint32_t nb = (so + lane_get(o_dnb, j)) >> 16;
+                b.add(so, nb);
+                so = uni(L.of.state[(int32_t)(so >> nb) + (int32_t)lane_get((uint32_t)o_df, j)]);
+                nb = (sm + lane_get(m_dnb, j)) >> 16;
+                b.add(sm, nb);
+                sm = uni(L.ml.state[(int32_t)(sm >> nb) + (int32_t)lane_get((uint32_t)m_df, j)]);
+                nb = (sl + lane_get(l_dnb, j)) >> 16;
+                b.add(sl, nb);
+                sl = uni(L.ll.state[(int32_t)(sl >> nb) + (int32_t)lane_get((uint32_t)l_df, j)]);
+                b.add(lane_get(llv, j), lane_get(llb, j));
+                b.add(lane_get(mlv, j), lane_get(mlb, j));
+                b.add(lane_get(ofv, j), lane_get(oc, j));
+            }
+            c1 -= cnt;
         }
         b.add(sm, (uint32_t)L.ml.log);
         b.add(so, (uint32_t)L.of.log);
         b.add(sl, (uint32_t)L.ll.log);
         op += b.close();
+        zprof(hs, 7);
         if (last_ncount != 0xFFFFFFFFu && op - last_ncount < 4u) return 0;
     }
     if (op >= src_size - gain) return 0;
@@ -1121,7 +1249,13 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
            uint32_t *__restrict__ out_size, int32_t *__restrict__ status, uint8_t *workspace,
            unsigned long long *stats)
 {
-    __shared__ EncLds L;
+    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
+    /* BATCH: the entropy stage's tables share LDS with the match finder's ring + table (dead while it runs;
+     * for frames of several blocks the table is parked in the workspace meanwhile) */
+    EncLds *Lp;
+    if constexpr (BATCH) Lp = reinterpret_cast<EncLds *>(dyn_lds);
+    else { __shared__ EncLds L_static; Lp = &L_static; }
+    EncLds &L = *Lp;
     unsigned long long t_mf = 0, t_en = 0, t_other = 0, t_prev = stats ? __builtin_amdgcn_s_memtime() : 0; /* CRYO_ZSTD_STATS */
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *ws = workspace + (uint64_t)blockIdx.x * kWsBytes;
@@ -1130,7 +1264,6 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
     /* match-finder table: BATCH: u16 | u8 entries in dynamic LDS behind the input ring (hashLog <= 14);
      * serial: u32 in LDS when hashLog <= 13, else in the workgroup's workspace */
     uint32_t *table = nullptr;
-    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     PosTab ptab = {nullptr, nullptr};
     if constexpr (BATCH) {
         ptab.lo = reinterpret_cast<uint16_t *>(dyn_lds + kZW);
@@ -1173,7 +1306,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         const uint8_t *base = src - 1;
         bool first = true;
         HufState hs;
-        hs.prev_valid = false; hs.next_new = false;
+        hs.prev_valid = false; hs.next_new = false; hs.prof = stats; hs.t = 0;
         uint32_t ip = 0;
         while (ip < n) {
             const uint32_t bs = (n - ip < kZBlk) ? n - ip : kZBlk;
@@ -1196,6 +1329,15 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 for (uint32_t i = lane; i < last_ll; i += 64u) (ws + kWsLit)[ss.nlit + i] = src[ip + bs - last_ll + i];
                 ss.nlit += last_ll;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                const bool more = ip + bs < n;
+                if constexpr (BATCH) {
+                    uint4 *park = reinterpret_cast<uint4 *>(ws + kWsHash);
+                    if (more) for (uint32_t i = lane; i < (3u << hlog) / 16u; i += 64u) park[i] = reinterpret_cast<const uint4 *>(dyn_lds + kZW)[i];
+                    __builtin_amdgcn_wave_barrier();
+                    if (hs.prev_valid) for (uint32_t i = lane; i < 256u; i += 64u) { L.pval[i] = reinterpret_cast<const uint16_t *>(ws + kWsPrev)[i]; L.pnb[i] = (ws + kWsPrev + 512u)[i]; }
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (stats) hs.t = __builtin_amdgcn_s_memtime();
                 csize = compress_sequences(L, dst + op + 3, ws, ss.nseq, ss.nlit, bs, ss.long_pos, ss.long_kind, hs,
                                            tlen > 0, lane);
                 if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_en += t - t_prev; t_prev = t; }
@@ -1208,8 +1350,21 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 if (csize > 1u) {
                     rep[0] = nrep[0]; rep[1] = nrep[1]; rep[2] = nrep[2];
                     if (hs.next_new) {
-                        for (uint32_t i = lane; i < 256u; i += 64u) { L.pval[i] = L.hval[i]; L.pnb[i] = L.hnb[i]; }
+                        for (uint32_t i = lane; i < 256u; i += 64u) {
+                            L.pval[i] = L.hval[i]; L.pnb[i] = L.hnb[i];
+                            if constexpr (BATCH) { reinterpret_cast<uint16_t *>(ws + kWsPrev)[i] = L.hval[i]; (ws + kWsPrev + 512u)[i] = L.hnb[i]; }
+                        }
                         hs.prev_valid = true;
+                    }
+                }
+                if constexpr (BATCH) {
+                    if (more) { /* bring the table back, restart the ring at the next block */
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        const uint4 *park = reinterpret_cast<const uint4 *>(ws + kWsHash);
+                        for (uint32_t i = lane; i < (3u << hlog) / 16u; i += 64u) reinterpret_cast<uint4 *>(dyn_lds + kZW)[i] = park[i];
+                        ring.reopen(ip + bs);
+                        __builtin_amdgcn_wave_barrier();
                     }
                 }
             }
@@ -1270,7 +1425,9 @@ static uint32_t zstd_enc_grid(uint64_t n_blocks, bool batch, int hlog)
     /* workgroups per CU by LDS: serial 2 (~47 KiB); batch: 14 KiB + ring + 3 bytes per table entry */
     uint64_t per_cu = 2;
     if (batch) {
-        per_cu = (160u * 1024u) / (sizeof(EncLds) + kZW + (3u << hlog));
+        size_t lds = kZW + (3u << hlog);
+        if (lds < sizeof(EncLds)) lds = sizeof(EncLds);
+        per_cu = (160u * 1024u) / lds;
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
     }
@@ -1297,13 +1454,14 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
     const uint32_t grid = zstd_enc_grid(n_blocks, batch, hlog);
     if (workspace_bytes < (size_t)grid * kWsBytes) return hipErrorInvalidValue;
     static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
-    unsigned long long *d_st = nullptr, h_st[3] = {0, 0, 0};
+    unsigned long long *d_st = nullptr, h_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (want_stats) {
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
     }
     if (batch)
-        hipLaunchKernelGGL(k_zstd_enc<true>, dim3(grid), dim3(64), kZW + (3u << hlog), s, d_src, src_stride, block_size,
+        hipLaunchKernelGGL(k_zstd_enc<true>, dim3(grid), dim3(64),
+                           (kZW + (3u << hlog)) > sizeof(EncLds) ? (kZW + (3u << hlog)) : sizeof(EncLds), s, d_src, src_stride, block_size,
                            n_blocks, d_dst, dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status,
                            (uint8_t *)d_workspace, d_st);
     else
@@ -1316,6 +1474,10 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
         const double tot = (double)(h_st[0] + h_st[1] + h_st[2]);
         fprintf(stderr, "[zstd enc cycles] match finder %.1f%%  entropy stage %.1f%%  other %.1f%%\n",
                 100.0 * h_st[0] / tot, 100.0 * h_st[1] / tot, 100.0 * h_st[2] / tot);
+        fprintf(stderr, "[zstd enc cycles] of the entropy stage: literal histogram %.1f%%  huffman build+table %.1f%%  "
+                        "huffman encode %.1f%%  sequence codes+tables %.1f%%  FSE encode %.1f%%\n",
+                100.0 * h_st[3] / h_st[1], 100.0 * h_st[4] / h_st[1], 100.0 * h_st[5] / h_st[1], 100.0 * h_st[6] / h_st[1],
+                100.0 * h_st[7] / h_st[1]);
     }
     return hipGetLastError();
 }
