@@ -1000,7 +1000,7 @@ __device__ uint32_t block_fast(uint32_t *table, const CPar &cp, const uint8_t *b
  * ZSTD_compressBlock_fast, 64 iterations per step (same idea as lz4_enc2.hip): the iterations of the
  * search loop whose step is the same -- (ip0 - anchor) >> 7 unchanged -- are taken by the lanes at once.
  * Each iteration reads its two table slots and then writes them; a lane reads what the latest earlier
- * lane wrote to the same slot, found by marking the slots' high bytes with the lane number.  The first
+ * lane wrote to the same slot, found by marking the slots' low halves with the lane number.  The first
  * iteration that finds anything (repeat offset at ip0+2, then ip0, then ip0+1, the library's order) ends
  * the batch, and only the iterations up to it are committed.  Input comes from the LDS ring (enc_ring.h),
  * positions are byte offsets in the frame's input, table entries are index = position + 1 as in the
@@ -1008,11 +1008,27 @@ __device__ uint32_t block_fast(uint32_t *table, const CPar &cp, const uint8_t *b
  */
 constexpr uint32_t kZW = 2048; /* input ring */
 
+/* BIT: indices below 2^17 (frames up to 128 KiB) keep bit 16 in a bitmap (LDS atomics), which brings a
+ * 2^13-entry table to 17 KiB; otherwise a byte per entry (indices below 2^24) */
+template <bool BIT>
 struct PosTab {
     uint16_t *lo;
     uint8_t *hi;
-    __device__ inline uint32_t get(uint32_t h) const { return (uint32_t)lo[h] | ((uint32_t)hi[h] << 16); }
-    __device__ inline void put(uint32_t h, uint32_t v) const { lo[h] = (uint16_t)v; hi[h] = (uint8_t)(v >> 16); }
+    __device__ inline uint32_t get(uint32_t h) const
+    {
+        if constexpr (BIT) return (uint32_t)lo[h] | (((reinterpret_cast<const uint32_t *>(hi)[h >> 5] >> (h & 31u)) & 1u) << 16);
+        else return (uint32_t)lo[h] | ((uint32_t)hi[h] << 16);
+    }
+    __device__ inline void put(uint32_t h, uint32_t v) const
+    {
+        lo[h] = (uint16_t)v;
+        if constexpr (BIT) {
+            uint32_t *w = reinterpret_cast<uint32_t *>(hi) + (h >> 5);
+            const uint32_t bit = 1u << (h & 31u);
+            if ((v >> 16) & 1u) atomicOr(w, bit); else atomicAnd(w, ~bit);
+        } else hi[h] = (uint8_t)(v >> 16);
+    }
+    static __host__ __device__ inline uint32_t bytes(int hlog) { return BIT ? (2u << hlog) + ((1u << hlog) >> 3) : (3u << hlog); }
 };
 
 /* ZSTD_hashPtr on the 8 bytes (lo, hi) read at a position */
@@ -1070,8 +1086,8 @@ __device__ inline void store_seq_r(const RingIn<kW> &r, uint8_t *ws, SeqStore &s
 }
 
 /* istart, n: the zstd block inside the frame's input (positions); returns the length of the last literals */
-template <uint32_t kW>
-__device__ uint32_t block_fast_batch(RingIn<kW> &r, const PosTab &tab, const CPar &cp, uint32_t istart, uint32_t n,
+template <uint32_t kW, bool BIT>
+__device__ uint32_t block_fast_batch(RingIn<kW> &r, const PosTab<BIT> &tab, const CPar &cp, uint32_t istart, uint32_t n,
                                      uint32_t *rep, uint8_t *ws, SeqStore &ss, uint32_t dict_limit, uint32_t lane)
 {
     const int hlog = cp.hlog, mls = cp.mml < 4 ? 4 : (cp.mml > 7 ? 7 : cp.mml);
@@ -1111,17 +1127,17 @@ __device__ uint32_t block_fast_batch(RingIn<kW> &r, const PosTab &tab, const CPa
             h1 = hash_v((lo >> 8) | (hi << 24), hi >> 8, hlog, mls);
             mi0 = tab.get(h0);
             mi1 = tab.get(h1); /* both read before either store, as the library does */
-            tab.hi[h0] = (uint8_t)lane; /* owner marks; the real high bytes are in mi0 / mi1 and come back below */
-            tab.hi[h1] = (uint8_t)lane;
+            tab.lo[h0] = (uint16_t)lane; /* owner marks; the real low halves are in mi0 / mi1 and come back below */
+            tab.lo[h1] = (uint16_t)lane;
         }
         const uint32_t v0 = lo, v1 = (lo >> 8) | (hi << 24), v2 = (lo >> 16) | (hi << 16);
         unsigned long long grouped = 0ull;
         {
             asm volatile("" ::: "memory"); /* the read-back must see what the WAVE wrote */
-            bool lost0 = valid && tab.hi[h0] != (uint8_t)lane;
-            bool lost1 = valid && tab.hi[h1] != (uint8_t)lane;
+            bool lost0 = valid && tab.lo[h0] != (uint16_t)lane;
+            bool lost1 = valid && tab.lo[h1] != (uint16_t)lane;
             asm volatile("" ::: "memory");
-            if (valid) { tab.hi[h0] = (uint8_t)(mi0 >> 16); tab.hi[h1] = (uint8_t)(mi1 >> 16); }
+            if (valid) { tab.lo[h0] = (uint16_t)mi0; tab.lo[h1] = (uint16_t)mi1; }
             unsigned long long losers = __ballot(lost0 || lost1);
             while (losers) {
                 const uint32_t j = ctz64(losers);
@@ -1242,7 +1258,7 @@ __device__ uint32_t block_fast_batch(RingIn<kW> &r, const PosTab &tab, const CPa
 
 } // namespace
 
-template <bool BATCH>
+template <bool BATCH, bool BIT>
 __global__ void __launch_bounds__(64)
 k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t n_blocks,
            uint8_t *__restrict__ dst_base, uint64_t dst_stride, int wlog, int hlog, int mml, int tlen,
@@ -1264,10 +1280,10 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
     /* match-finder table: BATCH: u16 | u8 entries in dynamic LDS behind the input ring (hashLog <= 14);
      * serial: u32 in LDS when hashLog <= 13, else in the workgroup's workspace */
     uint32_t *table = nullptr;
-    PosTab ptab = {nullptr, nullptr};
+    PosTab<BIT> ptab = {nullptr, nullptr};
     if constexpr (BATCH) {
         ptab.lo = reinterpret_cast<uint16_t *>(dyn_lds + kZW);
-        ptab.hi = dyn_lds + kZW + (2u << hlog);
+        ptab.hi = dyn_lds + kZW + (2u << hlog); /* bytes, or the bitmap (4-byte aligned: 2 KiB + 2^(hlog+1)) */
     } else {
         __shared__ uint32_t hash_lds[8192];
         table = (hlog <= 13) ? hash_lds : reinterpret_cast<uint32_t *>(ws + kWsHash);
@@ -1278,7 +1294,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         uint8_t *dst = dst_base + blk * dst_stride;
         RingIn<kZW> ring;
         if constexpr (BATCH) {
-            for (uint32_t i = lane; i < (3u << hlog) / 16u; i += 64u) reinterpret_cast<uint4 *>(dyn_lds + kZW)[i] = make_uint4(0, 0, 0, 0);
+            for (uint32_t i = lane; i < PosTab<BIT>::bytes(hlog) / 16u; i += 64u) reinterpret_cast<uint4 *>(dyn_lds + kZW)[i] = make_uint4(0, 0, 0, 0);
             ring.open(dyn_lds, src, n, lane);
             ring.ensure(kZW);
         } else {
@@ -1332,7 +1348,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 const bool more = ip + bs < n;
                 if constexpr (BATCH) {
                     uint4 *park = reinterpret_cast<uint4 *>(ws + kWsHash);
-                    if (more) for (uint32_t i = lane; i < (3u << hlog) / 16u; i += 64u) park[i] = reinterpret_cast<const uint4 *>(dyn_lds + kZW)[i];
+                    if (more) for (uint32_t i = lane; i < PosTab<BIT>::bytes(hlog) / 16u; i += 64u) park[i] = reinterpret_cast<const uint4 *>(dyn_lds + kZW)[i];
                     __builtin_amdgcn_wave_barrier();
                     if (hs.prev_valid) for (uint32_t i = lane; i < 256u; i += 64u) { L.pval[i] = reinterpret_cast<const uint16_t *>(ws + kWsPrev)[i]; L.pnb[i] = (ws + kWsPrev + 512u)[i]; }
                     __builtin_amdgcn_wave_barrier();
@@ -1362,7 +1378,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                         __builtin_amdgcn_wave_barrier();
                         const uint4 *park = reinterpret_cast<const uint4 *>(ws + kWsHash);
-                        for (uint32_t i = lane; i < (3u << hlog) / 16u; i += 64u) reinterpret_cast<uint4 *>(dyn_lds + kZW)[i] = park[i];
+                        for (uint32_t i = lane; i < PosTab<BIT>::bytes(hlog) / 16u; i += 64u) reinterpret_cast<uint4 *>(dyn_lds + kZW)[i] = park[i];
                         ring.reopen(ip + bs);
                         __builtin_amdgcn_wave_barrier();
                     }
@@ -1420,14 +1436,18 @@ static bool zstd_enc_batch(int hlog)
     return !serial_only && hlog <= 14;
 }
 
-static uint32_t zstd_enc_grid(uint64_t n_blocks, bool batch, int hlog)
+static size_t zstd_enc_dyn_lds(int hlog, bool bit)
+{
+    const size_t t = kZW + (bit ? PosTab<true>::bytes(hlog) : PosTab<false>::bytes(hlog));
+    return t > sizeof(EncLds) ? t : sizeof(EncLds);
+}
+
+static uint32_t zstd_enc_grid(uint64_t n_blocks, bool batch, int hlog, bool bit = false)
 {
     /* workgroups per CU by LDS: serial 2 (~47 KiB); batch: 14 KiB + ring + 3 bytes per table entry */
     uint64_t per_cu = 2;
     if (batch) {
-        size_t lds = kZW + (3u << hlog);
-        if (lds < sizeof(EncLds)) lds = sizeof(EncLds);
-        per_cu = (160u * 1024u) / lds;
+        per_cu = (160u * 1024u) / zstd_enc_dyn_lds(hlog, bit);
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
     }
@@ -1435,7 +1455,7 @@ static uint32_t zstd_enc_grid(uint64_t n_blocks, bool batch, int hlog)
     return (uint32_t)(n_blocks < cap ? n_blocks : cap);
 }
 
-size_t zstd_compress_workspace(uint64_t n_blocks) { return (size_t)zstd_enc_grid(n_blocks, true, 10) * kWsBytes + 256; }
+size_t zstd_compress_workspace(uint64_t n_blocks) { return (size_t)zstd_enc_grid(n_blocks, true, 10, true) * kWsBytes + 256; }
 
 bool zstd_compress_supported(int level, uint32_t block_size)
 {
@@ -1451,7 +1471,8 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
     int wlog, hlog, mml, tlen;
     if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen)) return hipErrorNotSupported;
     const bool batch = zstd_enc_batch(hlog);
-    const uint32_t grid = zstd_enc_grid(n_blocks, batch, hlog);
+    const bool bit = batch && block_size <= (128u << 10);
+    const uint32_t grid = zstd_enc_grid(n_blocks, batch, hlog, bit);
     if (workspace_bytes < (size_t)grid * kWsBytes) return hipErrorInvalidValue;
     static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
     unsigned long long *d_st = nullptr, h_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1459,13 +1480,16 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
     }
-    if (batch)
-        hipLaunchKernelGGL(k_zstd_enc<true>, dim3(grid), dim3(64),
-                           (kZW + (3u << hlog)) > sizeof(EncLds) ? (kZW + (3u << hlog)) : sizeof(EncLds), s, d_src, src_stride, block_size,
-                           n_blocks, d_dst, dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status,
+    if (batch && bit)
+        hipLaunchKernelGGL((k_zstd_enc<true, true>), dim3(grid), dim3(64), zstd_enc_dyn_lds(hlog, true), s, d_src, src_stride,
+                           block_size, n_blocks, d_dst, dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status,
+                           (uint8_t *)d_workspace, d_st);
+    else if (batch)
+        hipLaunchKernelGGL((k_zstd_enc<true, false>), dim3(grid), dim3(64), zstd_enc_dyn_lds(hlog, false), s, d_src, src_stride,
+                           block_size, n_blocks, d_dst, dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status,
                            (uint8_t *)d_workspace, d_st);
     else
-        hipLaunchKernelGGL(k_zstd_enc<false>, dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst,
+        hipLaunchKernelGGL((k_zstd_enc<false, false>), dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst,
                            dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status, (uint8_t *)d_workspace, d_st);
     if (want_stats) {
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
