@@ -69,7 +69,11 @@ int cryo_codec_sync(cryo_codec *c);
 size_t cryo_codec_bound(int method, size_t block_size);
 
 /* ---- device memory plumbing (plain hipMalloc/hipMemcpy wrappers so that C
- *      callers and ctypes need no HIP headers) ---- */
+ *      callers and ctypes need no HIP headers) ----
+ * The kernels read compressed input in aligned 16-byte pieces: up to 15 bytes before a block's
+ * first byte and after its last byte may be read (never used).  cryo_dev_alloc pads every
+ * allocation by 64 bytes; a caller that brings its own device memory must leave that slack
+ * after the last compressed block. */
 int cryo_dev_alloc(cryo_codec *c, size_t bytes, void **d_ptr);
 int cryo_dev_free(cryo_codec *c, void *d_ptr);
 int cryo_dev_upload(cryo_codec *c, void *d_dst, const void *h_src, size_t bytes);   /* sync */

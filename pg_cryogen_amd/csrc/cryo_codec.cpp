@@ -161,7 +161,8 @@ int cryo_dev_alloc(cryo_codec *c, size_t bytes, void **d_ptr)
     if (!c || !d_ptr) return CRYO_E_ARG;
     *d_ptr = nullptr;
     HIP_TRY(c, hipSetDevice(c->device));
-    hipError_t e = hipMalloc(d_ptr, bytes ? bytes : 1);
+    /* +64: the kernels read compressed input in aligned 16-byte pieces (up to 15 bytes past a block's end) */
+    hipError_t e = hipMalloc(d_ptr, bytes + 64);
     if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return CRYO_E_NOMEM; }
     if (e != hipSuccess) return fail(c, e, "hipMalloc");
     return CRYO_OK;
