@@ -13,7 +13,9 @@
  *                                tables built in LDS, stored to the workspace
  *   K2 k_zhuf   lane per stream  64 Huffman streams per wave (16 blocks x 4 streams), the 16 tables in
  *                                LDS; symbols go to the frame's literal pool
- *   K3 k_zseq   lane per frame   FSE sequence decode incl. repeat offsets -> (ll, ml, offset) records
+ *   K3 k_zseq   lane per block   FSE sequence decode -> (ll, ml, offset) records; 15 blocks per wave, their
+ *                                tables in LDS.  Repeat offsets are resolved on the fly in a frame's first
+ *                                block; k_zrep (lane per frame) resolves those of later blocks
  *   K4 k_zexec  wave per frame   sequence execution with the shared LZ copy engine (lz_common.h):
  *                                records are loaded 64 at a time, literals stream through the LDS
  *                                input ring, output ring in LDS, 1 KiB coalesced flushes
@@ -54,7 +56,9 @@ struct ZBlk { /* one zstd block of a frame; 128 bytes */
     uint32_t slots;          /* table slots: ll | of << 8 | ml << 16 */
     uint32_t logs;           /* table logs, same packing */
     uint32_t seq_base;       /* first record in the sequence pool */
-    uint32_t pad[9];
+    uint32_t seq_first;      /* 1: first block of the frame with sequences (repeat offsets start at 1, 4, 8) */
+    uint32_t rep_out[3];     /* repeat offsets after this block (written by K3 for seq_first blocks, else by k_zrep) */
+    uint32_t pad[5];
 };
 static_assert(sizeof(ZBlk) == 128, "descriptor size");
 
@@ -78,9 +82,12 @@ struct ZPipe {
     uint32_t *seqt, *predef;
     uint8_t *lits;
     uint4 *seqs;
-    uint32_t *counters; /* [0] sequence pool cursor, [1] Huffman items, [2] irregular frames */
+    uint32_t *counters; /* [0] sequence pool cursor, [1] Huffman items, [2] irregular frames, [3] sequence items,
+                           [60] frames with more than one sequence block */
     uint32_t *hitems;
     uint32_t *irregular;
+    uint32_t *sitems; /* blocks with sequences (f * nbmax + k) */
+    uint32_t *ritems; /* frames whose later blocks need their repeat offsets resolved */
 };
 
 struct PlanLds {
@@ -346,6 +353,14 @@ __global__ void __launch_bounds__(64) k_zplan(ZPipe P)
                     P.hitems[atomicAdd(&P.counters[1], 1u)] = f * P.nbmax + k;
                     atomicAdd(&P.counters[4 + (bd[k].huf_log & 15u)], 1u); /* histogram of table logs (diagnostics) */
                 }
+            uint32_t nsb = 0;
+            for (uint32_t k = 0; k < nblk; k++)
+                if (bd[k].type == 2u && bd[k].nseq) {
+                    bd[k].seq_first = nsb == 0u ? 1u : 0u;
+                    nsb++;
+                    P.sitems[atomicAdd(&P.counters[3], 1u)] = f * P.nbmax + k;
+                }
+            if (nsb > 1u) P.ritems[atomicAdd(&P.counters[60], 1u)] = f;
             for (uint32_t k = 0; k < nblk; k++)
                 if (bd[k].type == 2u && bd[k].nseq) {
                     atomicAdd(&P.counters[20 + (bd[k].logs & 15u)], 1u);
@@ -519,7 +534,6 @@ constexpr uint32_t kSeqPerWave = 15; /* frames per wave: 15 x 5 KiB of decoding 
 struct SeqLds {
     uint32_t tab[kSeqPerWave][kSeqTblWords];
     uint32_t ring[36][16];
-    uint32_t cur[kSeqPerWave][4];
     uint32_t llx[36], mlx[53]; /* base value | extra bits << 24 (LDS copies: a constant-memory load in the loop
                                   would wait on the ring's in-flight global loads as well) */
 };
@@ -536,6 +550,7 @@ __device__ inline uint32_t seq_bits(LaneBits<16> &lb, uint32_t nb)
     return v;
 }
 
+constexpr uint32_t kRepPending = 0x80000000u; /* record.z = kRepPending | repeat index 0..3 */
 struct SeqPre { uint32_t el, eo, em; }; /* table entries of the next sequence, already on their way from LDS */
 
 /* One sequence.  Entry: next-state base (10 bits) | state bits (4) | symbol (6) | extra bits (5).
@@ -546,7 +561,7 @@ struct SeqPre { uint32_t el, eo, em; }; /* table entries of the next sequence, a
  * fill covers the usual sequence, two more are taken only by the lanes that need them. */
 template <int J>
 __device__ inline void seq_step(LaneBits<16> &lb, const uint32_t *tab, const uint32_t *llx, const uint32_t *mlx, SeqState &z,
-                                SeqPre &pre, uint4 *out, uint32_t i, uint32_t nseq)
+                                SeqPre &pre, uint4 *out, uint32_t i, uint32_t nseq, bool resolve)
 {
     if (i + J < nseq) {
         const uint32_t el = pre.el, eo = pre.eo, em = pre.em;
@@ -575,7 +590,8 @@ __device__ inline void seq_step(LaneBits<16> &lb, const uint32_t *tab, const uin
         const uint32_t idx = (osym == 1u ? 1u + extra : 0u) + ll0; /* repeat-offset index 0..3 (unused when fresh) */
         uint32_t cand = idx == 0u ? z.rep0 : (idx == 1u ? z.rep1 : (idx == 2u ? z.rep2 : z.rep0 - 1u));
         if (cand == 0u) cand = 1u; /* 0 is not valid: forced to 1 like the library */
-        const uint32_t offset = fresh ? ((1u << osym) - 3u) + extra : cand;
+        /* a later block of a frame does not know its repeat offsets yet: k_zrep fills them in */
+        const uint32_t offset = fresh ? ((1u << osym) - 3u) + extra : (resolve ? cand : (kRepPending | idx));
         const uint32_t r0 = z.rep0, r1 = z.rep1;
         z.rep0 = offset;
         z.rep1 = (!fresh && idx == 0u) ? r1 : r0;
@@ -589,81 +605,113 @@ __global__ void __launch_bounds__(64) k_zseq(ZPipe P)
 {
     __shared__ __attribute__((aligned(16))) SeqLds L;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t f0 = blockIdx.x * kSeqPerWave;
-    const uint32_t f = f0 + lane;
-    bool mine = lane < kSeqPerWave && f < P.F;
-    uint32_t nblk = 0;
-    if (mine) {
-        const uint32_t flags = P.frames[f].flags;
-        if (flags & (F_BAD | F_IRREG)) mine = false;
-        else nblk = P.frames[f].nblk;
-    }
-    const uint32_t max_nblk = wave_max(nblk);
-    if (max_nblk == 0u) return;
-    if (lane < kSeqPerWave * 4u) (&L.cur[0][0])[lane] = 0xFFFFFFFFu;
+    const uint32_t nitems = uni(P.counters[3]);
+    const uint32_t i0 = blockIdx.x * kSeqPerWave;
+    if (i0 >= nitems) return;
     if (lane < 36u) L.llx[lane] = kLLBase[lane] | ((uint32_t)kLLBits[lane] << 24);
     if (lane < 53u) L.mlx[lane] = kMLBase[lane] | ((uint32_t)kMLBits[lane] << 24);
+    /* ---- stage the three decoding tables of each of the wave's 15 blocks ---- */
+    for (uint32_t j = 0; j < kSeqPerWave && i0 + j < nitems; j++) {
+        const uint32_t it = uni(P.sitems[i0 + j]);
+        const uint32_t fj = it / P.nbmax;
+        const ZBlk *d = P.blks + it;
+        const uint32_t slots = uni(d->slots), logs = uni(d->logs);
+#pragma unroll
+        for (int kind = 0; kind < 3; kind++) {
+            const uint32_t slot = (slots >> (8 * kind)) & 255u, lg = (logs >> (8 * kind)) & 255u;
+            const uint32_t goff = kind == 0 ? 0u : (kind == 1 ? 1024u : 512u);
+            const uint32_t *g = (slot == kPredefSlot ? P.predef : P.seqt + ((uint64_t)fj * P.nbmax + slot) * kSeqTblWords) + goff;
+            copy_words(&L.tab[j][goff], g, 1u << lg, lane);
+        }
+    }
     __builtin_amdgcn_wave_barrier();
-    const uint8_t *src = mine ? P.src_base + P.src_off[P.first + f] : P.src_base;
+
+    /* ---- lanes 0..14: one block each ---- */
+    bool act = lane < kSeqPerWave && i0 + lane < nitems;
+    const uint32_t it = act ? P.sitems[i0 + lane] : P.sitems[i0];
+    const uint32_t f = it / P.nbmax;
+    ZBlk *d = P.blks + it;
+    if (act && (P.frames[f].flags & (F_BAD | F_IRREG))) act = false;
+    const uint8_t *src = P.src_base + P.src_off[P.first + f];
+    const uint32_t logs = d->logs;
+    const bool resolve = d->seq_first != 0u;
+    uint32_t nseq = act ? d->nseq : 0u;
     SeqState z;
     z.rep0 = 1; z.rep1 = 4; z.rep2 = 8;
     z.sl = z.so = z.sm = 0;
     bool bad = false;
-
-    for (uint32_t k = 0; k < max_nblk; k++) {
-        /* ---- stage the tables block k of each frame uses (skipped when the slot is already resident) ---- */
-        for (uint32_t j = 0; j < kSeqPerWave && f0 + j < P.F; j++) {
-            const uint32_t fj = f0 + j;
-            const uint32_t fl = uni(P.frames[fj].flags);
-            if ((fl & (F_BAD | F_IRREG)) || k >= uni(P.frames[fj].nblk)) continue;
-            const ZBlk *d = P.blks + (uint64_t)fj * P.nbmax + k;
-            if (uni(d->type) != 2u || uni(d->nseq) == 0u) continue;
-            const uint32_t slots = uni(d->slots), logs = uni(d->logs);
-#pragma unroll
-            for (int kind = 0; kind < 3; kind++) {
-                const uint32_t slot = (slots >> (8 * kind)) & 255u, lg = (logs >> (8 * kind)) & 255u;
-                if (uni(L.cur[j][kind]) == slot) continue;
-                const uint32_t goff = kind == 0 ? 0u : (kind == 1 ? 1024u : 512u);
-                const uint32_t *g = (slot == kPredefSlot ? P.predef : P.seqt + ((uint64_t)fj * P.nbmax + slot) * kSeqTblWords) + goff;
-                copy_words(&L.tab[j][goff], g, 1u << lg, lane);
-                __builtin_amdgcn_wave_barrier();
-                if (lane == 0) L.cur[j][kind] = slot;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-
-        /* ---- lanes 0..14: block k of their frame ---- */
-        const ZBlk *d = P.blks + (uint64_t)(mine ? f : 0u) * P.nbmax + k;
-        bool act = mine && !bad && k < nblk;
-        uint32_t nseq = 0, logs = 0;
-        if (act) { act = d->type == 2u; }
-        if (act) { nseq = d->nseq; logs = d->logs; act = nseq != 0u; }
-        LaneBits<16> lb;
-        const bool opened = lb.init(&L.ring[0][lane & 15u], src, act ? d->sq_off : 0u, act ? d->sq_len : 0u, act);
-        if (act && !opened) { bad = true; }
-        if (!opened) nseq = 0;
-        const uint32_t *tab = L.tab[lane < kSeqPerWave ? lane : 0u];
-        uint4 *out = P.seqs + (opened ? d->seq_base : 0u);
-        SeqPre pre = {0, 0, 0};
-        if (opened) {
-            lb.fill();
-            z.sl = lb.read(logs & 255u);
-            z.so = lb.read((logs >> 8) & 255u);
-            z.sm = lb.read((logs >> 16) & 255u);
-            pre.el = tab[z.sl]; pre.eo = tab[1024u + z.so]; pre.em = tab[512u + z.sm];
-            lb.fill();
-        }
-        const uint32_t maxn = wave_max(nseq);
-        for (uint32_t i = 0; i < maxn; i += 4u) {
-            seq_step<0>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq);
-            seq_step<1>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq);
-            seq_step<2>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq);
-            seq_step<3>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq);
-        }
-        if (opened && lb.pos != 0) bad = true; /* the bitstream must be consumed exactly */
-        __builtin_amdgcn_wave_barrier();
+    LaneBits<16> lb;
+    const bool opened = lb.init(&L.ring[0][lane & 15u], src, act ? d->sq_off : 0u, act ? d->sq_len : 0u, act);
+    if (act && !opened) bad = true;
+    if (!opened) nseq = 0;
+    const uint32_t *tab = L.tab[lane < kSeqPerWave ? lane : 0u];
+    uint4 *out = P.seqs + (opened ? d->seq_base : 0u);
+    SeqPre pre = {0, 0, 0};
+    if (opened) {
+        lb.fill();
+        z.sl = lb.read(logs & 255u);
+        z.so = lb.read((logs >> 8) & 255u);
+        z.sm = lb.read((logs >> 16) & 255u);
+        pre.el = tab[z.sl]; pre.eo = tab[1024u + z.so]; pre.em = tab[512u + z.sm];
+        lb.fill();
     }
+    const uint32_t maxn = wave_max(nseq);
+    for (uint32_t i = 0; i < maxn; i += 4u) {
+        seq_step<0>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve);
+        seq_step<1>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve);
+        seq_step<2>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve);
+        seq_step<3>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve);
+    }
+    if (opened && lb.pos != 0) bad = true; /* the bitstream must be consumed exactly */
+    if (opened && resolve) { d->rep_out[0] = z.rep0; d->rep_out[1] = z.rep1; d->rep_out[2] = z.rep2; }
     if (bad) atomicOr(&P.frames[f].flags, F_BAD);
+}
+
+/* K3b: frames of several blocks (1 MiB cryo block = 8 zstd blocks).  The blocks' bitstreams were parsed
+ * independently; the repeat-offset history runs through the whole frame, so the later blocks' repeat codes
+ * are resolved here, one wave per frame, in one sequential walk over their records. */
+__global__ void __launch_bounds__(64) k_zrep(ZPipe P)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    if (blockIdx.x >= uni(P.counters[60])) return;
+    const uint32_t f = uni(P.ritems[blockIdx.x]);
+    if (uni(P.frames[f].flags) & (F_BAD | F_IRREG)) return;
+    const uint32_t nblk = uni(P.frames[f].nblk);
+    uint32_t r0 = 1, r1 = 4, r2 = 8; /* wave-uniform */
+    bool started = false;
+    for (uint32_t k = 0; k < nblk; k++) {
+        ZBlk *d = P.blks + (uint64_t)f * P.nbmax + k;
+        const uint32_t n = uni(d->nseq);
+        if (uni(d->type) != 2u || n == 0u) continue;
+        if (!started) { r0 = uni(d->rep_out[0]); r1 = uni(d->rep_out[1]); r2 = uni(d->rep_out[2]); started = true; continue; }
+        uint4 *q = P.seqs + uni(d->seq_base);
+        /* 64 records at a time: one coalesced load of the offsets, the history walked with v_readlane
+         * (no memory in the serial loop), changed offsets stored back */
+        uint32_t nz = lane < n ? q[lane].z : 0u;
+        for (uint32_t base = 0; base < n; base += 64u) {
+            const uint32_t cnt = n - base < 64u ? n - base : 64u;
+            const uint32_t z = nz;
+            if (base + 64u + lane < n) nz = q[base + 64u + lane].z;
+            uint32_t mine = z;
+            for (uint32_t j = 0; j < cnt; j++) {
+                const uint32_t o = lane_get(z, j);
+                if (o & kRepPending) {
+                    const uint32_t idx = o & 3u;
+                    uint32_t cand = idx == 0u ? r0 : (idx == 1u ? r1 : (idx == 2u ? r2 : r0 - 1u));
+                    if (cand == 0u) cand = 1u;
+                    if (lane == j) mine = cand;
+                    if (idx != 0u) {
+                        const uint32_t t0 = r0, t1 = r1;
+                        r0 = cand;
+                        r1 = t0;
+                        if (idx >= 2u) r2 = t1;
+                    }
+                } else { r2 = r1; r1 = r0; r0 = o; }
+            }
+            if (lane < cnt && mine != z) q[base + lane].z = mine;
+        }
+        if (lane == 0) { d->rep_out[0] = r0; d->rep_out[1] = r1; d->rep_out[2] = r2; }
+    }
 }
 
 /* ------------------------------------------------------------------------------------------------ K4 */
@@ -824,7 +872,7 @@ namespace {
 
 struct Layout {
     uint32_t F, nbmax, litcap, seqcap;
-    size_t o_frames, o_blks, o_huf, o_seqt, o_predef, o_lits, o_seqs, o_cnt, o_hitems, o_irreg, o_fused, total;
+    size_t o_frames, o_blks, o_huf, o_seqt, o_predef, o_lits, o_seqs, o_cnt, o_hitems, o_irreg, o_sitems, o_ritems, o_fused, total;
 };
 
 constexpr uint32_t kFusedGridForIrregular = 256;
@@ -841,7 +889,9 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
                              y.litcap + (size_t)B /* sequence pool share: B/16 records */ + 4u;
     /* Tile size.  K2 and K3 are bound by LDS capacity (two workgroups per CU, 512 per chip): 7680 frames
      * = 512 x 15 (K3) = 480 x 16 (K2) fill exactly one round of each; the workspace budget may force less. */
-    const size_t budget = (size_t)5 << 29; /* 2.5 GiB per tile in flight */
+    static const size_t budget_env = getenv("CRYO_ZSTD_WS_MB") ? (size_t)atoll(getenv("CRYO_ZSTD_WS_MB")) << 20 : 0; /* tuning aid */
+    const size_t budget = budget_env ? budget_env : (size_t)6 << 30; /* per tile in flight; reached only by blocks > 128 KiB,
+                                                                        whose tiles would otherwise be too few frames to fill K1/K4 */
     uint64_t F = budget / per_frame;
     if (F > 7680u) F = 7680u;
     if (F >= 240u) F -= F % 240u;
@@ -862,15 +912,21 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     y.o_cnt = o; o = al256(o + 256u);
     y.o_hitems = o; o = al256(o + (size_t)y.F * y.nbmax * 4u);
     y.o_irreg = o; o = al256(o + (size_t)y.F * 4u);
+    y.o_sitems = o; o = al256(o + (size_t)y.F * y.nbmax * 4u);
+    y.o_ritems = o; o = al256(o + (size_t)y.F * 4u);
     y.o_fused = o; o = al256(o + zstd_fused_workspace(kFusedGridForIrregular));
     y.total = o;
     return y;
 }
 
-bool two_lanes()
+/* two tiles in flight on two side streams: pays for frames of several blocks (measured at 1 MiB: 95 -> 107
+ * GB/s), where a tile has too few frames to fill the wave-per-frame kernels; nothing at 128 KiB */
+bool two_lanes(uint32_t block_size)
 {
-    static const bool on = getenv("CRYO_ZSTD_LANES") && getenv("CRYO_ZSTD_LANES")[0] == '2';
-    return on;
+    static const char *e = getenv("CRYO_ZSTD_LANES"); /* tuning aid: 1 / 2 */
+    if (e && e[0] == '1') return false;
+    if (e && e[0] == '2') return true;
+    return block_size > (256u << 10);
 }
 
 bool use_pipeline(uint64_t n_blocks)
@@ -886,7 +942,8 @@ bool use_pipeline(uint64_t n_blocks)
 size_t zstd_decompress_workspace(uint64_t n_blocks, uint32_t block_size)
 {
     if (!use_pipeline(n_blocks)) return zstd_fused_workspace(n_blocks);
-    return (two_lanes() ? 2u : 1u) * make_layout(n_blocks, block_size).total + 256;
+    const Layout y = make_layout(n_blocks, block_size);
+    return ((two_lanes(block_size) && n_blocks > y.F) ? 2u : 1u) * y.total + 256;
 }
 
 hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
@@ -899,13 +956,13 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
         return launch_zstd_fused(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status,
                                  d_workspace, workspace_bytes, nullptr, nullptr, 0);
     const Layout y = make_layout(n_blocks, block_size);
-    if (workspace_bytes < (two_lanes() ? 2u : 1u) * y.total) return hipErrorInvalidValue;
+    if (workspace_bytes < ((two_lanes(block_size) && n_blocks > y.F) ? 2u : 1u) * y.total) return hipErrorInvalidValue;
     uint8_t *ws0 = (uint8_t *)(((uintptr_t)d_workspace + 255u) & ~(uintptr_t)255u);
-    /* Optional (CRYO_ZSTD_LANES=2): tiles alternate between two side streams with a workspace each, so that
-     * K2/K3 of one tile (LDS-capacity bound) could overlap K1/K4 of the other (issue bound).  Measured: no
-     * gain yet -- K2/K3 leave < 8 KB of LDS per CU free, so K1/K4 workgroups cannot co-reside. */
+    /* Tiles may alternate between two side streams with a workspace each (two_lanes()): the wave-per-frame
+     * kernels of one tile fill the CUs the other tile's leave idle.  K2/K3 themselves leave < 8 KB of LDS per
+     * CU, so nothing co-resides with them: at 128 KiB (7680-frame tiles) the second lane gains nothing. */
     const uint64_t ntiles = (n_blocks + y.F - 1u) / y.F;
-    const int nl = (aux && ntiles > 1u && two_lanes()) ? 2 : 1;
+    const int nl = (aux && ntiles > 1u && two_lanes(block_size)) ? 2 : 1;
     hipError_t e;
     if (nl == 2) {
         if ((e = hipEventRecord(aux->fork, s)) != hipSuccess) return e;
@@ -935,13 +992,16 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
         P.counters = (uint32_t *)(ws + y.o_cnt);
         P.hitems = (uint32_t *)(ws + y.o_hitems);
         P.irregular = (uint32_t *)(ws + y.o_irreg);
+        P.sitems = (uint32_t *)(ws + y.o_sitems);
+        P.ritems = (uint32_t *)(ws + y.o_ritems);
         const uint64_t left = n_blocks - first;
         P.first = first;
         P.F = (uint32_t)(left < y.F ? left : y.F);
         if ((e = hipMemsetAsync(P.counters, 0, 256, st)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_zplan, dim3(P.F), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_zhuf, dim3((P.F * P.nbmax + kHufPerWave - 1u) / kHufPerWave), dim3(64), huf_pad, st, P);
-        hipLaunchKernelGGL(k_zseq, dim3((P.F + kSeqPerWave - 1u) / kSeqPerWave), dim3(64), seq_pad, st, P);
+        hipLaunchKernelGGL(k_zseq, dim3((P.F * P.nbmax + kSeqPerWave - 1u) / kSeqPerWave), dim3(64), seq_pad, st, P);
+        hipLaunchKernelGGL(k_zrep, dim3(P.F), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_zexec, dim3(P.F), dim3(64), 0, st, P);
         const uint64_t fg = P.F < kFusedGridForIrregular ? P.F : kFusedGridForIrregular;
         e = launch_zstd_fused(st, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, fg, d_status,
