@@ -132,8 +132,10 @@ int cryo_codec_decompress_block(cryo_codec *c, int method,
 /* ---- K blocks at once, HOST buffers: what the batch write/read staging calls
  *      (write-behind of K full blocks from multi_insert, read-ahead of K block chains;
  *      reference one-at-a-time equivalents: pg_cryogen.c:726 and cache.c:178).
- *      Synchronous: one H2D, one kernel launch, one D2H for the whole batch. ---- */
-/* block i: h_src + i*block_size  ->  h_dst + i*dst_stride, size in h_out_size[i] */
+ *      Synchronous: one H2D, one kernel launch, one D2H for the whole batch; device buffers and a pinned
+ *      staging buffer are kept in the handle (grow-only). ---- */
+/* block i: h_src + i*block_size  ->  h_dst + i*dst_stride, size in h_out_size[i].  dst_stride >= bound;
+ * the whole slot (up to bound bytes) may be written, only the first h_out_size[i] bytes are meaningful */
 int cryo_codec_compress_blocks(cryo_codec *c, int method, int param,
                                const void *h_src, size_t block_size, size_t n_blocks,
                                void *h_dst, size_t dst_stride, uint32_t *h_out_size);

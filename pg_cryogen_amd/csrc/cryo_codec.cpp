@@ -29,6 +29,11 @@ struct cryo_codec {
     /* zstd decode workspace */
     void *d_ws = nullptr;
     size_t ws_cap = 0;
+    /* host-buffer batch API: grow-only device buffers and one pinned staging buffer */
+    uint8_t *hb_src = nullptr, *hb_dst = nullptr, *hb_meta = nullptr;
+    size_t hb_src_cap = 0, hb_dst_cap = 0, hb_meta_cap = 0;
+    void *pin = nullptr;
+    size_t pin_cap = 0;
     /* side streams of the zstd batch pipeline (created on first use) */
     cryo::ZstdAux aux = {};
     bool have_aux = false;
@@ -56,6 +61,18 @@ int ensure(cryo_codec *c, uint8_t **p, size_t *cap, size_t need)
     if (*p) { HIP_TRY(c, hipFree(*p)); *p = nullptr; *cap = 0; }
     HIP_TRY(c, hipMalloc((void **)p, need));
     *cap = need;
+    return CRYO_OK;
+}
+
+int ensure_pinned(cryo_codec *c, size_t need)
+{
+    if (c->pin_cap >= need) return CRYO_OK;
+    if (c->pin) { HIP_TRY(c, hipHostFree(c->pin)); c->pin = nullptr; c->pin_cap = 0; }
+    need += need / 4; /* grow-only, with head room */
+    hipError_t e = hipHostMalloc(&c->pin, need, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return CRYO_E_NOMEM; }
+    if (e != hipSuccess) return fail(c, e, "hipHostMalloc");
+    c->pin_cap = need;
     return CRYO_OK;
 }
 
@@ -121,6 +138,10 @@ void cryo_codec_close(cryo_codec *c)
     if (c->d_size) (void)hipFree(c->d_size);
     if (c->d_status) (void)hipFree(c->d_status);
     if (c->d_ws) (void)hipFree(c->d_ws);
+    if (c->hb_src) (void)hipFree(c->hb_src);
+    if (c->hb_dst) (void)hipFree(c->hb_dst);
+    if (c->hb_meta) (void)hipFree(c->hb_meta);
+    if (c->pin) (void)hipHostFree(c->pin);
     for (int l = 0; l < 2; l++) {
         if (c->aux.lane[l]) { (void)hipStreamSynchronize(c->aux.lane[l]); (void)hipStreamDestroy(c->aux.lane[l]); }
         if (c->aux.join[l]) (void)hipEventDestroy(c->aux.join[l]);
@@ -321,6 +342,8 @@ int cryo_codec_decompress_block(cryo_codec *c, int method, const void *h_src, si
 }
 
 /* ---- K blocks, host buffers ---- */
+/* K blocks from / to host memory.  Device buffers and the pinned staging buffer live in the handle
+ * (grow-only); transfers are bulk: one H2D of the K blocks, one D2H of the K output slots. */
 int cryo_codec_compress_blocks(cryo_codec *c, int method, int param, const void *h_src, size_t block_size,
                                size_t n, void *h_dst, size_t dst_stride, uint32_t *h_out_size)
 {
@@ -329,41 +352,35 @@ int cryo_codec_compress_blocks(cryo_codec *c, int method, int param, const void 
     if (!h_src || !h_dst || !h_out_size) return CRYO_E_ARG;
     const size_t bound = cryo_codec_bound(method, block_size);
     if (dst_stride < bound) return CRYO_E_DSTSIZE;
-    const size_t dstride = (bound + 15) & ~(size_t)15;
-    uint8_t *d_src = nullptr, *d_dst = nullptr;
-    uint32_t *d_sz = nullptr;
-    int32_t *d_st = nullptr;
-    int rc = CRYO_OK;
-    hipError_t e = hipMalloc((void **)&d_src, n * block_size);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_dst, n * dstride);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_sz, n * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_st, n * sizeof(int32_t));
-    int32_t *h_st = (int32_t *)malloc(n * sizeof(int32_t));
-    if (e != hipSuccess || !h_st) rc = (e == hipSuccess || e == hipErrorOutOfMemory) ? CRYO_E_NOMEM : fail(c, e, "hipMalloc");
-    if (rc == CRYO_OK && (e = hipMemcpyAsync(d_src, h_src, n * block_size, hipMemcpyHostToDevice, c->stream)) != hipSuccess)
-        rc = fail(c, e, "hipMemcpyAsync");
-    if (rc == CRYO_OK)
-        rc = cryo_codec_compress_batch(c, method, param, d_src, block_size, (uint32_t)block_size, n, d_dst, dstride, d_sz, d_st);
-    if (rc == CRYO_OK) {
-        e = hipMemcpyAsync(h_out_size, d_sz, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_st, d_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(c, e, "compress_blocks D2H");
+    /* the device slots use the caller's stride, so the output goes back in one copy (a slot may be
+     * written beyond out_size[i], up to bound) */
+    const bool bulk = dst_stride <= bound + 4096;
+    const size_t dstride = bulk ? dst_stride : ((bound + 15) & ~(size_t)15);
+    int rc;
+    if ((rc = ensure(c, &c->hb_src, &c->hb_src_cap, n * block_size + 64)) != CRYO_OK) return rc;
+    if ((rc = ensure(c, &c->hb_dst, &c->hb_dst_cap, n * dstride + 64)) != CRYO_OK) return rc;
+    if ((rc = ensure(c, &c->hb_meta, &c->hb_meta_cap, n * 16 + 64)) != CRYO_OK) return rc;
+    uint32_t *d_sz = (uint32_t *)c->hb_meta;
+    int32_t *d_st = (int32_t *)(c->hb_meta + ((n * 4 + 15) & ~(size_t)15));
+    if ((rc = ensure_pinned(c, n * 4)) != CRYO_OK) return rc;
+    int32_t *h_st = (int32_t *)c->pin;
+    HIP_TRY(c, hipMemcpyAsync(c->hb_src, h_src, n * block_size, hipMemcpyHostToDevice, c->stream));
+    rc = cryo_codec_compress_batch(c, method, param, c->hb_src, block_size, (uint32_t)block_size, n, c->hb_dst, dstride, d_sz, d_st);
+    if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
+    HIP_TRY(c, hipMemcpyAsync(h_out_size, d_sz, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_st, d_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    if (bulk) HIP_TRY(c, hipMemcpyAsync(h_dst, c->hb_dst, (n - 1) * dstride + bound, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++) {
+        if (h_st[i] != CRYO_OK) return h_st[i];
+        if (h_out_size[i] == 0 || h_out_size[i] > bound) return CRYO_E_HIP;
     }
-    for (size_t i = 0; rc == CRYO_OK && i < n; i++) {
-        if (h_st[i] != CRYO_OK) { rc = h_st[i]; break; }
-        if (h_out_size[i] == 0 || h_out_size[i] > bound) { rc = CRYO_E_HIP; break; }
-        e = hipMemcpyAsync((uint8_t *)h_dst + i * dst_stride, d_dst + i * dstride, h_out_size[i], hipMemcpyDeviceToHost, c->stream);
-        if (e != hipSuccess) rc = fail(c, e, "compress_blocks D2H");
+    if (!bulk) {
+        for (size_t i = 0; i < n; i++)
+            HIP_TRY(c, hipMemcpyAsync((uint8_t *)h_dst + i * dst_stride, c->hb_dst + i * dstride, h_out_size[i], hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
-    if (rc == CRYO_OK && (e = hipStreamSynchronize(c->stream)) != hipSuccess) rc = fail(c, e, "hipStreamSynchronize");
-    (void)hipStreamSynchronize(c->stream);
-    free(h_st);
-    if (d_src) (void)hipFree(d_src);
-    if (d_dst) (void)hipFree(d_dst);
-    if (d_sz) (void)hipFree(d_sz);
-    if (d_st) (void)hipFree(d_st);
-    return rc;
+    return CRYO_OK;
 }
 
 int cryo_codec_decompress_blocks(cryo_codec *c, int method, const void *const *h_src, const uint32_t *h_src_size,
@@ -372,52 +389,37 @@ int cryo_codec_decompress_blocks(cryo_codec *c, int method, const void *const *h
     if (!c || !method_ok(method) || block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
     if (n == 0) return CRYO_OK;
     if (!h_src || !h_src_size || !h_dst || !h_status) return CRYO_E_ARG;
-    uint64_t *h_off = (uint64_t *)malloc(n * sizeof(uint64_t));
-    if (!h_off) return CRYO_E_NOMEM;
+    /* pinned staging: [offsets u64 x n][sizes u32 x n][compressed blocks, 16-byte aligned], sent in one copy */
+    const size_t o_off = 0, o_sz = n * 8, o_data = (n * 12 + 63) & ~(size_t)63;
     size_t total = 0;
     for (size_t i = 0; i < n; i++) {
-        h_off[i] = total;
+        if (h_src_size[i] != 0 && !h_src[i]) return CRYO_E_ARG;
         total += ((size_t)h_src_size[i] + 15) & ~(size_t)15;
     }
-    if (total == 0) total = 16;
-    uint8_t *d_src = nullptr, *d_dst = nullptr;
-    uint64_t *d_off = nullptr;
-    uint32_t *d_sz = nullptr;
-    int32_t *d_st = nullptr;
-    int rc = CRYO_OK;
-    hipError_t e = hipMalloc((void **)&d_src, total);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_dst, n * block_size);
-    if (e == hipSuccess) e = hipMalloc((void **)&d_off, n * sizeof(uint64_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_sz, n * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc((void **)&d_st, n * sizeof(int32_t));
-    if (e != hipSuccess) rc = (e == hipErrorOutOfMemory) ? CRYO_E_NOMEM : fail(c, e, "hipMalloc");
-    for (size_t i = 0; rc == CRYO_OK && i < n; i++) {
-        if (h_src_size[i] == 0) continue;
-        if (!h_src[i]) { rc = CRYO_E_ARG; break; }
-        e = hipMemcpyAsync(d_src + h_off[i], h_src[i], h_src_size[i], hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) rc = fail(c, e, "hipMemcpyAsync");
+    int rc;
+    if ((rc = ensure_pinned(c, o_data + total + 64)) != CRYO_OK) return rc;
+    if ((rc = ensure(c, &c->hb_src, &c->hb_src_cap, o_data + total + 64)) != CRYO_OK) return rc;
+    if ((rc = ensure(c, &c->hb_dst, &c->hb_dst_cap, n * block_size + 64)) != CRYO_OK) return rc;
+    if ((rc = ensure(c, &c->hb_meta, &c->hb_meta_cap, n * 16 + 64)) != CRYO_OK) return rc;
+    uint8_t *pin = (uint8_t *)c->pin;
+    uint64_t *p_off = (uint64_t *)(pin + o_off);
+    uint32_t *p_sz = (uint32_t *)(pin + o_sz);
+    size_t pos = 0;
+    for (size_t i = 0; i < n; i++) {
+        p_off[i] = o_data + pos;
+        p_sz[i] = h_src_size[i];
+        if (h_src_size[i]) memcpy(pin + o_data + pos, h_src[i], h_src_size[i]);
+        pos += ((size_t)h_src_size[i] + 15) & ~(size_t)15;
     }
-    if (rc == CRYO_OK) {
-        e = hipMemcpyAsync(d_off, h_off, n * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(d_sz, h_src_size, n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) rc = fail(c, e, "hipMemcpyAsync");
-    }
-    if (rc == CRYO_OK)
-        rc = cryo_codec_decompress_batch(c, method, d_src, d_off, d_sz, d_dst, block_size, (uint32_t)block_size, n, d_st);
-    if (rc == CRYO_OK) {
-        e = hipMemcpyAsync(h_status, d_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(h_dst, d_dst, n * block_size, hipMemcpyDeviceToHost, c->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) rc = fail(c, e, "decompress_blocks D2H");
-    }
-    (void)hipStreamSynchronize(c->stream);
-    free(h_off);
-    if (d_src) (void)hipFree(d_src);
-    if (d_dst) (void)hipFree(d_dst);
-    if (d_off) (void)hipFree(d_off);
-    if (d_sz) (void)hipFree(d_sz);
-    if (d_st) (void)hipFree(d_st);
-    return rc;
+    int32_t *d_st = (int32_t *)c->hb_meta;
+    HIP_TRY(c, hipMemcpyAsync(c->hb_src, pin, o_data + total, hipMemcpyHostToDevice, c->stream));
+    rc = cryo_codec_decompress_batch(c, method, c->hb_src, (const uint64_t *)(c->hb_src + o_off), (const uint32_t *)(c->hb_src + o_sz),
+                                     c->hb_dst, block_size, (uint32_t)block_size, n, d_st);
+    if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
+    HIP_TRY(c, hipMemcpyAsync(h_status, d_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_dst, c->hb_dst, n * block_size, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CRYO_OK;
 }
 
 /* ---- helpers ---- */

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the C host-buffer batch API (cryo_codec_{compress,decompress}_blocks: pageable host
+memory in, pageable host memory out, the calls host/staging.c and host/cache.c make), for DESIGN.md section 5.
+Not the bench metric."""
+import ctypes as C, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from pg_cryogen_amd import Codec, METHOD_LZ4, METHOD_ZSTD, bound
+
+def run(c, B, n, method, param, name):
+    L = c.L
+    d = c.alloc(n * B)
+    c.synth_batch(0, 0, n, B, 0, d)
+    c.sync()
+    raw = d.download()
+    d.free()
+    cap = bound(method, B)
+    comp = np.zeros(n * cap, np.uint8)
+    sizes = np.zeros(n, np.uint32)
+    out = np.zeros(n * B, np.uint8)
+    st = np.zeros(n, np.int32)
+    def enc():
+        rc = L.cryo_codec_compress_blocks(c.h, method, param, raw.ctypes.data, B, n, comp.ctypes.data, cap, sizes.ctypes.data)
+        assert rc == 0, rc
+    ptrs = (C.c_void_p * n)(*[comp.ctypes.data + i * cap for i in range(n)])
+    def dec():
+        rc = L.cryo_codec_decompress_blocks(c.h, method, ptrs, sizes.ctypes.data, n, out.ctypes.data, B, st.ctypes.data)
+        assert rc == 0, rc
+    enc(); dec()                       # warm up: buffers grow, pages get touched
+    t0 = time.perf_counter(); enc(); t1 = time.perf_counter(); dec(); t2 = time.perf_counter()
+    assert (st == 0).all() and np.array_equal(out, raw)
+    print("%s host API, %d x %d KiB: compress %.2f GB/s (%.2f ms), decompress %.2f GB/s (%.2f ms); uncompressed bytes, "
+          "PCIe and host copies included" % (name, n, B // 1024, n * B / (t1 - t0) / 1e9, (t1 - t0) * 1e3,
+                                             n * B / (t2 - t1) / 1e9, (t2 - t1) * 1e3))
+
+with Codec(0) as c:
+    for B, n in ((131072, 4096), (1 << 20, 16), (1 << 20, 512)):
+        run(c, B, n, METHOD_LZ4, 1, "lz4")
+        run(c, B, n, METHOD_ZSTD, 1, "zstd")
