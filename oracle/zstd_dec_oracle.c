@@ -22,6 +22,8 @@
  */
 #include "cryo_oracle.h"
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #define ZBLOCK_MAX (128u * 1024u)
 #define HUF_LOG_MAX 12
@@ -467,6 +469,7 @@ static long decode_block(zctx *z, const uint8_t *src, size_t n, uint8_t *dst, si
                 sm = em->next + br_read(&b, em->nbits);
                 so = eo->next + br_read(&b, eo->nbits);
             }
+            if (getenv("CRYO_ORACLE_TRACE")) fprintf(stderr, "seq out=%zu ll=%u ml=%u off=%u osym_extra=%u\n", out, llen, mlen, offset, (unsigned)eo->extra);
             /* execute */
             if (llen > lit_size - lit_pos) return ERR;
             if ((size_t)llen + mlen > cap - out) return ERR;

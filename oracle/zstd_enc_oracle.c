@@ -912,12 +912,10 @@ size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, siz
         const size_t bs = (n - ip < ZBLOCK_MAX) ? n - ip : ZBLOCK_MAX;
         const int last = (ip + bs == n);
         size_t csize = 0;
-        /* the window's low limit follows the block end (ZSTD_window_enforceMaxDist) */
-        {
-            const uint32_t end_idx = (uint32_t)(ip + bs) + 1;
-            const uint32_t max_dist = 1u << cp.wlog;
-            if (end_idx > max_dist && dict_limit < end_idx - max_dist) dict_limit = end_idx - max_dist;
-        }
+        /* libzstd 1.4.8's ZSTD_compress_frameChunk only calls ZSTD_checkDictValidity here (no dictionary: a
+         * no-op); window.dictLimit stays 1 for the whole frame and the window is enforced per block through
+         * ZSTD_getLowestPrefixIndex.  (Raising dict_limit like ZSTD_window_enforceMaxDist gives the same prefix
+         * index but clips repeat offsets too early: caught by tests/stress_gpu.py on a 1 MiB block.) */
         if (bs >= 3 + 3 + 1) {
             seqstore ss;
             uint32_t nrep[3];

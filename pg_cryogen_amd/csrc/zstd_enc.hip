@@ -1328,11 +1328,8 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
             const uint32_t bs = (n - ip < kZBlk) ? n - ip : kZBlk;
             const uint32_t last = (ip + bs == n) ? 1u : 0u;
             uint32_t csize = 0;
-            {
-                const uint32_t end_idx = ip + bs + 1u;
-                const uint32_t max_dist = 1u << wlog;
-                if (end_idx > max_dist && dict_limit < end_idx - max_dist) dict_limit = end_idx - max_dist;
-            }
+            /* window.dictLimit stays 1 for the whole frame (libzstd 1.4.8: ZSTD_compress_frameChunk only checks
+             * dictionary validity); the window is enforced per block through the lowest-prefix index */
             if (bs >= 7u) {
                 SeqStore ss;
                 ss.nseq = 0; ss.nlit = 0; ss.long_pos = 0; ss.long_kind = 0;

@@ -1,0 +1,95 @@
+"""Differential stress run on the GPU box (not collected by pytest: `python tests/stress_gpu.py [seconds] [seed]`).
+
+Random structured blocks (mixtures of text-like rows, runs, repeats at random distances, noise) at several
+block sizes; the device encoders must equal the stock liblz4 / libzstd byte for byte (all LZ4 accelerations,
+zstd levels -5..2), and the device decoders must reproduce the input from streams the stock libraries wrote at
+ANY level (zstd 1..19), through both zstd decode paths (fused for small batches, pipeline for large ones)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import oracle_lib
+from pg_cryogen_amd import Codec, METHOD_LZ4, METHOD_ZSTD
+
+
+def make_block(rng, n):
+    out = np.empty(n, np.uint8)
+    pos = 0
+    vocab = [rng.integers(32, 127, int(rng.integers(3, 40)), dtype=np.uint8) for _ in range(int(rng.integers(4, 60)))]
+    while pos < n:
+        kind = int(rng.integers(0, 7))
+        ln = int(min(n - pos, rng.integers(1, 4000) if kind != 3 else rng.integers(1, 40000)))
+        if kind == 0:      # noise
+            out[pos:pos + ln] = rng.integers(0, 256, ln, dtype=np.uint8)
+        elif kind == 1:    # run
+            out[pos:pos + ln] = rng.integers(0, 256)
+        elif kind == 2 and pos > 8:   # repeat from anywhere earlier (any distance, overlapping allowed)
+            src = int(rng.integers(0, pos))
+            for i in range(ln):
+                out[pos + i] = out[src + i]
+        elif kind == 3 and pos > 8:   # long non-overlapping repeat
+            src = int(rng.integers(0, pos))
+            ln = min(ln, pos - src)
+            out[pos:pos + ln] = out[src:src + ln]
+        elif kind == 4:    # words
+            i = 0
+            while i < ln:
+                w = vocab[int(rng.integers(0, len(vocab)))]
+                k = min(len(w), ln - i)
+                out[pos + i:pos + i + k] = w[:k]
+                i += k
+        elif kind == 5:    # low-entropy alphabet
+            out[pos:pos + ln] = rng.choice(np.frombuffer(b"0123456789abcdef", np.uint8), ln)
+        else:              # short period
+            p = rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8)
+            out[pos:pos + ln] = np.resize(p, ln)
+        pos += ln
+    return out
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    stock = oracle_lib.StockLibs()
+    assert stock.lz4 is not None and stock.zstd is not None, "stock libraries needed"
+    t_end = time.time() + budget
+    rounds = checks = 0
+    with Codec(0) as c:
+        while time.time() < t_end:
+            B = int(rng.choice([131072, 131072, 1 << 20, 65547, 70000, 20000, 300001]))
+            n = int(rng.choice([3, 20, 40]))
+            blocks = [make_block(rng, B) for _ in range(n)]
+            accel = int(rng.choice([1, 1, 2, 9, 50, 300]))
+            got = c.compress_blocks(METHOD_LZ4, accel, blocks)
+            for i in range(n):
+                exp = stock.lz4_compress(blocks[i], accel)
+                if not np.array_equal(got[i], exp):
+                    os.makedirs("gpurun_out", exist_ok=True)
+                    np.save("gpurun_out/fail_lz4_enc_block.npy", blocks[i])
+                    raise AssertionError(("lz4 enc", seed, rounds, B, accel, i, len(got[i]), len(exp)))
+            outs, st = c.decompress_blocks(METHOD_LZ4, got, B)
+            assert (st == 0).all() and all(np.array_equal(o, b) for o, b in zip(outs, blocks)), ("lz4 dec", seed, rounds, B)
+            checks += 2 * n
+            if B > 16384 and (B <= 131072 or B > 262144):
+                level = int(rng.choice([-5, -3, -1, 1, 1, 2]))
+                gotz = c.compress_blocks(METHOD_ZSTD, level, blocks)
+                for i in range(n):
+                    exp = stock.zstd_compress(blocks[i], level)
+                    if not np.array_equal(gotz[i], exp):
+                        os.makedirs("gpurun_out", exist_ok=True)
+                        np.save("gpurun_out/fail_zstd_enc_block.npy", blocks[i])
+                        np.save("gpurun_out/fail_zstd_enc_got.npy", gotz[i])
+                        raise AssertionError(("zstd enc", seed, rounds, B, level, i, len(gotz[i]), len(exp)))
+                checks += n
+            lvl = int(rng.choice([1, 3, 5, 9, 15, 19]))
+            zs = [stock.zstd_compress(b, lvl) for b in blocks[:8 if lvl > 9 else n]]
+            outs, st = c.decompress_blocks(METHOD_ZSTD, zs, B)
+            assert (st == 0).all() and all(np.array_equal(o, b) for o, b in zip(outs, blocks)), ("zstd dec", seed, rounds, B, lvl)
+            checks += len(zs)
+            rounds += 1
+    print("stress ok: seed %d, %d rounds, %d block checks in %.0f s" % (seed, rounds, checks, budget))
+
+
+if __name__ == "__main__":
+    main()

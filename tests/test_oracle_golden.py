@@ -288,3 +288,22 @@ def test_zstd_oracle_huffman_log12_crafted(oracle):
         if stock.zstd is not None:
             r2, out2 = stock.zstd_decompress(frame, len(lits))
             assert r2 == len(lits) and np.array_equal(out2, lits)
+
+
+def test_zstd_lz4_oracle_vs_stock_on_structured_blocks(oracle):
+    """structured random blocks (tests/stress_gpu.py's generator: repeats at any distance, runs, words, noise):
+    the oracle encoders equal the stock libraries.  1 MiB blocks exercise the window across zstd blocks (a
+    repeat offset larger than the distance to the window's low limit once slipped through the golden cells)."""
+    import stress_gpu
+    stock = oracle_lib.StockLibs()
+    if stock.zstd is None or stock.lz4 is None:
+        pytest.skip("stock liblz4/libzstd not present")
+    for seed, B in ((1, 1 << 20), (2, 1 << 20), (3, 300001), (4, 131072), (5, 1 << 20), (6, 70000)):
+        rng = np.random.default_rng(seed)
+        b = stress_gpu.make_block(rng, B)
+        for level in (-3, -1, 1, 2):
+            assert np.array_equal(oracle.zstd_compress(b, level), stock.zstd_compress(b, level)), (seed, B, level)
+        for accel in (1, 9):
+            assert np.array_equal(oracle.lz4_compress(b, accel), stock.lz4_compress(b, accel)), (seed, B, accel)
+        r, out = oracle.zstd_decompress(stock.zstd_compress(b, 3), B)
+        assert r == B and np.array_equal(out, b)
