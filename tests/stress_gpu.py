@@ -1,4 +1,5 @@
-"""Differential stress run on the GPU box (not collected by pytest: `python tests/stress_gpu.py [seconds] [seed]`).
+"""Differential stress run on the GPU box (not collected by pytest: `python tests/stress_gpu.py [seconds] [seed]`,
+`python tests/stress_gpu.py fuzz [seconds] [seed]` for malformed streams).
 
 Random structured blocks (mixtures of text-like rows, runs, repeats at random distances, noise) at several
 block sizes; the device encoders must equal the stock liblz4 / libzstd byte for byte (all LZ4 accelerations,
@@ -47,7 +48,66 @@ def make_block(rng, n):
     return out
 
 
+def mutate(rng, c):
+    c = c.copy()
+    for _ in range(int(rng.integers(1, 4))):
+        k = int(rng.integers(0, 6))
+        if len(c) < 8:
+            break
+        p = int(rng.integers(0, len(c)))
+        if k == 0:
+            c[p] ^= 1 << int(rng.integers(0, 8))
+        elif k == 1:
+            c[p] = rng.integers(0, 256)
+        elif k == 2:
+            c = c[:max(1, p)]
+        elif k == 3:
+            c = np.concatenate([c[:p], rng.integers(0, 256, int(rng.integers(1, 9)), dtype=np.uint8), c[p:]])
+        elif k == 4:
+            q = min(len(c), p + int(rng.integers(1, 64)))
+            c = np.concatenate([c[:p], c[q:]])
+        else:   # early bytes: headers
+            p = int(rng.integers(0, min(len(c), 24)))
+            c[p] = rng.integers(0, 256)
+    return c
+
+
+def fuzz(budget, seed):
+    """malformed streams: the device decoders' verdict and bytes equal the oracle's (which is pinned to the
+    libraries by tests/test_oracle_golden.py), through the fused kernel (3 per call) and the pipeline (40)"""
+    rng = np.random.default_rng(seed)
+    stock = oracle_lib.StockLibs()
+    ora = oracle_lib.Oracle()
+    t_end = time.time() + budget
+    rounds = bad_streams = 0
+    with Codec(0) as c:
+        while time.time() < t_end:
+            B = int(rng.choice([4096, 20000, 131072, 300001]))
+            base = [make_block(rng, B) for _ in range(4)]
+            for method, name in ((METHOD_ZSTD, "zstd"), (METHOD_LZ4, "lz4")):
+                valid = []
+                for b in base:
+                    valid.append(stock.zstd_compress(b, int(rng.choice([-3, 1, 3, 9]))) if method == METHOD_ZSTD
+                                 else stock.lz4_compress(b, int(rng.choice([1, 20]))))
+                for n in (3, 40):
+                    items = [mutate(rng, valid[int(rng.integers(0, 4))]) if rng.random() < 0.85 else valid[int(rng.integers(0, 4))]
+                             for _ in range(n)]
+                    outs, st = c.decompress_blocks(method, items, B)
+                    for i, m in enumerate(items):
+                        r, exp = (ora.zstd_decompress(m, B, fill=0xA5) if method == METHOD_ZSTD else ora.lz4_decompress(m, B, fill=0xA5))
+                        ok = (r == B)
+                        if ok != (st[i] == 0) or (ok and not np.array_equal(outs[i], exp)):
+                            os.makedirs("gpurun_out", exist_ok=True)
+                            np.save("gpurun_out/fail_fuzz_%s.npy" % name, m)
+                            raise AssertionError(("fuzz", name, seed, rounds, B, n, i, int(r), int(st[i])))
+                        bad_streams += 0 if ok else 1
+            rounds += 1
+    print("fuzz ok: seed %d, %d rounds, %d rejected streams among them, %.0f s" % (seed, rounds, bad_streams, budget))
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "fuzz":
+        return fuzz(float(sys.argv[2]) if len(sys.argv) > 2 else 60.0, int(sys.argv[3]) if len(sys.argv) > 3 else 1)
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
