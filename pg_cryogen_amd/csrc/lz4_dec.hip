@@ -116,7 +116,6 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
 {
     static_assert(R >= 4096, "ring must hold kTMax new bytes plus the near window");
     static_assert(NG * 64u <= kWMax, "window too large");
-    constexpr uint32_t kNear = R - kTMax - 64u;
     constexpr uint32_t W = NG * 64u;
     constexpr uint32_t G1 = NG + 4u, G2 = NG + 2u; /* groups of 64 in the d1 / d2 domains */
     const uint32_t lane = w.lane;
