@@ -474,9 +474,12 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
                     w.op += n;
                     rem -= n;
                 }
+                const bool pow2_period = off <= 16u && (off & (off - 1u)) == 0u; /* the period divides 16 */
                 while (rem) {
                     w.flush();
-                    const uint32_t n = rem < 64u ? rem : 64u;
+                    if (pow2_period && rem >= 2u * R && wave_stream_pattern(w, rem, false)) continue; /* long run: lz_common.h */
+                    uint32_t n = rem < 64u ? rem : 64u;
+                    if (pow2_period && rem >= 3u * R) { const uint32_t to = kChunk - (w.op & (kChunk - 1u)); n = n < to ? n : to; }
                     const uint8_t x = w.ring[(w.op - eff + lane) & (R - 1)];
                     if (lane < n) w.ring[(w.op + lane) & (R - 1)] = x;
                     w.op += n;

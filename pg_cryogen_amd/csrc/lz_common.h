@@ -153,6 +153,30 @@ __device__ inline uint32_t wave_copy_literals(Wave<R> &w, uint32_t p, uint32_t l
 }
 
 /*
+ * Long runs.  At a 1 KiB boundary with everything flushed, when the output continues a pattern whose
+ * period divides 16 (run of one byte, 2/4/8/16-byte records -- the zero gap of a cryo block is the common
+ * case) or is all zero (`zero`), the 16 bytes before op are the pattern for every aligned
+ * 16-byte slot to come: fill the ring with it once and stream whole 1 KiB chunks straight to the output,
+ * 16 bytes per lane and one store per KiB instead of 16 byte-wise LDS round trips.  The ring stays valid
+ * (every position holds pattern[x mod 16]).  Returns false when the conditions do not hold (yet).
+ */
+template <uint32_t R>
+__device__ inline bool wave_stream_pattern(Wave<R> &w, uint32_t &rem, bool zero)
+{
+    if (rem < 2u * R || w.flushed != w.op || !w.dst_aligned || (!zero && w.op < 16u)) return false;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (!zero) v = *reinterpret_cast<const uint4 *>(w.ring + ((w.op - 16u) & (R - 1)));
+#pragma unroll
+    for (uint32_t k = 0; k < R / kChunk; k++) *reinterpret_cast<uint4 *>(w.ring + ((k * kChunk + w.lane * 16u) & (R - 1))) = v;
+    const uint32_t nch = rem / kChunk;
+    for (uint32_t c = 0; c < nch; c++) *reinterpret_cast<uint4 *>(w.dst + w.op + c * kChunk + w.lane * 16u) = v;
+    w.op += nch * kChunk;
+    w.flushed = w.op;
+    rem -= nch * kChunk;
+    return true;
+}
+
+/*
  * Copy a match of `ml` bytes at distance `off` (1 <= off <= w.op).  Near sources come from
  * the LDS ring (overlapping matches are periodic: first 64 bytes via lane % off, later pieces
  * via the smallest multiple of the period >= 64); far sources (off > R - 128) were already
@@ -167,6 +191,7 @@ __device__ inline void wave_copy_match(Wave<R> &w, uint32_t off, uint32_t ml)
     if (off == 0u) {
         while (rem) {
             w.flush();
+            if (wave_stream_pattern(w, rem, true)) continue;
             const uint32_t n = rem < 64u ? rem : 64u;
             if (lane < n) w.ring[(w.op + lane) & (R - 1)] = 0;
             w.op += n;
@@ -191,9 +216,12 @@ __device__ inline void wave_copy_match(Wave<R> &w, uint32_t off, uint32_t ml)
             w.op += n;
             rem -= n;
         }
+        const bool pow2_period = off <= 16u && (off & (off - 1u)) == 0u; /* the period divides 16 */
         while (rem) {
             w.flush();
-            const uint32_t n = rem < 64u ? rem : 64u;
+            if (pow2_period && wave_stream_pattern(w, rem, false)) continue;
+            uint32_t n = rem < 64u ? rem : 64u;
+            if (pow2_period && rem >= 3u * R) { const uint32_t to = kChunk - (w.op & (kChunk - 1u)); n = n < to ? n : to; } /* land on the 1 KiB boundary */
             const uint8_t x = w.ring[(w.op - eff + lane) & (R - 1)];
             if (lane < n) w.ring[(w.op + lane) & (R - 1)] = x;
             w.op += n;
@@ -202,6 +230,15 @@ __device__ inline void wave_copy_match(Wave<R> &w, uint32_t off, uint32_t ml)
     } else {
         while (rem) {
             w.flush();
+            if (rem >= kChunk && w.flushed == w.op && w.dst_aligned && off >= kChunk) {
+                /* a whole flushed 1 KiB chunk from the output buffer: 16 bytes per lane, ring kept current */
+                uint4 v;
+                __builtin_memcpy(&v, w.dst + w.op - off + lane * 16u, 16);
+                *reinterpret_cast<uint4 *>(w.ring + ((w.op + lane * 16u) & (R - 1))) = v;
+                w.op += kChunk;
+                rem -= kChunk;
+                continue;
+            }
             const uint32_t n = rem < 64u ? rem : 64u;
             uint8_t x = 0;
             if (lane < n) x = w.dst[w.op - off + lane];

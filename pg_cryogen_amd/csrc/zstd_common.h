@@ -504,6 +504,7 @@ __device__ inline void wave_fill(Wave<R> &w, uint32_t byte, uint32_t len)
     uint32_t rem = len;
     while (rem) {
         w.flush();
+        if (len - rem >= 16u && wave_stream_pattern(w, rem, false)) continue; /* once 16 bytes of the run are out */
         const uint32_t n = rem < 64u ? rem : 64u;
         if (w.lane < n) w.ring[(w.op + w.lane) & (R - 1)] = (uint8_t)byte;
         w.op += n;
