@@ -389,9 +389,11 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
             uint32_t p = lp + n0;
             while (rem) {
                 w.flush();
+                if (wave_stream_literals(w, p, rem)) continue; /* long run at a 1 KiB boundary: lz_common.h */
                 w.need(p);
                 const uint32_t x = w.window(p);
-                const uint32_t n = rem < 64u ? rem : 64u;
+                uint32_t n = rem < 64u ? rem : 64u;
+                if (rem >= 3u * R) { const uint32_t to = kChunk - (w.op & (kChunk - 1u)); n = n < to ? n : to; } /* land on the boundary */
                 if (lane < n) w.ring[(w.op + lane) & (R - 1)] = (uint8_t)x;
                 w.op += n;
                 p += n;

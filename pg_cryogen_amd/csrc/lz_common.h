@@ -132,6 +132,32 @@ __device__ inline uint32_t lane_mod(uint32_t lane, uint32_t m)
 
 
 /*
+ * Long literal runs (incompressible blocks are one literal run).  At a 1 KiB boundary with everything
+ * flushed, whole chunks go from the input stream to the output 16 bytes per lane, global to global; only the
+ * last R bytes also pass through the output ring (later matches may reach them there).  The input ring is
+ * re-synchronised behind the run.  Returns false when the conditions do not hold (yet).
+ */
+template <uint32_t R>
+__device__ inline bool wave_stream_literals(Wave<R> &w, uint32_t &p, uint32_t &rem)
+{
+    if (rem < 2u * R || w.flushed != w.op || !w.dst_aligned) return false;
+    const uint32_t nch = rem / kChunk;
+    for (uint32_t c = 0; c < nch; c++) {
+        uint4 v;
+        __builtin_memcpy(&v, w.abase + p + c * kChunk + w.lane * 16u, 16);
+        *reinterpret_cast<uint4 *>(w.dst + w.op + c * kChunk + w.lane * 16u) = v;
+        if (c + R / kChunk >= nch) *reinterpret_cast<uint4 *>(w.ring + ((w.op + c * kChunk + w.lane * 16u) & (R - 1))) = v;
+    }
+    w.op += nch * kChunk;
+    w.flushed = w.op;
+    p += nch * kChunk;
+    rem -= nch * kChunk;
+    w.in_hi = p & ~(kInChunk - 1u); /* nothing before p is looked at again */
+    w.prefetch();
+    return true;
+}
+
+/*
  * Copy `ll` literal bytes that start at virtual position p of the staged stream into the
  * output ring (64 bytes per step).  Returns the position after the run.
  */
@@ -141,9 +167,11 @@ __device__ inline uint32_t wave_copy_literals(Wave<R> &w, uint32_t p, uint32_t l
     uint32_t rem = ll;
     while (rem) {
         w.flush();
+        if (wave_stream_literals(w, p, rem)) continue;
         w.need(p);
         const uint32_t x = w.window(p);
-        const uint32_t n = rem < 64u ? rem : 64u;
+        uint32_t n = rem < 64u ? rem : 64u;
+        if (rem >= 3u * R) { const uint32_t to = kChunk - (w.op & (kChunk - 1u)); n = n < to ? n : to; } /* land on the 1 KiB boundary */
         if (w.lane < n) w.ring[(w.op + w.lane) & (R - 1)] = (uint8_t)x;
         w.op += n;
         p += n;
