@@ -400,9 +400,11 @@ __device__ inline void batch_copy(Wave<R> &w, const uint8_t *__restrict__ in, un
                 uint32_t x = *sp[i];
                 if (f & 2u) x = xfar[i];
                 bool pend = (f & 5u) == 5u;
-                if ((f & 5u) == 1u) *dstp = (uint8_t)x;
+                /* stored by every lane: a pending lane's byte is rewritten below, and a lane past the end of the
+                 * batch lands on ring positions that are older than the near window (R - kTMax - 64 back) */
+                *dstp = (uint8_t)x;
                 unsigned long long donem = __ballot(!pend);
-                while (__ballot(pend) != 0ull) {
+                while (donem != ~0ull) {
                     st.rounds++;
                     const bool rdy = pend && ((donem >> ((lane - (f >> 8)) & 63u)) & 1ull);
                     if (rdy) *dstp = *sp[i];
