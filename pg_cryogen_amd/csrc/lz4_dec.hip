@@ -175,7 +175,11 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     {
         uint32_t b[NG];
 #pragma unroll
-        for (uint32_t g = 0; g < NG; g++) { const uint32_t j = g * 64u + lane + a4[g]; b[g] = j < W ? L.d4[j] : 0u; }
+        for (uint32_t g = 0; g < NG; g++) { /* clamped index + select: no exec-mask branch per group */
+            const uint32_t j = g * 64u + lane + a4[g];
+            const uint32_t v = L.d4[j < W ? j : W - 1u];
+            b[g] = j < W ? v : 0u;
+        }
 #pragma unroll
         for (uint32_t g = 0; g < NG; g++) {
             const uint32_t d8 = (a4[g] != 0u && b[g] != 0u) ? a4[g] + b[g] : 0u;

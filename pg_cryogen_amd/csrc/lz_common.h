@@ -337,8 +337,7 @@ __device__ inline void batch_copy(Wave<R> &w, const uint8_t *__restrict__ in, un
     static_assert(kNCh == 16, "chunk-count scan uses one DPP row");
     basev = scan16_incl(basev) - basev; /* exclusive: starts before this chunk */
     const uint32_t op0 = w.op;
-    st.batches++;
-    st.batch_seqs += nseq;
+    const ptrdiff_t in_delta = in - w.ring; /* both live in the workgroup's LDS block */
 
     /* Two halves of 8 chunks (keeps the register arrays at 8 entries).  Per half:
      * pass A: bytes that do not depend on this batch: literals (input ring -> ring) and far
@@ -364,9 +363,11 @@ __device__ inline void batch_copy(Wave<R> &w, const uint8_t *__restrict__ in, un
                 const uint32_t c = h * kHalf + i;
                 const uint32_t wlo = lane_get(bm_lo, c), whi = lane_get(bm_hi, c);
                 const uint32_t bc = lane_get(basev, c);
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi(whi, __builtin_amdgcn_mbcnt_lo(wlo, 0u));
-                const uint32_t own = (uint32_t)(((((unsigned long long)whi << 32) | wlo) >> lane) & 1ull);
-                idx[i] = (bc + below + own - 1u) & 63u;
+                /* starts at positions <= lane: the uniform bitmap shifted right by one (scalar) counts positions
+                 * 1..lane with mbcnt, bit 0 joins the scalar base */
+                const unsigned long long wsh = (((unsigned long long)whi << 32) | wlo) >> 1;
+                const uint32_t incl = __builtin_amdgcn_mbcnt_hi((uint32_t)(wsh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wsh, 0u));
+                idx[i] = (incl + (bc + (wlo & 1u) - 1u)) & 63u;
             }
 #pragma unroll
             for (uint32_t i = 0; i < kHalf; i++) m[i] = meta[idx[i]];
@@ -379,7 +380,9 @@ __device__ inline void batch_copy(Wave<R> &w, const uint8_t *__restrict__ in, un
                 const bool isLit = qo < (mlo & 0x7ffu);
                 const bool isFar = !isLit && moff >= kNear;
                 const bool inch = !isLit && moff <= lane; /* near source inside this very chunk */
-                sp[i] = isLit ? &in[(qo + mhi) & kInMask] : &w.ring[(op0 + qo - moff) & (R - 1)];
+                /* one base + selected offset (v_cndmask) instead of two pointer arms (exec-mask branches) */
+                const uint32_t ia = (uint32_t)in_delta + ((qo + mhi) & kInMask), ra = (op0 + qo - moff) & (R - 1);
+                sp[i] = w.ring + (isLit ? ia : ra);
                 fl[i] = (active ? 1u : 0u) | (isFar ? 2u : 0u) | (inch ? 4u : 0u) | (moff << 8);
                 /* unconditional load: lanes without a far byte read the first byte of the block */
                 const uint32_t goff = (active && isFar && !(st.ablate & 1u)) ? op0 + qo - moff : 0u;
