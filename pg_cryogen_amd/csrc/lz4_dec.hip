@@ -170,56 +170,24 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
 #pragma unroll
         for (uint32_t g = 0; g < NG; g++) L.d4[g * 64u + lane] = (uint8_t)a4[g];
     }
-    /* d8 for window offsets whose 8-token span stays inside the d4 domain (else 0 = "stop"; also 0
-     * when the span exceeds 255 bytes).  d2 is dead once d4 exists, so d8 reuses its storage. */
-    {
-        uint32_t b[NG];
-#pragma unroll
-        for (uint32_t g = 0; g < NG; g++) { /* clamped index + select: no exec-mask branch per group */
-            const uint32_t j = g * 64u + lane + a4[g];
-            const uint32_t v = L.d4[j < W ? j : W - 1u];
-            b[g] = j < W ? v : 0u;
-        }
-#pragma unroll
-        for (uint32_t g = 0; g < NG; g++) {
-            const uint32_t d8 = (a4[g] != 0u && b[g] != 0u) ? a4[g] + b[g] : 0u;
-            L.d2[g * 64u + lane] = (uint8_t)(d8 > 255u ? 0u : d8);
-        }
-    }
     stamp(st, 1);
-    /* ---- chase: start of every 4th sequence into lanes 0,4,8,... ---- */
+    /* ---- chase: start of every 4th sequence into lanes 0,4,8,... ----
+     * 16 serial hops over d4 (wave-uniform LDS reads).  A d8 table would halve the hops but costs a fourth
+     * table pass over the whole window; the kernel is bound by instruction issue, the hops only by latency,
+     * which the other waves of the SIMD cover. */
     uint32_t sl = 0;   /* window offset of this lane's sequence */
     uint32_t ngrp = 0; /* groups of 4 sequences found */
     {
-        /* starts of sequences 0,8,16,..,56 by serial hops over d8 (0 = fewer than 8 simple tokens left) */
-        uint32_t s8[8];
-        uint32_t n8 = 0;
-        {
-            uint32_t s0 = 0;
+        uint32_t s4 = 0, s0 = 0;
+        const uint32_t a = lane >> 2;
 #pragma unroll
-            for (uint32_t k = 0; k < 8u; k++) {
-                s8[k] = s0;
-                if (n8 == k && s0 < W) {
-                    const uint32_t dd = uni(L.d2[s0]);
-                    if (dd != 0u) { s0 += dd; n8 = k + 1u; }
-                }
+        for (uint32_t k = 0; k < 16u; k++) {
+            if (a == k) s4 = s0;
+            if (ngrp == k && s0 < W) {
+                const uint32_t dd = uni(L.d4[s0]);
+                if (dd != 0u) { s0 += dd; ngrp = k + 1u; }
             }
         }
-        /* lanes 4a..4a+3 (a = 0..15): start of 4-group a = start of 8-group a>>1, plus one d4 hop for odd a;
-         * a 4-group is usable while its own d4 is non-zero and it starts inside the window */
-        const uint32_t a = lane >> 2, g8 = a >> 1;
-        uint32_t s4 = s8[0];
-#pragma unroll
-        for (uint32_t k = 1; k < 8u; k++) if (g8 == k) s4 = s8[k];
-        bool alive = g8 <= n8;
-        {
-            const uint32_t dd = (alive && s4 < W) ? L.d4[s4] : 0u;
-            if (a & 1u) { alive = alive && dd != 0u; s4 += dd; }
-        }
-        const uint32_t dlast = (alive && s4 < W) ? L.d4[s4] : 0u;
-        alive = alive && dlast != 0u;
-        const unsigned long long dead = __ballot(!alive);
-        ngrp = dead ? (ctz64(dead) >> 2) : 16u;
         sl = s4;
     }
     if (ngrp == 0u) return 0;
