@@ -86,6 +86,11 @@ constexpr uint32_t kDMax = 63;    /* longest token-to-token distance the batch h
  * and hoists the next group's LDS reads above it (otherwise every group costs a full LDS
  * round trip and the batch is latency bound). */
 template <uint32_t R>
+/* Every table pass is "all lanes store, then lanes read what OTHER lanes stored".  The hardware keeps a
+ * wave's LDS operations in order; this keeps the compiler from moving the reads above the stores (seen
+ * with the uniform-address reads of the chase: stale d4 entries, wrong sequence starts). */
+#define LDS_TABLE_FENCE() asm volatile("" ::: "memory")
+
 struct WaveLds {
     uint8_t *__restrict__ ring;            /* R        output ring                       */
     uint8_t *__restrict__ in;              /* kInRing  input ring                        */
@@ -128,6 +133,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     stamp(st, 7);
     /* stage the window (no refill happens while the batch runs) */
     while (w.in_hi < vend && w.in_hi < vp + W + 256u + 72u) w.refill();
+    LDS_TABLE_FENCE(); /* the window below is read by other lanes than the ones that staged it */
     stamp(st, 0);
 
     /* ---- phase 1: d1 for every window offset, then d2, d4 ---- */
@@ -151,6 +157,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
 #pragma unroll
         for (uint32_t g = 0; g < G1; g++) L.d1[g * 64u + lane] = (uint8_t)a1[g];
     }
+    LDS_TABLE_FENCE();
     {
         uint32_t b[G2];
 #pragma unroll
@@ -160,6 +167,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
 #pragma unroll
         for (uint32_t g = 0; g < G2; g++) L.d2[g * 64u + lane] = (uint8_t)a2[g];
     }
+    LDS_TABLE_FENCE();
     uint32_t a4[NG];
     {
         uint32_t b[NG];
@@ -170,6 +178,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
 #pragma unroll
         for (uint32_t g = 0; g < NG; g++) L.d4[g * 64u + lane] = (uint8_t)a4[g];
     }
+    LDS_TABLE_FENCE();
     stamp(st, 1);
     /* ---- chase: start of every 4th sequence into lanes 0,4,8,... ----
      * 16 serial hops over d4 (wave-uniform LDS reads).  A d8 table would halve the hops but costs a fourth

@@ -332,6 +332,7 @@ __device__ inline void batch_copy(Wave<R> &w, const uint8_t *__restrict__ in, un
                        ((unsigned long long)lit_rel << 32);
         atomicOr(&bm[ostart >> 5], 1u << (ostart & 31u));
     }
+    asm volatile("" ::: "memory"); /* meta / bm are read below by other lanes than the ones that wrote them */
     const uint32_t bm_lo = bm[(lane & (kNCh - 1u)) * 2u], bm_hi = bm[(lane & (kNCh - 1u)) * 2u + 1u];
     uint32_t basev = (uint32_t)(__popc(bm_lo) + __popc(bm_hi)); /* lanes 0..kNCh-1: starts in chunk `lane` */
     static_assert(kNCh == 16, "chunk-count scan uses one DPP row");
