@@ -79,6 +79,7 @@ namespace {
 constexpr uint32_t kWMax = 1024;  /* sequences of a batch start at window offsets < W <= kWMax */
 constexpr uint32_t kD1N = kWMax + 256; /* d1 domain [0, W+256): d2 lookups reach < W+128+63     */
 constexpr uint32_t kD2N = kWMax + 128; /* d2 domain [0, W+128): d4 lookups reach < W+126        */
+constexpr uint32_t kDBad = 255;   /* table value for "no simple token (run) starts here"                */
 constexpr uint32_t kDMax = 63;    /* longest token-to-token distance the batch handles          */
 
 /* Per-wave LDS regions.  They are separate __shared__ objects on purpose: the compiler can
@@ -151,7 +152,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
             const uint32_t hi = t[g] >> 4;
             uint32_t d = hi + 3u + ((t[g] & 15u) == 15u ? 1u : 0u);
             if (hi == 15u) d += e1[g] + 1u;
-            if (d > kDMax) d = 0; /* 0 marks "not batchable from here" */
+            if (d > kDMax) d = kDBad; /* "not batchable from here": saturates every sum it enters */
             a1[g] = d;
         }
 #pragma unroll
@@ -161,9 +162,9 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     {
         uint32_t b[G2];
 #pragma unroll
-        for (uint32_t g = 0; g < G2; g++) b[g] = L.d1[g * 64u + lane + a1[g]];
+        for (uint32_t g = 0; g < G2; g++) b[g] = L.d1[g * 64u + lane + (a1[g] & 127u)];
 #pragma unroll
-        for (uint32_t g = 0; g < G2; g++) a2[g] = (a1[g] != 0u && b[g] != 0u) ? a1[g] + b[g] : 0u;
+        for (uint32_t g = 0; g < G2; g++) { const uint32_t v = a1[g] + b[g]; a2[g] = v < kDBad ? v : kDBad; } /* valid <= 126 */
 #pragma unroll
         for (uint32_t g = 0; g < G2; g++) L.d2[g * 64u + lane] = (uint8_t)a2[g];
     }
@@ -172,9 +173,9 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     {
         uint32_t b[NG];
 #pragma unroll
-        for (uint32_t g = 0; g < NG; g++) b[g] = L.d2[g * 64u + lane + a2[g]];
+        for (uint32_t g = 0; g < NG; g++) b[g] = L.d2[g * 64u + lane + (a2[g] & 127u)];
 #pragma unroll
-        for (uint32_t g = 0; g < NG; g++) a4[g] = (a2[g] != 0u && b[g] != 0u) ? a2[g] + b[g] : 0u;
+        for (uint32_t g = 0; g < NG; g++) { const uint32_t v = a2[g] + b[g]; a4[g] = v < kDBad ? v : kDBad; } /* valid <= 252 */
 #pragma unroll
         for (uint32_t g = 0; g < NG; g++) L.d4[g * 64u + lane] = (uint8_t)a4[g];
     }
@@ -194,7 +195,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
             if (a == k) s4 = s0;
             if (ngrp == k && s0 < W) {
                 const uint32_t dd = uni(L.d4[s0]);
-                if (dd != 0u) { s0 += dd; ngrp = k + 1u; }
+                if (dd != kDBad) { s0 += dd; ngrp = k + 1u; }
             }
         }
         sl = s4;
@@ -205,7 +206,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
 #pragma unroll
     for (uint32_t hp = 0; hp < 3u; hp++) {
         const uint32_t dd = L.d1[sl];
-        if ((lane & 3u) > hp) sl += dd;
+        if ((lane & 3u) > hp && lane < ncand) sl += dd; /* lanes past the last usable group stay put */
     }
 
     stamp(st, 2);
