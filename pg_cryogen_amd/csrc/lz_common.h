@@ -354,7 +354,8 @@ __device__ inline void batch_copy(Wave<R> &w, const uint8_t *__restrict__ in, un
         /* pass A: per output byte, find its sequence, classify it (literal / near match / far match)
          * and compute the LDS address of its source once; far bytes are requested from HBM now */
         const uint8_t *sp[kHalf]; /* LDS source of the byte (input ring or output ring) */
-        uint32_t fl[kHalf];       /* bit0 active, bit1 far, bit2 source inside this chunk, bits 8.. offset */
+        uint32_t moffv[kHalf];    /* match offset (the source lane of a byte whose source is inside its own chunk) */
+        bool farv[kHalf], pendv[kHalf]; /* lane masks, kept in scalar registers: far byte / source inside this chunk */
         uint32_t xfar[kHalf];
         {
             uint32_t idx[kHalf];
@@ -384,7 +385,9 @@ __device__ inline void batch_copy(Wave<R> &w, const uint8_t *__restrict__ in, un
                 /* one base + selected offset (v_cndmask) instead of two pointer arms (exec-mask branches) */
                 const uint32_t ia = (uint32_t)in_delta + ((qo + mhi) & kInMask), ra = (op0 + qo - moff) & (R - 1);
                 sp[i] = w.ring + (isLit ? ia : ra);
-                fl[i] = (active ? 1u : 0u) | (isFar ? 2u : 0u) | (inch ? 4u : 0u) | (moff << 8);
+                moffv[i] = moff;
+                farv[i] = isFar;
+                pendv[i] = active && inch;
                 /* unconditional load: lanes without a far byte read the first byte of the block */
                 const uint32_t goff = (active && isFar && !(st.ablate & 1u)) ? op0 + qo - moff : 0u;
                 xfar[i] = w.dst[goff];
@@ -399,18 +402,17 @@ __device__ inline void batch_copy(Wave<R> &w, const uint8_t *__restrict__ in, un
             const uint32_t c = h * kHalf + i;
             if (c * 64u < T && !(st.ablate & 2u)) {
                 st.chunks++;
-                const uint32_t f = fl[i];
                 uint8_t *dstp = &w.ring[(op0 + c * 64u + lane) & (R - 1)];
                 uint32_t x = *sp[i];
-                if (f & 2u) x = xfar[i];
-                bool pend = (f & 5u) == 5u;
+                if (farv[i]) x = xfar[i];
+                bool pend = pendv[i];
                 /* stored by every lane: a pending lane's byte is rewritten below, and a lane past the end of the
                  * batch lands on ring positions that are older than the near window (R - kTMax - 64 back) */
                 *dstp = (uint8_t)x;
                 unsigned long long donem = __ballot(!pend);
                 while (donem != ~0ull) {
                     st.rounds++;
-                    const bool rdy = pend && ((donem >> ((lane - (f >> 8)) & 63u)) & 1ull);
+                    const bool rdy = pend && ((donem >> ((lane - moffv[i]) & 63u)) & 1ull);
                     if (rdy) *dstp = *sp[i];
                     donem |= __ballot(rdy);
                     pend = pend && !rdy;
