@@ -389,9 +389,10 @@ __device__ int fse_decode_weights(LT &L, const uint8_t *src, uint32_t n)
     return out;
 }
 
-/* Huffman tree description -> L.huf.  Returns bytes consumed or -1; *hlog = table log. */
+/* Huffman tree description -> table (LDS or global; symbol | nbits << 8).  Returns bytes consumed or -1;
+ * *hlog = table log. */
 template <class LT>
-__device__ int huf_read_table(LT &L, const uint8_t *src, uint32_t n, int *hlog, uint32_t lane)
+__device__ int huf_read_table(LT &L, uint16_t *table, const uint8_t *src, uint32_t n, int *hlog, uint32_t lane)
 {
     if (n < 1u) return -1;
     const uint32_t h0 = uni(src[0]);
@@ -451,7 +452,7 @@ __device__ int huf_read_table(LT &L, const uint8_t *src, uint32_t n, int *hlog, 
         for (int r = 1; r <= kHufLogMax; r++) if (wv == (uint32_t)r) { st = start[r]; start[r] += (1u << wv) >> 1; }
         const uint32_t len = (1u << wv) >> 1;
         const uint16_t ent = (uint16_t)((uint32_t)i | (((uint32_t)log + 1u - wv) << 8));
-        for (uint32_t u = lane; u < len; u += 64u) L.huf[st + u] = ent;
+        for (uint32_t u = lane; u < len; u += 64u) table[st + u] = ent;
     }
     __builtin_amdgcn_wave_barrier();
     *hlog = log;

@@ -91,7 +91,6 @@ struct ZPipe {
 };
 
 struct PlanLds {
-    uint16_t huf[1 << kHufLogMax];
     uint32_t ll[512], ml[512], of[256];
     int16_t norm[256];
     uint16_t nxt[256];
@@ -158,13 +157,12 @@ __device__ bool plan_block(PlanLds &L, const ZPipe &P, PlanState &ps, const uint
         if (type == 3u) { if (!ps.huf_valid) return false; }
         else {
             int hlog = 0;
-            const int t = huf_read_table(L, p, left, &hlog, lane);
+            /* the decoding table is filled straight into the workspace (8 KiB less LDS: twice the workgroups per CU) */
+            const int t = huf_read_table(L, P.huf + ((uint64_t)f * P.nbmax + k) * kHufTblWords, p, left, &hlog, lane);
             if (t < 0) return false;
             ps.huf_valid = true;
             ps.huf_slot = k;
             ps.huf_log = (uint32_t)hlog;
-            copy_words(reinterpret_cast<uint32_t *>(P.huf + ((uint64_t)f * P.nbmax + k) * kHufTblWords),
-                       reinterpret_cast<const uint32_t *>(L.huf), (1u << hlog) >> 1, lane);
             p += t; left -= (uint32_t)t;
         }
         d.huf_slot = ps.huf_slot; d.huf_log = ps.huf_log;
