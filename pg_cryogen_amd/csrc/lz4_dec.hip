@@ -77,8 +77,8 @@ namespace {
 
 /* ---- batch engine constants ---- */
 constexpr uint32_t kWMax = 1024;  /* sequences of a batch start at window offsets < W <= kWMax */
-constexpr uint32_t kD1N = kWMax + 256; /* d1 domain [0, W+256): d2 lookups reach < W+128+63     */
-constexpr uint32_t kD2N = kWMax + 128; /* d2 domain [0, W+128): d4 lookups reach < W+126        */
+constexpr uint32_t kD1N = kWMax + 384; /* d1 domain [0, W+256); d2 lookups reach < W+128+255 (a "bad" 255 is followed too) */
+constexpr uint32_t kD2N = kWMax + 256; /* d2 domain [0, W+128); d4 lookups reach < W+255                         */
 constexpr uint32_t kDBad = 255;   /* table value for "no simple token (run) starts here"                */
 constexpr uint32_t kDMax = 63;    /* longest token-to-token distance the batch handles          */
 
@@ -123,7 +123,8 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     static_assert(R >= 4096, "ring must hold kTMax new bytes plus the near window");
     static_assert(NG * 64u <= kWMax, "window too large");
     constexpr uint32_t W = NG * 64u;
-    constexpr uint32_t G1 = NG + 4u, G2 = NG + 2u; /* groups of 64 in the d1 / d2 domains */
+    /* groups of 64 in the d1 / d2 domains: d4 on W needs d2 on W + 126, which needs d1 on W + 128 + 63 */
+    constexpr uint32_t G1 = NG + 3u, G2 = NG + 2u;
     const uint32_t lane = w.lane;
     const uint32_t vend = w.vend;
     *used = 0;
@@ -150,8 +151,8 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
 #pragma unroll
         for (uint32_t g = 0; g < G1; g++) {
             const uint32_t hi = t[g] >> 4;
-            uint32_t d = hi + 3u + ((t[g] & 15u) == 15u ? 1u : 0u);
-            if (hi == 15u) d += e1[g] + 1u;
+            const uint32_t ext3 = hi == 15u ? e1[g] + 4u : 3u; /* token + offset (3), + one extension byte and its value */
+            uint32_t d = hi + ext3 + ((t[g] & 15u) == 15u ? 1u : 0u);
             if (d > kDMax) d = kDBad; /* "not batchable from here": saturates every sum it enters */
             a1[g] = d;
         }
@@ -162,7 +163,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     {
         uint32_t b[G2];
 #pragma unroll
-        for (uint32_t g = 0; g < G2; g++) b[g] = L.d1[g * 64u + lane + (a1[g] & 127u)];
+        for (uint32_t g = 0; g < G2; g++) b[g] = L.d1[g * 64u + lane + a1[g]]; /* a bad entry reads 255 further on: inside the array, and its sum saturates anyway */
 #pragma unroll
         for (uint32_t g = 0; g < G2; g++) { const uint32_t v = a1[g] + b[g]; a2[g] = v < kDBad ? v : kDBad; } /* valid <= 126 */
 #pragma unroll
@@ -173,7 +174,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     {
         uint32_t b[NG];
 #pragma unroll
-        for (uint32_t g = 0; g < NG; g++) b[g] = L.d2[g * 64u + lane + (a2[g] & 127u)];
+        for (uint32_t g = 0; g < NG; g++) b[g] = L.d2[g * 64u + lane + a2[g]];
 #pragma unroll
         for (uint32_t g = 0; g < NG; g++) { const uint32_t v = a2[g] + b[g]; a4[g] = v < kDBad ? v : kDBad; } /* valid <= 252 */
 #pragma unroll
