@@ -189,17 +189,16 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     uint32_t sl = 0;   /* window offset of this lane's sequence */
     uint32_t ngrp = 0; /* groups of 4 sequences found */
     {
-        uint32_t s4 = 0, s0 = 0;
-        const uint32_t a = lane >> 2;
+        uint32_t sv = 0, s0 = 0;
 #pragma unroll
         for (uint32_t k = 0; k < 16u; k++) {
-            if (a == k) s4 = s0;
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(sv) : "s"(s0), "i"(4u * k)); /* start of group k -> lane 4k */
             if (ngrp == k && s0 < W) {
                 const uint32_t dd = uni(L.d4[s0]);
                 if (dd != kDBad) { s0 += dd; ngrp = k + 1u; }
             }
         }
-        sl = s4;
+        sl = (uint32_t)__builtin_amdgcn_mov_dpp((int)sv, 0x00, 0xf, 0xf, true); /* quad_perm [0,0,0,0]: lane 4k's value to its quad */
     }
     if (ngrp == 0u) return 0;
     const uint32_t ncand = ngrp * 4u;
