@@ -353,8 +353,10 @@ __device__ int read_seq_table(LT &L, uint32_t *t, int *log, int kind, int mode, 
 }
 
 /* FSE-compressed Huffman weights (wave-uniform).  Returns number of weights or -1. */
+/* src: the bytes as the header parser reads them (may be a staged LDS copy); gsrc: the same bytes in global
+ * memory for the bit reader */
 template <class LT>
-__device__ int fse_decode_weights(LT &L, const uint8_t *src, uint32_t n)
+__device__ int fse_decode_weights(LT &L, const uint8_t *src, const uint8_t *gsrc, uint32_t n)
 {
     int max_sym = 255, log = 0;
     const int hdr = read_ncount(L.norm, &max_sym, &log, src, n);
@@ -370,7 +372,7 @@ __device__ int fse_decode_weights(LT &L, const uint8_t *src, uint32_t n)
         dt[i] = ((ns << nb) - size) | (nb << 10) | (s << 14);
     }
     BitRd b;
-    if (!b.init(src + hdr, n - (uint32_t)hdr)) return -1;
+    if (!b.init(gsrc + hdr, n - (uint32_t)hdr)) return -1;
     uint32_t s1 = uni(b.read((uint32_t)log));
     uint32_t s2 = uni(b.read((uint32_t)log));
     int out = 0;
@@ -392,7 +394,7 @@ __device__ int fse_decode_weights(LT &L, const uint8_t *src, uint32_t n)
 /* Huffman tree description -> table (LDS or global; symbol | nbits << 8).  Returns bytes consumed or -1;
  * *hlog = table log. */
 template <class LT>
-__device__ int huf_read_table(LT &L, uint16_t *table, const uint8_t *src, uint32_t n, int *hlog, uint32_t lane)
+__device__ int huf_read_table(LT &L, uint16_t *table, const uint8_t *src, const uint8_t *gsrc, uint32_t n, int *hlog, uint32_t lane)
 {
     if (n < 1u) return -1;
     const uint32_t h0 = uni(src[0]);
@@ -408,7 +410,7 @@ __device__ int huf_read_table(LT &L, uint16_t *table, const uint8_t *src, uint32
     } else {
         used = 1 + (int)h0;
         if ((uint32_t)used > n) return -1;
-        nw = fse_decode_weights(L, src + 1, h0);
+        nw = fse_decode_weights(L, src + 1, gsrc + 1, h0);
         if (nw < 0) return -1;
     }
     __builtin_amdgcn_wave_barrier();

@@ -131,7 +131,7 @@ __device__ bool decode_block(ZLds &L, Wave<ZR> &w, FrameState &fs, const uint8_t
         uint32_t left = csize;
         if (type == 3u) { if (!fs.huf_valid) return false; }
         else {
-            const int t = huf_read_table(L, L.huf, p, left, &fs.huf_log, lane);
+            const int t = huf_read_table(L, L.huf, p, p, left, &fs.huf_log, lane);
             if (t < 0) return false;
             fs.huf_valid = true;
             p += t; left -= (uint32_t)t;

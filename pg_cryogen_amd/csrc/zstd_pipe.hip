@@ -92,6 +92,11 @@ struct ZPipe {
 
 struct PlanLds {
     uint32_t ll[512], ml[512], of[256];
+    int16_t norm3[3][64];   /* per table kind (LL, OF, ML): normalized counts, next-state counters, cell symbols */
+    uint16_t nxt3[3][64];
+    uint8_t cell3[3][512];
+    uint8_t hw[256]; /* staged: first bytes of a block (literals header, Huffman description, jump table) */
+    uint8_t sw[256]; /* staged: first bytes of its sequences section (count, modes, table descriptions) */
     int16_t norm[256];
     uint16_t nxt[256];
     uint32_t wdt[64];
@@ -121,36 +126,50 @@ __device__ inline void copy_seq_table(uint32_t *dst, const uint32_t *src, uint32
     }
 }
 
+/* 256 bytes from global memory into LDS in one coalesced load: the header parsers read single bytes, each
+ * of which would otherwise be a dependent global load (~150 of them per block) */
+__device__ inline void stage256(uint8_t *lds, const uint8_t *g, uint32_t avail, uint32_t lane)
+{
+    const uint32_t o = lane * 4u;
+    uint32_t v = 0;
+    if (o + 4u <= avail) __builtin_memcpy(&v, g + o, 4);
+    else for (uint32_t k = 0; k < 4u; k++) if (o + k < avail) v |= (uint32_t)g[o + k] << (8u * k);
+    reinterpret_cast<uint32_t *>(lds)[lane] = v;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
 /* K1: one compressed block's section headers -> descriptor + tables.  false = not plannable. */
-__device__ bool plan_block(PlanLds &L, const ZPipe &P, PlanState &ps, const uint8_t *src, uint32_t n, uint32_t boff,
+__device__ bool plan_block(PlanLds &L, const ZPipe &P, PlanState &ps, const uint8_t *src, const uint8_t *hs /* staged src[0..253) */,
+                           uint32_t n, uint32_t boff,
                            uint32_t f, uint32_t k, uint32_t &lit_cursor, ZBlk &d, uint32_t lane)
 {
     if (n < 3u) return false;
-    const uint32_t b0 = uni(src[0]);
+    const uint32_t b0 = uni(hs[0]);
     const uint32_t type = b0 & 3u, fmt = (b0 >> 2) & 3u;
     uint32_t regen, used;
     d.nstreams = 0;
     d.huf_slot = 0; d.huf_log = 0;
     if (type < 2u) {
         uint32_t hdr;
-        if (fmt == 1u) { hdr = 2; regen = (b0 >> 4) | (uni(src[1]) << 4); }
-        else if (fmt == 3u) { hdr = 3; regen = (b0 >> 4) | (uni(src[1]) << 4) | (uni(src[2]) << 12); }
+        if (fmt == 1u) { hdr = 2; regen = (b0 >> 4) | (uni(hs[1]) << 4); }
+        else if (fmt == 3u) { hdr = 3; regen = (b0 >> 4) | (uni(hs[1]) << 4) | (uni(hs[2]) << 12); }
         else { hdr = 1; regen = b0 >> 3; }
         if (type == 0u) {
             if (hdr + regen > n || regen > kZBlockMax) return false;
             d.lit_mode = 0; d.lit_src = boff + hdr; used = hdr + regen;
         } else {
             if ((fmt == 3u && n < 4u) || regen > kZBlockMax || hdr + 1u > n) return false;
-            d.lit_mode = 1; d.lit_src = uni(src[hdr]); used = hdr + 1u;
+            d.lit_mode = 1; d.lit_src = uni(hs[hdr]); used = hdr + 1u;
         }
     } else {
         if (n < 5u) return false;
-        const uint32_t h = b0 | (uni(src[1]) << 8) | (uni(src[2]) << 16) | (uni(src[3]) << 24);
+        const uint32_t h = b0 | (uni(hs[1]) << 8) | (uni(hs[2]) << 16) | (uni(hs[3]) << 24);
         uint32_t hdr, csize;
         bool single = false;
         if (fmt < 2u) { single = (fmt == 0u); hdr = 3; regen = (h >> 4) & 0x3FFu; csize = (h >> 14) & 0x3FFu; }
         else if (fmt == 2u) { hdr = 4; regen = (h >> 4) & 0x3FFFu; csize = h >> 18; }
-        else { hdr = 5; regen = (h >> 4) & 0x3FFFFu; csize = (h >> 22) + (uni(src[4]) << 10); }
+        else { hdr = 5; regen = (h >> 4) & 0x3FFFFu; csize = (h >> 22) + (uni(hs[4]) << 10); }
         if (regen > kZBlockMax || csize + hdr > n) return false;
         const uint8_t *p = src + hdr;
         uint32_t left = csize;
@@ -158,7 +177,7 @@ __device__ bool plan_block(PlanLds &L, const ZPipe &P, PlanState &ps, const uint
         else {
             int hlog = 0;
             /* the decoding table is filled straight into the workspace (8 KiB less LDS: twice the workgroups per CU) */
-            const int t = huf_read_table(L, P.huf + ((uint64_t)f * P.nbmax + k) * kHufTblWords, p, left, &hlog, lane);
+            const int t = huf_read_table(L, P.huf + ((uint64_t)f * P.nbmax + k) * kHufTblWords, hs + hdr, p, left, &hlog, lane);
             if (t < 0) return false;
             ps.huf_valid = true;
             ps.huf_slot = k;
@@ -174,9 +193,10 @@ __device__ bool plan_block(PlanLds &L, const ZPipe &P, PlanState &ps, const uint
             d.hs_len[1] = d.hs_len[2] = d.hs_len[3] = 0;
         } else {
             if (left < 10u) return false;
-            const uint32_t l1 = uni((uint32_t)p[0] | ((uint32_t)p[1] << 8));
-            const uint32_t l2 = uni((uint32_t)p[2] | ((uint32_t)p[3] << 8));
-            const uint32_t l3 = uni((uint32_t)p[4] | ((uint32_t)p[5] << 8));
+            const uint8_t *jt = hs + (uint32_t)(p - src); /* at most 5 + 129 bytes in: inside the staged window */
+            const uint32_t l1 = uni((uint32_t)jt[0] | ((uint32_t)jt[1] << 8));
+            const uint32_t l2 = uni((uint32_t)jt[2] | ((uint32_t)jt[3] << 8));
+            const uint32_t l3 = uni((uint32_t)jt[4] | ((uint32_t)jt[5] << 8));
             if (6u + l1 + l2 + l3 > left) return false;
             const uint32_t seg = (regen + 3u) / 4u;
             if (3u * seg > regen) return false;
@@ -194,9 +214,10 @@ __device__ bool plan_block(PlanLds &L, const ZPipe &P, PlanState &ps, const uint
     d.regen = regen;
 
     /* sequences section header */
-    const uint8_t *ip = src + used;
     uint32_t left = n - used;
     if (left < 1u) return false;
+    stage256(L.sw, src + used, left, lane);
+    const uint8_t *ip = L.sw; /* parsed from the staged copy: count, modes and the three descriptions fit in 256 bytes */
     uint32_t nseq = uni(ip[0]);
     ip++; left--;
     d.sq_off = 0; d.sq_len = 0; d.slots = 0; d.logs = 0;
@@ -211,30 +232,72 @@ __device__ bool plan_block(PlanLds &L, const ZPipe &P, PlanState &ps, const uint
         const uint32_t modes = uni(ip[0]);
         ip++; left--;
         uint32_t *gt = P.seqt + ((uint64_t)f * P.nbmax + k) * kSeqTblWords;
+        /* The three table descriptions are parsed in stream order (wave-uniform, cheap); the tables they
+         * describe are then built by lanes 0, 1, 2 at the same time -- same code, private scratch -- instead
+         * of one after the other on the whole wave. */
+        int bmode[3], bms[3], blg[3];
 #pragma unroll
         for (int kind = 0; kind < 3; kind++) { /* LL, OF, ML in stream order */
             const int mode = (int)((modes >> (6 - 2 * kind)) & 3u);
+            const int max_sym_k = kind == 0 ? 35 : (kind == 1 ? 31 : 52);
+            const int max_log_k = kind == 1 ? 8 : 9;
             uint32_t *lt = kind == 0 ? L.ll : (kind == 1 ? L.of : L.ml);
-            const uint32_t goff = kind == 0 ? 0u : (kind == 1 ? 1024u : 512u);
+            bmode[kind] = mode; bms[kind] = 0; blg[kind] = 0;
             if (mode == 0) { /* predefined: shared table built once per tile */
                 ps.slot[kind] = kPredefSlot;
                 ps.log[kind] = kind == 1 ? 5u : 6u;
-            } else {
-                int lg = 0;
-                const int u = read_seq_table(L, lt, &lg, kind, mode, ip, left, ps.fse_valid);
-                if (u < 0) return false;
-                ip += u; left -= (uint32_t)u;
-                if (mode != 3) {
-                    __builtin_amdgcn_wave_barrier();
-                    copy_seq_table(gt + goff, lt, 1u << lg, kind, lane);
-                    __builtin_amdgcn_wave_barrier();
-                    ps.slot[kind] = k;
-                    ps.log[kind] = (uint32_t)lg;
+            } else if (mode == 1) { /* RLE */
+                if (left < 1u) return false;
+                const uint32_t sy = uni(ip[0]);
+                if ((int)sy > max_sym_k) return false;
+                lt[0] = sy << 14;
+                ip += 1; left -= 1u;
+            } else if (mode == 2) {
+                int ms = max_sym_k, lg = 0;
+                const int used = read_ncount(L.norm3[kind], &ms, &lg, ip, left);
+                if (used < 0 || lg > max_log_k) return false;
+                bms[kind] = ms; blg[kind] = lg;
+                ip += used; left -= (uint32_t)used;
+            } else if (!ps.fse_valid) return false; /* repeat without a previous table */
+        }
+        __builtin_amdgcn_wave_barrier();
+        {
+            const uint32_t kd = lane < 3u ? lane : 0u;
+            const int my_mode = kd == 0u ? bmode[0] : (kd == 1u ? bmode[1] : bmode[2]);
+            const int my_ms = kd == 0u ? bms[0] : (kd == 1u ? bms[1] : bms[2]);
+            const int my_lg = kd == 0u ? blg[0] : (kd == 1u ? blg[1] : blg[2]);
+            uint32_t *my_t = kd == 0u ? L.ll : (kd == 1u ? L.of : L.ml);
+            bool okb = true;
+            if (lane < 3u && my_mode == 2) {
+                okb = fse_spread(L.cell3[kd], L.nxt3[kd], L.norm3[kd], my_ms, my_lg);
+                if (okb) {
+                    const uint32_t size = 1u << my_lg;
+                    for (uint32_t i = 0; i < size; i++) {
+                        const uint32_t sy = L.cell3[kd][i];
+                        const uint32_t ns = L.nxt3[kd][sy];
+                        L.nxt3[kd][sy] = (uint16_t)(ns + 1u);
+                        const uint32_t nb = (uint32_t)my_lg - hb32(ns);
+                        my_t[i] = ((ns << nb) - size) | (nb << 10) | (sy << 14);
+                    }
                 }
             }
+            if (__ballot(!okb) != 0ull) return false;
         }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int kind = 0; kind < 3; kind++) {
+            if (bmode[kind] == 1 || bmode[kind] == 2) {
+                const uint32_t *lt = kind == 0 ? L.ll : (kind == 1 ? L.of : L.ml);
+                const uint32_t goff = kind == 0 ? 0u : (kind == 1 ? 1024u : 512u);
+                copy_seq_table(gt + goff, lt, 1u << blg[kind], kind, lane);
+                ps.slot[kind] = k;
+                ps.log[kind] = (uint32_t)blg[kind];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
         ps.fse_valid = true;
-        d.sq_off = boff + (uint32_t)(ip - src);
+        if ((uint32_t)(ip - L.sw) > 248u) return false; /* descriptions longer than the staged window: not a layout the libraries produce */
+        d.sq_off = boff + used + (uint32_t)(ip - L.sw);
         d.sq_len = left;
         d.slots = ps.slot[0] | (ps.slot[1] << 8) | (ps.slot[2] << 16);
         d.logs = ps.log[0] | (ps.log[1] << 8) | (ps.log[2] << 16);
@@ -275,25 +338,27 @@ __global__ void __launch_bounds__(64) k_zplan(ZPipe P)
         uint32_t magic;
         __builtin_memcpy(&magic, src, 4);
         if (uni(magic) != 0xFD2FB528u) break;
-        const uint32_t fhd = uni(src[4]);
+        stage256(L.hw, src, csize, lane);
+        const uint8_t *fh = L.hw; /* the frame header is at most 18 bytes */
+        const uint32_t fhd = uni(fh[4]);
         const uint32_t single = (fhd >> 5) & 1u, did = fhd & 3u, fcs_flag = fhd >> 6, has_ck = (fhd >> 2) & 1u;
         const uint32_t did_sz = did == 3u ? 4u : did;
         const uint32_t fcs_sz = fcs_flag == 0u ? single : (1u << fcs_flag);
         const uint32_t hsz = 5u + (single ? 0u : 1u) + did_sz + fcs_sz;
         if ((fhd & 0x08u) || csize < hsz) break;
         uint32_t p = 5u;
-        if (!single) { if ((uni(src[p]) >> 3) + 10u > 31u) break; p++; }
+        if (!single) { if ((uni(fh[p]) >> 3) + 10u > 31u) break; p++; }
         if (did) {
             uint32_t id = 0;
-            for (uint32_t k = 0; k < did_sz; k++) id |= uni(src[p + k]) << (8u * k);
+            for (uint32_t k = 0; k < did_sz; k++) id |= uni(fh[p + k]) << (8u * k);
             if (id != 0u) break;
             p += did_sz;
         }
         uint64_t fcs = ~0ull;
-        if (fcs_flag == 0u) { if (single) fcs = uni(src[p]); }
+        if (fcs_flag == 0u) { if (single) fcs = uni(fh[p]); }
         else {
             uint64_t v = 0;
-            for (uint32_t k = 0; k < fcs_sz; k++) v |= (uint64_t)uni(src[p + k]) << (8u * k);
+            for (uint32_t k = 0; k < fcs_sz; k++) v |= (uint64_t)uni(fh[p + k]) << (8u * k);
             fcs = fcs_flag == 1u ? v + 256u : v;
         }
         uint32_t ip = hsz;
@@ -302,7 +367,8 @@ __global__ void __launch_bounds__(64) k_zplan(ZPipe P)
         bool okf = true;
         for (;;) {
             if (nblk >= P.nbmax || csize - ip < 3u) { okf = false; break; }
-            const uint32_t bh = uni((uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8) | ((uint32_t)src[ip + 2] << 16));
+            stage256(L.hw, src + ip, csize - ip, lane); /* block header + the first 253 bytes of the block */
+            const uint32_t bh = uni((uint32_t)L.hw[0] | ((uint32_t)L.hw[1] << 8) | ((uint32_t)L.hw[2] << 16));
             ip += 3u;
             const uint32_t last = bh & 1u, type = (bh >> 1) & 3u, bsize = bh >> 3;
             ZBlk d = {};
@@ -315,7 +381,7 @@ __global__ void __launch_bounds__(64) k_zplan(ZPipe P)
                 if (bsize > csize - ip) { okf = false; break; }
                 if (type == 2u) {
                     if (bsize >= kZBlockMax) { okf = false; break; }
-                    if (!plan_block(L, P, ps, src + ip, bsize, ip, f, nblk, lit_cursor, d, lane)) { okf = false; break; }
+                    if (!plan_block(L, P, ps, src + ip, L.hw + 3, bsize, ip, f, nblk, lit_cursor, d, lane)) { okf = false; break; }
                     total_seq += d.nseq;
                 }
                 ip += bsize;
