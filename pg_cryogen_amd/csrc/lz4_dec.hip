@@ -307,13 +307,16 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
             uint32_t n, used;
             do {
                 n = wmode == 0u ? lz4_batch<R, 2>(w, L, vp, B, &used, st)
-                  : (wmode == 1u ? lz4_batch<R, 8>(w, L, vp, B, &used, st) : lz4_batch<R, 16>(w, L, vp, B, &used, st));
+                  : (wmode == 1u ? lz4_batch<R, 8>(w, L, vp, B, &used, st)
+                  : (wmode == 2u ? lz4_batch<R, 12>(w, L, vp, B, &used, st) : lz4_batch<R, 16>(w, L, vp, B, &used, st)));
                 if (n == 0u) st.zero_batches++;
                 /* the window follows the data: long matches fill kTMax output bytes after few tokens
-                 * (128 bytes of input suffice), literal-heavy blocks need 1 KiB of input for 64 tokens */
-                const uint32_t wbytes = wmode == 0u ? 128u : (wmode == 1u ? 512u : 1024u);
+                 * (128 bytes of input suffice), literal-heavy blocks need up to 1 KiB of input for 64 tokens;
+                 * table work is proportional to the window, so it is kept just above what a batch consumes */
+                const uint32_t wbytes = wmode == 0u ? 128u : (wmode == 1u ? 512u : (wmode == 2u ? 768u : 1024u));
                 if (n != 0u && n < 64u && used < 96u) wmode = 0u;
-                else if (n != 0u && n < 56u && used + 64u > wbytes && wmode < 2u) wmode++;
+                else if (n != 0u && n < 40u && used + 64u > wbytes && wmode < 3u) wmode++;
+                else if (wmode == 3u && used < 640u) wmode = 2u;
                 else if (wmode == 2u && used < 400u) wmode = 1u;
                 else if (wmode == 0u && used >= 96u) wmode = 1u;
             } while (n >= 24u || (n >= 4u && wmode == 0u));
