@@ -258,7 +258,7 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     __shared__ __attribute__((aligned(16))) uint8_t s_d1[4][kD1N]; /* also holds meta[64] in phase 3 */
     __shared__ uint8_t s_d2[4][kD2N];
     __shared__ uint8_t s_d4[4][kWMax];
-    __shared__ uint32_t s_bm[4][kTMax / 32];
+    __shared__ __attribute__((aligned(8))) uint32_t s_bm[4][kTMax / 32 + 16]; /* bitmap + per-chunk bases */
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = uni(threadIdx.x >> 6);

@@ -281,6 +281,7 @@ __device__ inline void wave_copy_match(Wave<R> &w, uint32_t off, uint32_t ml)
 /* ---------------------------------------------------------------------------------------------
  * Batch copy: execute up to 64 non-overlapping LZ sequences (one per lane) one output byte per lane.
  *
+ *   (bm must hold kTMax/32 + 16 words.)
  *   lane i < nseq holds sequence i: ostart = its first output byte (offset inside the batch),
  *   ll literal bytes followed by a match at distance `off` (off >= match length), its literals at
  *   input-ring index (ostart + lit_rel + j) & kInMask; T = total output bytes (<= kTMax).
@@ -324,19 +325,26 @@ __device__ inline void batch_copy(Wave<R> &w, const uint8_t *__restrict__ in, un
     const uint32_t lane = w.lane;
     st.batches++;
     st.batch_seqs += nseq;
+    /* bm: bit (s - 1) set for every sequence start s >= 1 of the batch, so that the number of set bits BELOW an
+     * output position q is the index of the sequence q belongs to (the first sequence starts at 0 and has no
+     * bit); bm[kTMax/32 + c] = set bits before chunk c */
     if (lane < kTMax / 32u) bm[lane] = 0u;
     if (lane < nseq) {
         /* per sequence: lo = litend (11 bits, <= kTMax) | off << 11 (21 bits: zstd windows up to 2 MiB); hi = (first literal's input-ring index) - ostart, so
          * that a literal byte at batch offset qo sits at input-ring index (qo + hi) & kInMask */
         meta[lane] = (unsigned long long)(ostart + ll) | ((unsigned long long)off << 11) |
                        ((unsigned long long)lit_rel << 32);
-        atomicOr(&bm[ostart >> 5], 1u << (ostart & 31u));
+        if (ostart != 0u) atomicOr(&bm[(ostart - 1u) >> 5], 1u << ((ostart - 1u) & 31u));
     }
     asm volatile("" ::: "memory"); /* meta / bm are read below by other lanes than the ones that wrote them */
-    const uint32_t bm_lo = bm[(lane & (kNCh - 1u)) * 2u], bm_hi = bm[(lane & (kNCh - 1u)) * 2u + 1u];
-    uint32_t basev = (uint32_t)(__popc(bm_lo) + __popc(bm_hi)); /* lanes 0..kNCh-1: starts in chunk `lane` */
-    static_assert(kNCh == 16, "chunk-count scan uses one DPP row");
-    basev = scan16_incl(basev) - basev; /* exclusive: starts before this chunk */
+    {
+        const uint32_t bm_lo = bm[(lane & (kNCh - 1u)) * 2u], bm_hi = bm[(lane & (kNCh - 1u)) * 2u + 1u];
+        uint32_t basev = (uint32_t)(__popc(bm_lo) + __popc(bm_hi)); /* lanes 0..kNCh-1: bits in chunk `lane` */
+        static_assert(kNCh == 16, "chunk-count scan uses one DPP row");
+        basev = scan16_incl(basev) - basev; /* exclusive: bits before this chunk */
+        if (lane < kNCh) bm[kTMax / 32u + lane] = basev;
+    }
+    asm volatile("" ::: "memory");
     const uint32_t op0 = w.op;
     const ptrdiff_t in_delta = in - w.ring; /* both live in the workgroup's LDS block */
 
@@ -363,13 +371,10 @@ __device__ inline void batch_copy(Wave<R> &w, const uint8_t *__restrict__ in, un
 #pragma unroll
             for (uint32_t i = 0; i < kHalf; i++) {
                 const uint32_t c = h * kHalf + i;
-                const uint32_t wlo = lane_get(bm_lo, c), whi = lane_get(bm_hi, c);
-                const uint32_t bc = lane_get(basev, c);
-                /* starts at positions <= lane: the uniform bitmap shifted right by one (scalar) counts positions
-                 * 1..lane with mbcnt, bit 0 joins the scalar base */
-                const unsigned long long wsh = (((unsigned long long)whi << 32) | wlo) >> 1;
-                const uint32_t incl = __builtin_amdgcn_mbcnt_hi((uint32_t)(wsh >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)wsh, 0u));
-                idx[i] = (incl + (bc + (wlo & 1u) - 1u)) & 63u;
+                /* the chunk's bitmap words and base come as uniform LDS reads (LDS issue slots, not VALU ones) */
+                const uint2 wv = *reinterpret_cast<const uint2 *>(&bm[c * 2u]);
+                const uint32_t bc = bm[kTMax / 32u + c];
+                idx[i] = (bc + __builtin_amdgcn_mbcnt_hi(wv.y, __builtin_amdgcn_mbcnt_lo(wv.x, 0u))) & 63u;
             }
 #pragma unroll
             for (uint32_t i = 0; i < kHalf; i++) m[i] = meta[idx[i]];

@@ -42,7 +42,7 @@ struct ZLds {
     uint8_t wts[256];
     uint8_t cell[512];
     unsigned long long meta[64]; /* batch copy: per-sequence metadata */
-    uint32_t bm[kTMax / 32];     /* batch copy: bitmap of sequence starts */
+    uint32_t bm[kTMax / 32 + 16]; /* batch copy: bitmap of sequence starts + per-chunk bases */
 };
 
 /* decode the 4 (or 1) Huffman streams with lanes 0..3; symbols go to the literal buffer */

@@ -785,7 +785,7 @@ struct ExecLds {
     uint8_t ring[ZR];
     uint8_t in[kInRing];
     unsigned long long meta[64];
-    uint32_t bm[kTMax / 32];
+    uint32_t bm[kTMax / 32 + 16];
 };
 
 /* execute one compressed block's sequences; false on malformed input */
