@@ -99,7 +99,8 @@ struct WaveLds {
     uint8_t *__restrict__ d2;              /* kD2N; after d4 is built the same bytes hold d8 (kWMax) */
     uint8_t *__restrict__ d4;              /* kWMax                                       */
     unsigned long long *meta;              /* 64: litend | off<<16 | (litidx - ostart)<<32 */
-    uint32_t *__restrict__ bm;             /* kTMax/32: bit q = a sequence starts at q    */
+    uint32_t *__restrict__ bm;             /* kTMax/32 + 16: batch copy's bitmap and bases */
+    const uint8_t *lut;                    /* 256: token -> distance to the next token (see lz4_token_lut) */
 };
 
 /*
@@ -141,7 +142,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     /* ---- phase 1: d1 for every window offset, then d2, d4 ---- */
     uint32_t a1[G1], a2[G2];
     {
-        uint32_t t[G1], e1[G1];
+        uint32_t t[G1], e1[G1], tl[G1];
 #pragma unroll
         for (uint32_t g = 0; g < G1; g++) {
             const uint32_t pos = vp + g * 64u + lane;
@@ -149,10 +150,14 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
             e1[g] = L.in[(pos + 1u) & kInMask];
         }
 #pragma unroll
+        for (uint32_t g = 0; g < G1; g++) tl[g] = L.lut[t[g]];
+#pragma unroll
         for (uint32_t g = 0; g < G1; g++) {
-            const uint32_t hi = t[g] >> 4;
-            const uint32_t ext3 = hi == 15u ? e1[g] + 4u : 3u; /* token + offset (3), + one extension byte and its value */
-            uint32_t d = hi + ext3 + ((t[g] & 15u) == 15u ? 1u : 0u);
+            /* lut[token] = literal length + token + offset (+1 if the match length is extended); tokens whose
+             * literal length is extended carry +64 and need the extension byte's value (one byte: larger -> bad) */
+            const uint32_t b = tl[g];
+            const uint32_t dx = b + e1[g] - 63u; /* (b - 64) + extension byte + its value */
+            uint32_t d = b > 63u ? dx : b;
             if (d > kDMax) d = kDBad; /* "not batchable from here": saturates every sum it enters */
             a1[g] = d;
         }
@@ -259,6 +264,7 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     __shared__ uint8_t s_d2[4][kD2N];
     __shared__ uint8_t s_d4[4][kWMax];
     __shared__ __attribute__((aligned(8))) uint32_t s_bm[4][kTMax / 32 + 16]; /* bitmap + per-chunk bases */
+    __shared__ __attribute__((aligned(4))) uint8_t s_lut[256]; /* every wave writes the same values before it reads them */
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = uni(threadIdx.x >> 6);
@@ -271,7 +277,18 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
 
     Wave<R> w;
     const WaveLds<R> L = {s_ring[wid], s_in[wid], s_d1[wid], s_d2[wid], s_d4[wid],
-                          reinterpret_cast<unsigned long long *>(s_d1[wid]), s_bm[wid]};
+                          reinterpret_cast<unsigned long long *>(s_d1[wid]), s_bm[wid], s_lut};
+    {
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) {
+            const uint32_t tok = lane * 4u + k, hi = tok >> 4;
+            const uint32_t d = hi + 3u + ((tok & 15u) == 15u ? 1u : 0u);
+            v |= (hi == 15u ? d + 64u : d) << (8u * k);
+        }
+        reinterpret_cast<uint32_t *>(s_lut)[lane] = v;
+        LDS_TABLE_FENCE();
+    }
     w.ring = L.ring;
     w.in = L.in;
     w.lane = lane;
