@@ -44,9 +44,10 @@
  *  all its waves) and a wave-uniform token parse saturates it (measured: 69 SALU per
  *  sequence, profiles/r01_v2_scalar_parse_pmc.json).  So the parse is done by the
  *  lanes instead: for a window of W compressed bytes every lane computes, for "its"
- *  byte positions, the distance d1 to the next token *if* a token started there;
- *  two doubling passes give d2, d4; a 16-hop chase over d4 plus a 2-step fill puts
- *  the start of sequence i into lane i.  Each lane then decodes one sequence's
+ *  byte positions, the distance d1 to the next token *if* a token started there (a
+ *  256-entry token table in LDS does most of it); two doubling passes give d2, d4;
+ *  a 16-hop chase over d4 plus a 3-step fill over d1 puts the start of sequence i
+ *  into lane i.  Each lane then decodes one sequence's
  *  (literal length, offset, match length); a wave scan turns lengths into output
  *  positions; and the copy runs one output byte per lane, 64 bytes per step: a bitmap
  *  of sequence starts + mbcnt gives every byte its sequence, the byte's source is
@@ -96,7 +97,7 @@ struct WaveLds {
     uint8_t *__restrict__ ring;            /* R        output ring                       */
     uint8_t *__restrict__ in;              /* kInRing  input ring                        */
     uint8_t *d1;                           /* kD1N  (phase 3 reuses it as `meta`)         */
-    uint8_t *__restrict__ d2;              /* kD2N; after d4 is built the same bytes hold d8 (kWMax) */
+    uint8_t *__restrict__ d2;              /* kD2N                                        */
     uint8_t *__restrict__ d4;              /* kWMax                                       */
     unsigned long long *meta;              /* 64: litend | off<<16 | (litidx - ostart)<<32 */
     uint32_t *__restrict__ bm;             /* kTMax/32 + 16: batch copy's bitmap and bases */
