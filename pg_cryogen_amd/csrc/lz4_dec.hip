@@ -65,7 +65,7 @@
 #include <cstdlib>
 
 #ifndef LZ4_WAVES_PER_SIMD
-#define LZ4_WAVES_PER_SIMD 5
+#define LZ4_WAVES_PER_SIMD 4 /* LDS admits 4 workgroups of 4 waves per CU: let the register allocator use what that leaves */
 #endif
 #ifndef LZ4_HALVES
 #define LZ4_HALVES 2   /* copy passes work on kNCh / LZ4_HALVES chunks at a time (register arrays) */
