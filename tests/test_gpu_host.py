@@ -118,3 +118,38 @@ def test_gpu_compression_h_surface(HG, oracle):
     L.cryo_compress(host.COMP_ZSTD, raw.ctypes.data, C.byref(n))
     assert errors and errors[-1][1].startswith("pg_cryogen: compression failed")
     host.set_int("zstd_compression_level_guc", 1)
+
+
+def test_c_host_batch_api_strides_and_statuses(codec, oracle):
+    """cryo_codec_{compress,decompress}_blocks straight through the C ABI: exact and padded output strides
+    (bulk / per-block copy paths), mixed valid / corrupt inputs, reuse of the handle's grow-only buffers"""
+    import ctypes as C
+    from pg_cryogen_amd import METHOD_LZ4, METHOD_ZSTD, bound
+    L = codec.L
+    for method, name in ((METHOD_LZ4, "lz4"), (METHOD_ZSTD, "zstd")):
+        for B, n in ((131072, 5), (20000, 33), (131072, 2)):
+            raw = np.concatenate([oracle.synth(9, i, B, i % 5) for i in range(n)])
+            cap = bound(method, B)
+            for stride in (cap, cap + 4097, cap + 64):
+                comp = np.zeros(n * stride, np.uint8)
+                sizes = np.zeros(n, np.uint32)
+                rc = L.cryo_codec_compress_blocks(codec.h, method, 1, raw.ctypes.data, B, n, comp.ctypes.data, stride,
+                                                  sizes.ctypes.data)
+                assert rc == 0, (name, B, stride, rc)
+                for i in range(n):
+                    exp = oracle.lz4_compress(raw[i * B:(i + 1) * B], 1) if method == METHOD_LZ4 else \
+                        oracle.zstd_compress(raw[i * B:(i + 1) * B], 1)
+                    assert int(sizes[i]) == len(exp) and np.array_equal(comp[i * stride:i * stride + len(exp)], exp), (name, B, stride, i)
+            bufs = [comp[i * stride:i * stride + int(sizes[i])].copy() for i in range(n)]
+            bufs[n // 2] = bufs[n // 2][:len(bufs[n // 2]) // 2].copy()        # truncated -> corrupt
+            ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+            szs = np.array([len(b) for b in bufs], np.uint32)
+            out = np.zeros(n * B, np.uint8)
+            st = np.zeros(n, np.int32)
+            rc = L.cryo_codec_decompress_blocks(codec.h, method, ptrs, szs.ctypes.data, n, out.ctypes.data, B, st.ctypes.data)
+            assert rc == 0
+            for i in range(n):
+                if i == n // 2:
+                    assert st[i] != 0
+                else:
+                    assert st[i] == 0 and np.array_equal(out[i * B:(i + 1) * B], raw[i * B:(i + 1) * B]), (name, B, i)
