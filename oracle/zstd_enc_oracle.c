@@ -4,16 +4,17 @@
  * Restates ZSTD_compress(dst, ZSTD_compressBound(B), src, B, level) as libzstd 1.4.8 runs it
  * for the reference's call shape (compression.c:102-104), for the levels whose strategy is
  * `fast` (levels -5 .. 2 at cryo block sizes; the reference's default
- * level 1 is one of them).  Output bytes are identical to the library's; pinned by
+ * level 1 is one of them) or `dfast` (levels 3 and 4).  Output bytes are identical to the library's; pinned by
  * tests/golden/vectors.json (libzstd 1.4.8 == 1.4.9) and by a live differential test.
  *
  * Pipeline restated (all integer arithmetic):
  *   parameters by level and size -> frame header -> per 128 KiB block:
- *     greedy 2-position hash-table match finder with repeat-offset checks ("fast" strategy)
+ *     greedy 2-position hash-table match finder with repeat-offset checks ("fast" strategy), or
+ *     the two-table (8-byte long hash + short hash) finder of the "dfast" strategy
  *     -> sequences (literal length, match length, offset code) + literal bytes
  *     -> literals: raw / RLE / Huffman (length-limited tree, FSE-compressed or raw weights,
  *        1 or 4 backward bitstreams), with the library's "worth it" heuristics
- *     -> sequences: per-field encoding type (predefined / RLE / FSE) by the `fast`-strategy
+ *     -> sequences: per-field encoding type (predefined / RLE / FSE) by the below-`lazy`
  *        heuristic, FSE table normalisation + description, interleaved backward bitstream
  *     -> raw block fallback when the gain is below srcSize/64 + 2; RLE block for constant
  *        non-first blocks
@@ -613,13 +614,14 @@ static uint32_t ml_code(uint32_t mb)
 
 enum { SET_BASIC = 0, SET_RLE = 1, SET_COMPRESSED = 2, SET_REPEAT = 3 };
 
-/* ZSTD_selectEncodingType for strategy `fast` (no dictionary: repeat mode is never "valid") */
+/* ZSTD_selectEncodingType for strategies below `lazy` (no dictionary: repeat mode is never "valid") */
+static int g_strategy = 1; /* ZSTD_fast = 1, ZSTD_dfast = 2; set by the frame driver */
 static int select_type(uint32_t max, size_t most, size_t nseq, int def_log, int def_allowed)
 {
     (void)max;
     if (most == nseq) return (def_allowed && nseq <= 2) ? SET_BASIC : SET_RLE;
     if (def_allowed) {
-        const size_t mult = 10 - 1; /* strategy fast == 1 */
+        const size_t mult = 10 - (size_t)g_strategy;
         const size_t dyn_min = (((size_t)1 << def_log) * mult) >> 3;
         if (nseq < dyn_min || most < (nseq >> (def_log - 1))) return SET_BASIC;
     }
@@ -733,7 +735,7 @@ check:
 }
 
 /* ------------------------------------------------------------ match finder: strategy `fast` */
-typedef struct { int wlog, hlog, mml, tlen; } cpar;
+typedef struct { int wlog, clog, hlog, mml, tlen, dfast; } cpar;
 
 static uint32_t hash_ptr(const uint8_t *p, int hlog, int mls)
 {
@@ -743,6 +745,7 @@ static uint32_t hash_ptr(const uint8_t *p, int hlog, int mls)
     case 5: return (uint32_t)(((rd64(p) << 24) * 889523592379ull) >> (64 - hlog));
     case 6: return (uint32_t)(((rd64(p) << 16) * 227718039650203ull) >> (64 - hlog));
     case 7: return (uint32_t)(((rd64(p) << 8) * 58295818150454627ull) >> (64 - hlog));
+    case 8: return (uint32_t)((rd64(p) * 0xCF1BBCDCB7A56463ull) >> (64 - hlog));
     }
 }
 static size_t count_match(const uint8_t *a, const uint8_t *b, const uint8_t *end)
@@ -853,27 +856,121 @@ static size_t block_fast(uint32_t *table, const cpar *cp, const uint8_t *base, c
     return (size_t)(iend - anchor);
 }
 
+/* ------------------------------------------------------------ match finder: strategy `dfast`
+ * (libzstd 1.4.8 ZSTD_compressBlock_doubleFast, no dictionary): a long table hashed on 8 bytes and a short
+ * one on mml bytes, both updated at every visited position; order of tests: repeat offset at ip+1, long
+ * match at ip, then (only if the short candidate matches 4 bytes) long match at ip+1, else the short one. */
+static size_t block_dfast(uint32_t *tlong, uint32_t *tshort, const cpar *cp, const uint8_t *base, const uint8_t *istart,
+                          size_t n, uint32_t rep[3], seqstore *ss, uint32_t dict_limit)
+{
+    const int hl = cp->hlog, hs = cp->clog, mls = cp->mml < 4 ? 4 : (cp->mml > 7 ? 7 : cp->mml);
+    const uint8_t *ip = istart, *anchor = istart;
+    const uint32_t end_index = (uint32_t)(istart - base) + (uint32_t)n;
+    const uint32_t max_dist = 1u << cp->wlog;
+    const uint32_t prefix_idx = (end_index - dict_limit > max_dist) ? end_index - max_dist : dict_limit;
+    const uint8_t *prefix = base + prefix_idx;
+    const uint8_t *iend = istart + n, *ilimit = iend - HASH_READ;
+    uint32_t off1 = rep[0], off2 = rep[1], saved = 0;
+
+    ip += (ip == prefix);
+    {
+        const uint32_t cur = (uint32_t)(ip - base);
+        const uint32_t wlow = (cur - dict_limit > max_dist) ? cur - max_dist : dict_limit;
+        const uint32_t max_rep = cur - wlow;
+        if (off2 > max_rep) { saved = off2; off2 = 0; }
+        if (off1 > max_rep) { saved = off1; off1 = 0; }
+    }
+    while (ip < ilimit) {
+        size_t mlen;
+        uint32_t offset;
+        const uint32_t h2 = hash_ptr(ip, hl, 8), h = hash_ptr(ip, hs, mls);
+        const uint32_t cur = (uint32_t)(ip - base);
+        const uint32_t mil = tlong[h2], mis = tshort[h];
+        const uint8_t *ml = base + mil, *m = base + mis;
+        tlong[h2] = tshort[h] = cur;
+        if (off1 > 0 && rd32(ip + 1 - off1) == rd32(ip + 1)) {
+            mlen = count_match(ip + 1 + 4, ip + 1 + 4 - off1, iend) + 4;
+            ip++;
+            store_seq(ss, (size_t)(ip - anchor), anchor, 0, mlen - MINMATCH);
+            goto stored;
+        }
+        if (mil > prefix_idx && rd64(ml) == rd64(ip)) {
+            mlen = count_match(ip + 8, ml + 8, iend) + 8;
+            offset = (uint32_t)(ip - ml);
+            while (ip > anchor && ml > prefix && ip[-1] == ml[-1]) { ip--; ml--; mlen++; }
+            goto found;
+        }
+        if (mis > prefix_idx && rd32(m) == rd32(ip)) {
+            const uint32_t hl3 = hash_ptr(ip + 1, hl, 8);
+            const uint32_t mil3 = tlong[hl3];
+            const uint8_t *ml3 = base + mil3;
+            tlong[hl3] = cur + 1;
+            if (mil3 > prefix_idx && rd64(ml3) == rd64(ip + 1)) {
+                mlen = count_match(ip + 9, ml3 + 8, iend) + 8;
+                ip++;
+                offset = (uint32_t)(ip - ml3);
+                while (ip > anchor && ml3 > prefix && ip[-1] == ml3[-1]) { ip--; ml3--; mlen++; }
+                goto found;
+            }
+            mlen = count_match(ip + 4, m + 4, iend) + 4;
+            offset = (uint32_t)(ip - m);
+            while (ip > anchor && m > prefix && ip[-1] == m[-1]) { ip--; m--; mlen++; }
+            goto found;
+        }
+        ip += ((size_t)(ip - anchor) >> 8) + 1;
+        continue;
+    found:
+        off2 = off1;
+        off1 = offset;
+        store_seq(ss, (size_t)(ip - anchor), anchor, offset + REP_MOVE, mlen - MINMATCH);
+    stored:
+        ip += mlen;
+        anchor = ip;
+        if (ip <= ilimit) {
+            const uint32_t ins = cur + 2;
+            tlong[hash_ptr(base + ins, hl, 8)] = ins;
+            tlong[hash_ptr(ip - 2, hl, 8)] = (uint32_t)(ip - 2 - base);
+            tshort[hash_ptr(base + ins, hs, mls)] = ins;
+            tshort[hash_ptr(ip - 1, hs, mls)] = (uint32_t)(ip - 1 - base);
+            while (ip <= ilimit && off2 > 0 && rd32(ip) == rd32(ip - off2)) {
+                const size_t rlen = count_match(ip + 4, ip + 4 - off2, iend) + 4;
+                const uint32_t t = off2; off2 = off1; off1 = t;
+                tshort[hash_ptr(ip, hs, mls)] = (uint32_t)(ip - base);
+                tlong[hash_ptr(ip, hl, 8)] = (uint32_t)(ip - base);
+                store_seq(ss, 0, anchor, 0, rlen - MINMATCH);
+                ip += rlen;
+                anchor = ip;
+            }
+        }
+    }
+    rep[0] = off1 ? off1 : saved;
+    rep[1] = off2 ? off2 : saved;
+    return (size_t)(iend - anchor);
+}
+
 /* ------------------------------------------------------------ parameters (ZSTD_getCParams) */
 static int get_cpar(int level, size_t n, cpar *cp)
 {
-    /* rows: level 0(base for negatives),1,2 of the library's tables for the two size classes the
-     * cryo path uses; validated against ZSTD_getCParams by the tests */
-    static const int big[3][4] = {{19, 12, 13, 6}, {19, 13, 14, 7}, {20, 15, 16, 6}};   /* n > 256 KiB */
-    static const int k128[3][4] = {{17, 12, 12, 5}, {17, 12, 13, 6}, {17, 13, 15, 5}};  /* 16 KiB < n <= 128 KiB */
+    /* rows: level 0(base for negatives),1,2,3,4 of the library's tables for the two size classes the
+     * cryo path uses {windowLog, chainLog, hashLog, minMatch}; validated against ZSTD_getCParams by the tests */
+    static const int big[5][4] = {{19, 12, 13, 6}, {19, 13, 14, 7}, {20, 15, 16, 6}, {21, 16, 17, 5}, {21, 18, 18, 5}}; /* n > 256 KiB */
+    static const int k128[5][4] = {{17, 12, 12, 5}, {17, 12, 13, 6}, {17, 13, 15, 5}, {17, 15, 16, 5}, {17, 17, 17, 4}}; /* 16 KiB < n <= 128 KiB */
     const int (*t)[4];
     int row, srclog;
     if (level == 0) level = 3;
-    if (level > 2 || level < -131072) return -1; /* other levels: not `fast` */
+    if (level > 4 || level < -131072) return -1; /* other levels: neither `fast` nor `dfast` */
     if (n > 256u * 1024u) t = big;
     else if (n > 16u * 1024u && n <= 128u * 1024u) t = k128;
     else return -1;
     row = level < 0 ? 0 : level;
-    cp->wlog = t[row][0]; cp->hlog = t[row][2]; cp->mml = t[row][3];
+    cp->wlog = t[row][0]; cp->clog = t[row][1]; cp->hlog = t[row][2]; cp->mml = t[row][3];
     cp->tlen = level < 0 ? -level : 0;
-    /* ZSTD_adjustCParams_internal: shrink the window (and hash) to the source size */
+    cp->dfast = level >= 3;
+    /* ZSTD_adjustCParams_internal: shrink the window (and hash, chain) to the source size */
     srclog = (n < 64) ? 6 : hb((uint32_t)(n - 1)) + 1;
     if (cp->wlog > srclog) cp->wlog = srclog;
     if (cp->hlog > cp->wlog + 1) cp->hlog = cp->wlog + 1;
+    if (cp->clog > cp->wlog) cp->clog = cp->wlog;
     if (cp->wlog < 10) cp->wlog = 10;
     return 0;
 }
@@ -881,7 +978,7 @@ static int get_cpar(int level, size_t n, cpar *cp)
 /* ------------------------------------------------------------ frame */
 size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int level)
 {
-    static uint32_t table[1 << 16];
+    static uint32_t table[1 << 18], tshort[1 << 18];
     static seq_t seqs[ZBLOCK_MAX / 3 + 8];
     static uint8_t lits[ZBLOCK_MAX + 8];
     cpar cp;
@@ -894,6 +991,8 @@ size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, siz
     hprev.mode = 0;
     if (get_cpar(level, n, &cp) || cap < cryo_oracle_zstd_bound(n)) return 0;
     memset(table, 0, sizeof(uint32_t) << cp.hlog);
+    if (cp.dfast) memset(tshort, 0, sizeof(uint32_t) << cp.clog);
+    g_strategy = cp.dfast ? 2 : 1;
     /* frame header: content size always, no checksum, no dictionary id */
     {
         const uint64_t wsize = 1ull << cp.wlog;
@@ -922,7 +1021,8 @@ size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, siz
             size_t last_ll;
             ss.seqs = seqs; ss.nseq = 0; ss.lits = lits; ss.nlit = 0; ss.long_pos = 0; ss.long_kind = 0;
             nrep[0] = rep[0]; nrep[1] = rep[1]; nrep[2] = rep[2];
-            last_ll = block_fast(table, &cp, base, src + ip, bs, nrep, &ss, dict_limit);
+            last_ll = cp.dfast ? block_dfast(table, tshort, &cp, base, src + ip, bs, nrep, &ss, dict_limit)
+                               : block_fast(table, &cp, base, src + ip, bs, nrep, &ss, dict_limit);
             memcpy(lits + ss.nlit, src + ip + bs - last_ll, last_ll);
             ss.nlit += last_ll;
             csize = compress_sequences(dst + op + 3, seqs, ss.nseq, lits, ss.nlit, bs, ss.long_pos, ss.long_kind, &hprev, &hnext, cp.tlen > 0);
