@@ -235,9 +235,9 @@ int cryo_codec_compress_batch(cryo_codec *c, int method, int param, const void *
                                              n_blocks, (uint8_t *)d_dst, dst_stride, param,
                                              d_out_size, d_status));
     } else {
-        /* levels whose strategy is `fast` (-5..2 at cryo block sizes); others: no kernel yet */
+        /* levels whose strategy is `fast` or `dfast` (-5..4 at cryo block sizes); others: no kernel yet */
         if (!cryo::zstd_compress_supported(param, block_size)) return CRYO_E_UNSUPPORTED;
-        const size_t need = cryo::zstd_compress_workspace(n_blocks);
+        const size_t need = cryo::zstd_compress_workspace(n_blocks, param, block_size);
         int rc = ensure_ws(c, need);
         if (rc != CRYO_OK) return rc;
         HIP_TRY(c, cryo::launch_zstd_compress(c->stream, (const uint8_t *)d_src, src_stride, block_size, n_blocks,

@@ -60,7 +60,7 @@ size_t zstd_fused_workspace(uint64_t n_blocks);
 hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t src_stride, uint32_t block_size,
                                 uint64_t n_blocks, uint8_t *d_dst, uint64_t dst_stride, int level,
                                 uint32_t *d_out_size, int32_t *d_status, void *d_workspace, size_t workspace_bytes);
-size_t zstd_compress_workspace(uint64_t n_blocks);
+size_t zstd_compress_workspace(uint64_t n_blocks, int level, uint32_t block_size);
 bool zstd_compress_supported(int level, uint32_t block_size);
 
 } // namespace cryo

@@ -602,7 +602,7 @@ __device__ uint32_t huf_encode_streams(EncLds &L, uint8_t *dst, uint32_t hsz, co
     return op;
 }
 
-struct HufState { bool prev_valid; bool next_new; unsigned long long *prof; unsigned long long t; };
+struct HufState { bool prev_valid; bool next_new; unsigned long long *prof; unsigned long long t; uint32_t strat; };
 /* diagnostic phase stamps (CRYO_ZSTD_STATS): bucket k gets the cycles since the previous stamp */
 __device__ inline void zprof(HufState &hs, int k)
 {
@@ -714,11 +714,11 @@ __constant__ uint8_t kMLCode[128] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 1
 
 enum { SET_BASIC = 0, SET_RLE = 1, SET_COMPRESSED = 2 };
 
-__device__ inline int select_type(uint32_t most, uint32_t nseq, int def_log, bool def_allowed)
+__device__ inline int select_type(uint32_t most, uint32_t nseq, int def_log, bool def_allowed, uint32_t strat)
 {
     if (most == nseq) return (def_allowed && nseq <= 2u) ? SET_BASIC : SET_RLE;
     if (def_allowed) {
-        const uint32_t dyn_min = ((1u << def_log) * 9u) >> 3; /* strategy fast: mult = 10 - 1 */
+        const uint32_t dyn_min = ((1u << def_log) * (10u - strat)) >> 3; /* ZSTD_fast = 1, ZSTD_dfast = 2 */
         if (nseq < dyn_min || most < (nseq >> (def_log - 1))) return SET_BASIC;
     }
     return SET_COMPRESSED;
@@ -794,19 +794,19 @@ __device__ uint32_t compress_sequences(EncLds &L, uint8_t *dst, uint8_t *ws, uin
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     uint32_t max, most, last_ncount = 0xFFFFFFFFu;
     hist_codes(L, llc, nseq, kMaxLL, &max, &most, lane);
-    const int tll = select_type(most, nseq, 6, true);
+    const int tll = select_type(most, nseq, 6, true, hs.strat);
     uint32_t sz = build_ctable(L, dst + op, L.ll, 9, tll, max, llc, nseq, kELLDef, 6, kMaxLL, lane);
     if (sz == 0xFFFFFFFFu) return 0;
     if (tll == SET_COMPRESSED) last_ncount = op;
     op += sz;
     hist_codes(L, ofc, nseq, kMaxOff, &max, &most, lane);
-    const int tof = select_type(most, nseq, 5, max <= kDefMaxOff);
+    const int tof = select_type(most, nseq, 5, max <= kDefMaxOff, hs.strat);
     sz = build_ctable(L, dst + op, L.of, 8, tof, max, ofc, nseq, kEOFDef, 5, kDefMaxOff, lane);
     if (sz == 0xFFFFFFFFu) return 0;
     if (tof == SET_COMPRESSED) last_ncount = op;
     op += sz;
     hist_codes(L, mlc, nseq, kMaxML, &max, &most, lane);
-    const int tml = select_type(most, nseq, 6, true);
+    const int tml = select_type(most, nseq, 6, true, hs.strat);
     sz = build_ctable(L, dst + op, L.ml, 9, tml, max, mlc, nseq, kEMLDef, 6, kMaxML, lane);
     if (sz == 0xFFFFFFFFu) return 0;
     if (tml == SET_COMPRESSED) last_ncount = op;
@@ -868,7 +868,7 @@ __device__ uint32_t compress_sequences(EncLds &L, uint8_t *dst, uint8_t *ws, uin
 }
 
 /* ------------------------------------------------------------ match finder: strategy `fast` */
-struct CPar { int wlog, hlog, mml, tlen; };
+struct CPar { int wlog, clog, hlog, mml, tlen; };
 
 __device__ inline uint32_t hash_ptr(const uint8_t *p, int hlog, int mls)
 {
@@ -1256,27 +1256,31 @@ __device__ uint32_t block_fast_batch(RingIn<kW> &r, const PosTab<BIT> &tab, cons
     return iend - anchor;
 }
 
+#include "zstd_dfast.h"
+
 } // namespace
 
-template <bool BATCH, bool BIT>
+/* BATCH: the `fast` finder over the LDS ring + compact LDS table; DF: the `dfast` finder over two global
+ * tables behind the workgroup's workspace; neither: the serial `fast` finder (hashLog > 14, testing aid) */
+template <bool BATCH, bool BIT, bool DF = false>
 __global__ void __launch_bounds__(64)
 k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t n_blocks,
            uint8_t *__restrict__ dst_base, uint64_t dst_stride, int wlog, int hlog, int mml, int tlen,
            uint32_t *__restrict__ out_size, int32_t *__restrict__ status, uint8_t *workspace,
-           unsigned long long *stats)
+           unsigned long long *stats, int clog = 0, uint64_t ws_stride = kWsBytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     /* BATCH: the entropy stage's tables share LDS with the match finder's ring + table (dead while it runs;
      * for frames of several blocks the table is parked in the workspace meanwhile) */
     EncLds *Lp;
-    if constexpr (BATCH) Lp = reinterpret_cast<EncLds *>(dyn_lds);
+    if constexpr (BATCH || DF) Lp = reinterpret_cast<EncLds *>(dyn_lds);
     else { __shared__ EncLds L_static; Lp = &L_static; }
     EncLds &L = *Lp;
     unsigned long long t_mf = 0, t_en = 0, t_other = 0, t_prev = stats ? __builtin_amdgcn_s_memtime() : 0; /* CRYO_ZSTD_STATS */
     const uint32_t lane = threadIdx.x & 63u;
-    uint8_t *ws = workspace + (uint64_t)blockIdx.x * kWsBytes;
+    uint8_t *ws = workspace + (uint64_t)blockIdx.x * ws_stride;
     CPar cp;
-    cp.wlog = wlog; cp.hlog = hlog; cp.mml = mml; cp.tlen = tlen;
+    cp.wlog = wlog; cp.clog = clog; cp.hlog = hlog; cp.mml = mml; cp.tlen = tlen;
     /* match-finder table: BATCH: u16 | u8 entries in dynamic LDS behind the input ring (hashLog <= 14);
      * serial: u32 in LDS when hashLog <= 13, else in the workgroup's workspace */
     uint32_t *table = nullptr;
@@ -1284,10 +1288,14 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
     if constexpr (BATCH) {
         ptab.lo = reinterpret_cast<uint16_t *>(dyn_lds + kZW);
         ptab.hi = dyn_lds + kZW + (2u << hlog); /* bytes, or the bitmap (4-byte aligned: 2 KiB + 2^(hlog+1)) */
+    } else if constexpr (DF) {
+        table = reinterpret_cast<uint32_t *>(ws + kWsBytes); /* long table, then the short one */
     } else {
         __shared__ uint32_t hash_lds[8192];
         table = (hlog <= 13) ? hash_lds : reinterpret_cast<uint32_t *>(ws + kWsHash);
     }
+    uint32_t *tshort = DF ? table + (1u << hlog) : nullptr;
+    uint8_t *df_mark = dyn_lds + sizeof(EncLds); /* DF only */
 
     for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         const uint8_t *src = src_base + blk * src_stride;
@@ -1297,6 +1305,9 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
             for (uint32_t i = lane; i < PosTab<BIT>::bytes(hlog) / 16u; i += 64u) reinterpret_cast<uint4 *>(dyn_lds + kZW)[i] = make_uint4(0, 0, 0, 0);
             ring.open(dyn_lds, src, n, lane);
             ring.ensure(kZW);
+        } else if constexpr (DF) {
+            const uint32_t quads = ((1u << hlog) + (1u << clog)) / 4u;
+            for (uint32_t i = lane; i < quads; i += 64u) reinterpret_cast<uint4 *>(table)[i] = make_uint4(0, 0, 0, 0);
         } else {
             for (uint32_t i = lane; i < (1u << hlog); i += 64u) table[i] = 0;
         }
@@ -1322,7 +1333,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         const uint8_t *base = src - 1;
         bool first = true;
         HufState hs;
-        hs.prev_valid = false; hs.next_new = false; hs.prof = stats; hs.t = 0;
+        hs.prev_valid = false; hs.next_new = false; hs.prof = stats; hs.t = 0; hs.strat = DF ? 2u : 1u;
         uint32_t ip = 0;
         while (ip < n) {
             const uint32_t bs = (n - ip < kZBlk) ? n - ip : kZBlk;
@@ -1337,6 +1348,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_other += t - t_prev; t_prev = t; }
                 uint32_t last_ll;
                 if constexpr (BATCH) last_ll = block_fast_batch(ring, ptab, cp, ip, bs, nrep, ws, ss, dict_limit, lane);
+                else if constexpr (DF) last_ll = block_dfast_batch(table, tshort, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane);
                 else last_ll = block_fast(table, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane);
                 if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mf += t - t_prev; t_prev = t; }
                 for (uint32_t i = lane; i < last_ll; i += 64u) (ws + kWsLit)[ss.nlit + i] = src[ip + bs - last_ll + i];
@@ -1404,26 +1416,32 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
     }
 }
 
-/* ZSTD_getCParams + ZSTD_adjustCParams for the `fast` levels at cryo block sizes (oracle-checked) */
-static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *mml, int *tlen)
+/* ZSTD_getCParams + ZSTD_adjustCParams for the `fast` (-5..2) and `dfast` (3, 4) levels at cryo block sizes
+ * (oracle-checked).  *clog is only used by dfast: the short table's log. */
+static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *mml, int *tlen, int *clog = nullptr,
+                              bool *dfast = nullptr)
 {
-    static const int big[3][3] = {{19, 13, 6}, {19, 14, 7}, {20, 16, 6}};   /* n > 256 KiB: wlog, hlog, mml */
-    static const int k128[3][3] = {{17, 12, 5}, {17, 13, 6}, {17, 15, 5}};  /* 16 KiB < n <= 128 KiB       */
-    const int (*t)[3];
+    static const int big[5][4] = {{19, 12, 13, 6}, {19, 13, 14, 7}, {20, 15, 16, 6}, {21, 16, 17, 5}, {21, 18, 18, 5}}; /* n > 256 KiB: wlog, clog, hlog, mml */
+    static const int k128[5][4] = {{17, 12, 12, 5}, {17, 12, 13, 6}, {17, 13, 15, 5}, {17, 15, 16, 5}, {17, 17, 17, 4}}; /* 16 KiB < n <= 128 KiB */
+    const int (*t)[4];
     if (level == 0) level = 3;
-    if (level > 2 || level < -131072) return false;
+    if (level > 4 || level < -131072) return false;
     if (n > 256u * 1024u) t = big;
     else if (n > 16u * 1024u && n <= 128u * 1024u) t = k128;
     else return false;
     const int row = level < 0 ? 0 : level;
-    *wlog = t[row][0]; *hlog = t[row][1]; *mml = t[row][2];
+    int cl = t[row][1];
+    *wlog = t[row][0]; *hlog = t[row][2]; *mml = t[row][3];
     *tlen = level < 0 ? -level : 0;
     int srclog = 0;
     for (uint32_t v = n - 1u; v; v >>= 1) srclog++;
     if (n < 64u) srclog = 6;
     if (*wlog > srclog) *wlog = srclog;
     if (*hlog > *wlog + 1) *hlog = *wlog + 1;
+    if (cl > *wlog) cl = *wlog;
     if (*wlog < 10) *wlog = 10;
+    if (clog) *clog = cl;
+    if (dfast) *dfast = level >= 3;
     return true;
 }
 
@@ -1452,7 +1470,25 @@ static uint32_t zstd_enc_grid(uint64_t n_blocks, bool batch, int hlog, bool bit 
     return (uint32_t)(n_blocks < cap ? n_blocks : cap);
 }
 
-size_t zstd_compress_workspace(uint64_t n_blocks) { return (size_t)zstd_enc_grid(n_blocks, true, 10, true) * kWsBytes + 256; }
+/* dfast: EncLds + the duplicate filter in LDS -> 7 workgroups per CU; two u32 tables behind each workspace */
+static size_t zstd_dfast_lds() { return sizeof(EncLds) + kDfMark; }
+static uint32_t zstd_dfast_grid(uint64_t n_blocks)
+{
+    uint64_t per_cu = (160u * 1024u) / zstd_dfast_lds();
+    if (per_cu > 8) per_cu = 8;
+    const uint64_t cap = 256u * per_cu;
+    return (uint32_t)(n_blocks < cap ? n_blocks : cap);
+}
+static size_t zstd_dfast_stride(int hlog, int clog) { return kWsBytes + (((size_t)4u << hlog) + ((size_t)4u << clog)); }
+
+size_t zstd_compress_workspace(uint64_t n_blocks, int level, uint32_t block_size)
+{
+    int wlog, hlog, mml, tlen, clog;
+    bool dfast = false;
+    if (zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast) && dfast)
+        return (size_t)zstd_dfast_grid(n_blocks) * zstd_dfast_stride(hlog, clog) + 256;
+    return (size_t)zstd_enc_grid(n_blocks, true, 10, true) * kWsBytes + 256;
+}
 
 bool zstd_compress_supported(int level, uint32_t block_size)
 {
@@ -1465,8 +1501,18 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
                                 uint32_t *d_out_size, int32_t *d_status, void *d_workspace, size_t workspace_bytes)
 {
     if (n_blocks == 0) return hipSuccess;
-    int wlog, hlog, mml, tlen;
-    if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen)) return hipErrorNotSupported;
+    int wlog, hlog, mml, tlen, clog;
+    bool dfast = false;
+    if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast)) return hipErrorNotSupported;
+    if (dfast) {
+        const uint32_t grid = zstd_dfast_grid(n_blocks);
+        const size_t stride = zstd_dfast_stride(hlog, clog);
+        if (workspace_bytes < (size_t)grid * stride) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((k_zstd_enc<false, false, true>), dim3(grid), dim3(64), zstd_dfast_lds(), s, d_src, src_stride,
+                           block_size, n_blocks, d_dst, dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status,
+                           (uint8_t *)d_workspace, (unsigned long long *)nullptr, clog, (uint64_t)stride);
+        return hipGetLastError();
+    }
     const bool batch = zstd_enc_batch(hlog);
     const bool bit = batch && block_size <= (128u << 10);
     const uint32_t grid = zstd_enc_grid(n_blocks, batch, hlog, bit);

@@ -128,11 +128,11 @@ def test_zstd_single_block_host_api(codec, oracle):
     assert codec.decompress_block(METHOD_ZSTD, c[:-3], B) is None
 
 
-# ---------------- zstd encode (strategy `fast`: levels -5..2), reference compression.c:102-104 ----------------
+# ---------------- zstd encode (strategies `fast` and `dfast`: levels -5..4), reference compression.c:102-104 ----------------
 @pytest.mark.parametrize("B", [131072, 1 << 20, 65546, 20000])
 def test_zstd_encode_bit_exact(codec, oracle, B):
     blocks = [oracle.synth(3, blk, B, dist) for dist in range(5) for blk in range(2)]
-    for lvl in (-5, -1, 1, 2):
+    for lvl in (-5, -1, 1, 2, 3, 4):
         got = codec.compress_blocks(METHOD_ZSTD, lvl, blocks)
         for i, b in enumerate(blocks):
             exp = oracle.zstd_compress(b, lvl)
@@ -143,8 +143,8 @@ def test_zstd_encode_bit_exact(codec, oracle, B):
 
 def test_zstd_encode_matches_golden_vectors(codec, oracle):
     cells = [c for c in json.load(open(os.path.join(G, "vectors.json")))["cells"]
-             if c["method"] == "zstd" and c["param"] <= 2 and c["B"] == 131072]
-    assert len(cells) >= 40
+             if c["method"] == "zstd" and c["param"] <= 4 and c["B"] == 131072]
+    assert len(cells) >= 50
     for lvl in sorted(set(c["param"] for c in cells)):
         sub = [c for c in cells if c["param"] == lvl]
         blocks = [oracle.synth(0, c["block"], c["B"], c["dist"]) for c in sub]
@@ -163,7 +163,7 @@ def test_zstd_roundtrip_on_device_and_unsupported_levels(codec, oracle):
     for b, o in zip(blocks, outs):
         assert np.array_equal(b, o)
     with pytest.raises(CryoError) as e:
-        codec.compress_blocks(METHOD_ZSTD, 3, blocks[:1])      # dfast and above: no kernel (no CPU fallback)
+        codec.compress_blocks(METHOD_ZSTD, 5, blocks[:1])      # greedy and above: no kernel (no CPU fallback)
     assert e.value.code == E_UNSUPPORTED
 
 
@@ -230,7 +230,7 @@ def test_zstd_pipeline_many_frames_across_tiles(codec, oracle):
 def test_zstd_encode_batch_match_finder_corners(codec, oracle):
     """the 64-iterations-per-step match finder: incompressible data (growing steps), repeats at distances
     beyond the LDS ring and the window, long runs (repeat-offset loop), periodic data with noise;
-    block sizes at the edges of the supported ranges; every fast level.  Bar: bytes == oracle (== libzstd)."""
+    block sizes at the edges of the supported ranges; every fast and dfast level.  Bar: bytes == oracle (== libzstd)."""
     rng = np.random.default_rng(21)
     stock = oracle_lib.StockLibs()
     for n in (16385, 20000, 131072, 262145, 300000 + 7):
@@ -250,7 +250,7 @@ def test_zstd_encode_batch_match_finder_corners(codec, oracle):
         w = np.frombuffer((b"the quick brown fox jumps over the lazy dog, " * (n // 45 + 1))[:n], np.uint8).copy()
         w[rng.integers(0, n, n // 50)] = 0x5A
         blocks.append(w)
-        for level in (-5, -1, 1, 2):
+        for level in (-5, -1, 1, 2, 3, 4):
             got = codec.compress_blocks(METHOD_ZSTD, level, blocks)
             for i, b in enumerate(blocks):
                 exp = oracle.zstd_compress(b, level)
