@@ -1,6 +1,6 @@
 /*
  * zstd_dfast.h -- the `dfast` strategy's match finder (libzstd 1.4.8 ZSTD_compressBlock_doubleFast, no
- * dictionary; zstd levels 3 and 4 at cryo block sizes), 64 search positions per step.  Included by
+ * dictionary; zstd levels 3 and 4 at cryo block sizes), many search positions per step.  Included by
  * zstd_enc.hip inside its namespace; the entropy stage behind it is the one the `fast` levels use.
  *
  * Replaces the match-finding half of ZSTD_compress(dst, bound, src, B, level) (reference
@@ -12,14 +12,21 @@
  * also tried at ip+1 and wins if it matches).  No hit: ip += ((ip - anchor) >> 8) + 1.
  *
  * Both tables are too large for LDS (2^16 + 2^15 ... 2^18 + 2^18 entries), so they live in the workgroup's
- * global workspace and a position costs dependent trips to L2/HBM: input -> table -> candidate.  Taking the
- * next 64 positions of the walk at once (one per lane; they are known in advance as long as nothing is
- * found: same step while (ip - anchor) >> 8 is unchanged) pays those trips once per 64 positions.  A lane
- * must see what earlier lanes of the same step wrote to its slots; instead of resolving that, the step is
- * cut short in front of the first lane that could share a slot with an earlier one (a small LDS array
- * indexed by the slot's low bits, marked with lane numbers, finds those -- conservatively), so every lane
- * that stays reads exactly the table state the serial walk would see.  The first lane that finds anything
- * ends the step; only lanes up to it write their index to the tables.
+ * global workspace and a position costs dependent trips to memory: input -> table slots -> candidates.  The
+ * next positions of the walk are known in advance as long as nothing is found (same step while
+ * (ip - anchor) >> 8 is unchanged), so a step takes up to 64 of them at once, one per lane (32 by default:
+ * measured best), and pays those trips once.  A lane must see what earlier lanes of the same step wrote to
+ * its slots; instead of resolving that, the step is cut short in front of the first lane that could share a
+ * slot with an earlier one (a small LDS array indexed by the slot's low bits, marked with lane numbers, finds
+ * those -- conservatively), so every lane that stays reads exactly the table state the serial walk would
+ * see.  The first lane that finds anything ends the step; only lanes up to it write their index to the
+ * tables.  Per sequence the trips are: table slots -> the three candidates at once -> match extension both
+ * ways at once -> one tail trip (complementary insertions, immediate-repeat check, the next step's input and
+ * the next literal run together).  The long-table lookup at ip+1 that follows a short hit is the next lane's
+ * own lookup when the step is 1, so it costs no trip.
+ * Measured (65536 x 128 KiB text-like rows, one MI355X): level 3 7.2 GB/s, level 4 3.3 GB/s (three times
+ * the sequences); about 9-13 thousand cycles per sequence, shared between memory latency and the rate of
+ * scattered accesses the 1792 waves in flight put on HBM (tables: 0.4-2 MiB per wave, far beyond L2/MALL).
  */
 #pragma once
 
@@ -47,21 +54,43 @@ __device__ inline uint32_t wave_min_u32(uint32_t v)
     return uni(v);
 }
 
-/* how many bytes before a and b are equal, at most lim (the library's catch-up loop, 64 bytes per step) */
-__device__ inline uint32_t count_back(const uint8_t *a, const uint8_t *b, uint32_t lim, uint32_t lane)
+/* forward and backward extension of a match in one trip to memory: bytes equal from fa/fb on (limited by
+ * end) and bytes equal before ba/bb (at most blim: the library's catch-up loop); 64 bytes per step each */
+__device__ inline void count_both(const uint8_t *fa, const uint8_t *fb, const uint8_t *end, const uint8_t *ba,
+                                  const uint8_t *bb, uint32_t blim, uint32_t lane, uint32_t &fwd, uint32_t &back)
 {
-    uint32_t done = 0;
-    for (;;) {
-        const uint32_t k = done + lane;
-        const bool eq = k < lim && a[-1 - (int)k] == b[-1 - (int)k];
-        const unsigned long long neq = __ballot(!eq);
-        if (neq != 0ull) return done + ctz64(neq);
-        done += 64u;
+    const bool fin = fa + lane < end, bin = lane < blim;
+    uint32_t x0 = 0, x1 = 1, y0 = 0, y1 = 1;
+    if (fin) { x0 = fa[lane]; x1 = fb[lane]; }
+    if (bin) { y0 = ba[-1 - (int)lane]; y1 = bb[-1 - (int)lane]; }
+    const unsigned long long fne = __ballot(x0 != x1), bne = __ballot(y0 != y1);
+    fwd = fne ? ctz64(fne) : 64u;
+    back = bne ? ctz64(bne) : 64u;
+    if (!fne) {
+        uint32_t done = 64u;
+        for (;;) {
+            const bool inb = fa + done + lane < end;
+            const bool eq = inb && fa[done + lane] == fb[done + lane];
+            const unsigned long long neq = __ballot(!eq);
+            if (neq != 0ull) { fwd = done + ctz64(neq); break; }
+            done += 64u;
+        }
+    }
+    if (!bne) {
+        uint32_t done = 64u;
+        for (;;) {
+            const uint32_t k = done + lane;
+            const bool eq = k < blim && ba[-1 - (int)k] == bb[-1 - (int)k];
+            const unsigned long long neq = __ballot(!eq);
+            if (neq != 0ull) { back = done + ctz64(neq); break; }
+            done += 64u;
+        }
     }
 }
 
-/* marks `slot` with the lane number; returns the lowest lane that shares a marked slot with another lane (64: none) */
-__device__ inline uint32_t first_shared_slot(uint8_t *mark, uint32_t slot, bool on, uint32_t lane)
+/* marks `slot` with the lane number; returns how many leading lanes have slots no earlier lane shares
+ * (conservative: slots are the table slots' low bits) */
+__device__ inline uint32_t distinct_prefix(uint8_t *mark, uint32_t slot, bool on, uint32_t lane)
 {
     if (on) mark[slot] = (uint8_t)lane;
     asm volatile("" ::: "memory"); /* the read below must come from LDS, not from this lane's own store */
@@ -69,14 +98,38 @@ __device__ inline uint32_t first_shared_slot(uint8_t *mark, uint32_t slot, bool 
     const uint32_t r = on ? (uint32_t)mark[slot] : lane;
     asm volatile("" ::: "memory");
     __builtin_amdgcn_wave_barrier();
-    return wave_min_u32(r != lane ? (r < lane ? r : lane) : 64u);
+    const unsigned long long losers = __ballot(r != lane);
+    if (!losers) return 64u;
+    /* lanes in front of the first loser have distinct slots; the first loser itself is fine when the lane that
+     * won its slot comes later */
+    const uint32_t l = ctz64(losers);
+    return (uint32_t)__builtin_amdgcn_readlane(r, l) > l ? l + 1u : l;
 }
 
-/* ZSTD_compressBlock_doubleFast.  Indexes are the library's (base = src - 1: the first input byte is 1). */
+/* literal run of a sequence into the block's literal buffer: the first 64 bytes were loaded ahead (litv) */
+__device__ inline void store_seq_pre(uint8_t *ws, SeqStore &ss, uint32_t ll, uint32_t litv, const uint8_t *lit,
+                                     uint32_t offcode, uint32_t mlbase, uint32_t lane)
+{
+    uint8_t *lits = ws + kWsLit;
+    if (lane < ll) lits[ss.nlit + lane] = (uint8_t)litv;
+    for (uint32_t i = 64u + lane; i < ll; i += 64u) lits[ss.nlit + i] = lit[i];
+    ss.nlit += ll;
+    if (ll > 0xFFFFu) { ss.long_kind = 1; ss.long_pos = ss.nseq; }
+    if (mlbase > 0xFFFFu) { ss.long_kind = 2; ss.long_pos = ss.nseq; }
+    if (lane == 0) reinterpret_cast<uint2 *>(ws + kWsSeq)[ss.nseq] = make_uint2(offcode + 1u, (ll & 0xFFFFu) | (mlbase << 16));
+    ss.nseq++;
+}
+
+/* ZSTD_compressBlock_doubleFast.  Indexes are the library's (base = src - 1: the first input byte is 1).
+ * Trips to memory per sequence: [input of the step, loaded with the previous sequence's tail] -> table slots
+ * -> candidates (repeat offset, long, short: one trip, branch-free) -> match extension both ways -> tail
+ * (complementary insertions, immediate repeat check, next step's input, next literal run). */
 __device__ uint32_t block_dfast_batch(uint32_t *tl, uint32_t *ts, uint8_t *mark, const CPar &cp, const uint8_t *base,
                                       const uint8_t *istart, uint32_t n, uint32_t *rep, uint8_t *ws, SeqStore &ss,
-                                      uint32_t dict_limit, uint32_t lane)
+                                      uint32_t dict_limit, uint32_t lane, uint32_t W = 64, unsigned long long *prof = nullptr)
 {
+    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pn[3] = {0, 0, 0}, t0 = prof ? __builtin_amdgcn_s_memtime() : 0; /* CRYO_ZSTD_STATS */
+#define DFT(k) do { if (prof) { const unsigned long long t = __builtin_amdgcn_s_memtime(); pt[k] += t - t0; t0 = t; } } while (0)
     const int hl = cp.hlog, hs = cp.clog, mls = cp.mml < 4 ? 4 : (cp.mml > 7 ? 7 : cp.mml);
     uint32_t ip = (uint32_t)(istart - base), anchor = ip;
     const uint32_t iend = ip + n, ilimit = iend - 8u;
@@ -90,90 +143,130 @@ __device__ uint32_t block_dfast_batch(uint32_t *tl, uint32_t *ts, uint8_t *mark,
         if (off2 > max_rep) { saved = off2; off2 = 0; }
         if (off1 > max_rep) { saved = off1; off1 = 0; }
     }
+    uint32_t litv = anchor + lane < iend ? base[anchor + lane] : 0u; /* literal bytes anchor .. anchor+63 */
+    uint64_t v8n = 0;    /* input of the next step, when loaded ahead */
+    bool have = false;
     while (ip < ilimit) {
         const uint32_t st = ((ip - anchor) >> 8) + 1u;
         const uint32_t p = ip + lane * st;
-        bool valid = p < ilimit && ((p - anchor) >> 8) + 1u == st;
-        const uint64_t v8 = valid ? ld64v(base + p) : 0ull;
+        bool valid = lane < W && p < ilimit && ((p - anchor) >> 8) + 1u == st;
+        const uint64_t v8 = have ? v8n : (valid ? ld64v(base + p) : 0ull);
+        have = false;
         const uint32_t h2 = hash8_v(v8, hl), h = hashs_v(v8, hs, mls);
+        if (prof) asm volatile("" :: "v"(h2), "v"(h));
+        DFT(0);
         {
-            const uint32_t f1 = first_shared_slot(mark, h2 & (kDfMark - 1u), valid, lane);
-            const uint32_t f2 = first_shared_slot(mark, h & (kDfMark - 1u), valid, lane);
-            const uint32_t f = f1 < f2 ? f1 : f2;
-            valid = valid && lane <= f;
+            const uint32_t n1 = distinct_prefix(mark, h2 & (kDfMark - 1u), valid, lane);
+            const uint32_t n2 = distinct_prefix(mark, h & (kDfMark - 1u), valid, lane);
+            valid = valid && lane < (n1 < n2 ? n1 : n2);
         }
+        DFT(1);
         const uint32_t cl = valid ? tl[h2] : 0u, cs = valid ? ts[h] : 0u;
-        const bool rephit = valid && off1 > 0u && ld32v(base + p + 1u - off1) == (uint32_t)(v8 >> 8);
-        const bool longhit = valid && cl > prefix_idx && ld64v(base + cl) == v8;
-        const bool shorthit = valid && cs > prefix_idx && ld32v(base + cs) == (uint32_t)v8;
+        if (prof) asm volatile("" :: "v"(cl), "v"(cs));
+        DFT(2);
+        /* the three candidates in one trip: addresses of lanes that have no candidate point at ip */
+        const bool rc = valid && off1 > 0u, lc = valid && cl > prefix_idx, sc = valid && cs > prefix_idx;
+        const uint32_t rv = ld32v(base + (rc ? p + 1u - off1 : ip));
+        const uint64_t lv = ld64v(base + (lc ? cl : ip));
+        const uint32_t sv = ld32v(base + (sc ? cs : ip));
+        const bool rephit = rc && rv == (uint32_t)(v8 >> 8);
+        const bool longhit = lc && lv == v8;
+        const bool shorthit = sc && sv == (uint32_t)v8;
+        const unsigned long long validm = __ballot(valid);
         const unsigned long long repm = __ballot(rephit), longm = __ballot(longhit);
         const unsigned long long hitm = repm | longm | __ballot(shorthit);
         const uint32_t T = hitm ? ctz64(hitm) : 63u;
-        const uint32_t ncommit = hitm ? T + 1u : (uint32_t)__builtin_popcountll(__ballot(valid));
+        const uint32_t ncommit = hitm ? T + 1u : (uint32_t)__builtin_popcountll(validm);
+        DFT(3);
         if (lane < ncommit) { tl[h2] = p; ts[h] = p; }
+        pn[0]++; pn[1] += ncommit;
         if (!hitm) { ip += ncommit * st; continue; }
+        pn[2]++;
 
         const uint32_t cur = __builtin_amdgcn_readlane(p, T);
-        uint32_t mlen;
+        uint32_t mlen, ll, offcode;
         if ((repm >> T) & 1ull) {
             ip = cur + 1u;
             mlen = count_match(base + ip + 4u, base + ip + 4u - off1, base + iend, lane) + 4u;
-            store_seq(ws, ss, ip - anchor, base + anchor, 0, mlen - 3u, lane);
+            offcode = 0;
         } else {
-            uint32_t m;
+            uint32_t m, known;
             if ((longm >> T) & 1ull) {
                 m = __builtin_amdgcn_readlane(cl, T);
                 ip = cur;
-                mlen = count_match(base + ip + 8u, base + m + 8u, base + iend, lane) + 8u;
+                known = 8u;
             } else {
-                const uint64_t v9 = ld64u(base + cur + 1u);
-                const uint32_t hl3 = hash8_v(v9, hl);
-                const uint32_t mil3 = uni(tl[hl3]); /* after this step's own writes, as in the library */
-                if (lane == 0) tl[hl3] = cur + 1u;
-                if (mil3 > prefix_idx && ld64u(base + mil3) == v9) {
-                    m = mil3;
-                    ip = cur + 1u;
-                    mlen = count_match(base + ip + 8u, base + m + 8u, base + iend, lane) + 8u;
+                /* long table at ip+1.  With step 1 the next lane has read that slot and compared its candidate already
+                 * (its slot differs from every slot written by this step); otherwise look it up now */
+                uint32_t hl3, mil3;
+                bool hit3;
+                if (st == 1u && T < 63u && ((validm >> (T + 1u)) & 1ull)) {
+                    hl3 = __builtin_amdgcn_readlane(h2, T + 1u);
+                    mil3 = __builtin_amdgcn_readlane(cl, T + 1u);
+                    hit3 = (longm >> (T + 1u)) & 1ull;
                 } else {
-                    m = __builtin_amdgcn_readlane(cs, T);
-                    ip = cur;
-                    mlen = count_match(base + ip + 4u, base + m + 4u, base + iend, lane) + 4u;
+                    const uint64_t v9 = ld64u(base + cur + 1u);
+                    hl3 = hash8_v(v9, hl);
+                    mil3 = uni(tl[hl3]); /* after this step's own writes, as in the library */
+                    hit3 = mil3 > prefix_idx && ld64u(base + mil3) == v9;
                 }
+                if (lane == 0) tl[hl3] = cur + 1u;
+                if (hit3) { m = mil3; ip = cur + 1u; known = 8u; }
+                else { m = __builtin_amdgcn_readlane(cs, T); ip = cur; known = 4u; }
             }
             const uint32_t offset = ip - m;
             const uint32_t la = ip - anchor, lm = m - prefix_idx;
-            const uint32_t back = count_back(base + ip, base + m, la < lm ? la : lm, lane);
+            uint32_t fwd, back;
+            count_both(base + ip + known, base + m + known, base + iend, base + ip, base + m, la < lm ? la : lm, lane, fwd, back);
+            mlen = known + fwd + back;
             ip -= back;
-            mlen += back;
             off2 = off1;
             off1 = offset;
-            store_seq(ws, ss, ip - anchor, base + anchor, offset + 2u, mlen - 3u, lane);
+            offcode = offset + 2u;
         }
+        DFT(4);
+        ll = ip - anchor;
+        const uint32_t seq_anchor = anchor;
         ip += mlen;
         anchor = ip;
-        if (ip <= ilimit) {
-            const uint32_t ins = cur + 2u;
-            const uint64_t va = ld64u(base + ins), vb = ld64u(base + ip - 2u), vc = ld64u(base + ip - 1u);
-            if (lane == 0) {
-                tl[hash8_v(va, hl)] = ins;
-                tl[hash8_v(vb, hl)] = ip - 2u;
-                ts[hashs_v(va, hs, mls)] = ins;
-                ts[hashs_v(vc, hs, mls)] = ip - 1u;
-            }
-            while (ip <= ilimit && off2 > 0u && ld32u(base + ip) == ld32u(base + ip - off2)) {
-                const uint32_t rlen = count_match(base + ip + 4u, base + ip + 4u - off2, base + iend, lane) + 4u;
-                const uint32_t t = off2; off2 = off1; off1 = t;
+        /* tail: complementary insertions once, then immediate repeats (offset_2) as long as they match; every
+         * round loads the literal bytes and the search input at the new anchor with its other loads */
+        bool first = true;
+        if (ip > ilimit) store_seq_pre(ws, ss, ll, litv, base + seq_anchor, offcode, mlen - 3u, lane);
+        while (ip <= ilimit) {
+            const bool nv = lane < W && ip + lane < ilimit;
+            v8n = nv ? ld64v(base + ip + lane) : 0ull;
+            const uint32_t litn = ip + lane < iend ? base[ip + lane] : 0u;
+            const uint32_t r0 = ld32u(base + ip), r1 = off2 > 0u ? ld32u(base + ip - off2) : 0u;
+            if (first) {
+                const uint32_t ins = cur + 2u;
+                const uint64_t va = ld64u(base + ins), vb = ld64u(base + ip - 2u), vc = ld64u(base + ip - 1u);
+                /* the sequence's own stores go behind the loads of this round */
+                store_seq_pre(ws, ss, ll, litv, base + seq_anchor, offcode, mlen - 3u, lane);
                 if (lane == 0) {
-                    const uint64_t v = ld64v(base + ip);
-                    ts[hashs_v(v, hs, mls)] = ip;
-                    tl[hash8_v(v, hl)] = ip;
+                    tl[hash8_v(va, hl)] = ins;
+                    tl[hash8_v(vb, hl)] = ip - 2u;
+                    ts[hashs_v(va, hs, mls)] = ins;
+                    ts[hashs_v(vc, hs, mls)] = ip - 1u;
                 }
-                store_seq(ws, ss, 0, base + anchor, 0, rlen - 3u, lane);
-                ip += rlen;
-                anchor = ip;
+                first = false;
             }
+            litv = litn;
+            if (!(off2 > 0u && r0 == r1)) { have = true; break; }
+            const uint32_t rlen = count_match(base + ip + 4u, base + ip + 4u - off2, base + iend, lane) + 4u;
+            const uint32_t t = off2; off2 = off1; off1 = t;
+            {
+                const uint64_t v = ld64u(base + ip);
+                if (lane == 0) { ts[hashs_v(v, hs, mls)] = ip; tl[hash8_v(v, hl)] = ip; }
+            }
+            store_seq_pre(ws, ss, 0, 0, base + anchor, 0, rlen - 3u, lane);
+            ip += rlen;
+            anchor = ip;
         }
+        DFT(6);
     }
+    if (prof && lane == 0) { for (int k = 0; k < 8; k++) atomicAdd(&prof[8 + k], pt[k]); for (int k = 0; k < 3; k++) atomicAdd(&prof[16 + k], pn[k]); }
+#undef DFT
     rep[0] = off1 ? off1 : saved;
     rep[1] = off2 ? off2 : saved;
     return iend - anchor;

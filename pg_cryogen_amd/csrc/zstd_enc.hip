@@ -1267,7 +1267,7 @@ __global__ void __launch_bounds__(64)
 k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t n_blocks,
            uint8_t *__restrict__ dst_base, uint64_t dst_stride, int wlog, int hlog, int mml, int tlen,
            uint32_t *__restrict__ out_size, int32_t *__restrict__ status, uint8_t *workspace,
-           unsigned long long *stats, int clog = 0, uint64_t ws_stride = kWsBytes)
+           unsigned long long *stats, int clog = 0, uint64_t ws_stride = kWsBytes, uint32_t df_w = 32)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
     /* BATCH: the entropy stage's tables share LDS with the match finder's ring + table (dead while it runs;
@@ -1348,7 +1348,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_other += t - t_prev; t_prev = t; }
                 uint32_t last_ll;
                 if constexpr (BATCH) last_ll = block_fast_batch(ring, ptab, cp, ip, bs, nrep, ws, ss, dict_limit, lane);
-                else if constexpr (DF) last_ll = block_dfast_batch(table, tshort, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane);
+                else if constexpr (DF) last_ll = block_dfast_batch(table, tshort, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, df_w, stats);
                 else last_ll = block_fast(table, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane);
                 if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mf += t - t_prev; t_prev = t; }
                 for (uint32_t i = lane; i < last_ll; i += 64u) (ws + kWsLit)[ss.nlit + i] = src[ip + bs - last_ll + i];
@@ -1476,7 +1476,8 @@ static uint32_t zstd_dfast_grid(uint64_t n_blocks)
 {
     uint64_t per_cu = (160u * 1024u) / zstd_dfast_lds();
     if (per_cu > 8) per_cu = 8;
-    const uint64_t cap = 256u * per_cu;
+    static const uint64_t grid_env = getenv("CRYO_DFAST_GRID") ? (uint64_t)atoll(getenv("CRYO_DFAST_GRID")) : 0; /* tuning aid */
+    const uint64_t cap = grid_env ? grid_env : 256u * per_cu;
     return (uint32_t)(n_blocks < cap ? n_blocks : cap);
 }
 static size_t zstd_dfast_stride(int hlog, int clog) { return kWsBytes + (((size_t)4u << hlog) + ((size_t)4u << clog)); }
@@ -1504,26 +1505,25 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
     int wlog, hlog, mml, tlen, clog;
     bool dfast = false;
     if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast)) return hipErrorNotSupported;
-    if (dfast) {
-        const uint32_t grid = zstd_dfast_grid(n_blocks);
-        const size_t stride = zstd_dfast_stride(hlog, clog);
-        if (workspace_bytes < (size_t)grid * stride) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((k_zstd_enc<false, false, true>), dim3(grid), dim3(64), zstd_dfast_lds(), s, d_src, src_stride,
-                           block_size, n_blocks, d_dst, dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status,
-                           (uint8_t *)d_workspace, (unsigned long long *)nullptr, clog, (uint64_t)stride);
-        return hipGetLastError();
-    }
-    const bool batch = zstd_enc_batch(hlog);
+    const bool batch = !dfast && zstd_enc_batch(hlog);
     const bool bit = batch && block_size <= (128u << 10);
-    const uint32_t grid = zstd_enc_grid(n_blocks, batch, hlog, bit);
-    if (workspace_bytes < (size_t)grid * kWsBytes) return hipErrorInvalidValue;
+    const uint32_t grid = dfast ? zstd_dfast_grid(n_blocks) : zstd_enc_grid(n_blocks, batch, hlog, bit);
+    const size_t stride = dfast ? zstd_dfast_stride(hlog, clog) : kWsBytes;
+    if (workspace_bytes < (size_t)grid * stride) return hipErrorInvalidValue;
     static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
-    unsigned long long *d_st = nullptr, h_st[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long *d_st = nullptr, h_st[24] = {0};
     if (want_stats) {
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
     }
-    if (batch && bit)
+    /* dfast: search positions per step.  32 measured best on text-like rows (16: 6.6, 32: 7.4, 64: 6.9 GB/s at level 3):
+     * wider steps read table slots for positions behind the first match, narrower ones pay more trips per sequence */
+    static const uint32_t df_w = getenv("CRYO_DFAST_W") ? (uint32_t)atoi(getenv("CRYO_DFAST_W")) : 32u; /* tuning aid */
+    if (dfast)
+        hipLaunchKernelGGL((k_zstd_enc<false, false, true>), dim3(grid), dim3(64), zstd_dfast_lds(), s, d_src, src_stride,
+                           block_size, n_blocks, d_dst, dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status,
+                           (uint8_t *)d_workspace, d_st, clog, (uint64_t)stride, df_w);
+    else if (batch && bit)
         hipLaunchKernelGGL((k_zstd_enc<true, true>), dim3(grid), dim3(64), zstd_enc_dyn_lds(hlog, true), s, d_src, src_stride,
                            block_size, n_blocks, d_dst, dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status,
                            (uint8_t *)d_workspace, d_st);
@@ -1545,6 +1545,16 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
                         "huffman encode %.1f%%  sequence codes+tables %.1f%%  FSE encode %.1f%%\n",
                 100.0 * h_st[3] / h_st[1], 100.0 * h_st[4] / h_st[1], 100.0 * h_st[5] / h_st[1], 100.0 * h_st[6] / h_st[1],
                 100.0 * h_st[7] / h_st[1]);
+        if (dfast) {
+            double t = 0;
+            for (int k = 8; k < 16; k++) t += (double)h_st[k];
+            fprintf(stderr, "[zstd enc cycles] dfast finder: input+hash %.1f%%  dup filter %.1f%%  table gather %.1f%%  candidates %.1f%%  "
+                            "match (count, lookups) %.1f%%  store_seq %.1f%%  inserts+rep loop %.1f%% | steps %llu, positions/step %.1f, "
+                            "steps/sequence %.2f, cycles/sequence %.0f\n",
+                    100.0 * h_st[8] / t, 100.0 * h_st[9] / t, 100.0 * h_st[10] / t, 100.0 * h_st[11] / t, 100.0 * h_st[12] / t,
+                    100.0 * h_st[13] / t, 100.0 * h_st[14] / t, h_st[16], (double)h_st[17] / h_st[16], (double)h_st[16] / h_st[18],
+                    t / h_st[18]);
+        }
     }
     return hipGetLastError();
 }

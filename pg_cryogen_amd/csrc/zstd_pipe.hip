@@ -950,11 +950,11 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     if (y.nbmax > 254u) y.nbmax = 254u;
     y.litcap = ((B + 15u) & ~15u) + 16u * y.nbmax;
     const size_t per_frame = sizeof(ZFrame) + (size_t)y.nbmax * (sizeof(ZBlk) + kHufTblWords * 2u + kSeqTblWords * 4u + 4u) +
-                             y.litcap + (size_t)B /* sequence pool share: B/16 records */ + 4u;
+                             y.litcap + (size_t)(B / 6u) * sizeof(uint4) /* sequence pool share */ + 4u;
     /* Tile size.  K2 and K3 are bound by LDS capacity (two workgroups per CU, 512 per chip): 7680 frames
      * = 512 x 15 (K3) = 480 x 16 (K2) fill exactly one round of each; the workspace budget may force less. */
     static const size_t budget_env = getenv("CRYO_ZSTD_WS_MB") ? (size_t)atoll(getenv("CRYO_ZSTD_WS_MB")) << 20 : 0; /* tuning aid */
-    const size_t budget = budget_env ? budget_env : (size_t)6 << 30; /* per tile in flight; reached only by blocks > 128 KiB,
+    const size_t budget = budget_env ? budget_env : (size_t)10 << 30; /* per tile in flight; reached only by blocks > 128 KiB,
                                                                         whose tiles would otherwise be too few frames to fill K1/K4 */
     uint64_t F = budget / per_frame;
     if (F > 7680u) F = 7680u;
@@ -962,7 +962,9 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     else if (F < 16u) F = 16u;
     if (F > n_blocks) F = n_blocks;
     y.F = (uint32_t)F;
-    uint64_t seqcap = (uint64_t)y.F * (B / 16u) + 4096u;
+    /* sequence records: a share of B/6 per frame (levels 4..9 reach B/8 on text-like rows; the format allows B/3:
+     * frames that do not fit the pool go to the irregular list) */
+    uint64_t seqcap = (uint64_t)y.F * (B / 6u) + 4096u;
     if (seqcap > 0xFFFF0000ull) seqcap = 0xFFFF0000ull;
     y.seqcap = (uint32_t)seqcap;
     size_t o = 0;
