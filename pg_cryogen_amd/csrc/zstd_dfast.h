@@ -30,7 +30,7 @@
  */
 #pragma once
 
-constexpr uint32_t kDfMark = 8192; /* slots of the duplicate filter (bytes of LDS) */
+constexpr uint32_t kDfMark = 4096; /* slots of the duplicate filter (bytes of LDS) */
 
 __device__ inline uint64_t ld64v(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ inline uint32_t ld32v(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
@@ -267,6 +267,134 @@ __device__ uint32_t block_dfast_batch(uint32_t *tl, uint32_t *ts, uint8_t *mark,
     }
     if (prof && lane == 0) { for (int k = 0; k < 8; k++) atomicAdd(&prof[8 + k], pt[k]); for (int k = 0; k < 3; k++) atomicAdd(&prof[16 + k], pn[k]); }
 #undef DFT
+    rep[0] = off1 ? off1 : saved;
+    rep[1] = off2 ? off2 : saved;
+    return iend - anchor;
+}
+
+/* marks two slots per lane (read-then-written by one iteration of the `fast` walk); returns how many leading
+ * lanes have slots no earlier lane shares.  A lane's own two slots may coincide (the walk reads both before it
+ * writes either, and the second write wins: the stores below keep that order). */
+__device__ inline uint32_t distinct_prefix2(uint8_t *mark, uint32_t slot0, uint32_t slot1, bool on, uint32_t lane)
+{
+    if (on) mark[slot0] = (uint8_t)lane;
+    asm volatile("" ::: "memory");
+    if (on) mark[slot1] = (uint8_t)lane;
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t r0 = on ? (uint32_t)mark[slot0] : lane, r1 = on ? (uint32_t)mark[slot1] : lane;
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned long long losers = __ballot(r0 != lane || r1 != lane);
+    if (!losers) return 64u;
+    const uint32_t l = ctz64(losers);
+    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane(r0, l), w1 = (uint32_t)__builtin_amdgcn_readlane(r1, l);
+    return (w0 >= l && w1 >= l) ? l + 1u : l; /* the first loser stays when the lanes that won its slots come later */
+}
+
+/* ZSTD_compressBlock_fast over a table in global memory (hashLog > 14: level 2), many iterations of the search
+ * loop per step -- the scheme of block_dfast_batch: an iteration looks at ip0 and ip1 = ip0 + 1 (reads both
+ * slots, then writes both) and tests the repeat offset at ip0 + 2, then ip0, then ip1; no hit: both advance by
+ * ((ip0 - anchor) >> 7) + stepSize.  (zstd_enc.hip's block_fast_batch does the same over an LDS table for
+ * hashLog <= 14.) */
+__device__ uint32_t block_fast_gbatch(uint32_t *table, uint8_t *mark, const CPar &cp, const uint8_t *base,
+                                      const uint8_t *istart, uint32_t n, uint32_t *rep, uint8_t *ws, SeqStore &ss,
+                                      uint32_t dict_limit, uint32_t lane, uint32_t W)
+{
+    const int hlog = cp.hlog, mls = cp.mml < 4 ? 4 : (cp.mml > 7 ? 7 : cp.mml);
+    const uint32_t step_size = (uint32_t)cp.tlen + (cp.tlen ? 0u : 1u) + 1u;
+    uint32_t ip = (uint32_t)(istart - base), anchor = ip;
+    const uint32_t iend = ip + n, ilimit = iend - 8u;
+    const uint32_t max_dist = 1u << cp.wlog;
+    const uint32_t prefix_idx = (iend - dict_limit > max_dist) ? iend - max_dist : dict_limit;
+    uint32_t off1 = rep[0], off2 = rep[1], saved = 0;
+    if (ip == prefix_idx) ip++;
+    {
+        const uint32_t wlow = (ip - dict_limit > max_dist) ? ip - max_dist : dict_limit;
+        const uint32_t max_rep = ip - wlow;
+        if (off2 > max_rep) { saved = off2; off2 = 0; }
+        if (off1 > max_rep) { saved = off1; off1 = 0; }
+    }
+    uint32_t litv = anchor + lane < iend ? base[anchor + lane] : 0u;
+    uint64_t v0n = 0, v1n = 0;
+    bool have = false;
+    while (ip + 1u < ilimit) { /* ip is the walk's ip0; ip1 = ip0 + 1 */
+        const uint32_t st = ((ip - anchor) >> 7) + step_size;
+        const uint32_t i0 = ip + lane * st;
+        bool valid = lane < W && i0 + 1u < ilimit && ((i0 - anchor) >> 7) + step_size == st;
+        const uint64_t v0 = have ? v0n : (valid ? ld64v(base + i0) : 0ull);
+        const uint64_t v1 = have ? v1n : (valid ? ld64v(base + i0 + 1u) : 0ull);
+        have = false;
+        const uint32_t h0 = hashs_v(v0, hlog, mls), h1 = hashs_v(v1, hlog, mls);
+        valid = valid && lane < distinct_prefix2(mark, h0 & (kDfMark - 1u), h1 & (kDfMark - 1u), valid, lane);
+        const uint32_t mi0 = valid ? table[h0] : 0u, mi1 = valid ? table[h1] : 0u;
+        /* candidates in one trip; lanes without one read at ip.  rv: the byte in front of the repeat candidate, then its 4 bytes */
+        const bool rc = valid && off1 > 0u, c0 = valid && mi0 > prefix_idx, c1 = valid && mi1 > prefix_idx;
+        const uint64_t rv = ld64v(base + (rc ? i0 + 1u - off1 : ip));
+        const uint32_t s0 = ld32v(base + (c0 ? mi0 : ip)), s1 = ld32v(base + (c1 ? mi1 : ip));
+        const bool rephit = rc && (uint32_t)(rv >> 8) == (uint32_t)(v1 >> 8);
+        const bool hit0 = c0 && s0 == (uint32_t)v0, hit1 = c1 && s1 == (uint32_t)v1;
+        const unsigned long long repm = __ballot(rephit), m0m = __ballot(hit0);
+        const unsigned long long hitm = repm | m0m | __ballot(hit1);
+        const uint32_t T = hitm ? ctz64(hitm) : 63u;
+        const uint32_t ncommit = hitm ? T + 1u : (uint32_t)__builtin_popcountll(__ballot(valid));
+        if (lane < ncommit) table[h0] = i0;
+        asm volatile("" ::: "memory");
+        if (lane < ncommit) table[h1] = i0 + 1u;
+        if (!hitm) { ip += ncommit * st; continue; }
+
+        const uint32_t cur0 = __builtin_amdgcn_readlane(i0, T);
+        uint32_t mlen, offcode;
+        if ((repm >> T) & 1ull) {
+            const uint32_t rlo = __builtin_amdgcn_readlane((uint32_t)rv, T), vlo = __builtin_amdgcn_readlane((uint32_t)v1, T);
+            const uint32_t b = ((rlo ^ vlo) & 0xFFu) == 0u ? 1u : 0u; /* ip2[-1] == repMatch[-1] */
+            ip = cur0 + 2u - b;
+            mlen = 4u + b;
+            mlen += count_match(base + ip + mlen, base + ip - off1 + mlen, base + iend, lane);
+            offcode = 0;
+        } else {
+            uint32_t m;
+            if ((m0m >> T) & 1ull) { ip = cur0; m = __builtin_amdgcn_readlane(mi0, T); }
+            else { ip = cur0 + 1u; m = __builtin_amdgcn_readlane(mi1, T); }
+            off2 = off1;
+            off1 = ip - m;
+            offcode = off1 + 2u;
+            const uint32_t la = ip - anchor, lm = m - prefix_idx;
+            uint32_t fwd, back;
+            count_both(base + ip + 4u, base + m + 4u, base + iend, base + ip, base + m, la < lm ? la : lm, lane, fwd, back);
+            mlen = 4u + fwd + back;
+            ip -= back;
+        }
+        const uint32_t ll = ip - anchor, seq_anchor = anchor;
+        ip += mlen;
+        anchor = ip;
+        bool first = true;
+        if (ip > ilimit) store_seq_pre(ws, ss, ll, litv, base + seq_anchor, offcode, mlen - 3u, lane);
+        while (ip <= ilimit) {
+            const bool nv = lane < W && ip + lane * step_size + 1u < ilimit;
+            v0n = nv ? ld64v(base + ip + lane * step_size) : 0ull;
+            v1n = nv ? ld64v(base + ip + lane * step_size + 1u) : 0ull;
+            const uint32_t litn = ip + lane < iend ? base[ip + lane] : 0u;
+            const uint32_t r0 = ld32u(base + ip), r1 = off2 > 0u ? ld32u(base + ip - off2) : 0u;
+            if (first) {
+                const uint64_t va = ld64u(base + cur0 + 2u), vb = ld64u(base + ip - 2u);
+                store_seq_pre(ws, ss, ll, litv, base + seq_anchor, offcode, mlen - 3u, lane);
+                if (lane == 0) { table[hashs_v(va, hlog, mls)] = cur0 + 2u; table[hashs_v(vb, hlog, mls)] = ip - 2u; }
+                first = false;
+            }
+            litv = litn;
+            if (!(off2 > 0u && r0 == r1)) { have = true; break; }
+            const uint32_t rlen = count_match(base + ip + 4u, base + ip + 4u - off2, base + iend, lane) + 4u;
+            const uint32_t t = off2; off2 = off1; off1 = t;
+            {
+                const uint64_t v = ld64u(base + ip);
+                if (lane == 0) table[hashs_v(v, hlog, mls)] = ip;
+            }
+            store_seq_pre(ws, ss, 0, 0, base + anchor, 0, rlen - 3u, lane);
+            ip += rlen;
+            anchor = ip;
+        }
+    }
     rep[0] = off1 ? off1 : saved;
     rep[1] = off2 ? off2 : saved;
     return iend - anchor;

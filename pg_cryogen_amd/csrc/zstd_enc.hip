@@ -1260,8 +1260,9 @@ __device__ uint32_t block_fast_batch(RingIn<kW> &r, const PosTab<BIT> &tab, cons
 
 } // namespace
 
-/* BATCH: the `fast` finder over the LDS ring + compact LDS table; DF: the `dfast` finder over two global
- * tables behind the workgroup's workspace; neither: the serial `fast` finder (hashLog > 14, testing aid) */
+/* BATCH: the `fast` finder over the LDS ring + compact LDS table (hashLog <= 14); DF: finders over u32 tables in
+ * global memory behind the workgroup's workspace: `dfast` (clog > 0: two tables) or `fast` with hashLog > 14
+ * (clog == 0); neither: the serial `fast` finder (testing aid, CRYO_ZSTD_ENC=1) */
 template <bool BATCH, bool BIT, bool DF = false>
 __global__ void __launch_bounds__(64)
 k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t n_blocks,
@@ -1294,7 +1295,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         __shared__ uint32_t hash_lds[8192];
         table = (hlog <= 13) ? hash_lds : reinterpret_cast<uint32_t *>(ws + kWsHash);
     }
-    uint32_t *tshort = DF ? table + (1u << hlog) : nullptr;
+    uint32_t *tshort = DF ? table + (1u << hlog) : nullptr; /* dfast (clog > 0) only */
     uint8_t *df_mark = dyn_lds + sizeof(EncLds); /* DF only */
 
     for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
@@ -1306,7 +1307,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
             ring.open(dyn_lds, src, n, lane);
             ring.ensure(kZW);
         } else if constexpr (DF) {
-            const uint32_t quads = ((1u << hlog) + (1u << clog)) / 4u;
+            const uint32_t quads = ((1u << hlog) + (clog ? 1u << clog : 0u)) / 4u;
             for (uint32_t i = lane; i < quads; i += 64u) reinterpret_cast<uint4 *>(table)[i] = make_uint4(0, 0, 0, 0);
         } else {
             for (uint32_t i = lane; i < (1u << hlog); i += 64u) table[i] = 0;
@@ -1333,7 +1334,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         const uint8_t *base = src - 1;
         bool first = true;
         HufState hs;
-        hs.prev_valid = false; hs.next_new = false; hs.prof = stats; hs.t = 0; hs.strat = DF ? 2u : 1u;
+        hs.prev_valid = false; hs.next_new = false; hs.prof = stats; hs.t = 0; hs.strat = (DF && clog) ? 2u : 1u;
         uint32_t ip = 0;
         while (ip < n) {
             const uint32_t bs = (n - ip < kZBlk) ? n - ip : kZBlk;
@@ -1348,7 +1349,10 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_other += t - t_prev; t_prev = t; }
                 uint32_t last_ll;
                 if constexpr (BATCH) last_ll = block_fast_batch(ring, ptab, cp, ip, bs, nrep, ws, ss, dict_limit, lane);
-                else if constexpr (DF) last_ll = block_dfast_batch(table, tshort, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, df_w, stats);
+                else if constexpr (DF) {
+                    if (clog) last_ll = block_dfast_batch(table, tshort, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, df_w, stats);
+                    else last_ll = block_fast_gbatch(table, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, df_w);
+                }
                 else last_ll = block_fast(table, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane);
                 if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mf += t - t_prev; t_prev = t; }
                 for (uint32_t i = lane; i < last_ll; i += 64u) (ws + kWsLit)[ss.nlit + i] = src[ip + bs - last_ll + i];
@@ -1480,15 +1484,16 @@ static uint32_t zstd_dfast_grid(uint64_t n_blocks)
     const uint64_t cap = grid_env ? grid_env : 256u * per_cu;
     return (uint32_t)(n_blocks < cap ? n_blocks : cap);
 }
-static size_t zstd_dfast_stride(int hlog, int clog) { return kWsBytes + (((size_t)4u << hlog) + ((size_t)4u << clog)); }
+static size_t zstd_dfast_stride(int hlog, int clog) { return kWsBytes + (((size_t)4u << hlog) + (clog ? (size_t)4u << clog : 0u)); }
 
 size_t zstd_compress_workspace(uint64_t n_blocks, int level, uint32_t block_size)
 {
     int wlog, hlog, mml, tlen, clog;
     bool dfast = false;
-    if (zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast) && dfast)
-        return (size_t)zstd_dfast_grid(n_blocks) * zstd_dfast_stride(hlog, clog) + 256;
-    return (size_t)zstd_enc_grid(n_blocks, true, 10, true) * kWsBytes + 256;
+    const size_t lds_path = (size_t)zstd_enc_grid(n_blocks, true, 10, true) * kWsBytes + 256;
+    if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast)) return lds_path;
+    const size_t gtab_path = (size_t)zstd_dfast_grid(n_blocks) * zstd_dfast_stride(hlog, dfast ? clog : 0) + 256;
+    return gtab_path > lds_path ? gtab_path : lds_path; /* whichever finder the launch picks */
 }
 
 bool zstd_compress_supported(int level, uint32_t block_size)
@@ -1505,10 +1510,14 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
     int wlog, hlog, mml, tlen, clog;
     bool dfast = false;
     if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast)) return hipErrorNotSupported;
-    const bool batch = !dfast && zstd_enc_batch(hlog);
+    static const bool serial_only = getenv("CRYO_ZSTD_ENC") && getenv("CRYO_ZSTD_ENC")[0] == '1'; /* testing aid */
+    static const int gtab_min = getenv("CRYO_ZSTD_GTAB_MIN") ? atoi(getenv("CRYO_ZSTD_GTAB_MIN")) : 0; /* tuning aid */
+    const bool gtab = dfast || (hlog >= gtab_min && !serial_only); /* tables in global memory */
+    if (!dfast) clog = 0;
+    const bool batch = !gtab && zstd_enc_batch(hlog);
     const bool bit = batch && block_size <= (128u << 10);
-    const uint32_t grid = dfast ? zstd_dfast_grid(n_blocks) : zstd_enc_grid(n_blocks, batch, hlog, bit);
-    const size_t stride = dfast ? zstd_dfast_stride(hlog, clog) : kWsBytes;
+    const uint32_t grid = gtab ? zstd_dfast_grid(n_blocks) : zstd_enc_grid(n_blocks, batch, hlog, bit);
+    const size_t stride = gtab ? zstd_dfast_stride(hlog, clog) : kWsBytes;
     if (workspace_bytes < (size_t)grid * stride) return hipErrorInvalidValue;
     static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
     unsigned long long *d_st = nullptr, h_st[24] = {0};
@@ -1518,8 +1527,9 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
     }
     /* dfast: search positions per step.  32 measured best on text-like rows (16: 6.6, 32: 7.4, 64: 6.9 GB/s at level 3):
      * wider steps read table slots for positions behind the first match, narrower ones pay more trips per sequence */
-    static const uint32_t df_w = getenv("CRYO_DFAST_W") ? (uint32_t)atoi(getenv("CRYO_DFAST_W")) : 32u; /* tuning aid */
-    if (dfast)
+    static const uint32_t df_w_env = getenv("CRYO_DFAST_W") ? (uint32_t)atoi(getenv("CRYO_DFAST_W")) : 0u; /* tuning aid */
+    const uint32_t df_w = df_w_env ? df_w_env : (dfast ? 32u : 16u); /* `fast` iterations look at two positions each */
+    if (gtab)
         hipLaunchKernelGGL((k_zstd_enc<false, false, true>), dim3(grid), dim3(64), zstd_dfast_lds(), s, d_src, src_stride,
                            block_size, n_blocks, d_dst, dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status,
                            (uint8_t *)d_workspace, d_st, clog, (uint64_t)stride, df_w);
