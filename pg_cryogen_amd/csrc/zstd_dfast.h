@@ -1,12 +1,13 @@
 /*
- * zstd_dfast.h -- the `dfast` strategy's match finder (libzstd 1.4.8 ZSTD_compressBlock_doubleFast, no
- * dictionary; zstd levels 3 and 4 at cryo block sizes), many search positions per step.  Included by
- * zstd_enc.hip inside its namespace; the entropy stage behind it is the one the `fast` levels use.
+ * zstd_dfast.h -- the match finders of zstd's `dfast` and `fast` strategies (libzstd 1.4.8
+ * ZSTD_compressBlock_doubleFast / ZSTD_compressBlock_fast, no dictionary; levels 3, 4 and -5..2 at cryo
+ * block sizes) over tables in global memory, many search positions per step.  Included by zstd_enc.hip
+ * inside its namespace, in front of the entropy stage.
  *
  * Replaces the match-finding half of ZSTD_compress(dst, bound, src, B, level) (reference
- * compression.c:102-104) for level 3 / 4; restated for the CPU in oracle/zstd_enc_oracle.c (block_dfast).
+ * compression.c:102-104); restated for the CPU in oracle/zstd_enc_oracle.c (block_dfast, block_fast).
  *
- * The algorithm: a long table hashed on 8 bytes and a short one hashed on minMatch bytes; every visited
+ * dfast: a long table hashed on 8 bytes and a short one hashed on minMatch bytes; every visited
  * position reads its slot of both, then writes its own index to both.  Tests in order: repeat offset at
  * ip+1, long candidate at ip (8 bytes equal), short candidate at ip (4 bytes equal; then the long table is
  * also tried at ip+1 and wins if it matches).  No hit: ip += ((ip - anchor) >> 8) + 1.

@@ -1,29 +1,30 @@
 /*
  * zstd_enc.hip -- Zstandard frame encode, one wavefront per cryo block, output bytes identical
- * to libzstd 1.4.8 for the levels whose strategy is `fast` (levels -5 .. 2 at cryo block
- * sizes; the reference's default zstd_compression_level_guc = 1 is one of them).
+ * to libzstd 1.4.8 for the levels whose strategy is `fast` or `dfast` (levels -5 .. 4 at cryo
+ * block sizes; the reference's default zstd_compression_level_guc = 1 is one of them).
  *
  * Replaces ZSTD_compress(dst, ZSTD_compressBound(B), src, B, level)
  * (reference compression.c:102-104).
  *
  * Pipeline per 128 KiB zstd block (a 1 MiB cryo block is a frame of 8 dependent blocks):
- *   match finder  : the `fast` strategy's 2-positions-per-step hash probe with repeat-offset
- *                   checks.  A serial recurrence over one hash table, so it runs wave-uniform;
- *                   lanes co-operate on match extension (64 bytes/step, ballot + ctz) and on
- *                   copying literal runs into the block's literal buffer.
+ *   match finder  : strategy `fast` (levels -5..2) or `dfast` (3, 4), zstd_dfast.h: the walk is a serial
+ *                   recurrence over hash tables that do not fit LDS next to the entropy stage, so the
+ *                   tables live in global memory and a step takes the next 16-32 search positions at
+ *                   once, one per lane, paying the trips to memory (table slots, candidates, match
+ *                   extension, tail) once per step; a serial restatement (block_fast) is kept as a
+ *                   testing aid.
  *   literals      : histogram by LDS atomics (all lanes), length-limited Huffman tree
  *                   (serial, <= 256 symbols), weights FSE-compressed or raw, then the 4
- *                   backward bitstreams encoded by lanes 0..3 in parallel at offsets known
- *                   from a first pass that only sums code lengths.
+ *                   backward bitstreams: all 64 lanes per stream (runs of symbols, bit offsets by scan).
  *   sequences     : codes + histograms lane-parallel; encoding-type choice, FSE normalisation,
- *                   table description and the interleaved LL/OF/ML bitstream are serial.
+ *                   table description serial; the interleaved LL/OF/ML bitstream reads 64 sequences
+ *                   at a time into lanes.
  *   block         : raw fallback when the gain is below size/64 + 2, RLE block for constant
  *                   non-first blocks, repeat offsets / Huffman table state carried over only
  *                   by blocks emitted compressed.
- * Hash table: LDS when hashLog <= 13 (level 1 at 128 KiB), else a per-workgroup global table.
- * Sequences, literals and codes of the block live in a per-workgroup global workspace.
+ * Sequences, literals, codes and the finder's tables live in a per-workgroup global workspace.
  */
-#include "enc_ring.h"
+#include "lz_common.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -42,9 +43,7 @@ constexpr size_t kWsLit = kWsSeq + (size_t)kMaxSeq * 8u;        /* literals     
 constexpr size_t kWsLlc = kWsLit + kZBlk + 64u;                 /* LL / OF / ML codes                */
 constexpr size_t kWsOfc = kWsLlc + kMaxSeq;
 constexpr size_t kWsMlc = kWsOfc + kMaxSeq;
-constexpr size_t kWsHash = (kWsMlc + kMaxSeq + 255u) & ~(size_t)255u; /* u32 x 65536 (hashLog <= 16) */
-constexpr size_t kWsPrev = kWsHash + 65536u * 4u;                 /* previous block's Huffman table (batch kernel) */
-constexpr size_t kWsBytes = kWsPrev + 1024u;
+constexpr size_t kWsBytes = (kWsMlc + kMaxSeq + 255u) & ~(size_t)255u; /* the match finder's u32 table(s) follow */
 
 struct FseCt {
     uint16_t state[512];
@@ -996,321 +995,37 @@ __device__ uint32_t block_fast(uint32_t *table, const CPar &cp, const uint8_t *b
 }
 
 
-/* ------------------------------------------------------------------------------------------------
- * ZSTD_compressBlock_fast, 64 iterations per step (same idea as lz4_enc2.hip): the iterations of the
- * search loop whose step is the same -- (ip0 - anchor) >> 7 unchanged -- are taken by the lanes at once.
- * Each iteration reads its two table slots and then writes them; a lane reads what the latest earlier
- * lane wrote to the same slot, found by marking the slots' low halves with the lane number.  The first
- * iteration that finds anything (repeat offset at ip0+2, then ip0, then ip0+1, the library's order) ends
- * the batch, and only the iterations up to it are committed.  Input comes from the LDS ring (enc_ring.h),
- * positions are byte offsets in the frame's input, table entries are index = position + 1 as in the
- * library (base = src - 1), kept as u16 low | u8 high.
- */
-constexpr uint32_t kZW = 2048; /* input ring */
-
-/* BIT: indices below 2^17 (frames up to 128 KiB) keep bit 16 in a bitmap (LDS atomics), which brings a
- * 2^13-entry table to 17 KiB; otherwise a byte per entry (indices below 2^24) */
-template <bool BIT>
-struct PosTab {
-    uint16_t *lo;
-    uint8_t *hi;
-    __device__ inline uint32_t get(uint32_t h) const
-    {
-        if constexpr (BIT) return (uint32_t)lo[h] | (((reinterpret_cast<const uint32_t *>(hi)[h >> 5] >> (h & 31u)) & 1u) << 16);
-        else return (uint32_t)lo[h] | ((uint32_t)hi[h] << 16);
-    }
-    __device__ inline void put(uint32_t h, uint32_t v) const
-    {
-        lo[h] = (uint16_t)v;
-        if constexpr (BIT) {
-            uint32_t *w = reinterpret_cast<uint32_t *>(hi) + (h >> 5);
-            const uint32_t bit = 1u << (h & 31u);
-            if ((v >> 16) & 1u) atomicOr(w, bit); else atomicAnd(w, ~bit);
-        } else hi[h] = (uint8_t)(v >> 16);
-    }
-    static __host__ __device__ inline uint32_t bytes(int hlog) { return BIT ? (2u << hlog) + ((1u << hlog) >> 3) : (3u << hlog); }
-};
-
-/* ZSTD_hashPtr on the 8 bytes (lo, hi) read at a position */
-__device__ inline uint32_t hash_v(uint32_t lo, uint32_t hi, int hlog, int mls)
-{
-    if (mls == 4) return (lo * 2654435761u) >> (32 - hlog);
-    uint32_t x_lo, x_hi, c_lo, c_hi;
-    if (mls == 5) { x_lo = lo << 24; x_hi = (lo >> 8) | (hi << 24); c_lo = 0x1BBCDCBBu; c_hi = 0xCFu; }
-    else if (mls == 6) { x_lo = lo << 16; x_hi = (lo >> 16) | (hi << 16); c_lo = 0xBCDCBF9Bu; c_hi = 0xCF1Bu; }
-    else { x_lo = lo << 8; x_hi = (lo >> 24) | (hi << 8); c_lo = 0xDCBFA563u; c_hi = 0xCF1BBCu; }
-    const uint32_t top = __umulhi(x_lo, c_lo) + x_lo * c_hi + x_hi * c_lo;
-    return top >> (32 - hlog);
-}
-
-template <uint32_t kW>
-__device__ inline void rd64_any(const RingIn<kW> &r, uint32_t p, uint32_t &lo, uint32_t &hi)
-{
-    if (p >= r.lo_pos()) {
-        const uint32_t d0 = r.dw(p, 0), d1 = r.dw(p, 1), d2 = r.dw(p, 2), s = p & 3u;
-        lo = __builtin_amdgcn_alignbyte(d1, d0, s);
-        hi = __builtin_amdgcn_alignbyte(d2, d1, s);
-    } else {
-        uint64_t v;
-        __builtin_memcpy(&v, r.src + p, 8);
-        lo = (uint32_t)v; hi = (uint32_t)(v >> 32);
-    }
-}
-
-/* bytes equal from positions a / b forward, a limited by end (64 bytes per step) */
-template <uint32_t kW>
-__device__ inline uint32_t count_match_r(RingIn<kW> &r, uint32_t a, uint32_t b, uint32_t end, uint32_t lane)
-{
-    uint32_t done = 0;
-    for (;;) {
-        r.ensure(a + done + 64u);
-        const bool inb = a + done + lane < end;
-        const bool eq = inb && r.byte_any(a + done + lane) == r.byte_any(b + done + lane);
-        const unsigned long long neq = __ballot(!eq);
-        if (neq != 0ull) return done + ctz64(neq);
-        done += 64u;
-    }
-}
-
-template <uint32_t kW>
-__device__ inline void store_seq_r(const RingIn<kW> &r, uint8_t *ws, SeqStore &ss, uint32_t ll, uint32_t lit_pos, uint32_t offcode,
-                                   uint32_t mlbase, uint32_t lane)
-{
-    uint8_t *lits = ws + kWsLit;
-    for (uint32_t i = lane; i < ll; i += 64u) lits[ss.nlit + i] = (uint8_t)r.byte_any(lit_pos + i);
-    ss.nlit += ll;
-    if (ll > 0xFFFFu) { ss.long_kind = 1; ss.long_pos = ss.nseq; }
-    if (mlbase > 0xFFFFu) { ss.long_kind = 2; ss.long_pos = ss.nseq; }
-    if (lane == 0) reinterpret_cast<uint2 *>(ws + kWsSeq)[ss.nseq] = make_uint2(offcode + 1u, (ll & 0xFFFFu) | (mlbase << 16));
-    ss.nseq++;
-}
-
-/* istart, n: the zstd block inside the frame's input (positions); returns the length of the last literals */
-template <uint32_t kW, bool BIT>
-__device__ uint32_t block_fast_batch(RingIn<kW> &r, const PosTab<BIT> &tab, const CPar &cp, uint32_t istart, uint32_t n,
-                                     uint32_t *rep, uint8_t *ws, SeqStore &ss, uint32_t dict_limit, uint32_t lane)
-{
-    const int hlog = cp.hlog, mls = cp.mml < 4 ? 4 : (cp.mml > 7 ? 7 : cp.mml);
-    const uint32_t step_size = (uint32_t)cp.tlen + (cp.tlen ? 0u : 1u) + 1u;
-    const uint32_t end_index = istart + 1u + n;
-    const uint32_t max_dist = 1u << cp.wlog;
-    const uint32_t prefix_idx = (end_index - dict_limit > max_dist) ? end_index - max_dist : dict_limit;
-    const uint32_t prefix_pos = prefix_idx - 1u;
-    const uint32_t iend = istart + n, ilimit = iend - 8u;
-    const unsigned long long lt_mask = lane ? (~0ull >> (64u - lane)) : 0ull;
-    uint32_t ip0 = istart, anchor = istart;
-    uint32_t off1 = rep[0], off2 = rep[1], saved = 0;
-    if (ip0 == prefix_pos) ip0++;
-    {
-        const uint32_t cur = ip0 + 1u;
-        const uint32_t wlow = (cur - dict_limit > max_dist) ? cur - max_dist : dict_limit;
-        const uint32_t max_rep = cur - wlow;
-        if (off2 > max_rep) { saved = off2; off2 = 0; }
-        if (off1 > max_rep) { saved = off1; off1 = 0; }
-    }
-    while (ip0 + 1u < ilimit) {
-        /* ---------------- one batch: iterations k = 0 .. T-1 at ip0 + k * st ---------------- */
-        const uint32_t c = (ip0 - anchor) >> 7;
-        const uint32_t st = c + step_size;
-        const uint32_t p0 = ip0 + lane * st;
-        const bool stop = (((p0 - anchor) >> 7) != c) || !(p0 + 1u < ilimit) || !(p0 + 16u <= ip0 + (kW - kEncStage));
-        const unsigned long long stopm = __ballot(stop);
-        const uint32_t T = stopm ? ctz64(stopm) : 64u; /* >= 1: lane 0 never stops */
-        const bool valid = lane < T;
-        r.ensure(ip0 + (T - 1u) * st + 12u);
-        uint32_t lo = 0, hi = 0, h0 = 0, h1 = 0, mi0 = 0, mi1 = 0;
-        if (valid) {
-            const uint32_t d0 = r.dw(p0, 0), d1 = r.dw(p0, 1), d2 = r.dw(p0, 2), s = p0 & 3u;
-            lo = __builtin_amdgcn_alignbyte(d1, d0, s);
-            hi = __builtin_amdgcn_alignbyte(d2, d1, s);
-            h0 = hash_v(lo, hi, hlog, mls);
-            h1 = hash_v((lo >> 8) | (hi << 24), hi >> 8, hlog, mls);
-            mi0 = tab.get(h0);
-            mi1 = tab.get(h1); /* both read before either store, as the library does */
-            tab.lo[h0] = (uint16_t)lane; /* owner marks; the real low halves are in mi0 / mi1 and come back below */
-            tab.lo[h1] = (uint16_t)lane;
-        }
-        const uint32_t v0 = lo, v1 = (lo >> 8) | (hi << 24), v2 = (lo >> 16) | (hi << 16);
-        unsigned long long grouped = 0ull;
-        {
-            asm volatile("" ::: "memory"); /* the read-back must see what the WAVE wrote */
-            bool lost0 = valid && tab.lo[h0] != (uint16_t)lane;
-            bool lost1 = valid && tab.lo[h1] != (uint16_t)lane;
-            asm volatile("" ::: "memory");
-            if (valid) { tab.lo[h0] = (uint16_t)mi0; tab.lo[h1] = (uint16_t)mi1; }
-            unsigned long long losers = __ballot(lost0 || lost1);
-            while (losers) {
-                const uint32_t j = ctz64(losers);
-                const uint32_t hv = lane_get(lost0 ? h0 : h1, j);
-                const unsigned long long G0 = __ballot(valid && h0 == hv), G1 = __ballot(valid && h1 == hv);
-                const unsigned long long GE = G0 | G1;
-                const unsigned long long below = GE & lt_mask;
-                const uint32_t pj = below ? 63u - (uint32_t)__builtin_clzll(below) : lane;
-                /* the latest earlier iteration that wrote this slot: its ip1 store comes after its ip0 store */
-                const uint32_t val = ip0 + pj * st + 1u + (uint32_t)((G1 >> pj) & 1ull);
-                if (valid && below) {
-                    if (h0 == hv) mi0 = val;
-                    if (h1 == hv) mi1 = val;
-                }
-                if (h0 == hv) lost0 = false;
-                if (h1 == hv) lost1 = false;
-                grouped |= GE;
-                losers = __ballot(lost0 || lost1);
-            }
-        }
-        /* ---- what each iteration finds: repeat offset at ip0+2, match at ip0, match at ip0+1 ---- */
-        const uint32_t aR = p0 + 2u - off1, aA = mi0 - 1u, aB = mi1 - 1u;
-        const bool cR = valid && off1 > 0u, cA = valid && mi0 > prefix_idx, cB = valid && mi1 > prefix_idx;
-        const uint32_t lop = r.lo_pos();
-        const bool nR = aR >= lop, nA = aA >= lop, nB = aB >= lop;
-        bool hR = cR && nR && r.rd32(aR) == v2;
-        bool hA = cA && nA && r.rd32(aA) == v0;
-        bool hB = cB && nB && r.rd32(aB) == v1;
-        {
-            const unsigned long long hm_near = __ballot(hR || hA || hB);
-            const uint32_t first = hm_near ? ctz64(hm_near) : 64u;
-            const bool anyfar = (cR && !nR) || (cA && !nA) || (cB && !nB);
-            const unsigned long long far = __ballot(anyfar) & (first >= 63u ? ~0ull : ((2ull << first) - 1ull));
-            if (far) { /* older than the ring: global memory, only for iterations that can still come first */
-                if ((far >> lane) & 1ull) {
-                    uint32_t v;
-                    if (cR && !nR) { __builtin_memcpy(&v, r.src + aR, 4); hR = v == v2; }
-                    if (cA && !nA) { __builtin_memcpy(&v, r.src + aA, 4); hA = v == v0; }
-                    if (cB && !nB) { __builtin_memcpy(&v, r.src + aB, 4); hB = v == v1; }
-                }
-            }
-        }
-        const unsigned long long hm = __ballot(hR || hA || hB);
-        const uint32_t K = hm ? ctz64(hm) + 1u : T;
-        /* commit iterations 0 .. K-1 (ip0 store, then ip1 store); colliding ones one by one, ascending */
-        if (lane < K && !((grouped >> lane) & 1ull)) { tab.put(h0, p0 + 1u); tab.put(h1, p0 + 2u); }
-        {
-            unsigned long long g = grouped & (K >= 64u ? ~0ull : ((1ull << K) - 1ull));
-            while (g) {
-                const uint32_t j = ctz64(g);
-                if (lane == j) { tab.put(h0, p0 + 1u); tab.put(h1, p0 + 2u); }
-                g &= g - 1ull;
-            }
-        }
-        if (!hm) { ip0 += T * st; continue; }
-
-        /* ---------------- the match of iteration m = K-1 ---------------- */
-        const uint32_t m = K - 1u;
-        const uint32_t P0 = ip0 + m * st;
-        const bool kR = lane_get((uint32_t)hR, m) != 0u, kA = lane_get((uint32_t)hA, m) != 0u;
-        uint32_t mpos, mlen, offcode;
-        if (kR) {
-            const uint32_t ip2 = P0 + 2u, rp = ip2 - off1;
-            mlen = (uni(r.byte_any(ip2 - 1u)) == uni(r.byte_any(rp - 1u))) ? 1u : 0u;
-            ip0 = ip2 - mlen;
-            mpos = rp - mlen;
-            mlen += 4u;
-            offcode = 0;
-        } else {
-            if (kA) { ip0 = P0; mpos = lane_get(mi0, m) - 1u; }
-            else { ip0 = P0 + 1u; mpos = lane_get(mi1, m) - 1u; }
-            off2 = off1;
-            off1 = ip0 - mpos;
-            offcode = off1 + 2u;
-            mlen = 4u;
-            uint32_t room = ip0 - anchor < mpos - prefix_pos ? ip0 - anchor : mpos - prefix_pos;
-            while (room) { /* backwards, 64 bytes per step */
-                const bool in = lane < room;
-                const bool eq = in && r.byte_any(ip0 - 1u - lane) == r.byte_any(mpos - 1u - lane);
-                const unsigned long long neq = __ballot(!eq);
-                const uint32_t cb = neq ? ctz64(neq) : 64u;
-                ip0 -= cb; mpos -= cb; mlen += cb;
-                if (cb < 64u) break;
-                room -= 64u;
-            }
-        }
-        mlen += count_match_r(r, ip0 + mlen, mpos + mlen, iend, lane);
-        store_seq_r(r, ws, ss, ip0 - anchor, anchor, offcode, mlen - 3u, lane);
-        ip0 += mlen;
-        anchor = ip0;
-        if (ip0 <= ilimit) {
-            r.ensure(ip0 + 12u);
-            uint32_t a_lo, a_hi, b_lo, b_hi;
-            rd64_any(r, P0 + 2u, a_lo, a_hi);
-            tab.put(uni(hash_v(a_lo, a_hi, hlog, mls)), P0 + 3u);          /* base + current0 + 2 */
-            rd64_any(r, ip0 - 2u, b_lo, b_hi);
-            tab.put(uni(hash_v(b_lo, b_hi, hlog, mls)), ip0 - 1u);         /* ip0 - 2 */
-            if (off2 > 0u) {
-                while (ip0 <= ilimit) {
-                    r.ensure(ip0 + 12u);
-                    uint32_t c_lo, c_hi;
-                    rd64_any(r, ip0, c_lo, c_hi);
-                    if (uni(c_lo) != uni(r.rd32_any(ip0 - off2))) break;
-                    const uint32_t rlen = count_match_r(r, ip0 + 4u, ip0 + 4u - off2, iend, lane) + 4u;
-                    const uint32_t t = off2; off2 = off1; off1 = t;
-                    tab.put(uni(hash_v(c_lo, c_hi, hlog, mls)), ip0 + 1u);
-                    ip0 += rlen;
-                    store_seq_r(r, ws, ss, 0, anchor, 0, rlen - 3u, lane);
-                    anchor = ip0;
-                }
-            }
-        }
-    }
-    rep[0] = off1 ? off1 : saved;
-    rep[1] = off2 ? off2 : saved;
-    return iend - anchor;
-}
-
 #include "zstd_dfast.h"
 
 } // namespace
 
-/* BATCH: the `fast` finder over the LDS ring + compact LDS table (hashLog <= 14); DF: finders over u32 tables in
- * global memory behind the workgroup's workspace: `dfast` (clog > 0: two tables) or `fast` with hashLog > 14
- * (clog == 0); neither: the serial `fast` finder (testing aid, CRYO_ZSTD_ENC=1) */
-template <bool BATCH, bool BIT, bool DF = false>
+/* One wave per frame, persistent grid.  The match finder's tables (u32, zeroed per frame) live in global memory
+ * behind the workgroup's workspace: long/only table, then dfast's short table.  finder: 0 = `fast`, many
+ * iterations per step (block_fast_gbatch); 1 = `dfast` (block_dfast_batch); 2 = `fast`, the serial walk
+ * (block_fast: the plain restatement, CRYO_ZSTD_ENC=1). */
 __global__ void __launch_bounds__(64)
 k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t n_blocks,
-           uint8_t *__restrict__ dst_base, uint64_t dst_stride, int wlog, int hlog, int mml, int tlen,
-           uint32_t *__restrict__ out_size, int32_t *__restrict__ status, uint8_t *workspace,
-           unsigned long long *stats, int clog = 0, uint64_t ws_stride = kWsBytes, uint32_t df_w = 32)
+           uint8_t *__restrict__ dst_base, uint64_t dst_stride, int wlog, int hlog, int clog, int mml, int tlen,
+           int finder, uint32_t width, uint32_t *__restrict__ out_size, int32_t *__restrict__ status,
+           uint8_t *workspace, uint64_t ws_stride, unsigned long long *stats)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t dyn_lds[];
-    /* BATCH: the entropy stage's tables share LDS with the match finder's ring + table (dead while it runs;
-     * for frames of several blocks the table is parked in the workspace meanwhile) */
-    EncLds *Lp;
-    if constexpr (BATCH || DF) Lp = reinterpret_cast<EncLds *>(dyn_lds);
-    else { __shared__ EncLds L_static; Lp = &L_static; }
-    EncLds &L = *Lp;
+    __shared__ EncLds L;
+    __shared__ __attribute__((aligned(16))) uint8_t df_mark[kDfMark];
     unsigned long long t_mf = 0, t_en = 0, t_other = 0, t_prev = stats ? __builtin_amdgcn_s_memtime() : 0; /* CRYO_ZSTD_STATS */
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *ws = workspace + (uint64_t)blockIdx.x * ws_stride;
     CPar cp;
     cp.wlog = wlog; cp.clog = clog; cp.hlog = hlog; cp.mml = mml; cp.tlen = tlen;
-    /* match-finder table: BATCH: u16 | u8 entries in dynamic LDS behind the input ring (hashLog <= 14);
-     * serial: u32 in LDS when hashLog <= 13, else in the workgroup's workspace */
-    uint32_t *table = nullptr;
-    PosTab<BIT> ptab = {nullptr, nullptr};
-    if constexpr (BATCH) {
-        ptab.lo = reinterpret_cast<uint16_t *>(dyn_lds + kZW);
-        ptab.hi = dyn_lds + kZW + (2u << hlog); /* bytes, or the bitmap (4-byte aligned: 2 KiB + 2^(hlog+1)) */
-    } else if constexpr (DF) {
-        table = reinterpret_cast<uint32_t *>(ws + kWsBytes); /* long table, then the short one */
-    } else {
-        __shared__ uint32_t hash_lds[8192];
-        table = (hlog <= 13) ? hash_lds : reinterpret_cast<uint32_t *>(ws + kWsHash);
-    }
-    uint32_t *tshort = DF ? table + (1u << hlog) : nullptr; /* dfast (clog > 0) only */
-    uint8_t *df_mark = dyn_lds + sizeof(EncLds); /* DF only */
+    const bool dfast = finder == 1;
+    uint32_t *table = reinterpret_cast<uint32_t *>(ws + kWsBytes);
+    uint32_t *tshort = table + (1u << hlog); /* dfast only */
 
     for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         const uint8_t *src = src_base + blk * src_stride;
         uint8_t *dst = dst_base + blk * dst_stride;
-        RingIn<kZW> ring;
-        if constexpr (BATCH) {
-            for (uint32_t i = lane; i < PosTab<BIT>::bytes(hlog) / 16u; i += 64u) reinterpret_cast<uint4 *>(dyn_lds + kZW)[i] = make_uint4(0, 0, 0, 0);
-            ring.open(dyn_lds, src, n, lane);
-            ring.ensure(kZW);
-        } else if constexpr (DF) {
-            const uint32_t quads = ((1u << hlog) + (clog ? 1u << clog : 0u)) / 4u;
+        {
+            const uint32_t quads = ((1u << hlog) + (dfast ? 1u << clog : 0u)) / 4u;
             for (uint32_t i = lane; i < quads; i += 64u) reinterpret_cast<uint4 *>(table)[i] = make_uint4(0, 0, 0, 0);
-        } else {
-            for (uint32_t i = lane; i < (1u << hlog); i += 64u) table[i] = 0;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -1334,7 +1049,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         const uint8_t *base = src - 1;
         bool first = true;
         HufState hs;
-        hs.prev_valid = false; hs.next_new = false; hs.prof = stats; hs.t = 0; hs.strat = (DF && clog) ? 2u : 1u;
+        hs.prev_valid = false; hs.next_new = false; hs.prof = stats; hs.t = 0; hs.strat = dfast ? 2u : 1u;
         uint32_t ip = 0;
         while (ip < n) {
             const uint32_t bs = (n - ip < kZBlk) ? n - ip : kZBlk;
@@ -1348,24 +1063,13 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 uint32_t nrep[3] = {rep[0], rep[1], rep[2]};
                 if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_other += t - t_prev; t_prev = t; }
                 uint32_t last_ll;
-                if constexpr (BATCH) last_ll = block_fast_batch(ring, ptab, cp, ip, bs, nrep, ws, ss, dict_limit, lane);
-                else if constexpr (DF) {
-                    if (clog) last_ll = block_dfast_batch(table, tshort, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, df_w, stats);
-                    else last_ll = block_fast_gbatch(table, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, df_w);
-                }
+                if (finder == 1) last_ll = block_dfast_batch(table, tshort, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, width, stats);
+                else if (finder == 0) last_ll = block_fast_gbatch(table, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, width);
                 else last_ll = block_fast(table, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane);
                 if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mf += t - t_prev; t_prev = t; }
                 for (uint32_t i = lane; i < last_ll; i += 64u) (ws + kWsLit)[ss.nlit + i] = src[ip + bs - last_ll + i];
                 ss.nlit += last_ll;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                const bool more = ip + bs < n;
-                if constexpr (BATCH) {
-                    uint4 *park = reinterpret_cast<uint4 *>(ws + kWsHash);
-                    if (more) for (uint32_t i = lane; i < PosTab<BIT>::bytes(hlog) / 16u; i += 64u) park[i] = reinterpret_cast<const uint4 *>(dyn_lds + kZW)[i];
-                    __builtin_amdgcn_wave_barrier();
-                    if (hs.prev_valid) for (uint32_t i = lane; i < 256u; i += 64u) { L.pval[i] = reinterpret_cast<const uint16_t *>(ws + kWsPrev)[i]; L.pnb[i] = (ws + kWsPrev + 512u)[i]; }
-                    __builtin_amdgcn_wave_barrier();
-                }
                 if (stats) hs.t = __builtin_amdgcn_s_memtime();
                 csize = compress_sequences(L, dst + op + 3, ws, ss.nseq, ss.nlit, bs, ss.long_pos, ss.long_kind, hs,
                                            tlen > 0, lane);
@@ -1379,21 +1083,8 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 if (csize > 1u) {
                     rep[0] = nrep[0]; rep[1] = nrep[1]; rep[2] = nrep[2];
                     if (hs.next_new) {
-                        for (uint32_t i = lane; i < 256u; i += 64u) {
-                            L.pval[i] = L.hval[i]; L.pnb[i] = L.hnb[i];
-                            if constexpr (BATCH) { reinterpret_cast<uint16_t *>(ws + kWsPrev)[i] = L.hval[i]; (ws + kWsPrev + 512u)[i] = L.hnb[i]; }
-                        }
+                        for (uint32_t i = lane; i < 256u; i += 64u) { L.pval[i] = L.hval[i]; L.pnb[i] = L.hnb[i]; }
                         hs.prev_valid = true;
-                    }
-                }
-                if constexpr (BATCH) {
-                    if (more) { /* bring the table back, restart the ring at the next block */
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        const uint4 *park = reinterpret_cast<const uint4 *>(ws + kWsHash);
-                        for (uint32_t i = lane; i < PosTab<BIT>::bytes(hlog) / 16u; i += 64u) reinterpret_cast<uint4 *>(dyn_lds + kZW)[i] = park[i];
-                        ring.reopen(ip + bs);
-                        __builtin_amdgcn_wave_barrier();
                     }
                 }
             }
@@ -1449,51 +1140,24 @@ static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *
     return true;
 }
 
-static bool zstd_enc_batch(int hlog)
+/* workgroups per CU: LDS (entropy-stage tables + the finders' mark array) admits 8, and so do the registers */
+static uint32_t zstd_enc_grid(uint64_t n_blocks)
 {
-    static const bool serial_only = getenv("CRYO_ZSTD_ENC") && getenv("CRYO_ZSTD_ENC")[0] == '1'; /* testing aid */
-    return !serial_only && hlog <= 14;
-}
-
-static size_t zstd_enc_dyn_lds(int hlog, bool bit)
-{
-    const size_t t = kZW + (bit ? PosTab<true>::bytes(hlog) : PosTab<false>::bytes(hlog));
-    return t > sizeof(EncLds) ? t : sizeof(EncLds);
-}
-
-static uint32_t zstd_enc_grid(uint64_t n_blocks, bool batch, int hlog, bool bit = false)
-{
-    /* workgroups per CU by LDS: serial 2 (~47 KiB); batch: 14 KiB + ring + 3 bytes per table entry */
-    uint64_t per_cu = 2;
-    if (batch) {
-        per_cu = (160u * 1024u) / zstd_enc_dyn_lds(hlog, bit);
-        if (per_cu < 1) per_cu = 1;
-        if (per_cu > 8) per_cu = 8;
-    }
-    const uint64_t cap = 256u * per_cu;
-    return (uint32_t)(n_blocks < cap ? n_blocks : cap);
-}
-
-/* dfast: EncLds + the duplicate filter in LDS -> 7 workgroups per CU; two u32 tables behind each workspace */
-static size_t zstd_dfast_lds() { return sizeof(EncLds) + kDfMark; }
-static uint32_t zstd_dfast_grid(uint64_t n_blocks)
-{
-    uint64_t per_cu = (160u * 1024u) / zstd_dfast_lds();
+    uint64_t per_cu = (160u * 1024u) / (sizeof(EncLds) + kDfMark);
     if (per_cu > 8) per_cu = 8;
-    static const uint64_t grid_env = getenv("CRYO_DFAST_GRID") ? (uint64_t)atoll(getenv("CRYO_DFAST_GRID")) : 0; /* tuning aid */
+    static const uint64_t grid_env = getenv("CRYO_ZSTD_ENC_GRID") ? (uint64_t)atoll(getenv("CRYO_ZSTD_ENC_GRID")) : 0; /* tuning aid */
     const uint64_t cap = grid_env ? grid_env : 256u * per_cu;
     return (uint32_t)(n_blocks < cap ? n_blocks : cap);
 }
-static size_t zstd_dfast_stride(int hlog, int clog) { return kWsBytes + (((size_t)4u << hlog) + (clog ? (size_t)4u << clog : 0u)); }
+/* per workgroup: sequences, literals, codes (kWsBytes), then the match finder's table(s) */
+static size_t zstd_enc_stride(int hlog, int clog, bool dfast) { return kWsBytes + (((size_t)4u << hlog) + (dfast ? (size_t)4u << clog : 0u)); }
 
 size_t zstd_compress_workspace(uint64_t n_blocks, int level, uint32_t block_size)
 {
     int wlog, hlog, mml, tlen, clog;
     bool dfast = false;
-    const size_t lds_path = (size_t)zstd_enc_grid(n_blocks, true, 10, true) * kWsBytes + 256;
-    if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast)) return lds_path;
-    const size_t gtab_path = (size_t)zstd_dfast_grid(n_blocks) * zstd_dfast_stride(hlog, dfast ? clog : 0) + 256;
-    return gtab_path > lds_path ? gtab_path : lds_path; /* whichever finder the launch picks */
+    if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast)) return 256;
+    return (size_t)zstd_enc_grid(n_blocks) * zstd_enc_stride(hlog, clog, dfast) + 256;
 }
 
 bool zstd_compress_supported(int level, uint32_t block_size)
@@ -1510,14 +1174,15 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
     int wlog, hlog, mml, tlen, clog;
     bool dfast = false;
     if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast)) return hipErrorNotSupported;
-    static const bool serial_only = getenv("CRYO_ZSTD_ENC") && getenv("CRYO_ZSTD_ENC")[0] == '1'; /* testing aid */
-    static const int gtab_min = getenv("CRYO_ZSTD_GTAB_MIN") ? atoi(getenv("CRYO_ZSTD_GTAB_MIN")) : 0; /* tuning aid */
-    const bool gtab = dfast || (hlog >= gtab_min && !serial_only); /* tables in global memory */
-    if (!dfast) clog = 0;
-    const bool batch = !gtab && zstd_enc_batch(hlog);
-    const bool bit = batch && block_size <= (128u << 10);
-    const uint32_t grid = gtab ? zstd_dfast_grid(n_blocks) : zstd_enc_grid(n_blocks, batch, hlog, bit);
-    const size_t stride = gtab ? zstd_dfast_stride(hlog, clog) : kWsBytes;
+    static const bool serial_only = getenv("CRYO_ZSTD_ENC") && getenv("CRYO_ZSTD_ENC")[0] == '1'; /* testing aid: the serial `fast` walk */
+    const int finder = dfast ? 1 : (serial_only ? 2 : 0);
+    /* search positions (dfast) / iterations (fast: two positions each) per step.  Measured on text-like rows, GB/s:
+     * dfast level 3  16: 6.6  32: 7.4  64: 6.9;  fast level 1  16: 14.4  32: 13.9  64: 13.1 -- wider steps read
+     * table slots for positions behind the first match, narrower ones pay more trips per sequence */
+    static const uint32_t w_env = getenv("CRYO_ZSTD_ENC_WIDTH") ? (uint32_t)atoi(getenv("CRYO_ZSTD_ENC_WIDTH")) : 0u; /* tuning aid */
+    const uint32_t width = w_env ? w_env : (dfast ? 32u : 16u);
+    const uint32_t grid = zstd_enc_grid(n_blocks);
+    const size_t stride = zstd_enc_stride(hlog, clog, dfast);
     if (workspace_bytes < (size_t)grid * stride) return hipErrorInvalidValue;
     static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
     unsigned long long *d_st = nullptr, h_st[24] = {0};
@@ -1525,25 +1190,8 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
     }
-    /* dfast: search positions per step.  32 measured best on text-like rows (16: 6.6, 32: 7.4, 64: 6.9 GB/s at level 3):
-     * wider steps read table slots for positions behind the first match, narrower ones pay more trips per sequence */
-    static const uint32_t df_w_env = getenv("CRYO_DFAST_W") ? (uint32_t)atoi(getenv("CRYO_DFAST_W")) : 0u; /* tuning aid */
-    const uint32_t df_w = df_w_env ? df_w_env : (dfast ? 32u : 16u); /* `fast` iterations look at two positions each */
-    if (gtab)
-        hipLaunchKernelGGL((k_zstd_enc<false, false, true>), dim3(grid), dim3(64), zstd_dfast_lds(), s, d_src, src_stride,
-                           block_size, n_blocks, d_dst, dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status,
-                           (uint8_t *)d_workspace, d_st, clog, (uint64_t)stride, df_w);
-    else if (batch && bit)
-        hipLaunchKernelGGL((k_zstd_enc<true, true>), dim3(grid), dim3(64), zstd_enc_dyn_lds(hlog, true), s, d_src, src_stride,
-                           block_size, n_blocks, d_dst, dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status,
-                           (uint8_t *)d_workspace, d_st);
-    else if (batch)
-        hipLaunchKernelGGL((k_zstd_enc<true, false>), dim3(grid), dim3(64), zstd_enc_dyn_lds(hlog, false), s, d_src, src_stride,
-                           block_size, n_blocks, d_dst, dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status,
-                           (uint8_t *)d_workspace, d_st);
-    else
-        hipLaunchKernelGGL((k_zstd_enc<false, false>), dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst,
-                           dst_stride, wlog, hlog, mml, tlen, d_out_size, d_status, (uint8_t *)d_workspace, d_st);
+    hipLaunchKernelGGL(k_zstd_enc, dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride, wlog,
+                       hlog, clog, mml, tlen, finder, width, d_out_size, d_status, (uint8_t *)d_workspace, (uint64_t)stride, d_st);
     if (want_stats) {
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
@@ -1559,11 +1207,10 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
             double t = 0;
             for (int k = 8; k < 16; k++) t += (double)h_st[k];
             fprintf(stderr, "[zstd enc cycles] dfast finder: input+hash %.1f%%  dup filter %.1f%%  table gather %.1f%%  candidates %.1f%%  "
-                            "match (count, lookups) %.1f%%  store_seq %.1f%%  inserts+rep loop %.1f%% | steps %llu, positions/step %.1f, "
+                            "match (count, lookups) %.1f%%  tail (insertions, repeats, next input) %.1f%% | steps %llu, positions/step %.1f, "
                             "steps/sequence %.2f, cycles/sequence %.0f\n",
                     100.0 * h_st[8] / t, 100.0 * h_st[9] / t, 100.0 * h_st[10] / t, 100.0 * h_st[11] / t, 100.0 * h_st[12] / t,
-                    100.0 * h_st[13] / t, 100.0 * h_st[14] / t, h_st[16], (double)h_st[17] / h_st[16], (double)h_st[16] / h_st[18],
-                    t / h_st[18]);
+                    100.0 * h_st[14] / t, h_st[16], (double)h_st[17] / h_st[16], (double)h_st[16] / h_st[18], t / h_st[18]);
         }
     }
     return hipGetLastError();
