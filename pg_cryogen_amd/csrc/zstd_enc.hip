@@ -25,6 +25,7 @@
  * Sequences, literals, codes and the finder's tables live in a per-workgroup global workspace.
  */
 #include "lz_common.h"
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 
@@ -68,7 +69,7 @@ struct EncLds {
     uint32_t cumul[66];
     uint8_t cell[512];
     uint32_t seg_bits[4];
-    FseCt ll, of, ml, wt;
+    FseCt ll, of, ml;          /* ll doubles as the table of the Huffman weights (literals come before sequences) */
 };
 
 __device__ inline uint32_t hbit(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
@@ -431,25 +432,25 @@ __device__ uint32_t huf_compress_weights(EncLds &L, uint8_t *dst, uint32_t n)
     if (fse_normalize(L.norm, log, count, n, max_sym, false) <= 0) return 0;
     const uint32_t hsz = fse_write_ncount(dst, L.norm, max_sym, log);
     if (!hsz) return 0;
-    fse_build_ct(L.wt, L.norm, max_sym, log, L.cumul, L.cell);
+    fse_build_ct(L.ll, L.norm, max_sym, log, L.cumul, L.cell);
     if (n <= 2u) return 0;
     BitW b;
     b.init(dst + hsz);
     uint32_t ip = n, s1, s2;
     if (n & 1u) {
-        s1 = fse_init_state(L.wt, L.wts[--ip]);
-        s2 = fse_init_state(L.wt, L.wts[--ip]);
-        s1 = fse_encode(b, L.wt, s1, L.wts[--ip]);
+        s1 = fse_init_state(L.ll, L.wts[--ip]);
+        s2 = fse_init_state(L.ll, L.wts[--ip]);
+        s1 = fse_encode(b, L.ll, s1, L.wts[--ip]);
     } else {
-        s2 = fse_init_state(L.wt, L.wts[--ip]);
-        s1 = fse_init_state(L.wt, L.wts[--ip]);
+        s2 = fse_init_state(L.ll, L.wts[--ip]);
+        s1 = fse_init_state(L.ll, L.wts[--ip]);
     }
     while (ip > 0u) {
-        s2 = fse_encode(b, L.wt, s2, L.wts[--ip]);
-        s1 = fse_encode(b, L.wt, s1, L.wts[--ip]);
+        s2 = fse_encode(b, L.ll, s2, L.wts[--ip]);
+        s1 = fse_encode(b, L.ll, s1, L.wts[--ip]);
     }
-    b.add(s2, (uint32_t)L.wt.log);
-    b.add(s1, (uint32_t)L.wt.log);
+    b.add(s2, (uint32_t)L.ll.log);
+    b.add(s1, (uint32_t)L.ll.log);
     return hsz + b.close();
 }
 
@@ -1009,8 +1010,10 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
            int finder, uint32_t width, uint32_t *__restrict__ out_size, int32_t *__restrict__ status,
            uint8_t *workspace, uint64_t ws_stride, unsigned long long *stats)
 {
-    __shared__ EncLds L;
-    __shared__ __attribute__((aligned(16))) uint8_t df_mark[kDfMark];
+    __shared__ __attribute__((aligned(16))) EncLds L;
+    /* the finders' mark array lies over the entropy stage's scratch (histogram + tree nodes: dead while a finder runs) */
+    static_assert(offsetof(EncLds, nbyte) >= kDfMark, "mark array must stay inside the scratch part of EncLds");
+    uint8_t *df_mark = reinterpret_cast<uint8_t *>(&L);
     unsigned long long t_mf = 0, t_en = 0, t_other = 0, t_prev = stats ? __builtin_amdgcn_s_memtime() : 0; /* CRYO_ZSTD_STATS */
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *ws = workspace + (uint64_t)blockIdx.x * ws_stride;
@@ -1140,11 +1143,11 @@ static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *
     return true;
 }
 
-/* workgroups per CU: LDS (entropy-stage tables + the finders' mark array) admits 8, and so do the registers */
+/* workgroups per CU: LDS (entropy-stage tables; the finders' mark array lies inside) admits 11, the registers 12 */
 static uint32_t zstd_enc_grid(uint64_t n_blocks)
 {
-    uint64_t per_cu = (160u * 1024u) / (sizeof(EncLds) + kDfMark);
-    if (per_cu > 8) per_cu = 8;
+    uint64_t per_cu = (160u * 1024u) / (sizeof(EncLds) + 64u);
+    if (per_cu > 12) per_cu = 12;
     static const uint64_t grid_env = getenv("CRYO_ZSTD_ENC_GRID") ? (uint64_t)atoll(getenv("CRYO_ZSTD_ENC_GRID")) : 0; /* tuning aid */
     const uint64_t cap = grid_env ? grid_env : 256u * per_cu;
     return (uint32_t)(n_blocks < cap ? n_blocks : cap);
