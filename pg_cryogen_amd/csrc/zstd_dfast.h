@@ -235,13 +235,17 @@ __device__ uint32_t block_dfast_batch(uint32_t *tl, uint32_t *ts, uint8_t *mark,
         bool first = true;
         if (ip > ilimit) store_seq_pre(ws, ss, ll, litv, base + seq_anchor, offcode, mlen - 3u, lane);
         while (ip <= ilimit) {
+            /* every load of the round is issued before the first one is waited for (a wave-uniform value is read
+             * from lane 0 only after all of them are under way) */
             const bool nv = lane < W && ip + lane < ilimit;
             v8n = nv ? ld64v(base + ip + lane) : 0ull;
             const uint32_t litn = ip + lane < iend ? base[ip + lane] : 0u;
-            const uint32_t r0 = ld32u(base + ip), r1 = off2 > 0u ? ld32u(base + ip - off2) : 0u;
+            const uint32_t ins = cur + 2u;
+            const uint32_t r0v = ld32v(base + ip), r1v = ld32v(base + ip - off2);
+            const uint64_t vav = ld64v(base + (first ? ins : ip)), vbv = ld64v(base + ip - 2u), vcv = ld64v(base + ip - 1u);
+            const uint32_t r0 = uni(r0v), r1 = uni(r1v);
             if (first) {
-                const uint32_t ins = cur + 2u;
-                const uint64_t va = ld64u(base + ins), vb = ld64u(base + ip - 2u), vc = ld64u(base + ip - 1u);
+                const uint64_t va = uni64(vav), vb = uni64(vbv), vc = uni64(vcv);
                 /* the sequence's own stores go behind the loads of this round */
                 store_seq_pre(ws, ss, ll, litv, base + seq_anchor, offcode, mlen - 3u, lane);
                 if (lane == 0) {
@@ -376,9 +380,11 @@ __device__ uint32_t block_fast_gbatch(uint32_t *table, uint8_t *mark, const CPar
             v0n = nv ? ld64v(base + ip + lane * step_size) : 0ull;
             v1n = nv ? ld64v(base + ip + lane * step_size + 1u) : 0ull;
             const uint32_t litn = ip + lane < iend ? base[ip + lane] : 0u;
-            const uint32_t r0 = ld32u(base + ip), r1 = off2 > 0u ? ld32u(base + ip - off2) : 0u;
+            const uint32_t r0v = ld32v(base + ip), r1v = ld32v(base + ip - off2); /* all loads first, see block_dfast_batch */
+            const uint64_t vav = ld64v(base + (first ? cur0 + 2u : ip)), vbv = ld64v(base + ip - 2u);
+            const uint32_t r0 = uni(r0v), r1 = uni(r1v);
             if (first) {
-                const uint64_t va = ld64u(base + cur0 + 2u), vb = ld64u(base + ip - 2u);
+                const uint64_t va = uni64(vav), vb = uni64(vbv);
                 store_seq_pre(ws, ss, ll, litv, base + seq_anchor, offcode, mlen - 3u, lane);
                 if (lane == 0) { table[hashs_v(va, hlog, mls)] = cur0 + 2u; table[hashs_v(vb, hlog, mls)] = ip - 2u; }
                 first = false;
