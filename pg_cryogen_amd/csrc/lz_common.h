@@ -431,6 +431,46 @@ __device__ inline void batch_copy(Wave<R> &w, const uint8_t *__restrict__ in, un
 }
 
 } // namespace
+/* ---- helpers of the encoders that work against global memory (zstd_dfast.h) ---- */
+/* per-lane unaligned loads */
+__device__ inline uint64_t ld64v(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ inline uint32_t ld32v(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+
+/* forward and backward extension of a match in one trip to memory: bytes equal from fa/fb on (limited by
+ * end) and bytes equal before ba/bb (at most blim: the library's catch-up loop); 64 bytes per step each */
+__device__ inline void count_both(const uint8_t *fa, const uint8_t *fb, const uint8_t *end, const uint8_t *ba,
+                                  const uint8_t *bb, uint32_t blim, uint32_t lane, uint32_t &fwd, uint32_t &back)
+{
+    const bool fin = fa + lane < end, bin = lane < blim;
+    uint32_t x0 = 0, x1 = 1, y0 = 0, y1 = 1;
+    if (fin) { x0 = fa[lane]; x1 = fb[lane]; }
+    if (bin) { y0 = ba[-1 - (int)lane]; y1 = bb[-1 - (int)lane]; }
+    const unsigned long long fne = __ballot(x0 != x1), bne = __ballot(y0 != y1);
+    fwd = fne ? ctz64(fne) : 64u;
+    back = bne ? ctz64(bne) : 64u;
+    if (!fne) {
+        uint32_t done = 64u;
+        for (;;) {
+            const bool inb = fa + done + lane < end;
+            const bool eq = inb && fa[done + lane] == fb[done + lane];
+            const unsigned long long neq = __ballot(!eq);
+            if (neq != 0ull) { fwd = done + ctz64(neq); break; }
+            done += 64u;
+        }
+    }
+    if (!bne) {
+        uint32_t done = 64u;
+        for (;;) {
+            const uint32_t k = done + lane;
+            const bool eq = k < blim && ba[-1 - (int)k] == bb[-1 - (int)k];
+            const unsigned long long neq = __ballot(!eq);
+            if (neq != 0ull) { back = done + ctz64(neq); break; }
+            done += 64u;
+        }
+    }
+}
+
+
 } // namespace cryo
 
 #endif

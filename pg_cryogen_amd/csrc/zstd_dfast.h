@@ -33,8 +33,6 @@
 
 constexpr uint32_t kDfMark = 4096; /* slots of the duplicate filter (bytes of LDS) */
 
-__device__ inline uint64_t ld64v(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
-__device__ inline uint32_t ld32v(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
 __device__ inline uint32_t hash8_v(uint64_t v, int hlog) { return (uint32_t)((v * 0xCF1BBCDCB7A56463ull) >> (64 - hlog)); }
 __device__ inline uint32_t hashs_v(uint64_t v, int hlog, int mls)
@@ -53,40 +51,6 @@ __device__ inline uint32_t wave_min_u32(uint32_t v)
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)v, o, 64); v = x < v ? x : v; }
     return uni(v);
-}
-
-/* forward and backward extension of a match in one trip to memory: bytes equal from fa/fb on (limited by
- * end) and bytes equal before ba/bb (at most blim: the library's catch-up loop); 64 bytes per step each */
-__device__ inline void count_both(const uint8_t *fa, const uint8_t *fb, const uint8_t *end, const uint8_t *ba,
-                                  const uint8_t *bb, uint32_t blim, uint32_t lane, uint32_t &fwd, uint32_t &back)
-{
-    const bool fin = fa + lane < end, bin = lane < blim;
-    uint32_t x0 = 0, x1 = 1, y0 = 0, y1 = 1;
-    if (fin) { x0 = fa[lane]; x1 = fb[lane]; }
-    if (bin) { y0 = ba[-1 - (int)lane]; y1 = bb[-1 - (int)lane]; }
-    const unsigned long long fne = __ballot(x0 != x1), bne = __ballot(y0 != y1);
-    fwd = fne ? ctz64(fne) : 64u;
-    back = bne ? ctz64(bne) : 64u;
-    if (!fne) {
-        uint32_t done = 64u;
-        for (;;) {
-            const bool inb = fa + done + lane < end;
-            const bool eq = inb && fa[done + lane] == fb[done + lane];
-            const unsigned long long neq = __ballot(!eq);
-            if (neq != 0ull) { fwd = done + ctz64(neq); break; }
-            done += 64u;
-        }
-    }
-    if (!bne) {
-        uint32_t done = 64u;
-        for (;;) {
-            const uint32_t k = done + lane;
-            const bool eq = k < blim && ba[-1 - (int)k] == bb[-1 - (int)k];
-            const unsigned long long neq = __ballot(!eq);
-            if (neq != 0ull) { back = done + ctz64(neq); break; }
-            done += 64u;
-        }
-    }
 }
 
 /* marks `slot` with the lane number; returns how many leading lanes have slots no earlier lane shares
