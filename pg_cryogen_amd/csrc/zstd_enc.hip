@@ -55,11 +55,16 @@ struct FseCt {
 
 struct EncLds {
     uint32_t hist[256];
-    /* Huffman tree nodes; huffNode[i] of the library lives at index i+1, its "fake entry" at 0 */
-    uint32_t ncount[516];
-    uint16_t nparent[516];
-    uint8_t nbyte[516];
-    uint8_t nnb[516];
+    union { /* the literals stage is over before the sequence tables are built */
+        struct {
+            /* Huffman tree nodes; huffNode[i] of the library lives at index i+1, its "fake entry" at 0 */
+            uint32_t ncount[516];
+            uint16_t nparent[516];
+            uint8_t nbyte[516];
+            uint8_t nnb[516];
+        };
+        struct { FseCt of, ml; };
+    };
     uint16_t hval[256];        /* code table built for this block */
     uint8_t hnb[256];
     uint16_t pval[256];        /* table confirmed by the previous compressed block ("check" mode) */
@@ -69,7 +74,7 @@ struct EncLds {
     uint32_t cumul[66];
     uint8_t cell[512];
     uint32_t seg_bits[4];
-    FseCt ll, of, ml;          /* ll doubles as the table of the Huffman weights (literals come before sequences) */
+    FseCt ll;                  /* doubles as the table of the Huffman weights (literals come before sequences) */
 };
 
 __device__ inline uint32_t hbit(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
@@ -1004,7 +1009,7 @@ __device__ uint32_t block_fast(uint32_t *table, const CPar &cp, const uint8_t *b
  * behind the workgroup's workspace: long/only table, then dfast's short table.  finder: 0 = `fast`, many
  * iterations per step (block_fast_gbatch); 1 = `dfast` (block_dfast_batch); 2 = `fast`, the serial walk
  * (block_fast: the plain restatement, CRYO_ZSTD_ENC=1). */
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t n_blocks,
            uint8_t *__restrict__ dst_base, uint64_t dst_stride, int wlog, int hlog, int clog, int mml, int tlen,
            int finder, uint32_t width, uint32_t *__restrict__ out_size, int32_t *__restrict__ status,
@@ -1147,7 +1152,7 @@ static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *
 static uint32_t zstd_enc_grid(uint64_t n_blocks)
 {
     uint64_t per_cu = (160u * 1024u) / (sizeof(EncLds) + 64u);
-    if (per_cu > 12) per_cu = 12;
+    if (per_cu > 16) per_cu = 16;
     static const uint64_t grid_env = getenv("CRYO_ZSTD_ENC_GRID") ? (uint64_t)atoll(getenv("CRYO_ZSTD_ENC_GRID")) : 0; /* tuning aid */
     const uint64_t cap = grid_env ? grid_env : 256u * per_cu;
     return (uint32_t)(n_blocks < cap ? n_blocks : cap);
