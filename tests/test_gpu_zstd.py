@@ -258,3 +258,29 @@ def test_zstd_encode_batch_match_finder_corners(codec, oracle):
                 assert np.array_equal(got[i], exp), (n, level, i, len(got[i]), len(exp))
                 if stock.zstd is not None and level > 0:
                     assert np.array_equal(stock.zstd_compress(b, level), exp), (n, level, i)
+
+
+def test_zstd_pipeline_dense_sequences_pool_overflow(codec, oracle):
+    """streams with far more sequences than level 1 writes: text-like rows at levels 4/5 (B/8 sequences per frame)
+    fit the batch pipeline's sequence pool (B/6 per frame); 4-byte words with a random byte between them at
+    level 5 (B/5 per frame) overflow it, and the frames that do not fit must come out right through the
+    irregular list (fused decoder)"""
+    stock = oracle_lib.StockLibs()
+    if stock.zstd is None:
+        pytest.skip("needs the stock libzstd (levels above 4)")
+    B = 131072
+    rng = np.random.default_rng(5)
+    words = rng.integers(0, 256, (64, 4), dtype=np.uint8)
+    dense = []
+    for k in range(6):
+        a = np.zeros(B, np.uint8)
+        idx = rng.integers(0, 64, B // 5)
+        body = np.concatenate([words[idx], rng.integers(0, 256, (B // 5, 1), dtype=np.uint8)], axis=1).reshape(-1)
+        a[:len(body)] = body
+        dense.append(a)
+    raws = [dense[i % 6] for i in range(40)] + [oracle.synth(9, i, B, 0) for i in range(8)]
+    comps = [stock.zstd_compress(r, 5) for r in raws[:40]] + [stock.zstd_compress(r, 4 + (i & 1)) for i, r in enumerate(raws[40:])]
+    outs, st = codec.decompress_blocks(METHOD_ZSTD, comps, B)
+    assert (st == 0).all()
+    for o, r in zip(outs, raws):
+        assert np.array_equal(o, r)
