@@ -25,14 +25,14 @@
  * ways at once -> one tail trip (complementary insertions, immediate-repeat check, the next step's input and
  * the next literal run together).  The long-table lookup at ip+1 that follows a short hit is the next lane's
  * own lookup when the step is 1, so it costs no trip.
- * Measured (65536 x 128 KiB text-like rows, one MI355X): level 3 7.2 GB/s, level 4 3.3 GB/s (three times
- * the sequences); about 9-13 thousand cycles per sequence, shared between memory latency and the rate of
- * scattered accesses the 1792 waves in flight put on HBM (tables: 0.4-2 MiB per wave, far beyond L2/MALL).
+ * Measured (65536 x 128 KiB text-like rows, one MI355X, 4096 waves in flight): level 1 19.5, level 2 12.4,
+ * level 3 10.3, level 4 5.1 GB/s (three times the sequences); thousands of cycles per sequence, shared between
+ * memory latency and the rate of scattered accesses the waves put on HBM (tables: 0.06-2 MiB per wave, far
+ * beyond L2/MALL).  profiles/r01_zstd_encoders.txt has the history and the phase split.
  */
 #pragma once
 
-constexpr uint32_t kDfMark = 4096; /* slots of the duplicate filter (bytes of LDS) */
-
+constexpr uint32_t kDfMark = 4096; /* slots of the duplicate filter (bytes of LDS, over the entropy stage's scratch) */
 
 __device__ inline uint32_t hash8_v(uint64_t v, int hlog) { return (uint32_t)((v * 0xCF1BBCDCB7A56463ull) >> (64 - hlog)); }
 __device__ inline uint32_t hashs_v(uint64_t v, int hlog, int mls)
@@ -44,13 +44,6 @@ __device__ inline uint32_t hashs_v(uint64_t v, int hlog, int mls)
     case 6: return (uint32_t)(((v << 16) * 227718039650203ull) >> (64 - hlog));
     case 7: return (uint32_t)(((v << 8) * 58295818150454627ull) >> (64 - hlog));
     }
-}
-
-__device__ inline uint32_t wave_min_u32(uint32_t v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) { const uint32_t x = (uint32_t)__shfl_xor((int)v, o, 64); v = x < v ? x : v; }
-    return uni(v);
 }
 
 /* marks `slot` with the lane number; returns how many leading lanes have slots no earlier lane shares
@@ -91,7 +84,7 @@ __device__ inline void store_seq_pre(uint8_t *ws, SeqStore &ss, uint32_t ll, uin
  * (complementary insertions, immediate repeat check, next step's input, next literal run). */
 __device__ uint32_t block_dfast_batch(uint32_t *tl, uint32_t *ts, uint8_t *mark, const CPar &cp, const uint8_t *base,
                                       const uint8_t *istart, uint32_t n, uint32_t *rep, uint8_t *ws, SeqStore &ss,
-                                      uint32_t dict_limit, uint32_t lane, uint32_t W = 64, unsigned long long *prof = nullptr)
+                                      uint32_t dict_limit, uint32_t lane, uint32_t W, unsigned long long *prof)
 {
     unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pn[3] = {0, 0, 0}, t0 = prof ? __builtin_amdgcn_s_memtime() : 0; /* CRYO_ZSTD_STATS */
 #define DFT(k) do { if (prof) { const unsigned long long t = __builtin_amdgcn_s_memtime(); pt[k] += t - t0; t0 = t; } } while (0)
@@ -313,30 +306,78 @@ __device__ uint32_t block_fast_gbatch(uint32_t *table, uint8_t *mark, const CPar
         if (!hitm) { ip += ncommit * st; continue; }
 
         const uint32_t cur0 = __builtin_amdgcn_readlane(i0, T);
-        uint32_t mlen, offcode;
+        uint32_t mlen, offcode, m, known, blim;
         if ((repm >> T) & 1ull) {
             const uint32_t rlo = __builtin_amdgcn_readlane((uint32_t)rv, T), vlo = __builtin_amdgcn_readlane((uint32_t)v1, T);
             const uint32_t b = ((rlo ^ vlo) & 0xFFu) == 0u ? 1u : 0u; /* ip2[-1] == repMatch[-1] */
             ip = cur0 + 2u - b;
-            mlen = 4u + b;
-            mlen += count_match(base + ip + mlen, base + ip - off1 + mlen, base + iend, lane);
+            m = ip - off1;
+            known = 4u + b;
+            blim = 0;
             offcode = 0;
         } else {
-            uint32_t m;
             if ((m0m >> T) & 1ull) { ip = cur0; m = __builtin_amdgcn_readlane(mi0, T); }
             else { ip = cur0 + 1u; m = __builtin_amdgcn_readlane(mi1, T); }
             off2 = off1;
             off1 = ip - m;
             offcode = off1 + 2u;
+            known = 4u;
             const uint32_t la = ip - anchor, lm = m - prefix_idx;
-            uint32_t fwd, back;
-            count_both(base + ip + 4u, base + m + 4u, base + iend, base + ip, base + m, la < lm ? la : lm, lane, fwd, back);
-            mlen = 4u + fwd + back;
-            ip -= back;
+            blim = la < lm ? la : lm;
         }
+        /* Match extension, and with it everything the sequence's tail needs, whatever the match length turns out to
+         * be (below 64 bytes more): a window of the input behind the known part of the match -- lane j reads 8 bytes
+         * at wb + 2j (A) and wb + 2j + 1 (B), wb = ip + known - 2 -- serves the bytes at the end of the match (ip' - 2
+         * for the complementary insertion, ip' for the immediate-repeat check), the next step's search input and
+         * the next literal run; lane j also reads the immediate-repeat candidate for a match ending at ip + known + j. */
+        const uint32_t wb = ip + known - 2u;
+        const bool win_a = wb + 2u * lane + 8u <= iend, win_b = wb + 2u * lane + 9u <= iend;
+        const uint64_t A = ld64v(base + (win_a ? wb + 2u * lane : ip)), B = ld64v(base + (win_b ? wb + 2u * lane + 1u : ip));
+        const uint32_t r1s = ld32v(base + ((off2 > 0u && ip + known + lane + 4u <= iend) ? ip + known + lane - off2 : ip));
+        const uint64_t vas = ld64v(base + cur0 + 2u);
+        uint32_t fwd, back;
+        count_both(base + ip + known, base + m + known, base + iend, base + ip, base + m, blim, lane, fwd, back);
+        mlen = known + fwd + back;
+        ip -= back;
         const uint32_t ll = ip - anchor, seq_anchor = anchor;
         ip += mlen;
         anchor = ip;
+        if (fwd < 64u && ip <= ilimit) {
+            /* window position t <-> index wb + t; the match ends at t = fwd + 2 */
+            auto win64 = [&](uint32_t t) { /* 8 bytes at window position t (per lane), t <= 127 */
+                const int j = (int)(t >> 1);
+                const uint64_t a = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(A >> 32), j, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)A, j, 64);
+                const uint64_t b = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(B >> 32), j, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)B, j, 64);
+                return (t & 1u) ? b : a;
+            };
+            const uint32_t te = fwd + 2u;
+            const uint32_t r0 = (uint32_t)uni64(win64(te));
+            const uint32_t r1 = __builtin_amdgcn_readlane(r1s, fwd);
+            if (!(off2 > 0u && r0 == r1)) {
+                const uint64_t va = uni64(vas), vb = uni64(win64(fwd));
+                store_seq_pre(ws, ss, ll, litv, base + seq_anchor, offcode, mlen - 3u, lane);
+                if (lane == 0) { table[hashs_v(va, hlog, mls)] = cur0 + 2u; table[hashs_v(vb, hlog, mls)] = ip - 2u; }
+                /* next step: lane k looks at ip + k * step_size (and + 1) */
+                const bool nv = lane < W && ip + lane * step_size + 1u < ilimit;
+                const uint32_t t0 = te + lane * step_size;
+                const bool inw = t0 + 1u <= 127u;
+                v0n = win64(inw ? t0 : 0u);
+                v1n = win64(inw ? t0 + 1u : 0u);
+                if (nv && !inw) { v0n = ld64v(base + ip + lane * step_size); v1n = ld64v(base + ip + lane * step_size + 1u); }
+                if (!nv) { v0n = 0ull; v1n = 0ull; }
+                /* next literal run: byte at ip + lane = window position te + lane, inside A[j] for 2j <= t <= 2j + 7 */
+                {
+                    const uint32_t t = te + lane, j = (t >> 1) < 63u ? (t >> 1) : 63u;
+                    const uint64_t a = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(A >> 32), (int)j, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)A, (int)j, 64);
+                    const bool ok = wb + 2u * j + 8u <= iend; /* lane j's A was a real window read */
+                    uint32_t byte = (uint32_t)(a >> (8u * (t - 2u * j))) & 0xFFu;
+                    if (!ok && ip + lane < iend) byte = base[ip + lane];
+                    litv = ip + lane < iend ? byte : 0u;
+                }
+                have = true;
+                continue;
+            }
+        }
         bool first = true;
         if (ip > ilimit) store_seq_pre(ws, ss, ll, litv, base + seq_anchor, offcode, mlen - 3u, lane);
         while (ip <= ilimit) {
