@@ -82,12 +82,15 @@ __device__ inline void store_seq_pre(uint8_t *ws, SeqStore &ss, uint32_t ll, uin
  * Trips to memory per sequence: [input of the step, loaded with the previous sequence's tail] -> table slots
  * -> candidates (repeat offset, long, short: one trip, branch-free) -> match extension both ways -> tail
  * (complementary insertions, immediate repeat check, next step's input, next literal run). */
+template <bool PROF>
 __device__ uint32_t block_dfast_batch(uint32_t *tl, uint32_t *ts, uint8_t *mark, const CPar &cp, const uint8_t *base,
                                       const uint8_t *istart, uint32_t n, uint32_t *rep, uint8_t *ws, SeqStore &ss,
                                       uint32_t dict_limit, uint32_t lane, uint32_t W, unsigned long long *prof)
 {
-    unsigned long long pt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pn[3] = {0, 0, 0}, t0 = prof ? __builtin_amdgcn_s_memtime() : 0; /* CRYO_ZSTD_STATS */
-#define DFT(k) do { if (prof) { const unsigned long long t = __builtin_amdgcn_s_memtime(); pt[k] += t - t0; t0 = t; } } while (0)
+    /* CRYO_ZSTD_STATS (PROF): cycles per phase and event counts; compiled out of the production kernel */
+    unsigned long long pt[PROF ? 8 : 1] = {0}, pn[PROF ? 6 : 1] = {0}, t0 = PROF ? __builtin_amdgcn_s_memtime() : 0;
+#define DFT(k) do { if constexpr (PROF) { const unsigned long long t = __builtin_amdgcn_s_memtime(); pt[k] += t - t0; t0 = t; } } while (0)
+#define DFN(k, v) do { if constexpr (PROF) pn[k] += (v); } while (0)
     const int hl = cp.hlog, hs = cp.clog, mls = cp.mml < 4 ? 4 : (cp.mml > 7 ? 7 : cp.mml);
     uint32_t ip = (uint32_t)(istart - base), anchor = ip;
     const uint32_t iend = ip + n, ilimit = iend - 8u;
@@ -111,7 +114,7 @@ __device__ uint32_t block_dfast_batch(uint32_t *tl, uint32_t *ts, uint8_t *mark,
         const uint64_t v8 = have ? v8n : (valid ? ld64v(base + p) : 0ull);
         have = false;
         const uint32_t h2 = hash8_v(v8, hl), h = hashs_v(v8, hs, mls);
-        if (prof) asm volatile("" :: "v"(h2), "v"(h));
+        if constexpr (PROF) asm volatile("" :: "v"(h2), "v"(h));
         DFT(0);
         {
             const uint32_t n1 = distinct_prefix(mark, h2 & (kDfMark - 1u), valid, lane);
@@ -120,7 +123,7 @@ __device__ uint32_t block_dfast_batch(uint32_t *tl, uint32_t *ts, uint8_t *mark,
         }
         DFT(1);
         const uint32_t cl = valid ? tl[h2] : 0u, cs = valid ? ts[h] : 0u;
-        if (prof) asm volatile("" :: "v"(cl), "v"(cs));
+        if constexpr (PROF) asm volatile("" :: "v"(cl), "v"(cs));
         DFT(2);
         /* the three candidates in one trip: addresses of lanes that have no candidate point at ip */
         const bool rc = valid && off1 > 0u, lc = valid && cl > prefix_idx, sc = valid && cs > prefix_idx;
@@ -137,18 +140,19 @@ __device__ uint32_t block_dfast_batch(uint32_t *tl, uint32_t *ts, uint8_t *mark,
         const uint32_t ncommit = hitm ? T + 1u : (uint32_t)__builtin_popcountll(validm);
         DFT(3);
         if (lane < ncommit) { tl[h2] = p; ts[h] = p; }
-        pn[0]++; pn[1] += ncommit;
+        DFN(0, 1); DFN(1, ncommit);
         if (!hitm) { ip += ncommit * st; continue; }
-        pn[2]++;
+        DFN(2, 1);
 
         const uint32_t cur = __builtin_amdgcn_readlane(p, T);
-        uint32_t mlen, ll, offcode;
+        uint32_t mlen, ll, offcode, m, known, blim;
         if ((repm >> T) & 1ull) {
             ip = cur + 1u;
-            mlen = count_match(base + ip + 4u, base + ip + 4u - off1, base + iend, lane) + 4u;
+            m = ip - off1;
+            known = 4u;
+            blim = 0;
             offcode = 0;
         } else {
-            uint32_t m, known;
             if ((longm >> T) & 1ull) {
                 m = __builtin_amdgcn_readlane(cl, T);
                 ip = cur;
@@ -172,21 +176,69 @@ __device__ uint32_t block_dfast_batch(uint32_t *tl, uint32_t *ts, uint8_t *mark,
                 if (hit3) { m = mil3; ip = cur + 1u; known = 8u; }
                 else { m = __builtin_amdgcn_readlane(cs, T); ip = cur; known = 4u; }
             }
-            const uint32_t offset = ip - m;
             const uint32_t la = ip - anchor, lm = m - prefix_idx;
-            uint32_t fwd, back;
-            count_both(base + ip + known, base + m + known, base + iend, base + ip, base + m, la < lm ? la : lm, lane, fwd, back);
-            mlen = known + fwd + back;
-            ip -= back;
+            blim = la < lm ? la : lm;
             off2 = off1;
-            off1 = offset;
-            offcode = offset + 2u;
+            off1 = ip - m;
+            offcode = off1 + 2u;
         }
+        /* match extension, and with it what the sequence's tail needs whatever the length turns out to be (below 64
+         * bytes more), as in block_fast_gbatch: lane j reads 8 bytes at wb + j (A) and wb + 64 + j (A2), wb = ip +
+         * known - 2, and the immediate-repeat candidate of a match that ends at ip + known + j */
+        const uint32_t wb = ip + known - 2u;
+        const bool win_a = wb + lane + 8u <= iend, win_a2 = wb + 64u + lane + 8u <= iend;
+        const uint64_t A = ld64v(base + (win_a ? wb + lane : ip)), A2 = ld64v(base + (win_a2 ? wb + 64u + lane : ip));
+        const uint32_t r1s = ld32v(base + ((off2 > 0u && ip + known + lane + 4u <= iend) ? ip + known + lane - off2 : ip));
+        const uint64_t vas = ld64v(base + cur + 2u);
+        uint32_t fwd, back;
+        count_both(base + ip + known, base + m + known, base + iend, base + ip, base + m, blim, lane, fwd, back);
+        mlen = known + fwd + back;
+        ip -= back;
         DFT(4);
         ll = ip - anchor;
         const uint32_t seq_anchor = anchor;
         ip += mlen;
         anchor = ip;
+        if (fwd < 64u && ip <= ilimit) {
+            auto win64 = [&](uint32_t t) { /* 8 bytes at window position t (index wb + t), t <= 127 */
+                const int j = (int)(t & 63u);
+                const uint64_t a = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(A >> 32), j, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)A, j, 64);
+                const uint64_t b = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(A2 >> 32), j, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)A2, j, 64);
+                return t < 64u ? a : b;
+            };
+            const uint32_t te = fwd + 2u; /* the match ends at window position te */
+            const uint32_t r0 = (uint32_t)uni64(win64(te));
+            const uint32_t r1 = __builtin_amdgcn_readlane(r1s, fwd);
+            if (!(off2 > 0u && r0 == r1)) {
+                const uint32_t ins = cur + 2u;
+                const uint64_t va = uni64(vas), vb = uni64(win64(fwd)), vc = uni64(win64(fwd + 1u));
+                store_seq_pre(ws, ss, ll, litv, base + seq_anchor, offcode, mlen - 3u, lane);
+                if (lane == 0) {
+                    tl[hash8_v(va, hl)] = ins;
+                    tl[hash8_v(vb, hl)] = ip - 2u;
+                    ts[hashs_v(va, hs, mls)] = ins;
+                    ts[hashs_v(vc, hs, mls)] = ip - 1u;
+                }
+                const bool nv = lane < W && ip + lane < ilimit;
+                const uint32_t tn = te + lane;
+                const bool inw = tn <= 127u;
+                const uint64_t wv = win64(inw ? tn : 0u);
+                v8n = wv;
+                if (nv && !inw) v8n = ld64v(base + ip + lane);
+                if (!nv) v8n = 0ull;
+                {
+                    const bool ok = inw && wb + tn + 8u <= iend; /* that window lane was a real read */
+                    uint32_t byte = (uint32_t)wv & 0xFFu;
+                    if (!ok && ip + lane < iend) byte = base[ip + lane];
+                    litv = ip + lane < iend ? byte : 0u;
+                }
+                have = true;
+                DFN(3, 1);
+                DFT(6);
+                continue;
+            }
+            DFN(4, 1); /* immediate repeat: the tail loop below */
+        }
         /* tail: complementary insertions once, then immediate repeats (offset_2) as long as they match; every
          * round loads the literal bytes and the search input at the new anchor with its other loads */
         bool first = true;
@@ -224,11 +276,13 @@ __device__ uint32_t block_dfast_batch(uint32_t *tl, uint32_t *ts, uint8_t *mark,
             store_seq_pre(ws, ss, 0, 0, base + anchor, 0, rlen - 3u, lane);
             ip += rlen;
             anchor = ip;
+            DFN(5, 1);
         }
         DFT(6);
     }
-    if (prof && lane == 0) { for (int k = 0; k < 8; k++) atomicAdd(&prof[8 + k], pt[k]); for (int k = 0; k < 3; k++) atomicAdd(&prof[16 + k], pn[k]); }
+    if constexpr (PROF) { if (prof && lane == 0) { for (int k = 0; k < 8; k++) atomicAdd(&prof[8 + k], pt[k]); for (int k = 0; k < 6; k++) atomicAdd(&prof[16 + k], pn[k]); } }
 #undef DFT
+#undef DFN
     rep[0] = off1 ? off1 : saved;
     rep[1] = off2 ? off2 : saved;
     return iend - anchor;

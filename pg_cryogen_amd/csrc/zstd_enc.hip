@@ -1009,6 +1009,7 @@ __device__ uint32_t block_fast(uint32_t *table, const CPar &cp, const uint8_t *b
  * behind the workgroup's workspace: long/only table, then dfast's short table.  finder: 0 = `fast`, many
  * iterations per step (block_fast_gbatch); 1 = `dfast` (block_dfast_batch); 2 = `fast`, the serial walk
  * (block_fast: the plain restatement, CRYO_ZSTD_ENC=1). */
+template <bool PROF> /* PROF: CRYO_ZSTD_STATS counters */
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t n_blocks,
            uint8_t *__restrict__ dst_base, uint64_t dst_stride, int wlog, int hlog, int clog, int mml, int tlen,
@@ -1019,7 +1020,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
     /* the finders' mark array lies over the entropy stage's scratch (histogram + tree nodes: dead while a finder runs) */
     static_assert(offsetof(EncLds, nbyte) >= kDfMark, "mark array must stay inside the scratch part of EncLds");
     uint8_t *df_mark = reinterpret_cast<uint8_t *>(&L);
-    unsigned long long t_mf = 0, t_en = 0, t_other = 0, t_prev = stats ? __builtin_amdgcn_s_memtime() : 0; /* CRYO_ZSTD_STATS */
+    unsigned long long t_mf = 0, t_en = 0, t_other = 0, t_prev = PROF ? __builtin_amdgcn_s_memtime() : 0; /* CRYO_ZSTD_STATS */
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *ws = workspace + (uint64_t)blockIdx.x * ws_stride;
     CPar cp;
@@ -1057,7 +1058,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         const uint8_t *base = src - 1;
         bool first = true;
         HufState hs;
-        hs.prev_valid = false; hs.next_new = false; hs.prof = stats; hs.t = 0; hs.strat = dfast ? 2u : 1u;
+        hs.prev_valid = false; hs.next_new = false; hs.prof = PROF ? stats : nullptr; hs.t = 0; hs.strat = dfast ? 2u : 1u;
         uint32_t ip = 0;
         while (ip < n) {
             const uint32_t bs = (n - ip < kZBlk) ? n - ip : kZBlk;
@@ -1069,19 +1070,19 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 SeqStore ss;
                 ss.nseq = 0; ss.nlit = 0; ss.long_pos = 0; ss.long_kind = 0;
                 uint32_t nrep[3] = {rep[0], rep[1], rep[2]};
-                if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_other += t - t_prev; t_prev = t; }
+                if constexpr (PROF) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_other += t - t_prev; t_prev = t; }
                 uint32_t last_ll;
-                if (finder == 1) last_ll = block_dfast_batch(table, tshort, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, width, stats);
+                if (finder == 1) last_ll = block_dfast_batch<PROF>(table, tshort, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, width, stats);
                 else if (finder == 0) last_ll = block_fast_gbatch(table, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, width);
                 else last_ll = block_fast(table, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane);
-                if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mf += t - t_prev; t_prev = t; }
+                if constexpr (PROF) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mf += t - t_prev; t_prev = t; }
                 for (uint32_t i = lane; i < last_ll; i += 64u) (ws + kWsLit)[ss.nlit + i] = src[ip + bs - last_ll + i];
                 ss.nlit += last_ll;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                if (stats) hs.t = __builtin_amdgcn_s_memtime();
+                if constexpr (PROF) hs.t = __builtin_amdgcn_s_memtime();
                 csize = compress_sequences(L, dst + op + 3, ws, ss.nseq, ss.nlit, bs, ss.long_pos, ss.long_kind, hs,
                                            tlen > 0, lane);
-                if (stats) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_en += t - t_prev; t_prev = t; }
+                if constexpr (PROF) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_en += t - t_prev; t_prev = t; }
                 if (!first && csize < 25u) { /* RLE block for constant non-first blocks */
                     const uint32_t b0 = uni(src[ip]);
                     bool diff = false;
@@ -1113,7 +1114,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         if (lane == 0) { out_size[blk] = op; status[blk] = CRYO_ST_OK; }
         __builtin_amdgcn_wave_barrier();
     }
-    if (stats && lane == 0) {
+    if (PROF && stats && lane == 0) {
         t_other += __builtin_amdgcn_s_memtime() - t_prev;
         atomicAdd(&stats[0], t_mf); atomicAdd(&stats[1], t_en); atomicAdd(&stats[2], t_other);
     }
@@ -1198,8 +1199,12 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
     }
-    hipLaunchKernelGGL(k_zstd_enc, dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride, wlog,
-                       hlog, clog, mml, tlen, finder, width, d_out_size, d_status, (uint8_t *)d_workspace, (uint64_t)stride, d_st);
+    if (want_stats)
+        hipLaunchKernelGGL(k_zstd_enc<true>, dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride, wlog,
+                           hlog, clog, mml, tlen, finder, width, d_out_size, d_status, (uint8_t *)d_workspace, (uint64_t)stride, d_st);
+    else
+        hipLaunchKernelGGL(k_zstd_enc<false>, dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride, wlog,
+                           hlog, clog, mml, tlen, finder, width, d_out_size, d_status, (uint8_t *)d_workspace, (uint64_t)stride, d_st);
     if (want_stats) {
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
@@ -1216,9 +1221,9 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
             for (int k = 8; k < 16; k++) t += (double)h_st[k];
             fprintf(stderr, "[zstd enc cycles] dfast finder: input+hash %.1f%%  dup filter %.1f%%  table gather %.1f%%  candidates %.1f%%  "
                             "match (count, lookups) %.1f%%  tail (insertions, repeats, next input) %.1f%% | steps %llu, positions/step %.1f, "
-                            "steps/sequence %.2f, cycles/sequence %.0f\n",
+                            "steps/sequence %.2f, cycles/sequence %.0f; tails from the window %llu, immediate repeats seen there %llu, repeat sequences %llu\n",
                     100.0 * h_st[8] / t, 100.0 * h_st[9] / t, 100.0 * h_st[10] / t, 100.0 * h_st[11] / t, 100.0 * h_st[12] / t,
-                    100.0 * h_st[14] / t, h_st[16], (double)h_st[17] / h_st[16], (double)h_st[16] / h_st[18], t / h_st[18]);
+                    100.0 * h_st[14] / t, h_st[16], (double)h_st[17] / h_st[16], (double)h_st[16] / h_st[18], t / h_st[18], h_st[19], h_st[20], h_st[21]);
         }
     }
     return hipGetLastError();
