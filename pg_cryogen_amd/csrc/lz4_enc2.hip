@@ -23,7 +23,7 @@
  *   - backward / forward match extension compare 64 bytes per step; literal runs are copied 64 bytes
  *     per step straight to the output.
  * The kernel is latency bound (serial chain of LDS round trips per sequence), so what matters is waves
- * per CU, i.e. LDS per wave: the position table is 4096 x (u16 low | u8 high) = 12 KiB and the ring only
+ * per CU, i.e. LDS per wave: the position table is 4096 x (u16 low | 1, 4 or 8 high bits) = 8.5-12 KiB and the ring only
  * 2 KiB (measured on 64k x 128 KiB "wide" blocks: 64 KiB ring 8.6 GB/s, 16 KiB 19, 8 KiB 25.6, 2 KiB 29).
  */
 #include "enc_ring.h"
@@ -36,16 +36,20 @@ namespace {
 
 constexpr uint32_t kMfLimit = 12, kLastLiterals = 5, kMinLength = 13, kMaxDist = 65535, kSkipTrigger = 6;
 
-template <uint32_t kW>
+/* position table: u16 low halves + HB high bits per entry, packed and updated with LDS atomics when HB < 8:
+ * HB = 1 (blocks up to 128 KiB) makes the table 8.5 KiB and 15 workgroups fit a CU instead of 11 (32.5 -> 41.5
+ * GB/s on the headline blocks); HB = 4 (up to 1 MiB) 10 KiB, 13 per CU; HB = 8: a byte per entry (up to 16 MiB) */
+template <uint32_t kW, int HB>
 struct EncLds {
     uint8_t win[kW];
     uint16_t tlo[4096];
-    uint8_t thi[4096];
+    uint8_t thi[4096 * HB / 8];
 };
 
-template <uint32_t kW>
+template <uint32_t kW, int HB>
 struct Enc : RingIn<kW> {
-    EncLds<kW> *L;
+    static constexpr bool BIT = HB < 8; /* owner marks go to the low halves */
+    EncLds<kW, HB> *L;
     uint8_t *dst;
     uint32_t op;
     using RingIn<kW>::lane;
@@ -64,8 +68,31 @@ struct Enc : RingIn<kW> {
         const uint32_t top = __umulhi(x_lo, c_lo) + x_lo * c_hi + x_hi * c_lo;
         return top >> 20;
     }
-    __device__ inline uint32_t tab_get(uint32_t h) const { return (uint32_t)L->tlo[h] | ((uint32_t)L->thi[h] << 16); }
-    __device__ inline void tab_put(uint32_t h, uint32_t v) { L->tlo[h] = (uint16_t)v; L->thi[h] = (uint8_t)(v >> 16); }
+    __device__ inline uint32_t tab_get(uint32_t h) const
+    {
+        if constexpr (HB == 1) return (uint32_t)L->tlo[h] | (((reinterpret_cast<const uint32_t *>(L->thi)[h >> 5] >> (h & 31u)) & 1u) << 16);
+        else if constexpr (HB == 4) return (uint32_t)L->tlo[h] | (((reinterpret_cast<const uint32_t *>(L->thi)[h >> 3] >> (4u * (h & 7u))) & 15u) << 16);
+        else return (uint32_t)L->tlo[h] | ((uint32_t)L->thi[h] << 16);
+    }
+    __device__ inline void tab_put(uint32_t h, uint32_t v)
+    {
+        L->tlo[h] = (uint16_t)v;
+        if constexpr (HB == 1) {
+            uint32_t *w = reinterpret_cast<uint32_t *>(L->thi) + (h >> 5);
+            if ((v >> 16) & 1u) atomicOr(w, 1u << (h & 31u));
+            else atomicAnd(w, ~(1u << (h & 31u)));
+        } else if constexpr (HB == 4) { /* other lanes of the step may update other nibbles of the word: clear, then set */
+            uint32_t *w = reinterpret_cast<uint32_t *>(L->thi) + (h >> 3);
+            const uint32_t sh = 4u * (h & 7u);
+            atomicAnd(w, ~(15u << sh));
+            atomicOr(w, ((v >> 16) & 15u) << sh);
+        } else L->thi[h] = (uint8_t)(v >> 16);
+    }
+    /* owner marks for the in-step collision test: in the byte plane, or (BIT) in the low half, whose real value
+     * is in `cand` and comes back right after the test */
+    __device__ inline void mark(uint32_t h, uint32_t lane_id) { if constexpr (BIT) L->tlo[h] = (uint16_t)(0xFF00u | lane_id); else L->thi[h] = (uint8_t)lane_id; }
+    __device__ inline bool marked_by(uint32_t h, uint32_t lane_id) const { if constexpr (BIT) return L->tlo[h] == (uint16_t)(0xFF00u | lane_id); else return L->thi[h] == (uint8_t)lane_id; }
+    __device__ inline void unmark(uint32_t h, uint32_t cand) { if constexpr (BIT) L->tlo[h] = (uint16_t)cand; else L->thi[h] = (uint8_t)(cand >> 16); }
 
     /* 255-run length code */
     __device__ inline void put_len(uint32_t len)
@@ -84,25 +111,25 @@ struct Enc : RingIn<kW> {
 
 } // namespace
 
-template <uint32_t kW>
+template <uint32_t kW, int HB>
 __global__ void __launch_bounds__(64)
 k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t n_blocks,
            uint8_t *__restrict__ dst_base, uint64_t dst_stride, int accel_in,
            uint32_t *__restrict__ out_size, int32_t *__restrict__ status)
 {
-    __shared__ __attribute__((aligned(16))) EncLds<kW> L;
+    __shared__ __attribute__((aligned(16))) EncLds<kW, HB> L;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t blk = blockIdx.x;
     if (blk >= n_blocks) return;
 
-    Enc<kW> e;
+    Enc<kW, HB> e;
     e.L = &L;
     e.dst = dst_base + uni64(blk * dst_stride);
     e.op = 0;
     const uint32_t accel = accel_in < 1 ? 1u : (accel_in > 65537 ? 65537u : (uint32_t)accel_in);
 
     for (uint32_t i = lane; i < 512u; i += 64u) reinterpret_cast<uint4 *>(L.tlo)[i] = make_uint4(0, 0, 0, 0);
-    for (uint32_t i = lane; i < 256u; i += 64u) reinterpret_cast<uint4 *>(L.thi)[i] = make_uint4(0, 0, 0, 0);
+    for (uint32_t i = lane; i < sizeof(L.thi) / 16u; i += 64u) reinterpret_cast<uint4 *>(L.thi)[i] = make_uint4(0, 0, 0, 0);
     e.open(L.win, src_base + uni64(blk * src_stride), n, lane);
     e.ensure(2u * kEncStage);
     __builtin_amdgcn_wave_barrier();
@@ -145,7 +172,7 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 if (valid) {
                     h = e.hash(cur, own4);
                     cand = e.tab_get(h);
-                    L.thi[h] = (uint8_t)lane; /* owner mark; the slot's real high byte is in cand and comes back below */
+                    e.mark(h, lane); /* owner mark; what it overwrites is in cand and comes back below */
                 }
                 /* in-batch collisions: an earlier lane with the same hash is what the serial loop would read.
                  * Every lane marked its slot; a lane that does not read its own mark back shares the slot. */
@@ -153,9 +180,9 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 {
                     /* the read-back must see what the WAVE wrote, not be forwarded from this lane's own store */
                     asm volatile("" ::: "memory");
-                    const bool lost = valid && L.thi[h] != (uint8_t)lane;
+                    const bool lost = valid && !e.marked_by(h, lane);
                     asm volatile("" ::: "memory");
-                    if (valid) L.thi[h] = (uint8_t)(cand >> 16); /* all sharers hold the same old value */
+                    if (valid) e.unmark(h, cand); /* all sharers hold the same old value */
                     unsigned long long losers = __ballot(lost);
                     while (losers) {
                         const uint32_t j = ctz64(losers);
@@ -272,22 +299,28 @@ hipError_t launch_lz4_compress_batch64(hipStream_t s, const uint8_t *d_src, uint
     static const int wkb = getenv("CRYO_LZ4_ENC_WINDOW") ? atoi(getenv("CRYO_LZ4_ENC_WINDOW")) : 2; /* KiB; tuning aid */
     const dim3 grid((uint32_t)n_blocks), wg(64);
     if (wkb >= 64)
-        hipLaunchKernelGGL(k_lz4_enc2<65536>, grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
+        hipLaunchKernelGGL((k_lz4_enc2<65536, 8>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
                            accel, d_out_size, d_status);
     else if (wkb >= 32)
-        hipLaunchKernelGGL(k_lz4_enc2<32768>, grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
+        hipLaunchKernelGGL((k_lz4_enc2<32768, 8>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
                            accel, d_out_size, d_status);
     else if (wkb >= 16)
-        hipLaunchKernelGGL(k_lz4_enc2<16384>, grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
+        hipLaunchKernelGGL((k_lz4_enc2<16384, 8>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
                            accel, d_out_size, d_status);
     else if (wkb >= 8)
-        hipLaunchKernelGGL(k_lz4_enc2<8192>, grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
+        hipLaunchKernelGGL((k_lz4_enc2<8192, 8>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
                            accel, d_out_size, d_status);
     else if (wkb >= 4)
-        hipLaunchKernelGGL(k_lz4_enc2<4096>, grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
+        hipLaunchKernelGGL((k_lz4_enc2<4096, 8>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
+                           accel, d_out_size, d_status);
+    else if (block_size <= (128u << 10))
+        hipLaunchKernelGGL((k_lz4_enc2<2048, 1>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
+                           accel, d_out_size, d_status);
+    else if (block_size <= (1u << 20))
+        hipLaunchKernelGGL((k_lz4_enc2<2048, 4>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
                            accel, d_out_size, d_status);
     else
-        hipLaunchKernelGGL(k_lz4_enc2<2048>, grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
+        hipLaunchKernelGGL((k_lz4_enc2<2048, 8>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
                            accel, d_out_size, d_status);
     return hipGetLastError();
 }
