@@ -530,7 +530,7 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
     if (n_blocks == 0) return hipSuccess;
     const uint64_t grid = (n_blocks + 3) / 4;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    /* output ring size per wave: 4 KiB default (24 waves/CU); CRYO_LZ4_RING=4096|8192 for tuning */
+    /* output ring size per wave: 4 KiB default (16 waves/CU by LDS; 2 KiB is not possible: sources a batch calls far must already be flushed, i.e. lie kTMax + one 1 KiB flush unit back); CRYO_LZ4_RING=4096|8192 for tuning */
     static const int ring = [] {
         const char *e = getenv("CRYO_LZ4_RING");
         return e ? atoi(e) : 4096;
