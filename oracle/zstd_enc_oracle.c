@@ -4,23 +4,26 @@
  * Restates ZSTD_compress(dst, ZSTD_compressBound(B), src, B, level) as libzstd 1.4.8 runs it
  * for the reference's call shape (compression.c:102-104), for the levels whose strategy is
  * `fast` (levels -5 .. 2 at cryo block sizes; the reference's default
- * level 1 is one of them) or `dfast` (levels 3 and 4).  Output bytes are identical to the library's; pinned by
+ * level 1 is one of them), `dfast` (levels 3 and 4) or `greedy` / `lazy` / `lazy2` (levels 5 .. 10; these have no
+ * device kernel yet: restated ahead of it).  Output bytes are identical to the library's; pinned by
  * tests/golden/vectors.json (libzstd 1.4.8 == 1.4.9) and by a live differential test.
  *
  * Pipeline restated (all integer arithmetic):
  *   parameters by level and size -> frame header -> per 128 KiB block:
  *     greedy 2-position hash-table match finder with repeat-offset checks ("fast" strategy), or
- *     the two-table (8-byte long hash + short hash) finder of the "dfast" strategy
+ *     the two-table (8-byte long hash + short hash) finder of the "dfast" strategy, or the hash-chain
+ *     searcher with the greedy / lazy (depth 1, 2) parsers
  *     -> sequences (literal length, match length, offset code) + literal bytes
  *     -> literals: raw / RLE / Huffman (length-limited tree, FSE-compressed or raw weights,
  *        1 or 4 backward bitstreams), with the library's "worth it" heuristics
- *     -> sequences: per-field encoding type (predefined / RLE / FSE) by the below-`lazy`
- *        heuristic, FSE table normalisation + description, interleaved backward bitstream
+ *     -> sequences: per-field encoding type (predefined / RLE / FSE / repeat of the previous block's
+ *        table) by thresholds below `lazy`, by estimated costs from `lazy` on, FSE table normalisation + description, interleaved backward bitstream
  *     -> raw block fallback when the gain is below srcSize/64 + 2; RLE block for constant
  *        non-first blocks
  */
 #include "cryo_oracle.h"
 #include <string.h>
+#include <math.h>
 
 #define ZBLOCK_MAX (128u * 1024u)
 #define MINMATCH 3
@@ -68,6 +71,7 @@ static size_t bw_flush(bitw *b)
 typedef struct { int delta_find; uint32_t delta_nb; } fse_sym;
 typedef struct {
     int log;
+    uint32_t max_sym;         /* maxSymbolValue of the table (repeat-mode cost test) */
     uint16_t state[1 << 9];   /* table sizes here are <= 512 */
     fse_sym sym[256];
 } fse_ct;
@@ -212,6 +216,7 @@ static void fse_build_ct(fse_ct *ct, const int16_t *norm, uint32_t max_sym, int 
     uint32_t cumul[258];
     uint32_t high = size - 1, pos = 0, u;
     ct->log = log;
+    ct->max_sym = max_sym;
     cumul[0] = 0;
     for (u = 1; u <= max_sym + 1; u++) {
         if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; cell[high--] = (uint8_t)(u - 1); }
@@ -252,6 +257,7 @@ static void fse_build_ct(fse_ct *ct, const int16_t *norm, uint32_t max_sym, int 
 static void fse_build_ct_rle(fse_ct *ct, uint32_t sym)
 {
     ct->log = 0;
+    ct->max_sym = sym;
     ct->state[0] = 0; ct->state[1] = 0;
     ct->sym[sym].delta_nb = 0; ct->sym[sym].delta_find = 0;
 }
@@ -269,6 +275,8 @@ static uint32_t fse_encode(bitw *b, const fse_ct *ct, uint32_t state, uint32_t s
     bw_add(b, state, (int)nb);
     return ct->state[(int)(state >> nb) + t.delta_find];
 }
+
+static int g_strategy = 1; /* ZSTD_fast = 1, dfast 2, greedy 3, lazy 4, lazy2 5; set by the frame driver */
 
 /* ------------------------------------------------------------ Huffman (compression side) */
 typedef struct { uint16_t val; uint8_t nb; } huf_elt;
@@ -562,7 +570,7 @@ static size_t compress_literals(uint8_t *dst, const uint8_t *src, size_t n, cons
     /* ZSTD_disableLiteralsCompression: strategy fast with targetLength > 0 (negative levels) */
     if (disable) return lit_raw(dst, src, n);
     if (n <= 63) return lit_raw(dst, src, n);
-    c = huf_compress(dst + lh, src, n, single, next, n <= 1024, &reused);
+    c = huf_compress(dst + lh, src, n, single, next, g_strategy < 4 ? n <= 1024 : 0, &reused);
     if (reused) htype = 3;
     if (c == 0 || c >= n - min_gain(n)) { *next = *prev; return lit_raw(dst, src, n); }
     if (c == 1) { *next = *prev; return lit_rle(dst, src, n); }
@@ -614,17 +622,90 @@ static uint32_t ml_code(uint32_t mb)
 
 enum { SET_BASIC = 0, SET_RLE = 1, SET_COMPRESSED = 2, SET_REPEAT = 3 };
 
-/* ZSTD_selectEncodingType for strategies below `lazy` (no dictionary: repeat mode is never "valid") */
-static int g_strategy = 1; /* ZSTD_fast = 1, ZSTD_dfast = 2; set by the frame driver */
-static int select_type(uint32_t max, size_t most, size_t nseq, int def_log, int def_allowed)
+/* ---- ZSTD_selectEncodingType.  Strategies below `lazy`: thresholds; `lazy` and above: estimated costs, and
+ * the previous block's table may be repeated (FSE_repeat_check) ---- */
+#define COST_ERR ((size_t)-1)
+static unsigned inv_prob_log256(unsigned x) /* kInverseProbabilityLog256[x] = (unsigned)(-log2(x / 256.) * 256) */
 {
-    (void)max;
-    if (most == nseq) return (def_allowed && nseq <= 2) ? SET_BASIC : SET_RLE;
-    if (def_allowed) {
-        const size_t mult = 10 - (size_t)g_strategy;
-        const size_t dyn_min = (((size_t)1 << def_log) * mult) >> 3;
-        if (nseq < dyn_min || most < (nseq >> (def_log - 1))) return SET_BASIC;
+    static unsigned tab[256];
+    static int ready = 0;
+    if (!ready) {
+        unsigned i;
+        tab[0] = 0;
+        for (i = 1; i < 256; i++) tab[i] = (unsigned)((8.0 - log2((double)i)) * 256.0);
+        ready = 1;
     }
+    return tab[x];
+}
+static size_t entropy_cost(const uint32_t *count, uint32_t max, size_t total)
+{
+    unsigned cost = 0, s;
+    for (s = 0; s <= max; s++) {
+        unsigned norm = (unsigned)((256 * count[s]) / total);
+        if (count[s] != 0 && norm == 0) norm = 1;
+        cost += count[s] * inv_prob_log256(norm);
+    }
+    return cost >> 8;
+}
+static size_t cross_entropy_cost(const int16_t *norm, unsigned acc_log, const uint32_t *count, uint32_t max)
+{
+    const unsigned shift = 8 - acc_log;
+    size_t cost = 0;
+    unsigned s;
+    for (s = 0; s <= max; s++) {
+        const unsigned nacc = norm[s] != -1 ? (unsigned)norm[s] : 1;
+        cost += count[s] * inv_prob_log256(nacc << shift);
+    }
+    return cost >> 8;
+}
+static size_t fse_bit_cost(const fse_ct *ct, const uint32_t *count, uint32_t max)
+{
+    size_t cost = 0;
+    unsigned s;
+    if (ct->max_sym < max) return COST_ERR;
+    for (s = 0; s <= max; s++) {
+        const uint32_t tlog = (uint32_t)ct->log, bad = (tlog + 1) << 8;
+        const uint32_t min_nb = ct->sym[s].delta_nb >> 16;
+        const uint32_t threshold = (min_nb + 1) << 16;
+        const uint32_t from_thr = threshold - (ct->sym[s].delta_nb + (1u << tlog));
+        const uint32_t norm_from_thr = (from_thr << 8) >> tlog;
+        const uint32_t bit_cost = (min_nb + 1) * 256u - norm_from_thr;
+        if (count[s] == 0) continue;
+        if (bit_cost >= bad) return COST_ERR;
+        cost += (size_t)count[s] * bit_cost;
+    }
+    return cost >> 8;
+}
+static size_t ncount_cost(const uint32_t *count, uint32_t max, size_t nseq, int fse_log)
+{
+    uint8_t wksp[512];
+    int16_t norm[MaxML + 1];
+    const int log = fse_optimal_log(fse_log, nseq, max, 2);
+    size_t sz;
+    if (fse_normalize(norm, log, count, nseq, max, nseq >= 2048) <= 0) return COST_ERR;
+    sz = fse_write_ncount(wksp, norm, max, log);
+    return sz ? sz : COST_ERR;
+}
+/* *rep_mode: 0 none, 1 check (the previous compressed block left a usable table) */
+static int select_type(const uint32_t *count, uint32_t max, size_t most, size_t nseq, int fse_log, const fse_ct *prev, int *rep_mode,
+                       const int16_t *def_norm, int def_log, int def_allowed)
+{
+    if (most == nseq) { *rep_mode = 0; return (def_allowed && nseq <= 2) ? SET_BASIC : SET_RLE; }
+    if (g_strategy < 4) {
+        if (def_allowed) {
+            const size_t mult = 10 - (size_t)g_strategy;
+            const size_t dyn_min = (((size_t)1 << def_log) * mult) >> 3;
+            if (nseq < dyn_min || most < (nseq >> (def_log - 1))) { *rep_mode = 0; return SET_BASIC; }
+        }
+    } else {
+        const size_t basic = def_allowed ? cross_entropy_cost(def_norm, (unsigned)def_log, count, max) : COST_ERR;
+        const size_t repeat = *rep_mode != 0 ? fse_bit_cost(prev, count, max) : COST_ERR;
+        const size_t nc = ncount_cost(count, max, nseq, fse_log);
+        const size_t compressed = (nc << 3) + entropy_cost(count, max, nseq);
+        if (basic <= repeat && basic <= compressed) { *rep_mode = 0; return SET_BASIC; }
+        if (repeat <= compressed) return SET_REPEAT;
+    }
+    *rep_mode = 1;
     return SET_COMPRESSED;
 }
 
@@ -632,6 +713,7 @@ static int select_type(uint32_t max, size_t most, size_t nseq, int def_log, int 
 static size_t build_ctable(uint8_t *dst, fse_ct *ct, int fse_log, int type, uint32_t *count, uint32_t max,
                            const uint8_t *codes, size_t nseq, const int16_t *def_norm, int def_log, uint32_t def_max)
 {
+    if (type == SET_REPEAT) return 0; /* *ct already holds the previous block's table */
     if (type == SET_RLE) { fse_build_ct_rle(ct, max); dst[0] = codes[0]; return 1; }
     if (type == SET_BASIC) { fse_build_ct(ct, def_norm, def_max, def_log); return 0; }
     {
@@ -647,17 +729,23 @@ static size_t build_ctable(uint8_t *dst, fse_ct *ct, int fse_log, int type, uint
     }
 }
 
+/* sequence tables + repeat modes that a compressed block leaves to the next one of its frame */
+typedef struct { fse_ct ll, of, ml; int rep_ll, rep_of, rep_ml; } fse_state;
+
 /* literals + sequences of one block -> compressed block body; 0 = emit a raw block */
 static size_t compress_sequences(uint8_t *dst, const seq_t *seqs, size_t nseq, const uint8_t *lits, size_t nlit,
                                  size_t src_size, int long_pos, int long_kind, const huf_state *hprev, huf_state *hnext,
-                                 int disable_lit)
+                                 const fse_state *fprev, fse_state *fnext, int disable_lit)
 {
     static uint8_t llc[ZBLOCK_MAX / 3 + 8], mlc[ZBLOCK_MAX / 3 + 8], ofc[ZBLOCK_MAX / 3 + 8];
-    static fse_ct ct_ll, ct_of, ct_ml;
+#define ct_ll (fnext->ll)
+#define ct_of (fnext->of)
+#define ct_ml (fnext->ml)
     uint32_t count[MaxML + 1], max, s;
     size_t op, i, most;
     uint8_t *seq_head, *last_ncount = NULL;
     int tll, tof, tml;
+    *fnext = *fprev;
     op = compress_literals(dst, lits, nlit, hprev, hnext, disable_lit);
     if (nseq < 128) dst[op++] = (uint8_t)nseq;
     else if (nseq < 0x7F00) { dst[op] = (uint8_t)((nseq >> 8) + 0x80); dst[op + 1] = (uint8_t)nseq; op += 2; }
@@ -683,19 +771,19 @@ static size_t compress_sequences(uint8_t *dst, const seq_t *seqs, size_t nseq, c
     {
         size_t sz;
         HIST(llc, MaxLL);
-        tll = select_type(max, most, nseq, 6, 1);
+        tll = select_type(count, max, most, nseq, LLFSELog, &fprev->ll, &fnext->rep_ll, LL_def, 6, 1);
         sz = build_ctable(dst + op, &ct_ll, LLFSELog, tll, count, max, llc, nseq, LL_def, 6, MaxLL);
         if (sz == (size_t)-1) return 0;
         if (tll == SET_COMPRESSED) last_ncount = dst + op;
         op += sz;
         HIST(ofc, MaxOff);
-        tof = select_type(max, most, nseq, 5, max <= DefaultMaxOff);
+        tof = select_type(count, max, most, nseq, OffFSELog, &fprev->of, &fnext->rep_of, OF_def, 5, max <= DefaultMaxOff);
         sz = build_ctable(dst + op, &ct_of, OffFSELog, tof, count, max, ofc, nseq, OF_def, 5, DefaultMaxOff);
         if (sz == (size_t)-1) return 0;
         if (tof == SET_COMPRESSED) last_ncount = dst + op;
         op += sz;
         HIST(mlc, MaxML);
-        tml = select_type(max, most, nseq, 6, 1);
+        tml = select_type(count, max, most, nseq, MLFSELog, &fprev->ml, &fnext->rep_ml, ML_def, 6, 1);
         sz = build_ctable(dst + op, &ct_ml, MLFSELog, tml, count, max, mlc, nseq, ML_def, 6, MaxML);
         if (sz == (size_t)-1) return 0;
         if (tml == SET_COMPRESSED) last_ncount = dst + op;
@@ -732,10 +820,13 @@ static size_t compress_sequences(uint8_t *dst, const seq_t *seqs, size_t nseq, c
 check:
     if (op >= src_size - min_gain(src_size)) return 0;
     return op;
+#undef ct_ll
+#undef ct_of
+#undef ct_ml
 }
 
 /* ------------------------------------------------------------ match finder: strategy `fast` */
-typedef struct { int wlog, clog, hlog, mml, tlen, dfast; } cpar;
+typedef struct { int wlog, clog, hlog, slog, mml, tlen, dfast, lazy_depth; /* lazy_depth: -1 none, 0 greedy, 1 lazy, 2 lazy2 */ } cpar;
 
 static uint32_t hash_ptr(const uint8_t *p, int hlog, int mls)
 {
@@ -948,29 +1039,173 @@ static size_t block_dfast(uint32_t *tlong, uint32_t *tshort, const cpar *cp, con
     return (size_t)(iend - anchor);
 }
 
+/* ------------------------------------------------------------ match finder: strategies `greedy`, `lazy`, `lazy2`
+ * (libzstd 1.4.8 ZSTD_compressBlock_lazy_generic over the hash-chain searcher ZSTD_HcFindBestMatch, no
+ * dictionary): every position up to the one searched is inserted into a hash table + chain table; a search
+ * walks at most 2^searchLog chain links and keeps the longest match; depth 1/2 retry at ip+1 (ip+2) and keep
+ * the candidate whose gain estimate is better.  Groundwork for the next encoder row: there is no device
+ * kernel for these levels yet (the product returns CRYO_E_UNSUPPORTED). */
+typedef struct { uint32_t *hash, *chain; uint32_t next_to_update; } hc_state;
+
+static uint32_t hc_insert_find(hc_state *hc, const cpar *cp, const uint8_t *base, uint32_t target, int mls)
+{
+    const uint32_t cmask = (1u << cp->clog) - 1u;
+    uint32_t idx = hc->next_to_update;
+    while (idx < target) {
+        const uint32_t h = hash_ptr(base + idx, cp->hlog, mls);
+        hc->chain[idx & cmask] = hc->hash[h];
+        hc->hash[h] = idx;
+        idx++;
+    }
+    hc->next_to_update = target;
+    return hc->hash[hash_ptr(base + target, cp->hlog, mls)];
+}
+
+static size_t hc_find_best(hc_state *hc, const cpar *cp, const uint8_t *base, const uint8_t *ip, const uint8_t *ilimit_end,
+                           size_t *offset_ptr, int mls)
+{
+    const uint32_t csize = 1u << cp->clog, cmask = csize - 1u;
+    const uint32_t cur = (uint32_t)(ip - base);
+    const uint32_t max_dist = 1u << cp->wlog;
+    const uint32_t lowest_valid = 1; /* window.lowLimit */
+    const uint32_t low_limit = (cur - lowest_valid > max_dist) ? cur - max_dist : lowest_valid;
+    const uint32_t min_chain = cur > csize ? cur - csize : 0;
+    uint32_t attempts = 1u << cp->slog;
+    size_t ml = 4 - 1;
+    uint32_t mi = hc_insert_find(hc, cp, base, cur, mls);
+    for (; (mi >= low_limit) && (attempts > 0); attempts--) {
+        size_t cml = 0;
+        const uint8_t *match = base + mi;
+        if (match[ml] == ip[ml]) cml = count_match(ip, match, ilimit_end);
+        if (cml > ml) {
+            ml = cml;
+            *offset_ptr = cur - mi + REP_MOVE;
+            if (ip + cml == ilimit_end) break;
+        }
+        if (mi <= min_chain) break;
+        mi = hc->chain[mi & cmask];
+    }
+    return ml;
+}
+
+static int hb32(uint32_t v) { return hb(v); }
+
+static size_t block_lazy(hc_state *hc, const cpar *cp, const uint8_t *base, const uint8_t *istart, size_t n, uint32_t rep[3],
+                         seqstore *ss)
+{
+    const int depth = cp->lazy_depth;
+    const int mls = cp->mml < 4 ? 4 : (cp->mml > 6 ? 6 : cp->mml);
+    const uint8_t *ip = istart, *anchor = istart;
+    const uint8_t *iend = istart + n, *ilimit = iend - 8;
+    const uint8_t *prefix_lowest = base + 1; /* window.dictLimit: not window-limited here */
+    uint32_t off1 = rep[0], off2 = rep[1], saved = 0;
+    ip += (ip == prefix_lowest);
+    {
+        const uint32_t cur = (uint32_t)(ip - base);
+        const uint32_t max_dist = 1u << cp->wlog;
+        const uint32_t wlow = (cur - 1u > max_dist) ? cur - max_dist : 1u;
+        const uint32_t max_rep = cur - wlow;
+        if (off2 > max_rep) { saved = off2; off2 = 0; }
+        if (off1 > max_rep) { saved = off1; off1 = 0; }
+    }
+    while (ip < ilimit) {
+        size_t mlen = 0, offset = 0;
+        const uint8_t *start = ip + 1;
+        if (off1 > 0 && rd32(ip + 1 - off1) == rd32(ip + 1)) {
+            mlen = count_match(ip + 1 + 4, ip + 1 + 4 - off1, iend) + 4;
+            if (depth == 0) goto store;
+        }
+        {
+            size_t off_found = 999999999;
+            const size_t ml2 = hc_find_best(hc, cp, base, ip, iend, &off_found, mls);
+            if (ml2 > mlen) { mlen = ml2; start = ip; offset = off_found; }
+        }
+        if (mlen < 4) { ip += ((size_t)(ip - anchor) >> 8) + 1; continue; }
+        if (depth >= 1)
+            while (ip < ilimit) {
+                ip++;
+                if (offset && off1 > 0 && rd32(ip) == rd32(ip - off1)) {
+                    const size_t ml_rep = count_match(ip + 4, ip + 4 - off1, iend) + 4;
+                    const int gain2 = (int)(ml_rep * 3);
+                    const int gain1 = (int)(mlen * 3 - (size_t)hb32((uint32_t)offset + 1) + 1);
+                    if (ml_rep >= 4 && gain2 > gain1) { mlen = ml_rep; offset = 0; start = ip; }
+                }
+                {
+                    size_t off2f = 999999999;
+                    const size_t ml2 = hc_find_best(hc, cp, base, ip, iend, &off2f, mls);
+                    const int gain2 = (int)(ml2 * 4 - (size_t)hb32((uint32_t)off2f + 1));
+                    const int gain1 = (int)(mlen * 4 - (size_t)hb32((uint32_t)offset + 1) + 4);
+                    if (ml2 >= 4 && gain2 > gain1) { mlen = ml2; offset = off2f; start = ip; continue; }
+                }
+                if (depth == 2 && ip < ilimit) {
+                    ip++;
+                    if (offset && off1 > 0 && rd32(ip) == rd32(ip - off1)) {
+                        const size_t ml_rep = count_match(ip + 4, ip + 4 - off1, iend) + 4;
+                        const int gain2 = (int)(ml_rep * 4);
+                        const int gain1 = (int)(mlen * 4 - (size_t)hb32((uint32_t)offset + 1) + 1);
+                        if (ml_rep >= 4 && gain2 > gain1) { mlen = ml_rep; offset = 0; start = ip; }
+                    }
+                    {
+                        size_t off2f = 999999999;
+                        const size_t ml2 = hc_find_best(hc, cp, base, ip, iend, &off2f, mls);
+                        const int gain2 = (int)(ml2 * 4 - (size_t)hb32((uint32_t)off2f + 1));
+                        const int gain1 = (int)(mlen * 4 - (size_t)hb32((uint32_t)offset + 1) + 7);
+                        if (ml2 >= 4 && gain2 > gain1) { mlen = ml2; offset = off2f; start = ip; continue; }
+                    }
+                }
+                break;
+            }
+        if (offset) {
+            while (start > anchor && start - (offset - REP_MOVE) > prefix_lowest && start[-1] == (start - (offset - REP_MOVE))[-1]) { start--; mlen++; }
+            off2 = off1;
+            off1 = (uint32_t)(offset - REP_MOVE);
+        }
+    store:
+        store_seq(ss, (size_t)(start - anchor), anchor, (uint32_t)offset, mlen - MINMATCH);
+        anchor = ip = start + mlen;
+        while (ip <= ilimit && off2 > 0 && rd32(ip) == rd32(ip - off2)) {
+            mlen = count_match(ip + 4, ip + 4 - off2, iend) + 4;
+            offset = off2; off2 = off1; off1 = (uint32_t)offset;
+            store_seq(ss, 0, anchor, 0, mlen - MINMATCH);
+            ip += mlen;
+            anchor = ip;
+        }
+    }
+    rep[0] = off1 ? off1 : saved;
+    rep[1] = off2 ? off2 : saved;
+    return (size_t)(iend - anchor);
+}
+
 /* ------------------------------------------------------------ parameters (ZSTD_getCParams) */
 static int get_cpar(int level, size_t n, cpar *cp)
 {
-    /* rows: level 0(base for negatives),1,2,3,4 of the library's tables for the two size classes the
-     * cryo path uses {windowLog, chainLog, hashLog, minMatch}; validated against ZSTD_getCParams by the tests */
-    static const int big[5][4] = {{19, 12, 13, 6}, {19, 13, 14, 7}, {20, 15, 16, 6}, {21, 16, 17, 5}, {21, 18, 18, 5}}; /* n > 256 KiB */
-    static const int k128[5][4] = {{17, 12, 12, 5}, {17, 12, 13, 6}, {17, 13, 15, 5}, {17, 15, 16, 5}, {17, 17, 17, 4}}; /* 16 KiB < n <= 128 KiB */
-    const int (*t)[4];
-    int row, srclog;
+    /* rows: level 0 (base for negatives), 1 .. 10 of the library's tables for the two size classes the cryo path
+     * uses {windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy: 1 fast 2 dfast 3 greedy
+     * 4 lazy 5 lazy2}; validated against ZSTD_getCParams by the tests */
+    static const int big[11][7] = {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2},
+                                   {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}, {21, 19, 19, 3, 5, 8, 4},
+                                   {21, 19, 19, 3, 5, 16, 5}, {21, 19, 20, 4, 5, 16, 5}, {22, 20, 21, 4, 5, 16, 5}}; /* n > 256 KiB */
+    static const int k128[11][7] = {{17, 12, 12, 1, 5, 1, 1}, {17, 12, 13, 1, 6, 0, 1}, {17, 13, 15, 1, 5, 0, 1}, {17, 15, 16, 2, 5, 0, 2},
+                                    {17, 17, 17, 2, 4, 0, 2}, {17, 16, 17, 3, 4, 2, 3}, {17, 17, 17, 3, 4, 4, 4}, {17, 17, 17, 3, 4, 8, 5},
+                                    {17, 17, 17, 4, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 5}, {17, 17, 17, 6, 4, 8, 5}}; /* 16 KiB < n <= 128 KiB */
+    const int (*t)[7];
+    int row, srclog, strat;
     if (level == 0) level = 3;
-    if (level > 4 || level < -131072) return -1; /* other levels: neither `fast` nor `dfast` */
+    if (level > 10 || level < -131072) return -1; /* other levels: bt* strategies, not restated */
     if (n > 256u * 1024u) t = big;
     else if (n > 16u * 1024u && n <= 128u * 1024u) t = k128;
     else return -1;
     row = level < 0 ? 0 : level;
-    cp->wlog = t[row][0]; cp->clog = t[row][1]; cp->hlog = t[row][2]; cp->mml = t[row][3];
-    cp->tlen = level < 0 ? -level : 0;
-    cp->dfast = level >= 3;
+    cp->wlog = t[row][0]; cp->clog = t[row][1]; cp->hlog = t[row][2]; cp->slog = t[row][3]; cp->mml = t[row][4];
+    cp->tlen = level < 0 ? -level : t[row][5];
+    strat = t[row][6];
+    cp->dfast = strat == 2;
+    cp->lazy_depth = strat >= 3 ? strat - 3 : -1;
     /* ZSTD_adjustCParams_internal: shrink the window (and hash, chain) to the source size */
     srclog = (n < 64) ? 6 : hb((uint32_t)(n - 1)) + 1;
     if (cp->wlog > srclog) cp->wlog = srclog;
     if (cp->hlog > cp->wlog + 1) cp->hlog = cp->wlog + 1;
-    if (cp->clog > cp->wlog) cp->clog = cp->wlog;
+    if (cp->clog > cp->wlog) cp->clog = cp->wlog; /* cycleLog == chainLog for the non-bt strategies */
     if (cp->wlog < 10) cp->wlog = 10;
     return 0;
 }
@@ -978,7 +1213,8 @@ static int get_cpar(int level, size_t n, cpar *cp)
 /* ------------------------------------------------------------ frame */
 size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int level)
 {
-    static uint32_t table[1 << 18], tshort[1 << 18];
+    static uint32_t table[1 << 21], tshort[1 << 20]; /* hash (long) table; short table / chain table */
+    hc_state hc;
     static seq_t seqs[ZBLOCK_MAX / 3 + 8];
     static uint8_t lits[ZBLOCK_MAX + 8];
     cpar cp;
@@ -988,11 +1224,14 @@ size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, siz
     const uint8_t *base = src - 1;
     int first = 1;
     static huf_state hprev, hnext;
+    static fse_state fprev, fnext;
     hprev.mode = 0;
+    fprev.rep_ll = fprev.rep_of = fprev.rep_ml = 0;
     if (get_cpar(level, n, &cp) || cap < cryo_oracle_zstd_bound(n)) return 0;
     memset(table, 0, sizeof(uint32_t) << cp.hlog);
-    if (cp.dfast) memset(tshort, 0, sizeof(uint32_t) << cp.clog);
-    g_strategy = cp.dfast ? 2 : 1;
+    if (cp.dfast || cp.lazy_depth >= 0) memset(tshort, 0, sizeof(uint32_t) << cp.clog);
+    g_strategy = cp.lazy_depth >= 0 ? 3 + cp.lazy_depth : (cp.dfast ? 2 : 1);
+    hc.hash = table; hc.chain = tshort; hc.next_to_update = 1;
     /* frame header: content size always, no checksum, no dictionary id */
     {
         const uint64_t wsize = 1ull << cp.wlog;
@@ -1021,17 +1260,27 @@ size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, siz
             size_t last_ll;
             ss.seqs = seqs; ss.nseq = 0; ss.lits = lits; ss.nlit = 0; ss.long_pos = 0; ss.long_kind = 0;
             nrep[0] = rep[0]; nrep[1] = rep[1]; nrep[2] = rep[2];
-            last_ll = cp.dfast ? block_dfast(table, tshort, &cp, base, src + ip, bs, nrep, &ss, dict_limit)
-                               : block_fast(table, &cp, base, src + ip, bs, nrep, &ss, dict_limit);
+            if (cp.lazy_depth >= 0) {
+                /* ZSTD_buildSeqStore: limited catch-up after a very long match */
+                const uint32_t cur = (uint32_t)(ip + 1);
+                if (cur > hc.next_to_update + 384u) {
+                    const uint32_t d = cur - hc.next_to_update - 384u;
+                    hc.next_to_update = cur - (d < 192u ? d : 192u);
+                }
+                last_ll = block_lazy(&hc, &cp, base, src + ip, bs, nrep, &ss);
+            } else
+                last_ll = cp.dfast ? block_dfast(table, tshort, &cp, base, src + ip, bs, nrep, &ss, dict_limit)
+                                   : block_fast(table, &cp, base, src + ip, bs, nrep, &ss, dict_limit);
             memcpy(lits + ss.nlit, src + ip + bs - last_ll, last_ll);
             ss.nlit += last_ll;
-            csize = compress_sequences(dst + op + 3, seqs, ss.nseq, lits, ss.nlit, bs, ss.long_pos, ss.long_kind, &hprev, &hnext, cp.tlen > 0);
+            csize = compress_sequences(dst + op + 3, seqs, ss.nseq, lits, ss.nlit, bs, ss.long_pos, ss.long_kind, &hprev, &hnext,
+                                       &fprev, &fnext, cp.lazy_depth < 0 && !cp.dfast && cp.tlen > 0);
             if (!first && csize < 25) { /* RLE block for constant non-first blocks */
                 size_t k = 1;
                 while (k < bs && src[ip + k] == src[ip]) k++;
                 if (k == bs) { csize = 1; dst[op + 3] = src[ip]; }
             }
-            if (csize > 1) { rep[0] = nrep[0]; rep[1] = nrep[1]; rep[2] = nrep[2]; hprev = hnext; }
+            if (csize > 1) { rep[0] = nrep[0]; rep[1] = nrep[1]; rep[2] = nrep[2]; hprev = hnext; fprev = fnext; }
         }
         if (csize == 0) {
             const uint32_t h = (uint32_t)last + (0u << 1) + ((uint32_t)bs << 3);
