@@ -10,7 +10,7 @@ cd "$T"
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer"
 make -s -C oracle clean
 make -s -C oracle CFLAGS="-O1 -g -fPIC -Wall -std=c99 $SAN"
-gcc -shared -o oracle/libcryo_oracle.so oracle/*.o -lpthread -ldl $SAN
+gcc -shared -o oracle/libcryo_oracle.so oracle/*.o -lpthread -ldl -lm $SAN
 make -s -C pg_cryogen_amd/host clean
 make -s -C pg_cryogen_amd/host CFLAGS="-O1 -g -fPIC -Wall -std=gnu11 -I../../include $SAN"
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
