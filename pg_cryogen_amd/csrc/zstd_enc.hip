@@ -873,7 +873,7 @@ __device__ uint32_t compress_sequences(EncLds &L, uint8_t *dst, uint8_t *ws, uin
 }
 
 /* ------------------------------------------------------------ match finder: strategy `fast` */
-struct CPar { int wlog, clog, hlog, mml, tlen; };
+struct CPar { int wlog, clog, hlog, slog, mml, tlen; };
 
 __device__ inline uint32_t hash_ptr(const uint8_t *p, int hlog, int mls)
 {
@@ -1002,13 +1002,15 @@ __device__ uint32_t block_fast(uint32_t *table, const CPar &cp, const uint8_t *b
 
 
 #include "zstd_dfast.h"
+#include "zstd_lazy.h"
 
 } // namespace
 
 /* One wave per frame, persistent grid.  The match finder's tables (u32, zeroed per frame) live in global memory
  * behind the workgroup's workspace: long/only table, then dfast's short table.  finder: 0 = `fast`, many
  * iterations per step (block_fast_gbatch); 1 = `dfast` (block_dfast_batch); 2 = `fast`, the serial walk
- * (block_fast: the plain restatement, CRYO_ZSTD_ENC=1). */
+ * (block_fast: the plain restatement, CRYO_ZSTD_ENC=1); 3 = `greedy` (block_greedy: hash table, then chain table;
+ * `width` carries searchLog). */
 template <bool PROF> /* PROF: CRYO_ZSTD_STATS counters */
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t n_blocks,
@@ -1024,8 +1026,9 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *ws = workspace + (uint64_t)blockIdx.x * ws_stride;
     CPar cp;
-    cp.wlog = wlog; cp.clog = clog; cp.hlog = hlog; cp.mml = mml; cp.tlen = tlen;
+    cp.wlog = wlog; cp.clog = clog; cp.hlog = hlog; cp.slog = (int)width; cp.mml = mml; cp.tlen = tlen;
     const bool dfast = finder == 1;
+    const bool two_tables = finder == 1 || finder == 3;
     uint32_t *table = reinterpret_cast<uint32_t *>(ws + kWsBytes);
     uint32_t *tshort = table + (1u << hlog); /* dfast only */
 
@@ -1033,7 +1036,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         const uint8_t *src = src_base + blk * src_stride;
         uint8_t *dst = dst_base + blk * dst_stride;
         {
-            const uint32_t quads = ((1u << hlog) + (dfast ? 1u << clog : 0u)) / 4u;
+            const uint32_t quads = ((1u << hlog) + (two_tables ? 1u << clog : 0u)) / 4u;
             for (uint32_t i = lane; i < quads; i += 64u) reinterpret_cast<uint4 *>(table)[i] = make_uint4(0, 0, 0, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1058,7 +1061,8 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         const uint8_t *base = src - 1;
         bool first = true;
         HufState hs;
-        hs.prev_valid = false; hs.next_new = false; hs.prof = PROF ? stats : nullptr; hs.t = 0; hs.strat = dfast ? 2u : 1u;
+        hs.prev_valid = false; hs.next_new = false; hs.prof = PROF ? stats : nullptr; hs.t = 0; hs.strat = finder == 3 ? 3u : (dfast ? 2u : 1u);
+        HcState hc = {table, tshort, 1u};
         uint32_t ip = 0;
         while (ip < n) {
             const uint32_t bs = (n - ip < kZBlk) ? n - ip : kZBlk;
@@ -1073,6 +1077,14 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 if constexpr (PROF) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_other += t - t_prev; t_prev = t; }
                 uint32_t last_ll;
                 if (finder == 1) last_ll = block_dfast_batch<PROF>(table, tshort, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, width, stats);
+                else if (finder == 3) {
+                    const uint32_t cur = ip + 1u; /* ZSTD_buildSeqStore: limited catch-up after a very long match */
+                    if (cur > hc.next_to_update + 384u) {
+                        const uint32_t d = cur - hc.next_to_update - 384u;
+                        hc.next_to_update = cur - (d < 192u ? d : 192u);
+                    }
+                    last_ll = block_greedy(hc, df_mark, cp, base, src + ip, bs, nrep, ws, ss, lane);
+                }
                 else if (finder == 0) last_ll = block_fast_gbatch(table, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, width);
                 else last_ll = block_fast(table, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane);
                 if constexpr (PROF) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mf += t - t_prev; t_prev = t; }
@@ -1081,7 +1093,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 if constexpr (PROF) hs.t = __builtin_amdgcn_s_memtime();
                 csize = compress_sequences(L, dst + op + 3, ws, ss.nseq, ss.nlit, bs, ss.long_pos, ss.long_kind, hs,
-                                           tlen > 0, lane);
+                                           (finder == 0 || finder == 2) && tlen > 0 /* literals stay raw only for `fast` with a target length */, lane);
                 if constexpr (PROF) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_en += t - t_prev; t_prev = t; }
                 if (!first && csize < 25u) { /* RLE block for constant non-first blocks */
                     const uint32_t b0 = uni(src[ip]);
@@ -1120,23 +1132,27 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
     }
 }
 
-/* ZSTD_getCParams + ZSTD_adjustCParams for the `fast` (-5..2) and `dfast` (3, 4) levels at cryo block sizes
- * (oracle-checked).  *clog is only used by dfast: the short table's log. */
+/* ZSTD_getCParams + ZSTD_adjustCParams for the levels with a kernel at cryo block sizes (oracle-checked): `fast`
+ * (-5..2), `dfast` (3, 4), `greedy` (5; 6 above 256 KiB).  *clog: dfast's short table / greedy's chain table;
+ * *strategy: 1 fast, 2 dfast, 3 greedy; *slog: greedy's searchLog. */
 static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *mml, int *tlen, int *clog = nullptr,
-                              bool *dfast = nullptr)
+                              bool *dfast = nullptr, int *strategy = nullptr, int *slog = nullptr)
 {
-    static const int big[5][4] = {{19, 12, 13, 6}, {19, 13, 14, 7}, {20, 15, 16, 6}, {21, 16, 17, 5}, {21, 18, 18, 5}}; /* n > 256 KiB: wlog, clog, hlog, mml */
-    static const int k128[5][4] = {{17, 12, 12, 5}, {17, 12, 13, 6}, {17, 13, 15, 5}, {17, 15, 16, 5}, {17, 17, 17, 4}}; /* 16 KiB < n <= 128 KiB */
-    const int (*t)[4];
+    static const int big[7][7] = {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2},
+                                  {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}}; /* n > 256 KiB: wlog, clog, hlog, slog, mml, tlen, strategy */
+    static const int k128[6][7] = {{17, 12, 12, 1, 5, 1, 1}, {17, 12, 13, 1, 6, 0, 1}, {17, 13, 15, 1, 5, 0, 1}, {17, 15, 16, 2, 5, 0, 2},
+                                   {17, 17, 17, 2, 4, 0, 2}, {17, 16, 17, 3, 4, 2, 3}}; /* 16 KiB < n <= 128 KiB */
+    const int (*t)[7];
+    int maxl;
     if (level == 0) level = 3;
-    if (level > 4 || level < -131072) return false;
-    if (n > 256u * 1024u) t = big;
-    else if (n > 16u * 1024u && n <= 128u * 1024u) t = k128;
+    if (n > 256u * 1024u) { t = big; maxl = 6; }
+    else if (n > 16u * 1024u && n <= 128u * 1024u) { t = k128; maxl = 5; }
     else return false;
+    if (level > maxl || level < -131072) return false;
     const int row = level < 0 ? 0 : level;
     int cl = t[row][1];
-    *wlog = t[row][0]; *hlog = t[row][2]; *mml = t[row][3];
-    *tlen = level < 0 ? -level : 0;
+    *wlog = t[row][0]; *hlog = t[row][2]; *mml = t[row][4];
+    *tlen = level < 0 ? -level : t[row][5];
     int srclog = 0;
     for (uint32_t v = n - 1u; v; v >>= 1) srclog++;
     if (n < 64u) srclog = 6;
@@ -1145,7 +1161,9 @@ static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *
     if (cl > *wlog) cl = *wlog;
     if (*wlog < 10) *wlog = 10;
     if (clog) *clog = cl;
-    if (dfast) *dfast = level >= 3;
+    if (dfast) *dfast = t[row][6] == 2;
+    if (strategy) *strategy = t[row][6];
+    if (slog) *slog = t[row][3];
     return true;
 }
 
@@ -1159,14 +1177,15 @@ static uint32_t zstd_enc_grid(uint64_t n_blocks)
     return (uint32_t)(n_blocks < cap ? n_blocks : cap);
 }
 /* per workgroup: sequences, literals, codes (kWsBytes), then the match finder's table(s) */
-static size_t zstd_enc_stride(int hlog, int clog, bool dfast) { return kWsBytes + (((size_t)4u << hlog) + (dfast ? (size_t)4u << clog : 0u)); }
+static size_t zstd_enc_stride(int hlog, int clog, bool two_tables) { return kWsBytes + (((size_t)4u << hlog) + (two_tables ? (size_t)4u << clog : 0u)); }
 
 size_t zstd_compress_workspace(uint64_t n_blocks, int level, uint32_t block_size)
 {
     int wlog, hlog, mml, tlen, clog;
     bool dfast = false;
-    if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast)) return 256;
-    return (size_t)zstd_enc_grid(n_blocks) * zstd_enc_stride(hlog, clog, dfast) + 256;
+    int strategy = 1;
+    if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast, &strategy)) return 256;
+    return (size_t)zstd_enc_grid(n_blocks) * zstd_enc_stride(hlog, clog, strategy >= 2) + 256;
 }
 
 bool zstd_compress_supported(int level, uint32_t block_size)
@@ -1182,16 +1201,17 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
     if (n_blocks == 0) return hipSuccess;
     int wlog, hlog, mml, tlen, clog;
     bool dfast = false;
-    if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast)) return hipErrorNotSupported;
+    int strategy = 1, slog = 0;
+    if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast, &strategy, &slog)) return hipErrorNotSupported;
     static const bool serial_only = getenv("CRYO_ZSTD_ENC") && getenv("CRYO_ZSTD_ENC")[0] == '1'; /* testing aid: the serial `fast` walk */
-    const int finder = dfast ? 1 : (serial_only ? 2 : 0);
+    const int finder = strategy == 3 ? 3 : (dfast ? 1 : (serial_only ? 2 : 0));
     /* search positions (dfast) / iterations (fast: two positions each) per step.  Measured on text-like rows, GB/s:
      * dfast level 3  16: 6.6  32: 7.4  64: 6.9;  fast level 1  16: 14.4  32: 13.9  64: 13.1 -- wider steps read
      * table slots for positions behind the first match, narrower ones pay more trips per sequence */
     static const uint32_t w_env = getenv("CRYO_ZSTD_ENC_WIDTH") ? (uint32_t)atoi(getenv("CRYO_ZSTD_ENC_WIDTH")) : 0u; /* tuning aid */
-    const uint32_t width = w_env ? w_env : (dfast ? 32u : 16u);
+    const uint32_t width = strategy == 3 ? (uint32_t)slog : (w_env ? w_env : (dfast ? 32u : 16u));
     const uint32_t grid = zstd_enc_grid(n_blocks);
-    const size_t stride = zstd_enc_stride(hlog, clog, dfast);
+    const size_t stride = zstd_enc_stride(hlog, clog, strategy >= 2);
     if (workspace_bytes < (size_t)grid * stride) return hipErrorInvalidValue;
     static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
     unsigned long long *d_st = nullptr, h_st[24] = {0};
@@ -1199,6 +1219,8 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
     }
+    /* one kernel for all finders, chosen at run time: instantiating it per finder makes the compiler inline each
+     * finder into the frame loop and spill three times as much */
     if (want_stats)
         hipLaunchKernelGGL(k_zstd_enc<true>, dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride, wlog,
                            hlog, clog, mml, tlen, finder, width, d_out_size, d_status, (uint8_t *)d_workspace, (uint64_t)stride, d_st);

@@ -1,0 +1,131 @@
+/*
+ * zstd_lazy.h -- the `greedy` strategy's match finder (libzstd 1.4.8 ZSTD_compressBlock_lazy_generic at depth 0
+ * over the hash-chain searcher ZSTD_HcFindBestMatch, no dictionary; zstd level 5 at cryo block sizes, level 6
+ * at 1 MiB).  Included by zstd_enc.hip inside its namespace, after zstd_dfast.h.
+ *
+ * Replaces the match-finding half of ZSTD_compress(dst, bound, src, B, level) (reference
+ * compression.c:102-104); restated for the CPU in oracle/zstd_enc_oracle.c (block_lazy, hc_find_best).
+ *
+ * First correct version: the walk is wave-uniform.  Every position up to the one searched is inserted into the
+ * hash table and the chain table (64 positions per step as long as their slots differ -- the mark array of the
+ * other finders -- which is exact: chain[idx] = hash[h]; hash[h] = idx for distinct h in any order); a search
+ * walks at most 2^searchLog chain links, each a dependent load, and extends candidates 64 bytes per step.
+ * Tables: hash (2^hashLog u32) then chain (2^chainLog u32) behind the workgroup's workspace.  `lazy` / `lazy2`
+ * (levels 6+) additionally need the cost-based sequence-table choice in the entropy stage (oracle: select_type)
+ * and are not built yet.
+ */
+#pragma once
+
+struct HcState { uint32_t *hash, *chain; uint32_t next_to_update; };
+
+/* how many bytes before a and b are equal, at most lim (the library's catch-up loop, 64 bytes per step) */
+__device__ inline uint32_t count_back(const uint8_t *a, const uint8_t *b, uint32_t lim, uint32_t lane)
+{
+    uint32_t done = 0;
+    for (;;) {
+        const uint32_t k = done + lane;
+        const bool eq = k < lim && a[-1 - (int)k] == b[-1 - (int)k];
+        const unsigned long long neq = __ballot(!eq);
+        if (neq != 0ull) return done + ctz64(neq);
+        done += 64u;
+    }
+}
+
+/* ZSTD_insertAndFindFirstIndex: positions next_to_update .. target-1 go into the tables; returns the head of
+ * target's chain */
+__device__ inline uint32_t hc_insert_find(HcState &hc, uint8_t *mark, const CPar &cp, const uint8_t *base, uint32_t target, int mls,
+                                          uint32_t lane)
+{
+    const uint32_t cmask = (1u << cp.clog) - 1u;
+    uint32_t idx = hc.next_to_update;
+    while (idx < target) {
+        const uint32_t my = idx + lane;
+        bool on = my < target;
+        const uint32_t h = hashs_v(on ? ld64v(base + my) : 0ull, cp.hlog, mls);
+        const uint32_t keep = distinct_prefix(mark, h & (kDfMark - 1u), on, lane);
+        on = on && lane < keep;
+        if (on) { const uint32_t old = hc.hash[h]; hc.chain[my & cmask] = old; hc.hash[h] = my; }
+        idx += (uint32_t)__builtin_popcountll(__ballot(on));
+    }
+    hc.next_to_update = target;
+    return uni(hc.hash[hashs_v(ld64u(base + target), cp.hlog, mls)]);
+}
+
+/* ZSTD_HcFindBestMatch: longest match among at most 2^searchLog chain links; *offset_ptr = distance + 2 */
+__device__ inline uint32_t hc_find_best(HcState &hc, uint8_t *mark, const CPar &cp, const uint8_t *base, uint32_t cur, uint32_t iend,
+                                        uint32_t *offset_ptr, int mls, uint32_t lane)
+{
+    const uint32_t csize = 1u << cp.clog, cmask = csize - 1u;
+    const uint32_t max_dist = 1u << cp.wlog;
+    const uint32_t low_limit = (cur - 1u > max_dist) ? cur - max_dist : 1u; /* window.lowLimit = 1 */
+    const uint32_t min_chain = cur > csize ? cur - csize : 0u;
+    uint32_t attempts = 1u << cp.slog;
+    uint32_t ml = 4u - 1u;
+    uint32_t mi = hc_insert_find(hc, mark, cp, base, cur, mls, lane);
+    for (; mi >= low_limit && attempts > 0u; attempts--) {
+        uint32_t cml = 0;
+        if (uni(base[mi + ml]) == uni(base[cur + ml])) cml = count_match(base + cur, base + mi, base + iend, lane);
+        if (cml > ml) {
+            ml = cml;
+            *offset_ptr = cur - mi + 2u;
+            if (cur + cml == iend) break;
+        }
+        if (mi <= min_chain) break;
+        mi = uni(hc.chain[mi & cmask]);
+    }
+    return ml;
+}
+
+/* ZSTD_compressBlock_lazy_generic, depth 0 (greedy).  Indexes are the library's (base = src - 1). */
+__device__ uint32_t block_greedy(HcState &hc, uint8_t *mark, const CPar &cp, const uint8_t *base, const uint8_t *istart, uint32_t n,
+                                 uint32_t *rep, uint8_t *ws, SeqStore &ss, uint32_t lane)
+{
+    const int mls = cp.mml < 4 ? 4 : (cp.mml > 6 ? 6 : cp.mml);
+    uint32_t ip = (uint32_t)(istart - base), anchor = ip;
+    const uint32_t iend = ip + n, ilimit = iend - 8u;
+    const uint32_t prefix_lowest = 1u; /* window.dictLimit: the catch-up is not window-limited */
+    uint32_t off1 = rep[0], off2 = rep[1], saved = 0;
+    if (ip == prefix_lowest) ip++;
+    {
+        const uint32_t max_dist = 1u << cp.wlog;
+        const uint32_t wlow = (ip - 1u > max_dist) ? ip - max_dist : 1u;
+        const uint32_t max_rep = ip - wlow;
+        if (off2 > max_rep) { saved = off2; off2 = 0; }
+        if (off1 > max_rep) { saved = off1; off1 = 0; }
+    }
+    while (ip < ilimit) {
+        uint32_t mlen = 0, offset = 0, start = ip + 1u;
+        bool have = false;
+        if (off1 > 0u && ld32u(base + ip + 1u - off1) == ld32u(base + ip + 1u)) {
+            mlen = count_match(base + ip + 1u + 4u, base + ip + 1u + 4u - off1, base + iend, lane) + 4u;
+            have = true; /* depth 0: taken as it is */
+        }
+        if (!have) {
+            uint32_t off_found = 999999999u;
+            const uint32_t ml2 = hc_find_best(hc, mark, cp, base, ip, iend, &off_found, mls, lane);
+            if (ml2 > mlen) { mlen = ml2; start = ip; offset = off_found; }
+            if (mlen < 4u) { ip += ((ip - anchor) >> 8) + 1u; continue; }
+            if (offset) { /* catch up */
+                const uint32_t m = start - (offset - 2u);
+                const uint32_t la = start - anchor, lm = m - prefix_lowest;
+                const uint32_t back = count_back(base + start, base + m, la < lm ? la : lm, lane);
+                start -= back;
+                mlen += back;
+                off2 = off1;
+                off1 = offset - 2u;
+            }
+        }
+        store_seq(ws, ss, start - anchor, base + anchor, offset, mlen - 3u, lane);
+        anchor = ip = start + mlen;
+        while (ip <= ilimit && off2 > 0u && ld32u(base + ip) == ld32u(base + ip - off2)) {
+            const uint32_t rlen = count_match(base + ip + 4u, base + ip + 4u - off2, base + iend, lane) + 4u;
+            const uint32_t t = off2; off2 = off1; off1 = t;
+            store_seq(ws, ss, 0, base + anchor, 0, rlen - 3u, lane);
+            ip += rlen;
+            anchor = ip;
+        }
+    }
+    rep[0] = off1 ? off1 : saved;
+    rep[1] = off2 ? off2 : saved;
+    return iend - anchor;
+}
