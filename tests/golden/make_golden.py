@@ -40,7 +40,7 @@ import oracle_lib  # noqa: E402
 
 SIZES = [131072, 1 << 20]
 LZ4_ACCELS = [0, 1, 2, 7, 50]
-ZSTD_LEVELS = [-5, -1, 1, 2, 3, 22]
+ZSTD_LEVELS = [-5, -1, 1, 2, 3, 4, 5, 7, 22]  # 4, 5, 7 added with the dfast / greedy kernels and the lazy oracle
 DISTS = list(range(5))
 BLOCKS = [0, 1, 2, 3]
 SEED = 0
