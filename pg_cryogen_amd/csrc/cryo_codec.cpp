@@ -260,9 +260,14 @@ int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
     if (!d_src || !d_src_off || !d_src_size || !d_dst || !d_status || dst_stride < block_size)
         return CRYO_E_ARG;
     if (method == CRYO_METHOD_LZ4) {
+        const size_t need = cryo::lz4_decompress_workspace(n_blocks, block_size);
+        if (need != 0) {
+            int rc = ensure_ws(c, need);
+            if (rc != CRYO_OK) return rc;
+        }
         HIP_TRY(c, cryo::launch_lz4_decompress(c->stream, (const uint8_t *)d_src, d_src_off, d_src_size,
                                                (uint8_t *)d_dst, dst_stride, block_size, n_blocks,
-                                               d_status));
+                                               d_status, need ? c->d_ws : nullptr, need ? c->ws_cap : 0));
     } else {
         const size_t need = cryo::zstd_decompress_workspace(n_blocks, block_size);
         int rc = ensure_ws(c, need);

@@ -26,7 +26,10 @@ hipError_t launch_compare(hipStream_t s, const uint8_t *d_a, uint64_t a_stride, 
 /* LZ4 block format */
 hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                  const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
-                                 uint32_t block_size, uint64_t n_blocks, int32_t *d_status);
+                                 uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
+                                 size_t workspace_bytes);
+/* bytes of workspace the sequence-index pass of a batch this large wants (0: the batch is decoded without one) */
+size_t lz4_decompress_workspace(uint64_t n_blocks, uint32_t block_size);
 
 hipError_t launch_lz4_compress(hipStream_t s, const uint8_t *d_src, uint64_t src_stride,
                                uint32_t block_size, uint64_t n_blocks, uint8_t *d_dst,

@@ -74,56 +74,78 @@ static int allocate_slot(void)
     return victim;
 }
 
+/* unpinned slots: what one batch can be given without evicting its own members */
+static int evictable_slots(void)
+{
+    int i, n = 0;
+    for (i = 0; i < nslots; i++) if (!slots[i].pinned) n++;
+    return n;
+}
+
 static CryoError load_blocks(CryoRel *rel, SeqScanIterator *iter, const BlockNumber *blocks, int k,
                              CacheEntry *results, CryoError *errors)
 {
-    /* gather the chains of every missing block, then ONE decompress call per method */
+    /* gather the chains of every missing block, then ONE decompress call per method.
+     *
+     * Every slot a batch hands out -- hit or miss -- is pinned until the batch returns, so a later miss of
+     * the same batch cannot evict it (a batch larger than the cache gets CRYO_ERR_CACHE_IS_FULL for the
+     * members that do not fit, never another block's data).  A chain is read into temporaries and a victim
+     * is only chosen, and overwritten, once the read succeeded: a failed probe (continuation page of a
+     * bitmap scan, broken chain) leaves the cache as it was (reference cache.c:184-233 removes the victim
+     * from its hash before reuse; same effect). */
     const CryoCodecOps *ops = cryo_host_codec_ops();
     char **comp = calloc((size_t)k, sizeof *comp);
     uint32_t *csz = calloc((size_t)k, sizeof *csz);
-    int *slot_of = malloc((size_t)k * sizeof *slot_of);
+    int *slot_of = malloc((size_t)k * sizeof *slot_of);   /* slot this entry loads (miss), else Invalid */
+    int *pinned_by = malloc((size_t)k * sizeof *pinned_by); /* slot this entry pinned for the batch, else Invalid */
     CompressionMethod *meth = calloc((size_t)k, sizeof *meth);
+    BlockNumber *tmp_blocks = malloc((size_t)(max_chain ? max_chain : 1) * sizeof *tmp_blocks);
     CryoError first_err = CRYO_ERR_SUCCESS;
     int i, m;
-    if (!comp || !csz || !slot_of || !meth) { free(comp); free(csz); free(slot_of); free(meth); return CRYO_ERR_CACHE_IS_FULL; }
+    if (!comp || !csz || !slot_of || !pinned_by || !meth || !tmp_blocks) {
+        free(comp); free(csz); free(slot_of); free(pinned_by); free(meth); free(tmp_blocks);
+        return CRYO_ERR_CACHE_IS_FULL;
+    }
 
     for (i = 0; i < k; i++) {
         int s;
-        slot_of[i] = InvalidCacheEntry;
+        slot_of[i] = pinned_by[i] = InvalidCacheEntry;
         errors[i] = CRYO_ERR_SUCCESS;
         if (rel->ops->nblocks(rel->handle) <= blocks[i] || blocks[i] == CRYO_META_PAGE) {
             errors[i] = CRYO_ERR_WRONG_STARTING_BLOCK; results[i] = InvalidCacheEntry; continue;
         }
         s = find_slot(rel->relid, blocks[i]);
         if (s != InvalidCacheEntry) {
+            /* cached, or claimed by an earlier entry of this batch (a repeated block number) */
             uint32 j;
             n_hits++; slots[s].ts = ++tick; results[i] = s;
+            if (!slots[s].pinned) { slots[s].pinned = true; pinned_by[i] = s; }
             /* the cached block's pages must not be handed out again (cache.c:235-242,290-292) */
             for (j = 0; j < slots[s].nblocks; j++) cryo_seqscan_iter_exclude(iter, slots[s].blocks[j], true);
             continue;
         }
         n_misses++;
-        s = allocate_slot();
-        if (s == InvalidCacheEntry) { errors[i] = CRYO_ERR_CACHE_IS_FULL; results[i] = InvalidCacheEntry; continue; }
         {
             Size cs = 0;
-            Slot *sl = &slots[s];
-            sl->nblocks = 0;
-            errors[i] = cryo_stage_read_chain(rel, blocks[i], &comp[i], &cs, &meth[i], &sl->xid, sl->blocks,
-                                              max_chain, &sl->nblocks);
+            uint32 nb = 0, j;
+            TransactionId xid = 0;
+            Slot *sl;
+            errors[i] = cryo_stage_read_chain(rel, blocks[i], &comp[i], &cs, &meth[i], &xid, tmp_blocks, max_chain, &nb);
             if (errors[i] != CRYO_ERR_SUCCESS) { results[i] = InvalidCacheEntry; continue; }
-            {
-                /* continuation pages are not block starts (cache.c:174).  miss_ok: the reference
-                 * passes false here and its regression output pins the resulting internal error
-                 * (expected/pg_cryogen.out:166); a page the iterator already handed out is
-                 * harmless (it reads as WRONG_STARTING_BLOCK), so it is tolerated here */
-                uint32 j;
-                for (j = 1; j < sl->nblocks; j++) cryo_seqscan_iter_exclude(iter, sl->blocks[j], true);
-            }
+            s = allocate_slot();
+            if (s == InvalidCacheEntry) { errors[i] = CRYO_ERR_CACHE_IS_FULL; results[i] = InvalidCacheEntry; continue; }
+            sl = &slots[s];
+            /* continuation pages are not block starts (cache.c:174).  miss_ok: the reference
+             * passes false here and its regression output pins the resulting internal error
+             * (expected/pg_cryogen.out:166); a page the iterator already handed out is
+             * harmless (it reads as WRONG_STARTING_BLOCK), so it is tolerated here */
+            for (j = 1; j < nb; j++) cryo_seqscan_iter_exclude(iter, tmp_blocks[j], true);
             csz[i] = (uint32_t)cs;
             /* claim the slot now (pinned for the duration of the batch so a later miss cannot evict it) */
+            memcpy(sl->blocks, tmp_blocks, (size_t)nb * sizeof *tmp_blocks);
+            sl->nblocks = nb; sl->xid = xid;
             sl->relid = rel->relid; sl->blockno = blocks[i]; sl->ts = ++tick; sl->pinned = true;
-            slot_of[i] = s;
+            slot_of[i] = pinned_by[i] = s;
             results[i] = s;
         }
     }
@@ -136,29 +158,50 @@ static CryoError load_blocks(CryoRel *rel, SeqScanIterator *iter, const BlockNum
             uint32_t *sz = malloc((size_t)cnt * sizeof *sz);
             int32_t *st = calloc((size_t)cnt, sizeof *st);
             int *idx = malloc((size_t)cnt * sizeof *idx);
-            char *out = malloc((size_t)cnt * cryo_blcksz);
+            char **outs = malloc((size_t)cnt * sizeof *outs);
             int rc = -1;
-            if (srcs && sz && st && idx && out && ops) {
+            if (srcs && sz && st && idx && outs && ops) {
                 for (i = 0; i < k; i++)
-                    if (slot_of[i] != InvalidCacheEntry && (int)meth[i] == m) { srcs[j] = comp[i]; sz[j] = csz[i]; idx[j] = i; j++; }
-                rc = ops->decompress_blocks(ops->ctx, m, srcs, sz, (size_t)cnt, out, cryo_blcksz, st);
+                    if (slot_of[i] != InvalidCacheEntry && (int)meth[i] == m) {
+                        srcs[j] = comp[i]; sz[j] = csz[i]; idx[j] = i; outs[j] = slots[slot_of[i]].data; j++;
+                    }
+                /* decoded blocks land in their cache slots directly (no second copy) */
+                rc = ops->decompress_blocks_scatter
+                         ? ops->decompress_blocks_scatter(ops->ctx, m, srcs, sz, (size_t)cnt, (void *const *)outs, cryo_blcksz, st)
+                         : -1;
+                if (!ops->decompress_blocks_scatter) {
+                    char *out = malloc((size_t)cnt * cryo_blcksz);
+                    if (out) {
+                        rc = ops->decompress_blocks(ops->ctx, m, srcs, sz, (size_t)cnt, out, cryo_blcksz, st);
+                        for (j = 0; j < cnt; j++)
+                            if (rc == 0 && st[j] == 0) memcpy(outs[j], out + (size_t)j * cryo_blcksz, cryo_blcksz);
+                        free(out);
+                    }
+                }
                 n_codec_calls++;
             }
-            for (j = 0; j < cnt; j++) {
-                const int bi = idx ? idx[j] : 0;
-                Slot *sl = &slots[slot_of[bi]];
-                if (rc == 0 && st[j] == 0) memcpy(sl->data, out + (size_t)j * cryo_blcksz, cryo_blcksz);
-                else { errors[bi] = CRYO_ERR_DECOMPRESSION_FAILED; results[bi] = InvalidCacheEntry; sl->ts = 0; }
+            for (i = 0, j = 0; i < k; i++) {
+                if (slot_of[i] == InvalidCacheEntry || (int)meth[i] != m) continue;
+                if (!(rc == 0 && st && st[j] == 0)) {
+                    errors[i] = CRYO_ERR_DECOMPRESSION_FAILED; results[i] = InvalidCacheEntry; slots[slot_of[i]].ts = 0;
+                }
+                j++;
             }
-            free(srcs); free(sz); free(st); free(idx); free(out);
+            free(srcs); free(sz); free(st); free(idx); free(outs);
         }
     }
     for (i = 0; i < k; i++) {
-        if (slot_of[i] != InvalidCacheEntry) slots[slot_of[i]].pinned = false;
+        /* a repeated block number shares the fate of its first occurrence */
+        if (errors[i] == CRYO_ERR_SUCCESS && results[i] != InvalidCacheEntry && slots[results[i]].ts == 0) {
+            errors[i] = CRYO_ERR_DECOMPRESSION_FAILED; results[i] = InvalidCacheEntry;
+        }
+    }
+    for (i = 0; i < k; i++) {
+        if (pinned_by[i] != InvalidCacheEntry) slots[pinned_by[i]].pinned = false;
         free(comp[i]);
         if (errors[i] != CRYO_ERR_SUCCESS && first_err == CRYO_ERR_SUCCESS) first_err = errors[i];
     }
-    free(comp); free(csz); free(slot_of); free(meth);
+    free(comp); free(csz); free(slot_of); free(pinned_by); free(meth); free(tmp_blocks);
     return first_err;
 }
 
@@ -191,6 +234,12 @@ int cryo_scan_next_batch(CryoRel *rel, void *iter_, int k, BlockNumber *starts, 
     CryoError *errs = malloc((size_t)k * sizeof *errs);
     int got = 0;
     if (!cand || !res || !errs || k <= 0) { free(cand); free(res); free(errs); return 0; }
+    /* a batch pins every slot it hands out: never pop more block starts than there are evictable slots, or
+     * the surplus would be lost to the scan as CRYO_ERR_CACHE_IS_FULL (the caller comes back for the rest) */
+    {
+        const int room = evictable_slots();
+        if (k > room) k = room > 0 ? room : 1;
+    }
     while (got < k) {
         int want = k - got, nc = 0, i;
         /* candidates whose first page really starts a chain (cheap header look, no decode) */
