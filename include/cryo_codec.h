@@ -7,7 +7,7 @@
  * /root/reference) it replaces.  Plain C, plain pointers and sizes, no HIP or
  * torch types.  Nothing here ever calls elog()/exit()/throws: every function
  * returns a cryo_status (0 = ok, negative = error) so that the PG-side C shim
- * (pg_cryogen_amd/shim/compression.c) can raise ereport(ERROR) itself without a
+ * (pg_cryogen_amd/host/compression.c) can raise ereport(ERROR) itself without a
  * longjmp crossing C++ frames.
  *
  * Process model: a cryo_codec handle is bound to one GPU and one HIP stream and
@@ -48,7 +48,7 @@ typedef struct cryo_codec cryo_codec; /* opaque: device id, stream, workspace */
 
 /* ---- library / device ---- */
 
-/* "cryo-codec X.Y (lz4 block format as liblz4 1.9.3; zstd as libzstd 1.4.9)" */
+/* "cryo-codec X.Y (lz4 block format as liblz4 1.9.3; zstd frames as libzstd 1.4.8)" */
 const char *cryo_codec_version(void);
 /* number of visible HIP devices, or a negative cryo_status */
 int cryo_codec_device_count(void);
@@ -147,6 +147,12 @@ int cryo_codec_compress_blocks(cryo_codec *c, int method, int param,
 int cryo_codec_decompress_blocks(cryo_codec *c, int method,
                                  const void *const *h_src, const uint32_t *h_src_size, size_t n_blocks,
                                  void *h_dst, size_t block_size, int32_t *h_status);
+/* the same with one destination pointer per block (the slots of the decompressed-block cache, reference
+ * cache.c:46,178: `out` is a cache entry's data[]): block i -> h_dst[i]; a block whose status is not CRYO_OK
+ * leaves its destination untouched */
+int cryo_codec_decompress_blocks_to(cryo_codec *c, int method,
+                                    const void *const *h_src, const uint32_t *h_src_size, size_t n_blocks,
+                                    void *const *h_dst, size_t block_size, int32_t *h_status);
 
 /* ---- batch helpers used by staging, tests and the benchmark ---- */
 

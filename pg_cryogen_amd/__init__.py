@@ -2,8 +2,8 @@
 
 Layout (only what the path needs):
   csrc/      gfx950 HIP kernels + the C-ABI host code  -> libcryo_codec.so
-  shim/      C mirror of the reference's compression.h over the C ABI
-  staging/   page-chain write/read staging and the decompressed-block cache (C)
+  host/      C mirror of the reference's compression.h over the C ABI, page-chain write/read
+             staging, the decompressed-block cache and the scan iterator  -> libcryo_host.so
   codec.py   ctypes binding used by tests/ and bench.py
 The public contract is include/cryo_codec.h.
 """

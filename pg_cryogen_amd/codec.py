@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "cryo_dev_alloc", "cryo_dev_free", "cryo_dev_upload", "cryo_dev_download", "cryo_dev_memset",
     "cryo_codec_compress_batch", "cryo_codec_decompress_batch", "cryo_codec_compress_block",
     "cryo_codec_decompress_block", "cryo_codec_compress_blocks", "cryo_codec_decompress_blocks",
+    "cryo_codec_decompress_blocks_to",
     "cryo_codec_synth_batch", "cryo_codec_checksum_batch",
     "cryo_codec_compare_batch", "cryo_checksum64", "cryo_codec_timer_start",
     "cryo_codec_timer_stop", "cryo_codec_get_counters",
@@ -80,6 +81,7 @@ def lib():
     L.cryo_codec_decompress_block.argtypes = [vp, i32, vp, sz, vp, sz]
     L.cryo_codec_compress_blocks.argtypes = [vp, i32, i32, vp, sz, sz, vp, sz, vp]
     L.cryo_codec_decompress_blocks.argtypes = [vp, i32, vp, vp, sz, vp, sz, vp]
+    L.cryo_codec_decompress_blocks_to.argtypes = [vp, i32, vp, vp, sz, vp, sz, vp]
     L.cryo_codec_synth_batch.argtypes = [vp, u64, u64, u64, u64, u32, i32, vp, u64]
     L.cryo_codec_checksum_batch.argtypes = [vp, vp, u64, vp, u32, u64, vp]
     L.cryo_codec_compare_batch.argtypes = [vp, vp, u64, vp, u64, u32, u64, vp]

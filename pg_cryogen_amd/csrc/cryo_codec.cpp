@@ -53,6 +53,21 @@ int fail(cryo_codec *c, hipError_t e, const char *what)
         if (e_ != hipSuccess) return fail((c), e_, #call);                                         \
     } while (0)
 
+/* One handle = one GPU, but the calling thread's current device is whatever the process last set (another
+ * handle's cryo_codec_open, torch.cuda.set_device, ...).  Every entry point that allocates, launches or records
+ * events makes the handle's device current for its duration and restores the caller's afterwards. */
+struct DevGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit DevGuard(const cryo_codec *c)
+    {
+        if (!c) return;
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != c->device) switched = hipSetDevice(c->device) == hipSuccess;
+    }
+    ~DevGuard() { if (switched && prev >= 0) (void)hipSetDevice(prev); }
+};
+
 bool method_ok(int m) { return m == CRYO_METHOD_LZ4 || m == CRYO_METHOD_ZSTD; }
 
 int ensure(cryo_codec *c, uint8_t **p, size_t *cap, size_t need)
@@ -91,7 +106,7 @@ extern "C" {
 
 const char *cryo_codec_version(void)
 {
-    return "cryo-codec 0.1 gfx950 (lz4 block format as liblz4 1.9.3; zstd frames as libzstd 1.4.9)";
+    return "cryo-codec 0.2 gfx950 (lz4 block format as liblz4 1.9.3; zstd frames as libzstd 1.4.8)";
 }
 
 int cryo_codec_device_count(void)
@@ -158,6 +173,7 @@ void *cryo_codec_stream(cryo_codec *c) { return c ? (void *)c->stream : nullptr;
 
 int cryo_codec_sync(cryo_codec *c)
 {
+    DevGuard dev_(c);
     if (!c) return CRYO_E_ARG;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return CRYO_OK;
@@ -179,9 +195,9 @@ size_t cryo_codec_bound(int method, size_t n)
 /* ---- device memory plumbing ---- */
 int cryo_dev_alloc(cryo_codec *c, size_t bytes, void **d_ptr)
 {
+    DevGuard dev_(c);
     if (!c || !d_ptr) return CRYO_E_ARG;
     *d_ptr = nullptr;
-    HIP_TRY(c, hipSetDevice(c->device));
     /* +64: the kernels read compressed input in aligned 16-byte pieces (up to 15 bytes past a block's end) */
     hipError_t e = hipMalloc(d_ptr, bytes + 64);
     if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return CRYO_E_NOMEM; }
@@ -190,6 +206,7 @@ int cryo_dev_alloc(cryo_codec *c, size_t bytes, void **d_ptr)
 }
 int cryo_dev_free(cryo_codec *c, void *d_ptr)
 {
+    DevGuard dev_(c);
     if (!c) return CRYO_E_ARG;
     if (!d_ptr) return CRYO_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -198,6 +215,7 @@ int cryo_dev_free(cryo_codec *c, void *d_ptr)
 }
 int cryo_dev_upload(cryo_codec *c, void *d_dst, const void *h_src, size_t bytes)
 {
+    DevGuard dev_(c);
     if (!c || (bytes && (!d_dst || !h_src))) return CRYO_E_ARG;
     if (!bytes) return CRYO_OK;
     HIP_TRY(c, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream));
@@ -206,6 +224,7 @@ int cryo_dev_upload(cryo_codec *c, void *d_dst, const void *h_src, size_t bytes)
 }
 int cryo_dev_download(cryo_codec *c, void *h_dst, const void *d_src, size_t bytes)
 {
+    DevGuard dev_(c);
     if (!c || (bytes && (!h_dst || !d_src))) return CRYO_E_ARG;
     if (!bytes) return CRYO_OK;
     HIP_TRY(c, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream));
@@ -214,6 +233,7 @@ int cryo_dev_download(cryo_codec *c, void *h_dst, const void *d_src, size_t byte
 }
 int cryo_dev_memset(cryo_codec *c, void *d_dst, int value, size_t bytes)
 {
+    DevGuard dev_(c);
     if (!c || (bytes && !d_dst)) return CRYO_E_ARG;
     if (!bytes) return CRYO_OK;
     HIP_TRY(c, hipMemsetAsync(d_dst, value, bytes, c->stream));
@@ -226,6 +246,7 @@ int cryo_codec_compress_batch(cryo_codec *c, int method, int param, const void *
                               void *d_dst, uint64_t dst_stride, uint32_t *d_out_size,
                               int32_t *d_status)
 {
+    DevGuard dev_(c);
     if (!c || !method_ok(method) || block_size == 0) return CRYO_E_ARG;
     if (n_blocks == 0) return CRYO_OK;
     if (!d_src || !d_dst || !d_out_size || !d_status || src_stride < block_size) return CRYO_E_ARG;
@@ -235,7 +256,7 @@ int cryo_codec_compress_batch(cryo_codec *c, int method, int param, const void *
                                              n_blocks, (uint8_t *)d_dst, dst_stride, param,
                                              d_out_size, d_status));
     } else {
-        /* levels whose strategy is `fast` or `dfast` (-5..4 at cryo block sizes); others: no kernel yet */
+        /* levels whose strategy has a kernel (fast, dfast, greedy: -5..5, and 6 above 256 KiB); others: CRYO_E_UNSUPPORTED */
         if (!cryo::zstd_compress_supported(param, block_size)) return CRYO_E_UNSUPPORTED;
         const size_t need = cryo::zstd_compress_workspace(n_blocks, param, block_size);
         int rc = ensure_ws(c, need);
@@ -255,6 +276,7 @@ int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
                                 uint64_t dst_stride, uint32_t block_size, uint64_t n_blocks,
                                 int32_t *d_status)
 {
+    DevGuard dev_(c);
     if (!c || !method_ok(method) || block_size == 0) return CRYO_E_ARG;
     if (n_blocks == 0) return CRYO_OK;
     if (!d_src || !d_src_off || !d_src_size || !d_dst || !d_status || dst_stride < block_size)
@@ -273,7 +295,6 @@ int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
         int rc = ensure_ws(c, need);
         if (rc != CRYO_OK) return rc;
         if (!c->have_aux) {
-            HIP_TRY(c, hipSetDevice(c->device));
             for (int l = 0; l < 2; l++) {
                 HIP_TRY(c, hipStreamCreateWithFlags(&c->aux.lane[l], hipStreamNonBlocking));
                 HIP_TRY(c, hipEventCreateWithFlags(&c->aux.join[l], hipEventDisableTiming));
@@ -295,6 +316,7 @@ int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
 int cryo_codec_compress_block(cryo_codec *c, int method, int param, const void *h_src,
                               size_t block_size, void *h_dst, size_t dst_cap, size_t *out_size)
 {
+    DevGuard dev_(c);
     if (!c || !h_src || !h_dst || !out_size || !method_ok(method)) return CRYO_E_ARG;
     if (block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
     const size_t bound = cryo_codec_bound(method, block_size);
@@ -322,6 +344,7 @@ int cryo_codec_compress_block(cryo_codec *c, int method, int param, const void *
 int cryo_codec_decompress_block(cryo_codec *c, int method, const void *h_src, size_t src_size,
                                 void *h_dst, size_t block_size)
 {
+    DevGuard dev_(c);
     if (!c || !h_src || !h_dst || !method_ok(method)) return CRYO_E_ARG;
     if (block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
     if (src_size == 0 || src_size > 0xFFFFFFFFu) return CRYO_E_CORRUPT;
@@ -352,6 +375,7 @@ int cryo_codec_decompress_block(cryo_codec *c, int method, const void *h_src, si
 int cryo_codec_compress_blocks(cryo_codec *c, int method, int param, const void *h_src, size_t block_size,
                                size_t n, void *h_dst, size_t dst_stride, uint32_t *h_out_size)
 {
+    DevGuard dev_(c);
     if (!c || !method_ok(method) || block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
     if (n == 0) return CRYO_OK;
     if (!h_src || !h_dst || !h_out_size) return CRYO_E_ARG;
@@ -388,12 +412,13 @@ int cryo_codec_compress_blocks(cryo_codec *c, int method, int param, const void 
     return CRYO_OK;
 }
 
-int cryo_codec_decompress_blocks(cryo_codec *c, int method, const void *const *h_src, const uint32_t *h_src_size,
-                                 size_t n, void *h_dst, size_t block_size, int32_t *h_status)
+static int decompress_blocks_impl(cryo_codec *c, int method, const void *const *h_src, const uint32_t *h_src_size,
+                                  size_t n, void *h_dst, void *const *h_dst_each, size_t block_size, int32_t *h_status)
 {
+    DevGuard dev_(c);
     if (!c || !method_ok(method) || block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
     if (n == 0) return CRYO_OK;
-    if (!h_src || !h_src_size || !h_dst || !h_status) return CRYO_E_ARG;
+    if (!h_src || !h_src_size || (!h_dst && !h_dst_each) || !h_status) return CRYO_E_ARG;
     /* pinned staging: [offsets u64 x n][sizes u32 x n][compressed blocks, 16-byte aligned], sent in one copy */
     const size_t o_off = 0, o_sz = n * 8, o_data = (n * 12 + 63) & ~(size_t)63;
     size_t total = 0;
@@ -422,15 +447,40 @@ int cryo_codec_decompress_blocks(cryo_codec *c, int method, const void *const *h
                                      c->hb_dst, block_size, (uint32_t)block_size, n, d_st);
     if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
     HIP_TRY(c, hipMemcpyAsync(h_status, d_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(h_dst, c->hb_dst, n * block_size, hipMemcpyDeviceToHost, c->stream));
+    if (h_dst) {
+        HIP_TRY(c, hipMemcpyAsync(h_dst, c->hb_dst, n * block_size, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        return CRYO_OK;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++) {
+        if (h_status[i] != CRYO_OK) continue;
+        if (!h_dst_each[i]) return CRYO_E_ARG;
+        HIP_TRY(c, hipMemcpyAsync(h_dst_each[i], c->hb_dst + i * block_size, block_size, hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return CRYO_OK;
+}
+
+int cryo_codec_decompress_blocks(cryo_codec *c, int method, const void *const *h_src, const uint32_t *h_src_size,
+                                 size_t n, void *h_dst, size_t block_size, int32_t *h_status)
+{
+    if (!h_dst) return CRYO_E_ARG;
+    return decompress_blocks_impl(c, method, h_src, h_src_size, n, h_dst, nullptr, block_size, h_status);
+}
+
+int cryo_codec_decompress_blocks_to(cryo_codec *c, int method, const void *const *h_src, const uint32_t *h_src_size,
+                                    size_t n, void *const *h_dst, size_t block_size, int32_t *h_status)
+{
+    if (!h_dst) return CRYO_E_ARG;
+    return decompress_blocks_impl(c, method, h_src, h_src_size, n, nullptr, h_dst, block_size, h_status);
 }
 
 /* ---- helpers ---- */
 int cryo_codec_synth_batch(cryo_codec *c, uint64_t seed, uint64_t first_block, uint64_t block_step,
                            uint64_t n_blocks, uint32_t block_size, int dist, void *d_dst, uint64_t dst_stride)
 {
+    DevGuard dev_(c);
     if (!c || block_size < 64 || dist < 0 || dist > 4) return CRYO_E_ARG;
     if (n_blocks == 0) return CRYO_OK;
     if (!d_dst || dst_stride < block_size) return CRYO_E_ARG;
@@ -444,6 +494,7 @@ int cryo_codec_checksum_batch(cryo_codec *c, const void *d_src, uint64_t src_str
                               const uint32_t *d_sizes, uint32_t fixed_size, uint64_t n_blocks,
                               uint64_t *d_sums)
 {
+    DevGuard dev_(c);
     if (!c) return CRYO_E_ARG;
     if (n_blocks == 0) return CRYO_OK;
     if (!d_src || !d_sums) return CRYO_E_ARG;
@@ -457,6 +508,7 @@ int cryo_codec_compare_batch(cryo_codec *c, const void *d_a, uint64_t a_stride, 
                              uint64_t b_stride, uint32_t block_size, uint64_t n_blocks,
                              uint64_t *d_mismatch)
 {
+    DevGuard dev_(c);
     if (!c) return CRYO_E_ARG;
     if (n_blocks == 0) return CRYO_OK;
     if (!d_a || !d_b || !d_mismatch) return CRYO_E_ARG;
@@ -469,12 +521,14 @@ int cryo_codec_compare_batch(cryo_codec *c, const void *d_a, uint64_t a_stride, 
 /* ---- timing ---- */
 int cryo_codec_timer_start(cryo_codec *c)
 {
+    DevGuard dev_(c);
     if (!c) return CRYO_E_ARG;
     HIP_TRY(c, hipEventRecord(c->ev0, c->stream));
     return CRYO_OK;
 }
 int cryo_codec_timer_stop(cryo_codec *c, float *ms)
 {
+    DevGuard dev_(c);
     if (!c || !ms) return CRYO_E_ARG;
     HIP_TRY(c, hipEventRecord(c->ev1, c->stream));
     HIP_TRY(c, hipEventSynchronize(c->ev1));

@@ -30,6 +30,15 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
                                  size_t workspace_bytes);
 /* bytes of workspace the sequence-index pass of a batch this large wants (0: the batch is decoded without one) */
 size_t lz4_decompress_workspace(uint64_t n_blocks, uint32_t block_size);
+/* lz4_dec2.hip: sequence index (one lane per block) + the decoder that consumes it */
+uint32_t lz4_index_cap(uint32_t block_size);
+size_t lz4_index_workspace(uint64_t n_blocks, uint32_t block_size);
+hipError_t launch_lz4_index(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
+                            uint64_t n_blocks, uint16_t *tbl, uint32_t cap, uint32_t *tbl_n);
+hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
+                                         const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
+                                         uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
+                                         size_t workspace_bytes);
 
 hipError_t launch_lz4_compress(hipStream_t s, const uint8_t *d_src, uint64_t src_stride,
                                uint32_t block_size, uint64_t n_blocks, uint8_t *d_dst,

@@ -251,167 +251,9 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
 }
 
 
-/* ---------------------------------------------------------------------------------------------
- * Sequence index (large batches).  Finding where the sequences of an LZ4 block start is a serial walk
- * (token -> literal length -> next token); done inside the decoding wave it needs speculative
- * per-byte tables (lz4_batch above: ~7 VALU instructions and four dependent LDS passes per sequence).
- * Across a batch the walk is embarrassingly parallel, so k_lz4_index runs it one LANE per block:
- * 64 blocks per wave, one hop per lane per iteration, and writes the low 16 bits of every token
- * position to a per-block row of the workspace.  The decoding wave then loads 64 positions with one
- * coalesced load (lz4_batch_tbl).  It does not trust the row: lane 0's position must be the wave's own
- * stream position and every lane checks that its sequence ends where the next one starts, so a wrong or
- * truncated row only costs speed (the wave falls back to parsing for itself).
- * --------------------------------------------------------------------------------------------- */
+/* Table-driven batches: sequence starts from the index row written by k_lz4_index (lz4_dec2.hip, which also has
+ * the decoder built for them; this variant is kept for A/B runs: CRYO_LZ4_ENGINE=1). */
 constexpr uint32_t kTblWin = 1536; /* compressed bytes a table batch may span (in_hi stays < vp + kInRing) */
-
-/*
- * k_lz4_index: 32 blocks per wave (lanes 0..31 each walk one block's token chain), 8 waves per CU, so
- * every block of a 64k-block batch has its walk in flight at once and the pass takes
- * (sequences per block) x (one hop), a hop being an LDS round trip plus ~70 instructions.
- *
- * A lane that read its block straight from global memory paid ~1 us per hop (64 lanes = 64 cache lines
- * per load, every hop a dependent trip to L2 or beyond: 6.9 ms for the headline batch, measured).  So each
- * block's stream is staged through a private 512-byte LDS ring, filled 128 bytes at a time: in turn j of
- * four the wave's 64 lanes load one chunk for each of blocks 8j..8j+7 (8 lanes x 16 bytes per block, one
- * cache line) if that block has room, and store it into the ring one round of turns later, so the load's
- * latency is covered by four hops.  The walk is a small state machine per lane (token / literal-length
- * extension / match-length extension) so that one LDS read per hop serves every lane, whatever it is in.
- */
-constexpr uint32_t kIdxLanes = 32, kIdxRing = 512, kIdxStride = kIdxRing + 16 /* bank skew between rings */, kIdxChunk = 128;
-
-__device__ inline uint32_t bperm(uint32_t v, uint32_t src_lane)
-{
-    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
-}
-
-__global__ void __launch_bounds__(64)
-k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
-            const uint32_t *__restrict__ src_size, uint64_t n_blocks, uint16_t *__restrict__ tbl, uint32_t cap,
-            uint32_t *__restrict__ tbl_n)
-{
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kIdxLanes * kIdxStride];
-    const uint32_t lane = threadIdx.x;
-    const uint64_t blk = (uint64_t)blockIdx.x * kIdxLanes + (lane & (kIdxLanes - 1u));
-    const bool owner = lane < kIdxLanes && blk < n_blocks;
-    /* stream of this lane's block, in "virtual" positions: vp = delta + offset in the block, so that chunk
-     * addresses are 16-byte aligned */
-    uint64_t aoff = 0;
-    uint32_t delta = 0, vend = 0;
-    if (owner) {
-        const uint64_t o = src_off[blk];
-        aoff = o & ~(uint64_t)15;
-        delta = (uint32_t)(o & 15u);
-        vend = delta + src_size[blk];
-    }
-    uint16_t *row = tbl + blk * cap;
-    uint16_t *dummy = tbl + n_blocks * cap + lane * 4u; /* 8 bytes per lane behind the rows: where lanes without a block store */
-    if (!owner) {
-        /* lanes 32..63 only help with the loads; a lane past the end of the batch re-reads block 0 */
-        aoff = src_off[0] & ~(uint64_t)15;
-    }
-    uint8_t *ring = s_ring + (lane & (kIdxLanes - 1u)) * kIdxStride;
-    uint32_t pos = delta;        /* next byte to interpret */
-    uint32_t requested = 0;      /* chunks requested up to here (multiple of kIdxChunk) */
-    uint32_t filled = 0;         /* chunks stored in the ring up to here */
-    bool inflight = false;       /* a chunk of this lane is on its way and still wanted */
-    uint32_t state = 0;          /* 0 token, 1 literal-length extension, 2 match-length extension */
-    uint32_t acc = 0, tm = 0;    /* literal length being accumulated; match nibble of the current token */
-    uint32_t k = 0;
-    unsigned long long pack = 0;
-    bool done = !owner || vend == delta;
-
-    /* chunks on their way: one per turn, committed a round later (separate variables, not an array: the
-     * compiler kept an indexed array in scratch memory) */
-    uint4 fd0 = make_uint4(0, 0, 0, 0), fd1 = fd0, fd2 = fd0, fd3 = fd0;
-    uint32_t fa0 = 0, fa1 = 0, fa2 = 0, fa3 = 0;
-    bool fp0 = false, fp1 = false, fp2 = false, fp3 = false;
-
-    auto turn = [&](const uint32_t j, uint4 &fd, uint32_t &fa, bool &fp) __attribute__((always_inline)) {
-        const bool myturn = (lane >> 3) == j; /* lanes 8j..8j+7 (owners: lane < 32) */
-        /* ---- commit the chunks requested one round ago ---- */
-        if (fp) *reinterpret_cast<uint4 *>(s_ring + fa) = fd;
-        if (myturn && inflight) { filled += kIdxChunk; inflight = false; }
-        /* ---- request the next chunk of blocks 8j..8j+7 ---- */
-        {
-            const bool want = myturn && !done && requested < vend && pos + (kIdxRing - kIdxChunk) >= requested;
-            const uint32_t req_old = requested;
-            if (want) { requested += kIdxChunk; inflight = true; }
-            const uint32_t s = 8u * j + (lane >> 3), piece = lane & 7u;
-            const uint32_t w_s = bperm(want ? 1u : 0u, s), r_s = bperm(req_old, s), ve_s = bperm(vend, s);
-            const uint32_t lo_s = bperm((uint32_t)aoff, s), hi_s = bperm((uint32_t)(aoff >> 32), s);
-            const uint32_t o = r_s + 16u * piece;
-            const bool ld = w_s != 0u && o < ve_s;
-            fp = w_s != 0u;
-            fa = s * kIdxStride + (o & (kIdxRing - 1u));
-            /* always one load per turn (a lane with nothing to fetch re-reads its block's first 16 bytes): with a
-             * fixed number of vector-memory operations per turn the compiler can wait for exactly the chunk it
-             * commits (vmcnt(N)); a conditional load made it drain the queue once per round (2.3 us a round) */
-            const uint64_t ga = (((uint64_t)hi_s << 32) | lo_s) + (ld ? o : 0u);
-            fd = *reinterpret_cast<const uint4 *>(src_base + ga);
-        }
-        /* ---- one hop ---- */
-        if (!done) {
-            if (pos >= vend) {
-                done = true;
-            } else if (pos >= requested) {
-                /* jumped over everything requested (a long literal run): restart the ring at the chunk of pos;
-                 * a chunk still in flight lands in a slot that is rewritten before it is read */
-                requested = filled = pos & ~(kIdxChunk - 1u);
-                inflight = false;
-            } else if (pos + 8u <= filled || filled >= vend) {
-                const uint32_t w0 = *reinterpret_cast<const uint32_t *>(ring + (pos & (kIdxRing - 4u)));
-                const uint32_t w1 = *reinterpret_cast<const uint32_t *>(ring + ((pos + 4u) & (kIdxRing - 4u)));
-                const uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, pos & 3u);
-                uint32_t q = 0;       /* position after the literals, when they are known */
-                bool lit_done = false;
-                if (state == 0u) {
-                    pack = (pack >> 16) | ((unsigned long long)((pos - delta) & 0xffffu) << 48);
-                    k++;
-                    const uint32_t t = x & 255u, e1 = (x >> 8) & 255u;
-                    tm = t & 15u;
-                    const uint32_t ll = t >> 4;
-                    if (ll == 15u && e1 == 255u) { state = 1u; acc = 15u + 255u; pos += 2u; }
-                    else { q = pos + 1u + ll + (ll == 15u ? e1 + 1u : 0u); lit_done = true; }
-                } else {
-                    const uint32_t nx = ~x;
-                    const uint32_t n = nx ? (uint32_t)__builtin_ctz(nx) >> 3 : 4u; /* leading 0xFF bytes */
-                    if (state == 1u) {
-                        if (n == 4u) { acc += 1020u; pos += 4u; if (acc >= vend) done = true; }
-                        else { acc += 255u * n + ((x >> (8u * n)) & 255u); q = pos + n + 1u + acc; lit_done = true; if (acc >= vend) done = true; }
-                    } else {
-                        pos += n == 4u ? 4u : n + 1u;
-                        if (n != 4u) state = 0u;
-                    }
-                }
-                if (lit_done && !done) {
-                    if (q + 2u > vend) done = true;                 /* last sequence: literals only */
-                    else { pos = q + 2u; state = tm == 15u ? 2u : 0u; }
-                }
-                if (k >= cap) done = true;
-            }
-        }
-    };
-
-    while (__any(!done)) {
-        /* the last four positions go out once per round (a lane gains at most four per round; re-writing older
-         * entries with the same values is harmless): one unconditional store, see the note on the loads */
-        {
-            const uint32_t at = k >= 4u ? k - 4u : 0u;
-            const unsigned long long v = k >= 4u ? pack : (k ? pack >> (16u * (4u - k)) : 0ull);
-            __builtin_memcpy((owner ? row : dummy) + at, &v, 8);
-        }
-        turn(0u, fd0, fa0, fp0);
-        turn(1u, fd1, fa1, fp1);
-        turn(2u, fd2, fa2, fp2);
-        turn(3u, fd3, fa3, fp3);
-    }
-    if (owner) {
-        const uint32_t at = k >= 4u ? k - 4u : 0u;
-        const unsigned long long v = k >= 4u ? pack : (k ? pack >> (16u * (4u - k)) : 0ull);
-        __builtin_memcpy(row + at, &v, 8);
-        tbl_n[blk] = k;
-    }
-}
 
 /* lane i gets lane i+1's value (lane 63: 0) */
 __device__ inline uint32_t lane_next(uint32_t v)
@@ -777,8 +619,6 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     }
 }
 
-/* workspace of the sequence index: per block a row of `cap` u16 token positions, then one u32 count per block */
-static uint32_t lz4_index_cap(uint32_t block_size) { return ((block_size / 8u + 64u) + 3u) & ~3u; }
 static uint64_t lz4_index_min_blocks()
 {
     /* the index walk is one lane per block: below a few thousand blocks its latency-bound pass costs more than the
@@ -792,7 +632,7 @@ static uint64_t lz4_index_min_blocks()
 size_t lz4_decompress_workspace(uint64_t n_blocks, uint32_t block_size)
 {
     if (n_blocks < lz4_index_min_blocks()) return 0;
-    return (size_t)n_blocks * lz4_index_cap(block_size) * 2u + 1024u /* dummy slots */ + (size_t)n_blocks * 4u + 64u;
+    return lz4_index_workspace(n_blocks, block_size);
 }
 
 hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
@@ -809,16 +649,23 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
         return e ? atoi(e) : 4096;
     }();
     const dim3 g((uint32_t)grid), b(256);
-    /* sequence index pass (large batches with a workspace) */
+    /* large batches with a workspace: sequence index pass + the decoder built for it (lz4_dec2.hip) */
     const uint16_t *tbl = nullptr;
     const uint32_t *tbl_n = nullptr;
     const uint32_t cap = lz4_index_cap(block_size);
     const size_t need = lz4_decompress_workspace(n_blocks, block_size);
+    static const int engine = [] {
+        const char *e = getenv("CRYO_LZ4_ENGINE"); /* 2 (default) = run-space copy engine, 1 = round-1 copy engine on the index (A/B) */
+        return e ? atoi(e) : 2;
+    }();
     if (need != 0 && d_workspace != nullptr && workspace_bytes >= need) {
+        if (engine != 1)
+            return launch_lz4_decompress_indexed(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks,
+                                                 d_status, d_workspace, workspace_bytes);
         uint16_t *t = static_cast<uint16_t *>(d_workspace);
         uint32_t *tn = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_workspace) + (((size_t)n_blocks * cap * 2u + 1024u + 15u) & ~(size_t)15u));
-        hipLaunchKernelGGL(k_lz4_index, dim3((uint32_t)((n_blocks + kIdxLanes - 1) / kIdxLanes)), dim3(64), 0, s, d_src, d_src_off, d_src_size,
-                           n_blocks, t, cap, tn);
+        hipError_t e = launch_lz4_index(s, d_src, d_src_off, d_src_size, n_blocks, t, cap, tn);
+        if (e != hipSuccess) return e;
         tbl = t;
         tbl_n = tn;
     }

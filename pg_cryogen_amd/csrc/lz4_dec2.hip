@@ -1,0 +1,676 @@
+/*
+ * lz4_dec2.hip -- LZ4 block decode for large batches: sequence index pass + run-space copy engine.
+ *
+ * Replaces LZ4_decompress_safe(compressed, out, compressed_size, CRYO_BLCKSZ) (reference
+ * compression.c:84) for a batch of independent blocks, with the accept/reject rules listed at the top of
+ * lz4_dec.hip (whose kernel stays the path for small batches).  Two kernels:
+ *
+ *   k_lz4_index   one LANE per block: walks the token chain and writes the low 16 bits of every token
+ *                 position to the block's row of the workspace (the serial part of LZ4 decoding, run
+ *                 for all blocks of the batch at once);
+ *   k_lz4_dec_seq one WAVE per block: lane i loads position i of the row, decodes "its" sequence
+ *                 (literal length, offset, match length), a wave scan gives output positions, and the
+ *                 bytes are moved by the run-space copy engine below.  The row is only a hint: every
+ *                 batch checks it against the stream (lz4_seq_batch), so a wrong row costs speed, never bytes.
+ *
+ * Run-space copy engine (seq_copy).  Round 1 moved one OUTPUT byte per lane and had to decide, per byte,
+ * whether it was a literal or a match byte (pass A: 24 VALU instructions per 64 bytes).  Here the literal
+ * bytes of a batch and its match bytes are two separate dense index spaces:
+ *   literal space: byte j of the concatenated literal runs -> run r(j) -> source in the input ring, destination
+ *                  in the output ring; no dependencies, pure streaming;
+ *   match space:   byte m of the concatenated matches -> sequence s(m) -> destination, source = destination -
+ *                  offset; chunks of 64 match bytes are produced in order, so only a source inside the
+ *                  chunk's own span can be unready (frontier rounds, see below).
+ * r(j) / s(m) come from a bitmap of run starts and v_mbcnt, as before; each space has one kind of byte, so
+ * the per-byte work is two additions and two masks.
+ */
+#include "lz_common.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace cryo {
+
+/* ---------------------------------------------------------------------------------------------
+ * Sequence index.  Finding where the sequences of an LZ4 block start is a serial walk (token ->
+ * literal length -> next token); done inside the decoding wave it needs speculative per-byte tables
+ * (lz4_dec.hip, lz4_batch: ~7 VALU instructions and four dependent LDS passes per sequence).  Across a
+ * batch the walk is embarrassingly parallel.
+ *
+ * k_lz4_index: 32 blocks per wave (lanes 0..31 each walk one block's token chain), 8 waves per CU, so
+ * every block of a 64k-block batch has its walk in flight at once and the pass takes
+ * (sequences per block) x (one hop).
+ *
+ * A lane that read its block straight from global memory paid ~1 us per hop (64 lanes = 64 cache lines
+ * per load, every hop a dependent trip to L2 or beyond: 6.9 ms for the headline batch, measured).  So each
+ * block's stream is staged through a private 512-byte LDS ring, filled 128 bytes at a time: in turn j of
+ * four the wave's 64 lanes load one chunk for each of blocks 8j..8j+7 (8 lanes x 16 bytes per block, one
+ * cache line) if that block has room, and store it into the ring one round of turns later, so the load's
+ * latency is covered by four hops.  The walk is a small state machine per lane (token / literal-length
+ * extension / match-length extension) so that one LDS read per hop serves every lane, whatever it is in.
+ * --------------------------------------------------------------------------------------------- */
+constexpr uint32_t kIdxLanes = 32, kIdxRing = 512, kIdxStride = kIdxRing + 16 /* bank skew between rings */, kIdxChunk = 128;
+
+__device__ inline uint32_t bperm(uint32_t v, uint32_t src_lane)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
+}
+
+__global__ void __launch_bounds__(64)
+k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
+            const uint32_t *__restrict__ src_size, uint64_t n_blocks, uint16_t *__restrict__ tbl, uint32_t cap,
+            uint32_t *__restrict__ tbl_n)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kIdxLanes * kIdxStride];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t blk = (uint64_t)blockIdx.x * kIdxLanes + (lane & (kIdxLanes - 1u));
+    const bool owner = lane < kIdxLanes && blk < n_blocks;
+    /* stream of this lane's block, in "virtual" positions: vp = delta + offset in the block, so that chunk
+     * addresses are 16-byte aligned */
+    uint64_t aoff = 0;
+    uint32_t delta = 0, vend = 0;
+    if (owner) {
+        const uint64_t o = src_off[blk];
+        aoff = o & ~(uint64_t)15;
+        delta = (uint32_t)(o & 15u);
+        vend = delta + src_size[blk];
+    }
+    uint16_t *row = tbl + blk * cap;
+    uint16_t *dummy = tbl + n_blocks * cap + lane * 4u; /* 8 bytes per lane behind the rows: where lanes without a block store */
+    if (!owner) aoff = src_off[0] & ~(uint64_t)15; /* lanes 32..63 only help with the loads; a lane past the end of the batch re-reads block 0 */
+    uint8_t *ring = s_ring + (lane & (kIdxLanes - 1u)) * kIdxStride;
+    uint32_t pos = delta;        /* next byte to interpret */
+    uint32_t requested = 0;      /* chunks requested up to here (multiple of kIdxChunk) */
+    uint32_t filled = 0;         /* chunks stored in the ring up to here */
+    bool inflight = false;       /* a chunk of this lane is on its way and still wanted */
+    uint32_t state = 0;          /* 0 token, 1 literal-length extension, 2 match-length extension */
+    uint32_t acc = 0, tm = 0;    /* literal length being accumulated; match nibble of the current token */
+    uint32_t k = 0;
+    unsigned long long pack = 0;
+    bool done = !owner || vend == delta;
+
+    /* chunks on their way: one per turn, committed a round later (separate variables, not an array: the
+     * compiler kept an indexed array in scratch memory) */
+    uint4 fd0 = make_uint4(0, 0, 0, 0), fd1 = fd0, fd2 = fd0, fd3 = fd0;
+    uint32_t fa0 = 0, fa1 = 0, fa2 = 0, fa3 = 0;
+    bool fp0 = false, fp1 = false, fp2 = false, fp3 = false;
+
+    auto turn = [&](const uint32_t j, uint4 &fd, uint32_t &fa, bool &fp) __attribute__((always_inline)) {
+        const bool myturn = (lane >> 3) == j; /* lanes 8j..8j+7 (owners: lane < 32) */
+        /* ---- commit the chunks requested one round ago ---- */
+        if (fp) *reinterpret_cast<uint4 *>(s_ring + fa) = fd;
+        if (myturn && inflight) { filled += kIdxChunk; inflight = false; }
+        /* ---- request the next chunk of blocks 8j..8j+7 ---- */
+        {
+            const bool want = myturn && !done && requested < vend && pos + (kIdxRing - kIdxChunk) >= requested;
+            const uint32_t req_old = requested;
+            if (want) { requested += kIdxChunk; inflight = true; }
+            const uint32_t s = 8u * j + (lane >> 3), piece = lane & 7u;
+            const uint32_t w_s = bperm(want ? 1u : 0u, s), r_s = bperm(req_old, s), ve_s = bperm(vend, s);
+            const uint32_t lo_s = bperm((uint32_t)aoff, s), hi_s = bperm((uint32_t)(aoff >> 32), s);
+            const uint32_t o = r_s + 16u * piece;
+            const bool ld = w_s != 0u && o < ve_s;
+            fp = w_s != 0u;
+            fa = s * kIdxStride + (o & (kIdxRing - 1u));
+            /* always one load per turn (a lane with nothing to fetch re-reads its block's first 16 bytes): with a
+             * fixed number of vector-memory operations per turn the compiler can wait for exactly the chunk it
+             * commits (vmcnt(N)); a conditional load made it drain the queue once per round (2.3 us a round) */
+            const uint64_t ga = (((uint64_t)hi_s << 32) | lo_s) + (ld ? o : 0u);
+            fd = *reinterpret_cast<const uint4 *>(src_base + ga);
+        }
+        /* ---- one hop ---- */
+        if (!done) {
+            if (pos >= vend) {
+                done = true;
+            } else if (pos >= requested) {
+                /* jumped over everything requested (a long literal run): restart the ring at the chunk of pos;
+                 * a chunk still in flight lands in a slot that is rewritten before it is read */
+                requested = filled = pos & ~(kIdxChunk - 1u);
+                inflight = false;
+            } else if (pos + 8u <= filled || filled >= vend) {
+                const uint32_t w0 = *reinterpret_cast<const uint32_t *>(ring + (pos & (kIdxRing - 4u)));
+                const uint32_t w1 = *reinterpret_cast<const uint32_t *>(ring + ((pos + 4u) & (kIdxRing - 4u)));
+                const uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, pos & 3u);
+                uint32_t q = 0;       /* position after the literals, when they are known */
+                bool lit_done = false;
+                if (state == 0u) {
+                    pack = (pack >> 16) | ((unsigned long long)((pos - delta) & 0xffffu) << 48);
+                    k++;
+                    const uint32_t t = x & 255u, e1 = (x >> 8) & 255u;
+                    tm = t & 15u;
+                    const uint32_t ll = t >> 4;
+                    if (ll == 15u && e1 == 255u) { state = 1u; acc = 15u + 255u; pos += 2u; }
+                    else { q = pos + 1u + ll + (ll == 15u ? e1 + 1u : 0u); lit_done = true; }
+                } else {
+                    const uint32_t nx = ~x;
+                    const uint32_t n = nx ? (uint32_t)__builtin_ctz(nx) >> 3 : 4u; /* leading 0xFF bytes */
+                    if (state == 1u) {
+                        if (n == 4u) { acc += 1020u; pos += 4u; if (acc >= vend) done = true; }
+                        else { acc += 255u * n + ((x >> (8u * n)) & 255u); q = pos + n + 1u + acc; lit_done = true; if (acc >= vend) done = true; }
+                    } else {
+                        pos += n == 4u ? 4u : n + 1u;
+                        if (n != 4u) state = 0u;
+                    }
+                }
+                if (lit_done && !done) {
+                    if (q + 2u > vend) done = true;                 /* last sequence: literals only */
+                    else { pos = q + 2u; state = tm == 15u ? 2u : 0u; }
+                }
+                if (k >= cap) done = true;
+            }
+        }
+    };
+
+    while (__any(!done)) {
+        /* the last four positions go out once per round (a lane gains at most four per round; re-writing older
+         * entries with the same values is harmless): one unconditional store, see the note on the loads */
+        {
+            const uint32_t at = k >= 4u ? k - 4u : 0u;
+            const unsigned long long v = k >= 4u ? pack : (k ? pack >> (16u * (4u - k)) : 0ull);
+            __builtin_memcpy((owner ? row : dummy) + at, &v, 8);
+        }
+        turn(0u, fd0, fa0, fp0);
+        turn(1u, fd1, fa1, fp1);
+        turn(2u, fd2, fa2, fp2);
+        turn(3u, fd3, fa3, fp3);
+    }
+    if (owner) {
+        const uint32_t at = k >= 4u ? k - 4u : 0u;
+        const unsigned long long v = k >= 4u ? pack : (k ? pack >> (16u * (4u - k)) : 0ull);
+        __builtin_memcpy(row + at, &v, 8);
+        tbl_n[blk] = k;
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------
+ * Decoder
+ * --------------------------------------------------------------------------------------------- */
+#define LDS_FENCE() asm volatile("" ::: "memory")
+
+constexpr uint32_t kSeqWin = 1536;  /* compressed bytes a batch may span (in_hi stays < vp + kInRing)   */
+constexpr uint32_t kT2 = 1024;      /* output bytes per batch                                           */
+constexpr uint32_t kBmW = kT2 / 32; /* bitmap words per run space                                       */
+constexpr uint32_t kNc = kT2 / 64;  /* chunks per run space (at most)                                   */
+
+template <uint32_t R>
+struct SeqLds {
+    uint8_t *ring;                 /* R, R-aligned: output ring                                         */
+    uint8_t *in;                   /* kInRing, kInRing-aligned: input ring                              */
+    uint2 *lmeta;                  /* 64: literal run r -> (ring index of its byte 0 minus its position in literal space, input-ring index likewise) */
+    uint2 *mmeta;                  /* 64: sequence s   -> (output position of its match minus its position in match space, offset)                    */
+    uint32_t *lbm, *mbm;           /* kBmW + kNc each: bitmap of run starts, then per-chunk bases        */
+};
+
+/* lane i gets lane i+1's value (lane 63: 0) */
+__device__ inline uint32_t lane_next(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+}
+
+/*
+ * Copy the bytes of up to 64 sequences (lane i < nseq holds sequence i).
+ *   ostart: first output byte of the sequence inside the batch; ll literal bytes from virtual input position
+ *   lpos, then ml match bytes at distance off (off >= ml: no overlap inside one match); T = total bytes <= kT2.
+ */
+template <uint32_t R>
+__device__ inline void seq_copy(Wave<R> &w, const SeqLds<R> &L, const uint32_t nseq, const uint32_t ostart,
+                                const uint32_t ll, const uint32_t ml, const uint32_t off, const uint32_t lpos,
+                                const uint32_t T, Stats &st)
+{
+    static_assert(R >= 2048 + kT2, "ring must hold a batch plus a useful near window");
+    constexpr uint32_t kNear = R - kT2 - 64u; /* sources at least this far back were flushed before the batch began */
+    const uint32_t lane = w.lane;
+    const uint32_t op0 = w.op;
+    const bool act = lane < nseq;
+    st.batches++;
+    st.batch_seqs += nseq;
+
+    /* ---- the two run spaces ---- */
+    const uint32_t llx = act ? ll : 0u;
+    const uint32_t lend = scan64_incl(llx);
+    const uint32_t lcum = lend - llx;          /* literal bytes before this sequence's literals */
+    const uint32_t mcum = ostart - lcum;       /* match bytes before this sequence's match      */
+    const uint32_t LT = lane_get(lend, nseq - 1u), MT = T - LT;
+    const unsigned long long haslit = __ballot(llx != 0u);
+    const uint32_t lrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(haslit >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)haslit, 0u));
+
+    if (lane < kBmW) { L.lbm[lane] = 0u; L.mbm[lane] = 0u; }
+    LDS_FENCE();
+    if (act) {
+        /* bit (start - 1) for every run that starts at a position >= 1: the number of set bits BELOW a position is
+         * the index of the run it belongs to.  Empty literal runs have no entry (literal runs are ranked). */
+        L.mmeta[lane] = make_uint2(op0 + ostart + ll - mcum, off);
+        if (mcum != 0u) atomicOr(&L.mbm[(mcum - 1u) >> 5], 1u << ((mcum - 1u) & 31u));
+        if (llx != 0u) {
+            L.lmeta[lrank] = make_uint2(op0 + ostart - lcum, lpos - lcum);
+            if (lcum != 0u) atomicOr(&L.lbm[(lcum - 1u) >> 5], 1u << ((lcum - 1u) & 31u));
+        }
+    }
+    LDS_FENCE();
+    {
+        /* bits before each chunk: lanes 0..15 literal space, 16..31 match space (one DPP row each) */
+        static_assert(kNc == 16, "chunk-count scan uses one DPP row per space");
+        const uint32_t *bm = lane < 16u ? L.lbm : L.mbm;
+        const uint32_t c = lane & 15u;
+        const uint2 wv = *reinterpret_cast<const uint2 *>(&bm[c * 2u]);
+        uint32_t cnt = (uint32_t)(__popc(wv.x) + __popc(wv.y));
+        cnt = scan16_incl(cnt) - cnt;
+        if (lane < 16u) L.lbm[kBmW + c] = cnt;
+        else if (lane < 32u) L.mbm[kBmW + c] = cnt;
+    }
+    LDS_FENCE();
+    stamp(st, 4);
+
+    /* ---- literal space: independent bytes, four chunks in flight ---- */
+    {
+        const uint32_t nL = (LT + 63u) >> 6;
+        for (uint32_t c0 = 0; c0 < nL; c0 += 4u) {
+            uint32_t idx[4], x[4];
+            uint2 mt[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                const uint32_t c = c0 + u < kNc ? c0 + u : kNc - 1u;
+                const uint2 wv = *reinterpret_cast<const uint2 *>(&L.lbm[c * 2u]);
+                const uint32_t bc = L.lbm[kBmW + c];
+                idx[u] = (bc + __builtin_amdgcn_mbcnt_hi(wv.y, __builtin_amdgcn_mbcnt_lo(wv.x, 0u))) & 63u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) mt[u] = L.lmeta[idx[u]];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                const uint32_t j = (c0 + u) * 64u + lane;
+                x[u] = L.in[(j + mt[u].y) & kInMask];
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                const uint32_t j = (c0 + u) * 64u + lane;
+                if (j < LT) L.ring[(j + mt[u].x) & (R - 1u)] = (uint8_t)x[u];
+            }
+        }
+    }
+    LDS_FENCE();
+    stamp(st, 5);
+
+    /* ---- match space: chunks in order ---- */
+    {
+        const uint32_t nM = (MT + 63u) >> 6;
+        constexpr uint32_t U = 4;
+        for (uint32_t c0 = 0; c0 < nM; c0 += U) {
+            uint32_t da[U], ra[U], xf[U];
+            bool farv[U], pendv[U], actv[U];
+            {
+                uint32_t idx[U];
+                uint2 mt[U];
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) {
+                    const uint32_t c = c0 + u < kNc ? c0 + u : kNc - 1u;
+                    const uint2 wv = *reinterpret_cast<const uint2 *>(&L.mbm[c * 2u]);
+                    const uint32_t bc = L.mbm[kBmW + c];
+                    idx[u] = (bc + __builtin_amdgcn_mbcnt_hi(wv.y, __builtin_amdgcn_mbcnt_lo(wv.x, 0u))) & 63u;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) mt[u] = L.mmeta[idx[u]];
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) {
+                    const uint32_t m = (c0 + u) * 64u + lane;
+                    const bool a = m < MT;
+                    da[u] = m + mt[u].x;                  /* absolute output position of this byte */
+                    ra[u] = da[u] - mt[u].y;              /* ... and of its source                  */
+                    const bool isFar = mt[u].y >= kNear;
+                    const uint32_t d0 = uni(da[u]);       /* first byte of the chunk               */
+                    actv[u] = a;
+                    farv[u] = isFar;
+                    pendv[u] = a && !isFar && ra[u] >= d0;
+                    /* unconditional load: lanes without a far byte read the first byte of the block */
+                    xf[u] = w.dst[(a && isFar) ? ra[u] : 0u];
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                if ((c0 + u) * 64u < MT) {
+                    st.chunks++;
+                    uint8_t *dp = &L.ring[da[u] & (R - 1u)];
+                    const uint8_t *sp = &L.ring[ra[u] & (R - 1u)];
+                    uint32_t x = *sp;
+                    if (farv[u]) x = xf[u];
+                    if (actv[u]) *dp = (uint8_t)x;
+                    /* a source inside this chunk's own span may not be written yet (or be a literal, which is):
+                     * everything below the first pending byte is final, so a pending byte whose source lies below
+                     * it can be taken; the first pending byte itself always can */
+                    bool pend = pendv[u];
+                    unsigned long long pm = __ballot(pend);
+                    while (pm != 0ull) {
+                        st.rounds++;
+                        const uint32_t f = ctz64(pm);
+                        const uint32_t F = lane_get(da[u], f);
+                        const bool rdy = pend && (ra[u] < F || lane == f);
+                        if (rdy) *dp = *sp;
+                        pm &= ~__ballot(rdy);
+                        pend = pend && !rdy;
+                    }
+                }
+            }
+        }
+    }
+    stamp(st, 6);
+    w.op = op0 + T;
+    w.flush();
+}
+
+/*
+ * One batch: sequences n0 .. n0+63 of the block start at the positions in the index row (epos = this lane's
+ * entry).  Returns the number of sequences decoded (0: the caller takes one sequence through the general path).
+ */
+template <uint32_t R>
+__device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const SeqLds<R> &L, uint32_t &vp, const uint32_t B,
+                                         const uint32_t epos, const uint32_t navail, const uint16_t *__restrict__ trow,
+                                         const uint32_t n0, const uint32_t ntab, uint32_t &epre, Stats &st)
+{
+    const uint32_t lane = w.lane;
+    const uint32_t vend = w.vend;
+    if (vend < 32u || B < 32u || navail == 0u) return 0;
+    const uint32_t vsafe = vend - 16u;
+    if (vp + 64u > vsafe || w.op + 64u > B) return 0;
+    stamp(st, 7);
+    while (w.in_hi < vend && w.in_hi < vp + kSeqWin) w.refill();
+    LDS_FENCE();
+    stamp(st, 0);
+    /* positions: the row holds the low 16 bits of the offset in the compressed block; a batch spans < 64 KiB */
+    const uint32_t pos = vp + ((epos + w.delta - vp) & 0xffffu);
+    const bool cand = lane < navail && pos + 8u <= vp + kSeqWin; /* also keeps the reads below inside the staged window */
+    const uint32_t rp = cand ? pos : vp;
+    const uint32_t t = L.in[rp & kInMask];
+    const uint32_t e1 = L.in[(rp + 1u) & kInMask];
+    uint32_t ll = t >> 4;
+    uint32_t k = 1u;
+    if (ll == 15u) { ll += e1; k = 2u; }
+    const uint32_t q = rp + k + ll; /* offset field */
+    const bool inwin = q + 8u <= vp + kSeqWin;
+    const uint32_t rq = inwin ? q : vp;
+    const uint32_t off = (uint32_t)L.in[rq & kInMask] | ((uint32_t)L.in[(rq + 1u) & kInMask] << 8);
+    const uint32_t e2 = L.in[(rq + 2u) & kInMask];
+    uint32_t ml = (t & 15u) + 4u;
+    uint32_t dlen = k + ll + 2u;
+    const bool hasM = (t & 15u) == 15u;
+    if (hasM) { ml += e2; dlen += 1u; }
+    const uint32_t outlen = cand ? ll + ml : 0u;
+    const uint32_t oend = scan64_incl(outlen);
+    const uint32_t ostart = oend - outlen;
+    const uint32_t mabs = w.op + ostart + ll;
+    /* the row is a hint: lane 0 must sit on the wave's own position and every sequence must end where the
+     * next lane's starts (the last candidate needs no successor) */
+    const uint32_t npos = lane_next(pos);
+    const bool chain = (lane == 0u ? pos == vp : true) && (lane + 1u >= navail || lane == 63u || npos == pos + dlen);
+    const bool ok = cand && inwin && chain && !(t >= 0xf0u && e1 == 255u) && !(hasM && e2 == 255u) && off >= ml && off <= mabs &&
+                    pos + dlen <= vsafe && oend <= kT2 && w.op + oend + 16u <= B;
+    const unsigned long long badmask = __ballot(!ok);
+    const uint32_t nseq = badmask ? ctz64(badmask) : 64u;
+    if (nseq == 0u) return 0;
+    const uint32_t T = lane_get(oend, nseq - 1u);
+    const uint32_t used = lane_get(pos + dlen, nseq - 1u) - vp;
+    /* the next batch's positions are requested now: their trip to memory hides behind this batch's copy */
+    epre = 0;
+    if (n0 + nseq + lane < ntab) epre = trow[n0 + nseq + lane];
+    stamp(st, 3);
+    seq_copy<R>(w, L, nseq, ostart, ll, ml, off, pos + k, T, st);
+    vp += used;
+    stamp(st, 0);
+    return nseq;
+}
+
+/*
+ * One sequence through the wave-uniform parser: every token form (255-runs, literal runs and matches of any
+ * length, overlapping matches, the block's last sequence) and every reject rule.  Returns 0 = decoded,
+ * 1 = decoded and it was the block's last sequence, 2 = malformed.
+ */
+template <uint32_t R>
+__device__ inline uint32_t lz4_general_seq(Wave<R> &w, uint32_t &vp, const uint32_t B)
+{
+    const uint32_t lane = w.lane, vend = w.vend;
+    w.flush();
+    w.need(vp);
+    uint32_t win = w.window(vp);
+
+    /* ---- token and literal length (window lane 0 = token) ---- */
+    const uint32_t token = lane_get(win, 0);
+    uint32_t ll = token >> 4;
+    uint32_t k = 1; /* window lane of the first byte after the literal-length field */
+    if (ll == 15u) {
+        /* extension bytes: 255 ... 255 x ; find the terminating byte with a ballot */
+        uint32_t wbase = vp;
+        for (;;) {
+            const unsigned long long m = __ballot(win != 255u) & ~((1ull << k) - 1ull);
+            if (m != 0ull) {
+                const uint32_t f = ctz64(m);
+                ll += (f - k) * 255u + lane_get(win, f);
+                k = f + 1u;
+                break;
+            }
+            /* a 255 at position q is only legal while q + 16 < csize */
+            if (wbase + 63u + 16u >= vend) return 2u;
+            ll += (64u - k) * 255u;
+            wbase += 64u;
+            w.need(wbase);
+            win = w.window(wbase);
+            k = 0;
+        }
+        /* terminating byte at position pe must satisfy pe + 15 < csize */
+        if (wbase + (k - 1u) + 15u >= vend) return 2u;
+        vp = wbase; /* lane k of the current window is the byte after the field */
+    }
+    const uint32_t lp = vp + k; /* virtual position of the first literal */
+
+    /* ---- literal run ---- */
+    const bool last = (w.op + ll + 12u > B) || (lp + ll + 8u > vend);
+    if (last && (lp + ll != vend || w.op + ll > B)) return 2u;
+    {
+        /* first piece straight from the window registers */
+        uint32_t n0 = 64u - k;
+        if (n0 > ll) n0 = ll;
+        if (lane >= k && lane < k + n0) w.ring[(w.op + lane - k) & (R - 1)] = (uint8_t)win;
+        w.op += n0;
+        uint32_t rem = ll - n0;
+        uint32_t p = lp + n0;
+        while (rem) {
+            w.flush();
+            if (wave_stream_literals(w, p, rem)) continue; /* long run at a 1 KiB boundary: lz_common.h */
+            w.need(p);
+            const uint32_t x = w.window(p);
+            uint32_t n = rem < 64u ? rem : 64u;
+            if (rem >= 3u * R) { const uint32_t to = kChunk - (w.op & (kChunk - 1u)); n = n < to ? n : to; } /* land on the boundary */
+            if (lane < n) w.ring[(w.op + lane) & (R - 1)] = (uint8_t)x;
+            w.op += n;
+            p += n;
+            rem -= n;
+        }
+        if (last) return 1u;
+        /* keep the 2 offset bytes and the first length byte inside the window */
+        if (p - vp > 61u) {
+            vp = p;
+            w.need(vp);
+            win = w.window(vp);
+        }
+        k = p - vp; /* window lane of the offset's low byte */
+    }
+
+    /* ---- offset and match length ---- */
+    const uint32_t off = lane_get(win, k) | (lane_get(win, k + 1u) << 8);
+    uint32_t ml = token & 15u;
+    k += 2u;
+    if (ml == 15u) {
+        uint32_t wbase = vp;
+        for (;;) {
+            const unsigned long long m = (k < 64u) ? (__ballot(win != 255u) & ~((1ull << k) - 1ull)) : 0ull;
+            if (m != 0ull) {
+                const uint32_t f = ctz64(m);
+                ml += (f - k) * 255u + lane_get(win, f);
+                k = f + 1u;
+                break;
+            }
+            /* every extension byte at position q needs q + 5 < csize */
+            if (wbase + 63u + 5u >= vend) return 2u;
+            ml += (64u - k) * 255u;
+            wbase += 64u;
+            w.need(wbase);
+            win = w.window(wbase);
+            k = 0;
+        }
+        if (wbase + (k - 1u) + 5u >= vend) return 2u;
+        vp = wbase;
+    }
+    ml += 4u;
+    if (off > w.op || w.op + ml + 5u > B) return 2u;
+    vp += k;
+    wave_copy_match(w, off, ml); /* lz_common.h: near / far / overlapping / offset 0 */
+    return 0u;
+}
+
+template <uint32_t R, bool STATS>
+__global__ void __launch_bounds__(256, 5)
+k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
+              const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
+              uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats,
+              const uint16_t *__restrict__ tbl, uint32_t tbl_cap, const uint32_t *__restrict__ tbl_n)
+{
+    Stats st = {};
+    st.on = STATS;
+    if (STATS) { st.ablate = (uint32_t)stats[7]; st.t0 = __builtin_amdgcn_s_memtime(); }
+    __shared__ __attribute__((aligned(R))) uint8_t s_ring[4][R];
+    __shared__ __attribute__((aligned(kInRing))) uint8_t s_in[4][kInRing];
+    __shared__ __attribute__((aligned(8))) uint2 s_lmeta[4][64];
+    __shared__ __attribute__((aligned(8))) uint2 s_mmeta[4][64];
+    __shared__ __attribute__((aligned(8))) uint32_t s_lbm[4][kBmW + kNc];
+    __shared__ __attribute__((aligned(8))) uint32_t s_mbm[4][kBmW + kNc];
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wid = uni(threadIdx.x >> 6);
+    const uint64_t blk = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid;
+    if (blk >= n_blocks) return;
+
+    const uint8_t *base = src_base + uni64(src_off[blk]);
+    const uint32_t csize = uni(src_size[blk]);
+
+    Wave<R> w;
+    const SeqLds<R> L = {s_ring[wid], s_in[wid], s_lmeta[wid], s_mmeta[wid], s_lbm[wid], s_mbm[wid]};
+    w.ring = L.ring;
+    w.in = L.in;
+    w.lane = lane;
+    w.delta = (uint32_t)(reinterpret_cast<uintptr_t>(base) & 15u);
+    w.abase = base - w.delta;
+    w.vend = w.delta + csize;
+    w.in_hi = 0;
+    w.dst = dst_base + uni64(blk * dst_stride);
+    w.dst_aligned = (reinterpret_cast<uintptr_t>(w.dst) & 15u) == 0;
+    w.op = 0;
+    w.flushed = 0;
+
+    uint32_t vp = w.delta;
+    bool bad = (csize == 0);
+    bool done = bad;
+    uint32_t skip = 0;
+    const uint16_t *trow = tbl + uni64(blk * (uint64_t)tbl_cap);
+    const uint32_t ntab = uni(tbl_n[blk]);
+    uint32_t n0 = 0; /* sequences decoded so far */
+
+    if (!bad) {
+        w.prefetch();
+        w.refill();
+        if (w.in_hi < w.vend) w.refill();
+    }
+
+    while (!done) {
+        if (skip == 0u) {
+            uint32_t n;
+            uint32_t epre = 0;
+            bool have_pre = false;
+            do {
+                uint32_t e = epre;
+                const uint32_t navail = n0 < ntab ? (ntab - n0 < 64u ? ntab - n0 : 64u) : 0u;
+                if (!have_pre) { e = 0; if (lane < navail) e = trow[n0 + lane]; }
+                n = lz4_seq_batch<R>(w, L, vp, B, e, navail, trow, n0, ntab, epre, st);
+                have_pre = n != 0u;
+                n0 += n;
+                if (n == 0u) st.zero_batches++;
+            } while (n >= 8u);
+            if (n < 4u) skip = 4u;
+        } else {
+            skip--;
+        }
+        st.general_seqs++;
+        n0++;
+        const uint32_t r = lz4_general_seq<R>(w, vp, B);
+        if (r == 2u) { bad = true; break; }
+        if (r == 1u) done = true;
+    }
+
+    if (!bad && w.op != B) bad = true;
+    if (!bad) {
+        w.flush();
+        w.flush_tail();
+    }
+    if (lane == 0) status[blk] = bad ? CRYO_ST_CORRUPT : CRYO_ST_OK;
+    if (STATS && lane == 0) {
+        atomicAdd(&stats[0], (unsigned long long)st.batches);
+        atomicAdd(&stats[1], (unsigned long long)st.batch_seqs);
+        atomicAdd(&stats[2], (unsigned long long)st.general_seqs);
+        atomicAdd(&stats[3], (unsigned long long)st.chunks);
+        atomicAdd(&stats[4], (unsigned long long)st.rounds);
+        atomicAdd(&stats[5], (unsigned long long)st.zero_batches);
+        stamp(st, 7);
+        for (int k = 0; k < 8; k++) atomicAdd(&stats[8 + k], st.t[k]);
+    }
+}
+
+/* ---- launcher ---- */
+uint32_t lz4_index_cap(uint32_t block_size) { return ((block_size / 8u + 64u) + 3u) & ~3u; }
+
+size_t lz4_index_workspace(uint64_t n_blocks, uint32_t block_size)
+{
+    return (size_t)n_blocks * lz4_index_cap(block_size) * 2u + 1024u /* dummy slots */ + (size_t)n_blocks * 4u + 64u;
+}
+
+hipError_t launch_lz4_index(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
+                            uint64_t n_blocks, uint16_t *tbl, uint32_t cap, uint32_t *tbl_n)
+{
+    hipLaunchKernelGGL(k_lz4_index, dim3((uint32_t)((n_blocks + kIdxLanes - 1) / kIdxLanes)), dim3(64), 0, s, d_src, d_src_off, d_src_size,
+                       n_blocks, tbl, cap, tbl_n);
+    return hipGetLastError();
+}
+
+hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
+                                         const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
+                                         uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
+                                         size_t workspace_bytes)
+{
+    if (n_blocks == 0) return hipSuccess;
+    const uint64_t grid = (n_blocks + 3) / 4;
+    if (grid > 0x7fffffffull || workspace_bytes < lz4_index_workspace(n_blocks, block_size) || !d_workspace) return hipErrorInvalidValue;
+    const uint32_t cap = lz4_index_cap(block_size);
+    uint16_t *tbl = static_cast<uint16_t *>(d_workspace);
+    uint32_t *tbl_n = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_workspace) + (((size_t)n_blocks * cap * 2u + 1024u + 15u) & ~(size_t)15u));
+    hipLaunchKernelGGL(k_lz4_index, dim3((uint32_t)((n_blocks + kIdxLanes - 1) / kIdxLanes)), dim3(64), 0, s, d_src, d_src_off, d_src_size,
+                       n_blocks, tbl, cap, tbl_n);
+    const dim3 g((uint32_t)grid), b(256);
+    static const bool want_stats = getenv("CRYO_LZ4_STATS") != nullptr; /* debugging aid */
+    if (want_stats) {
+        unsigned long long *d_st = nullptr, h_st[16];
+        if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
+        (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
+        hipLaunchKernelGGL((k_lz4_dec_seq<4096, true>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
+                           block_size, n_blocks, d_status, d_st, tbl, cap, tbl_n);
+        (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
+        (void)hipStreamSynchronize(s);
+        (void)hipFree(d_st);
+        fprintf(stderr, "[lz4 seq stats] batches %llu batch_seqs %llu general_seqs %llu match chunks %llu rounds %llu zero_batches %llu\n",
+                h_st[0], h_st[1], h_st[2], h_st[3], h_st[4], h_st[5]);
+        unsigned long long tot = 0;
+        for (int k = 0; k < 8; k++) tot += h_st[8 + k];
+        static const char *nm[8] = {"stage+flush", "-", "-", "decode+validate", "spaces+bitmaps", "literal space", "match space", "general+other"};
+        for (int k = 0; k < 8; k++) fprintf(stderr, "[lz4 seq cycles] %-16s %5.1f%%\n", nm[k], 100.0 * (double)h_st[8 + k] / (double)(tot ? tot : 1));
+        return hipGetLastError();
+    }
+    hipLaunchKernelGGL((k_lz4_dec_seq<4096, false>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
+                       block_size, n_blocks, d_status, nullptr, tbl, cap, tbl_n);
+    return hipGetLastError();
+}
+
+} // namespace cryo

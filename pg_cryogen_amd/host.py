@@ -25,7 +25,7 @@ ERROR_HANDLER = C.CFUNCTYPE(None, C.c_int, C.c_char_p)
 
 class CryoCodecOps(C.Structure):
     _fields_ = [("bound", BOUND_FN), ("compress_blocks", COMPRESS_FN), ("decompress_blocks", DECOMPRESS_FN),
-                ("ctx", C.c_void_p)]
+                ("ctx", C.c_void_p), ("decompress_blocks_scatter", C.c_void_p)]  # optional member: NULL in test doubles
 
 
 class CryoRel(C.Structure):

@@ -15,6 +15,9 @@
  */
 #include "compression.h"
 #include "cryo_codec.h"
+#ifdef CRYO_HAVE_POSTGRES
+#include "utils/guc.h" /* DefineCustom*Variable, config_enum_entry, PGC_USERSET (reference compression.c:4) */
+#endif
 
 #include <stdarg.h>
 #include <stdio.h>
@@ -41,7 +44,13 @@ static int hip_decompress_blocks(void *ctx, int method, const void *const *src, 
     return cryo_codec_decompress_blocks((cryo_codec *)ctx, method, src, sz, n, dst, bs, st);
 }
 
-static CryoCodecOps hip_ops = {hip_bound, hip_compress_blocks, hip_decompress_blocks, NULL};
+static int hip_decompress_blocks_scatter(void *ctx, int method, const void *const *src, const uint32_t *sz, size_t n,
+                                         void *const *dst, size_t bs, int32_t *st)
+{
+    return cryo_codec_decompress_blocks_to((cryo_codec *)ctx, method, src, sz, n, dst, bs, st);
+}
+
+static CryoCodecOps hip_ops = {hip_bound, hip_compress_blocks, hip_decompress_blocks, NULL, hip_decompress_blocks_scatter};
 static const CryoCodecOps *bound_ops; /* test double, if any */
 
 void cryo_host_set_codec_ops(const CryoCodecOps *ops) { bound_ops = ops; }
@@ -111,6 +120,9 @@ char *cryo_compress(CompressionMethod method, const char *data, Size *compressed
                               estimate, &csize);
     if (rc != 0 || csize == 0) {
         pfree(compressed);
+        if (rc == CRYO_E_UNSUPPORTED)   /* same ERROR as the reference, with the reason (this build has no kernel for it) */
+            elog(ERROR, "pg_cryogen: compression failed (no GPU kernel for %s parameter %d at block size %lu)",
+                 method == COMP_LZ4 ? "lz4" : "zstd", method_param(method), (unsigned long)cryo_blcksz);
         elog(ERROR, "pg_cryogen: compression failed");
         return NULL;
     }

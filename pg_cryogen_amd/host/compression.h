@@ -52,6 +52,9 @@ typedef struct CryoCodecOps {
     int (*decompress_blocks)(void *ctx, int method, const void *const *src, const uint32_t *src_size, size_t n,
                              void *dst, size_t block_size, int32_t *status);
     void *ctx;
+    /* optional (may be NULL): one destination per block, so the cache decodes straight into its slots */
+    int (*decompress_blocks_scatter)(void *ctx, int method, const void *const *src, const uint32_t *src_size, size_t n,
+                                     void *const *dst, size_t block_size, int32_t *status);
 } CryoCodecOps;
 void cryo_host_set_codec_ops(const CryoCodecOps *ops); /* NULL restores the HIP binding */
 const CryoCodecOps *cryo_host_codec_ops(void);         /* lazily opens the GPU codec */

@@ -340,3 +340,61 @@ def test_seqscan_read_ahead_in_iterator_order(H):
     assert not errors
     L.cryo_seqscan_iter_free(it)
     L.cryo_memrel_destroy(mem)
+
+
+def test_batch_larger_than_cache_never_aliases_slots(H):
+    """A batch with more blocks than evictable slots: hits and earlier misses of the batch stay pinned, the
+    surplus gets CACHE_IS_FULL, and every delivered entry holds its own block (round-1 advisor finding:
+    a later miss evicted an earlier hit and entry 0 silently carried another block's rows)."""
+    L, dbl, errors = H
+    host.set_block_size(4096)
+    L.cryo_cache_configure(4)
+    rows = [struct.pack("<i", i) for i in range(1, 801)]
+    mem, rel, blocks, firsts = _load(L, rows, 1, host.COMP_LZ4)
+    assert len(firsts) >= 6
+    e = C.c_int(-1)
+    assert L.cryo_read_data(C.byref(rel), None, firsts[0], C.byref(e)) == 0        # block 0 cached
+    want0 = fetch_rows(L, L.cryo_cache_get_data(e.value))
+    pin = L.cryo_cache_allocate(C.byref(rel), 9999)                               # one slot held by an insert buffer
+    k = 4
+    res, errs = (C.c_int * k)(), (C.c_int * k)()
+    blks = (C.c_uint32 * k)(firsts[0], firsts[1], firsts[2], firsts[3])
+    rc = L.cryo_read_data_batch(C.byref(rel), blks, k, res, errs)
+    assert rc == host.CRYO_ERR_CACHE_IS_FULL
+    assert list(errs) == [0, 0, 0, host.CRYO_ERR_CACHE_IS_FULL] and res[3] == -1
+    assert len({res[0], res[1], res[2], pin}) == 4                                 # four distinct slots
+    assert fetch_rows(L, L.cryo_cache_get_data(res[0])) == want0                   # the hit still holds block 0
+    got = [struct.unpack("<i", r)[0] for i in range(3) for r in fetch_rows(L, L.cryo_cache_get_data(res[i]))]
+    assert got == list(range(1, len(got) + 1))                                     # blocks 0,1,2 in order, own rows
+    # repeated block numbers inside one batch share a slot
+    L.cryo_cache_release(pin)
+    blks = (C.c_uint32 * 3)(firsts[4], firsts[4], firsts[5])
+    res, errs = (C.c_int * 3)(), (C.c_int * 3)()
+    assert L.cryo_read_data_batch(C.byref(rel), blks, 3, res, errs) == 0
+    assert res[0] == res[1] != res[2]
+    assert not errors
+    L.cryo_memrel_destroy(mem)
+
+
+def test_failed_probe_leaves_the_cache_untouched(H):
+    """a continuation-page probe (bitmap scans do this, reference pg_cryogen.c:442-444) fails with
+    WRONG_STARTING_BLOCK and must not clobber the LRU victim's page list or xid (round-1 advisor finding)"""
+    L, dbl, errors = H
+    host.set_block_size(131072)
+    L.cryo_cache_configure(1)
+    rng = np.random.default_rng(3)
+    rows = [struct.pack("<i", i) + rng.integers(0, 256, 400, dtype=np.uint8).tobytes() for i in range(1, 291)]
+    mem, rel, blocks, firsts = _load(L, rows, 2, host.COMP_LZ4)
+    e = C.c_int(-1)
+    assert L.cryo_read_data(C.byref(rel), None, firsts[0], C.byref(e)) == 0
+    npg, xid = L.cryo_cache_get_pg_nblocks(e.value), L.cryo_cache_get_xid(e.value)
+    assert npg >= 15
+    nxt = struct.unpack_from("<I", C.string_at(L.cryo_memrel_page(mem, firsts[0]), 64), 28)[0]
+    e2 = C.c_int(-1)
+    assert L.cryo_read_data(C.byref(rel), None, nxt, C.byref(e2)) == host.CRYO_ERR_WRONG_STARTING_BLOCK
+    misses = L.cryo_cache_misses()
+    assert L.cryo_read_data(C.byref(rel), None, firsts[0], C.byref(e)) == 0        # still a hit, metadata intact
+    assert L.cryo_cache_misses() == misses
+    assert L.cryo_cache_get_pg_nblocks(e.value) == npg and L.cryo_cache_get_xid(e.value) == xid
+    assert fetch_rows(L, L.cryo_cache_get_data(e.value)) == rows
+    L.cryo_memrel_destroy(mem)
