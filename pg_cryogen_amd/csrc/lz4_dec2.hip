@@ -13,16 +13,15 @@
  *                 bytes are moved by the run-space copy engine below.  The row is only a hint: every
  *                 batch checks it against the stream (lz4_seq_batch), so a wrong row costs speed, never bytes.
  *
- * Run-space copy engine (seq_copy).  Round 1 moved one OUTPUT byte per lane and had to decide, per byte,
- * whether it was a literal or a match byte (pass A: 24 VALU instructions per 64 bytes).  Here the literal
- * bytes of a batch and its match bytes are two separate dense index spaces:
- *   literal space: byte j of the concatenated literal runs -> run r(j) -> source in the input ring, destination
- *                  in the output ring; no dependencies, pure streaming;
- *   match space:   byte m of the concatenated matches -> sequence s(m) -> destination, source = destination -
- *                  offset; chunks of 64 match bytes are produced in order, so only a source inside the
- *                  chunk's own span can be unready (frontier rounds, see below).
- * r(j) / s(m) come from a bitmap of run starts and v_mbcnt, as before; each space has one kind of byte, so
- * the per-byte work is two additions and two masks.
+ * Copy engine (seq_copy).  Round 1 moved one OUTPUT byte per lane and had to decide, per byte, whether it was a
+ * literal or a match byte (pass A: 24 VALU instructions per 64 bytes).  Here the kinds never meet:
+ *   literals and independent matches (source ends before the batch begins; far matches -- source no longer in
+ *             the ring, requested from the flushed output when the batch was decoded -- are among them): one lane
+ *             per sequence copies its run 16 bytes per step with unaligned wide LDS accesses, exact to the byte;
+ *             no dependencies, a few LDS round trips per batch whatever its size;
+ *   dependent matches: "match space" = their bytes concatenated; byte m -> match r(m) (bitmap of match starts +
+ *             v_mbcnt) -> destination, source = destination - offset, one byte per lane.  Chunks of 64 match bytes
+ *             are produced in order, so only a source inside the chunk's own span can be unready (frontier rounds).
  */
 #include "lz_common.h"
 #include <cstdio>
@@ -187,17 +186,17 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
 #define LDS_FENCE() asm volatile("" ::: "memory")
 
 constexpr uint32_t kSeqWin = 1536;  /* compressed bytes a batch may span (in_hi stays < vp + kInRing)   */
-constexpr uint32_t kT2 = 1024;      /* output bytes per batch                                           */
+constexpr uint32_t kT2 = 1536;      /* output bytes per batch: the largest T with R - T >= T + 1023 at R = 4096, i.e. every
+                                     * offset is either still in the ring (off < R - T) or flushed (off >= T + 1023) */
 constexpr uint32_t kBmW = kT2 / 32; /* bitmap words per run space                                       */
 constexpr uint32_t kNc = kT2 / 64;  /* chunks per run space (at most)                                   */
 
 template <uint32_t R>
 struct SeqLds {
-    uint8_t *ring;                 /* R, R-aligned: output ring                                         */
-    uint8_t *in;                   /* kInRing, kInRing-aligned: input ring                              */
-    uint2 *lmeta;                  /* 64: literal run r -> (ring index of its byte 0 minus its position in literal space, input-ring index likewise) */
+    uint8_t *ring;                 /* R + 16: output ring; a literal piece that runs over the end lands in the 16 extra bytes and is folded back */
+    uint8_t *in;                   /* kInRing + 16: input ring; the extra bytes mirror its first 16 (16-byte reads near the end) */
     uint2 *mmeta;                  /* 64: sequence s   -> (output position of its match minus its position in match space, offset)                    */
-    uint32_t *lbm, *mbm;           /* kBmW + kNc each: bitmap of run starts, then per-chunk bases        */
+    uint32_t *mbm;                 /* kBmW + kNc: bitmap of match starts in match space, then per-chunk bases */
 };
 
 /* lane i gets lane i+1's value (lane 63: 0) */
@@ -207,96 +206,120 @@ __device__ inline uint32_t lane_next(uint32_t v)
 }
 
 /*
+ * One run per lane, 16 bytes per step, exact to the byte: `rem` bytes from `src` (a pointer into LDS, or -- FAR -- the
+ * registers xa, xb) to ring position `dv`.  Unaligned wide LDS accesses are exact on gfx950 and cost about one LDS
+ * cycle per active lane whatever their width (profiles/microbench).  The rest of a run goes out as 8/4/2/1-byte
+ * pieces: a byte too many would land in the next run.  A piece that runs over the ring's end lands in the 16
+ * bytes behind it; `spill` counts them (folded back by the caller).
+ */
+template <uint32_t R, uint32_t SMASK>
+__device__ inline void lane_runs(uint8_t *ring, const uint8_t *sbase, uint32_t rem, uint32_t sv, uint32_t dv, const bool far,
+                                 const uint4 xa, const uint4 xb, uint32_t &spill)
+{
+    uint32_t it = 0;
+    while (__any(rem >= 16u)) {
+        if (rem >= 16u) {
+            uint4 v = it == 0u ? xa : xb;
+            if (!far) __builtin_memcpy(&v, sbase + (sv & SMASK), 16);
+            const uint32_t di = dv & (R - 1u);
+            __builtin_memcpy(ring + di, &v.x, 8);
+            __builtin_memcpy(ring + di + 8u, &v.z, 8);
+            if (di + 16u > R) spill = di + 16u - R;
+            sv += 16u; dv += 16u; rem -= 16u;
+            it++;
+        }
+    }
+    if (rem != 0u) {
+        uint4 v = it == 0u ? xa : xb;
+        if (!far) __builtin_memcpy(&v, sbase + (sv & SMASK), 16);
+        uint32_t di = dv & (R - 1u);
+        if (di + rem > R) spill = di + rem - R;
+        if (rem & 8u) { __builtin_memcpy(ring + di, &v.x, 8); di += 8u; v.x = v.z; v.y = v.w; }
+        if (rem & 4u) { __builtin_memcpy(ring + di, &v.x, 4); di += 4u; v.x = v.y; }
+        if (rem & 2u) { const uint16_t h = (uint16_t)v.x; __builtin_memcpy(ring + di, &h, 2); di += 2u; v.x >>= 16; }
+        if (rem & 1u) ring[di] = (uint8_t)v.x;
+    }
+}
+
+/*
  * Copy the bytes of up to 64 sequences (lane i < nseq holds sequence i).
  *   ostart: first output byte of the sequence inside the batch; ll literal bytes from virtual input position
  *   lpos, then ml match bytes at distance off (off >= ml: no overlap inside one match); T = total bytes <= kT2.
+ *   isfar: the match's source is no longer in the ring; its bytes are in xfa/xfb (requested by the caller).
  */
 template <uint32_t R>
 __device__ inline void seq_copy(Wave<R> &w, const SeqLds<R> &L, const uint32_t nseq, const uint32_t ostart,
                                 const uint32_t ll, const uint32_t ml, const uint32_t off, const uint32_t lpos,
-                                const uint32_t T, Stats &st)
+                                const uint32_t T, const bool isfar, const uint4 xfa, const uint4 xfb, Stats &st)
 {
-    static_assert(R >= 2048 + kT2, "ring must hold a batch plus a useful near window");
-    constexpr uint32_t kNear = R - kT2 - 64u; /* sources at least this far back were flushed before the batch began */
+    static_assert(R - kT2 >= kT2 + 1023u, "an offset must be either in the ring or flushed");
     const uint32_t lane = w.lane;
     const uint32_t op0 = w.op;
     const bool act = lane < nseq;
     st.batches++;
     st.batch_seqs += nseq;
 
-    /* ---- the two run spaces ---- */
-    const uint32_t llx = act ? ll : 0u;
-    const uint32_t lend = scan64_incl(llx);
-    const uint32_t lcum = lend - llx;          /* literal bytes before this sequence's literals */
-    const uint32_t mcum = ostart - lcum;       /* match bytes before this sequence's match      */
-    const uint32_t LT = lane_get(lend, nseq - 1u), MT = T - LT;
-    const unsigned long long haslit = __ballot(llx != 0u);
-    const uint32_t lrank = __builtin_amdgcn_mbcnt_hi((uint32_t)(haslit >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)haslit, 0u));
+    /* A match whose source ends before the batch begins depends on nothing the batch produces (about half of them
+     * on tuple data, far matches included): those go lane-per-sequence like the literals.  The others form the
+     * "match space". */
+    const uint32_t mrel = ostart + ll;                           /* match start inside the batch */
+    const bool indep = act && (isfar || off >= mrel + ml);
+    const bool dep = act && !indep;
+    const uint32_t mlx = dep ? ml : 0u;
+    const uint32_t mend = scan64_incl(mlx);
+    const uint32_t mcum = mend - mlx;                            /* dependent match bytes before this sequence's */
+    const uint32_t MT = lane_get(mend, 63u);
+    const unsigned long long depm = __ballot(dep);
+    const uint32_t drank = __builtin_amdgcn_mbcnt_hi((uint32_t)(depm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)depm, 0u));
 
-    if (lane < kBmW) { L.lbm[lane] = 0u; L.mbm[lane] = 0u; }
+    if (lane < kBmW) L.mbm[lane] = 0u;
     LDS_FENCE();
-    if (act) {
-        /* bit (start - 1) for every run that starts at a position >= 1: the number of set bits BELOW a position is
-         * the index of the run it belongs to.  Empty literal runs have no entry (literal runs are ranked). */
-        L.mmeta[lane] = make_uint2(op0 + ostart + ll - mcum, off);
+    if (dep) {
+        /* bit (start - 1) for every dependent match that starts at a position >= 1 of match space: the number of set
+         * bits BELOW a position is the rank of the match it belongs to.
+         * meta: x = output position of the match minus its position in match space; y = offset */
+        L.mmeta[drank] = make_uint2(op0 + mrel - mcum, off);
         if (mcum != 0u) atomicOr(&L.mbm[(mcum - 1u) >> 5], 1u << ((mcum - 1u) & 31u));
-        if (llx != 0u) {
-            L.lmeta[lrank] = make_uint2(op0 + ostart - lcum, lpos - lcum);
-            if (lcum != 0u) atomicOr(&L.lbm[(lcum - 1u) >> 5], 1u << ((lcum - 1u) & 31u));
+    }
+    LDS_FENCE();
+
+    /* ---- literals and independent matches: one lane per sequence ---- */
+    {
+        uint32_t spill = 0; /* bytes this lane wrote beyond the ring's end */
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        lane_runs<R, kInMask>(L.ring, L.in, act ? ll : 0u, lpos, op0 + ostart, false, z, z, spill);
+        /* (the 16 bytes behind the ring mirror its first 16 for reads that start in its last 15: lz4_seq_batch) */
+        lane_runs<R, R - 1u>(L.ring, L.ring, indep ? ml : 0u, op0 + mrel - off, op0 + mrel, isfar, xfa, xfb, spill);
+        /* a batch crosses the ring's end at most once: fold the bytes that ran over back to the start */
+        const unsigned long long sm = __ballot(spill != 0u);
+        if (sm != 0ull) {
+            LDS_FENCE();
+            const uint32_t k = lane_get(spill, ctz64(sm));
+            if (lane < k) L.ring[lane] = L.ring[R + lane];
         }
     }
     LDS_FENCE();
     {
-        /* bits before each chunk: lanes 0..15 literal space, 16..31 match space (one DPP row each) */
-        static_assert(kNc == 16, "chunk-count scan uses one DPP row per space");
-        const uint32_t *bm = lane < 16u ? L.lbm : L.mbm;
-        const uint32_t c = lane & 15u;
-        const uint2 wv = *reinterpret_cast<const uint2 *>(&bm[c * 2u]);
-        uint32_t cnt = (uint32_t)(__popc(wv.x) + __popc(wv.y));
-        cnt = scan16_incl(cnt) - cnt;
-        if (lane < 16u) L.lbm[kBmW + c] = cnt;
-        else if (lane < 32u) L.mbm[kBmW + c] = cnt;
+        /* bits before each match-space chunk */
+        static_assert(kNc <= 64, "one lane per chunk");
+        uint32_t cnt = 0;
+        if (lane < kNc) {
+            const uint2 wv = *reinterpret_cast<const uint2 *>(&L.mbm[lane * 2u]);
+            cnt = (uint32_t)(__popc(wv.x) + __popc(wv.y));
+        }
+        const uint32_t exc = scan64_incl(cnt) - cnt;
+        if (lane < kNc) L.mbm[kBmW + lane] = exc;
     }
     LDS_FENCE();
     stamp(st, 4);
-
-    /* ---- literal space: independent bytes, four chunks in flight ---- */
-    {
-        const uint32_t nL = (LT + 63u) >> 6;
-        for (uint32_t c0 = 0; c0 < nL; c0 += 4u) {
-            uint32_t idx[4], x[4];
-            uint2 mt[4];
-#pragma unroll
-            for (uint32_t u = 0; u < 4u; u++) {
-                const uint32_t c = c0 + u < kNc ? c0 + u : kNc - 1u;
-                const uint2 wv = *reinterpret_cast<const uint2 *>(&L.lbm[c * 2u]);
-                const uint32_t bc = L.lbm[kBmW + c];
-                idx[u] = (bc + __builtin_amdgcn_mbcnt_hi(wv.y, __builtin_amdgcn_mbcnt_lo(wv.x, 0u))) & 63u;
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < 4u; u++) mt[u] = L.lmeta[idx[u]];
-#pragma unroll
-            for (uint32_t u = 0; u < 4u; u++) {
-                const uint32_t j = (c0 + u) * 64u + lane;
-                x[u] = L.in[(j + mt[u].y) & kInMask];
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < 4u; u++) {
-                const uint32_t j = (c0 + u) * 64u + lane;
-                if (j < LT) L.ring[(j + mt[u].x) & (R - 1u)] = (uint8_t)x[u];
-            }
-        }
-    }
-    LDS_FENCE();
-    stamp(st, 5);
 
     /* ---- match space: chunks in order ---- */
     {
         const uint32_t nM = (MT + 63u) >> 6;
         constexpr uint32_t U = 4;
         for (uint32_t c0 = 0; c0 < nM; c0 += U) {
-            uint32_t da[U], ra[U], xf[U];
-            bool farv[U], pendv[U], actv[U];
+            uint32_t da[U], ra[U];
+            bool pendv[U], actv[U];
             {
                 uint32_t idx[U];
                 uint2 mt[U];
@@ -315,13 +338,9 @@ __device__ inline void seq_copy(Wave<R> &w, const SeqLds<R> &L, const uint32_t n
                     const bool a = m < MT;
                     da[u] = m + mt[u].x;                  /* absolute output position of this byte */
                     ra[u] = da[u] - mt[u].y;              /* ... and of its source                  */
-                    const bool isFar = mt[u].y >= kNear;
                     const uint32_t d0 = uni(da[u]);       /* first byte of the chunk               */
                     actv[u] = a;
-                    farv[u] = isFar;
-                    pendv[u] = a && !isFar && ra[u] >= d0;
-                    /* unconditional load: lanes without a far byte read the first byte of the block */
-                    xf[u] = w.dst[(a && isFar) ? ra[u] : 0u];
+                    pendv[u] = a && ra[u] >= d0;
                 }
             }
 #pragma unroll
@@ -330,8 +349,7 @@ __device__ inline void seq_copy(Wave<R> &w, const SeqLds<R> &L, const uint32_t n
                     st.chunks++;
                     uint8_t *dp = &L.ring[da[u] & (R - 1u)];
                     const uint8_t *sp = &L.ring[ra[u] & (R - 1u)];
-                    uint32_t x = *sp;
-                    if (farv[u]) x = xf[u];
+                    const uint32_t x = *sp;
                     if (actv[u]) *dp = (uint8_t)x;
                     /* a source inside this chunk's own span may not be written yet (or be a literal, which is):
                      * everything below the first pending byte is final, so a pending byte whose source lies below
@@ -352,8 +370,7 @@ __device__ inline void seq_copy(Wave<R> &w, const SeqLds<R> &L, const uint32_t n
         }
     }
     stamp(st, 6);
-    w.op = op0 + T;
-    w.flush();
+    w.op = op0 + T; /* flushed by the next batch (or the general path), together with its own requests */
 }
 
 /*
@@ -371,8 +388,18 @@ __device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const SeqLds<R> &L, uint32_
     const uint32_t vsafe = vend - 16u;
     if (vp + 64u > vsafe || w.op + 64u > B) return 0;
     stamp(st, 7);
-    while (w.in_hi < vend && w.in_hi < vp + kSeqWin) w.refill();
+    /* Vector-memory operations of a batch, in issue order: [start] none -- the staging below only writes chunks that
+     * were requested in the middle of the previous batch -- then, once the batch is decoded: the output stores of
+     * the previous batch, the next input chunks, the next batch's index entries, this batch's far sources.  The one
+     * wait that follows them (the far sources, seq_copy) comes after the literal copy.  vmcnt counts in order, so a
+     * request issued just before a wait is a full trip to memory on the wave's critical path: with the requests
+     * at the end of a batch and the waits at its start, 32 % of the wave's cycles were that. */
+    while (w.in_hi < vend && w.in_hi < vp + kSeqWin) w.refill_deferred();
     LDS_FENCE();
+    /* 16-byte literal reads may start in the ring's last 15 bytes: keep a copy of its first 16 behind it */
+    uint2 mir = make_uint2(0, 0);
+    if (lane < 2u) mir = *reinterpret_cast<const uint2 *>(L.in + lane * 8u);
+    else if (lane < 4u) mir = *reinterpret_cast<const uint2 *>(L.ring + (lane - 2u) * 8u); /* the output ring likewise */
     stamp(st, 0);
     /* positions: the row holds the low 16 bits of the offset in the compressed block; a batch spans < 64 KiB */
     const uint32_t pos = vp + ((epos + w.delta - vp) & 0xffffu);
@@ -388,6 +415,8 @@ __device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const SeqLds<R> &L, uint32_
     const uint32_t rq = inwin ? q : vp;
     const uint32_t off = (uint32_t)L.in[rq & kInMask] | ((uint32_t)L.in[(rq + 1u) & kInMask] << 8);
     const uint32_t e2 = L.in[(rq + 2u) & kInMask];
+    if (lane < 2u) *reinterpret_cast<uint2 *>(L.in + kInRing + lane * 8u) = mir;
+    else if (lane < 4u) *reinterpret_cast<uint2 *>(L.ring + R + (lane - 2u) * 8u) = mir;
     uint32_t ml = (t & 15u) + 4u;
     uint32_t dlen = k + ll + 2u;
     const bool hasM = (t & 15u) == 15u;
@@ -400,18 +429,33 @@ __device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const SeqLds<R> &L, uint32_
      * next lane's starts (the last candidate needs no successor) */
     const uint32_t npos = lane_next(pos);
     const bool chain = (lane == 0u ? pos == vp : true) && (lane + 1u >= navail || lane == 63u || npos == pos + dlen);
+    /* far matches (source older than the ring can still hold when the batch is done; already flushed): two 16-byte
+     * requests per lane */
+    constexpr uint32_t kNear = R - kT2;
+    const bool isfar = cand && off >= kNear;
     const bool ok = cand && inwin && chain && !(t >= 0xf0u && e1 == 255u) && !(hasM && e2 == 255u) && off >= ml && off <= mabs &&
-                    pos + dlen <= vsafe && oend <= kT2 && w.op + oend + 16u <= B;
+                    pos + dlen <= vsafe && oend <= kT2 && w.op + oend + 16u <= B && !(isfar && ml > 32u);
     const unsigned long long badmask = __ballot(!ok);
     const uint32_t nseq = badmask ? ctz64(badmask) : 64u;
+    stamp(st, 1);
+    w.flush();   /* what earlier batches produced; far sources below are read back from it */
+    stamp(st, 2);
+    w.top_up();
     if (nseq == 0u) return 0;
     const uint32_t T = lane_get(oend, nseq - 1u);
     const uint32_t used = lane_get(pos + dlen, nseq - 1u) - vp;
     /* the next batch's positions are requested now: their trip to memory hides behind this batch's copy */
     epre = 0;
     if (n0 + nseq + lane < ntab) epre = trow[n0 + nseq + lane];
+    /* ... and so are the sources of its far matches (flushed output: off >= T + 1023 behind a match) */
+    uint4 xfa = make_uint4(0, 0, 0, 0), xfb = xfa;
+    if (lane < nseq && isfar) {
+        const uint8_t *g = w.dst + (mabs - off);
+        __builtin_memcpy(&xfa, g, 16);
+        __builtin_memcpy(&xfb, g + 16, 16);
+    }
     stamp(st, 3);
-    seq_copy<R>(w, L, nseq, ostart, ll, ml, off, pos + k, T, st);
+    seq_copy<R>(w, L, nseq, ostart, ll, ml, off, pos + k, T, isfar, xfa, xfb, st);
     vp += used;
     stamp(st, 0);
     return nseq;
@@ -534,11 +578,9 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     Stats st = {};
     st.on = STATS;
     if (STATS) { st.ablate = (uint32_t)stats[7]; st.t0 = __builtin_amdgcn_s_memtime(); }
-    __shared__ __attribute__((aligned(R))) uint8_t s_ring[4][R];
-    __shared__ __attribute__((aligned(kInRing))) uint8_t s_in[4][kInRing];
-    __shared__ __attribute__((aligned(8))) uint2 s_lmeta[4][64];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][R + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[4][kInRing + 16];
     __shared__ __attribute__((aligned(8))) uint2 s_mmeta[4][64];
-    __shared__ __attribute__((aligned(8))) uint32_t s_lbm[4][kBmW + kNc];
     __shared__ __attribute__((aligned(8))) uint32_t s_mbm[4][kBmW + kNc];
 
     const uint32_t lane = threadIdx.x & 63u;
@@ -550,7 +592,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     const uint32_t csize = uni(src_size[blk]);
 
     Wave<R> w;
-    const SeqLds<R> L = {s_ring[wid], s_in[wid], s_lmeta[wid], s_mmeta[wid], s_lbm[wid], s_mbm[wid]};
+    const SeqLds<R> L = {s_ring[wid], s_in[wid], s_mmeta[wid], s_mbm[wid]};
     w.ring = L.ring;
     w.in = L.in;
     w.lane = lane;
@@ -570,6 +612,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     const uint16_t *trow = tbl + uni64(blk * (uint64_t)tbl_cap);
     const uint32_t ntab = uni(tbl_n[blk]);
     uint32_t n0 = 0; /* sequences decoded so far */
+    uint32_t poor = 0;
 
     if (!bad) {
         w.prefetch();
@@ -591,7 +634,11 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
                 n0 += n;
                 if (n == 0u) st.zero_batches++;
             } while (n >= 8u);
-            if (n < 4u) skip = 4u;
+            /* a batch stops in front of a sequence it cannot take (overlapping match, long run, end of block):
+             * that one goes through the general path and the batches resume.  Only data that keeps yielding
+             * short batches (runs of overlapping matches) stays on the general path for a while. */
+            poor = n < 4u ? poor + 1u : 0u;
+            if (poor >= 3u) { skip = 8u; poor = 0u; }
         } else {
             skip--;
         }
@@ -664,7 +711,7 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
                 h_st[0], h_st[1], h_st[2], h_st[3], h_st[4], h_st[5]);
         unsigned long long tot = 0;
         for (int k = 0; k < 8; k++) tot += h_st[8 + k];
-        static const char *nm[8] = {"stage+flush", "-", "-", "decode+validate", "spaces+bitmaps", "literal space", "match space", "general+other"};
+        static const char *nm[8] = {"stage", "decode+validate", "flush", "requests", "lane runs+bitmap", "-", "match space", "general+other"};
         for (int k = 0; k < 8; k++) fprintf(stderr, "[lz4 seq cycles] %-16s %5.1f%%\n", nm[k], 100.0 * (double)h_st[8 + k] / (double)(tot ? tot : 1));
         return hipGetLastError();
     }

@@ -46,7 +46,8 @@ struct Wave {
     uint32_t delta;       /* first byte = abase + delta                                */
     uint32_t vend;        /* delta + csize: end of stream in "virtual" positions       */
     uint32_t in_hi;       /* virtual position staged up to (multiple of kInChunk)      */
-    uint2 pre;            /* prefetched next chunk                                     */
+    uint2 pre, pre2, pre3; /* the next three chunks, on their way (a batch consumes up to three) */
+    uint32_t nstale;       /* trailing prefetch slots emptied by refill_deferred() and not requested again yet */
     /* output */
     uint8_t *dst;
     uint32_t op;      /* bytes produced      */
@@ -54,18 +55,46 @@ struct Wave {
     bool dst_aligned;
     uint32_t lane;
 
+    __device__ inline uint2 fetch(uint32_t at) const
+    {
+        const uint32_t o = at + lane * 8u;
+        uint2 v = make_uint2(0, 0);
+        if (o < vend) v = *reinterpret_cast<const uint2 *>(abase + o);
+        return v;
+    }
     __device__ inline void prefetch()
     {
-        const uint32_t o = in_hi + lane * 8u;
-        pre = make_uint2(0, 0);
-        if (o < vend) pre = *reinterpret_cast<const uint2 *>(abase + o);
+        pre = fetch(in_hi);
+        pre2 = fetch(in_hi + kInChunk);
+        pre3 = fetch(in_hi + 2u * kInChunk);
+        nstale = 0;
     }
-    /* write the prefetched chunk into the input ring, start fetching the one after */
+    /* write the oldest prefetched chunk into the input ring, start fetching the one after the others */
     __device__ inline void refill()
     {
         *reinterpret_cast<uint2 *>(in + ((in_hi + lane * 8u) & kInMask)) = pre;
         in_hi += kInChunk;
-        prefetch();
+        pre = pre2;
+        pre2 = pre3;
+        pre3 = fetch(in_hi + 2u * kInChunk);
+    }
+    /* the same without the new request (at most three times between two top_up() calls): a wave whose next
+     * wait on memory must not include a load issued a moment ago (vmcnt counts in order) stages at the start of
+     * a batch and requests in the middle of it */
+    __device__ inline void refill_deferred()
+    {
+        *reinterpret_cast<uint2 *>(in + ((in_hi + lane * 8u) & kInMask)) = pre;
+        in_hi += kInChunk;
+        pre = pre2;
+        pre2 = pre3;
+        nstale++;
+    }
+    __device__ inline void top_up()
+    {
+        if (nstale >= 3u) pre = fetch(in_hi);
+        if (nstale >= 2u) pre2 = fetch(in_hi + kInChunk);
+        if (nstale >= 1u) pre3 = fetch(in_hi + 2u * kInChunk);
+        nstale = 0;
     }
     /* keep at least 128 staged bytes ahead of virtual position vp (the chunk after that is
      * already on its way in `pre`) */

@@ -306,7 +306,7 @@ k_zstd_dec(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ sr
         w.dst_aligned = (reinterpret_cast<uintptr_t>(w.dst) & 15u) == 0;
         w.op = 0;
         w.flushed = 0;
-        w.delta = 0; w.abase = src; w.vend = 0; w.in_hi = 0; w.pre = make_uint2(0, 0);
+        w.delta = 0; w.abase = src; w.vend = 0; w.in_hi = 0; w.pre = make_uint2(0, 0); w.pre2 = make_uint2(0, 0); w.pre3 = make_uint2(0, 0); w.nstale = 0;
 
         bool bad = false;
         uint32_t ip = 0;

@@ -895,7 +895,7 @@ __global__ void __launch_bounds__(64) k_zexec(ZPipe P)
     w.dst_aligned = (reinterpret_cast<uintptr_t>(w.dst) & 15u) == 0;
     w.op = 0;
     w.flushed = 0;
-    w.delta = 0; w.abase = src; w.vend = 0; w.in_hi = 0; w.pre = make_uint2(0, 0);
+    w.delta = 0; w.abase = src; w.vend = 0; w.in_hi = 0; w.pre = make_uint2(0, 0); w.pre2 = make_uint2(0, 0); w.pre3 = make_uint2(0, 0); w.nstale = 0;
 
     bool bad = false;
     for (uint32_t k = 0; k < nblk; k++) {
