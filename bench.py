@@ -1,173 +1,154 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the cryo-block codec hot path on MI355X.
+"""bench.py -- benchmark of the cryo-block codec hot path on MI355X.
 
-Metric (BASELINE.json): uncompressed GB/s of LZ4 decompress over a batch of
-synthetic 128 KiB cryo blocks resident in HBM (configs[1]: 64k x 128 KiB on one
-GPU; weak scaling: every rank decodes its own 64k blocks, block i of the job
-belongs to rank i mod N, no collective on the data path).
+Metric (BASELINE.json): uncompressed GB/s over a batch of synthetic 128 KiB cryo blocks resident in HBM,
+bit-exact against liblz4 / libzstd.
 
-A "step" = one decode pass over the rank's whole batch (one kernel launch).
-Setup (untimed): blocks are generated on the device, compressed on the device
-by the bit-exact HIP LZ4 encoder, and a strided sample is verified against the
-CPU oracle; after the timed region every decoded block is compared on the
-device with its original.
+  --workload lz4_decode (default, headline)   LZ4 decompress.  N = 1: BASELINE configs[1], 65 536 blocks.
+                                              N > 1: configs[3], 1 Mi blocks over 8 GPUs = 131 072 blocks
+                                              per GPU (the same per-GPU share at N = 2, 4: weak scaling),
+                                              block i of the job on rank i mod N, no collective.
+  --workload zstd_decode                      same shape, zstd level --level
+  --workload lz4 | zstd                       compress + decompress of the batch (configs[2] shape)
+  --workload mixed                            configs[4]: even blocks zstd level 22 (streams made by the stock
+                                              library on the host, untimed: no GPU kernel encodes level 22),
+                                              odd blocks lz4 acceleration 50 (GPU encoder); decode of both
 
-Prints ONE JSON line on rank 0 (see the driver contract in the task).
+A "step" = one pass of the workload over the rank's whole batch.  Setup (untimed): blocks are generated on the
+device, compressed on the device by the bit-exact HIP encoder, and a strided sample is verified against the CPU
+oracle; after the timed region every decoded block is compared on the device with its original.
+
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (child
+processes, before anything touches the GPU) and relays rank 0's line; under torch.distributed.run it uses the
+ranks it is given.  Prints ONE JSON line on rank 0 (see the driver contract in the task).
 """
 import argparse
 import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "HBM3E peak BW"
+CONFIG4_TOTAL_BLOCKS = 1 << 20  # BASELINE.json configs[3]: 1 M x 128 KB blocks over 8 GPUs
 
 
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--blocks", type=int, default=65536, help="cryo blocks per GPU")
+    ap.add_argument("--steps", type=int, default=200, help="default: a timed region of about 2 s")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--blocks", type=int, default=0, help="cryo blocks per GPU (default: 65536 at N=1, 131072 at N>1, 16384 for mixed)")
     ap.add_argument("--block-size", type=int, default=131072)
     ap.add_argument("--dist", default="wide", choices=["wide", "narrow", "int4", "random", "zeros"])
     ap.add_argument("--accel", type=int, default=1, help="lz4 acceleration used to produce the inputs")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
+    ap.add_argument("--cpu-blocks", type=int, default=4096, help="distinct blocks of the cpu_baseline sample (SURVEY.md 8d)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="diagnostic ablation runs only: result is not valid")
-    ap.add_argument("--workload", default="lz4_decode", choices=["lz4_decode", "zstd_decode", "zstd", "lz4"],
-                    help="lz4_decode = headline (BASELINE configs[1]); zstd_decode = same shape for the zstd method; zstd / lz4 = compress+decompress of the same "
-                         "batch (configs[2] shape), a secondary measurement")
-    ap.add_argument("--level", type=int, default=1, help="zstd level for --workload zstd")
+    ap.add_argument("--workload", default="lz4_decode", choices=["lz4_decode", "zstd_decode", "zstd", "lz4", "mixed"])
+    ap.add_argument("--level", type=int, default=1, help="zstd level")
     return ap.parse_args()
 
 
-def cpu_baseline(comps, B, budget_s, method=0):
-    """cpu_baseline leg: the oracle ("port", 1 thread) and -- reported beside it -- the stock library the
-    reference links (reference compression.c:84/116 call shape), 1 thread and all cores, timed by
-    oracle/cpu_bench.c on this machine's host cores over the same sample of compressed blocks."""
-    import oracle_lib
-    ora = oracle_lib.Oracle()
-    fn = ora.L.cryo_oracle_cpu_decode_bench
+# ------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: start the ranks here, before any GPU / torch.cuda call in this process
+# ------------------------------------------------------------------------------------------------
+def self_launch(a):
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = p.wait() or rc
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    sys.exit(rc)
+
+
+# ------------------------------------------------------------------------------------------------
+# cpu_baseline: the library the reference links, on this machine's host cores
+# ------------------------------------------------------------------------------------------------
+def cpu_baseline(ora, np, method, encode, param, blobs, sizes, B, reps=5):
+    """One pass over the sample's distinct blocks, median of `reps`: stock liblz4 / libzstd called
+    exactly as reference compression.c:70-72,84,102-104,116 calls them, 1 thread (`value`) and all hardware threads
+    (`all_cores_value`); the oracle port's 1-thread rate beside it."""
+    fn = ora.L.cryo_oracle_cpu_pass_bench
     fn.restype = ctypes.c_double
-    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32,
-                   ctypes.c_uint32, ctypes.c_int, ctypes.c_double, ctypes.c_char_p, ctypes.c_size_t]
-    offs = np.zeros(len(comps), np.uint64)
+    fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                   ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    n = len(sizes)
+    offs = np.zeros(n, np.uint64)
     pos = 0
-    for i, c in enumerate(comps):
+    for i in range(n):
         offs[i] = pos
-        pos += (len(c) + 63) & ~63
+        pos += (int(sizes[i]) + 63) & ~63
     packed = np.zeros(pos + 64, np.uint8)
-    for i, c in enumerate(comps):
-        packed[int(offs[i]):int(offs[i]) + len(c)] = c
-    sizes = np.array([len(c) for c in comps], np.uint32)
+    for i in range(n):
+        packed[int(offs[i]):int(offs[i]) + int(sizes[i])] = blobs[i]
+    sz = np.asarray(sizes, np.uint32)
     ver = ctypes.create_string_buffer(64)
 
-    def run(stock, threads, secs):
-        return fn(method, stock, packed.ctypes.data, offs.ctypes.data, sizes.ctypes.data, len(comps), B, threads,
-                  secs, ver, 64)
-    name = "lz4" if method == 0 else "zstd"
-    v = run(0, 1, budget_s * 0.4)
-    res = {"value": round(v, 3), "unit": "GB/s", "cores": 1, "kind": "port",
-           "sample": "%d distinct compressed blocks (%.1f MiB uncompressed) decoded repeatedly for %.1f s by "
-                     "oracle/%s, 1 thread" % (len(comps), len(comps) * B / 2**20, budget_s * 0.4,
-                                              "lz4_oracle.c" if method == 0 else "zstd_dec_oracle.c")}
+    def run(stock, threads, r):
+        return fn(method, 1 if encode else 0, stock, param, packed.ctypes.data, offs.ctypes.data, sz.ctypes.data, n, B, threads, r,
+                  None, ver, 64)
     T = os.cpu_count() or 1
-    one = run(1, 1, budget_s * 0.25)
+    lib = "liblz4" if method == 0 else "libzstd"
+    call = {(0, False): "LZ4_decompress_safe(src,dst,csize,B)", (0, True): "LZ4_compress_fast(src,dst,B,bound,accel)",
+            (1, False): "ZSTD_decompress(dst,B,src,csize)", (1, True): "ZSTD_compress(dst,bound,src,B,level)"}[(method, encode)]
+    one = run(1, 1, reps)
+    port = run(0, 1, max(1, reps // 2))
+    res = {"unit": "GB/s", "cores": 1,
+           "sample": "%d distinct blocks (%.0f MiB uncompressed), one pass, median of %d" % (n, n * B / 2**20, reps)}
     if one > 0:
-        allc = run(1, T, budget_s * 0.35)
-        res["stock_lib%s" % name] = {"version": ver.value.decode(),
-                                     "call": "LZ4_decompress_safe(src,dst,csize,B)" if method == 0
-                                     else "ZSTD_decompress(dst,B,src,csize)",
-                                     "GBps_1_thread": round(one, 3), "GBps_all_threads": round(allc, 3), "threads": T}
+        allc = run(1, T, reps)
+        res.update({"value": round(one, 3), "kind": "reference", "library": "%s %s via dlopen (what the reference links, Makefile:5); %s"
+                    % (lib, ver.value.decode(), call), "all_cores_value": round(allc, 3), "threads": T,
+                    "port_value": round(port, 3)})
+    else:   # the stock library is not on this machine: the restatement is all there is
+        res.update({"value": round(port, 3), "kind": "port", "library": "oracle/ restatement (stock %s not loadable here)" % lib})
     return res
 
 
-def bench_roundtrip(a, codec, rank, world, barrier, torch, dist):
-    """secondary workload: compress + decompress of the rank's batch (BASELINE configs[2] shape)"""
-    from pg_cryogen_amd import METHOD_LZ4, METHOD_ZSTD, bound
-    from pg_cryogen_amd.codec import DIST_NAMES
-    import oracle_lib
-    method = METHOD_ZSTD if a.workload == "zstd" else METHOD_LZ4
-    param = a.level if method == METHOD_ZSTD else a.accel
-    B, n = a.block_size, a.blocks
-    dist_id = DIST_NAMES.index(a.dist)
-    stride = (bound(method, B) + 15) & ~15
-    d_raw, d_comp, d_out = codec.alloc(n * B), codec.alloc(n * stride), codec.alloc(n * B)
-    d_sizes, d_status, d_off, d_mis = codec.alloc(4 * n), codec.alloc(4 * n), codec.alloc(8 * n), codec.alloc(8)
-    codec.synth_batch(0, rank, n, B, dist_id, d_raw, block_step=world)
-    d_off.upload(np.arange(n, dtype=np.uint64) * np.uint64(stride))
-    enc_ms, dec_ms = [], []
-
-    def step(timed):
-        codec.timer_start()
-        codec.compress_batch(method, param, d_raw, B, B, n, d_comp, stride, d_sizes, d_status)
-        t1 = codec.timer_stop()
-        codec.timer_start()
-        codec.decompress_batch(method, d_comp, d_off, d_sizes, d_out, B, B, n, d_status)
-        t2 = codec.timer_stop()
-        if timed:
-            enc_ms.append(t1)
-            dec_ms.append(t2)
-    for _ in range(a.warmup):
-        step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step(True)
-    codec.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    assert (d_status.download(dtype=np.int32) == 0).all()
-    d_mis.memset(0)
-    codec.compare_batch(d_raw, B, d_out, B, B, n, d_mis)
-    codec.sync()
-    assert int(d_mis.download(dtype=np.uint64)[0]) == 0, "round trip mismatch"
-    sizes = d_sizes.download(dtype=np.uint32)
-    ora = oracle_lib.Oracle()
-    for i in sorted(set(list(range(0, n, max(1, n // 8)))[:8] + [n - 1])):
-        c = d_comp.download(int(sizes[i]), offset=i * stride)
-        raw = ora.synth(0, rank + i * world, B, dist_id)
-        exp = ora.zstd_compress(raw, param) if method == METHOD_ZSTD else ora.lz4_compress(raw, param)
-        assert np.array_equal(c, exp), "device encode differs from oracle at block %d" % i
-    t = torch.tensor([elapsed], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    if rank == 0:
-        comp_bytes = int(sizes.astype(np.uint64).sum())
-        e, d = float(np.mean(enc_ms)), float(np.mean(dec_ms))
-        algo = 2 * (n * B + comp_bytes)
-        print(json.dumps({
-            "metric": "%s_compress_plus_decompress_uncompressed_GBps" % a.workload,
-            "value": round(2 * n * world * B * a.steps / float(t[0]) / 1e9, 2), "unit": "GB/s", "n_gpus": world,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(float(t[0]) / a.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s param %d: compress + decompress %d x %d KiB synthetic cryo blocks per GPU"
-                                   % (a.workload, param, n, B // 1024), "distribution": a.dist,
-                       "compression_ratio": round(n * B / comp_bytes, 3),
-                       "encode_GBps": round(n * B / (e * 1e-3) / 1e9, 2), "decode_GBps": round(n * B / (d * 1e-3) / 1e9, 2),
-                       "bit_exact": "encode == oracle (libzstd 1.4.8 / liblz4 1.9.3 pinned) on sampled blocks; "
-                                    "decode == original on all blocks"},
-            "roofline": {"bound": "hbm", "achieved": round(algo / ((e + d) * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
-                         "unit": "GB/s", "frac": round(algo / ((e + d) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                         "traffic": None, "kernel": "encode+decode pair"}}), flush=True)
+def lookup_traffic(mname, n, B, dist, param):
+    """HBM bytes per launch from the PMC passes of the same workload (profiles/*_hbm_traffic.json), else None"""
+    try:
+        for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
+            if fn.endswith("_hbm_traffic.json"):
+                t = json.load(open(os.path.join(ROOT, "profiles", fn)))
+                wl = t.get("workload", {})
+                if (wl.get("method", "lz4"), wl.get("blocks_per_gpu"), wl.get("block_size"), wl.get("distribution"),
+                        wl.get("param", wl.get("lz4_acceleration"))) == (mname, n, B, dist, param):
+                    return t["traffic_bytes_per_launch"]
+    except OSError:
+        pass
+    return None
 
 
 def main():
     a = parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(a)   # does not return
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != a.gpus and world > 1:
-        a.gpus = world
+    if not a.blocks:
+        a.blocks = 16384 if a.workload == "mixed" else (65536 if world == 1 else CONFIG4_TOTAL_BLOCKS // 8)
 
+    import numpy as np
     import torch  # plumbing only: process group + device sync; loaded first so ONE HIP runtime is shared
     import torch.distributed as dist
     if world > 1:
@@ -181,7 +162,7 @@ def main():
     if have_cuda:
         torch.cuda.set_device(dev)
 
-    from pg_cryogen_amd import Codec, METHOD_LZ4, bound
+    from pg_cryogen_amd import Codec, METHOD_LZ4, METHOD_ZSTD, bound
     from pg_cryogen_amd.codec import DIST_NAMES
     import oracle_lib
 
@@ -194,125 +175,248 @@ def main():
     B, n = a.block_size, a.blocks
     dist_id = DIST_NAMES.index(a.dist)
     codec = Codec(dev)
-    if not a.workload.endswith("_decode"):
-        bench_roundtrip(a, codec, rank, world, barrier, torch, dist)
-        codec.close()
-        if world > 1:
-            dist.destroy_process_group()
-        return
-    from pg_cryogen_amd import METHOD_ZSTD
-    is_lz4 = a.workload == "lz4_decode"
-    method, param, mname = (METHOD_LZ4, a.accel, "lz4") if is_lz4 else (METHOD_ZSTD, a.level, "zstd")
-    stride = (bound(method, B) + 15) & ~15
-
-    # ---------------- setup (untimed) ----------------
-    d_raw = codec.alloc(n * B)
-    d_comp = codec.alloc(n * stride)
-    d_out = codec.alloc(n * B)
-    d_sizes, d_status = codec.alloc(4 * n), codec.alloc(4 * n)
-    d_off = codec.alloc(8 * n)
-    d_mis = codec.alloc(8)
-    # block i of the job lives on rank i mod N: this rank's k-th block is job block rank + k*N
-    # (pg_cryogen_amd/shard.py); every block of the job is distinct
-    job_block = lambda k: rank + k * world
-    codec.synth_batch(0, rank, n, B, dist_id, d_raw, block_step=world)
-    codec.timer_start()
-    codec.compress_batch(method, param, d_raw, B, B, n, d_comp, stride, d_sizes, d_status)
-    enc_ms = codec.timer_stop()
-    st = d_status.download(dtype=np.int32)
-    assert (st == 0).all(), "encode status"
-    sizes = d_sizes.download(dtype=np.uint32)
-    d_off.upload(np.arange(n, dtype=np.uint64) * np.uint64(stride))
-    comp_bytes = int(sizes.astype(np.uint64).sum())
-
-    # spot check vs the CPU oracle: strided sample of the device-encoded blocks
     ora = oracle_lib.Oracle()
-    sample_idx = sorted(set(list(range(0, n, max(1, n // 16)))[:16] + [n - 1]))
-    sample_comps = []
-    for i in sample_idx:
-        c = d_comp.download(int(sizes[i]), offset=i * stride)
-        raw = ora.synth(0, job_block(i), B, dist_id)
-        exp = ora.lz4_compress(raw, param) if is_lz4 else ora.zstd_compress(raw, param)
-        assert np.array_equal(c, exp), "device encode differs from oracle at block %d" % i
-        sample_comps.append(c)
-    # cpu_baseline sample: 512 device-encoded blocks (64 MiB uncompressed), enough for every host thread
-    cpu_idx = list(range(0, n, max(1, n // 512)))[:512]
-    cpu_comps = [d_comp.download(int(sizes[i]), offset=i * stride) for i in cpu_idx] if (world == 1 and not a.no_cpu_baseline) else []
+    job_block = lambda k: rank + k * world   # block i of the job lives on rank i mod N (pg_cryogen_amd/shard.py)
+    want_cpu = world == 1 and not a.no_cpu_baseline
+    bufs = []
 
-    def step():
-        codec.decompress_batch(method, d_comp, d_off, d_sizes, d_out, B, B, n, d_status)
+    def alloc(nbytes):
+        b = codec.alloc(nbytes)
+        bufs.append(b)
+        return b
 
-    for _ in range(a.warmup):
-        step()
-    codec.sync()
+    def max_over_ranks(x):
+        t = torch.tensor([x], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t[0])
 
-    # ---------------- timed region ----------------
-    barrier()
-    t0 = time.perf_counter()
-    kernel_ms = []
-    for _ in range(a.steps):
-        codec.timer_start()          # HIP events on the codec's own stream
-        step()
-        kernel_ms.append(codec.timer_stop())
-    codec.sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    def oracle_encode(method, param, k):
+        raw = ora.synth(0, job_block(k), B, dist_id)
+        return ora.zstd_compress(raw, param) if method == METHOD_ZSTD else ora.lz4_compress(raw, param)
 
-    # ---------------- verification (untimed) ----------------
-    st = d_status.download(dtype=np.int32)
-    assert a.no_verify or (st == 0).all(), "decode status"
-    d_mis.memset(0)
-    codec.compare_batch(d_raw, B, d_out, B, B, n, d_mis)
-    codec.sync()
-    mismatch = int(d_mis.download(dtype=np.uint64)[0])
-    assert a.no_verify or mismatch == 0, "decoded blocks differ from originals: %d" % mismatch
+    d_raw = alloc(n * B)
+    d_out = alloc(n * B)
+    d_status, d_mis = alloc(4 * n), alloc(8)
+    codec.synth_batch(0, rank, n, B, dist_id, d_raw, block_step=world)
+    ncpu = min(a.cpu_blocks, n)
+    cpu_idx = list(range(0, n, max(1, n // ncpu)))[:ncpu]
 
-    t = torch.tensor([elapsed], dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t[0])
+    base = {"n_gpus": world, "steps": a.steps, "warmup": a.warmup, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic"}
 
-    if rank == 0:
-        total_blocks = n * world
-        value = total_blocks * B * a.steps / elapsed / 1e9
-        avg_ms = float(np.mean(kernel_ms))
-        algo_bytes = comp_bytes + n * B        # per launch: compressed bytes read + B written per block
-        achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
-        traffic = None   # HBM bytes per launch from the PMC passes of the same workload (profiles/)
-        try:
-            for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
-                if fn.endswith("_hbm_traffic.json"):
-                    t = json.load(open(os.path.join(ROOT, "profiles", fn)))
-                    wl = t.get("workload", {})
-                    if (wl.get("method", "lz4"), wl.get("blocks_per_gpu"), wl.get("block_size"), wl.get("distribution"),
-                            wl.get("param", wl.get("lz4_acceleration"))) == (mname, n, B, a.dist, param):
-                        traffic = t["traffic_bytes_per_launch"]
-                        break
-        except OSError:
-            pass
-        out = {
-            "metric": "%s_decompress_uncompressed_GBps" % mname, "value": round(value, 2), "unit": "GB/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(elapsed / a.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "%s decompress %d x %d KiB synthetic cryo blocks per GPU" % (mname.upper(), n, B // 1024),
-                       "distribution": a.dist, "method": mname, "param": param, "block_size": B,
-                       "blocks_per_gpu": n, "sharding": "block i -> rank i mod N, no collective",
-                       "compression_ratio": round(n * B / comp_bytes, 3),
-                       "bit_exact": "encode == oracle on %d sampled blocks; decode == original on all %d blocks"
-                                    % (len(sample_idx), n),
-                       "setup_encode_GBps": round(n * B / (enc_ms * 1e-3) / 1e9, 2)},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                         "kernel": "k_lz4_dec_ring" if is_lz4 else "k_zplan+k_zhuf+k_zseq+k_zexec (one decode call)",
-                         "avg_launch_ms": round(avg_ms, 4),
-                         "algorithmic_bytes_per_launch": algo_bytes},
-        }
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cpu_comps, B, a.cpu_seconds, 0 if is_lz4 else 1)
-        print(json.dumps(out), flush=True)
+    def verify_all():
+        st = d_status.download(dtype=np.int32)
+        assert a.no_verify or (st == 0).all(), "decode status"
+        d_mis.memset(0)
+        codec.compare_batch(d_raw, B, d_out, B, B, n, d_mis)
+        codec.sync()
+        mismatch = int(d_mis.download(dtype=np.uint64)[0])
+        assert a.no_verify or mismatch == 0, "decoded blocks differ from originals: %d" % mismatch
 
-    for b in (d_raw, d_comp, d_out, d_sizes, d_status, d_off, d_mis):
+    # =============================== decode workloads (headline) ===============================
+    if a.workload.endswith("_decode"):
+        is_lz4 = a.workload == "lz4_decode"
+        method, param, mname = (METHOD_LZ4, a.accel, "lz4") if is_lz4 else (METHOD_ZSTD, a.level, "zstd")
+        stride = (bound(method, B) + 15) & ~15
+        d_comp, d_sizes, d_off = alloc(n * stride), alloc(4 * n), alloc(8 * n)
+        codec.timer_start()
+        codec.compress_batch(method, param, d_raw, B, B, n, d_comp, stride, d_sizes, d_status)
+        enc_ms = codec.timer_stop()
+        assert (d_status.download(dtype=np.int32) == 0).all(), "encode status"
+        sizes = d_sizes.download(dtype=np.uint32)
+        d_off.upload(np.arange(n, dtype=np.uint64) * np.uint64(stride))
+        comp_bytes = int(sizes.astype(np.uint64).sum())
+        sample_idx = sorted(set(list(range(0, n, max(1, n // 16)))[:16] + [n - 1]))
+        for i in sample_idx:   # spot check vs the CPU oracle
+            c = d_comp.download(int(sizes[i]), offset=i * stride)
+            assert np.array_equal(c, oracle_encode(method, param, i)), "device encode differs from oracle at block %d" % i
+        cpu_comps = [d_comp.download(int(sizes[i]), offset=i * stride) for i in cpu_idx] if want_cpu else []
+
+        def step():
+            codec.decompress_batch(method, d_comp, d_off, d_sizes, d_out, B, B, n, d_status)
+        for _ in range(a.warmup):
+            step()
+        codec.sync()
+        barrier()
+        t0 = time.perf_counter()
+        kernel_ms = []
+        for _ in range(a.steps):
+            codec.timer_start()          # HIP events on the codec's own stream
+            step()
+            kernel_ms.append(codec.timer_stop())
+        codec.sync()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        verify_all()
+        if rank == 0:
+            avg_ms = float(np.mean(kernel_ms))
+            algo_bytes = comp_bytes + n * B        # per decode call: compressed bytes read + B written per block
+            achieved = algo_bytes / (avg_ms * 1e-3) / 1e9
+            value = n * world * B * a.steps / elapsed / 1e9
+            out = dict(base, metric="%s_decompress_uncompressed_GBps" % mname, value=round(value, 2), unit="GB/s",
+                       ms_per_step=round(elapsed / a.steps * 1e3, 4), per_gpu_GBps=round(value / world, 2))
+            out["config"] = {"workload": "%s decompress %d x %d KiB synthetic cryo blocks per GPU" % (mname.upper(), n, B // 1024)
+                             + (" (BASELINE configs[1])" if (world == 1 and n == 65536 and is_lz4) else "")
+                             + (" (BASELINE configs[3]: 1 Mi blocks over 8 GPUs)" if (n * world == CONFIG4_TOTAL_BLOCKS and is_lz4) else ""),
+                             "distribution": a.dist, "method": mname, "param": param, "block_size": B,
+                             "blocks_per_gpu": n, "total_blocks": n * world, "sharding": "block i -> rank i mod N, no collective",
+                             "compression_ratio": round(n * B / comp_bytes, 3),
+                             "bit_exact": "encode == oracle on %d sampled blocks; decode == original on all %d blocks" % (len(sample_idx), n),
+                             "setup_encode_GBps": round(n * B / (enc_ms * 1e-3) / 1e9, 2)}
+            out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": lookup_traffic(mname, n, B, a.dist, param),
+                               "kernel": ("k_lz4_index + k_lz4_dec_seq (one decode call; below 12288 blocks: k_lz4_dec_ring)" if is_lz4
+                                          else "k_zplan+k_zhuf+k_zseq+k_zexec (one decode call)"),
+                               "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": algo_bytes}
+            if want_cpu:
+                out["cpu_baseline"] = cpu_baseline(ora, np, 0 if is_lz4 else 1, False, param, cpu_comps, [len(c) for c in cpu_comps], B)
+            print(json.dumps(out), flush=True)
+
+    # =============================== compress + decompress (configs[2]) ===============================
+    elif a.workload in ("lz4", "zstd"):
+        method, param, mname = (METHOD_ZSTD, a.level, "zstd") if a.workload == "zstd" else (METHOD_LZ4, a.accel, "lz4")
+        stride = (bound(method, B) + 15) & ~15
+        d_comp, d_sizes, d_off = alloc(n * stride), alloc(4 * n), alloc(8 * n)
+        d_off.upload(np.arange(n, dtype=np.uint64) * np.uint64(stride))
+        enc_ms, dec_ms = [], []
+
+        def step(timed):
+            codec.timer_start()
+            codec.compress_batch(method, param, d_raw, B, B, n, d_comp, stride, d_sizes, d_status)
+            t1 = codec.timer_stop()
+            codec.timer_start()
+            codec.decompress_batch(method, d_comp, d_off, d_sizes, d_out, B, B, n, d_status)
+            t2 = codec.timer_stop()
+            if timed:
+                enc_ms.append(t1)
+                dec_ms.append(t2)
+        steps = min(a.steps, 20) if a.steps == 200 else a.steps   # an encode pass is 10-50x a decode pass
+        for _ in range(min(a.warmup, 2)):
+            step(False)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(True)
+        codec.sync()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        verify_all()
+        sizes = d_sizes.download(dtype=np.uint32)
+        for i in sorted(set(list(range(0, n, max(1, n // 8)))[:8] + [n - 1])):
+            c = d_comp.download(int(sizes[i]), offset=i * stride)
+            assert np.array_equal(c, oracle_encode(method, param, i)), "device encode differs from oracle at block %d" % i
+        if rank == 0:
+            comp_bytes = int(sizes.astype(np.uint64).sum())
+            e, d = float(np.mean(enc_ms)), float(np.mean(dec_ms))
+            algo = 2 * (n * B + comp_bytes)
+            out = dict(base, steps=steps, metric="%s_compress_plus_decompress_uncompressed_GBps" % a.workload,
+                       value=round(2 * n * world * B * steps / elapsed / 1e9, 2), unit="GB/s",
+                       ms_per_step=round(elapsed / steps * 1e3, 3))
+            out["config"] = {"workload": "%s param %d: compress + decompress %d x %d KiB synthetic cryo blocks per GPU (BASELINE configs[2] shape)"
+                             % (a.workload, param, n, B // 1024), "distribution": a.dist, "blocks_per_gpu": n,
+                             "compression_ratio": round(n * B / comp_bytes, 3),
+                             "encode_GBps": round(n * B / (e * 1e-3) / 1e9, 2), "decode_GBps": round(n * B / (d * 1e-3) / 1e9, 2),
+                             "bit_exact": "encode == oracle (libzstd 1.4.8 / liblz4 1.9.3 pinned) on sampled blocks; decode == original on all blocks"}
+            out["roofline"] = {"bound": "hbm", "achieved": round(algo / ((e + d) * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": round(algo / ((e + d) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                               "traffic": lookup_traffic(mname + "_roundtrip", n, B, a.dist, param), "kernel": "encode + decode pair",
+                               "encode_frac": round((n * B + comp_bytes) / (e * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                               "decode_frac": round((n * B + comp_bytes) / (d * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                               "algorithmic_bytes_per_launch": algo}
+            if want_cpu:
+                m = 0 if method == METHOD_LZ4 else 1
+                comps = [d_comp.download(int(sizes[i]), offset=i * stride) for i in cpu_idx]
+                raws = [d_raw.download(B, offset=i * B) for i in cpu_idx]
+                dec = cpu_baseline(ora, np, m, False, param, comps, [len(c) for c in comps], B)
+                enc = cpu_baseline(ora, np, m, True, param, raws, [B] * len(raws), B, reps=3)
+                # flat keys: the pair rate of the host doing both passes, 1 thread and all threads
+                pair = lambda x, y: round(2.0 / (1.0 / x + 1.0 / y), 3)
+                cb = {"unit": "GB/s", "cores": 1, "kind": dec["kind"], "sample": dec["sample"], "library": dec.get("library"),
+                      "value": pair(enc["value"], dec["value"]), "decode": dec, "encode": enc}
+                if "all_cores_value" in dec and "all_cores_value" in enc:
+                    cb["all_cores_value"] = pair(enc["all_cores_value"], dec["all_cores_value"])
+                    cb["threads"] = dec["threads"]
+                out["cpu_baseline"] = cb
+            print(json.dumps(out), flush=True)
+
+    # =============================== mixed batch (configs[4]) ===============================
+    else:
+        zl, acc = 22, 50
+        stride = (max(bound(METHOD_LZ4, B), bound(METHOD_ZSTD, B)) + 15) & ~15
+        ne, no = (n + 1) // 2, n // 2                     # even job slots: zstd level 22; odd: lz4 acceleration 50
+        # lz4 half: GPU encoder over the odd slots (strided view of d_raw)
+        d_lz, d_lzs, d_lzo, d_lzst = alloc(no * stride), alloc(4 * no), alloc(8 * no), alloc(4 * no)
+        # gather odd / even raw blocks on the host for the stock encoder and the strided GPU calls
+        T = os.cpu_count() or 1
+        raw_even = np.empty(ne * B, np.uint8)
+        for k in range(ne):
+            raw_even[k * B:(k + 1) * B] = d_raw.download(B, offset=(2 * k) * B)
+        zs = np.empty(ne * stride, np.uint8)
+        zsz = np.zeros(ne, np.uint32)
+        fn = ora.L.cryo_oracle_stock_compress_many
+        fn.restype = ctypes.c_int
+        fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_size_t,
+                       ctypes.c_void_p, ctypes.c_int]
+        t_host = time.perf_counter()
+        rc = fn(1, zl, raw_even.ctypes.data, ne, B, zs.ctypes.data, stride, zsz.ctypes.data, T)
+        t_host = time.perf_counter() - t_host
+        assert rc == 0, "stock libzstd level-22 encode failed (%d): libzstd.so.1 is needed for this workload" % rc
+        d_zs, d_zss, d_zso, d_zsst = alloc(ne * stride), alloc(4 * ne), alloc(8 * ne), alloc(4 * ne)
+        d_zs.upload(zs)
+        d_zss.upload(zsz)
+        d_zso.upload(np.arange(ne, dtype=np.uint64) * np.uint64(stride))
+        d_lzo.upload(np.arange(no, dtype=np.uint64) * np.uint64(stride))
+        # odd raw blocks start at d_raw + B with stride 2B
+        codec.timer_start()
+        codec._chk(codec.L.cryo_codec_compress_batch(codec.h, METHOD_LZ4, acc, d_raw.ptr + B, 2 * B, B, no, d_lz.ptr, stride, d_lzs.ptr, d_lzst.ptr), "compress_batch")
+        lz_enc_ms = codec.timer_stop()
+        assert (d_lzst.download(dtype=np.int32) == 0).all(), "lz4 encode status"
+        lzsz = d_lzs.download(dtype=np.uint32)
+        for k in (0, no // 2, no - 1):
+            c = d_lz.download(int(lzsz[k]), offset=k * stride)
+            assert np.array_equal(c, ora.lz4_compress(ora.synth(0, job_block(2 * k + 1), B, dist_id), acc)), "lz4 accel 50 encode differs from oracle"
+
+        def step():
+            codec._chk(codec.L.cryo_codec_decompress_batch(codec.h, METHOD_ZSTD, d_zs.ptr, d_zso.ptr, d_zss.ptr, d_out.ptr, 2 * B, B, ne, d_zsst.ptr), "decompress_batch")
+            codec._chk(codec.L.cryo_codec_decompress_batch(codec.h, METHOD_LZ4, d_lz.ptr, d_lzo.ptr, d_lzs.ptr, d_out.ptr + B, 2 * B, B, no, d_lzst.ptr), "decompress_batch")
+        steps = min(a.steps, 50) if a.steps == 200 else a.steps
+        for _ in range(min(a.warmup, 2)):
+            step()
+        codec.sync()
+        barrier()
+        t0 = time.perf_counter()
+        ms = []
+        for _ in range(steps):
+            codec.timer_start()
+            step()
+            ms.append(codec.timer_stop())
+        codec.sync()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        assert (d_zsst.download(dtype=np.int32) == 0).all() and (d_lzst.download(dtype=np.int32) == 0).all(), "decode status"
+        d_status.memset(0)
+        verify_all()
+        if rank == 0:
+            zbytes, lbytes = int(zsz.astype(np.uint64).sum()), int(lzsz.astype(np.uint64).sum())
+            algo = zbytes + lbytes + n * B
+            avg_ms = float(np.mean(ms))
+            out = dict(base, steps=steps, metric="mixed_zstd22_lz4a50_decompress_uncompressed_GBps",
+                       value=round(n * world * B * steps / elapsed / 1e9, 2), unit="GB/s", ms_per_step=round(elapsed / steps * 1e3, 3))
+            out["config"] = {"workload": "BASELINE configs[4]: mixed batch of %d x %d KiB blocks per GPU, even = zstd level 22, odd = lz4 acceleration 50; decode of both"
+                             % (n, B // 1024), "distribution": a.dist, "blocks_per_gpu": n,
+                             "ratio_zstd22": round(ne * B / zbytes, 3), "ratio_lz4_a50": round(no * B / lbytes, 3),
+                             "ratio_batch": round(n * B / (zbytes + lbytes), 3),
+                             "level22_encode": "stock libzstd on %d host threads, untimed (%.2f GB/s): no GPU kernel encodes zstd levels above 5" % (T, ne * B / t_host / 1e9),
+                             "lz4_a50_encode_GBps": round(no * B / (lz_enc_ms * 1e-3) / 1e9, 2),
+                             "bit_exact": "lz4 encode == oracle on sampled blocks; decode of both halves == original on all blocks"}
+            out["roofline"] = {"bound": "hbm", "achieved": round(algo / (avg_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                               "frac": round(algo / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
+                               "kernel": "zstd decode pipeline + lz4 decode (one step)", "avg_launch_ms": round(avg_ms, 4),
+                               "algorithmic_bytes_per_launch": algo}
+            print(json.dumps(out), flush=True)
+
+    for b in bufs:
         b.free()
     codec.close()
     if world > 1:

@@ -118,3 +118,167 @@ double cryo_oracle_cpu_decode_bench(int method, int stock, const uint8_t *base, 
     if (failed) return -2.0;
     return (double)total * (double)B / dt / 1e9;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * One pass over n DISTINCT blocks, repeated `reps` times, median pass time: thread t
+ * handles blocks i = t mod T with a private output buffer; a pass is timed from a common start to the
+ * last thread's finish.  direction 0 = decode (src = compressed blocks at off[i], size[i] bytes each),
+ * 1 = encode (src = raw blocks at off[i], B bytes each; `param` = lz4 acceleration / zstd level).
+ * stock = 1: the library the reference links, called as reference compression.c:70-72,84,102-104,116
+ * does; stock = 0: this repo's restatement (zstd: single-threaded, its context is static).
+ * Returns uncompressed GB/s (1e9) or a negative value: -1 library missing, -2 wrong result.
+ * ------------------------------------------------------------------------------------------------ */
+typedef int (*lz4_enc_fn)(const char *, char *, int, int, int);
+typedef size_t (*zstd_enc_fn)(void *, size_t, const void *, size_t, int);
+
+typedef struct {
+    const uint8_t *base;
+    const uint64_t *off;
+    const uint32_t *size;
+    uint32_t n, B;
+    int t, T, method, stock, encode, param, reps;
+    lz4_dec_fn lz4d; zstd_dec_fn zstdd; lz4_enc_fn lz4e; zstd_enc_fn zstde;
+    pthread_barrier_t *bar;
+    double *pass_s; /* written by thread 0 */
+    uint64_t out_bytes;
+    int failed;
+} job2;
+
+static void *worker2(void *arg)
+{
+    job2 *j = arg;
+    const size_t cap = (size_t)j->B + (size_t)j->B / 128 + 1024;
+    uint8_t *out = malloc(cap);
+    int r;
+    if (!out) j->failed = 1;
+    for (r = 0; r < j->reps; r++) {
+        uint32_t i;
+        double t0;
+        pthread_barrier_wait(j->bar);
+        t0 = now();
+        for (i = (uint32_t)j->t; out && i < j->n; i += (uint32_t)j->T) {
+            const uint8_t *src = j->base + j->off[i];
+            long res;
+            if (!j->encode) {
+                if (j->stock) res = j->method == 0 ? (long)j->lz4d((const char *)src, (char *)out, (int)j->size[i], (int)j->B)
+                                                   : (long)j->zstdd(out, j->B, src, j->size[i]);
+                else res = j->method == 0 ? cryo_oracle_lz4_decompress(src, j->size[i], out, j->B)
+                                          : cryo_oracle_zstd_decompress(src, j->size[i], out, j->B);
+                if (res != (long)j->B) j->failed = 1;
+            } else {
+                if (j->stock) res = j->method == 0 ? (long)j->lz4e((const char *)src, (char *)out, (int)j->B, (int)cap, j->param)
+                                                   : (long)j->zstde(out, cap, src, j->B, j->param);
+                else res = j->method == 0 ? (long)cryo_oracle_lz4_compress(src, j->B, out, cap, j->param)
+                                          : (long)cryo_oracle_zstd_compress(src, j->B, out, cap, j->param);
+                if (res <= 0 || (size_t)res > cap) j->failed = 1;
+                if (r == 0) j->out_bytes += (uint64_t)res;
+            }
+        }
+        pthread_barrier_wait(j->bar);
+        if (j->t == 0) j->pass_s[r] = now() - t0;
+    }
+    free(out);
+    return NULL;
+}
+
+static int cmp_double(const void *a, const void *b) { return (*(const double *)a > *(const double *)b) - (*(const double *)a < *(const double *)b); }
+
+double cryo_oracle_cpu_pass_bench(int method, int encode, int stock, int param, const uint8_t *base, const uint64_t *off,
+                                  const uint32_t *size, uint32_t n, uint32_t B, int threads, int reps,
+                                  uint64_t *out_bytes, char *version, size_t version_cap)
+{
+    job2 proto;
+    pthread_t *th;
+    job2 *jobs;
+    pthread_barrier_t bar;
+    double *pass_s, med;
+    int t, failed = 0;
+    memset(&proto, 0, sizeof proto);
+    if (version && version_cap) version[0] = 0;
+    if (threads < 1) threads = 1;
+    if (reps < 1) reps = 1;
+    if (stock) {
+        void *h = dlopen(method == 0 ? "liblz4.so.1" : "libzstd.so.1", RTLD_NOW);
+        const char *(*ver)(void);
+        if (!h) return -1.0;
+        if (method == 0) {
+            proto.lz4d = (lz4_dec_fn)dlsym(h, "LZ4_decompress_safe");
+            proto.lz4e = (lz4_enc_fn)dlsym(h, "LZ4_compress_fast");
+            ver = (const char *(*)(void))dlsym(h, "LZ4_versionString");
+            if (!proto.lz4d || !proto.lz4e) return -1.0;
+        } else {
+            proto.zstdd = (zstd_dec_fn)dlsym(h, "ZSTD_decompress");
+            proto.zstde = (zstd_enc_fn)dlsym(h, "ZSTD_compress");
+            ver = (const char *(*)(void))dlsym(h, "ZSTD_versionString");
+            if (!proto.zstdd || !proto.zstde) return -1.0;
+        }
+        if (ver && version) strncpy(version, ver(), version_cap - 1);
+    } else if (method != 0 && threads > 1) {
+        threads = 1;
+    }
+    th = calloc((size_t)threads, sizeof *th);
+    jobs = calloc((size_t)threads, sizeof *jobs);
+    pass_s = calloc((size_t)reps, sizeof *pass_s);
+    if (!th || !jobs || !pass_s) return -1.0;
+    pthread_barrier_init(&bar, NULL, (unsigned)threads);
+    for (t = 0; t < threads; t++) {
+        jobs[t] = proto;
+        jobs[t].base = base; jobs[t].off = off; jobs[t].size = size; jobs[t].n = n; jobs[t].B = B;
+        jobs[t].t = t; jobs[t].T = threads; jobs[t].method = method; jobs[t].stock = stock; jobs[t].encode = encode;
+        jobs[t].param = param; jobs[t].reps = reps; jobs[t].bar = &bar; jobs[t].pass_s = pass_s;
+        pthread_create(&th[t], NULL, worker2, &jobs[t]);
+    }
+    if (out_bytes) *out_bytes = 0;
+    for (t = 0; t < threads; t++) {
+        pthread_join(th[t], NULL);
+        failed |= jobs[t].failed;
+        if (out_bytes) *out_bytes += jobs[t].out_bytes;
+    }
+    pthread_barrier_destroy(&bar);
+    qsort(pass_s, (size_t)reps, sizeof *pass_s, cmp_double);
+    med = pass_s[reps / 2];
+    free(th); free(jobs); free(pass_s);
+    if (failed) return -2.0;
+    return (double)n * (double)B / med / 1e9;
+}
+
+/* stock-library compression of n raw blocks with T threads into fixed-stride slots (bench.py's mixed workload:
+ * zstd level-22 streams are produced on the host, untimed) */
+typedef struct { const uint8_t *src; uint8_t *dst; uint32_t *csize; uint32_t n, B; size_t stride; int t, T, method, param; lz4_enc_fn lz4e; zstd_enc_fn zstde; int failed; } job3;
+static void *worker3(void *arg)
+{
+    job3 *j = arg;
+    uint32_t i;
+    for (i = (uint32_t)j->t; i < j->n; i += (uint32_t)j->T) {
+        long r = j->method == 0 ? (long)j->lz4e((const char *)(j->src + (size_t)i * j->B), (char *)(j->dst + (size_t)i * j->stride), (int)j->B, (int)j->stride, j->param)
+                                : (long)j->zstde(j->dst + (size_t)i * j->stride, j->stride, j->src + (size_t)i * j->B, j->B, j->param);
+        if (r <= 0 || (size_t)r > j->stride) { j->failed = 1; r = 0; }
+        j->csize[i] = (uint32_t)r;
+    }
+    return NULL;
+}
+int cryo_oracle_stock_compress_many(int method, int param, const uint8_t *src, uint32_t n, uint32_t B, uint8_t *dst, size_t stride,
+                                    uint32_t *csize, int threads)
+{
+    void *h = dlopen(method == 0 ? "liblz4.so.1" : "libzstd.so.1", RTLD_NOW);
+    pthread_t *th;
+    job3 *jobs;
+    int t, failed = 0;
+    if (!h) return -1;
+    if (threads < 1) threads = 1;
+    th = calloc((size_t)threads, sizeof *th);
+    jobs = calloc((size_t)threads, sizeof *jobs);
+    if (!th || !jobs) return -1;
+    for (t = 0; t < threads; t++) {
+        job3 *j = &jobs[t];
+        j->src = src; j->dst = dst; j->csize = csize; j->n = n; j->B = B; j->stride = stride; j->t = t; j->T = threads;
+        j->method = method; j->param = param;
+        j->lz4e = (lz4_enc_fn)dlsym(h, "LZ4_compress_fast");
+        j->zstde = (zstd_enc_fn)dlsym(h, "ZSTD_compress");
+        if ((method == 0 && !j->lz4e) || (method != 0 && !j->zstde)) return -1;
+        pthread_create(&th[t], NULL, worker3, j);
+    }
+    for (t = 0; t < threads; t++) { pthread_join(th[t], NULL); failed |= jobs[t].failed; }
+    free(th); free(jobs);
+    return failed ? -2 : 0;
+}

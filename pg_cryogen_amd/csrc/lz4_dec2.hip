@@ -80,98 +80,132 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     uint32_t pos = delta;        /* next byte to interpret */
     uint32_t requested = 0;      /* chunks requested up to here (multiple of kIdxChunk) */
     uint32_t filled = 0;         /* chunks stored in the ring up to here */
-    bool inflight = false;       /* a chunk of this lane is on its way and still wanted */
+    uint32_t outst = 0, drop = 0; /* chunks of this lane on their way; how many of them a restart of the ring disowned */
     uint32_t state = 0;          /* 0 token, 1 literal-length extension, 2 match-length extension */
     uint32_t acc = 0, tm = 0;    /* literal length being accumulated; match nibble of the current token */
     uint32_t k = 0;
     unsigned long long pack = 0;
     bool done = !owner || vend == delta;
 
-    /* chunks on their way: one per turn, committed a round later (separate variables, not an array: the
-     * compiler kept an indexed array in scratch memory) */
-    uint4 fd0 = make_uint4(0, 0, 0, 0), fd1 = fd0, fd2 = fd0, fd3 = fd0;
-    uint32_t fa0 = 0, fa1 = 0, fa2 = 0, fa3 = 0;
-    bool fp0 = false, fp1 = false, fp2 = false, fp3 = false;
+    /* what this lane serves in turn j: one 16-byte piece of the next chunk of block s = 8j + (lane >> 3) */
+    const uint32_t piece16 = (lane & 7u) * 16u;
+    uint64_t saoff[4];
+    uint32_t svend[4];
+#pragma unroll
+    for (uint32_t j = 0; j < 4u; j++) {
+        const uint32_t s = 8u * j + (lane >> 3);
+        saoff[j] = ((uint64_t)bperm((uint32_t)(aoff >> 32), s) << 32) | bperm((uint32_t)aoff, s);
+        svend[j] = bperm(vend, s);
+    }
+    const uint32_t rb = (lane & (kIdxLanes - 1u)) * kIdxStride; /* this lane's ring inside s_ring */
 
-    auto turn = [&](const uint32_t j, uint4 &fd, uint32_t &fa, bool &fp) __attribute__((always_inline)) {
+    /* chunks on their way: one per turn, committed FOUR rounds later -- a chunk's trip to memory took ~2 us under
+     * this load (measured: with one round of distance every turn waited for it, 1050 cycles a turn), and a lane
+     * with room in its ring requests one chunk per round, up to four outstanding.  Sixteen separate variables,
+     * not arrays: the compiler kept an indexed array in scratch memory. */
+#define IDX_SLOT(n) uint4 fd##n = make_uint4(0, 0, 0, 0); uint32_t fa##n = 0; bool fp##n = false, fo##n = false;
+    IDX_SLOT(0) IDX_SLOT(1) IDX_SLOT(2) IDX_SLOT(3) IDX_SLOT(4) IDX_SLOT(5) IDX_SLOT(6) IDX_SLOT(7)
+    IDX_SLOT(8) IDX_SLOT(9) IDX_SLOT(10) IDX_SLOT(11) IDX_SLOT(12) IDX_SLOT(13) IDX_SLOT(14) IDX_SLOT(15)
+#undef IDX_SLOT
+
+    auto turn = [&](const uint32_t j, uint4 &fd, uint32_t &fa, bool &fp, bool &fpo, const uint64_t soff, const uint32_t sve) __attribute__((always_inline)) {
         const bool myturn = (lane >> 3) == j; /* lanes 8j..8j+7 (owners: lane < 32) */
         /* ---- commit the chunks requested one round ago ---- */
         if (fp) *reinterpret_cast<uint4 *>(s_ring + fa) = fd;
-        if (myturn && inflight) { filled += kIdxChunk; inflight = false; }
-        /* ---- request the next chunk of blocks 8j..8j+7 ---- */
+        if (myturn && outst != 0u && fpo) { /* fpo: this lane did request in the turn being committed */
+            outst--;
+            if (drop != 0u) drop--; else filled += kIdxChunk;
+        }
+        /* ---- request the next chunk of blocks 8j..8j+7 (one bpermute: requested | want) ---- */
         {
             const bool want = myturn && !done && requested < vend && pos + (kIdxRing - kIdxChunk) >= requested;
-            const uint32_t req_old = requested;
-            if (want) { requested += kIdxChunk; inflight = true; }
-            const uint32_t s = 8u * j + (lane >> 3), piece = lane & 7u;
-            const uint32_t w_s = bperm(want ? 1u : 0u, s), r_s = bperm(req_old, s), ve_s = bperm(vend, s);
-            const uint32_t lo_s = bperm((uint32_t)aoff, s), hi_s = bperm((uint32_t)(aoff >> 32), s);
-            const uint32_t o = r_s + 16u * piece;
-            const bool ld = w_s != 0u && o < ve_s;
-            fp = w_s != 0u;
-            fa = s * kIdxStride + (o & (kIdxRing - 1u));
+            const uint32_t msg = requested | (want ? 1u : 0u);
+            fpo = want;
+            if (want) { requested += kIdxChunk; outst++; }
+            const uint32_t m_s = bperm(msg, 8u * j + (lane >> 3));
+            const uint32_t o = (m_s & ~1u) + piece16;
+            fp = (m_s & 1u) != 0u;
+            const bool ld = fp && o < sve;
+            fa = (8u * j + (lane >> 3)) * kIdxStride + (o & (kIdxRing - 1u));
             /* always one load per turn (a lane with nothing to fetch re-reads its block's first 16 bytes): with a
              * fixed number of vector-memory operations per turn the compiler can wait for exactly the chunk it
              * commits (vmcnt(N)); a conditional load made it drain the queue once per round (2.3 us a round) */
-            const uint64_t ga = (((uint64_t)hi_s << 32) | lo_s) + (ld ? o : 0u);
-            fd = *reinterpret_cast<const uint4 *>(src_base + ga);
+            fd = *reinterpret_cast<const uint4 *>(src_base + (soff + (ld ? o : 0u)));
         }
-        /* ---- one hop ---- */
-        if (!done) {
-            if (pos >= vend) {
-                done = true;
-            } else if (pos >= requested) {
-                /* jumped over everything requested (a long literal run): restart the ring at the chunk of pos;
-                 * a chunk still in flight lands in a slot that is rewritten before it is read */
-                requested = filled = pos & ~(kIdxChunk - 1u);
-                inflight = false;
-            } else if (pos + 8u <= filled || filled >= vend) {
-                const uint32_t w0 = *reinterpret_cast<const uint32_t *>(ring + (pos & (kIdxRing - 4u)));
-                const uint32_t w1 = *reinterpret_cast<const uint32_t *>(ring + ((pos + 4u) & (kIdxRing - 4u)));
-                const uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, pos & 3u);
-                uint32_t q = 0;       /* position after the literals, when they are known */
-                bool lit_done = false;
-                if (state == 0u) {
-                    pack = (pack >> 16) | ((unsigned long long)((pos - delta) & 0xffffu) << 48);
-                    k++;
-                    const uint32_t t = x & 255u, e1 = (x >> 8) & 255u;
-                    tm = t & 15u;
-                    const uint32_t ll = t >> 4;
-                    if (ll == 15u && e1 == 255u) { state = 1u; acc = 15u + 255u; pos += 2u; }
-                    else { q = pos + 1u + ll + (ll == 15u ? e1 + 1u : 0u); lit_done = true; }
-                } else {
-                    const uint32_t nx = ~x;
-                    const uint32_t n = nx ? (uint32_t)__builtin_ctz(nx) >> 3 : 4u; /* leading 0xFF bytes */
-                    if (state == 1u) {
+        /* ---- one hop, branch-free for the two common states (token, match-length extension) ---- */
+        {
+            const bool live = !done && pos < vend;
+            const bool canread = pos < requested && (pos + 8u <= filled || filled >= vend);
+            const uint32_t w0 = *reinterpret_cast<const uint32_t *>(s_ring + rb + (pos & (kIdxRing - 4u)));
+            const uint32_t w1 = *reinterpret_cast<const uint32_t *>(s_ring + rb + ((pos + 4u) & (kIdxRing - 4u)));
+            const uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, pos & 3u);
+            const bool go = live && canread && state != 1u;
+            /* token */
+            const uint32_t ll = (x >> 4) & 15u, e1 = (x >> 8) & 255u, tmn = x & 15u;
+            const bool l15 = ll == 15u;
+            const uint32_t q2 = pos + 3u + ll + (l15 ? e1 + 1u : 0u);  /* behind the literals and the offset */
+            const bool tok = go && state == 0u;
+            const bool longlit = tok && l15 && e1 == 255u;            /* 255-run: slow path below */
+            /* match-length extension bytes */
+            const uint32_t nx = ~x;
+            const uint32_t n = nx ? (uint32_t)__builtin_ctz(nx) >> 3 : 4u; /* leading 0xFF bytes */
+            const uint32_t adv = n == 4u ? 4u : n + 1u;
+            const bool ext = go && state == 2u;
+            /* record + advance */
+            const bool rec = tok;
+            if (rec) {
+                pack = (pack >> 16) | ((unsigned long long)((pos - delta) & 0xffffu) << 48);
+                k++;
+                tm = tmn;
+            }
+            const bool fin = tok && !longlit && q2 > vend;              /* last sequence: literals only */
+            if (tok && !longlit && !fin) { pos = q2; state = tmn == 15u ? 2u : 0u; }
+            if (ext) { pos += adv; state = n == 4u ? 2u : 0u; }
+            if (longlit) { state = 1u; acc = 15u + 255u; pos += 2u; }
+            if (fin || (!done && !live) || k >= cap) done = true;
+            /* rare: literal-length 255-runs, and jumps over everything requested (a long literal run) */
+            const bool slow = !done && (state == 1u || pos >= requested) && !longlit;
+            if (__any(slow)) {
+                if (slow && pos < vend) {
+                    if (pos >= requested) {
+                        /* restart the ring at the chunk of pos; a chunk still in flight lands in a slot that is
+                         * rewritten before it is read */
+                        requested = filled = pos & ~(kIdxChunk - 1u);
+                        drop = outst;
+                    } else if (state == 1u && live && canread) {
                         if (n == 4u) { acc += 1020u; pos += 4u; if (acc >= vend) done = true; }
-                        else { acc += 255u * n + ((x >> (8u * n)) & 255u); q = pos + n + 1u + acc; lit_done = true; if (acc >= vend) done = true; }
-                    } else {
-                        pos += n == 4u ? 4u : n + 1u;
-                        if (n != 4u) state = 0u;
+                        else {
+                            acc += 255u * n + ((x >> (8u * n)) & 255u);
+                            const uint32_t q = pos + n + 1u + acc;
+                            if (acc >= vend || q + 2u > vend) done = true;
+                            else { pos = q + 2u; state = tm == 15u ? 2u : 0u; }
+                        }
                     }
                 }
-                if (lit_done && !done) {
-                    if (q + 2u > vend) done = true;                 /* last sequence: literals only */
-                    else { pos = q + 2u; state = tm == 15u ? 2u : 0u; }
-                }
-                if (k >= cap) done = true;
             }
         }
     };
 
-    while (__any(!done)) {
+    auto put = [&]() __attribute__((always_inline)) {
         /* the last four positions go out once per round (a lane gains at most four per round; re-writing older
          * entries with the same values is harmless): one unconditional store, see the note on the loads */
-        {
-            const uint32_t at = k >= 4u ? k - 4u : 0u;
-            const unsigned long long v = k >= 4u ? pack : (k ? pack >> (16u * (4u - k)) : 0ull);
-            __builtin_memcpy((owner ? row : dummy) + at, &v, 8);
-        }
-        turn(0u, fd0, fa0, fp0);
-        turn(1u, fd1, fa1, fp1);
-        turn(2u, fd2, fa2, fp2);
-        turn(3u, fd3, fa3, fp3);
+        const uint32_t at = k >= 4u ? k - 4u : 0u;
+        const unsigned long long v = k >= 4u ? pack : (k ? pack >> (16u * (4u - k)) : 0ull);
+        __builtin_memcpy((owner ? row : dummy) + at, &v, 8);
+    };
+#define IDX_ROUND(a, b, c, d)                                   \
+    put();                                                      \
+    turn(0u, fd##a, fa##a, fp##a, fo##a, saoff[0], svend[0]);   \
+    turn(1u, fd##b, fa##b, fp##b, fo##b, saoff[1], svend[1]);   \
+    turn(2u, fd##c, fa##c, fp##c, fo##c, saoff[2], svend[2]);   \
+    turn(3u, fd##d, fa##d, fp##d, fo##d, saoff[3], svend[3]);
+    while (__any(!done)) {
+        IDX_ROUND(0, 1, 2, 3)
+        IDX_ROUND(4, 5, 6, 7)
+        IDX_ROUND(8, 9, 10, 11)
+        IDX_ROUND(12, 13, 14, 15)
     }
+#undef IDX_ROUND
     if (owner) {
         const uint32_t at = k >= 4u ? k - 4u : 0u;
         const unsigned long long v = k >= 4u ? pack : (k ? pack >> (16u * (4u - k)) : 0ull);
