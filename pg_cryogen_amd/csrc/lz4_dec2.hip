@@ -47,7 +47,7 @@ namespace cryo {
  * latency is covered by four hops.  The walk is a small state machine per lane (token / literal-length
  * extension / match-length extension) so that one LDS read per hop serves every lane, whatever it is in.
  * --------------------------------------------------------------------------------------------- */
-constexpr uint32_t kIdxLanes = 32, kIdxRing = 512, kIdxStride = kIdxRing + 16 /* bank skew between rings */, kIdxChunk = 128;
+constexpr uint32_t kIdxLanes = 64, kIdxRing = 512, kIdxStride = kIdxRing + 16 /* bank skew between rings */, kIdxChunk = 128;
 
 __device__ inline uint32_t bperm(uint32_t v, uint32_t src_lane)
 {
@@ -62,7 +62,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[kIdxLanes * kIdxStride];
     const uint32_t lane = threadIdx.x;
     const uint64_t blk = (uint64_t)blockIdx.x * kIdxLanes + (lane & (kIdxLanes - 1u));
-    const bool owner = lane < kIdxLanes && blk < n_blocks;
+    const bool owner = blk < n_blocks;
     /* stream of this lane's block, in "virtual" positions: vp = delta + offset in the block, so that chunk
      * addresses are 16-byte aligned */
     uint64_t aoff = 0;
@@ -75,7 +75,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     }
     uint16_t *row = tbl + blk * cap;
     uint16_t *dummy = tbl + n_blocks * cap + lane * 4u; /* 8 bytes per lane behind the rows: where lanes without a block store */
-    if (!owner) aoff = src_off[0] & ~(uint64_t)15; /* lanes 32..63 only help with the loads; a lane past the end of the batch re-reads block 0 */
+    if (!owner) aoff = src_off[0] & ~(uint64_t)15; /* a lane past the end of the batch re-reads block 0 */
     uint8_t *ring = s_ring + (lane & (kIdxLanes - 1u)) * kIdxStride;
     uint32_t pos = delta;        /* next byte to interpret */
     uint32_t requested = 0;      /* chunks requested up to here (multiple of kIdxChunk) */
@@ -87,12 +87,13 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     unsigned long long pack = 0;
     bool done = !owner || vend == delta;
 
-    /* what this lane serves in turn j: one 16-byte piece of the next chunk of block s = 8j + (lane >> 3) */
+    /* what this lane serves in turn j: one 16-byte piece of the next chunk of blocks 16j + (lane >> 3) and
+     * 16j + 8 + (lane >> 3) (two loads per turn: every block has a turn every fourth hop) */
     const uint32_t piece16 = (lane & 7u) * 16u;
-    uint64_t saoff[4];
-    uint32_t svend[4];
+    uint64_t saoff[8];
+    uint32_t svend[8];
 #pragma unroll
-    for (uint32_t j = 0; j < 4u; j++) {
+    for (uint32_t j = 0; j < 8u; j++) {
         const uint32_t s = 8u * j + (lane >> 3);
         saoff[j] = ((uint64_t)bperm((uint32_t)(aoff >> 32), s) << 32) | bperm((uint32_t)aoff, s);
         svend[j] = bperm(vend, s);
@@ -103,15 +104,17 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
      * this load (measured: with one round of distance every turn waited for it, 1050 cycles a turn), and a lane
      * with room in its ring requests one chunk per round, up to four outstanding.  Sixteen separate variables,
      * not arrays: the compiler kept an indexed array in scratch memory. */
-#define IDX_SLOT(n) uint4 fd##n = make_uint4(0, 0, 0, 0); uint32_t fa##n = 0; bool fp##n = false, fo##n = false;
+#define IDX_SLOT(n) uint4 fd##n = make_uint4(0, 0, 0, 0), fe##n = fd##n; uint32_t fa##n = 0, fb##n = 0; bool fp##n = false, fq##n = false, fo##n = false;
     IDX_SLOT(0) IDX_SLOT(1) IDX_SLOT(2) IDX_SLOT(3) IDX_SLOT(4) IDX_SLOT(5) IDX_SLOT(6) IDX_SLOT(7)
     IDX_SLOT(8) IDX_SLOT(9) IDX_SLOT(10) IDX_SLOT(11) IDX_SLOT(12) IDX_SLOT(13) IDX_SLOT(14) IDX_SLOT(15)
 #undef IDX_SLOT
 
-    auto turn = [&](const uint32_t j, uint4 &fd, uint32_t &fa, bool &fp, bool &fpo, const uint64_t soff, const uint32_t sve) __attribute__((always_inline)) {
-        const bool myturn = (lane >> 3) == j; /* lanes 8j..8j+7 (owners: lane < 32) */
-        /* ---- commit the chunks requested one round ago ---- */
+    auto turn = [&](const uint32_t j, uint4 &fd, uint4 &fe, uint32_t &fa, uint32_t &fb, bool &fp, bool &fq, bool &fpo,
+                    const uint64_t soff, const uint32_t sve, const uint64_t soff2, const uint32_t sve2) __attribute__((always_inline)) {
+        const bool myturn = (lane >> 4) == j; /* lanes 16j..16j+15 */
+        /* ---- commit the chunks requested four rounds ago ---- */
         if (fp) *reinterpret_cast<uint4 *>(s_ring + fa) = fd;
+        if (fq) *reinterpret_cast<uint4 *>(s_ring + fb) = fe;
         if (myturn && outst != 0u && fpo) { /* fpo: this lane did request in the turn being committed */
             outst--;
             if (drop != 0u) drop--; else filled += kIdxChunk;
@@ -122,15 +125,18 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             const uint32_t msg = requested | (want ? 1u : 0u);
             fpo = want;
             if (want) { requested += kIdxChunk; outst++; }
-            const uint32_t m_s = bperm(msg, 8u * j + (lane >> 3));
-            const uint32_t o = (m_s & ~1u) + piece16;
-            fp = (m_s & 1u) != 0u;
-            const bool ld = fp && o < sve;
-            fa = (8u * j + (lane >> 3)) * kIdxStride + (o & (kIdxRing - 1u));
-            /* always one load per turn (a lane with nothing to fetch re-reads its block's first 16 bytes): with a
-             * fixed number of vector-memory operations per turn the compiler can wait for exactly the chunk it
+            const uint32_t s1 = 16u * j + (lane >> 3), s2 = s1 + 8u;
+            const uint32_t m1 = bperm(msg, s1), m2 = bperm(msg, s2);
+            const uint32_t o1 = (m1 & ~1u) + piece16, o2 = (m2 & ~1u) + piece16;
+            fp = (m1 & 1u) != 0u;
+            fq = (m2 & 1u) != 0u;
+            fa = s1 * kIdxStride + (o1 & (kIdxRing - 1u));
+            fb = s2 * kIdxStride + (o2 & (kIdxRing - 1u));
+            /* always two loads per turn (a lane with nothing to fetch re-reads its block's first 16 bytes): with a
+             * fixed number of vector-memory operations per turn the compiler can wait for exactly the chunks it
              * commits (vmcnt(N)); a conditional load made it drain the queue once per round (2.3 us a round) */
-            fd = *reinterpret_cast<const uint4 *>(src_base + (soff + (ld ? o : 0u)));
+            fd = *reinterpret_cast<const uint4 *>(src_base + (soff + ((fp && o1 < sve) ? o1 : 0u)));
+            fe = *reinterpret_cast<const uint4 *>(src_base + (soff2 + ((fq && o2 < sve2) ? o2 : 0u)));
         }
         /* ---- one hop, branch-free for the two common states (token, match-length extension) ---- */
         {
@@ -193,12 +199,10 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
         const unsigned long long v = k >= 4u ? pack : (k ? pack >> (16u * (4u - k)) : 0ull);
         __builtin_memcpy((owner ? row : dummy) + at, &v, 8);
     };
+#define IDX_TURN(j, n) turn(j, fd##n, fe##n, fa##n, fb##n, fp##n, fq##n, fo##n, saoff[2 * j], svend[2 * j], saoff[2 * j + 1], svend[2 * j + 1]);
 #define IDX_ROUND(a, b, c, d)                                   \
     put();                                                      \
-    turn(0u, fd##a, fa##a, fp##a, fo##a, saoff[0], svend[0]);   \
-    turn(1u, fd##b, fa##b, fp##b, fo##b, saoff[1], svend[1]);   \
-    turn(2u, fd##c, fa##c, fp##c, fo##c, saoff[2], svend[2]);   \
-    turn(3u, fd##d, fa##d, fp##d, fo##d, saoff[3], svend[3]);
+    IDX_TURN(0, a) IDX_TURN(1, b) IDX_TURN(2, c) IDX_TURN(3, d)
     while (__any(!done)) {
         IDX_ROUND(0, 1, 2, 3)
         IDX_ROUND(4, 5, 6, 7)
@@ -206,6 +210,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
         IDX_ROUND(12, 13, 14, 15)
     }
 #undef IDX_ROUND
+#undef IDX_TURN
     if (owner) {
         const uint32_t at = k >= 4u ? k - 4u : 0u;
         const unsigned long long v = k >= 4u ? pack : (k ? pack >> (16u * (4u - k)) : 0ull);
