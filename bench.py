@@ -266,7 +266,7 @@ def main():
                              "setup_encode_GBps": round(n * B / (enc_ms * 1e-3) / 1e9, 2)}
             out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": lookup_traffic(mname, n, B, a.dist, param),
-                               "kernel": ("k_lz4_index + k_lz4_dec_seq (one decode call; below 12288 blocks: k_lz4_dec_ring)" if is_lz4
+                               "kernel": ("k_lz4_index + k_lz4_dec_seq (one decode call; below 24576 blocks: k_lz4_dec_ring)" if is_lz4
                                           else "k_zplan+k_zhuf+k_zseq+k_zexec (one decode call)"),
                                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": algo_bytes}
             if want_cpu:

@@ -625,7 +625,7 @@ static uint64_t lz4_index_min_blocks()
      * in-wave parse it replaces.  CRYO_LZ4_INDEX_MIN overrides (0 = always, huge = never). */
     static const uint64_t v = [] {
         const char *e = getenv("CRYO_LZ4_INDEX_MIN");
-        return e ? strtoull(e, nullptr, 0) : 12288ull;
+        return e ? strtoull(e, nullptr, 0) : 24576ull;
     }();
     return v;
 }

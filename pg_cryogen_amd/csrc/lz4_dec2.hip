@@ -119,6 +119,9 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             outst--;
             if (drop != 0u) drop--; else filled += kIdxChunk;
         }
+        /* the hop's two ring reads go out before the exchange below: one LDS round trip per turn, not two */
+        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(s_ring + rb + (pos & (kIdxRing - 4u)));
+        const uint32_t w1 = *reinterpret_cast<const uint32_t *>(s_ring + rb + ((pos + 4u) & (kIdxRing - 4u)));
         /* ---- request the next chunk of blocks 8j..8j+7 (one bpermute: requested | want) ---- */
         {
             const bool want = myturn && !done && requested < vend && pos + (kIdxRing - kIdxChunk) >= requested;
@@ -142,8 +145,6 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
         {
             const bool live = !done && pos < vend;
             const bool canread = pos < requested && (pos + 8u <= filled || filled >= vend);
-            const uint32_t w0 = *reinterpret_cast<const uint32_t *>(s_ring + rb + (pos & (kIdxRing - 4u)));
-            const uint32_t w1 = *reinterpret_cast<const uint32_t *>(s_ring + rb + ((pos + 4u) & (kIdxRing - 4u)));
             const uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, pos & 3u);
             const bool go = live && canread && state != 1u;
             /* token */
@@ -261,8 +262,7 @@ __device__ inline void lane_runs(uint8_t *ring, const uint8_t *sbase, uint32_t r
             uint4 v = it == 0u ? xa : xb;
             if (!far) __builtin_memcpy(&v, sbase + (sv & SMASK), 16);
             const uint32_t di = dv & (R - 1u);
-            __builtin_memcpy(ring + di, &v.x, 8);
-            __builtin_memcpy(ring + di + 8u, &v.z, 8);
+            __builtin_memcpy(ring + di, &v, 16);
             if (di + 16u > R) spill = di + 16u - R;
             sv += 16u; dv += 16u; rem -= 16u;
             it++;

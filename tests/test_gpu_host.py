@@ -153,3 +153,51 @@ def test_c_host_batch_api_strides_and_statuses(codec, oracle):
                     assert st[i] != 0
                 else:
                     assert st[i] == 0 and np.array_equal(out[i * B:(i + 1) * B], raw[i * B:(i + 1) * B]), (name, B, i)
+
+
+def test_gpu_seqscan_read_ahead_through_hip_codec(HG):
+    """SURVEY.md 8f-3 on the device: cryo_scan_next_batch pops block starts in the reference's order
+    (scan_iterator.c:55-127), never offers continuation pages, and decodes K chains -- multi-page and
+    single-page, lz4 and zstd mixed in one table -- with one HIP codec call per method and batch."""
+    from test_host_plumbing import pack_rows
+    L, errors = HG
+    L.cryo_cache_configure(32)
+    rng = np.random.default_rng(5)
+    mem = L.cryo_memrel_create()
+    rel = host.CryoRel()
+    L.cryo_memrel_bind(mem, 7, C.byref(rel))
+    all_rows, firsts, methods = [], [], []
+    for b in range(11):
+        if b % 2:   # incompressible rows -> ~15-page chain
+            rows = [struct.pack("<i", 1000 * b + i) + rng.integers(0, 256, 400, dtype=np.uint8).tobytes() for i in range(290)]
+        else:
+            rows = [struct.pack("<i", 1000 * b + i) for i in range(290)]
+        blk = pack_rows(L, rows, 2 if b % 2 else 1, 131072)
+        assert len(blk) == 1
+        m = host.COMP_ZSTD if b % 3 == 0 else host.COMP_LZ4
+        fb = (C.c_uint32 * 1)(L.cryo_memrel_reserve(mem))
+        assert L.cryo_stage_write_batch(C.byref(rel), blk[0], 1, m, 5, fb) == 0
+        if b == 4:
+            L.cryo_memrel_reserve(mem)          # a reserved-but-unwritten page in the middle (EMPTY_BLOCK)
+        all_rows.append(rows)
+        firsts.append(fb[0])
+        methods.append(m)
+    it = L.cryo_seqscan_iter_create()
+    calls0 = L.cryo_cache_codec_calls()
+    got_rows, got_starts = [], []
+    while True:
+        K = 4
+        starts, ents, errs = (C.c_uint32 * K)(), (C.c_int * K)(), (C.c_int * K)()
+        n = L.cryo_scan_next_batch(C.byref(rel), it, K, starts, ents, errs)
+        if n == 0:
+            break
+        for i in range(n):
+            assert errs[i] == 0
+            got_starts.append(starts[i])
+            got_rows.append(fetch_rows(L, L.cryo_cache_get_data(ents[i])))
+    assert got_starts == firsts                       # block starts only, in increasing order
+    assert got_rows == all_rows
+    assert 3 <= L.cryo_cache_codec_calls() - calls0 <= 6   # 11 chains, K = 4, two methods -> at most 2 calls per batch
+    assert not errors
+    L.cryo_seqscan_iter_free(it)
+    L.cryo_memrel_destroy(mem)

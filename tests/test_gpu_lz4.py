@@ -191,3 +191,102 @@ def test_lz4_encode_batch_kernel_corners(codec, oracle):
             for i, b in enumerate(lst):
                 exp = oracle.lz4_compress(b, accel)
                 assert np.array_equal(got[i], exp), (n, accel, i, len(got[i]), len(exp))
+
+
+def test_lz4_golden_cells_on_gpu(codec, oracle):
+    """tests/golden/vectors.json (liblz4 1.9.3 called as reference compression.c:70-72): the device encoder's
+    bytes hash to the golden comp_sha256 for every LZ4 cell, all sizes incl. 128 KiB and 1 MiB, and the device
+    decoder turns them back into blocks that hash to raw_sha256 -- GPU against the library directly, not through
+    the oracle."""
+    import hashlib
+    import json
+    import os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    cells = [c for c in json.load(open(os.path.join(G, "vectors.json")))["cells"] if c["method"] == "lz4"]
+    assert len(cells) >= 200
+    for B in sorted(set(c["B"] for c in cells)):
+        for accel in sorted(set(c["param"] for c in cells if c["B"] == B)):
+            sub = [c for c in cells if c["B"] == B and c["param"] == accel]
+            blocks = [oracle.synth(0, c["block"], B, c["dist"]) for c in sub]
+            got = codec.compress_blocks(METHOD_LZ4, accel, blocks)
+            for c, b, g in zip(sub, blocks, got):
+                assert sha(b) == c["raw_sha256"], c
+                assert len(g) == c["csize"] and sha(g) == c["comp_sha256"], c
+            outs, st = codec.decompress_blocks(METHOD_LZ4, got, B)
+            assert (st == 0).all()
+            for c, o in zip(sub, outs):
+                assert sha(o) == c["raw_sha256"], c
+
+
+def test_lz4_indexed_decoder_large_batch(codec, oracle):
+    """Batches of 24576 blocks and more take the sequence-index pass + the decoder built on it (lz4_dec2.hip).
+    32768 small blocks: every distribution, three accelerations, block sizes whose sequences end in every way
+    (4 KiB, and 1 KiB where whole blocks are a handful of sequences), plus mutated streams among them: statuses
+    and bytes must equal the oracle's, block by block."""
+    from pg_cryogen_amd import METHOD_LZ4
+    rng = np.random.default_rng(21)
+    for B, n in ((4096, 32768), (1024, 40000)):
+        uniq_raw, uniq_comp = [], []
+        for dist in range(5):
+            for blk in range(6):
+                for accel in (1, 7, 50):
+                    r = oracle.synth(3, blk, B, dist)
+                    uniq_raw.append(r)
+                    uniq_comp.append(oracle.lz4_compress(r, accel))
+        # structured random blocks (repeats at many distances, runs, noise)
+        for k in range(40):
+            a = rng.integers(0, 256, B, dtype=np.uint8)
+            for _ in range(int(rng.integers(1, 12))):
+                ln = int(rng.integers(4, 300)); src = int(rng.integers(0, B - ln)); dst = int(rng.integers(0, B - ln))
+                a[dst:dst + ln] = a[src:src + ln].copy()
+            if k % 3 == 0:
+                p = int(rng.integers(0, B - 600)); a[p:p + 600] = a[p]
+            uniq_raw.append(a)
+            uniq_comp.append(oracle.lz4_compress(a, 1))
+        # mutated streams: verdict and bytes as the oracle's
+        muts = []
+        for c in uniq_comp[:30]:
+            for it in range(6):
+                m = c.copy()
+                if it % 3 == 0:
+                    m[int(rng.integers(0, len(m)))] = int(rng.integers(0, 256))
+                elif it % 3 == 1:
+                    m = m[:int(rng.integers(1, len(m)))].copy()
+                else:
+                    p = int(rng.integers(0, len(m) - 1)); m[p] = 0; m[p + 1] = 0
+                r, out = oracle.lz4_decompress(m, B, fill=0xA5)
+                muts.append((m, out.copy() if r == B else None))
+        nu = len(uniq_comp)
+        pick = rng.integers(0, nu + len(muts), n)
+        comps = [uniq_comp[i] if i < nu else muts[i - nu][0] for i in pick]
+        offs = np.zeros(n, np.uint64)
+        pos = 5
+        for i, c in enumerate(comps):
+            offs[i] = pos
+            pos += len(c) + (i % 3)                      # packed at arbitrary byte offsets
+        packed = np.zeros(pos + 64, np.uint8)
+        for o, c in zip(offs, comps):
+            packed[int(o):int(o) + len(c)] = c
+        d_src, d_off, d_sz = codec.alloc(packed.nbytes), codec.alloc(8 * n), codec.alloc(4 * n)
+        d_dst, d_st = codec.alloc(n * B), codec.alloc(4 * n)
+        d_src.upload(packed)
+        d_off.upload(offs)
+        d_sz.upload(np.array([len(c) for c in comps], np.uint32))
+        d_dst.memset(0xA5)
+        codec.decompress_batch(METHOD_LZ4, d_src, d_off, d_sz, d_dst, B, B, n, d_st)
+        codec.sync()
+        st = d_st.download(dtype=np.int32)
+        raw = d_dst.download().reshape(n, B)
+        bad = 0
+        for j, i in enumerate(pick):
+            exp = uniq_raw[i] if i < nu else muts[i - nu][1]
+            if exp is None:
+                assert st[j] != 0, (B, j)
+                bad += 1
+            else:
+                assert st[j] == 0, (B, j, int(i))
+                assert np.array_equal(raw[j], exp), (B, j, int(i))
+        assert bad > 100
+        for x in (d_src, d_off, d_sz, d_dst, d_st):
+            x.free()

@@ -1,0 +1,47 @@
+"""GPU tests of the N > 1 path on a 1-GPU box: two ranks / two handles sharing device 0."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_share_one_gpu():
+    """`python bench.py --gpus 2` with no launcher: the parent starts both ranks before touching the GPU, each rank
+    decodes its own shard (block i of the job on rank i mod 2), every decoded block is verified on the device, and
+    rank 0 reports n_gpus = 2 (BASELINE configs[3] shape at a small size)."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--blocks", "1024"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["config"]["total_blocks"] == 2048 and j["value"] > 0
+    assert "decode == original on all 1024 blocks" in j["config"]["bit_exact"]
+
+
+def test_two_handles_one_process(oracle):
+    """two codec handles in one process (the product dispatcher opens one per device): interleaved calls, each with
+    its own stream, workspace and staging buffers"""
+    from pg_cryogen_amd import Codec, METHOD_LZ4, METHOD_ZSTD
+    B = 131072
+    blocks = [oracle.synth(4, i, B, i % 5) for i in range(12)]
+    with Codec(0) as a, Codec(0) as b:
+        ca = a.compress_blocks(METHOD_LZ4, 1, blocks[:6])
+        cb = b.compress_blocks(METHOD_ZSTD, 1, blocks[6:])
+        oa, sa = b.decompress_blocks(METHOD_LZ4, ca, B)     # decoded by the OTHER handle
+        ob, sb = a.decompress_blocks(METHOD_ZSTD, cb, B)
+        assert (sa == 0).all() and (sb == 0).all()
+        for x, y in zip(blocks[:6], oa):
+            assert np.array_equal(x, y)
+        for x, y in zip(blocks[6:], ob):
+            assert np.array_equal(x, y)
+        for x, c in zip(blocks[:6], ca):
+            assert np.array_equal(c, oracle.lz4_compress(x, 1))
