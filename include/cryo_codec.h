@@ -154,6 +154,24 @@ int cryo_codec_decompress_blocks_to(cryo_codec *c, int method,
                                     const void *const *h_src, const uint32_t *h_src_size, size_t n_blocks,
                                     void *const *h_dst, size_t block_size, int32_t *h_status);
 
+/* ---- several GPUs behind one call: the dispatcher of BASELINE's "independent cryo blocks from a COPY multi_insert
+ *      or a seq-scan shard embarrassingly across the 8 GPUs of one node (round-robin dispatch, no collective)".
+ *      One codec handle per listed device (a device may be listed more than once), block i of a call goes to
+ *      handle i mod G, one host thread per handle drives its share through the K-block calls above; results land
+ *      where the single-handle calls would have put them.  The reference has no counterpart (one block, one core:
+ *      pg_cryogen.c:726, cache.c:178). ---- */
+typedef struct cryo_multi cryo_multi;
+int cryo_multi_open(const int *devices, int n_devices, cryo_multi **out);
+void cryo_multi_close(cryo_multi *m);
+int cryo_multi_count(const cryo_multi *m);
+const char *cryo_multi_last_error(const cryo_multi *m);
+int cryo_multi_compress_blocks(cryo_multi *m, int method, int param,
+                               const void *h_src, size_t block_size, size_t n_blocks,
+                               void *h_dst, size_t dst_stride, uint32_t *h_out_size);
+int cryo_multi_decompress_blocks(cryo_multi *m, int method,
+                                 const void *const *h_src, const uint32_t *h_src_size, size_t n_blocks,
+                                 void *h_dst, size_t block_size, int32_t *h_status);
+
 /* ---- batch helpers used by staging, tests and the benchmark ---- */
 
 /* synthetic cryo blocks (include/cryo_synth.h) on device: slot k holds job block

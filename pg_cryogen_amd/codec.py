@@ -31,6 +31,8 @@ ABI_SYMBOLS = [
     "cryo_codec_compress_batch", "cryo_codec_decompress_batch", "cryo_codec_compress_block",
     "cryo_codec_decompress_block", "cryo_codec_compress_blocks", "cryo_codec_decompress_blocks",
     "cryo_codec_decompress_blocks_to",
+    "cryo_multi_open", "cryo_multi_close", "cryo_multi_count", "cryo_multi_last_error",
+    "cryo_multi_compress_blocks", "cryo_multi_decompress_blocks",
     "cryo_codec_synth_batch", "cryo_codec_checksum_batch",
     "cryo_codec_compare_batch", "cryo_checksum64", "cryo_codec_timer_start",
     "cryo_codec_timer_stop", "cryo_codec_get_counters",
@@ -82,6 +84,14 @@ def lib():
     L.cryo_codec_compress_blocks.argtypes = [vp, i32, i32, vp, sz, sz, vp, sz, vp]
     L.cryo_codec_decompress_blocks.argtypes = [vp, i32, vp, vp, sz, vp, sz, vp]
     L.cryo_codec_decompress_blocks_to.argtypes = [vp, i32, vp, vp, sz, vp, sz, vp]
+    L.cryo_multi_open.argtypes = [C.POINTER(i32), i32, C.POINTER(vp)]
+    L.cryo_multi_close.argtypes = [vp]
+    L.cryo_multi_close.restype = None
+    L.cryo_multi_count.argtypes = [vp]
+    L.cryo_multi_last_error.argtypes = [vp]
+    L.cryo_multi_last_error.restype = C.c_char_p
+    L.cryo_multi_compress_blocks.argtypes = [vp, i32, i32, vp, sz, sz, vp, sz, vp]
+    L.cryo_multi_decompress_blocks.argtypes = [vp, i32, vp, vp, sz, vp, sz, vp]
     L.cryo_codec_synth_batch.argtypes = [vp, u64, u64, u64, u64, u32, i32, vp, u64]
     L.cryo_codec_checksum_batch.argtypes = [vp, vp, u64, vp, u32, u64, vp]
     L.cryo_codec_compare_batch.argtypes = [vp, vp, u64, vp, u64, u32, u64, vp]

@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <thread>
+#include <vector>
 
 struct cryo_codec {
     int device = -1;
@@ -474,6 +476,139 @@ int cryo_codec_decompress_blocks_to(cryo_codec *c, int method, const void *const
 {
     if (!h_dst) return CRYO_E_ARG;
     return decompress_blocks_impl(c, method, h_src, h_src_size, n, nullptr, h_dst, block_size, h_status);
+}
+
+/* ---- several GPUs behind one call ---- */
+struct cryo_multi {
+    std::vector<cryo_codec *> h;
+    char err[320] = {0};
+};
+
+/* K blocks given by pointer, results to pointers: what one device's host thread runs for its share */
+static int compress_blocks_ptrs(cryo_codec *c, int method, int param, const void *const *h_src, size_t block_size, size_t n,
+                                void *const *h_dst, uint32_t *out_size)
+{
+    DevGuard dev_(c);
+    if (n == 0) return CRYO_OK;
+    const size_t bound = cryo_codec_bound(method, block_size);
+    const size_t dstride = (bound + 15) & ~(size_t)15;
+    int rc;
+    if ((rc = ensure(c, &c->hb_src, &c->hb_src_cap, n * block_size + 64)) != CRYO_OK) return rc;
+    if ((rc = ensure(c, &c->hb_dst, &c->hb_dst_cap, n * dstride + 64)) != CRYO_OK) return rc;
+    if ((rc = ensure(c, &c->hb_meta, &c->hb_meta_cap, n * 16 + 64)) != CRYO_OK) return rc;
+    if ((rc = ensure_pinned(c, n * block_size + n * 8)) != CRYO_OK) return rc;
+    uint8_t *pin = (uint8_t *)c->pin;
+    for (size_t i = 0; i < n; i++) memcpy(pin + i * block_size, h_src[i], block_size);
+    int32_t *h_st = (int32_t *)(pin + n * block_size);
+    uint32_t *d_sz = (uint32_t *)c->hb_meta;
+    int32_t *d_st = (int32_t *)(c->hb_meta + ((n * 4 + 15) & ~(size_t)15));
+    HIP_TRY(c, hipMemcpyAsync(c->hb_src, pin, n * block_size, hipMemcpyHostToDevice, c->stream));
+    rc = cryo_codec_compress_batch(c, method, param, c->hb_src, block_size, (uint32_t)block_size, n, c->hb_dst, dstride, d_sz, d_st);
+    if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
+    HIP_TRY(c, hipMemcpyAsync(out_size, d_sz, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(h_st, d_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++) {
+        if (h_st[i] != CRYO_OK) return h_st[i];
+        if (out_size[i] == 0 || out_size[i] > bound) return CRYO_E_HIP;
+        HIP_TRY(c, hipMemcpyAsync(h_dst[i], c->hb_dst + i * dstride, out_size[i], hipMemcpyDeviceToHost, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CRYO_OK;
+}
+
+int cryo_multi_open(const int *devices, int n_devices, cryo_multi **out)
+{
+    if (!out || !devices || n_devices <= 0) return CRYO_E_ARG;
+    *out = nullptr;
+    cryo_multi *m = new (std::nothrow) cryo_multi;
+    if (!m) return CRYO_E_NOMEM;
+    for (int i = 0; i < n_devices; i++) {
+        cryo_codec *c = nullptr;
+        const int rc = cryo_codec_open(devices[i], &c);
+        if (rc != CRYO_OK) { cryo_multi_close(m); return rc; }
+        m->h.push_back(c);
+    }
+    *out = m;
+    return CRYO_OK;
+}
+
+void cryo_multi_close(cryo_multi *m)
+{
+    if (!m) return;
+    for (cryo_codec *c : m->h) cryo_codec_close(c);
+    delete m;
+}
+
+int cryo_multi_count(const cryo_multi *m) { return m ? (int)m->h.size() : 0; }
+const char *cryo_multi_last_error(const cryo_multi *m) { return m ? m->err : ""; }
+
+} /* extern "C" */
+#include <functional>
+/* block i -> handle i mod G; `fn(g, idx)` runs on its own host thread with the block indices of handle g */
+static int multi_run(cryo_multi *m, size_t n, const std::function<int(size_t, const std::vector<size_t> &)> &fn)
+{
+    const size_t G = m->h.size();
+    std::vector<std::vector<size_t>> share(G);
+    for (size_t i = 0; i < n; i++) share[i % G].push_back(i);
+    std::vector<int> rc(G, CRYO_OK);
+    std::vector<std::thread> th;
+    for (size_t g = 1; g < G; g++)
+        if (!share[g].empty()) th.emplace_back([&, g] { rc[g] = fn(g, share[g]); });
+    if (!share[0].empty()) rc[0] = fn(0, share[0]);
+    for (auto &t : th) t.join();
+    for (size_t g = 0; g < G; g++)
+        if (rc[g] != CRYO_OK) {
+            snprintf(m->err, sizeof m->err, "device handle %zu: %s", g, cryo_codec_last_error(m->h[g]));
+            return rc[g];
+        }
+    return CRYO_OK;
+}
+extern "C" {
+
+int cryo_multi_compress_blocks(cryo_multi *m, int method, int param, const void *h_src, size_t block_size, size_t n,
+                               void *h_dst, size_t dst_stride, uint32_t *h_out_size)
+{
+    if (!m || m->h.empty() || !method_ok(method) || block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
+    if (n == 0) return CRYO_OK;
+    if (!h_src || !h_dst || !h_out_size) return CRYO_E_ARG;
+    if (dst_stride < cryo_codec_bound(method, block_size)) return CRYO_E_DSTSIZE;
+    if (m->h.size() == 1) return cryo_codec_compress_blocks(m->h[0], method, param, h_src, block_size, n, h_dst, dst_stride, h_out_size);
+    return multi_run(m, n, [&](size_t g, const std::vector<size_t> &idx) {
+        std::vector<const void *> src(idx.size());
+        std::vector<void *> dst(idx.size());
+        std::vector<uint32_t> sz(idx.size());
+        for (size_t k = 0; k < idx.size(); k++) {
+            src[k] = (const uint8_t *)h_src + idx[k] * block_size;
+            dst[k] = (uint8_t *)h_dst + idx[k] * dst_stride;
+        }
+        const int rc = compress_blocks_ptrs(m->h[g], method, param, src.data(), block_size, idx.size(), dst.data(), sz.data());
+        if (rc == CRYO_OK) for (size_t k = 0; k < idx.size(); k++) h_out_size[idx[k]] = sz[k];
+        return rc;
+    });
+}
+
+int cryo_multi_decompress_blocks(cryo_multi *m, int method, const void *const *h_src, const uint32_t *h_src_size, size_t n,
+                                 void *h_dst, size_t block_size, int32_t *h_status)
+{
+    if (!m || m->h.empty() || !method_ok(method) || block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
+    if (n == 0) return CRYO_OK;
+    if (!h_src || !h_src_size || !h_dst || !h_status) return CRYO_E_ARG;
+    if (m->h.size() == 1) return cryo_codec_decompress_blocks(m->h[0], method, h_src, h_src_size, n, h_dst, block_size, h_status);
+    return multi_run(m, n, [&](size_t g, const std::vector<size_t> &idx) {
+        std::vector<const void *> src(idx.size());
+        std::vector<void *> dst(idx.size());
+        std::vector<uint32_t> sz(idx.size());
+        std::vector<int32_t> st(idx.size());
+        for (size_t k = 0; k < idx.size(); k++) {
+            src[k] = h_src[idx[k]];
+            sz[k] = h_src_size[idx[k]];
+            dst[k] = (uint8_t *)h_dst + idx[k] * block_size;
+        }
+        const int rc = decompress_blocks_impl(m->h[g], method, src.data(), sz.data(), idx.size(), nullptr, dst.data(), block_size, st.data());
+        if (rc == CRYO_OK) for (size_t k = 0; k < idx.size(); k++) h_status[idx[k]] = st[k];
+        return rc;
+    });
 }
 
 /* ---- helpers ---- */

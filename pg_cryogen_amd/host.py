@@ -7,7 +7,8 @@ import os
 from . import _loader
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HOST_LIB_PATH = os.path.join(_HERE, "libcryo_host.so")
+HOST_LIB_PATH = os.path.join(_HERE, "libcryo_host.so")            # production: no test hooks exported
+HOST_TEST_LIB_PATH = os.path.join(_HERE, "libcryo_host_test.so")  # + cryo_host_set_codec_ops (tests/conftest.py asks for it)
 
 COMP_LZ4, COMP_ZSTD = 0, 1
 (CRYO_ERR_SUCCESS, CRYO_ERR_DECOMPRESSION_FAILED, CRYO_ERR_WRONG_STARTING_BLOCK, CRYO_ERR_EMPTY_BLOCK,
@@ -44,17 +45,19 @@ def lib():
     if _lib is not None:
         return _lib
     _loader.load()  # libcryo_codec.so + one HIP runtime first
-    if not os.path.exists(HOST_LIB_PATH):
-        raise ImportError("pg_cryogen_amd: %s is missing; build with `make -C pg_cryogen_amd/host`" % HOST_LIB_PATH)
-    L = C.CDLL(HOST_LIB_PATH)
+    path = HOST_TEST_LIB_PATH if os.environ.get("CRYO_HOST_TEST_HOOKS") == "1" else HOST_LIB_PATH
+    if not os.path.exists(path):
+        raise ImportError("pg_cryogen_amd: %s is missing; build with `make -C pg_cryogen_amd/host`" % path)
+    L = C.CDLL(path)
     vp, u32, i32, sz = C.c_void_p, C.c_uint32, C.c_int, C.c_size_t
     L.cryo_compress.argtypes = [i32, vp, C.POINTER(sz)]
     L.cryo_compress.restype = vp
     L.cryo_decompress.argtypes = [i32, vp, sz, vp]
     L.cryo_decompress.restype = C.c_bool
     L.cryo_define_compression_gucs.restype = None
-    L.cryo_host_set_codec_ops.argtypes = [C.POINTER(CryoCodecOps)]
-    L.cryo_host_set_codec_ops.restype = None
+    if hasattr(L, "cryo_host_set_codec_ops"):   # test build only
+        L.cryo_host_set_codec_ops.argtypes = [C.POINTER(CryoCodecOps)]
+        L.cryo_host_set_codec_ops.restype = None
     L.cryo_host_codec_error.restype = C.c_char_p
     L.cryo_compat_set_error_handler.argtypes = [ERROR_HANDLER]
     L.cryo_compat_set_error_handler.restype = None

@@ -26,48 +26,62 @@ int compression_method_guc = COMP_ZSTD;
 int lz4_acceleration_guc = 1;
 int zstd_compression_level_guc = 1;
 int cryo_gpu_device_guc = 0;
+int cryo_gpu_count_guc = 1;
 Size cryo_blcksz = (Size)1 << 20; /* CRYO_BLCKSZ, reference storage.h:18 */
 
 /* ---------------- codec binding ---------------- */
-static cryo_codec *hip_codec;
+/* one handle per GPU of this backend: pg_cryogen.gpu_device is the first, pg_cryogen.gpu_count how many (consecutive
+ * device numbers, wrapping).  With more than one, the K-block calls of the staging and cache code go through the
+ * dispatcher of include/cryo_codec.h (block i of a call -> GPU i mod G, one host thread per GPU). */
+static cryo_multi *hip_multi;
+static int hip_multi_first = -1, hip_multi_count = 0;
 static char codec_err[320];
 
 static size_t hip_bound(int method, size_t n) { return cryo_codec_bound(method, n); }
 static int hip_compress_blocks(void *ctx, int method, int param, const void *src, size_t bs, size_t n, void *dst,
                                size_t stride, uint32_t *out)
 {
-    return cryo_codec_compress_blocks((cryo_codec *)ctx, method, param, src, bs, n, dst, stride, out);
+    return cryo_multi_compress_blocks((cryo_multi *)ctx, method, param, src, bs, n, dst, stride, out);
 }
 static int hip_decompress_blocks(void *ctx, int method, const void *const *src, const uint32_t *sz, size_t n,
                                  void *dst, size_t bs, int32_t *st)
 {
-    return cryo_codec_decompress_blocks((cryo_codec *)ctx, method, src, sz, n, dst, bs, st);
+    return cryo_multi_decompress_blocks((cryo_multi *)ctx, method, src, sz, n, dst, bs, st);
 }
 
-static int hip_decompress_blocks_scatter(void *ctx, int method, const void *const *src, const uint32_t *sz, size_t n,
-                                         void *const *dst, size_t bs, int32_t *st)
-{
-    return cryo_codec_decompress_blocks_to((cryo_codec *)ctx, method, src, sz, n, dst, bs, st);
-}
+static CryoCodecOps hip_ops = {hip_bound, hip_compress_blocks, hip_decompress_blocks, NULL, NULL};
+static const CryoCodecOps *bound_ops; /* CPU-only plumbing tests bind a double here (CRYO_HOST_TEST_HOOKS builds only) */
 
-static CryoCodecOps hip_ops = {hip_bound, hip_compress_blocks, hip_decompress_blocks, NULL, hip_decompress_blocks_scatter};
-static const CryoCodecOps *bound_ops; /* test double, if any */
-
+#ifdef CRYO_HOST_TEST_HOOKS
 void cryo_host_set_codec_ops(const CryoCodecOps *ops) { bound_ops = ops; }
+#endif
 const char *cryo_host_codec_error(void) { return codec_err; }
 
 const CryoCodecOps *cryo_host_codec_ops(void)
 {
     if (bound_ops) return bound_ops;
-    if (!hip_codec) {
-        int rc = cryo_codec_open(cryo_gpu_device_guc, &hip_codec);
-        if (rc != CRYO_OK) {
-            snprintf(codec_err, sizeof codec_err, "cryo_codec_open(%d) failed with %d (no CPU fallback)",
-                     cryo_gpu_device_guc, rc);
-            hip_codec = NULL;
+    if (hip_multi && (hip_multi_first != cryo_gpu_device_guc || hip_multi_count != cryo_gpu_count_guc)) {
+        cryo_multi_close(hip_multi); /* the GUCs changed: rebind */
+        hip_multi = NULL;
+    }
+    if (!hip_multi) {
+        int devs[64], i, ndev = cryo_codec_device_count(), rc;
+        int cnt = cryo_gpu_count_guc < 1 ? 1 : (cryo_gpu_count_guc > 64 ? 64 : cryo_gpu_count_guc);
+        if (ndev <= 0) {
+            snprintf(codec_err, sizeof codec_err, "no GPU visible to the HIP runtime (%d; no CPU fallback)", ndev);
             return NULL;
         }
-        hip_ops.ctx = hip_codec;
+        for (i = 0; i < cnt; i++) devs[i] = (cryo_gpu_device_guc + i) % ndev;
+        rc = cryo_multi_open(devs, cnt, &hip_multi);
+        if (rc != CRYO_OK) {
+            snprintf(codec_err, sizeof codec_err, "cryo_multi_open(first %d, count %d) failed with %d (no CPU fallback)",
+                     cryo_gpu_device_guc, cnt, rc);
+            hip_multi = NULL;
+            return NULL;
+        }
+        hip_multi_first = cryo_gpu_device_guc;
+        hip_multi_count = cryo_gpu_count_guc;
+        hip_ops.ctx = hip_multi;
     }
     return &hip_ops;
 }
@@ -87,6 +101,8 @@ void cryo_define_compression_gucs(void)
                             &zstd_compression_level_guc, 1, -5, 22, PGC_USERSET, 0, NULL, NULL, NULL);
     DefineCustomIntVariable("pg_cryogen.gpu_device", "GPU used by this backend.", NULL, &cryo_gpu_device_guc, 0,
                             0, 63, PGC_USERSET, 0, NULL, NULL, NULL);
+    DefineCustomIntVariable("pg_cryogen.gpu_count", "Number of GPUs (from gpu_device on) the K-block calls of this backend are spread over.",
+                            NULL, &cryo_gpu_count_guc, 1, 1, 64, PGC_USERSET, 0, NULL, NULL, NULL);
 #else
     /* no GUC machinery without PostgreSQL: the variables keep the reference's defaults */
     compression_method_guc = COMP_ZSTD;

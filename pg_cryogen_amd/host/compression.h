@@ -42,6 +42,8 @@ extern void cryo_define_compression_gucs(void);
 extern Size cryo_blcksz;
 /* GPU used by this backend (additive GUC pg_cryogen.gpu_device, default 0) */
 extern int cryo_gpu_device_guc;
+/* how many GPUs, from gpu_device on, the K-block calls are spread over (additive GUC pg_cryogen.gpu_count, default 1) */
+extern int cryo_gpu_count_guc;
 
 /* the codec entry points the host side calls; production binds them to libcryo_codec.so
  * (include/cryo_codec.h), CPU-only plumbing tests may bind a test double */
@@ -56,7 +58,9 @@ typedef struct CryoCodecOps {
     int (*decompress_blocks_scatter)(void *ctx, int method, const void *const *src, const uint32_t *src_size, size_t n,
                                      void *const *dst, size_t block_size, int32_t *status);
 } CryoCodecOps;
-void cryo_host_set_codec_ops(const CryoCodecOps *ops); /* NULL restores the HIP binding */
+#ifdef CRYO_HOST_TEST_HOOKS
+void cryo_host_set_codec_ops(const CryoCodecOps *ops); /* test builds only: bind a double; NULL restores the HIP binding */
+#endif
 const CryoCodecOps *cryo_host_codec_ops(void);         /* lazily opens the GPU codec */
 const char *cryo_host_codec_error(void);
 

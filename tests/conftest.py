@@ -4,6 +4,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["CRYO_HOST_TEST_HOOKS"] = "1"   # the host library build that exports cryo_host_set_codec_ops (codec double)
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 

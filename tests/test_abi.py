@@ -52,3 +52,14 @@ def test_product_never_touches_oracle():
                 if re.search(r"#include\s*[\"<][^\">]*oracle|libcryo_oracle|cryo_oracle_|import\s+oracle|oracle_lib", txt):
                     bad.append(os.path.join(dp, fn))
     assert not bad, bad
+
+
+def test_production_host_library_has_no_test_hook():
+    """the codec-double hook of the CPU plumbing tests exists only in libcryo_host_test.so"""
+    import ctypes
+    from pg_cryogen_amd import _loader, host
+    _loader.load()
+    prod = ctypes.CDLL(host.HOST_LIB_PATH)
+    assert not hasattr(prod, "cryo_host_set_codec_ops")
+    assert hasattr(prod, "cryo_compress") and hasattr(prod, "cryo_decompress") and hasattr(prod, "cryo_scan_next_batch")
+    assert hasattr(ctypes.CDLL(host.HOST_TEST_LIB_PATH), "cryo_host_set_codec_ops")

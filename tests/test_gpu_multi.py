@@ -45,3 +45,43 @@ def test_two_handles_one_process(oracle):
             assert np.array_equal(x, y)
         for x, c in zip(blocks[:6], ca):
             assert np.array_equal(c, oracle.lz4_compress(x, 1))
+
+
+def test_multi_handle_dispatcher_round_robin(oracle):
+    """cryo_multi_*: block i of a call goes to handle i mod G, one host thread per handle; on a 1-GPU
+    box the G handles share device 0.  Bytes and statuses are those of the single-handle calls."""
+    import ctypes as C
+    from pg_cryogen_amd import codec as cc, METHOD_LZ4, METHOD_ZSTD
+    L = cc.lib()
+    B, n = 131072, 23
+    blocks = [oracle.synth(6, i, B, i % 5) for i in range(n)]
+    raw = np.concatenate(blocks)
+    for G in (2, 3):
+        h = C.c_void_p()
+        devs = (C.c_int * G)(*([0] * G))
+        assert L.cryo_multi_open(devs, G, C.byref(h)) == 0 and L.cryo_multi_count(h) == G
+        for method, param in ((METHOD_LZ4, 1), (METHOD_ZSTD, 1)):
+            stride = (cc.bound(method, B) + 15) & ~15
+            out = np.zeros(n * stride, np.uint8)
+            sizes = np.zeros(n, np.uint32)
+            rc = L.cryo_multi_compress_blocks(h, method, param, raw.ctypes.data, B, n, out.ctypes.data, stride, sizes.ctypes.data)
+            assert rc == 0, L.cryo_multi_last_error(h)
+            comps = []
+            for i, b in enumerate(blocks):
+                exp = oracle.lz4_compress(b, param) if method == METHOD_LZ4 else oracle.zstd_compress(b, param)
+                got = out[i * stride:i * stride + int(sizes[i])]
+                assert np.array_equal(got, exp), (G, method, i)
+                comps.append(np.ascontiguousarray(got))
+            comps[5] = comps[5][:100].copy()                     # one truncated stream among them
+            ptrs = (C.c_void_p * n)(*[c.ctypes.data for c in comps])
+            csz = np.array([len(c) for c in comps], np.uint32)
+            dec = np.zeros(n * B, np.uint8)
+            st = np.zeros(n, np.int32)
+            rc = L.cryo_multi_decompress_blocks(h, method, ptrs, csz.ctypes.data, n, dec.ctypes.data, B, st.ctypes.data)
+            assert rc == 0, L.cryo_multi_last_error(h)
+            for i, b in enumerate(blocks):
+                if i == 5:
+                    assert st[i] != 0
+                else:
+                    assert st[i] == 0 and np.array_equal(dec[i * B:(i + 1) * B], b), (G, method, i)
+        L.cryo_multi_close(h)
