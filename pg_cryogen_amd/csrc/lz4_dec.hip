@@ -61,6 +61,7 @@
  *  rule; the batch only ever accepts sequences that pass all of them.
  */
 #include "lz_common.h"
+#include "lz4_copy.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -99,8 +100,8 @@ struct WaveLds {
     uint8_t *d1;                           /* kD1N  (phase 3 reuses it as `meta`)         */
     uint8_t *__restrict__ d2;              /* kD2N                                        */
     uint8_t *__restrict__ d4;              /* kWMax                                       */
-    unsigned long long *meta;              /* 64: litend | off<<16 | (litidx - ostart)<<32 */
-    uint32_t *__restrict__ bm;             /* kTMax/32 + 16: batch copy's bitmap and bases */
+    uint2 *mmeta;                          /* 64: match meta of the copy engine (lz4_copy.h); lies over d1, dead by then */
+    uint32_t *bm;                          /* kTMax/32 + 16: the copy engine's match-space bitmap and chunk bases */
     const uint8_t *lut;                    /* 256: token -> distance to the next token (see lz4_token_lut) */
 };
 
@@ -138,6 +139,9 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     /* stage the window (no refill happens while the batch runs) */
     while (w.in_hi < vend && w.in_hi < vp + W + 256u + 72u) w.refill();
     LDS_TABLE_FENCE(); /* the window below is read by other lanes than the ones that staged it */
+    uint2 mir = make_uint2(0, 0);
+    if (lane < 2u) mir = *reinterpret_cast<const uint2 *>(L.in + lane * 8u);
+    else if (lane < 4u) mir = *reinterpret_cast<const uint2 *>(L.ring + (lane - 2u) * 8u);
     stamp(st, 0);
 
     /* ---- phase 1: d1 for every window offset, then d2, d4 ---- */
@@ -235,107 +239,46 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     const uint32_t oend = scan64_incl(outlen);
     const uint32_t ostart = oend - outlen;
     const uint32_t mabs = w.op + ostart + ll; /* absolute output position of the match */
+    const bool isfar = cand && off >= R - kTMax; /* R - T >= T + 1023: in the ring for the whole batch, or flushed before it */
     const bool ok = cand && !(hasM && e2 == 255u) && off >= ml && off <= mabs &&
-                    pos + dlen <= vsafe && oend <= kTMax && w.op + oend + 16u <= B;
+                    pos + dlen <= vsafe && oend <= kTMax && w.op + oend + 16u <= B && !(isfar && ml > 32u);
     const unsigned long long badmask = __ballot(!ok);
     const uint32_t nseq = badmask ? ctz64(badmask) : 64u;
+    /* the output ring's first 16 bytes are mirrored behind it, like the input ring's (16-byte reads of the copy
+     * engine that start in a ring's last 15 bytes) */
+    if (lane < 2u) *reinterpret_cast<uint2 *>(L.in + kInRing + lane * 8u) = mir;
+    else if (lane < 4u) *reinterpret_cast<uint2 *>(L.ring + R + (lane - 2u) * 8u) = mir;
+    w.flush();   /* what earlier batches produced: far sources are read back from it */
     if (nseq == 0u) return 0;
     const uint32_t T = lane_get(oend, nseq - 1u);
     *used = lane_get(sl + dlen, nseq - 1u);
-
+    /* far matches (source may leave the ring before the batch is done; flushed): two 16-byte requests per lane */
+    uint4 xfa = make_uint4(0, 0, 0, 0), xfb = xfa;
+    if (lane < nseq && isfar) {
+        const uint8_t *g = w.dst + (mabs - off);
+        __builtin_memcpy(&xfa, g, 16);
+        __builtin_memcpy(&xfb, g + 16, 16);
+    }
     stamp(st, 3);
-    batch_copy<R>(w, L.in, L.meta, L.bm, nseq, ostart, ll, off, (pos + k) - ostart, T, st);
+    const SeqLds<R, kTMax> SL = {L.ring, L.in, L.mmeta, L.bm};
+    seq_copy<R, kTMax>(w, SL, nseq, ostart, ll, ml, off, pos + k, T, isfar, xfa, xfb, st);
     vp += *used;
     stamp(st, 0);
     return nseq;
 }
 
-
-/* Table-driven batches: sequence starts from the index row written by k_lz4_index (lz4_dec2.hip, which also has
- * the decoder built for them; this variant is kept for A/B runs: CRYO_LZ4_ENGINE=1). */
-constexpr uint32_t kTblWin = 1536; /* compressed bytes a table batch may span (in_hi stays < vp + kInRing) */
-
-/* lane i gets lane i+1's value (lane 63: 0) */
-__device__ inline uint32_t lane_next(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-}
-
-/*
- * Table-driven batch: sequences n0 .. n0+63 of the block start at the positions in `row` (k_lz4_index).
- * Same contract as lz4_batch (returns the sequences consumed, 0 = none).
- */
-template <uint32_t R>
-__device__ inline uint32_t lz4_batch_tbl(Wave<R> &w, const WaveLds<R> &L, uint32_t &vp, const uint32_t B,
-                                         uint32_t *used, const uint32_t epos, const uint32_t navail,
-                                         const uint16_t *__restrict__ trow, const uint32_t n0, const uint32_t ntab,
-                                         uint32_t &epre, Stats &st)
-{
-    const uint32_t lane = w.lane;
-    const uint32_t vend = w.vend;
-    *used = 0;
-    if (vend < 32u || B < 32u || navail == 0u) return 0;
-    const uint32_t vsafe = vend - 16u;
-    if (vp + 64u > vsafe || w.op + 64u > B) return 0;
-    stamp(st, 7);
-    while (w.in_hi < vend && w.in_hi < vp + kTblWin) w.refill();
-    LDS_TABLE_FENCE();
-    stamp(st, 0);
-    /* positions: the row holds the low 16 bits of the offset in the compressed block; a batch spans < 64 KiB */
-    const uint32_t pos = vp + ((epos + w.delta - vp) & 0xffffu);
-    const bool cand = lane < navail && pos + 8u <= vp + kTblWin; /* also keeps the reads below inside the staged window */
-    const uint32_t rp = cand ? pos : vp;
-    const uint32_t t = L.in[rp & kInMask];
-    const uint32_t e1 = L.in[(rp + 1u) & kInMask];
-    uint32_t ll = t >> 4;
-    uint32_t k = 1u;
-    if (ll == 15u) { ll += e1; k = 2u; }
-    const uint32_t q = rp + k + ll; /* offset field */
-    const bool inwin = q + 8u <= vp + kTblWin;
-    const uint32_t rq = inwin ? q : vp;
-    const uint32_t off = (uint32_t)L.in[rq & kInMask] | ((uint32_t)L.in[(rq + 1u) & kInMask] << 8);
-    const uint32_t e2 = L.in[(rq + 2u) & kInMask];
-    uint32_t ml = (t & 15u) + 4u;
-    uint32_t dlen = k + ll + 2u;
-    const bool hasM = (t & 15u) == 15u;
-    if (hasM) { ml += e2; dlen += 1u; }
-    const uint32_t outlen = cand ? ll + ml : 0u;
-    const uint32_t oend = scan64_incl(outlen);
-    const uint32_t ostart = oend - outlen;
-    const uint32_t mabs = w.op + ostart + ll;
-    /* the row is a hint: lane 0 must sit on the wave's own position and every sequence must end where the
-     * next lane's starts (the last candidate needs no successor) */
-    const uint32_t npos = lane_next(pos);
-    const bool chain = (lane == 0u ? pos == vp : true) && (lane + 1u >= navail || lane == 63u || npos == pos + dlen);
-    const bool ok = cand && inwin && chain && !(t >= 0xf0u && e1 == 255u) && !(hasM && e2 == 255u) && off >= ml && off <= mabs &&
-                    pos + dlen <= vsafe && oend <= kTMax && w.op + oend + 16u <= B;
-    const unsigned long long badmask = __ballot(!ok);
-    const uint32_t nseq = badmask ? ctz64(badmask) : 64u;
-    if (nseq == 0u) return 0;
-    const uint32_t T = lane_get(oend, nseq - 1u);
-    *used = lane_get(pos + dlen, nseq - 1u) - vp;
-    /* the next batch's positions are requested now: their trip to memory hides behind this batch's copy */
-    epre = 0;
-    if (n0 + nseq + lane < ntab) epre = trow[n0 + nseq + lane];
-    stamp(st, 3);
-    batch_copy<R>(w, L.in, L.meta, L.bm, nseq, ostart, ll, off, (pos + k) - ostart, T, st);
-    vp += *used;
-    stamp(st, 0);
-    return nseq;
-}
 
 template <uint32_t R, bool STATS>
 __global__ void __launch_bounds__(256, LZ4_WAVES_PER_SIMD) /* VGPR cap matching what the LDS budget admits */
 k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
-               uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats,
-               const uint16_t *__restrict__ tbl, uint32_t tbl_cap, const uint32_t *__restrict__ tbl_n)
+               uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats)
 {
     Stats st = {};
     st.on = STATS;
     if (STATS) { st.ablate = (uint32_t)stats[7]; st.t0 = __builtin_amdgcn_s_memtime(); }
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][R];
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[4][kInRing];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][R + 16];      /* + the 16-byte tail of the copy engine (lz4_copy.h) */
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[4][kInRing + 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_d1[4][kD1N]; /* also holds meta[64] in phase 3 */
     __shared__ uint8_t s_d2[4][kD2N];
     __shared__ uint8_t s_d4[4][kWMax];
@@ -353,7 +296,7 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
 
     Wave<R> w;
     const WaveLds<R> L = {s_ring[wid], s_in[wid], s_d1[wid], s_d2[wid], s_d4[wid],
-                          reinterpret_cast<unsigned long long *>(s_d1[wid]), s_bm[wid], s_lut};
+                          reinterpret_cast<uint2 *>(s_d1[wid]), s_bm[wid], s_lut};
     {
         uint32_t v = 0;
 #pragma unroll
@@ -384,10 +327,6 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     bool done = bad;
     uint32_t skip = 0;
     uint32_t wmode = 1u; /* parse window: 0 = 128 B, 1 = 512 B, 2 = 1 KiB */
-    /* index row of this block (large batches only): token positions of its sequences */
-    const uint16_t *trow = tbl ? tbl + uni64(blk * (uint64_t)tbl_cap) : nullptr;
-    const uint32_t ntab = tbl ? uni(tbl_n[blk]) : 0u;
-    uint32_t n0 = 0; /* sequences decoded so far */
 
     if (!bad) {
         w.prefetch();
@@ -400,23 +339,7 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
         /* =====================  BATCH PATH  =====================
          * The window W follows the compressed bytes a batch actually consumed (long matches
          * make a batch hit kTMax output bytes after few tokens). */
-        if (skip == 0u && trow != nullptr) {
-            /* sequence starts come from the index row (k_lz4_index); a batch that stops early only ends the run */
-            uint32_t n, used;
-            uint32_t epre = 0;
-            bool have_pre = false;
-            do {
-                uint32_t e = epre;
-                const uint32_t navail = n0 < ntab ? (ntab - n0 < 64u ? ntab - n0 : 64u) : 0u;
-                if (!have_pre) { e = 0; if (lane < navail) e = trow[n0 + lane]; }
-                n = lz4_batch_tbl<R>(w, L, vp, B, &used, e, navail, trow, n0, ntab, epre, st);
-                have_pre = n != 0u;
-                n0 += n;
-                if (n == 0u) st.zero_batches++;
-            } while (n >= 8u);
-            if (n < 4u) skip = 4u;
-            if (n0 >= ntab) trow = nullptr; /* row exhausted (more sequences than it holds, or not the wave's chain): parse here */
-        } else if (skip == 0u) {
+        if (skip == 0u) {
             uint32_t n, used;
             do {
                 n = wmode == 0u ? lz4_batch<R, 2>(w, L, vp, B, &used, st)
@@ -440,7 +363,6 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
 
         /* =====================  GENERAL PATH: one sequence  ===================== */
         st.general_seqs++;
-        n0++;
         w.flush();
         w.need(vp);
         win = w.window(vp);
@@ -650,25 +572,10 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
     }();
     const dim3 g((uint32_t)grid), b(256);
     /* large batches with a workspace: sequence index pass + the decoder built for it (lz4_dec2.hip) */
-    const uint16_t *tbl = nullptr;
-    const uint32_t *tbl_n = nullptr;
-    const uint32_t cap = lz4_index_cap(block_size);
     const size_t need = lz4_decompress_workspace(n_blocks, block_size);
-    static const int engine = [] {
-        const char *e = getenv("CRYO_LZ4_ENGINE"); /* 2 (default) = run-space copy engine, 1 = round-1 copy engine on the index (A/B) */
-        return e ? atoi(e) : 2;
-    }();
-    if (need != 0 && d_workspace != nullptr && workspace_bytes >= need) {
-        if (engine != 1)
-            return launch_lz4_decompress_indexed(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks,
-                                                 d_status, d_workspace, workspace_bytes);
-        uint16_t *t = static_cast<uint16_t *>(d_workspace);
-        uint32_t *tn = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_workspace) + (((size_t)n_blocks * cap * 2u + 1024u + 15u) & ~(size_t)15u));
-        hipError_t e = launch_lz4_index(s, d_src, d_src_off, d_src_size, n_blocks, t, cap, tn);
-        if (e != hipSuccess) return e;
-        tbl = t;
-        tbl_n = tn;
-    }
+    if (need != 0 && d_workspace != nullptr && workspace_bytes >= need)
+        return launch_lz4_decompress_indexed(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks,
+                                             d_status, d_workspace, workspace_bytes);
     static const bool want_stats = getenv("CRYO_LZ4_STATS") != nullptr; /* debugging aid */
     if (want_stats) {
         unsigned long long *d_st = nullptr, h_st[16];
@@ -677,7 +584,7 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
         (void)hipMemcpyAsync(d_st + 7, &abl, sizeof abl, hipMemcpyHostToDevice, s);
         hipLaunchKernelGGL((k_lz4_dec_ring<4096, true>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
-                           block_size, n_blocks, d_status, d_st, tbl, cap, tbl_n);
+                           block_size, n_blocks, d_status, d_st);
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
         (void)hipFree(d_st);
@@ -693,10 +600,10 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
     }
     if (ring == 8192)
         hipLaunchKernelGGL((k_lz4_dec_ring<8192, false>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
-                           block_size, n_blocks, d_status, nullptr, tbl, cap, tbl_n);
+                           block_size, n_blocks, d_status, nullptr);
     else
         hipLaunchKernelGGL((k_lz4_dec_ring<4096, false>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
-                           block_size, n_blocks, d_status, nullptr, tbl, cap, tbl_n);
+                           block_size, n_blocks, d_status, nullptr);
     return hipGetLastError();
 }
 

@@ -24,6 +24,7 @@
  *             are produced in order, so only a source inside the chunk's own span can be unready (frontier rounds).
  */
 #include "lz_common.h"
+#include "lz4_copy.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -223,21 +224,10 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
 /* ---------------------------------------------------------------------------------------------
  * Decoder
  * --------------------------------------------------------------------------------------------- */
-#define LDS_FENCE() asm volatile("" ::: "memory")
 
 constexpr uint32_t kSeqWin = 1536;  /* compressed bytes a batch may span (in_hi stays < vp + kInRing)   */
 constexpr uint32_t kT2 = 1536;      /* output bytes per batch: the largest T with R - T >= T + 1023 at R = 4096, i.e. every
                                      * offset is either still in the ring (off < R - T) or flushed (off >= T + 1023) */
-constexpr uint32_t kBmW = kT2 / 32; /* bitmap words per run space                                       */
-constexpr uint32_t kNc = kT2 / 64;  /* chunks per run space (at most)                                   */
-
-template <uint32_t R>
-struct SeqLds {
-    uint8_t *ring;                 /* R + 16: output ring; a literal piece that runs over the end lands in the 16 extra bytes and is folded back */
-    uint8_t *in;                   /* kInRing + 16: input ring; the extra bytes mirror its first 16 (16-byte reads near the end) */
-    uint2 *mmeta;                  /* 64: sequence s   -> (output position of its match minus its position in match space, offset)                    */
-    uint32_t *mbm;                 /* kBmW + kNc: bitmap of match starts in match space, then per-chunk bases */
-};
 
 /* lane i gets lane i+1's value (lane 63: 0) */
 __device__ inline uint32_t lane_next(uint32_t v)
@@ -246,178 +236,11 @@ __device__ inline uint32_t lane_next(uint32_t v)
 }
 
 /*
- * One run per lane, 16 bytes per step, exact to the byte: `rem` bytes from `src` (a pointer into LDS, or -- FAR -- the
- * registers xa, xb) to ring position `dv`.  Unaligned wide LDS accesses are exact on gfx950 and cost about one LDS
- * cycle per active lane whatever their width (profiles/microbench).  The rest of a run goes out as 8/4/2/1-byte
- * pieces: a byte too many would land in the next run.  A piece that runs over the ring's end lands in the 16
- * bytes behind it; `spill` counts them (folded back by the caller).
- */
-template <uint32_t R, uint32_t SMASK>
-__device__ inline void lane_runs(uint8_t *ring, const uint8_t *sbase, uint32_t rem, uint32_t sv, uint32_t dv, const bool far,
-                                 const uint4 xa, const uint4 xb, uint32_t &spill)
-{
-    uint32_t it = 0;
-    while (__any(rem >= 16u)) {
-        if (rem >= 16u) {
-            uint4 v = it == 0u ? xa : xb;
-            if (!far) __builtin_memcpy(&v, sbase + (sv & SMASK), 16);
-            const uint32_t di = dv & (R - 1u);
-            __builtin_memcpy(ring + di, &v, 16);
-            if (di + 16u > R) spill = di + 16u - R;
-            sv += 16u; dv += 16u; rem -= 16u;
-            it++;
-        }
-    }
-    if (rem != 0u) {
-        uint4 v = it == 0u ? xa : xb;
-        if (!far) __builtin_memcpy(&v, sbase + (sv & SMASK), 16);
-        uint32_t di = dv & (R - 1u);
-        if (di + rem > R) spill = di + rem - R;
-        if (rem & 8u) { __builtin_memcpy(ring + di, &v.x, 8); di += 8u; v.x = v.z; v.y = v.w; }
-        if (rem & 4u) { __builtin_memcpy(ring + di, &v.x, 4); di += 4u; v.x = v.y; }
-        if (rem & 2u) { const uint16_t h = (uint16_t)v.x; __builtin_memcpy(ring + di, &h, 2); di += 2u; v.x >>= 16; }
-        if (rem & 1u) ring[di] = (uint8_t)v.x;
-    }
-}
-
-/*
- * Copy the bytes of up to 64 sequences (lane i < nseq holds sequence i).
- *   ostart: first output byte of the sequence inside the batch; ll literal bytes from virtual input position
- *   lpos, then ml match bytes at distance off (off >= ml: no overlap inside one match); T = total bytes <= kT2.
- *   isfar: the match's source is no longer in the ring; its bytes are in xfa/xfb (requested by the caller).
- */
-template <uint32_t R>
-__device__ inline void seq_copy(Wave<R> &w, const SeqLds<R> &L, const uint32_t nseq, const uint32_t ostart,
-                                const uint32_t ll, const uint32_t ml, const uint32_t off, const uint32_t lpos,
-                                const uint32_t T, const bool isfar, const uint4 xfa, const uint4 xfb, Stats &st)
-{
-    static_assert(R - kT2 >= kT2 + 1023u, "an offset must be either in the ring or flushed");
-    const uint32_t lane = w.lane;
-    const uint32_t op0 = w.op;
-    const bool act = lane < nseq;
-    st.batches++;
-    st.batch_seqs += nseq;
-
-    /* A match whose source ends before the batch begins depends on nothing the batch produces (about half of them
-     * on tuple data, far matches included): those go lane-per-sequence like the literals.  The others form the
-     * "match space". */
-    const uint32_t mrel = ostart + ll;                           /* match start inside the batch */
-    const bool indep = act && (isfar || off >= mrel + ml);
-    const bool dep = act && !indep;
-    const uint32_t mlx = dep ? ml : 0u;
-    const uint32_t mend = scan64_incl(mlx);
-    const uint32_t mcum = mend - mlx;                            /* dependent match bytes before this sequence's */
-    const uint32_t MT = lane_get(mend, 63u);
-    const unsigned long long depm = __ballot(dep);
-    const uint32_t drank = __builtin_amdgcn_mbcnt_hi((uint32_t)(depm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)depm, 0u));
-
-    if (lane < kBmW) L.mbm[lane] = 0u;
-    LDS_FENCE();
-    if (dep) {
-        /* bit (start - 1) for every dependent match that starts at a position >= 1 of match space: the number of set
-         * bits BELOW a position is the rank of the match it belongs to.
-         * meta: x = output position of the match minus its position in match space; y = offset */
-        L.mmeta[drank] = make_uint2(op0 + mrel - mcum, off);
-        if (mcum != 0u) atomicOr(&L.mbm[(mcum - 1u) >> 5], 1u << ((mcum - 1u) & 31u));
-    }
-    LDS_FENCE();
-
-    /* ---- literals and independent matches: one lane per sequence ---- */
-    {
-        uint32_t spill = 0; /* bytes this lane wrote beyond the ring's end */
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        lane_runs<R, kInMask>(L.ring, L.in, act ? ll : 0u, lpos, op0 + ostart, false, z, z, spill);
-        /* (the 16 bytes behind the ring mirror its first 16 for reads that start in its last 15: lz4_seq_batch) */
-        lane_runs<R, R - 1u>(L.ring, L.ring, indep ? ml : 0u, op0 + mrel - off, op0 + mrel, isfar, xfa, xfb, spill);
-        /* a batch crosses the ring's end at most once: fold the bytes that ran over back to the start */
-        const unsigned long long sm = __ballot(spill != 0u);
-        if (sm != 0ull) {
-            LDS_FENCE();
-            const uint32_t k = lane_get(spill, ctz64(sm));
-            if (lane < k) L.ring[lane] = L.ring[R + lane];
-        }
-    }
-    LDS_FENCE();
-    {
-        /* bits before each match-space chunk */
-        static_assert(kNc <= 64, "one lane per chunk");
-        uint32_t cnt = 0;
-        if (lane < kNc) {
-            const uint2 wv = *reinterpret_cast<const uint2 *>(&L.mbm[lane * 2u]);
-            cnt = (uint32_t)(__popc(wv.x) + __popc(wv.y));
-        }
-        const uint32_t exc = scan64_incl(cnt) - cnt;
-        if (lane < kNc) L.mbm[kBmW + lane] = exc;
-    }
-    LDS_FENCE();
-    stamp(st, 4);
-
-    /* ---- match space: chunks in order ---- */
-    {
-        const uint32_t nM = (MT + 63u) >> 6;
-        constexpr uint32_t U = 4;
-        for (uint32_t c0 = 0; c0 < nM; c0 += U) {
-            uint32_t da[U], ra[U];
-            bool pendv[U], actv[U];
-            {
-                uint32_t idx[U];
-                uint2 mt[U];
-#pragma unroll
-                for (uint32_t u = 0; u < U; u++) {
-                    const uint32_t c = c0 + u < kNc ? c0 + u : kNc - 1u;
-                    const uint2 wv = *reinterpret_cast<const uint2 *>(&L.mbm[c * 2u]);
-                    const uint32_t bc = L.mbm[kBmW + c];
-                    idx[u] = (bc + __builtin_amdgcn_mbcnt_hi(wv.y, __builtin_amdgcn_mbcnt_lo(wv.x, 0u))) & 63u;
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < U; u++) mt[u] = L.mmeta[idx[u]];
-#pragma unroll
-                for (uint32_t u = 0; u < U; u++) {
-                    const uint32_t m = (c0 + u) * 64u + lane;
-                    const bool a = m < MT;
-                    da[u] = m + mt[u].x;                  /* absolute output position of this byte */
-                    ra[u] = da[u] - mt[u].y;              /* ... and of its source                  */
-                    const uint32_t d0 = uni(da[u]);       /* first byte of the chunk               */
-                    actv[u] = a;
-                    pendv[u] = a && ra[u] >= d0;
-                }
-            }
-#pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                if ((c0 + u) * 64u < MT) {
-                    st.chunks++;
-                    uint8_t *dp = &L.ring[da[u] & (R - 1u)];
-                    const uint8_t *sp = &L.ring[ra[u] & (R - 1u)];
-                    const uint32_t x = *sp;
-                    if (actv[u]) *dp = (uint8_t)x;
-                    /* a source inside this chunk's own span may not be written yet (or be a literal, which is):
-                     * everything below the first pending byte is final, so a pending byte whose source lies below
-                     * it can be taken; the first pending byte itself always can */
-                    bool pend = pendv[u];
-                    unsigned long long pm = __ballot(pend);
-                    while (pm != 0ull) {
-                        st.rounds++;
-                        const uint32_t f = ctz64(pm);
-                        const uint32_t F = lane_get(da[u], f);
-                        const bool rdy = pend && (ra[u] < F || lane == f);
-                        if (rdy) *dp = *sp;
-                        pm &= ~__ballot(rdy);
-                        pend = pend && !rdy;
-                    }
-                }
-            }
-        }
-    }
-    stamp(st, 6);
-    w.op = op0 + T; /* flushed by the next batch (or the general path), together with its own requests */
-}
-
-/*
  * One batch: sequences n0 .. n0+63 of the block start at the positions in the index row (epos = this lane's
  * entry).  Returns the number of sequences decoded (0: the caller takes one sequence through the general path).
  */
 template <uint32_t R>
-__device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const SeqLds<R> &L, uint32_t &vp, const uint32_t B,
+__device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const SeqLds<R, kT2> &L, uint32_t &vp, const uint32_t B,
                                          const uint32_t epos, const uint32_t navail, const uint16_t *__restrict__ trow,
                                          const uint32_t n0, const uint32_t ntab, uint32_t &epre, Stats &st)
 {
@@ -494,7 +317,7 @@ __device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const SeqLds<R> &L, uint32_
         __builtin_memcpy(&xfb, g + 16, 16);
     }
     stamp(st, 3);
-    seq_copy<R>(w, L, nseq, ostart, ll, ml, off, pos + k, T, isfar, xfa, xfb, st);
+    seq_copy<R, kT2>(w, L, nseq, ostart, ll, ml, off, pos + k, T, isfar, xfa, xfb, st);
     vp += used;
     stamp(st, 0);
     return nseq;
@@ -620,7 +443,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][R + 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_in[4][kInRing + 16];
     __shared__ __attribute__((aligned(8))) uint2 s_mmeta[4][64];
-    __shared__ __attribute__((aligned(8))) uint32_t s_mbm[4][kBmW + kNc];
+    __shared__ __attribute__((aligned(8))) uint32_t s_mbm[4][SeqLds<R, kT2>::kWords];
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = uni(threadIdx.x >> 6);
@@ -631,7 +454,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     const uint32_t csize = uni(src_size[blk]);
 
     Wave<R> w;
-    const SeqLds<R> L = {s_ring[wid], s_in[wid], s_mmeta[wid], s_mbm[wid]};
+    const SeqLds<R, kT2> L = {s_ring[wid], s_in[wid], s_mmeta[wid], s_mbm[wid]};
     w.ring = L.ring;
     w.in = L.in;
     w.lane = lane;
