@@ -247,20 +247,30 @@ int cryo_scan_next_batch(CryoRel *rel, void *iter_, int k, BlockNumber *starts, 
             const BlockNumber b = cryo_seqscan_iter_next(iter);
             const CryoPageHeader *pg;
             if (!BlockNumberIsValid(b) || b >= rel->ops->nblocks(rel->handle)) { want = nc; break; }
+#define RELEASE(x) do { if (rel->ops->release_page) rel->ops->release_page(rel->handle, (x)); } while (0)
             pg = (const CryoPageHeader *)rel->ops->read_page(rel->handle, b);
-            if (!pg || pg->base.pd_upper == 0 || pg->first != b) continue; /* empty page / continuation page */
+            if (!pg) continue;
+            if (pg->base.pd_upper == 0 || pg->first != b) { RELEASE(b); continue; } /* empty page / continuation page */
             {
                 /* exclude this chain's continuation pages now so they are not offered as candidates */
-                const CryoPageHeader *q = pg;
-                BlockNumber nb = q->next;
+                BlockNumber nb = pg->next;
                 uint32 guard = 0;
+                RELEASE(b);
                 while (BlockNumberIsValid(nb) && nb < rel->ops->nblocks(rel->handle) && guard++ < max_chain) {
+                    const CryoPageHeader *q;
+                    BlockNumber nn;
+                    bool mine;
                     cryo_seqscan_iter_exclude(iter, nb, true);
                     q = (const CryoPageHeader *)rel->ops->read_page(rel->handle, nb);
-                    if (!q || q->first != b) break;
-                    nb = q->next;
+                    if (!q) break;
+                    mine = q->first == b;
+                    nn = q->next;
+                    RELEASE(nb);
+                    if (!mine) break;
+                    nb = nn;
                 }
             }
+#undef RELEASE
             cand[nc++] = b;
         }
         if (nc == 0) break;

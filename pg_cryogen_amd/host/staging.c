@@ -50,6 +50,7 @@ int cryo_stage_write_chain(CryoRel *rel, BlockNumber first_block, CompressionMet
         memcpy(page + hdr_size, p, content);
         p += content;
         left -= content;
+        if (rel->ops->page_done) rel->ops->page_done(rel->handle, blocks[i], page);
     }
     *npages_out = npages;
     return 0;
@@ -96,36 +97,40 @@ CryoError cryo_stage_read_chain(CryoRel *rel, BlockNumber block, char **compress
     Size size, csize;
     char *buf, *p;
 
+#define RELEASE(b) do { if (rel->ops->release_page) rel->ops->release_page(rel->handle, (b)); } while (0)
     *compressed = NULL;
     *nblocks = 0;
-    if (!page || page->base.pd_upper == 0) /* PageIsNew */
-        return CRYO_ERR_EMPTY_BLOCK;
+    if (!page) return CRYO_ERR_EMPTY_BLOCK;
+    if (page->base.pd_upper == 0) { RELEASE(block); return CRYO_ERR_EMPTY_BLOCK; } /* PageIsNew */
     /* a BRIN bitmap scan may ask for a block in the middle of a chain (cache.c:122-130) */
-    if (page->first != block)
-        return CRYO_ERR_WRONG_STARTING_BLOCK;
+    if (page->first != block) { RELEASE(block); return CRYO_ERR_WRONG_STARTING_BLOCK; }
     fh = (const CryoFirstPageHeader *)page;
     size = csize = fh->compressed_size;
     *method = fh->compression_method;
     /* frozen blocks are flagged in the visibility map, not rewritten (cache.c:137-149) */
     *xid = rel->ops->all_frozen(rel->handle, block) ? FrozenTransactionId : fh->created_xid;
-    if (csize == 0) return CRYO_ERR_DECOMPRESSION_FAILED;
+    if (csize == 0) { RELEASE(block); return CRYO_ERR_DECOMPRESSION_FAILED; }
     p = buf = malloc(csize);
-    if (!buf) return CRYO_ERR_DECOMPRESSION_FAILED;
+    if (!buf) { RELEASE(block); return CRYO_ERR_DECOMPRESSION_FAILED; }
     if (*nblocks < max_blocks) blocks[(*nblocks)++] = block;
 
     for (;;) {
         const Size hdr_size = CryoPageHeaderSize(page, block);
         const Size l = MIN((Size)BLCKSZ - hdr_size, size);
+        const BlockNumber cur = block;
         memcpy(p, (const char *)page + hdr_size, l);
         p += l;
         size -= l;
         block = page->next;
+        RELEASE(cur);
         if (size == 0) break;
         if (!BlockNumberIsValid(block) || block >= rel->ops->nblocks(rel->handle)) break;
         page = (const CryoPageHeader *)rel->ops->read_page(rel->handle, block);
-        if (!page || page->first != first_block) break; /* broken chain */
+        if (!page) break;
+        if (page->first != first_block) { RELEASE(block); break; } /* broken chain */
         if (*nblocks < max_blocks) blocks[(*nblocks)++] = block;
     }
+#undef RELEASE
     if (size != 0) { /* chain shorter than compressed_size: the reference would decode garbage */
         free(buf);
         return CRYO_ERR_DECOMPRESSION_FAILED;
@@ -159,7 +164,7 @@ static BlockNumber mem_extend(void *r)
 static const char *mem_read(void *r, BlockNumber b) { CryoMemRel *m = r; return b < m->n ? m->pages[b] : NULL; }
 static char *mem_write(void *r, BlockNumber b) { CryoMemRel *m = r; return b < m->n ? m->pages[b] : NULL; }
 static bool mem_frozen(void *r, BlockNumber b) { CryoMemRel *m = r; return b < m->n && m->frozen[b]; }
-static const CryoRelOps mem_ops = {mem_nblocks, mem_read, mem_write, mem_extend, mem_frozen};
+static const CryoRelOps mem_ops = {mem_nblocks, mem_read, mem_write, mem_extend, mem_frozen, NULL, NULL};
 
 CryoMemRel *cryo_memrel_create(void)
 {

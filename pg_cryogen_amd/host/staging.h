@@ -33,6 +33,11 @@ typedef struct CryoRelOps {
     char *(*page_for_write)(void *rel, BlockNumber b);  /* buffer locked exclusive, WAL-registered */
     BlockNumber (*extend)(void *rel);                  /* P_NEW under the extension lock       */
     bool (*all_frozen)(void *rel, BlockNumber b);      /* visibilitymap ALL_FROZEN bit         */
+    /* optional (NULL in the in-memory harness): a written page is complete -- PageSetChecksumInplace, MarkBufferDirty,
+     * GenericXLogFinish, UnlockReleaseBuffer (reference pg_cryogen.c:798-805,823-824) */
+    void (*page_done)(void *rel, BlockNumber b, char *page);
+    /* optional: a page obtained with read_page is no longer needed -- ReleaseBuffer (reference cache.c:171) */
+    void (*release_page)(void *rel, BlockNumber b);
 } CryoRelOps;
 
 typedef struct CryoRel {
