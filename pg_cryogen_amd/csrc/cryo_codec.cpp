@@ -36,6 +36,12 @@ struct cryo_codec {
     size_t hb_src_cap = 0, hb_dst_cap = 0, hb_meta_cap = 0;
     void *pin = nullptr;
     size_t pin_cap = 0;
+    /* pipelined K-block calls: two pinned input and two pinned output staging buffers, a transfer stream for the
+     * device-to-host direction, events */
+    void *pipe_pin[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t pipe_pin_cap[4] = {0, 0, 0, 0};
+    hipStream_t xfer = nullptr;
+    hipEvent_t ev_in[2] = {nullptr, nullptr}, ev_k[2] = {nullptr, nullptr}, ev_out[2] = {nullptr, nullptr};
     /* side streams of the zstd batch pipeline (created on first use) */
     cryo::ZstdAux aux = {};
     bool have_aux = false;
@@ -91,6 +97,65 @@ int ensure_pinned(cryo_codec *c, size_t need)
     if (e != hipSuccess) return fail(c, e, "hipHostMalloc");
     c->pin_cap = need;
     return CRYO_OK;
+}
+
+int ensure_pipe(cryo_codec *c, int which, size_t need)
+{
+    if (c->pipe_pin_cap[which] >= need) return CRYO_OK;
+    if (c->pipe_pin[which]) { HIP_TRY(c, hipHostFree(c->pipe_pin[which])); c->pipe_pin[which] = nullptr; c->pipe_pin_cap[which] = 0; }
+    need += need / 8;
+    hipError_t e = hipHostMalloc(&c->pipe_pin[which], need, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return CRYO_E_NOMEM; }
+    if (e != hipSuccess) return fail(c, e, "hipHostMalloc");
+    c->pipe_pin_cap[which] = need;
+    return CRYO_OK;
+}
+
+int ensure_pipe_streams(cryo_codec *c)
+{
+    if (c->xfer) return CRYO_OK;
+    HIP_TRY(c, hipStreamCreateWithFlags(&c->xfer, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_in[i], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_k[i], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_out[i], hipEventDisableTiming));
+    }
+    return CRYO_OK;
+}
+
+/* host copies of a K-block call, spread over a few threads (one thread moves ~8 GB/s; the staging copies of a
+ * 4096-block call were its longest part) */
+struct CopyJob { void *dst; const void *src; size_t len; };
+unsigned host_threads()
+{
+    static const unsigned v = [] {
+        const char *e = getenv("CRYO_HOST_THREADS");
+        unsigned t = e ? (unsigned)atoi(e) : 8u, hw = std::thread::hardware_concurrency();
+        if (hw && t > hw) t = hw;
+        return t < 1u ? 1u : t;
+    }();
+    return v;
+}
+void parallel_copy(const std::vector<CopyJob> &jobs)
+{
+    size_t total = 0;
+    for (const CopyJob &j : jobs) total += j.len;
+    const unsigned T = total < (4u << 20) ? 1u : host_threads();
+    if (T == 1u) { for (const CopyJob &j : jobs) memcpy(j.dst, j.src, j.len); return; }
+    /* equal byte shares: thread t takes the jobs (or parts of jobs) covering bytes [t, t+1) * total / T */
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < T; t++)
+        th.emplace_back([&, t] {
+            const size_t lo = total * t / T, hi = total * (t + 1) / T;
+            size_t pos = 0;
+            for (const CopyJob &j : jobs) {
+                const size_t a = pos > lo ? pos : lo, b = pos + j.len < hi ? pos + j.len : hi;
+                if (a < b) memcpy((uint8_t *)j.dst + (a - pos), (const uint8_t *)j.src + (a - pos), b - a);
+                pos += j.len;
+                if (pos >= hi) break;
+            }
+        });
+    for (auto &x : th) x.join();
 }
 
 int ensure_ws(cryo_codec *c, size_t need)
@@ -159,6 +224,13 @@ void cryo_codec_close(cryo_codec *c)
     if (c->hb_dst) (void)hipFree(c->hb_dst);
     if (c->hb_meta) (void)hipFree(c->hb_meta);
     if (c->pin) (void)hipHostFree(c->pin);
+    for (int i = 0; i < 4; i++) if (c->pipe_pin[i]) (void)hipHostFree(c->pipe_pin[i]);
+    if (c->xfer) { (void)hipStreamSynchronize(c->xfer); (void)hipStreamDestroy(c->xfer); }
+    for (int i = 0; i < 2; i++) {
+        if (c->ev_in[i]) (void)hipEventDestroy(c->ev_in[i]);
+        if (c->ev_k[i]) (void)hipEventDestroy(c->ev_k[i]);
+        if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]);
+    }
     for (int l = 0; l < 2; l++) {
         if (c->aux.lane[l]) { (void)hipStreamSynchronize(c->aux.lane[l]); (void)hipStreamDestroy(c->aux.lane[l]); }
         if (c->aux.join[l]) (void)hipEventDestroy(c->aux.join[l]);
@@ -372,6 +444,201 @@ int cryo_codec_decompress_block(cryo_codec *c, int method, const void *h_src, si
 }
 
 /* ---- K blocks, host buffers ---- */
+} /* extern "C" */
+
+/* ---- pipelined K-block calls -------------------------------------------------------------------------------
+ * A call with tens of megabytes is cut into chunks; while chunk c runs on the GPU, chunk c+1 is gathered into a
+ * pinned buffer by a few host threads and chunk c-1 travels back on a second stream and is scattered to the
+ * caller's memory.  One chunk's life: host gather -> H2D (codec stream) -> kernel(s) (codec stream) -> D2H
+ * (transfer stream) -> host scatter.  The one-shot path (one H2D of everything, the kernel, one D2H from pageable
+ * memory, single-threaded copies) reached 13-19 GB/s on 4096 x 128 KiB, a quarter of the link. */
+static size_t pipe_chunk_blocks(size_t n, size_t block_size, int method)
+{
+    (void)method;
+    size_t k = (n + 7) / 8;
+    const size_t min_blocks = (8u << 20) / block_size + 1; /* at least 8 MiB per chunk */
+    if (k < min_blocks) k = min_blocks;
+    return (k + 63) & ~(size_t)63;
+}
+/* one block is one wavefront's serial job: a launch needs thousands of blocks to fill the chip, so kernels run per
+ * chunk only when a chunk still has that many (LZ4 decode of 128 KiB blocks); otherwise the transfers are chunked
+ * around ONE launch over the whole call (the encoders took 8 x longer cut in eight) */
+static bool pipe_kernel_per_chunk(size_t chunk_blocks, int method, bool encode)
+{
+    return !encode && method == CRYO_METHOD_LZ4 && chunk_blocks >= 512;
+}
+
+static int compress_blocks_piped(cryo_codec *c, int method, int param, const uint8_t *h_src, size_t block_size, size_t n,
+                                 uint8_t *h_dst, size_t dst_stride, uint32_t *h_out_size)
+{
+    const size_t bound = cryo_codec_bound(method, block_size);
+    const size_t dstride = (bound + 15) & ~(size_t)15;
+    const size_t K = pipe_chunk_blocks(n, block_size, method), nch = (n + K - 1) / K;
+    int rc;
+    if ((rc = ensure_pipe_streams(c)) != CRYO_OK) return rc;
+    if ((rc = ensure(c, &c->hb_src, &c->hb_src_cap, n * block_size + 64)) != CRYO_OK) return rc;
+    if ((rc = ensure(c, &c->hb_dst, &c->hb_dst_cap, n * dstride + 64)) != CRYO_OK) return rc;
+    if ((rc = ensure(c, &c->hb_meta, &c->hb_meta_cap, n * 16 + 64)) != CRYO_OK) return rc;
+    if ((rc = ensure_pinned(c, n * 8 + 64)) != CRYO_OK) return rc;
+    for (int b = 0; b < 2; b++) {
+        if ((rc = ensure_pipe(c, b, K * block_size)) != CRYO_OK) return rc;
+        if ((rc = ensure_pipe(c, 2 + b, K * dstride)) != CRYO_OK) return rc;
+    }
+    uint32_t *d_sz = (uint32_t *)c->hb_meta;
+    int32_t *d_st = (int32_t *)(c->hb_meta + ((n * 4 + 15) & ~(size_t)15));
+    uint32_t *p_sz = (uint32_t *)c->pin;
+    int32_t *p_st = (int32_t *)((uint8_t *)c->pin + n * 4);
+    /* in: host gather of chunk c+1 overlaps the H2D of chunk c */
+    for (size_t ch = 0; ch < nch; ch++) {
+        const size_t lo = ch * K, hi = lo + K < n ? lo + K : n, cnt = hi - lo;
+        const int b = (int)(ch & 1);
+        if (ch >= 2) HIP_TRY(c, hipEventSynchronize(c->ev_in[b])); /* staging buffer b has left for the device */
+        parallel_copy({{c->pipe_pin[b], h_src + lo * block_size, cnt * block_size}});
+        HIP_TRY(c, hipMemcpyAsync(c->hb_src + lo * block_size, c->pipe_pin[b], cnt * block_size, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipEventRecord(c->ev_in[b], c->stream));
+    }
+    rc = cryo_codec_compress_batch(c, method, param, c->hb_src, block_size, (uint32_t)block_size, n, c->hb_dst, dstride, d_sz, d_st);
+    if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
+    HIP_TRY(c, hipMemcpyAsync(p_sz, d_sz, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(p_st, d_st, n * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (size_t i = 0; i < n; i++) {
+        if (p_st[i] != CRYO_OK) return p_st[i];
+        if (p_sz[i] == 0 || p_sz[i] > bound) return CRYO_E_HIP;
+        h_out_size[i] = p_sz[i];
+    }
+    /* out: the D2H of chunk c+1 overlaps the host scatter of chunk c; only the bytes the blocks occupy travel */
+    auto d2h = [&](size_t ch) -> int {
+        const size_t lo = ch * K, hi = lo + K < n ? lo + K : n;
+        HIP_TRY(c, hipMemcpyAsync(c->pipe_pin[2 + (ch & 1)], c->hb_dst + lo * dstride, (hi - lo - 1) * dstride + p_sz[hi - 1],
+                                  hipMemcpyDeviceToHost, c->xfer));
+        HIP_TRY(c, hipEventRecord(c->ev_out[ch & 1], c->xfer));
+        return CRYO_OK;
+    };
+    if ((rc = d2h(0)) != CRYO_OK) return rc;
+    for (size_t ch = 0; ch < nch; ch++) {
+        const size_t lo = ch * K, hi = lo + K < n ? lo + K : n;
+        if (ch + 1 < nch && (rc = d2h(ch + 1)) != CRYO_OK) return rc;
+        HIP_TRY(c, hipEventSynchronize(c->ev_out[ch & 1]));
+        const uint8_t *po = (const uint8_t *)c->pipe_pin[2 + (ch & 1)];
+        std::vector<CopyJob> jobs;
+        for (size_t i = lo; i < hi; i++) jobs.push_back({h_dst + i * dst_stride, po + (i - lo) * dstride, p_sz[i]});
+        parallel_copy(jobs);
+    }
+    return CRYO_OK;
+}
+
+static int decompress_blocks_piped(cryo_codec *c, int method, const void *const *h_src, const uint32_t *h_src_size, size_t n,
+                                   uint8_t *h_dst, size_t block_size, int32_t *h_status)
+{
+    const size_t K = pipe_chunk_blocks(n, block_size, method), nch = (n + K - 1) / K;
+    const bool per_chunk = pipe_kernel_per_chunk(K, method, false);
+    /* device layout of the compressed side: [offsets u64 x n][sizes u32 x n][blocks, 16-byte aligned] */
+    const size_t o_off = 0, o_sz = n * 8, o_data = (n * 12 + 63) & ~(size_t)63;
+    std::vector<uint64_t> pos(n + 1);
+    size_t total = 0, max_chunk_in = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (h_src_size[i] != 0 && !h_src[i]) return CRYO_E_ARG;
+        pos[i] = total;
+        total += ((size_t)h_src_size[i] + 15) & ~(size_t)15;
+    }
+    pos[n] = total;
+    for (size_t ch = 0; ch < nch; ch++) {
+        const size_t lo = ch * K, hi = lo + K < n ? lo + K : n;
+        if (pos[hi] - pos[lo] > max_chunk_in) max_chunk_in = pos[hi] - pos[lo];
+    }
+    int rc;
+    if ((rc = ensure_pipe_streams(c)) != CRYO_OK) return rc;
+    if ((rc = ensure_pinned(c, o_data + n * 4 + 64)) != CRYO_OK) return rc;
+    if ((rc = ensure(c, &c->hb_src, &c->hb_src_cap, o_data + total + 64)) != CRYO_OK) return rc;
+    if ((rc = ensure(c, &c->hb_dst, &c->hb_dst_cap, n * block_size + 64)) != CRYO_OK) return rc;
+    if ((rc = ensure(c, &c->hb_meta, &c->hb_meta_cap, n * 16 + 64)) != CRYO_OK) return rc;
+    for (int b = 0; b < 2; b++) {
+        if ((rc = ensure_pipe(c, b, max_chunk_in + 64)) != CRYO_OK) return rc;
+        if ((rc = ensure_pipe(c, 2 + b, K * block_size)) != CRYO_OK) return rc;
+    }
+    uint8_t *pin = (uint8_t *)c->pin;
+    uint64_t *p_off = (uint64_t *)(pin + o_off);
+    uint32_t *p_sz = (uint32_t *)(pin + o_sz);
+    int32_t *p_st = (int32_t *)(pin + o_data);
+    for (size_t i = 0; i < n; i++) { p_off[i] = o_data + pos[i]; p_sz[i] = h_src_size[i]; }
+    HIP_TRY(c, hipMemcpyAsync(c->hb_src, pin, o_data, hipMemcpyHostToDevice, c->stream));
+    int32_t *d_st = (int32_t *)c->hb_meta;
+    const uint64_t *d_off = (const uint64_t *)(c->hb_src + o_off);
+    const uint32_t *d_sz = (const uint32_t *)(c->hb_src + o_sz);
+    auto scatter = [&](size_t ch) -> int {
+        const size_t lo = ch * K, hi = lo + K < n ? lo + K : n;
+        HIP_TRY(c, hipEventSynchronize(c->ev_out[ch & 1]));
+        parallel_copy({{h_dst + lo * block_size, c->pipe_pin[2 + (ch & 1)], (hi - lo) * block_size}});
+        return CRYO_OK;
+    };
+    for (size_t ch = 0; ch < nch; ch++) {
+        const size_t lo = ch * K, hi = lo + K < n ? lo + K : n, cnt = hi - lo;
+        const int b = (int)(ch & 1);
+        if (ch >= 2) HIP_TRY(c, hipEventSynchronize(c->ev_in[b]));
+        {
+            uint8_t *pi = (uint8_t *)c->pipe_pin[b];
+            std::vector<CopyJob> jobs;
+            for (size_t i = lo; i < hi; i++)
+                if (h_src_size[i]) jobs.push_back({pi + (pos[i] - pos[lo]), h_src[i], h_src_size[i]});
+            parallel_copy(jobs);
+        }
+        if (pos[hi] > pos[lo])
+            HIP_TRY(c, hipMemcpyAsync(c->hb_src + o_data + pos[lo], c->pipe_pin[b], pos[hi] - pos[lo], hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipEventRecord(c->ev_in[b], c->stream));
+        if (!per_chunk) continue;
+        rc = cryo_codec_decompress_batch(c, method, c->hb_src, d_off + lo, d_sz + lo, c->hb_dst + lo * block_size, block_size,
+                                         (uint32_t)block_size, cnt, d_st + lo);
+        if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); (void)hipStreamSynchronize(c->xfer); return rc; }
+        HIP_TRY(c, hipEventRecord(c->ev_k[b], c->stream));
+        if (ch >= 2 && (rc = scatter(ch - 2)) != CRYO_OK) return rc; /* frees output buffer b */
+        HIP_TRY(c, hipStreamWaitEvent(c->xfer, c->ev_k[b], 0));
+        HIP_TRY(c, hipMemcpyAsync(c->pipe_pin[2 + b], c->hb_dst + lo * block_size, cnt * block_size, hipMemcpyDeviceToHost, c->xfer));
+        HIP_TRY(c, hipEventRecord(c->ev_out[b], c->xfer));
+    }
+    if (!per_chunk) {
+        /* one launch over the whole call, then the D2H of chunk c+1 overlaps the host scatter of chunk c */
+        rc = cryo_codec_decompress_batch(c, method, c->hb_src, d_off, d_sz, c->hb_dst, block_size, (uint32_t)block_size, n, d_st);
+        if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
+        HIP_TRY(c, hipEventRecord(c->ev_k[0], c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->xfer, c->ev_k[0], 0));
+        auto d2h = [&](size_t ch) -> int {
+            const size_t lo = ch * K, hi = lo + K < n ? lo + K : n;
+            HIP_TRY(c, hipMemcpyAsync(c->pipe_pin[2 + (ch & 1)], c->hb_dst + lo * block_size, (hi - lo) * block_size, hipMemcpyDeviceToHost, c->xfer));
+            HIP_TRY(c, hipEventRecord(c->ev_out[ch & 1], c->xfer));
+            return CRYO_OK;
+        };
+        if ((rc = d2h(0)) != CRYO_OK) return rc;
+        for (size_t ch = 0; ch < nch; ch++) {
+            if (ch + 1 < nch) {
+                if (ch >= 1) { /* buffer (ch+1)&1 was scattered in the previous iteration */ }
+                if ((rc = d2h(ch + 1)) != CRYO_OK) return rc;
+            }
+            if ((rc = scatter(ch)) != CRYO_OK) return rc;
+        }
+        HIP_TRY(c, hipMemcpyAsync(p_st, d_st, n * 4, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        memcpy(h_status, p_st, n * 4);
+        return CRYO_OK;
+    }
+    HIP_TRY(c, hipMemcpyAsync(p_st, d_st, n * 4, hipMemcpyDeviceToHost, c->stream));
+    for (size_t ch = nch >= 2 ? nch - 2 : 0; ch < nch; ch++)
+        if ((rc = scatter(ch)) != CRYO_OK) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    memcpy(h_status, p_st, n * 4);
+    return CRYO_OK;
+}
+
+static bool pipe_worth_it(size_t n, size_t block_size)
+{
+    static const size_t min_bytes = [] {
+        const char *e = getenv("CRYO_PIPE_MIN_MB"); /* 0 = always, huge = never */
+        return (size_t)(e ? atoll(e) : 64) << 20;
+    }();
+    return n * block_size >= min_bytes && n >= 128;
+}
+extern "C" {
+
 /* K blocks from / to host memory.  Device buffers and the pinned staging buffer live in the handle
  * (grow-only); transfers are bulk: one H2D of the K blocks, one D2H of the K output slots. */
 int cryo_codec_compress_blocks(cryo_codec *c, int method, int param, const void *h_src, size_t block_size,
@@ -383,6 +650,8 @@ int cryo_codec_compress_blocks(cryo_codec *c, int method, int param, const void 
     if (!h_src || !h_dst || !h_out_size) return CRYO_E_ARG;
     const size_t bound = cryo_codec_bound(method, block_size);
     if (dst_stride < bound) return CRYO_E_DSTSIZE;
+    if (pipe_worth_it(n, block_size))
+        return compress_blocks_piped(c, method, param, (const uint8_t *)h_src, block_size, n, (uint8_t *)h_dst, dst_stride, h_out_size);
     /* the device slots use the caller's stride, so the output goes back in one copy (a slot may be
      * written beyond out_size[i], up to bound) */
     const bool bulk = dst_stride <= bound + 4096;
@@ -421,6 +690,8 @@ static int decompress_blocks_impl(cryo_codec *c, int method, const void *const *
     if (!c || !method_ok(method) || block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
     if (n == 0) return CRYO_OK;
     if (!h_src || !h_src_size || (!h_dst && !h_dst_each) || !h_status) return CRYO_E_ARG;
+    if (h_dst && pipe_worth_it(n, block_size))
+        return decompress_blocks_piped(c, method, h_src, h_src_size, n, (uint8_t *)h_dst, block_size, h_status);
     /* pinned staging: [offsets u64 x n][sizes u32 x n][compressed blocks, 16-byte aligned], sent in one copy */
     const size_t o_off = 0, o_sz = n * 8, o_data = (n * 12 + 63) & ~(size_t)63;
     size_t total = 0;

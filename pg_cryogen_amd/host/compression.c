@@ -178,7 +178,8 @@ char *cryo_compress(CompressionMethod method, const char *data, Size *compressed
         if (rc == CRYO_E_UNSUPPORTED)   /* same ERROR as the reference, with the reason (this build has no kernel for it) */
             elog(ERROR, "pg_cryogen: compression failed (no GPU kernel for %s parameter %d at block size %lu)",
                  method == COMP_LZ4 ? "lz4" : "zstd", method_param(method), (unsigned long)cryo_blcksz);
-        elog(ERROR, "pg_cryogen: compression failed");
+        else
+            elog(ERROR, "pg_cryogen: compression failed");
         return NULL;
     }
     *compressed_size = csize;

@@ -1,0 +1,2 @@
+#!/bin/bash
+timeout 900 python3 -m pytest tests/test_gpu_host.py -x -q -m gpu 2>&1 | tail -30

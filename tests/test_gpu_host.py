@@ -222,3 +222,40 @@ def test_gpu_seqscan_read_ahead_through_hip_codec(HG):
     assert not errors
     L.cryo_seqscan_iter_free(it)
     L.cryo_memrel_destroy(mem)
+
+
+def test_c_host_batch_api_pipelined_path(codec, oracle):
+    """K-block calls of 64 MiB and more are cut into chunks that overlap host copies, PCIe transfers and kernels
+    (two pinned buffers each way, a second stream): same bytes, sizes and statuses as the one-shot path -- odd
+    chunk tails, a padded destination stride, a corrupt block and an empty one among the inputs."""
+    from pg_cryogen_amd import METHOD_LZ4, METHOD_ZSTD, bound
+    L = codec.L
+    B, n = 131072, 777                       # 97 MiB: 8 / 4 chunks with a ragged last one
+    uniq = [oracle.synth(9, i, B, i % 5) for i in range(24)]
+    raw = np.concatenate([uniq[i % 24] for i in range(n)])
+    for method, param in ((METHOD_LZ4, 1), (METHOD_ZSTD, 1)):
+        enc = (oracle.lz4_compress if method == METHOD_LZ4 else oracle.zstd_compress)
+        exp = [enc(u, param) for u in uniq]
+        stride = bound(method, B) + 4096 + 40        # padded, not a multiple of 16
+        out = np.zeros(n * stride, np.uint8)
+        sizes = np.zeros(n, np.uint32)
+        rc = L.cryo_codec_compress_blocks(codec.h, method, param, raw.ctypes.data, B, n, out.ctypes.data, stride, sizes.ctypes.data)
+        assert rc == 0
+        comps = []
+        for i in range(n):
+            e = exp[i % 24]
+            assert int(sizes[i]) == len(e) and np.array_equal(out[i * stride:i * stride + len(e)], e), (method, i)
+            comps.append(np.ascontiguousarray(out[i * stride:i * stride + len(e)]))
+        comps[300] = comps[300][:200].copy()         # truncated
+        comps[301] = np.zeros(0, np.uint8)           # empty
+        ptrs = (C.c_void_p * n)(*[c.ctypes.data if len(c) else None for c in comps])
+        csz = np.array([len(c) for c in comps], np.uint32)
+        dec = np.full(n * B, 0x5A, np.uint8)
+        st = np.zeros(n, np.int32)
+        rc = L.cryo_codec_decompress_blocks(codec.h, method, ptrs, csz.ctypes.data, n, dec.ctypes.data, B, st.ctypes.data)
+        assert rc == 0
+        for i in range(n):
+            if i in (300, 301):
+                assert st[i] != 0, i
+            else:
+                assert st[i] == 0 and np.array_equal(dec[i * B:(i + 1) * B], uniq[i % 24]), (method, i)
