@@ -65,18 +65,18 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     const uint64_t blk = (uint64_t)blockIdx.x * kIdxLanes + (lane & (kIdxLanes - 1u));
     const bool owner = blk < n_blocks;
     /* stream of this lane's block, in "virtual" positions: vp = delta + offset in the block, so that chunk
-     * addresses are 16-byte aligned */
+     * addresses are 128-byte aligned */
     uint64_t aoff = 0;
     uint32_t delta = 0, vend = 0;
     if (owner) {
         const uint64_t o = src_off[blk];
-        aoff = o & ~(uint64_t)15;
-        delta = (uint32_t)(o & 15u);
+        aoff = o & ~(uint64_t)127;     /* chunks are whole 128-byte lines: each line of the input is fetched once */
+        delta = (uint32_t)(o & 127u);
         vend = delta + src_size[blk];
     }
     uint16_t *row = tbl + blk * cap;
-    uint16_t *dummy = tbl + n_blocks * cap + lane * 4u; /* 8 bytes per lane behind the rows: where lanes without a block store */
-    if (!owner) aoff = src_off[0] & ~(uint64_t)15; /* a lane past the end of the batch re-reads block 0 */
+    uint16_t *dummy = tbl + n_blocks * cap + lane * 8u; /* 8 bytes per lane behind the rows: where lanes without a block store */
+    if (!owner) aoff = src_off[0] & ~(uint64_t)127; /* a lane past the end of the batch re-reads block 0 */
     uint8_t *ring = s_ring + (lane & (kIdxLanes - 1u)) * kIdxStride;
     uint32_t pos = delta;        /* next byte to interpret */
     uint32_t requested = 0;      /* chunks requested up to here (multiple of kIdxChunk) */
@@ -85,7 +85,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     uint32_t state = 0;          /* 0 token, 1 literal-length extension, 2 match-length extension */
     uint32_t acc = 0, tm = 0;    /* literal length being accumulated; match nibble of the current token */
     uint32_t k = 0;
-    unsigned long long pack = 0;
+    unsigned long long pack = 0, packp = 0; /* the group of four positions being filled, the one before it */
     bool done = !owner || vend == delta;
 
     /* what this lane serves in turn j: one 16-byte piece of the next chunk of blocks 16j + (lane >> 3) and
@@ -162,7 +162,8 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             /* record + advance */
             const bool rec = tok;
             if (rec) {
-                pack = (pack >> 16) | ((unsigned long long)((pos - delta) & 0xffffu) << 48);
+                const unsigned long long e = (unsigned long long)((pos - delta) & 0xffffu) << (16u * (k & 3u));
+                if ((k & 3u) == 0u) { packp = pack; pack = e; } else pack |= e;
                 k++;
                 tm = tmn;
             }
@@ -195,11 +196,15 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     };
 
     auto put = [&]() __attribute__((always_inline)) {
-        /* the last four positions go out once per round (a lane gains at most four per round; re-writing older
-         * entries with the same values is harmless): one unconditional store, see the note on the loads */
-        const uint32_t at = k >= 4u ? k - 4u : 0u;
-        const unsigned long long v = k >= 4u ? pack : (k ? pack >> (16u * (4u - k)) : 0ull);
-        __builtin_memcpy((owner ? row : dummy) + at, &v, 8);
+        /* positions go out in aligned groups of four (8 bytes): once per round the group being filled and the one
+         * before it (a lane gains at most four positions per round, so no group is missed); a group is stored a few
+         * times while it fills, always whole and aligned, so the L2 merges the stores of a row into full lines.
+         * (Storing "the last four entries" at a 2-byte granular address instead wrote 5.2 GB for a 0.8 GB index.)
+         * Two unconditional stores per round, see the note on the loads. */
+        const uint32_t g = k ? (k - 1u) >> 2 : 0u;
+        uint16_t *r = owner ? row : dummy;
+        __builtin_memcpy(r + 4u * (g ? g - 1u : 0u), g ? &packp : &pack, 8);
+        __builtin_memcpy(r + 4u * g, &pack, 8);
     };
 #define IDX_TURN(j, n) turn(j, fd##n, fe##n, fa##n, fb##n, fp##n, fq##n, fo##n, saoff[2 * j], svend[2 * j], saoff[2 * j + 1], svend[2 * j + 1]);
 #define IDX_ROUND(a, b, c, d)                                   \
@@ -214,9 +219,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
 #undef IDX_ROUND
 #undef IDX_TURN
     if (owner) {
-        const uint32_t at = k >= 4u ? k - 4u : 0u;
-        const unsigned long long v = k >= 4u ? pack : (k ? pack >> (16u * (4u - k)) : 0ull);
-        __builtin_memcpy(row + at, &v, 8);
+        put();
         tbl_n[blk] = k;
     }
 }
@@ -300,9 +303,10 @@ __device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const SeqLds<R, kT2> &L, ui
     const unsigned long long badmask = __ballot(!ok);
     const uint32_t nseq = badmask ? ctz64(badmask) : 64u;
     stamp(st, 1);
-    w.flush();   /* what earlier batches produced; far sources below are read back from it */
+    if (!(st.ablate & 2u)) w.flush();   /* what earlier batches produced; far sources below are read back from it */
+    else w.flushed = w.op & ~(kChunk - 1u);
     stamp(st, 2);
-    w.top_up();
+    if (!(st.ablate & 4u)) w.top_up(); else w.nstale = 0;
     if (nseq == 0u) return 0;
     const uint32_t T = lane_get(oend, nseq - 1u);
     const uint32_t used = lane_get(pos + dlen, nseq - 1u) - vp;
@@ -311,7 +315,7 @@ __device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const SeqLds<R, kT2> &L, ui
     if (n0 + nseq + lane < ntab) epre = trow[n0 + nseq + lane];
     /* ... and so are the sources of its far matches (flushed output: off >= T + 1023 behind a match) */
     uint4 xfa = make_uint4(0, 0, 0, 0), xfb = xfa;
-    if (lane < nseq && isfar) {
+    if (lane < nseq && isfar && !(st.ablate & 1u)) {
         const uint8_t *g = w.dst + (mabs - off);
         __builtin_memcpy(&xfa, g, 16);
         __builtin_memcpy(&xfb, g + 16, 16);
@@ -458,7 +462,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     w.ring = L.ring;
     w.in = L.in;
     w.lane = lane;
-    w.delta = (uint32_t)(reinterpret_cast<uintptr_t>(base) & 15u);
+    w.delta = (uint32_t)(reinterpret_cast<uintptr_t>(base) & 127u); /* staging chunks are whole lines */
     w.abase = base - w.delta;
     w.vend = w.delta + csize;
     w.in_hi = 0;
@@ -564,6 +568,8 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
         unsigned long long *d_st = nullptr, h_st[16];
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
+        static const unsigned long long abl = getenv("CRYO_LZ4_ABLATE") ? strtoull(getenv("CRYO_LZ4_ABLATE"), nullptr, 0) : 0ull; /* timing experiments: wrong bytes */
+        (void)hipMemcpyAsync(d_st + 7, &abl, sizeof abl, hipMemcpyHostToDevice, s);
         hipLaunchKernelGGL((k_lz4_dec_seq<4096, true>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
                            block_size, n_blocks, d_status, d_st, tbl, cap, tbl_n);
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
