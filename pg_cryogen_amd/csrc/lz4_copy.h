@@ -24,7 +24,7 @@ namespace {
 #define LDS_FENCE() asm volatile("" ::: "memory")
 
 template <uint32_t R, uint32_t TMAX>
-struct SeqLds {
+struct CopyLds {
     static constexpr uint32_t kBmW = TMAX / 32; /* bitmap words of match space      */
     static constexpr uint32_t kNc = TMAX / 64;  /* chunks of match space (at most)  */
     static constexpr uint32_t kWords = kBmW + kNc;
@@ -76,12 +76,12 @@ __device__ inline void lane_runs(uint8_t *ring, const uint8_t *sbase, uint32_t r
  *   isfar: the match's source is no longer in the ring; its bytes are in xfa/xfb (requested by the caller).
  */
 template <uint32_t R, uint32_t TMAX>
-__device__ inline void seq_copy(Wave<R> &w, const SeqLds<R, TMAX> &L, const uint32_t nseq, const uint32_t ostart,
+__device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uint32_t nseq, const uint32_t ostart,
                                 const uint32_t ll, const uint32_t ml, const uint32_t off, const uint32_t lpos,
                                 const uint32_t T, const bool isfar, const uint4 xfa, const uint4 xfb, Stats &st)
 {
     static_assert(R - TMAX >= TMAX + 1023u, "an offset must be either in the ring or flushed");
-    constexpr uint32_t kBmW = SeqLds<R, TMAX>::kBmW, kNc = SeqLds<R, TMAX>::kNc;
+    constexpr uint32_t kBmW = CopyLds<R, TMAX>::kBmW, kNc = CopyLds<R, TMAX>::kNc;
     const uint32_t lane = w.lane;
     const uint32_t op0 = w.op;
     const bool act = lane < nseq;

@@ -68,9 +68,6 @@
 #ifndef LZ4_WAVES_PER_SIMD
 #define LZ4_WAVES_PER_SIMD 4 /* LDS admits 4 workgroups of 4 waves per CU: let the register allocator use what that leaves */
 #endif
-#ifndef LZ4_HALVES
-#define LZ4_HALVES 2   /* copy passes work on kNCh / LZ4_HALVES chunks at a time (register arrays) */
-#endif
 
 namespace cryo {
 
@@ -260,7 +257,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
         __builtin_memcpy(&xfb, g + 16, 16);
     }
     stamp(st, 3);
-    const SeqLds<R, kTMax> SL = {L.ring, L.in, L.mmeta, L.bm};
+    const CopyLds<R, kTMax> SL = {L.ring, L.in, L.mmeta, L.bm};
     seq_copy<R, kTMax>(w, SL, nseq, ostart, ll, ml, off, pos + k, T, isfar, xfa, xfb, st);
     vp += *used;
     stamp(st, 0);

@@ -243,7 +243,7 @@ __device__ inline uint32_t lane_next(uint32_t v)
  * entry).  Returns the number of sequences decoded (0: the caller takes one sequence through the general path).
  */
 template <uint32_t R>
-__device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const SeqLds<R, kT2> &L, uint32_t &vp, const uint32_t B,
+__device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const CopyLds<R, kT2> &L, uint32_t &vp, const uint32_t B,
                                          const uint32_t epos, const uint32_t navail, const uint16_t *__restrict__ trow,
                                          const uint32_t n0, const uint32_t ntab, uint32_t &epre, Stats &st)
 {
@@ -447,7 +447,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][R + 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_in[4][kInRing + 16];
     __shared__ __attribute__((aligned(8))) uint2 s_mmeta[4][64];
-    __shared__ __attribute__((aligned(8))) uint32_t s_mbm[4][SeqLds<R, kT2>::kWords];
+    __shared__ __attribute__((aligned(8))) uint32_t s_mbm[4][CopyLds<R, kT2>::kWords];
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = uni(threadIdx.x >> 6);
@@ -458,7 +458,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     const uint32_t csize = uni(src_size[blk]);
 
     Wave<R> w;
-    const SeqLds<R, kT2> L = {s_ring[wid], s_in[wid], s_mmeta[wid], s_mbm[wid]};
+    const CopyLds<R, kT2> L = {s_ring[wid], s_in[wid], s_mmeta[wid], s_mbm[wid]};
     w.ring = L.ring;
     w.in = L.in;
     w.lane = lane;

@@ -10,9 +10,6 @@
 #ifndef CRYO_LZ_COMMON_H
 #define CRYO_LZ_COMMON_H
 
-#ifndef LZ4_HALVES
-#define LZ4_HALVES 2   /* copy passes work on kNCh / LZ4_HALVES chunks at a time (register arrays) */
-#endif
 
 #include "kernels.h"
 
@@ -307,21 +304,7 @@ __device__ inline void wave_copy_match(Wave<R> &w, uint32_t off, uint32_t ml)
 }
 
 
-/* ---------------------------------------------------------------------------------------------
- * Batch copy: execute up to 64 non-overlapping LZ sequences (one per lane) one output byte per lane.
- *
- *   (bm must hold kTMax/32 + 16 words.)
- *   lane i < nseq holds sequence i: ostart = its first output byte (offset inside the batch),
- *   ll literal bytes followed by a match at distance `off` (off >= match length), its literals at
- *   input-ring index (ostart + lit_rel + j) & kInMask; T = total output bytes (<= kTMax).
- *
- * A bitmap of sequence starts + mbcnt maps every output byte to its sequence.  Pass A classifies
- * each byte (literal / near match / far match), computes its LDS source address once and requests
- * every far-match byte of the batch from the already flushed output in HBM/L2 (one memory latency
- * per batch).  Pass B walks the 64-byte chunks in order: a byte whose source is not inside the
- * chunk itself is final after one LDS read; sources inside the chunk are resolved in rounds guarded
- * by a ballot of finished lanes.  Used by the LZ4 and the zstd block decoders.
- * --------------------------------------------------------------------------------------------- */
+/* (the copy engine of the block decoders lives in lz4_copy.h) */
 constexpr uint32_t kTMax = 1024;  /* output bytes per batch (16 chunks of 64) */
 constexpr uint32_t kNCh = kTMax / 64;
 
@@ -342,122 +325,6 @@ __device__ inline void stamp(Stats &st, int k)
     }
 }
 
-
-template <uint32_t R>
-__device__ inline void batch_copy(Wave<R> &w, const uint8_t *__restrict__ in, unsigned long long *meta,
-                                  uint32_t *__restrict__ bm, const uint32_t nseq, const uint32_t ostart,
-                                  const uint32_t ll, const uint32_t off, const uint32_t lit_rel, const uint32_t T,
-                                  Stats &st)
-{
-    static_assert(R >= 4096, "ring must hold kTMax new bytes plus the near window");
-    constexpr uint32_t kNear = R - kTMax - 64u;
-    const uint32_t lane = w.lane;
-    st.batches++;
-    st.batch_seqs += nseq;
-    /* bm: bit (s - 1) set for every sequence start s >= 1 of the batch, so that the number of set bits BELOW an
-     * output position q is the index of the sequence q belongs to (the first sequence starts at 0 and has no
-     * bit); bm[kTMax/32 + c] = set bits before chunk c */
-    if (lane < kTMax / 32u) bm[lane] = 0u;
-    if (lane < nseq) {
-        /* per sequence: lo = litend (11 bits, <= kTMax) | off << 11 (21 bits: zstd windows up to 2 MiB); hi = (first literal's input-ring index) - ostart, so
-         * that a literal byte at batch offset qo sits at input-ring index (qo + hi) & kInMask */
-        meta[lane] = (unsigned long long)(ostart + ll) | ((unsigned long long)off << 11) |
-                       ((unsigned long long)lit_rel << 32);
-        if (ostart != 0u) atomicOr(&bm[(ostart - 1u) >> 5], 1u << ((ostart - 1u) & 31u));
-    }
-    asm volatile("" ::: "memory"); /* meta / bm are read below by other lanes than the ones that wrote them */
-    {
-        const uint32_t bm_lo = bm[(lane & (kNCh - 1u)) * 2u], bm_hi = bm[(lane & (kNCh - 1u)) * 2u + 1u];
-        uint32_t basev = (uint32_t)(__popc(bm_lo) + __popc(bm_hi)); /* lanes 0..kNCh-1: bits in chunk `lane` */
-        static_assert(kNCh == 16, "chunk-count scan uses one DPP row");
-        basev = scan16_incl(basev) - basev; /* exclusive: bits before this chunk */
-        if (lane < kNCh) bm[kTMax / 32u + lane] = basev;
-    }
-    asm volatile("" ::: "memory");
-    const uint32_t op0 = w.op;
-    const ptrdiff_t in_delta = in - w.ring; /* both live in the workgroup's LDS block */
-
-    /* Two halves of 8 chunks (keeps the register arrays at 8 entries).  Per half:
-     * pass A: bytes that do not depend on this batch: literals (input ring -> ring) and far
-     *         matches (requested now from the output buffer, written in pass B);
-     * pass B: chunks in order; far bytes land first, then near matches read the ring.  Only a
-     *         source inside the current chunk can be unready: extra rounds guarded by a
-     *         ballot of finished lanes. */
-    constexpr uint32_t kHalf = kNCh / LZ4_HALVES;
-#pragma unroll
-    for (uint32_t h = 0; h < (uint32_t)LZ4_HALVES; h++) {
-        if (h * kHalf * 64u >= T) break;
-        stamp(st, 4);
-        /* pass A: per output byte, find its sequence, classify it (literal / near match / far match)
-         * and compute the LDS address of its source once; far bytes are requested from HBM now */
-        const uint8_t *sp[kHalf]; /* LDS source of the byte (input ring or output ring) */
-        uint32_t moffv[kHalf];    /* match offset (the source lane of a byte whose source is inside its own chunk) */
-        bool farv[kHalf], pendv[kHalf]; /* lane masks, kept in scalar registers: far byte / source inside this chunk */
-        uint32_t xfar[kHalf];
-        {
-            uint32_t idx[kHalf];
-            unsigned long long m[kHalf];
-#pragma unroll
-            for (uint32_t i = 0; i < kHalf; i++) {
-                const uint32_t c = h * kHalf + i;
-                /* the chunk's bitmap words and base come as uniform LDS reads (LDS issue slots, not VALU ones) */
-                const uint2 wv = *reinterpret_cast<const uint2 *>(&bm[c * 2u]);
-                const uint32_t bc = bm[kTMax / 32u + c];
-                idx[i] = (bc + __builtin_amdgcn_mbcnt_hi(wv.y, __builtin_amdgcn_mbcnt_lo(wv.x, 0u))) & 63u;
-            }
-#pragma unroll
-            for (uint32_t i = 0; i < kHalf; i++) m[i] = meta[idx[i]];
-#pragma unroll
-            for (uint32_t i = 0; i < kHalf; i++) {
-                const uint32_t qo = (h * kHalf + i) * 64u + lane; /* batch output offset of this lane's byte */
-                const uint32_t mlo = (uint32_t)m[i], mhi = (uint32_t)(m[i] >> 32);
-                const uint32_t moff = mlo >> 11;
-                const bool active = qo < T;
-                const bool isLit = qo < (mlo & 0x7ffu);
-                const bool isFar = !isLit && moff >= kNear;
-                const bool inch = !isLit && moff <= lane; /* near source inside this very chunk */
-                /* one base + selected offset (v_cndmask) instead of two pointer arms (exec-mask branches) */
-                const uint32_t ia = (uint32_t)in_delta + ((qo + mhi) & kInMask), ra = (op0 + qo - moff) & (R - 1);
-                sp[i] = w.ring + (isLit ? ia : ra);
-                moffv[i] = moff;
-                farv[i] = isFar;
-                pendv[i] = active && inch;
-                /* unconditional load: lanes without a far byte read the first byte of the block */
-                const uint32_t goff = (active && isFar && !(st.ablate & 1u)) ? op0 + qo - moff : 0u;
-                xfar[i] = w.dst[goff];
-            }
-        }
-        stamp(st, 5);
-        /* pass B: chunks in order.  Every byte whose source is not inside the chunk itself is final
-         * after one LDS read; sources inside the chunk are resolved in rounds guarded by a ballot
-         * of finished lanes. */
-#pragma unroll
-        for (uint32_t i = 0; i < kHalf; i++) {
-            const uint32_t c = h * kHalf + i;
-            if (c * 64u < T && !(st.ablate & 2u)) {
-                st.chunks++;
-                uint8_t *dstp = &w.ring[(op0 + c * 64u + lane) & (R - 1)];
-                uint32_t x = *sp[i];
-                if (farv[i]) x = xfar[i];
-                bool pend = pendv[i];
-                /* stored by every lane: a pending lane's byte is rewritten below, and a lane past the end of the
-                 * batch lands on ring positions that are older than the near window (R - kTMax - 64 back) */
-                *dstp = (uint8_t)x;
-                unsigned long long donem = __ballot(!pend);
-                while (donem != ~0ull) {
-                    st.rounds++;
-                    const bool rdy = pend && ((donem >> ((lane - moffv[i]) & 63u)) & 1ull);
-                    if (rdy) *dstp = *sp[i];
-                    donem |= __ballot(rdy);
-                    pend = pend && !rdy;
-                }
-            }
-        }
-    }
-    stamp(st, 6);
-    w.op = op0 + T;
-    w.flush();
-}
 
 } // namespace
 /* ---- helpers of the encoders that work against global memory (zstd_dfast.h) ---- */

@@ -24,6 +24,7 @@
  *     matches read back from the flushed output, 1 KiB coalesced flushes to HBM.
  */
 #include "zstd_common.h"
+#include "lz4_copy.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -32,8 +33,8 @@ namespace cryo {
 namespace {
 
 struct ZLds {
-    uint8_t ring[ZR];
-    uint8_t in[kInRing];
+    uint8_t ring[ZR + 16];   /* + the copy engine's 16-byte tail (lz4_copy.h) */
+    uint8_t in[kInRing + 16];
     uint16_t huf[1 << kHufLogMax]; /* symbol | nbits << 8 */
     uint32_t ll[512], ml[512], of[256]; /* next | nbits << 10 | symbol << 14 */
     int16_t norm[256];
@@ -41,8 +42,8 @@ struct ZLds {
     uint32_t wdt[64]; /* FSE table of the Huffman weights */
     uint8_t wts[256];
     uint8_t cell[512];
-    unsigned long long meta[64]; /* batch copy: per-sequence metadata */
-    uint32_t bm[kTMax / 32 + 16]; /* batch copy: bitmap of sequence starts + per-chunk bases */
+    uint2 meta[64];              /* copy engine: match meta */
+    uint32_t bm[CopyLds<ZR, kTMax>::kWords]; /* copy engine: bitmap of match starts + per-chunk bases */
 };
 
 /* decode the 4 (or 1) Huffman streams with lanes 0..3; symbols go to the literal buffer */
@@ -231,7 +232,8 @@ __device__ bool decode_block(ZLds &L, Wave<ZR> &w, FrameState &fs, const uint8_t
             const uint32_t ostart = oend - outlen;
             const uint32_t litend = scan64_incl(inq ? q_ll : 0u); /* literals consumed up to and incl. this sequence */
             const uint32_t mabs = w.op + ostart + q_ll;
-            const bool ok = inq && lit_mode == 0 && q_ml <= q_off && q_off <= mabs && q_off < (1u << 21) &&
+            const bool isfar = inq && q_off >= ZR - kTMax;
+            const bool ok = inq && lit_mode == 0 && q_ml <= q_off && q_off <= mabs && !(isfar && q_ml > 32u) &&
                             litend <= regen - lit_pos && oend <= kTMax && (uint64_t)w.op + oend <= cap;
             const unsigned long long badmask = __ballot(!ok);
             const uint32_t nb = badmask ? ctz64(badmask) : 64u;
@@ -240,7 +242,19 @@ __device__ bool decode_block(ZLds &L, Wave<ZR> &w, FrameState &fs, const uint8_t
                 const uint32_t lits = lane_get(litend, nb - 1u);
                 /* stage the literals of the whole batch (<= kTMax bytes) in the input ring */
                 while (w.in_hi < w.vend && w.in_hi < lvp + lits + 8u) w.refill();
-                batch_copy<ZR>(w, L.in, L.meta, L.bm, nb, ostart, q_ll, q_off, (lvp + (litend - q_ll)) - ostart, T, st);
+                asm volatile("" ::: "memory");
+                if (lane < 2u) *reinterpret_cast<uint2 *>(L.in + kInRing + lane * 8u) = *reinterpret_cast<const uint2 *>(L.in + lane * 8u);
+                else if (lane < 4u) *reinterpret_cast<uint2 *>(L.ring + ZR + (lane - 2u) * 8u) = *reinterpret_cast<const uint2 *>(L.ring + (lane - 2u) * 8u);
+                w.flush();
+                uint4 xfa = make_uint4(0, 0, 0, 0), xfb = xfa;
+                if (lane < nb && isfar) {
+                    const uint8_t *g = w.dst + (mabs - q_off);
+                    __builtin_memcpy(&xfa, g, 16);
+                    __builtin_memcpy(&xfb, g + 16, 16);
+                }
+                const CopyLds<ZR, kTMax> SL = {L.ring, L.in, L.meta, L.bm};
+                seq_copy<ZR, kTMax>(w, SL, nb, ostart, q_ll, q_ml, q_off, lvp + (litend - q_ll), T, isfar, xfa, xfb, st);
+                w.flush();
                 lvp += lits;
                 lit_pos += lits;
                 /* drop the executed prefix from the queue */

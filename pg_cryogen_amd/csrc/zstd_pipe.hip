@@ -28,6 +28,7 @@
  * workspace stays bounded (~2.3 GiB for 128 KiB blocks).
  */
 #include "zstd_common.h"
+#include "lz4_copy.h"
 #include "kernels.h"
 #include <cstdio>
 #include <cstdlib>
@@ -782,10 +783,10 @@ __global__ void __launch_bounds__(64) k_zrep(ZPipe P)
 namespace {
 
 struct ExecLds {
-    uint8_t ring[ZR];
-    uint8_t in[kInRing];
-    unsigned long long meta[64];
-    uint32_t bm[kTMax / 32 + 16];
+    uint8_t ring[ZR + 16];   /* + the copy engine's 16-byte tail (lz4_copy.h) */
+    uint8_t in[kInRing + 16];
+    uint2 meta[64];
+    uint32_t bm[CopyLds<ZR, kTMax>::kWords];
 };
 
 /* execute one compressed block's sequences; false on malformed input */
@@ -829,7 +830,8 @@ __device__ bool exec_block(ExecLds &L, Wave<ZR> &w, const ZPipe &P, const ZBlk *
         const uint32_t ostart = oend - outlen;
         const uint32_t litend = scan64_incl(inq ? q_ll : 0u);
         const uint32_t mabs = w.op + ostart + q_ll;
-        const bool ok = inq && streamed && q_ml <= q_off && q_off <= mabs && q_off < (1u << 21) &&
+        const bool isfar = inq && q_off >= ZR - kTMax; /* in the ring for the whole batch, or flushed before it (lz4_copy.h) */
+        const bool ok = inq && streamed && q_ml <= q_off && q_off <= mabs && !(isfar && q_ml > 32u) &&
                         litend <= regen - lit_pos && oend <= kTMax && (uint64_t)w.op + oend <= cap;
         const unsigned long long badmask = __ballot(!ok);
         const uint32_t nb = badmask ? ctz64(badmask) : 64u;
@@ -837,7 +839,21 @@ __device__ bool exec_block(ExecLds &L, Wave<ZR> &w, const ZPipe &P, const ZBlk *
             const uint32_t T = lane_get(oend, nb - 1u);
             const uint32_t lits = lane_get(litend, nb - 1u);
             while (w.in_hi < w.vend && w.in_hi < lvp + lits + 8u) w.refill();
-            batch_copy<ZR>(w, L.in, L.meta, L.bm, nb, ostart, q_ll, q_off, (lvp + (litend - q_ll)) - ostart, T, st);
+            /* the copy engine of the LZ4 decoders (lz4_copy.h): literals and independent matches one lane per
+             * sequence, dependent matches byte per lane; the rings' first 16 bytes are mirrored behind them */
+            asm volatile("" ::: "memory");
+            if (lane < 2u) *reinterpret_cast<uint2 *>(L.in + kInRing + lane * 8u) = *reinterpret_cast<const uint2 *>(L.in + lane * 8u);
+            else if (lane < 4u) *reinterpret_cast<uint2 *>(L.ring + ZR + (lane - 2u) * 8u) = *reinterpret_cast<const uint2 *>(L.ring + (lane - 2u) * 8u);
+            w.flush();
+            uint4 xfa = make_uint4(0, 0, 0, 0), xfb = xfa;
+            if (lane < nb && isfar) {
+                const uint8_t *g = w.dst + (mabs - q_off);
+                __builtin_memcpy(&xfa, g, 16);
+                __builtin_memcpy(&xfb, g + 16, 16);
+            }
+            const CopyLds<ZR, kTMax> SL = {L.ring, L.in, L.meta, L.bm};
+            seq_copy<ZR, kTMax>(w, SL, nb, ostart, q_ll, q_ml, q_off, lvp + (litend - q_ll), T, isfar, xfa, xfb, st);
+            w.flush();
             lvp += lits;
             lit_pos += lits;
             q_ll = __shfl(q_ll, (int)((lane + nb) & 63u), 64);
