@@ -184,15 +184,18 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
         for (uint32_t g = 0; g < NG; g++) b[g] = L.d2[g * 64u + lane + a2[g]];
 #pragma unroll
         for (uint32_t g = 0; g < NG; g++) { const uint32_t v = a2[g] + b[g]; a4[g] = v < kDBad ? v : kDBad; } /* valid <= 252 */
-#pragma unroll
-        for (uint32_t g = 0; g < NG; g++) L.d4[g * 64u + lane] = (uint8_t)a4[g];
     }
-    LDS_TABLE_FENCE();
+    /* d4 stays in registers, four window positions per dword: position p = 64 g + lane sits in byte (g & 3) of
+     * word g >> 2 of lane `lane` */
+    constexpr uint32_t NW = (NG + 3u) / 4u;
+    uint32_t pk[4] = {~0u, ~0u, ~0u, ~0u};
+#pragma unroll
+    for (uint32_t g = 0; g < NG; g++) pk[g >> 2] = (pk[g >> 2] & ~(255u << (8u * (g & 3u)))) | (a4[g] << (8u * (g & 3u)));
     stamp(st, 1);
     /* ---- chase: start of every 4th sequence into lanes 0,4,8,... ----
-     * 16 serial hops over d4 (wave-uniform LDS reads).  A d8 table would halve the hops but costs a fourth
-     * table pass over the whole window; the kernel is bound by instruction issue, the hops only by latency,
-     * which the other waves of the SIMD cover. */
+     * 16 serial hops over d4.  A hop used to be a wave-uniform LDS read: ~300 cycles each with the CU's waves
+     * hammering the LDS, 4.8 k cycles per batch, a third of its time.  Now v_readlane from the registers above and a
+     * few scalar instructions. */
     uint32_t sl = 0;   /* window offset of this lane's sequence */
     uint32_t ngrp = 0; /* groups of 4 sequences found */
     {
@@ -201,7 +204,12 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
         for (uint32_t k = 0; k < 16u; k++) {
             asm("v_writelane_b32 %0, %1, %2" : "+v"(sv) : "s"(s0), "i"(4u * k)); /* start of group k -> lane 4k */
             if (ngrp == k && s0 < W) {
-                const uint32_t dd = uni(L.d4[s0]);
+                const uint32_t ln = s0 & 63u, wsel = s0 >> 8;
+                uint32_t word = lane_get(pk[0], ln);
+                if (NW > 1u && wsel == 1u) word = lane_get(pk[1], ln);
+                if (NW > 2u && wsel == 2u) word = lane_get(pk[2], ln);
+                if (NW > 3u && wsel == 3u) word = lane_get(pk[3], ln);
+                const uint32_t dd = (word >> (((s0 >> 6) & 3u) * 8u)) & 255u;
                 if (dd != kDBad) { s0 += dd; ngrp = k + 1u; }
             }
         }
