@@ -85,29 +85,23 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     uint32_t state = 0;          /* 0 token, 1 literal-length extension, 2 match-length extension */
     uint32_t acc = 0, tm = 0;    /* literal length being accumulated; match nibble of the current token */
     uint32_t k = 0;
-    unsigned long long pack = 0, packp = 0; /* the group of four positions being filled, the one before it */
+    unsigned long long pack = 0, packp = 0, packpp = 0; /* the group of four positions being filled, the two before it */
     bool done = !owner || vend == delta;
 
     /* what this lane serves in turn j: one 16-byte piece of the next chunk of blocks 16j + (lane >> 3) and
      * 16j + 8 + (lane >> 3) (two loads per turn: every block has a turn every fourth hop) */
     const uint32_t piece16 = (lane & 7u) * 16u;
-    uint64_t saoff[8];
-    uint32_t svend[8];
-#pragma unroll
-    for (uint32_t j = 0; j < 8u; j++) {
-        const uint32_t s = 8u * j + (lane >> 3);
-        saoff[j] = ((uint64_t)bperm((uint32_t)(aoff >> 32), s) << 32) | bperm((uint32_t)aoff, s);
-        svend[j] = bperm(vend, s);
-    }
+#define IDX_SRC(j) const uint64_t saoff##j = ((uint64_t)bperm((uint32_t)(aoff >> 32), 8u * j + (lane >> 3)) << 32) | bperm((uint32_t)aoff, 8u * j + (lane >> 3)); \
+                   const uint32_t svend##j = bperm(vend, 8u * j + (lane >> 3));
+    IDX_SRC(0) IDX_SRC(1) IDX_SRC(2) IDX_SRC(3) IDX_SRC(4) IDX_SRC(5) IDX_SRC(6) IDX_SRC(7)
+#undef IDX_SRC
     const uint32_t rb = (lane & (kIdxLanes - 1u)) * kIdxStride; /* this lane's ring inside s_ring */
 
-    /* chunks on their way: one per turn, committed FOUR rounds later -- a chunk's trip to memory took ~2 us under
-     * this load (measured: with one round of distance every turn waited for it, 1050 cycles a turn), and a lane
-     * with room in its ring requests one chunk per round, up to four outstanding.  Sixteen separate variables,
-     * not arrays: the compiler kept an indexed array in scratch memory. */
+    /* chunks on their way: two per turn, committed TWO rounds later (a lane with room in its ring requests one chunk
+     * per round, up to two outstanding; four rounds of distance bought nothing and its 32 slots spilled registers).
+     * Separate variables, not arrays: the compiler kept an indexed array in scratch memory. */
 #define IDX_SLOT(n) uint4 fd##n = make_uint4(0, 0, 0, 0), fe##n = fd##n; uint32_t fa##n = 0, fb##n = 0; bool fp##n = false, fq##n = false, fo##n = false;
     IDX_SLOT(0) IDX_SLOT(1) IDX_SLOT(2) IDX_SLOT(3) IDX_SLOT(4) IDX_SLOT(5) IDX_SLOT(6) IDX_SLOT(7)
-    IDX_SLOT(8) IDX_SLOT(9) IDX_SLOT(10) IDX_SLOT(11) IDX_SLOT(12) IDX_SLOT(13) IDX_SLOT(14) IDX_SLOT(15)
 #undef IDX_SLOT
 
     auto turn = [&](const uint32_t j, uint4 &fd, uint4 &fe, uint32_t &fa, uint32_t &fb, bool &fp, bool &fq, bool &fpo,
@@ -123,6 +117,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
         /* the hop's two ring reads go out before the exchange below: one LDS round trip per turn, not two */
         const uint32_t w0 = *reinterpret_cast<const uint32_t *>(s_ring + rb + (pos & (kIdxRing - 4u)));
         const uint32_t w1 = *reinterpret_cast<const uint32_t *>(s_ring + rb + ((pos + 4u) & (kIdxRing - 4u)));
+        const uint32_t w2 = *reinterpret_cast<const uint32_t *>(s_ring + rb + ((pos + 8u) & (kIdxRing - 4u)));
         /* ---- request the next chunk of blocks 8j..8j+7 (one bpermute: requested | want) ---- */
         {
             const bool want = myturn && !done && requested < vend && pos + (kIdxRing - kIdxChunk) >= requested;
@@ -163,12 +158,31 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             const bool rec = tok;
             if (rec) {
                 const unsigned long long e = (unsigned long long)((pos - delta) & 0xffffu) << (16u * (k & 3u));
-                if ((k & 3u) == 0u) { packp = pack; pack = e; } else pack |= e;
+                if ((k & 3u) == 0u) { packpp = packp; packp = pack; pack = e; } else pack |= e;
                 k++;
                 tm = tmn;
             }
             const bool fin = tok && !longlit && q2 > vend;              /* last sequence: literals only */
             if (tok && !longlit && !fin) { pos = q2; state = tmn == 15u ? 2u : 0u; }
+            /* a second token in the same turn when the first one leaves it inside the eight bytes just read: no or
+             * up to two literals and a short match (half of the sequences of tuple data) */
+            {
+                const bool dbl = tok && !longlit && !fin && !l15 && tmn != 15u && ll <= 2u && q2 < vend && k + 1u < cap;
+                const uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, (q2 - 3u - ll) & 3u); /* bytes 4..7 behind the first token */
+                const unsigned long long xx = ((unsigned long long)x1 << 32) | x;
+                const uint32_t y = (uint32_t)(xx >> (8u * (3u + ll)));
+                const uint32_t llb = (y >> 4) & 15u, e1b = (y >> 8) & 255u, tmb = y & 15u;
+                const bool l15b = llb == 15u;
+                const uint32_t q2b = q2 + 3u + llb + (l15b ? e1b + 1u : 0u);
+                if (dbl && !(l15b && e1b == 255u)) {
+                    const unsigned long long e = (unsigned long long)((q2 - delta) & 0xffffu) << (16u * (k & 3u));
+                    if ((k & 3u) == 0u) { packpp = packp; packp = pack; pack = e; } else pack |= e;
+                    k++;
+                    tm = tmb;
+                    if (q2b > vend) done = true;
+                    else { pos = q2b; state = tmb == 15u ? 2u : 0u; }
+                }
+            }
             if (ext) { pos += adv; state = n == 4u ? 2u : 0u; }
             if (longlit) { state = 1u; acc = 15u + 255u; pos += 2u; }
             if (fin || (!done && !live) || k >= cap) done = true;
@@ -195,31 +209,33 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
         }
     };
 
-    auto put = [&]() __attribute__((always_inline)) {
-        /* positions go out in aligned groups of four (8 bytes): once per round the group being filled and the one
-         * before it (a lane gains at most four positions per round, so no group is missed); a group is stored a few
-         * times while it fills, always whole and aligned, so the L2 merges the stores of a row into full lines.
-         * (Storing "the last four entries" at a 2-byte granular address instead wrote 5.2 GB for a 0.8 GB index.)
-         * Two unconditional stores per round, see the note on the loads. */
-        const uint32_t g = k ? (k - 1u) >> 2 : 0u;
-        uint16_t *r = owner ? row : dummy;
-        __builtin_memcpy(r + 4u * (g ? g - 1u : 0u), g ? &packp : &pack, 8);
-        __builtin_memcpy(r + 4u * g, &pack, 8);
-    };
-#define IDX_TURN(j, n) turn(j, fd##n, fe##n, fa##n, fb##n, fp##n, fq##n, fo##n, saoff[2 * j], svend[2 * j], saoff[2 * j + 1], svend[2 * j + 1]);
+    /* positions go out in aligned groups of four (8 bytes): once per round the group being filled and the two before
+     * it (a lane gains at most eight positions per round, so no group is missed); a group is stored a few times while
+     * it fills, always whole and aligned, so the L2 merges the stores of a row into full lines.  (Storing "the last
+     * four entries" at a 2-byte granular address instead wrote 5.2 GB for a 0.8 GB index.)  Three unconditional
+     * stores per round, see the note on the loads.  A macro, not a lambda: captured by a lambda, the packs lived in
+     * scratch memory. */
+#define IDX_PUT()                                                                                            \
+    {                                                                                                        \
+        const uint32_t g = k ? (k - 1u) >> 2 : 0u;                                                           \
+        uint16_t *r = owner ? row : dummy;                                                                   \
+        const unsigned long long v2 = g > 1u ? packpp : (g ? packp : pack), v1 = g ? packp : pack, v0 = pack; \
+        __builtin_memcpy(r + 4u * (g > 1u ? g - 2u : 0u), &v2, 8);                                           \
+        __builtin_memcpy(r + 4u * (g ? g - 1u : 0u), &v1, 8);                                                \
+        __builtin_memcpy(r + 4u * g, &v0, 8);                                                                \
+    }
+#define IDX_TURN(j, n, sa, sb) turn(j, fd##n, fe##n, fa##n, fb##n, fp##n, fq##n, fo##n, saoff##sa, svend##sa, saoff##sb, svend##sb);
 #define IDX_ROUND(a, b, c, d)                                   \
-    put();                                                      \
-    IDX_TURN(0, a) IDX_TURN(1, b) IDX_TURN(2, c) IDX_TURN(3, d)
+    IDX_PUT()                                                   \
+    IDX_TURN(0, a, 0, 1) IDX_TURN(1, b, 2, 3) IDX_TURN(2, c, 4, 5) IDX_TURN(3, d, 6, 7)
     while (__any(!done)) {
         IDX_ROUND(0, 1, 2, 3)
         IDX_ROUND(4, 5, 6, 7)
-        IDX_ROUND(8, 9, 10, 11)
-        IDX_ROUND(12, 13, 14, 15)
     }
 #undef IDX_ROUND
 #undef IDX_TURN
     if (owner) {
-        put();
+        IDX_PUT()
         tbl_n[blk] = k;
     }
 }
