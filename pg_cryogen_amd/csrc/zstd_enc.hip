@@ -45,14 +45,16 @@ constexpr size_t kWsLit = kWsSeq + (size_t)kMaxSeq * 8u;        /* literals     
 constexpr size_t kWsLlc = kWsLit + kZBlk + 64u;                 /* LL / OF / ML codes                */
 constexpr size_t kWsOfc = kWsLlc + kMaxSeq;
 constexpr size_t kWsMlc = kWsOfc + kMaxSeq;
-constexpr size_t kWsBytes = (kWsMlc + kMaxSeq + 255u) & ~(size_t)255u; /* the match finder's u32 table(s) follow */
 
 struct FseCt {
     uint16_t state[512];
     int32_t dfind[64];
     uint32_t dnb[64];
     int log;
+    uint32_t max_sym;          /* maxSymbolValue of the table (the repeat-mode cost test) */
 };
+constexpr size_t kWsTabs = (kWsMlc + kMaxSeq + 15u) & ~(size_t)15u; /* LL, OF, ML tables of the previous compressed block (`lazy`+) */
+constexpr size_t kWsBytes = (kWsTabs + 3u * sizeof(FseCt) + 255u) & ~(size_t)255u; /* the match finder's u32 table(s) follow */
 
 struct EncLds {
     uint32_t hist[256];
@@ -245,6 +247,7 @@ __device__ void fse_build_ct(FseCt &ct, const int16_t *norm, uint32_t max_sym, i
     const uint32_t size = 1u << log, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
     uint32_t high = size - 1u, pos = 0;
     ct.log = log;
+    ct.max_sym = max_sym;
     cumul[0] = 0;
     for (uint32_t u = 1; u <= max_sym + 1u; u++) {
         const int c = norm[u - 1u];
@@ -282,6 +285,7 @@ __device__ void fse_build_ct(FseCt &ct, const int16_t *norm, uint32_t max_sym, i
 __device__ inline void fse_build_ct_rle(FseCt &ct, uint32_t sym)
 {
     ct.log = 0;
+    ct.max_sym = sym;
     ct.state[0] = 0; ct.state[1] = 0;
     ct.dnb[sym] = 0; ct.dfind[sym] = 0;
 }
@@ -654,7 +658,7 @@ __device__ uint32_t compress_literals(EncLds &L, uint8_t *dst, const uint8_t *sr
             for (uint32_t s = 0; s <= max_sym; s++) bad |= (L.hist[s] != 0u) && (L.pnb[s] == 0u);
             if (bad) mode = false;
         }
-        if (n <= 1024u && mode) { reused = true; c = huf_encode_streams(L, dst + lh, 0, src, n, L.pval, L.pnb, single, lane); }
+        if (hs.strat < 4u && n <= 1024u && mode) { reused = true; /* preferRepeat: below `lazy` only */ c = huf_encode_streams(L, dst + lh, 0, src, n, L.pval, L.pnb, single, lane); }
         else {
             uint32_t log = (uint32_t)fse_optimal_log(11, n, max_sym, 1);
             zprof(hs, 3);
@@ -718,15 +722,92 @@ __constant__ uint8_t kMLCode[128] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 1
     40, 40, 40, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 41, 42, 42, 42, 42, 42, 42, 42, 42,
     42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42, 42};
 
-enum { SET_BASIC = 0, SET_RLE = 1, SET_COMPRESSED = 2 };
+enum { SET_BASIC = 0, SET_RLE = 1, SET_COMPRESSED = 2, SET_REPEAT = 3 };
 
-__device__ inline int select_type(uint32_t most, uint32_t nseq, int def_log, bool def_allowed, uint32_t strat)
+/* kInverseProbabilityLog256[x] = (unsigned)(-log2(x / 256.) * 256) of the library's cost model */
+__constant__ uint16_t kInvProbLog256[256] = {0, 2048, 1792, 1642, 1536, 1453, 1386, 1329, 1280, 1236, 1197, 1162, 1130, 1100, 1073, 1047,
+    1024, 1001, 980, 960, 941, 923, 906, 889, 874, 859, 844, 830, 817, 804, 791, 779, 768, 756, 745, 734, 724, 714, 704, 694, 685, 676,
+    667, 658, 650, 642, 633, 626, 618, 610, 603, 595, 588, 581, 574, 567, 561, 554, 548, 542, 535, 529, 523, 517, 512, 506, 500, 495, 489,
+    484, 478, 473, 468, 463, 458, 453, 448, 443, 438, 434, 429, 424, 420, 415, 411, 407, 402, 398, 394, 390, 386, 382, 377, 373, 370, 366,
+    362, 358, 354, 350, 347, 343, 339, 336, 332, 329, 325, 322, 318, 315, 311, 308, 305, 302, 298, 295, 292, 289, 286, 282, 279, 276, 273,
+    270, 267, 264, 261, 258, 256, 253, 250, 247, 244, 241, 239, 236, 233, 230, 228, 225, 222, 220, 217, 215, 212, 209, 207, 204, 202, 199,
+    197, 194, 192, 190, 187, 185, 182, 180, 178, 175, 173, 171, 168, 166, 164, 162, 159, 157, 155, 153, 151, 149, 146, 144, 142, 140, 138,
+    136, 134, 132, 130, 128, 126, 123, 121, 119, 117, 115, 114, 112, 110, 108, 106, 104, 102, 100, 98, 96, 94, 93, 91, 89, 87, 85, 83, 82,
+    80, 78, 76, 74, 73, 71, 69, 67, 66, 64, 62, 61, 59, 57, 55, 54, 52, 50, 49, 47, 46, 44, 42, 41, 39, 37, 36, 34, 33, 31, 30, 28, 26, 25,
+    23, 22, 20, 19, 17, 16, 14, 13, 11, 10, 8, 7, 5, 4, 2, 1};
+
+constexpr uint64_t kCostErr = ~0ull;
+
+/* ZSTD_entropyCost / ZSTD_crossEntropyCost / ZSTD_fseBitCost / ZSTD_NCountCost (libzstd 1.4.8 zstd_compress_sequences.c;
+ * oracle/zstd_enc_oracle.c entropy_cost .. ncount_cost).  Wave-uniform like the rest of the table stage. */
+__device__ uint64_t entropy_cost(const uint32_t *count, uint32_t max, uint32_t total)
 {
-    if (most == nseq) return (def_allowed && nseq <= 2u) ? SET_BASIC : SET_RLE;
-    if (def_allowed) {
-        const uint32_t dyn_min = ((1u << def_log) * (10u - strat)) >> 3; /* ZSTD_fast = 1, ZSTD_dfast = 2 */
-        if (nseq < dyn_min || most < (nseq >> (def_log - 1))) return SET_BASIC;
+    uint32_t cost = 0;
+    for (uint32_t s = 0; s <= max; s++) {
+        const uint32_t c = count[s];
+        uint32_t norm = (256u * c) / total;
+        if (c != 0u && norm == 0u) norm = 1u;
+        cost += c * kInvProbLog256[norm];
     }
+    return cost >> 8;
+}
+__device__ uint64_t cross_entropy_cost(const int16_t *norm, uint32_t acc_log, const uint32_t *count, uint32_t max)
+{
+    const uint32_t shift = 8u - acc_log;
+    uint64_t cost = 0;
+    for (uint32_t s = 0; s <= max; s++) {
+        const uint32_t nacc = norm[s] != -1 ? (uint32_t)norm[s] : 1u;
+        cost += (uint64_t)count[s] * kInvProbLog256[nacc << shift];
+    }
+    return cost >> 8;
+}
+__device__ uint64_t fse_bit_cost(const FseCt *ct, const uint32_t *count, uint32_t max)
+{
+    const uint32_t tlog = (uint32_t)uni((uint32_t)ct->log), bad = (tlog + 1u) << 8;
+    uint64_t cost = 0;
+    if (uni(ct->max_sym) < max) return kCostErr;
+    for (uint32_t s = 0; s <= max; s++) {
+        const uint32_t dnb = uni(ct->dnb[s]);
+        const uint32_t min_nb = dnb >> 16;
+        const uint32_t threshold = (min_nb + 1u) << 16;
+        const uint32_t from_thr = threshold - (dnb + (1u << tlog));
+        const uint32_t norm_from_thr = (from_thr << 8) >> tlog;
+        const uint32_t bit_cost = (min_nb + 1u) * 256u - norm_from_thr;
+        if (count[s] == 0u) continue;
+        if (bit_cost >= bad) return kCostErr;
+        cost += (uint64_t)count[s] * bit_cost;
+    }
+    return cost >> 8;
+}
+/* `scratch`: where the description would go (at least 512 bytes of the output bound are still free there) */
+__device__ uint64_t ncount_cost(int16_t *norm, uint8_t *scratch, const uint32_t *count, uint32_t max, uint32_t nseq, int fse_log)
+{
+    const int log = fse_optimal_log(fse_log, nseq, max, 2);
+    if (fse_normalize(norm, log, count, nseq, max, nseq >= 2048u) <= 0) return kCostErr;
+    const uint32_t sz = fse_write_ncount(scratch, norm, max, log);
+    return sz ? sz : kCostErr;
+}
+
+/* ZSTD_selectEncodingType.  Strategies below `lazy`: thresholds; `lazy` and above: estimated costs, and the previous
+ * block's table may be repeated.  *rep_mode: 0 none, 1 check (the previous compressed block left a usable table). */
+__device__ int select_type(int16_t *norm, uint8_t *scratch, const uint32_t *count, uint32_t max, uint32_t most, uint32_t nseq, int fse_log,
+                           const FseCt *prev, int *rep_mode, const int16_t *def_norm, int def_log, bool def_allowed, uint32_t strat)
+{
+    if (most == nseq) { *rep_mode = 0; return (def_allowed && nseq <= 2u) ? SET_BASIC : SET_RLE; }
+    if (strat < 4u) {
+        if (def_allowed) {
+            const uint32_t dyn_min = ((1u << def_log) * (10u - strat)) >> 3; /* ZSTD_fast = 1, ZSTD_dfast = 2, ZSTD_greedy = 3 */
+            if (nseq < dyn_min || most < (nseq >> (def_log - 1))) { *rep_mode = 0; return SET_BASIC; }
+        }
+    } else {
+        const uint64_t basic = def_allowed ? cross_entropy_cost(def_norm, (uint32_t)def_log, count, max) : kCostErr;
+        const uint64_t repeat = *rep_mode != 0 ? fse_bit_cost(prev, count, max) : kCostErr;
+        const uint64_t nc = ncount_cost(norm, scratch, count, max, nseq, fse_log);
+        const uint64_t compressed = (nc << 3) + entropy_cost(count, max, nseq);
+        if (basic <= repeat && basic <= compressed) { *rep_mode = 0; return SET_BASIC; }
+        if (repeat <= compressed) return SET_REPEAT;
+    }
+    *rep_mode = 1;
     return SET_COMPRESSED;
 }
 
@@ -748,8 +829,16 @@ __device__ void hist_codes(EncLds &L, const uint8_t *codes, uint32_t nseq, uint3
 /* ZSTD_buildCTable; returns bytes of table description, 0xFFFFFFFF on error */
 __device__ uint32_t build_ctable(EncLds &L, uint8_t *dst, FseCt &ct, int fse_log, int type, uint32_t max,
                                  const uint8_t *codes, uint32_t nseq, const int16_t *def_norm, int def_log,
-                                 uint32_t def_max, uint32_t lane)
+                                 uint32_t def_max, const FseCt *prev, uint32_t lane)
 {
+    if (type == SET_REPEAT) { /* the previous block's table, kept in the workgroup's workspace */
+        const uint32_t *from = reinterpret_cast<const uint32_t *>(prev);
+        uint32_t *to = reinterpret_cast<uint32_t *>(&ct);
+        for (uint32_t i = lane; i < sizeof(FseCt) / 4u; i += 64u) to[i] = from[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return 0;
+    }
     if (type == SET_RLE) { fse_build_ct_rle(ct, max); if (lane == 0) dst[0] = codes[0]; return 1; }
     if (type == SET_BASIC) {
         for (uint32_t i = 0; i <= def_max; i++) L.norm[i] = def_norm[i];
@@ -767,11 +856,18 @@ __device__ uint32_t build_ctable(EncLds &L, uint8_t *dst, FseCt &ct, int fse_log
     return sz;
 }
 
+/* sequence tables + repeat modes that a compressed block leaves to the next one of its frame (`lazy` and above):
+ * prev[0..2] = LL, OF, ML tables in the workgroup's workspace; rep = modes confirmed by the last compressed block,
+ * nrep = the ones this block would leave */
+struct SeqTabs { FseCt *prev; int rep[3]; int nrep[3]; bool built; /* this block built (or repeated) its three tables */ };
+
 /* literals + sequences -> compressed block body at dst; 0 = emit a raw block */
 __device__ uint32_t compress_sequences(EncLds &L, uint8_t *dst, uint8_t *ws, uint32_t nseq, uint32_t nlit,
-                                       uint32_t src_size, uint32_t long_pos, uint32_t long_kind, HufState &hs,
+                                       uint32_t src_size, uint32_t long_pos, uint32_t long_kind, HufState &hs, SeqTabs &tb,
                                        bool disable_lit, uint32_t lane)
 {
+    tb.nrep[0] = tb.rep[0]; tb.nrep[1] = tb.rep[1]; tb.nrep[2] = tb.rep[2];
+    tb.built = false;
     const uint2 *seqs = reinterpret_cast<const uint2 *>(ws + kWsSeq);
     const uint8_t *lits = ws + kWsLit;
     uint8_t *llc = ws + kWsLlc, *ofc = ws + kWsOfc, *mlc = ws + kWsMlc;
@@ -800,23 +896,24 @@ __device__ uint32_t compress_sequences(EncLds &L, uint8_t *dst, uint8_t *ws, uin
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     uint32_t max, most, last_ncount = 0xFFFFFFFFu;
     hist_codes(L, llc, nseq, kMaxLL, &max, &most, lane);
-    const int tll = select_type(most, nseq, 6, true, hs.strat);
-    uint32_t sz = build_ctable(L, dst + op, L.ll, 9, tll, max, llc, nseq, kELLDef, 6, kMaxLL, lane);
+    const int tll = select_type(L.norm, dst + op, L.hist, max, most, nseq, 9, tb.prev + 0, &tb.nrep[0], kELLDef, 6, true, hs.strat);
+    uint32_t sz = build_ctable(L, dst + op, L.ll, 9, tll, max, llc, nseq, kELLDef, 6, kMaxLL, tb.prev + 0, lane);
     if (sz == 0xFFFFFFFFu) return 0;
     if (tll == SET_COMPRESSED) last_ncount = op;
     op += sz;
     hist_codes(L, ofc, nseq, kMaxOff, &max, &most, lane);
-    const int tof = select_type(most, nseq, 5, max <= kDefMaxOff, hs.strat);
-    sz = build_ctable(L, dst + op, L.of, 8, tof, max, ofc, nseq, kEOFDef, 5, kDefMaxOff, lane);
+    const int tof = select_type(L.norm, dst + op, L.hist, max, most, nseq, 8, tb.prev + 1, &tb.nrep[1], kEOFDef, 5, max <= kDefMaxOff, hs.strat);
+    sz = build_ctable(L, dst + op, L.of, 8, tof, max, ofc, nseq, kEOFDef, 5, kDefMaxOff, tb.prev + 1, lane);
     if (sz == 0xFFFFFFFFu) return 0;
     if (tof == SET_COMPRESSED) last_ncount = op;
     op += sz;
     hist_codes(L, mlc, nseq, kMaxML, &max, &most, lane);
-    const int tml = select_type(most, nseq, 6, true, hs.strat);
-    sz = build_ctable(L, dst + op, L.ml, 9, tml, max, mlc, nseq, kEMLDef, 6, kMaxML, lane);
+    const int tml = select_type(L.norm, dst + op, L.hist, max, most, nseq, 9, tb.prev + 2, &tb.nrep[2], kEMLDef, 6, true, hs.strat);
+    sz = build_ctable(L, dst + op, L.ml, 9, tml, max, mlc, nseq, kEMLDef, 6, kMaxML, tb.prev + 2, lane);
     if (sz == 0xFFFFFFFFu) return 0;
     if (tml == SET_COMPRESSED) last_ncount = op;
     op += sz;
+    tb.built = true;
     if (lane == 0) dst[seq_head] = (uint8_t)((tll << 6) + (tof << 4) + (tml << 2));
     __builtin_amdgcn_wave_barrier();
     zprof(hs, 6);
@@ -1029,7 +1126,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
     CPar cp;
     cp.wlog = wlog; cp.clog = clog; cp.hlog = hlog; cp.slog = (int)width; cp.mml = mml; cp.tlen = tlen;
     const bool dfast = finder == 1;
-    const bool two_tables = finder == 1 || finder == 3;
+    const bool two_tables = finder == 1 || finder >= 3;
     uint32_t *table = reinterpret_cast<uint32_t *>(ws + kWsBytes);
     uint32_t *tshort = table + (1u << hlog); /* dfast only */
 
@@ -1062,8 +1159,11 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         const uint8_t *base = src - 1;
         bool first = true;
         HufState hs;
-        hs.prev_valid = false; hs.next_new = false; hs.prof = PROF ? stats : nullptr; hs.t = 0; hs.strat = finder == 3 ? 3u : (dfast ? 2u : 1u);
+        hs.prev_valid = false; hs.next_new = false; hs.prof = PROF ? stats : nullptr; hs.t = 0; hs.strat = finder >= 3 ? (uint32_t)finder : (dfast ? 2u : 1u);
         HcState hc = {table, tshort, 1u};
+        SeqTabs tb;
+        tb.prev = reinterpret_cast<FseCt *>(ws + kWsTabs);
+        tb.rep[0] = tb.rep[1] = tb.rep[2] = 0;
         uint32_t ip = 0;
         while (ip < n) {
             const uint32_t bs = (n - ip < kZBlk) ? n - ip : kZBlk;
@@ -1078,13 +1178,13 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 if constexpr (PROF) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_other += t - t_prev; t_prev = t; }
                 uint32_t last_ll;
                 if (finder == 1) last_ll = block_dfast_batch<PROF>(table, tshort, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, width, stats);
-                else if (finder == 3) {
+                else if (finder >= 3) {
                     const uint32_t cur = ip + 1u; /* ZSTD_buildSeqStore: limited catch-up after a very long match */
                     if (cur > hc.next_to_update + 384u) {
                         const uint32_t d = cur - hc.next_to_update - 384u;
                         hc.next_to_update = cur - (d < 192u ? d : 192u);
                     }
-                    last_ll = block_greedy(hc, df_mark, cp, base, src + ip, bs, nrep, ws, ss, lane);
+                    last_ll = block_lazy(hc, df_mark, cp, finder - 3, base, src + ip, bs, nrep, ws, ss, lane);
                 }
                 else if (finder == 0) last_ll = block_fast_gbatch(table, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, width);
                 else last_ll = block_fast(table, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane);
@@ -1093,7 +1193,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 ss.nlit += last_ll;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 if constexpr (PROF) hs.t = __builtin_amdgcn_s_memtime();
-                csize = compress_sequences(L, dst + op + 3, ws, ss.nseq, ss.nlit, bs, ss.long_pos, ss.long_kind, hs,
+                csize = compress_sequences(L, dst + op + 3, ws, ss.nseq, ss.nlit, bs, ss.long_pos, ss.long_kind, hs, tb,
                                            (finder == 0 || finder == 2) && tlen > 0 /* literals stay raw only for `fast` with a target length */, lane);
                 if constexpr (PROF) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_en += t - t_prev; t_prev = t; }
                 if (!first && csize < 25u) { /* RLE block for constant non-first blocks */
@@ -1107,6 +1207,15 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                     if (hs.next_new) {
                         for (uint32_t i = lane; i < 256u; i += 64u) { L.pval[i] = L.hval[i]; L.pnb[i] = L.hnb[i]; }
                         hs.prev_valid = true;
+                    }
+                    if (finder >= 4 && !last && tb.built) { /* ZSTD_confirmRepcodesAndEntropyTables: the sequence tables too */
+                        tb.rep[0] = tb.nrep[0]; tb.rep[1] = tb.nrep[1]; tb.rep[2] = tb.nrep[2];
+                        const uint32_t *t0 = reinterpret_cast<const uint32_t *>(&L.ll), *t1 = reinterpret_cast<const uint32_t *>(&L.of),
+                                       *t2 = reinterpret_cast<const uint32_t *>(&L.ml);
+                        uint32_t *p = reinterpret_cast<uint32_t *>(tb.prev);
+                        constexpr uint32_t W = sizeof(FseCt) / 4u;
+                        for (uint32_t i = lane; i < W; i += 64u) { p[i] = t0[i]; p[W + i] = t1[i]; p[2u * W + i] = t2[i]; }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     }
                 }
             }
@@ -1134,20 +1243,22 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
 }
 
 /* ZSTD_getCParams + ZSTD_adjustCParams for the levels with a kernel at cryo block sizes (oracle-checked): `fast`
- * (-5..2), `dfast` (3, 4), `greedy` (5; 6 above 256 KiB).  *clog: dfast's short table / greedy's chain table;
- * *strategy: 1 fast, 2 dfast, 3 greedy; *slog: greedy's searchLog. */
+ * (-5..2), `dfast` (3, 4), `greedy` (5; 6 above 256 KiB), `lazy` / `lazy2` (up to 10).  *clog: dfast's short table /
+ * the chain table; *strategy: 1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2; *slog: the hash-chain searchLog. */
 static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *mml, int *tlen, int *clog = nullptr,
                               bool *dfast = nullptr, int *strategy = nullptr, int *slog = nullptr)
 {
-    static const int big[7][7] = {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2},
-                                  {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}}; /* n > 256 KiB: wlog, clog, hlog, slog, mml, tlen, strategy */
-    static const int k128[6][7] = {{17, 12, 12, 1, 5, 1, 1}, {17, 12, 13, 1, 6, 0, 1}, {17, 13, 15, 1, 5, 0, 1}, {17, 15, 16, 2, 5, 0, 2},
-                                   {17, 17, 17, 2, 4, 0, 2}, {17, 16, 17, 3, 4, 2, 3}}; /* 16 KiB < n <= 128 KiB */
+    static const int big[11][7] = {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2},
+                                   {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}, {21, 19, 19, 3, 5, 8, 4},
+                                   {21, 19, 19, 3, 5, 16, 5}, {21, 19, 20, 4, 5, 16, 5}, {22, 20, 21, 4, 5, 16, 5}}; /* n > 256 KiB: wlog, clog, hlog, slog, mml, tlen, strategy */
+    static const int k128[11][7] = {{17, 12, 12, 1, 5, 1, 1}, {17, 12, 13, 1, 6, 0, 1}, {17, 13, 15, 1, 5, 0, 1}, {17, 15, 16, 2, 5, 0, 2},
+                                    {17, 17, 17, 2, 4, 0, 2}, {17, 16, 17, 3, 4, 2, 3}, {17, 17, 17, 3, 4, 4, 4}, {17, 17, 17, 3, 4, 8, 5},
+                                    {17, 17, 17, 4, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 5}, {17, 17, 17, 6, 4, 8, 5}}; /* 16 KiB < n <= 128 KiB */
     const int (*t)[7];
     int maxl;
     if (level == 0) level = 3;
-    if (n > 256u * 1024u) { t = big; maxl = 6; }
-    else if (n > 16u * 1024u && n <= 128u * 1024u) { t = k128; maxl = 5; }
+    if (n > 256u * 1024u) { t = big; maxl = 10; }
+    else if (n > 16u * 1024u && n <= 128u * 1024u) { t = k128; maxl = 10; }
     else return false;
     if (level > maxl || level < -131072) return false;
     const int row = level < 0 ? 0 : level;
@@ -1169,12 +1280,15 @@ static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *
 }
 
 /* workgroups per CU: LDS (entropy-stage tables; the finders' mark array lies inside) admits 11, the registers 12 */
-static uint32_t zstd_enc_grid(uint64_t n_blocks)
+static uint32_t zstd_enc_grid(uint64_t n_blocks, size_t stride)
 {
     uint64_t per_cu = (160u * 1024u) / (sizeof(EncLds) + 64u);
     if (per_cu > 16) per_cu = 16;
     static const uint64_t grid_env = getenv("CRYO_ZSTD_ENC_GRID") ? (uint64_t)atoll(getenv("CRYO_ZSTD_ENC_GRID")) : 0; /* tuning aid */
-    const uint64_t cap = grid_env ? grid_env : 256u * per_cu;
+    uint64_t cap = grid_env ? grid_env : 256u * per_cu;
+    /* the deep levels' tables reach 12 MiB per workgroup: keep the workspace under 24 GiB, at least one workgroup per CU */
+    const uint64_t fit = ((uint64_t)24 << 30) / stride;
+    if (cap > fit) cap = fit < 256u ? 256u : fit;
     return (uint32_t)(n_blocks < cap ? n_blocks : cap);
 }
 /* per workgroup: sequences, literals, codes (kWsBytes), then the match finder's table(s) */
@@ -1186,7 +1300,8 @@ size_t zstd_compress_workspace(uint64_t n_blocks, int level, uint32_t block_size
     bool dfast = false;
     int strategy = 1;
     if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast, &strategy)) return 256;
-    return (size_t)zstd_enc_grid(n_blocks) * zstd_enc_stride(hlog, clog, strategy >= 2) + 256;
+    const size_t stride = zstd_enc_stride(hlog, clog, strategy >= 2);
+    return (size_t)zstd_enc_grid(n_blocks, stride) * stride + 256;
 }
 
 bool zstd_compress_supported(int level, uint32_t block_size)
@@ -1205,14 +1320,14 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
     int strategy = 1, slog = 0;
     if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast, &strategy, &slog)) return hipErrorNotSupported;
     static const bool serial_only = getenv("CRYO_ZSTD_ENC") && getenv("CRYO_ZSTD_ENC")[0] == '1'; /* testing aid: the serial `fast` walk */
-    const int finder = strategy == 3 ? 3 : (dfast ? 1 : (serial_only ? 2 : 0));
+    const int finder = strategy >= 3 ? strategy : (dfast ? 1 : (serial_only ? 2 : 0)); /* 3 greedy, 4 lazy, 5 lazy2 */
     /* search positions (dfast) / iterations (fast: two positions each) per step.  Measured on text-like rows, GB/s:
      * dfast level 3  16: 6.6  32: 7.4  64: 6.9;  fast level 1  16: 14.4  32: 13.9  64: 13.1 -- wider steps read
      * table slots for positions behind the first match, narrower ones pay more trips per sequence */
     static const uint32_t w_env = getenv("CRYO_ZSTD_ENC_WIDTH") ? (uint32_t)atoi(getenv("CRYO_ZSTD_ENC_WIDTH")) : 0u; /* tuning aid */
-    const uint32_t width = strategy == 3 ? (uint32_t)slog : (w_env ? w_env : (dfast ? 32u : 16u));
-    const uint32_t grid = zstd_enc_grid(n_blocks);
+    const uint32_t width = strategy >= 3 ? (uint32_t)slog : (w_env ? w_env : (dfast ? 32u : 16u));
     const size_t stride = zstd_enc_stride(hlog, clog, strategy >= 2);
+    const uint32_t grid = zstd_enc_grid(n_blocks, stride);
     if (workspace_bytes < (size_t)grid * stride) return hipErrorInvalidValue;
     static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
     unsigned long long *d_st = nullptr, h_st[24] = {0};

@@ -1,7 +1,7 @@
 /*
- * zstd_lazy.h -- the `greedy` strategy's match finder (libzstd 1.4.8 ZSTD_compressBlock_lazy_generic at depth 0
- * over the hash-chain searcher ZSTD_HcFindBestMatch, no dictionary; zstd level 5 at cryo block sizes, level 6
- * at 1 MiB).  Included by zstd_enc.hip inside its namespace, after zstd_dfast.h.
+ * zstd_lazy.h -- the `greedy`, `lazy` and `lazy2` strategies' match finder (libzstd 1.4.8
+ * ZSTD_compressBlock_lazy_generic at depth 0, 1, 2 over the hash-chain searcher ZSTD_HcFindBestMatch, no dictionary;
+ * zstd levels 5 .. 10 at cryo block sizes).  Included by zstd_enc.hip inside its namespace, after zstd_dfast.h.
  *
  * Replaces the match-finding half of ZSTD_compress(dst, bound, src, B, level) (reference
  * compression.c:102-104); restated for the CPU in oracle/zstd_enc_oracle.c (block_lazy, hc_find_best).
@@ -11,8 +11,8 @@
  * other finders -- which is exact: chain[idx] = hash[h]; hash[h] = idx for distinct h in any order); a search
  * walks at most 2^searchLog chain links, each a dependent load, and extends candidates 64 bytes per step.
  * Tables: hash (2^hashLog u32) then chain (2^chainLog u32) behind the workgroup's workspace.  `lazy` / `lazy2`
- * (levels 6+) additionally need the cost-based sequence-table choice in the entropy stage (oracle: select_type)
- * and are not built yet.
+ * (levels 6 .. 10) run the same searcher again at ip+1 (and ip+2) and choose their sequence tables by estimated cost
+ * (zstd_enc.hip select_type).
  */
 #pragma once
 
@@ -76,9 +76,11 @@ __device__ inline uint32_t hc_find_best(HcState &hc, uint8_t *mark, const CPar &
     return ml;
 }
 
-/* ZSTD_compressBlock_lazy_generic, depth 0 (greedy).  Indexes are the library's (base = src - 1). */
-__device__ uint32_t block_greedy(HcState &hc, uint8_t *mark, const CPar &cp, const uint8_t *base, const uint8_t *istart, uint32_t n,
-                                 uint32_t *rep, uint8_t *ws, SeqStore &ss, uint32_t lane)
+/* ZSTD_compressBlock_lazy_generic: depth 0 greedy, 1 lazy, 2 lazy2 (oracle: block_lazy).  Indexes are the library's
+ * (base = src - 1).  The walk is wave-uniform; depth 1 / 2 search again at ip+1 (ip+2) and keep the candidate whose
+ * gain estimate (4 x length - log2(offset code)) is better. */
+__device__ uint32_t block_lazy(HcState &hc, uint8_t *mark, const CPar &cp, int depth, const uint8_t *base, const uint8_t *istart, uint32_t n,
+                               uint32_t *rep, uint8_t *ws, SeqStore &ss, uint32_t lane)
 {
     const int mls = cp.mml < 4 ? 4 : (cp.mml > 6 ? 6 : cp.mml);
     uint32_t ip = (uint32_t)(istart - base), anchor = ip;
@@ -98,13 +100,49 @@ __device__ uint32_t block_greedy(HcState &hc, uint8_t *mark, const CPar &cp, con
         bool have = false;
         if (off1 > 0u && ld32u(base + ip + 1u - off1) == ld32u(base + ip + 1u)) {
             mlen = count_match(base + ip + 1u + 4u, base + ip + 1u + 4u - off1, base + iend, lane) + 4u;
-            have = true; /* depth 0: taken as it is */
+            have = depth == 0; /* greedy: taken as it is */
         }
         if (!have) {
-            uint32_t off_found = 999999999u;
-            const uint32_t ml2 = hc_find_best(hc, mark, cp, base, ip, iend, &off_found, mls, lane);
-            if (ml2 > mlen) { mlen = ml2; start = ip; offset = off_found; }
+            {
+                uint32_t off_found = 999999999u;
+                const uint32_t ml2 = hc_find_best(hc, mark, cp, base, ip, iend, &off_found, mls, lane);
+                if (ml2 > mlen) { mlen = ml2; start = ip; offset = off_found; }
+            }
             if (mlen < 4u) { ip += ((ip - anchor) >> 8) + 1u; continue; }
+            if (depth >= 1)
+                while (ip < ilimit) {
+                    ip++;
+                    if (offset && off1 > 0u && ld32u(base + ip) == ld32u(base + ip - off1)) {
+                        const uint32_t ml_rep = count_match(base + ip + 4u, base + ip + 4u - off1, base + iend, lane) + 4u;
+                        const int gain2 = (int)(ml_rep * 3u);
+                        const int gain1 = (int)(mlen * 3u - hbit(offset + 1u) + 1u);
+                        if (ml_rep >= 4u && gain2 > gain1) { mlen = ml_rep; offset = 0; start = ip; }
+                    }
+                    {
+                        uint32_t off2f = 999999999u;
+                        const uint32_t ml2 = hc_find_best(hc, mark, cp, base, ip, iend, &off2f, mls, lane);
+                        const int gain2 = (int)(ml2 * 4u - hbit(off2f + 1u));
+                        const int gain1 = (int)(mlen * 4u - hbit(offset + 1u) + 4u);
+                        if (ml2 >= 4u && gain2 > gain1) { mlen = ml2; offset = off2f; start = ip; continue; }
+                    }
+                    if (depth == 2 && ip < ilimit) {
+                        ip++;
+                        if (offset && off1 > 0u && ld32u(base + ip) == ld32u(base + ip - off1)) {
+                            const uint32_t ml_rep = count_match(base + ip + 4u, base + ip + 4u - off1, base + iend, lane) + 4u;
+                            const int gain2 = (int)(ml_rep * 4u);
+                            const int gain1 = (int)(mlen * 4u - hbit(offset + 1u) + 1u);
+                            if (ml_rep >= 4u && gain2 > gain1) { mlen = ml_rep; offset = 0; start = ip; }
+                        }
+                        {
+                            uint32_t off2f = 999999999u;
+                            const uint32_t ml2 = hc_find_best(hc, mark, cp, base, ip, iend, &off2f, mls, lane);
+                            const int gain2 = (int)(ml2 * 4u - hbit(off2f + 1u));
+                            const int gain1 = (int)(mlen * 4u - hbit(offset + 1u) + 7u);
+                            if (ml2 >= 4u && gain2 > gain1) { mlen = ml2; offset = off2f; start = ip; continue; }
+                        }
+                    }
+                    break;
+                }
             if (offset) { /* catch up */
                 const uint32_t m = start - (offset - 2u);
                 const uint32_t la = start - anchor, lm = m - prefix_lowest;

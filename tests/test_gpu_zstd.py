@@ -128,11 +128,11 @@ def test_zstd_single_block_host_api(codec, oracle):
     assert codec.decompress_block(METHOD_ZSTD, c[:-3], B) is None
 
 
-# ---------------- zstd encode (strategies `fast`, `dfast`, `greedy`: levels -5..5), reference compression.c:102-104 ----------------
+# ---------------- zstd encode (strategies `fast`, `dfast`, `greedy`, `lazy`, `lazy2`: levels -5..10), reference compression.c:102-104 ----------------
 @pytest.mark.parametrize("B", [131072, 1 << 20, 65546, 20000])
 def test_zstd_encode_bit_exact(codec, oracle, B):
     blocks = [oracle.synth(3, blk, B, dist) for dist in range(5) for blk in range(2)]
-    for lvl in (-5, -1, 1, 2, 3, 4, 5) + ((6,) if B > 262144 else ()):   # level 6 is `greedy` above 256 KiB, `lazy` below
+    for lvl in (-5, -1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10):   # level 6 is `greedy` above 256 KiB, `lazy` below; 7+ `lazy` / `lazy2`
         got = codec.compress_blocks(METHOD_ZSTD, lvl, blocks)
         for i, b in enumerate(blocks):
             exp = oracle.zstd_compress(b, lvl)
@@ -143,8 +143,8 @@ def test_zstd_encode_bit_exact(codec, oracle, B):
 
 def test_zstd_encode_matches_golden_vectors(codec, oracle):
     cells = [c for c in json.load(open(os.path.join(G, "vectors.json")))["cells"]
-             if c["method"] == "zstd" and c["param"] <= 5 and c["B"] == 131072]
-    assert len(cells) >= 130
+             if c["method"] == "zstd" and c["param"] <= 10 and c["B"] == 131072]
+    assert len(cells) >= 160
     for lvl in sorted(set(c["param"] for c in cells)):
         sub = [c for c in cells if c["param"] == lvl]
         blocks = [oracle.synth(0, c["block"], c["B"], c["dist"]) for c in sub]
@@ -163,7 +163,7 @@ def test_zstd_roundtrip_on_device_and_unsupported_levels(codec, oracle):
     for b, o in zip(blocks, outs):
         assert np.array_equal(b, o)
     with pytest.raises(CryoError) as e:
-        codec.compress_blocks(METHOD_ZSTD, 7, blocks[:1])      # lazy and above: no kernel (no CPU fallback)
+        codec.compress_blocks(METHOD_ZSTD, 11, blocks[:1])     # the bt* strategies: no kernel (no CPU fallback)
     assert e.value.code == E_UNSUPPORTED
 
 
@@ -250,7 +250,7 @@ def test_zstd_encode_batch_match_finder_corners(codec, oracle):
         w = np.frombuffer((b"the quick brown fox jumps over the lazy dog, " * (n // 45 + 1))[:n], np.uint8).copy()
         w[rng.integers(0, n, n // 50)] = 0x5A
         blocks.append(w)
-        for level in (-5, -1, 1, 2, 3, 4, 5):
+        for level in (-5, -1, 1, 2, 3, 4, 5, 6, 7, 8, 10):
             got = codec.compress_blocks(METHOD_ZSTD, level, blocks)
             for i, b in enumerate(blocks):
                 exp = oracle.zstd_compress(b, level)
