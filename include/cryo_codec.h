@@ -97,8 +97,8 @@ int cryo_dev_memset(cryo_codec *c, void *d_dst, int value, size_t bytes);       
  *                output bytes identical to liblz4 1.9.3.
  *   method ZSTD: replaces ZSTD_compress(dst,bound,src,B,level) (compression.c:102-104);
  *                param = zstd_compression_level_guc (-5..22).  Output bytes identical to
- *                libzstd 1.4.8 for levels -5..5 (strategies fast, dfast, greedy; also level 6
- *                for blocks above 256 KiB); higher levels return CRYO_E_UNSUPPORTED (no CPU
+ *                libzstd 1.4.8 for levels -5..10 (strategies fast, dfast, greedy, lazy, lazy2);
+ *                levels 11..22 (the binary-tree strategies) return CRYO_E_UNSUPPORTED (no CPU
  *                fallback).
  */
 int cryo_codec_compress_batch(cryo_codec *c, int method, int param,

@@ -4,8 +4,7 @@
  * Restates ZSTD_compress(dst, ZSTD_compressBound(B), src, B, level) as libzstd 1.4.8 runs it
  * for the reference's call shape (compression.c:102-104), for the levels whose strategy is
  * `fast` (levels -5 .. 2 at cryo block sizes; the reference's default
- * level 1 is one of them), `dfast` (levels 3 and 4) or `greedy` / `lazy` / `lazy2` (levels 5 .. 10; these have no
- * device kernel yet: restated ahead of it).  Output bytes are identical to the library's; pinned by
+ * level 1 is one of them), `dfast` (levels 3 and 4) or `greedy` / `lazy` / `lazy2` (levels 5 .. 10).  Output bytes are identical to the library's; pinned by
  * tests/golden/vectors.json (libzstd 1.4.8 == 1.4.9) and by a live differential test.
  *
  * Pipeline restated (all integer arithmetic):
@@ -1043,8 +1042,7 @@ static size_t block_dfast(uint32_t *tlong, uint32_t *tshort, const cpar *cp, con
  * (libzstd 1.4.8 ZSTD_compressBlock_lazy_generic over the hash-chain searcher ZSTD_HcFindBestMatch, no
  * dictionary): every position up to the one searched is inserted into a hash table + chain table; a search
  * walks at most 2^searchLog chain links and keeps the longest match; depth 1/2 retry at ip+1 (ip+2) and keep
- * the candidate whose gain estimate is better.  Groundwork for the next encoder row: there is no device
- * kernel for these levels yet (the product returns CRYO_E_UNSUPPORTED). */
+ * the candidate whose gain estimate is better. */
 typedef struct { uint32_t *hash, *chain; uint32_t next_to_update; } hc_state;
 
 static uint32_t hc_insert_find(hc_state *hc, const cpar *cp, const uint8_t *base, uint32_t target, int mls)

@@ -330,7 +330,7 @@ int cryo_codec_compress_batch(cryo_codec *c, int method, int param, const void *
                                              n_blocks, (uint8_t *)d_dst, dst_stride, param,
                                              d_out_size, d_status));
     } else {
-        /* levels whose strategy has a kernel (fast, dfast, greedy: -5..5, and 6 above 256 KiB); others: CRYO_E_UNSUPPORTED */
+        /* levels whose strategy has a kernel (fast, dfast, greedy, lazy, lazy2: -5..10); others: CRYO_E_UNSUPPORTED */
         if (!cryo::zstd_compress_supported(param, block_size)) return CRYO_E_UNSUPPORTED;
         const size_t need = cryo::zstd_compress_workspace(n_blocks, param, block_size);
         int rc = ensure_ws(c, need);

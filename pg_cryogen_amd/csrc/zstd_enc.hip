@@ -1,14 +1,14 @@
 /*
  * zstd_enc.hip -- Zstandard frame encode, one wavefront per cryo block, output bytes identical
- * to libzstd 1.4.8 for the levels whose strategy is `fast`, `dfast` or `greedy` (levels -5 .. 5 at
- * cryo block sizes; the reference's default zstd_compression_level_guc = 1 is one of them).
+ * to libzstd 1.4.8 for the levels whose strategy is `fast`, `dfast`, `greedy`, `lazy` or `lazy2` (levels
+ * -5 .. 10 at cryo block sizes; the reference's default zstd_compression_level_guc = 1 is one of them).
  *
  * Replaces ZSTD_compress(dst, ZSTD_compressBound(B), src, B, level)
  * (reference compression.c:102-104).
  *
  * Pipeline per 128 KiB zstd block (a 1 MiB cryo block is a frame of 8 dependent blocks):
- *   match finder  : strategy `fast` (levels -5..2) or `dfast` (3, 4), zstd_dfast.h (and `greedy`, level 5,
- *                   zstd_lazy.h: a first wave-uniform version): the walk is a serial
+ *   match finder  : strategy `fast` (levels -5..2) or `dfast` (3, 4), zstd_dfast.h (and `greedy` / `lazy` /
+ *                   `lazy2`, levels 5..10, zstd_lazy.h: a wave-uniform hash-chain walk): the walk is a serial
  *                   recurrence over hash tables that do not fit LDS next to the entropy stage, so the
  *                   tables live in global memory and a step takes the next 16-32 search positions at
  *                   once, one per lane, paying the trips to memory (table slots, candidates, match
@@ -17,8 +17,9 @@
  *   literals      : histogram by LDS atomics (all lanes), length-limited Huffman tree
  *                   (serial, <= 256 symbols), weights FSE-compressed or raw, then the 4
  *                   backward bitstreams: all 64 lanes per stream (runs of symbols, bit offsets by scan).
- *   sequences     : codes + histograms lane-parallel; encoding-type choice, FSE normalisation,
- *                   table description serial; the interleaved LL/OF/ML bitstream reads 64 sequences
+ *   sequences     : codes + histograms lane-parallel; encoding-type choice (thresholds below `lazy`,
+ *                   estimated costs + repeat of the previous block's table from `lazy` on), FSE
+ *                   normalisation, table description serial; the interleaved LL/OF/ML bitstream reads 64 sequences
  *                   at a time into lanes.
  *   block         : raw fallback when the gain is below size/64 + 2, RLE block for constant
  *                   non-first blocks, repeat offsets / Huffman table state carried over only

@@ -113,10 +113,15 @@ def test_gpu_compression_h_surface(HG, oracle):
     assert np.array_equal(zc, oracle.zstd_compress(raw, 1))
     assert L.cryo_decompress(host.COMP_ZSTD, zc.ctypes.data, len(zc), out.ctypes.data) is True
     assert np.array_equal(out, raw) and not errors
-    # levels whose strategy has no kernel (lazy .. btultra2): the reference's error is raised, no CPU fallback ...
+    # a `lazy2` level (9) has a kernel: same bytes as the library
     host.set_int("zstd_compression_level_guc", 9)
+    p = L.cryo_compress(host.COMP_ZSTD, raw.ctypes.data, C.byref(n))
+    z9 = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value,)).copy()
+    assert np.array_equal(z9, oracle.zstd_compress(raw, 9)) and not errors
+    # levels whose strategy has no kernel (btlazy2 .. btultra2, 11..22): the reference's error is raised, no CPU fallback ...
+    host.set_int("zstd_compression_level_guc", 15)
     L.cryo_compress(host.COMP_ZSTD, raw.ctypes.data, C.byref(n))
-    assert errors and errors[-1][1].startswith("pg_cryogen: compression failed") and "no GPU kernel for zstd parameter 9" in errors[-1][1]
+    assert errors and errors[-1][1].startswith("pg_cryogen: compression failed") and "no GPU kernel for zstd parameter 15" in errors[-1][1]
     # ... unless the operator opts in (pg_cryogen.zstd_host_fallback, default off): then the stock library the reference
     # links serves the call on the host, counted, with the library's own bytes -- and the GPU decodes them
     L.cryo_host_fallback_blocks.restype = C.c_uint64
@@ -125,7 +130,7 @@ def test_gpu_compression_h_surface(HG, oracle):
         del errors[:]
         before = L.cryo_host_fallback_blocks()
         host.set_int("cryo_zstd_host_fallback_guc", 1)
-        for lvl in (9, 22):
+        for lvl in (15, 22):
             host.set_int("zstd_compression_level_guc", lvl)
             p = L.cryo_compress(host.COMP_ZSTD, raw.ctypes.data, C.byref(n))
             z = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value,)).copy()

@@ -142,11 +142,12 @@ def test_zstd_encode_bit_exact(codec, oracle, B):
 
 
 def test_zstd_encode_matches_golden_vectors(codec, oracle):
+    """every golden cell of a level with a kernel (-5 .. 10), 128 KiB and 1 MiB blocks"""
     cells = [c for c in json.load(open(os.path.join(G, "vectors.json")))["cells"]
-             if c["method"] == "zstd" and c["param"] <= 10 and c["B"] == 131072]
-    assert len(cells) >= 160
-    for lvl in sorted(set(c["param"] for c in cells)):
-        sub = [c for c in cells if c["param"] == lvl]
+             if c["method"] == "zstd" and c["param"] <= 10 and c["B"] in (131072, 1 << 20)]
+    assert len(cells) >= 320
+    for B, lvl in sorted(set((c["B"], c["param"]) for c in cells)):
+        sub = [c for c in cells if c["param"] == lvl and c["B"] == B]
         blocks = [oracle.synth(0, c["block"], c["B"], c["dist"]) for c in sub]
         got = codec.compress_blocks(METHOD_ZSTD, lvl, blocks)
         for c, g in zip(sub, got):
