@@ -13,8 +13,8 @@
  *                                tables built in LDS, stored to the workspace
  *   K2 k_zhuf   lane per stream  64 Huffman streams per wave (16 blocks x 4 streams), the 16 tables in
  *                                LDS; symbols go to the frame's literal pool
- *   K3 k_zseq   lane per block   FSE sequence decode -> (ll, ml, offset) records; 15 blocks per wave, their
- *                                tables in LDS.  Repeat offsets are resolved on the fly in a frame's first
+ *   K3 k_zseq   lane per block   FSE sequence decode -> (ll, ml, offset) records; 29 blocks per wave, their
+ *                                tables (16-bit entries) in LDS.  Repeat offsets are resolved on the fly in a frame's first
  *                                block; k_zrep (lane per frame) resolves those of later blocks
  *   K4 k_zexec  wave per frame   sequence execution with the shared LZ copy engine (lz_common.h):
  *                                records are loaded 64 at a time, literals stream through the LDS
@@ -24,7 +24,7 @@
  * skippable frames, malformed headers, pool exhaustion) is put on an irregular list and decoded by the
  * fused kernel afterwards, so coverage and error behaviour are exactly the fused decoder's.
  *
- * The batch is processed in tiles of F <= 7680 frames (one full round of K2 and of K3 on 256 CUs) so the
+ * The batch is processed in tiles of F <= 14848 frames (one full round of K3, two of K2 on 256 CUs) so the
  * workspace stays bounded (~2.3 GiB for 128 KiB blocks).
  */
 #include "zstd_common.h"
@@ -594,11 +594,16 @@ __global__ void __launch_bounds__(64) k_zhuf(ZPipe P)
 }
 
 /* ------------------------------------------------------------------------------------------------ K3 */
-constexpr uint32_t kSeqPerWave = 15; /* frames per wave: 15 x 5 KiB of decoding tables in LDS, 2 workgroups per CU */
+constexpr uint32_t kSeqPerWave = 29; /* frames per wave: 29 x 2.5 KiB of decoding tables in LDS, 2 workgroups per CU */
 
+/* K3 is bound by LDS capacity (frames in flight per CU = LDS / table bytes per frame; the per-sequence chain
+ * entry -> bit count -> state bits -> next entry is serial), so the tables are staged as 16-bit entries:
+ * symbol (6 bits) | v (10 bits), v = 1 << (log - nb) | base >> nb -- a next-state base is a multiple of 2^nb by
+ * construction ((nextState << nb) - size), so the position of v's top bit gives nb and the rest gives the base.
+ * The extra-bit counts come from the symbol by arithmetic (seq_xbits), not from the entry. */
 struct SeqLds {
-    uint32_t tab[kSeqPerWave][kSeqTblWords];
-    uint32_t ring[36][16];
+    uint16_t tab[kSeqPerWave][kSeqTblWords];
+    uint32_t ring[36][32];
     uint32_t llx[36], mlx[53]; /* base value | extra bits << 24 (LDS copies: a constant-memory load in the loop
                                   would wait on the ring's in-flight global loads as well) */
 };
@@ -608,7 +613,7 @@ struct SeqState {
 };
 
 /* nb <= 31 bits off the top of the container */
-__device__ inline uint32_t seq_bits(LaneBits<16> &lb, uint32_t nb)
+__device__ inline uint32_t seq_bits(LaneBits<32> &lb, uint32_t nb)
 {
     const uint32_t v = __builtin_amdgcn_ubfe((uint32_t)(lb.c >> 32), 32u - nb, nb);
     lb.skip(nb);
@@ -618,20 +623,36 @@ __device__ inline uint32_t seq_bits(LaneBits<16> &lb, uint32_t nb)
 constexpr uint32_t kRepPending = 0x80000000u; /* record.z = kRepPending | repeat index 0..3 */
 struct SeqPre { uint32_t el, eo, em; }; /* table entries of the next sequence, already on their way from LDS */
 
-/* One sequence.  Entry: next-state base (10 bits) | state bits (4) | symbol (6) | extra bits (5).
+/* extra bits of a literal-length / match-length code: 0 below 16 / 32, a packed nibble table for the next 9 / 11
+ * codes, code - 19 / code - 36 above (the format's tables, RFC 8878 3.1.1.3.2.1.1) */
+__device__ inline uint32_t ll_xbits(uint32_t sym)
+{
+    const uint32_t k = sym - 16u;
+    const uint32_t nib = (uint32_t)(0x433221111ull >> (4u * (k & 15u))) & 15u;
+    return sym < 16u ? 0u : (sym >= 25u ? sym - 19u : nib);
+}
+__device__ inline uint32_t ml_xbits(uint32_t sym)
+{
+    const uint32_t k = sym - 32u;
+    const uint32_t nib = (uint32_t)(0x54433221111ull >> (4u * (k & 15u))) & 15u;
+    return sym < 32u ? 0u : (sym >= 43u ? sym - 36u : nib);
+}
+
+/* One sequence.  Entry (16 bits): symbol (6) | v (10), see SeqLds; cl / co / cm = table log - 31, so that the
+ * state-bit count is clz(v) + c.
  * The serial chain is entries -> bit counts -> state bits -> next states -> next entries; the entry reads
  * and the container fill for sequence i+1 are issued as soon as the states are known, and everything else
  * (base values, repeat offsets, the record store, the ring tick) runs while they are in flight.
  * Bit budget after a fill is >= 57: offset code <= 31 bits, length extras <= 32, state updates <= 26 -- one
  * fill covers the usual sequence, two more are taken only by the lanes that need them. */
 template <int J>
-__device__ inline void seq_step(LaneBits<16> &lb, const uint32_t *tab, const uint32_t *llx, const uint32_t *mlx, SeqState &z,
-                                SeqPre &pre, uint4 *out, uint32_t i, uint32_t nseq, bool resolve)
+__device__ inline void seq_step(LaneBits<32> &lb, const uint16_t *tab, const uint32_t *llx, const uint32_t *mlx, SeqState &z,
+                                SeqPre &pre, uint4 *out, uint32_t i, uint32_t nseq, bool resolve, int32_t cl, int32_t co, int32_t cm)
 {
     if (i + J < nseq) {
         const uint32_t el = pre.el, eo = pre.eo, em = pre.em;
-        const uint32_t lsym = (el >> 14) & 63u, osym = (eo >> 14) & 63u, msym = (em >> 14) & 63u;
-        const uint32_t llbits = (el >> 20) & 31u, mlbits = (em >> 20) & 31u;
+        const uint32_t lsym = el >> 10, osym = eo >> 10, msym = em >> 10;
+        const uint32_t llbits = ll_xbits(lsym), mlbits = ml_xbits(msym);
         int32_t avail = 57;
         /* offset code: osym extra bits (the 1-bit repeat index when osym == 1, none when 0) */
         const uint32_t extra = seq_bits(lb, osym);
@@ -641,11 +662,13 @@ __device__ inline void seq_step(LaneBits<16> &lb, const uint32_t *tab, const uin
         const uint32_t llv = seq_bits(lb, llbits);
         avail -= (int32_t)(mlbits + llbits);
         if (i + J + 1u < nseq) { /* state updates: LL, ML, OF; then start fetching the next sequence */
-            const uint32_t nl = (el >> 10) & 15u, nm = (em >> 10) & 15u, no = (eo >> 10) & 15u;
+            const uint32_t vl = el & 1023u, vm = em & 1023u, vo = eo & 1023u;
+            const uint32_t nl = (uint32_t)(__builtin_clz(vl) + cl), nm = (uint32_t)(__builtin_clz(vm) + cm), no = (uint32_t)(__builtin_clz(vo) + co);
             if (avail < (int32_t)(nl + nm + no)) lb.fill();
-            z.sl = (el & 1023u) + seq_bits(lb, nl);
-            z.sm = (em & 1023u) + seq_bits(lb, nm);
-            z.so = (eo & 1023u) + seq_bits(lb, no);
+            /* (v << nb) - size + bits; size = 1 << (c + 31) */
+            z.sl = (vl << nl) - (1u << (cl + 31)) + seq_bits(lb, nl);
+            z.sm = (vm << nm) - (1u << (cm + 31)) + seq_bits(lb, nm);
+            z.so = (vo << no) - (1u << (co + 31)) + seq_bits(lb, no);
             pre.el = tab[z.sl]; pre.eo = tab[1024u + z.so]; pre.em = tab[512u + z.sm];
             lb.fill();
         }
@@ -686,7 +709,10 @@ __global__ void __launch_bounds__(64) k_zseq(ZPipe P)
             const uint32_t slot = (slots >> (8 * kind)) & 255u, lg = (logs >> (8 * kind)) & 255u;
             const uint32_t goff = kind == 0 ? 0u : (kind == 1 ? 1024u : 512u);
             const uint32_t *g = (slot == kPredefSlot ? P.predef : P.seqt + ((uint64_t)fj * P.nbmax + slot) * kSeqTblWords) + goff;
-            copy_words(&L.tab[j][goff], g, 1u << lg, lane);
+            for (uint32_t q = lane; q < (1u << lg); q += 64u) { /* 25-bit workspace entry -> 16-bit LDS entry */
+                const uint32_t e = g[q], nb = (e >> 10) & 15u;
+                L.tab[j][goff + q] = (uint16_t)((((e >> 14) & 63u) << 10) | (1u << (lg - nb)) | ((e & 1023u) >> nb));
+            }
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -705,11 +731,12 @@ __global__ void __launch_bounds__(64) k_zseq(ZPipe P)
     z.rep0 = 1; z.rep1 = 4; z.rep2 = 8;
     z.sl = z.so = z.sm = 0;
     bool bad = false;
-    LaneBits<16> lb;
-    const bool opened = lb.init(&L.ring[0][lane & 15u], src, act ? d->sq_off : 0u, act ? d->sq_len : 0u, act);
+    LaneBits<32> lb;
+    const bool opened = lb.init(&L.ring[0][lane & 31u], src, act ? d->sq_off : 0u, act ? d->sq_len : 0u, act);
     if (act && !opened) bad = true;
     if (!opened) nseq = 0;
-    const uint32_t *tab = L.tab[lane < kSeqPerWave ? lane : 0u];
+    const uint16_t *tab = L.tab[lane < kSeqPerWave ? lane : 0u];
+    const int32_t cl = (int32_t)(logs & 255u) - 31, co = (int32_t)((logs >> 8) & 255u) - 31, cm = (int32_t)((logs >> 16) & 255u) - 31;
     uint4 *out = P.seqs + (opened ? d->seq_base : 0u);
     SeqPre pre = {0, 0, 0};
     if (opened) {
@@ -722,10 +749,10 @@ __global__ void __launch_bounds__(64) k_zseq(ZPipe P)
     }
     const uint32_t maxn = wave_max(nseq);
     for (uint32_t i = 0; i < maxn; i += 4u) {
-        seq_step<0>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve);
-        seq_step<1>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve);
-        seq_step<2>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve);
-        seq_step<3>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve);
+        seq_step<0>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve, cl, co, cm);
+        seq_step<1>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve, cl, co, cm);
+        seq_step<2>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve, cl, co, cm);
+        seq_step<3>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve, cl, co, cm);
     }
     if (opened && lb.pos != 0) bad = true; /* the bitstream must be consumed exactly */
     if (opened && resolve) { d->rep_out[0] = z.rep0; d->rep_out[1] = z.rep1; d->rep_out[2] = z.rep2; }
@@ -967,14 +994,15 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     y.litcap = ((B + 15u) & ~15u) + 16u * y.nbmax;
     const size_t per_frame = sizeof(ZFrame) + (size_t)y.nbmax * (sizeof(ZBlk) + kHufTblWords * 2u + kSeqTblWords * 4u + 4u) +
                              y.litcap + (size_t)(B / 6u) * sizeof(uint4) /* sequence pool share */ + 4u;
-    /* Tile size.  K2 and K3 are bound by LDS capacity (two workgroups per CU, 512 per chip): 7680 frames
-     * = 512 x 15 (K3) = 480 x 16 (K2) fill exactly one round of each; the workspace budget may force less. */
+    /* Tile size.  K2 and K3 are bound by LDS capacity (two workgroups per CU, 512 per chip): 14848 frames
+     * = 512 x 29 fill exactly one round of K3 (and 928 waves of 16 = two rounds of K2, the second 81 % full); the
+     * workspace budget may force less. */
     static const size_t budget_env = getenv("CRYO_ZSTD_WS_MB") ? (size_t)atoll(getenv("CRYO_ZSTD_WS_MB")) << 20 : 0; /* tuning aid */
     const size_t budget = budget_env ? budget_env : (size_t)10 << 30; /* per tile in flight; reached only by blocks > 128 KiB,
                                                                         whose tiles would otherwise be too few frames to fill K1/K4 */
     uint64_t F = budget / per_frame;
-    if (F > 7680u) F = 7680u;
-    if (F >= 240u) F -= F % 240u;
+    if (F > 14848u) F = 14848u;
+    if (F >= 464u) F -= F % 464u;
     else if (F < 16u) F = 16u;
     if (F > n_blocks) F = n_blocks;
     y.F = (uint32_t)F;
