@@ -36,8 +36,8 @@ namespace cryo {
  * (lz4_dec.hip, lz4_batch: ~7 VALU instructions and four dependent LDS passes per sequence).  Across a
  * batch the walk is embarrassingly parallel.
  *
- * k_lz4_index: 32 blocks per wave (lanes 0..31 each walk one block's token chain), 8 waves per CU, so
- * every block of a 64k-block batch has its walk in flight at once and the pass takes
+ * k_lz4_index: 64 blocks per wave (every lane walks one block's token chain), 4 waves per CU (8 with the
+ * smaller rings), so every block of a 64k-block batch has its walk in flight at once and the pass takes
  * (sequences per block) x (one hop).
  *
  * A lane that read its block straight from global memory paid ~1 us per hop (64 lanes = 64 cache lines
@@ -48,18 +48,20 @@ namespace cryo {
  * latency is covered by four hops.  The walk is a small state machine per lane (token / literal-length
  * extension / match-length extension) so that one LDS read per hop serves every lane, whatever it is in.
  * --------------------------------------------------------------------------------------------- */
-constexpr uint32_t kIdxLanes = 64, kIdxRing = 512, kIdxStride = kIdxRing + 16 /* bank skew between rings */, kIdxChunk = 128;
+constexpr uint32_t kIdxLanes = 64, kIdxChunk = 128;
 
 __device__ inline uint32_t bperm(uint32_t v, uint32_t src_lane)
 {
     return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
 }
 
+template <uint32_t kIdxRing> /* bytes of LDS ring per block: 512, or 256 (twice the waves per CU) */
 __global__ void __launch_bounds__(64)
 k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
             const uint32_t *__restrict__ src_size, uint64_t n_blocks, uint16_t *__restrict__ tbl, uint32_t cap,
             uint32_t *__restrict__ tbl_n)
 {
+    constexpr uint32_t kIdxStride = kIdxRing + 16u; /* bank skew between rings */
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[kIdxLanes * kIdxStride];
     const uint32_t lane = threadIdx.x;
     const uint64_t blk = (uint64_t)blockIdx.x * kIdxLanes + (lane & (kIdxLanes - 1u));
@@ -77,7 +79,6 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     uint16_t *row = tbl + blk * cap;
     uint16_t *dummy = tbl + n_blocks * cap + lane * 8u; /* 8 bytes per lane behind the rows: where lanes without a block store */
     if (!owner) aoff = src_off[0] & ~(uint64_t)127; /* a lane past the end of the batch re-reads block 0 */
-    uint8_t *ring = s_ring + (lane & (kIdxLanes - 1u)) * kIdxStride;
     uint32_t pos = delta;        /* next byte to interpret */
     uint32_t requested = 0;      /* chunks requested up to here (multiple of kIdxChunk) */
     uint32_t filled = 0;         /* chunks stored in the ring up to here */
@@ -560,8 +561,14 @@ size_t lz4_index_workspace(uint64_t n_blocks, uint32_t block_size)
 hipError_t launch_lz4_index(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
                             uint64_t n_blocks, uint16_t *tbl, uint32_t cap, uint32_t *tbl_n)
 {
-    hipLaunchKernelGGL(k_lz4_index, dim3((uint32_t)((n_blocks + kIdxLanes - 1) / kIdxLanes)), dim3(64), 0, s, d_src, d_src_off, d_src_size,
-                       n_blocks, tbl, cap, tbl_n);
+    /* 512-byte rings admit four waves per CU (one per SIMD).  256-byte rings (eight waves per CU) were measured and lose:
+     * 65 536 blocks 895 -> 677 GB/s, 131 072 blocks 907 -> 657 GB/s end to end -- a chunk is requested only when the
+     * walk is within 128 bytes of the end of what it has, and waits for it. */
+    static const uint32_t ring_env = getenv("CRYO_LZ4_IDX_RING") ? (uint32_t)atoi(getenv("CRYO_LZ4_IDX_RING")) : 0u; /* tuning aid */
+    const uint32_t ring = ring_env ? ring_env : 512u;
+    const dim3 g((uint32_t)((n_blocks + kIdxLanes - 1) / kIdxLanes));
+    if (ring == 256u) hipLaunchKernelGGL(k_lz4_index<256>, g, dim3(64), 0, s, d_src, d_src_off, d_src_size, n_blocks, tbl, cap, tbl_n);
+    else hipLaunchKernelGGL(k_lz4_index<512>, g, dim3(64), 0, s, d_src, d_src_off, d_src_size, n_blocks, tbl, cap, tbl_n);
     return hipGetLastError();
 }
 
@@ -576,8 +583,7 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
     const uint32_t cap = lz4_index_cap(block_size);
     uint16_t *tbl = static_cast<uint16_t *>(d_workspace);
     uint32_t *tbl_n = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_workspace) + (((size_t)n_blocks * cap * 2u + 1024u + 15u) & ~(size_t)15u));
-    hipLaunchKernelGGL(k_lz4_index, dim3((uint32_t)((n_blocks + kIdxLanes - 1) / kIdxLanes)), dim3(64), 0, s, d_src, d_src_off, d_src_size,
-                       n_blocks, tbl, cap, tbl_n);
+    if (hipError_t e = launch_lz4_index(s, d_src, d_src_off, d_src_size, n_blocks, tbl, cap, tbl_n); e != hipSuccess) return e;
     const dim3 g((uint32_t)grid), b(256);
     static const bool want_stats = getenv("CRYO_LZ4_STATS") != nullptr; /* debugging aid */
     if (want_stats) {
