@@ -51,7 +51,9 @@ __device__ inline uint32_t hc_insert_find(HcState &hc, uint8_t *mark, const CPar
     return uni(hc.hash[hashs_v(ld64u(base + target), cp.hlog, mls)]);
 }
 
-/* ZSTD_HcFindBestMatch: longest match among at most 2^searchLog chain links; *offset_ptr = distance + 2 */
+/* ZSTD_HcFindBestMatch: longest match among at most 2^searchLog chain links; *offset_ptr = distance + 2.
+ * One trip to memory per link: the next link and the candidate's first 64 bytes are requested together (the
+ * library's byte test at [ml] before counting is only a shortcut: a candidate that fails it cannot be longer). */
 __device__ inline uint32_t hc_find_best(HcState &hc, uint8_t *mark, const CPar &cp, const uint8_t *base, uint32_t cur, uint32_t iend,
                                         uint32_t *offset_ptr, int mls, uint32_t lane)
 {
@@ -62,16 +64,21 @@ __device__ inline uint32_t hc_find_best(HcState &hc, uint8_t *mark, const CPar &
     uint32_t attempts = 1u << cp.slog;
     uint32_t ml = 4u - 1u;
     uint32_t mi = hc_insert_find(hc, mark, cp, base, cur, mls, lane);
+    const bool inb = cur + lane < iend;
+    const uint32_t mine = inb ? base[cur + lane] : 0u; /* the 64 bytes at the search position, one per lane */
     for (; mi >= low_limit && attempts > 0u; attempts--) {
-        uint32_t cml = 0;
-        if (uni(base[mi + ml]) == uni(base[cur + ml])) cml = count_match(base + cur, base + mi, base + iend, lane);
+        const uint32_t nxt = hc.chain[mi & cmask];
+        const uint32_t theirs = inb ? base[mi + lane] : 256u;
+        const unsigned long long neq = __ballot(theirs != mine);
+        uint32_t cml = neq ? ctz64(neq) : 64u;
+        if (cml == 64u) cml += count_match(base + cur + 64u, base + mi + 64u, base + iend, lane);
         if (cml > ml) {
             ml = cml;
             *offset_ptr = cur - mi + 2u;
             if (cur + cml == iend) break;
         }
         if (mi <= min_chain) break;
-        mi = uni(hc.chain[mi & cmask]);
+        mi = uni(nxt);
     }
     return ml;
 }
