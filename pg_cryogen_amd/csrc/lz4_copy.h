@@ -72,7 +72,8 @@ __device__ inline void lane_runs(uint8_t *ring, const uint8_t *sbase, uint32_t r
 /*
  * Copy the bytes of up to 64 sequences (lane i < nseq holds sequence i).
  *   ostart: first output byte of the sequence inside the batch; ll literal bytes from virtual input position
- *   lpos, then ml match bytes at distance off (off >= ml: no overlap inside one match); T = total bytes <= TMAX.
+ *   lpos, then ml match bytes at distance off (a match with off < ml overlaps itself: it is always a dependent one
+ *   and the frontier rounds take it off bytes at a time; callers keep those short); T = total bytes <= TMAX.
  *   isfar: the match's source is no longer in the ring; its bytes are in xfa/xfb (requested by the caller).
  */
 template <uint32_t R, uint32_t TMAX>

@@ -245,7 +245,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     const uint32_t ostart = oend - outlen;
     const uint32_t mabs = w.op + ostart + ll; /* absolute output position of the match */
     const bool isfar = cand && off >= R - kTMax; /* R - T >= T + 1023: in the ring for the whole batch, or flushed before it */
-    const bool ok = cand && !(hasM && e2 == 255u) && off >= ml && off <= mabs &&
+    const bool ok = cand && !(hasM && e2 == 255u) && (off >= ml || (off != 0u && ml <= 64u)) /* short self-overlap: a dependent match, lz4_copy.h */ && off <= mabs &&
                     pos + dlen <= vsafe && oend <= kTMax && w.op + oend + 16u <= B && !(isfar && ml > 32u);
     const unsigned long long badmask = __ballot(!ok);
     const uint32_t nseq = badmask ? ctz64(badmask) : 64u;

@@ -262,7 +262,8 @@ __device__ inline uint32_t lane_next(uint32_t v)
 template <uint32_t R>
 __device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const CopyLds<R, kT2> &L, uint32_t &vp, const uint32_t B,
                                          const uint32_t epos, const uint32_t navail, const uint16_t *__restrict__ trow,
-                                         const uint32_t n0, const uint32_t ntab, uint32_t &epre, Stats &st)
+                                         const uint32_t n0, const uint32_t ntab, uint32_t &epre, Stats &st,
+                                         unsigned long long *stop_hist = nullptr)
 {
     const uint32_t lane = w.lane;
     const uint32_t vend = w.vend;
@@ -314,11 +315,20 @@ __device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const CopyLds<R, kT2> &L, u
     /* far matches (source older than the ring can still hold when the batch is done; already flushed): two 16-byte
      * requests per lane */
     constexpr uint32_t kNear = R - kT2;
+    /* a short match that overlaps itself (runs: offset 1..3) stays in the batch: it is a dependent match, and the
+     * frontier rounds of match space resolve it off bytes per round.  Leaving it to the general path cost a cut
+     * batch, an empty one and the wave-uniform parser, 12 times per block on tuple data. */
+    constexpr uint32_t kOvlMax = 64;
     const bool isfar = cand && off >= kNear;
-    const bool ok = cand && inwin && chain && !(t >= 0xf0u && e1 == 255u) && !(hasM && e2 == 255u) && off >= ml && off <= mabs &&
+    const bool ok = cand && inwin && chain && !(t >= 0xf0u && e1 == 255u) && !(hasM && e2 == 255u) && (off >= ml || (off != 0u && ml <= kOvlMax)) && off <= mabs &&
                     pos + dlen <= vsafe && oend <= kT2 && w.op + oend + 16u <= B && !(isfar && ml > 32u);
     const unsigned long long badmask = __ballot(!ok);
     const uint32_t nseq = badmask ? ctz64(badmask) : 64u;
+    if (st.on && stop_hist && badmask && nseq < navail && lane == nseq) { /* why the batch stops in front of this sequence */
+        const int why = !cand ? 0 : !inwin ? 1 : !chain ? 2 : (t >= 0xf0u && e1 == 255u) ? 3 : (hasM && e2 == 255u) ? 4 : (off < ml && (off == 0u || ml > kOvlMax)) ? 5 : off > mabs ? 6
+                        : pos + dlen > vsafe ? 7 : oend > kT2 ? 8 : w.op + oend + 16u > B ? 9 : 10;
+        atomicAdd(&stop_hist[why], 1ull);
+    }
     stamp(st, 1);
     if (!(st.ablate & 2u)) w.flush();   /* what earlier batches produced; far sources below are read back from it */
     else w.flushed = w.op & ~(kChunk - 1u);
@@ -512,7 +522,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
                 uint32_t e = epre;
                 const uint32_t navail = n0 < ntab ? (ntab - n0 < 64u ? ntab - n0 : 64u) : 0u;
                 if (!have_pre) { e = 0; if (lane < navail) e = trow[n0 + lane]; }
-                n = lz4_seq_batch<R>(w, L, vp, B, e, navail, trow, n0, ntab, epre, st);
+                n = lz4_seq_batch<R>(w, L, vp, B, e, navail, trow, n0, ntab, epre, st, STATS ? stats + 16 : nullptr);
                 have_pre = n != 0u;
                 n0 += n;
                 if (n == 0u) st.zero_batches++;
@@ -587,7 +597,7 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
     const dim3 g((uint32_t)grid), b(256);
     static const bool want_stats = getenv("CRYO_LZ4_STATS") != nullptr; /* debugging aid */
     if (want_stats) {
-        unsigned long long *d_st = nullptr, h_st[16];
+        unsigned long long *d_st = nullptr, h_st[32];
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
         static const unsigned long long abl = getenv("CRYO_LZ4_ABLATE") ? strtoull(getenv("CRYO_LZ4_ABLATE"), nullptr, 0) : 0ull; /* timing experiments: wrong bytes */
@@ -603,6 +613,9 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
         for (int k = 0; k < 8; k++) tot += h_st[8 + k];
         static const char *nm[8] = {"stage", "decode+validate", "flush", "requests", "lane runs+bitmap", "-", "match space", "general+other"};
         for (int k = 0; k < 8; k++) fprintf(stderr, "[lz4 seq cycles] %-16s %5.1f%%\n", nm[k], 100.0 * (double)h_st[8 + k] / (double)(tot ? tot : 1));
+        fprintf(stderr, "[lz4 seq stops] not a candidate %llu, offset outside the window %llu, chain %llu, literal 255-run %llu, match 255-run %llu, "
+                        "overlapping match %llu, offset too far %llu, end of input %llu, batch full (T) %llu, end of output %llu, far and long %llu\n",
+                h_st[16], h_st[17], h_st[18], h_st[19], h_st[20], h_st[21], h_st[22], h_st[23], h_st[24], h_st[25], h_st[26]);
         return hipGetLastError();
     }
     hipLaunchKernelGGL((k_lz4_dec_seq<4096, false>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,

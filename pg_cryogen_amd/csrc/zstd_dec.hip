@@ -233,7 +233,7 @@ __device__ bool decode_block(ZLds &L, Wave<ZR> &w, FrameState &fs, const uint8_t
             const uint32_t litend = scan64_incl(inq ? q_ll : 0u); /* literals consumed up to and incl. this sequence */
             const uint32_t mabs = w.op + ostart + q_ll;
             const bool isfar = inq && q_off >= ZR - kTMax;
-            const bool ok = inq && lit_mode == 0 && q_ml <= q_off && q_off <= mabs && !(isfar && q_ml > 32u) &&
+            const bool ok = inq && lit_mode == 0 && (q_ml <= q_off || (q_off != 0u && q_ml <= 64u)) /* short self-overlap: a dependent match, lz4_copy.h */ && q_off <= mabs && !(isfar && q_ml > 32u) &&
                             litend <= regen - lit_pos && oend <= kTMax && (uint64_t)w.op + oend <= cap;
             const unsigned long long badmask = __ballot(!ok);
             const uint32_t nb = badmask ? ctz64(badmask) : 64u;

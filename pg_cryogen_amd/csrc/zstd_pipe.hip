@@ -858,7 +858,7 @@ __device__ bool exec_block(ExecLds &L, Wave<ZR> &w, const ZPipe &P, const ZBlk *
         const uint32_t litend = scan64_incl(inq ? q_ll : 0u);
         const uint32_t mabs = w.op + ostart + q_ll;
         const bool isfar = inq && q_off >= ZR - kTMax; /* in the ring for the whole batch, or flushed before it (lz4_copy.h) */
-        const bool ok = inq && streamed && q_ml <= q_off && q_off <= mabs && !(isfar && q_ml > 32u) &&
+        const bool ok = inq && streamed && (q_ml <= q_off || (q_off != 0u && q_ml <= 64u)) /* short self-overlap: a dependent match, lz4_copy.h */ && q_off <= mabs && !(isfar && q_ml > 32u) &&
                         litend <= regen - lit_pos && oend <= kTMax && (uint64_t)w.op + oend <= cap;
         const unsigned long long badmask = __ballot(!ok);
         const uint32_t nb = badmask ? ctz64(badmask) : 64u;
