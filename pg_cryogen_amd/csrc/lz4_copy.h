@@ -30,7 +30,7 @@ struct CopyLds {
     static constexpr uint32_t kWords = kBmW + kNc;
     uint8_t *ring;                 /* R + 16: output ring; a literal piece that runs over the end lands in the 16 extra bytes and is folded back */
     uint8_t *in;                   /* kInRing + 16: input ring; the extra bytes mirror its first 16 (16-byte reads near the end) */
-    uint2 *mmeta;                  /* 64: sequence s   -> (output position of its match minus its position in match space, offset)                    */
+    uint32_t *mmeta;               /* 64: dependent match -> (start of its match inside the batch minus its position in match space: 11 bits) | offset << 11 */
     uint32_t *mbm;                 /* kBmW + kNc: bitmap of match starts in match space, then per-chunk bases */
 };
 
@@ -56,6 +56,17 @@ __device__ inline void lane_runs(uint8_t *ring, const uint8_t *sbase, uint32_t r
             sv += 16u; dv += 16u; rem -= 16u;
             it++;
         }
+    }
+    /* what is left of a run that already moved 16 bytes: one more 16-byte copy that ends where the run ends (it
+     * rewrites a few bytes with the same data) instead of up to four exact pieces */
+    const bool lap = rem != 0u && it != 0u && !far;
+    if (lap) {
+        uint4 v;
+        __builtin_memcpy(&v, sbase + ((sv + rem - 16u) & SMASK), 16);
+        const uint32_t di = (dv + rem - 16u) & (R - 1u);
+        __builtin_memcpy(ring + di, &v, 16);
+        if (di + 16u > R) spill = di + 16u - R;
+        rem = 0u;
     }
     if (rem != 0u) {
         uint4 v = it == 0u ? xa : xb;
@@ -108,7 +119,8 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
         /* bit (start - 1) for every dependent match that starts at a position >= 1 of match space: the number of set
          * bits BELOW a position is the rank of the match it belongs to.
          * meta: x = output position of the match minus its position in match space; y = offset */
-        L.mmeta[drank] = make_uint2(op0 + mrel - mcum, off);
+        static_assert(TMAX < 2048u, "11 bits");
+        L.mmeta[drank] = (mrel - mcum) | (off << 11); /* off < 2^21: LZ4's 16 bits, zstd's window */
         if (mcum != 0u) atomicOr(&L.mbm[(mcum - 1u) >> 5], 1u << ((mcum - 1u) & 31u));
     }
     LDS_FENCE();
@@ -152,7 +164,7 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
             bool pendv[U], actv[U];
             {
                 uint32_t idx[U];
-                uint2 mt[U];
+                uint32_t mt[U];
 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) {
                     const uint32_t c = c0 + u < kNc ? c0 + u : kNc - 1u;
@@ -166,8 +178,8 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
                 for (uint32_t u = 0; u < U; u++) {
                     const uint32_t m = (c0 + u) * 64u + lane;
                     const bool a = m < MT;
-                    da[u] = m + mt[u].x;                  /* absolute output position of this byte */
-                    ra[u] = da[u] - mt[u].y;              /* ... and of its source                  */
+                    da[u] = op0 + m + (mt[u] & 2047u);    /* absolute output position of this byte */
+                    ra[u] = da[u] - (mt[u] >> 11);            /* ... and of its source                  */
                     const uint32_t d0 = uni(da[u]);       /* first byte of the chunk               */
                     actv[u] = a;
                     pendv[u] = a && ra[u] >= d0;

@@ -97,7 +97,7 @@ struct WaveLds {
     uint8_t *d1;                           /* kD1N  (phase 3 reuses it as `meta`)         */
     uint8_t *__restrict__ d2;              /* kD2N                                        */
     uint8_t *__restrict__ d4;              /* kWMax                                       */
-    uint2 *mmeta;                          /* 64: match meta of the copy engine (lz4_copy.h); lies over d1, dead by then */
+    uint32_t *mmeta;                       /* 64: match meta of the copy engine (lz4_copy.h); lies over d1, dead by then */
     uint32_t *bm;                          /* kTMax/32 + 16: the copy engine's match-space bitmap and chunk bases */
     const uint8_t *lut;                    /* 256: token -> distance to the next token (see lz4_token_lut) */
 };
@@ -301,7 +301,7 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
 
     Wave<R> w;
     const WaveLds<R> L = {s_ring[wid], s_in[wid], s_d1[wid], s_d2[wid], s_d4[wid],
-                          reinterpret_cast<uint2 *>(s_d1[wid]), s_bm[wid], s_lut};
+                          reinterpret_cast<uint32_t *>(s_d1[wid]), s_bm[wid], s_lut};
     {
         uint32_t v = 0;
 #pragma unroll

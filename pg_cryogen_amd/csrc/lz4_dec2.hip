@@ -462,7 +462,7 @@ __device__ inline uint32_t lz4_general_seq(Wave<R> &w, uint32_t &vp, const uint3
 }
 
 template <uint32_t R, bool STATS>
-__global__ void __launch_bounds__(256, 5)
+__global__ void __launch_bounds__(256, 6)
 k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
               const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
               uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats,
@@ -473,7 +473,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     if (STATS) { st.ablate = (uint32_t)stats[7]; st.t0 = __builtin_amdgcn_s_memtime(); }
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][R + 16];
     __shared__ __attribute__((aligned(16))) uint8_t s_in[4][kInRing + 16];
-    __shared__ __attribute__((aligned(8))) uint2 s_mmeta[4][64];
+    __shared__ __attribute__((aligned(8))) uint32_t s_mmeta[4][64]; /* packed: 26 880 bytes per workgroup, six per CU */
     __shared__ __attribute__((aligned(8))) uint32_t s_mbm[4][CopyLds<R, kT2>::kWords];
 
     const uint32_t lane = threadIdx.x & 63u;

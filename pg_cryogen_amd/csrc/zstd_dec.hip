@@ -42,7 +42,7 @@ struct ZLds {
     uint32_t wdt[64]; /* FSE table of the Huffman weights */
     uint8_t wts[256];
     uint8_t cell[512];
-    uint2 meta[64];              /* copy engine: match meta */
+    uint32_t meta[64];           /* copy engine: match meta */
     uint32_t bm[CopyLds<ZR, kTMax>::kWords]; /* copy engine: bitmap of match starts + per-chunk bases */
 };
 

@@ -812,7 +812,7 @@ namespace {
 struct ExecLds {
     uint8_t ring[ZR + 16];   /* + the copy engine's 16-byte tail (lz4_copy.h) */
     uint8_t in[kInRing + 16];
-    uint2 meta[64];
+    uint32_t meta[64];
     uint32_t bm[CopyLds<ZR, kTMax>::kWords];
 };
 
