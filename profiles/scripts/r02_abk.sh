@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of two builds, per-kernel times by rocprofv3
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-prof() { rm -rf /tmp/abk; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abk -o r -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > /dev/null 2>&1
+prof() { rm -rf /tmp/abk; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abk -o r -- python3 bench.py --steps ${STEPS:-20} --warmup ${WARM:-3} --no-cpu-baseline "$@" > /dev/null 2>&1
 python3 - <<'PY'
 import csv,glob
 f=glob.glob('/tmp/abk/**/*kernel_stats.csv',recursive=True)[0]
