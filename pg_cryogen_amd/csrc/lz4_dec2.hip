@@ -573,7 +573,9 @@ hipError_t launch_lz4_index(hipStream_t s, const uint8_t *d_src, const uint64_t 
 {
     /* 512-byte rings admit four waves per CU (one per SIMD).  256-byte rings (eight waves per CU) were measured and lose:
      * 65 536 blocks 895 -> 677 GB/s, 131 072 blocks 907 -> 657 GB/s end to end -- a chunk is requested only when the
-     * walk is within 128 bytes of the end of what it has, and waits for it. */
+     * walk is within 128 bytes of the end of what it has, and waits for it.  Nor do 64-byte chunks into 256-byte rings
+     * (two request turns per round; measured 902 -> 818 and 931 -> 746 GB/s): more resident waves make this pass slower,
+     * not faster, so it is not only a lone wave's instruction issue that paces it. */
     static const uint32_t ring_env = getenv("CRYO_LZ4_IDX_RING") ? (uint32_t)atoi(getenv("CRYO_LZ4_IDX_RING")) : 0u; /* tuning aid */
     const uint32_t ring = ring_env ? ring_env : 512u;
     const dim3 g((uint32_t)((n_blocks + kIdxLanes - 1) / kIdxLanes));
