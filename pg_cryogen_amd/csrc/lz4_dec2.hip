@@ -63,6 +63,8 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
 {
     constexpr uint32_t kIdxStride = kIdxRing + 16u; /* bank skew between rings */
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[kIdxLanes * kIdxStride];
+    /* the last 16 positions of every lane (4 groups of 4) + one slot where a lane that records nothing writes */
+    __shared__ __attribute__((aligned(8))) uint16_t s_pos[kIdxLanes][20];
     const uint32_t lane = threadIdx.x;
     const uint64_t blk = (uint64_t)blockIdx.x * kIdxLanes + (lane & (kIdxLanes - 1u));
     const bool owner = blk < n_blocks;
@@ -86,7 +88,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     uint32_t state = 0;          /* 0 token, 1 literal-length extension, 2 match-length extension */
     uint32_t acc = 0, tm = 0;    /* literal length being accumulated; match nibble of the current token */
     uint32_t k = 0;
-    unsigned long long pack = 0, packp = 0, packpp = 0; /* the group of four positions being filled, the two before it */
+    uint16_t *pbuf = s_pos[lane & (kIdxLanes - 1u)];
     bool done = !owner || vend == delta;
 
     /* what this lane serves in turn j: one 16-byte piece of the next chunk of blocks 16j + (lane >> 3) and
@@ -157,12 +159,8 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             const bool ext = go && state == 2u;
             /* record + advance */
             const bool rec = tok;
-            if (rec) {
-                const unsigned long long e = (unsigned long long)((pos - delta) & 0xffffu) << (16u * (k & 3u));
-                if ((k & 3u) == 0u) { packpp = packp; packp = pack; pack = e; } else pack |= e;
-                k++;
-                tm = tmn;
-            }
+            pbuf[rec ? (k & 15u) : 16u] = (uint16_t)(pos - delta); /* unconditional: a store in a branch costs more than the branch saves */
+            if (rec) { k++; tm = tmn; }
             const bool fin = tok && !longlit && q2 > vend;              /* last sequence: literals only */
             if (tok && !longlit && !fin) { pos = q2; state = tmn == 15u ? 2u : 0u; }
             /* a second token in the same turn when the first one leaves it inside the eight bytes just read: no or
@@ -175,9 +173,9 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
                 const uint32_t llb = (y >> 4) & 15u, e1b = (y >> 8) & 255u, tmb = y & 15u;
                 const bool l15b = llb == 15u;
                 const uint32_t q2b = q2 + 3u + llb + (l15b ? e1b + 1u : 0u);
-                if (dbl && !(l15b && e1b == 255u)) {
-                    const unsigned long long e = (unsigned long long)((q2 - delta) & 0xffffu) << (16u * (k & 3u));
-                    if ((k & 3u) == 0u) { packpp = packp; packp = pack; pack = e; } else pack |= e;
+                const bool rec2 = dbl && !(l15b && e1b == 255u);
+                pbuf[rec2 ? (k & 15u) : 16u] = (uint16_t)(q2 - delta);
+                if (rec2) {
                     k++;
                     tm = tmb;
                     if (q2b > vend) done = true;
@@ -219,10 +217,14 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
 #define IDX_PUT()                                                                                            \
     {                                                                                                        \
         const uint32_t g = k ? (k - 1u) >> 2 : 0u;                                                           \
+        const uint32_t g2 = g > 1u ? g - 2u : 0u, g1 = g ? g - 1u : 0u;                                      \
         uint16_t *r = owner ? row : dummy;                                                                   \
-        const unsigned long long v2 = g > 1u ? packpp : (g ? packp : pack), v1 = g ? packp : pack, v0 = pack; \
-        __builtin_memcpy(r + 4u * (g > 1u ? g - 2u : 0u), &v2, 8);                                           \
-        __builtin_memcpy(r + 4u * (g ? g - 1u : 0u), &v1, 8);                                                \
+        unsigned long long v2, v1, v0;                                                                       \
+        __builtin_memcpy(&v2, pbuf + 4u * (g2 & 3u), 8);                                                     \
+        __builtin_memcpy(&v1, pbuf + 4u * (g1 & 3u), 8);                                                     \
+        __builtin_memcpy(&v0, pbuf + 4u * (g & 3u), 8);                                                      \
+        __builtin_memcpy(r + 4u * g2, &v2, 8);                                                               \
+        __builtin_memcpy(r + 4u * g1, &v1, 8);                                                               \
         __builtin_memcpy(r + 4u * g, &v0, 8);                                                                \
     }
 #define IDX_TURN(j, n, sa, sb) turn(j, fd##n, fe##n, fa##n, fb##n, fp##n, fq##n, fo##n, saoff##sa, svend##sa, saoff##sb, svend##sb);
