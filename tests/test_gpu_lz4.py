@@ -244,6 +244,21 @@ def test_lz4_indexed_decoder_large_batch(codec, oracle):
                 p = int(rng.integers(0, B - 600)); a[p:p + 600] = a[p]
             uniq_raw.append(a)
             uniq_comp.append(oracle.lz4_compress(a, 1))
+        # run-heavy blocks: many short matches that overlap themselves (offset 1..8 < length <= ~80), at every phase
+        # of a batch and across the 64-byte chunks of match space: the copy engine keeps those up to 64 bytes in the batch
+        for k in range(40):
+            a = np.empty(B, np.uint8)
+            pos_ = 0
+            while pos_ < B:
+                per = int(rng.integers(1, 9)); ln = int(rng.integers(5, 80)); lit = int(rng.integers(0, 6))
+                seg = np.concatenate([rng.integers(0, 256, lit + per, dtype=np.uint8), np.zeros(ln, np.uint8)])
+                for j in range(lit + per, len(seg)):
+                    seg[j] = seg[j - per]
+                take = min(len(seg), B - pos_)
+                a[pos_:pos_ + take] = seg[:take]
+                pos_ += take
+            uniq_raw.append(a)
+            uniq_comp.append(oracle.lz4_compress(a, 1))
         # mutated streams: verdict and bytes as the oracle's
         muts = []
         for c in uniq_comp[:30]:
