@@ -249,6 +249,9 @@ def main():
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         verify_all()
+        if rank == 0 and os.environ.get("CRYO_BENCH_TRACE"):   # diagnostic: the per-step times, ten per line
+            for i in range(0, len(kernel_ms), 10):
+                print("[bench trace] steps %3d..: %s" % (i, " ".join("%.2f" % x for x in kernel_ms[i:i + 10])), file=sys.stderr)
         if rank == 0:
             avg_ms = float(np.mean(kernel_ms))
             algo_bytes = comp_bytes + n * B        # per decode call: compressed bytes read + B written per block
