@@ -218,7 +218,7 @@ def main():
     if a.workload.endswith("_decode"):
         is_lz4 = a.workload == "lz4_decode"
         method, param, mname = (METHOD_LZ4, a.accel, "lz4") if is_lz4 else (METHOD_ZSTD, a.level, "zstd")
-        stride = (bound(method, B) + 15) & ~15
+        stride = ((bound(method, B) + 15) & ~15) + int(os.environ.get("CRYO_BENCH_STRIDE_PAD", "0"))   # pad: layout experiments
         d_comp, d_sizes, d_off = alloc(n * stride), alloc(4 * n), alloc(8 * n)
         codec.timer_start()
         codec.compress_batch(method, param, d_raw, B, B, n, d_comp, stride, d_sizes, d_status)
@@ -250,6 +250,7 @@ def main():
         elapsed = max_over_ranks(time.perf_counter() - t0)
         verify_all()
         if rank == 0 and os.environ.get("CRYO_BENCH_TRACE"):   # diagnostic: the per-step times, ten per line
+            print("[bench trace] device pointers: comp %#x out %#x raw %#x" % tuple(int(getattr(x, "ptr", 0) or 0) for x in (d_comp, d_out, d_raw)), file=sys.stderr)
             for i in range(0, len(kernel_ms), 10):
                 print("[bench trace] steps %3d..: %s" % (i, " ".join("%.2f" % x for x in kernel_ms[i:i + 10])), file=sys.stderr)
         if rank == 0:
