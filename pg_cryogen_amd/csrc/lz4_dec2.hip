@@ -509,6 +509,10 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     uint32_t n0 = 0; /* sequences decoded so far */
     uint32_t poor = 0;
 
+    /* the first batch's index entries travel with the first input chunks (one trip to memory at the start of a block, not two) */
+    uint32_t efirst = 0;
+    if (!bad && lane < ntab) efirst = trow[lane];
+    bool have_first = !bad;
     if (!bad) {
         w.prefetch();
         w.refill();
@@ -518,8 +522,9 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     while (!done) {
         if (skip == 0u) {
             uint32_t n;
-            uint32_t epre = 0;
-            bool have_pre = false;
+            uint32_t epre = efirst;
+            bool have_pre = have_first;
+            have_first = false;
             do {
                 uint32_t e = epre;
                 const uint32_t navail = n0 < ntab ? (ntab - n0 < 64u ? ntab - n0 : 64u) : 0u;
