@@ -568,7 +568,15 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
 }
 
 /* ---- launcher ---- */
-uint32_t lz4_index_cap(uint32_t block_size) { return ((block_size / 8u + 64u) + 3u) & ~3u; }
+/* Entries per row: B/8 + 64 rounded up to 1024 entries, i.e. rows 2 KiB-granular (34 816 bytes at 128 KiB blocks).  The
+ * index pass writes 64 rows at once, 8 bytes each, and is sensitive to the row stride: with 33 024 bytes (+64 entries)
+ * it always runs 17 % slower (3.6 instead of 3.05 ms), with the natural 32 896 sometimes, with 33 792 / 34 816 never
+ * in 30 samples each (profiles/scripts/r02_cap.sh). */
+uint32_t lz4_index_cap(uint32_t block_size)
+{
+    static const uint32_t pad = getenv("CRYO_LZ4_IDX_CAP_PAD") ? (uint32_t)atoi(getenv("CRYO_LZ4_IDX_CAP_PAD")) & ~3u : 0u; /* layout experiments */
+    return ((block_size / 8u + 64u + 1023u) & ~1023u) + pad;
+}
 
 size_t lz4_index_workspace(uint64_t n_blocks, uint32_t block_size)
 {
