@@ -196,7 +196,8 @@ def main():
         return ora.zstd_compress(raw, param) if method == METHOD_ZSTD else ora.lz4_compress(raw, param)
 
     d_raw = alloc(n * B)
-    d_out = alloc(n * B)
+    ostride = B + int(os.environ.get("CRYO_BENCH_OUT_PAD", "0"))   # pad: layout experiments (decode workloads)
+    d_out = alloc(n * ostride)
     d_status, d_mis = alloc(4 * n), alloc(8)
     codec.synth_batch(0, rank, n, B, dist_id, d_raw, block_step=world)
     ncpu = min(a.cpu_blocks, n)
@@ -209,7 +210,7 @@ def main():
         st = d_status.download(dtype=np.int32)
         assert a.no_verify or (st == 0).all(), "decode status"
         d_mis.memset(0)
-        codec.compare_batch(d_raw, B, d_out, B, B, n, d_mis)
+        codec.compare_batch(d_raw, B, d_out, ostride if a.workload.endswith("_decode") else B, B, n, d_mis)
         codec.sync()
         mismatch = int(d_mis.download(dtype=np.uint64)[0])
         assert a.no_verify or mismatch == 0, "decoded blocks differ from originals: %d" % mismatch
@@ -234,7 +235,7 @@ def main():
         cpu_comps = [d_comp.download(int(sizes[i]), offset=i * stride) for i in cpu_idx] if want_cpu else []
 
         def step():
-            codec.decompress_batch(method, d_comp, d_off, d_sizes, d_out, B, B, n, d_status)
+            codec.decompress_batch(method, d_comp, d_off, d_sizes, d_out, ostride, B, n, d_status)
         for _ in range(a.warmup):
             step()
         codec.sync()
