@@ -4,7 +4,8 @@
  * cryo_scan_next_batch) run inside a backend.  SURVEY.md row f-4.
  *
  * Compiled only in a PGXS build (-DCRYO_HAVE_POSTGRES, pg/Makefile); the development image has no PostgreSQL
- * headers, so this file has never been compiled there.  It restates, call for call, what the reference does
+ * headers, so this file has only been syntax-checked there (tests/test_pg_syntax.py, declaration-only stand-ins),
+ * never built.  It restates, call for call, what the reference does
  * around its one-block-at-a-time codec calls:
  *
  *   page_for_write   reference pg_cryogen.c:757-770   ReadBuffer + LockBuffer(EXCLUSIVE) + GenericXLogStart +
