@@ -22,6 +22,9 @@ namespace cryo {
 namespace {
 
 #define LDS_FENCE() asm volatile("" ::: "memory")
+#ifndef CRYO_ABL
+#define CRYO_ABL 0 /* timing experiments only (profiles/scripts/r02_ablate3.sh): parts of the copy engine compiled out, wrong bytes */
+#endif
 
 template <uint32_t R, uint32_t TMAX>
 struct CopyLds {
@@ -129,8 +132,10 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
     {
         uint32_t spill = 0; /* bytes this lane wrote beyond the ring's end */
         const uint4 z = make_uint4(0, 0, 0, 0);
+        if (!(CRYO_ABL & 8))
         lane_runs<R, kInMask>(L.ring, L.in, act ? ll : 0u, lpos, op0 + ostart, false, z, z, spill);
         /* (the 16 bytes behind the ring mirror its first 16 for reads that start in its last 15: lz4_seq_batch) */
+        if (!(CRYO_ABL & 16))
         lane_runs<R, R - 1u>(L.ring, L.ring, indep ? ml : 0u, op0 + mrel - off, op0 + mrel, isfar, xfa, xfb, spill);
         /* a batch crosses the ring's end at most once: fold the bytes that ran over back to the start */
         const unsigned long long sm = __ballot(spill != 0u);
@@ -157,7 +162,7 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
 
     /* ---- match space: chunks in order ---- */
     {
-        const uint32_t nM = (MT + 63u) >> 6;
+        const uint32_t nM = (CRYO_ABL & 32) ? 0u : (MT + 63u) >> 6;
         constexpr uint32_t U = 4;
         for (uint32_t c0 = 0; c0 < nM; c0 += U) {
             uint32_t da[U], ra[U];
