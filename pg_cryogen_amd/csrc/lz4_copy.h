@@ -116,6 +116,7 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
     const unsigned long long depm = __ballot(dep);
     const uint32_t drank = __builtin_amdgcn_mbcnt_hi((uint32_t)(depm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)depm, 0u));
 
+    if (!(CRYO_ABL & 128)) {
     if (lane < kBmW) L.mbm[lane] = 0u;
     LDS_FENCE();
     if (dep) {
@@ -127,6 +128,7 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
         if (mcum != 0u) atomicOr(&L.mbm[(mcum - 1u) >> 5], 1u << ((mcum - 1u) & 31u));
     }
     LDS_FENCE();
+    }
 
     /* ---- literals and independent matches: one lane per sequence ---- */
     {
@@ -146,7 +148,7 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
         }
     }
     LDS_FENCE();
-    {
+    if (!(CRYO_ABL & 128)) {
         /* bits before each match-space chunk */
         static_assert(kNc <= 64, "one lane per chunk");
         uint32_t cnt = 0;

@@ -332,7 +332,8 @@ __device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const CopyLds<R, kT2> &L, u
         atomicAdd(&stop_hist[why], 1ull);
     }
     stamp(st, 1);
-    if (!(st.ablate & 2u)) w.flush();   /* what earlier batches produced; far sources below are read back from it */
+    if (!(st.ablate & 2u) && !(CRYO_ABL & 64)) w.flush();   /* what earlier batches produced; far sources below are read back from it */
+    else if (CRYO_ABL & 64) w.flushed = w.op & ~(kChunk - 1u);
     else w.flushed = w.op & ~(kChunk - 1u);
     stamp(st, 2);
     if (!(st.ablate & 4u)) w.top_up(); else w.nstale = 0;

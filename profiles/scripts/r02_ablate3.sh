@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 # build the variants first: for a in 8 16 32 56; do rm -f lz4_dec2.o; make -C pg_cryogen_amd/csrc EXTRA=-DCRYO_ABL=$a; cp pg_cryogen_amd/libcryo_codec.so pg_cryogen_amd/libcryo_codec_abl$a.so; done; then rebuild the product
 cp pg_cryogen_amd/libcryo_codec.so /tmp/orig.so
-for a in 0 8 16 32 56 0; do
+for a in ${ABLS:-0 8 16 32 56 0}; do
 [ $a = 0 ] && cp /tmp/orig.so pg_cryogen_amd/libcryo_codec.so || cp pg_cryogen_amd/libcryo_codec_abl$a.so pg_cryogen_amd/libcryo_codec.so
 rm -rf /tmp/abl; timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/abl -o r -- python3 bench.py --no-cpu-baseline --no-verify --steps 10 --warmup 2 > /dev/null 2>&1
 echo "ablate $a: $(python3 - <<'PY'
