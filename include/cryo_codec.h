@@ -62,6 +62,22 @@ void *cryo_codec_stream(cryo_codec *c);
 /* wait for everything queued on the handle's stream */
 int cryo_codec_sync(cryo_codec *c);
 
+/* ---- per-handle options (tuning and tests; the defaults are what production runs) ----
+ * Values are read at every call, so a test can flip a path between two batches of one handle. */
+typedef enum {
+    /* LZ4 decode path: 0 = automatic (by the work in the batch), 1 = in-wave parse kernel (k_lz4_dec_ring),
+     * 2 = sequence index + indexed decoder (k_lz4_index* + k_lz4_dec_seq) whatever the batch size */
+    CRYO_OPT_LZ4_DECODE_PATH = 1,
+    /* walkers per block of the sequence-index pass: 0 = automatic, else a power of two 1..64 */
+    CRYO_OPT_LZ4_INDEX_WALKERS = 2,
+    /* K-block host calls: minimum bytes of a call that is cut into pipelined chunks (default 64 MiB) */
+    CRYO_OPT_PIPE_MIN_BYTES = 3,
+    /* device-resident block pool (cryo_pool_*): capacity in bytes (0 = pool off, the default) */
+    CRYO_OPT_POOL_BYTES = 4
+} cryo_option;
+int cryo_codec_set_option(cryo_codec *c, int option, int64_t value);
+int cryo_codec_get_option(const cryo_codec *c, int option, int64_t *value);
+
 /* ---- sizes ---- */
 
 /* replaces LZ4_compressBound (compression.c:67) / ZSTD_compressBound (compression.c:99):
@@ -98,8 +114,9 @@ int cryo_dev_memset(cryo_codec *c, void *d_dst, int value, size_t bytes);       
  *   method ZSTD: replaces ZSTD_compress(dst,bound,src,B,level) (compression.c:102-104);
  *                param = zstd_compression_level_guc (-5..22).  Output bytes identical to
  *                libzstd 1.4.8 for levels -5..10 (strategies fast, dfast, greedy, lazy, lazy2);
- *                levels 11..22 (the binary-tree strategies) return CRYO_E_UNSUPPORTED (no CPU
- *                fallback).
+ *                levels 11..22 return CRYO_E_UNSUPPORTED (no CPU fallback): btlazy2 ... btultra2 at
+ *                block sizes up to 256 KiB; above that libzstd 1.4.8 maps 11 and 12 to lazy2 with
+ *                window log 22, a parameter row this build has no kernel instantiation for either.
  */
 int cryo_codec_compress_batch(cryo_codec *c, int method, int param,
                               const void *d_src, uint64_t src_stride,
@@ -171,6 +188,11 @@ int cryo_multi_compress_blocks(cryo_multi *m, int method, int param,
 int cryo_multi_decompress_blocks(cryo_multi *m, int method,
                                  const void *const *h_src, const uint32_t *h_src_size, size_t n_blocks,
                                  void *h_dst, size_t block_size, int32_t *h_status);
+/* one destination per block (cryo_codec_decompress_blocks_to across the devices): what the decompressed-block cache
+ * binds, its slots are the destinations (reference cache.c:46,178) */
+int cryo_multi_decompress_blocks_to(cryo_multi *m, int method,
+                                    const void *const *h_src, const uint32_t *h_src_size, size_t n_blocks,
+                                    void *const *h_dst, size_t block_size, int32_t *h_status);
 
 /* ---- batch helpers used by staging, tests and the benchmark ---- */
 

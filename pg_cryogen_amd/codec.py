@@ -20,6 +20,10 @@ _ERR_NAMES = {0: "CRYO_OK", -1: "CRYO_E_ARG", -2: "CRYO_E_HIP", -3: "CRYO_E_NODE
               -4: "CRYO_E_CORRUPT", -5: "CRYO_E_DSTSIZE", -6: "CRYO_E_UNSUPPORTED",
               -7: "CRYO_E_NOMEM"}
 
+# cryo_option (include/cryo_codec.h)
+OPT_LZ4_DECODE_PATH, OPT_LZ4_INDEX_WALKERS, OPT_PIPE_MIN_BYTES, OPT_POOL_BYTES = 1, 2, 3, 4
+LZ4_PATH_AUTO, LZ4_PATH_RING, LZ4_PATH_INDEXED = 0, 1, 2
+
 DIST_WIDE, DIST_NARROW, DIST_INT4, DIST_RANDOM, DIST_ZEROS = range(5)
 DIST_NAMES = ["wide", "narrow", "int4", "random", "zeros"]
 
@@ -27,12 +31,13 @@ DIST_NAMES = ["wide", "narrow", "int4", "random", "zeros"]
 ABI_SYMBOLS = [
     "cryo_codec_version", "cryo_codec_device_count", "cryo_codec_open", "cryo_codec_close",
     "cryo_codec_last_error", "cryo_codec_stream", "cryo_codec_sync", "cryo_codec_bound",
+    "cryo_codec_set_option", "cryo_codec_get_option",
     "cryo_dev_alloc", "cryo_dev_free", "cryo_dev_upload", "cryo_dev_download", "cryo_dev_memset",
     "cryo_codec_compress_batch", "cryo_codec_decompress_batch", "cryo_codec_compress_block",
     "cryo_codec_decompress_block", "cryo_codec_compress_blocks", "cryo_codec_decompress_blocks",
     "cryo_codec_decompress_blocks_to",
     "cryo_multi_open", "cryo_multi_close", "cryo_multi_count", "cryo_multi_last_error",
-    "cryo_multi_compress_blocks", "cryo_multi_decompress_blocks",
+    "cryo_multi_compress_blocks", "cryo_multi_decompress_blocks", "cryo_multi_decompress_blocks_to",
     "cryo_codec_synth_batch", "cryo_codec_checksum_batch",
     "cryo_codec_compare_batch", "cryo_checksum64", "cryo_codec_timer_start",
     "cryo_codec_timer_stop", "cryo_codec_get_counters",
@@ -70,6 +75,8 @@ def lib():
     L.cryo_codec_stream.argtypes = [vp]
     L.cryo_codec_stream.restype = vp
     L.cryo_codec_sync.argtypes = [vp]
+    L.cryo_codec_set_option.argtypes = [vp, i32, C.c_int64]
+    L.cryo_codec_get_option.argtypes = [vp, i32, C.POINTER(C.c_int64)]
     L.cryo_codec_bound.argtypes = [i32, sz]
     L.cryo_codec_bound.restype = sz
     L.cryo_dev_alloc.argtypes = [vp, sz, C.POINTER(vp)]
@@ -92,6 +99,7 @@ def lib():
     L.cryo_multi_last_error.restype = C.c_char_p
     L.cryo_multi_compress_blocks.argtypes = [vp, i32, i32, vp, sz, sz, vp, sz, vp]
     L.cryo_multi_decompress_blocks.argtypes = [vp, i32, vp, vp, sz, vp, sz, vp]
+    L.cryo_multi_decompress_blocks_to.argtypes = [vp, i32, vp, vp, sz, vp, sz, vp]
     L.cryo_codec_synth_batch.argtypes = [vp, u64, u64, u64, u64, u32, i32, vp, u64]
     L.cryo_codec_checksum_batch.argtypes = [vp, vp, u64, vp, u32, u64, vp]
     L.cryo_codec_compare_batch.argtypes = [vp, vp, u64, vp, u64, u32, u64, vp]
@@ -187,6 +195,14 @@ class Codec:
 
     def sync(self):
         self._chk(self.L.cryo_codec_sync(self.h), "cryo_codec_sync")
+
+    def set_option(self, option, value):
+        self._chk(self.L.cryo_codec_set_option(self.h, option, int(value)), "cryo_codec_set_option")
+
+    def get_option(self, option):
+        v = C.c_int64()
+        self._chk(self.L.cryo_codec_get_option(self.h, option, C.byref(v)), "cryo_codec_get_option")
+        return v.value
 
     def timer_start(self):
         self._chk(self.L.cryo_codec_timer_start(self.h), "timer_start")

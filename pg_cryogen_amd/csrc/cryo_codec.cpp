@@ -9,12 +9,99 @@
 #include "cryo_codec.h"
 #include "kernels.h"
 
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <new>
+#include <pthread.h>
+#include <signal.h>
 #include <thread>
 #include <vector>
+
+/* A few host threads kept by a handle (staging copies of the K-block calls) or by the multi-GPU dispatcher (one per
+ * further device).  The caller of the C ABI is a PostgreSQL backend: workers are created with every signal blocked
+ * (the backend's SIGUSR1/SIGTERM/SIGINT handlers must only ever run on its own thread), they are created once and
+ * joined when their owner is closed, and a worker that cannot be started just is not there: run() then executes
+ * the shares on the calling thread.  Nothing here throws. */
+namespace {
+class WorkerPool {
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    const std::function<void(unsigned)> *job_ = nullptr;
+    unsigned n_ = 0, next_ = 0, running_ = 0;
+    unsigned long gen_ = 0;
+    bool stop_ = false;
+
+    void loop()
+    {
+        unsigned long seen = 0;
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_.wait(lk, [&] { return stop_ || (gen_ != seen && next_ < n_); });
+            if (stop_) return;
+            seen = gen_;
+            while (next_ < n_) {
+                const unsigned i = next_++;
+                running_++;
+                lk.unlock();
+                (*job_)(i);
+                lk.lock();
+                running_--;
+            }
+            if (running_ == 0) done_.notify_all();
+        }
+    }
+
+public:
+    explicit WorkerPool(unsigned workers) noexcept
+    {
+        sigset_t all, old;
+        sigfillset(&all);
+        const bool masked = pthread_sigmask(SIG_SETMASK, &all, &old) == 0;
+        for (unsigned i = 0; i < workers; i++) {
+            try { th_.emplace_back([this] { loop(); }); } catch (...) { break; } /* EAGAIN, bad_alloc: fewer workers */
+        }
+        if (masked) (void)pthread_sigmask(SIG_SETMASK, &old, nullptr);
+    }
+    ~WorkerPool()
+    {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (auto &t : th_) if (t.joinable()) t.join();
+    }
+    unsigned workers() const { return (unsigned)th_.size(); }
+    /* f(0) .. f(n-1), spread over the workers and the calling thread; returns when all have run.  f must not throw. */
+    void run(unsigned n, const std::function<void(unsigned)> &f) noexcept
+    {
+        if (n == 0) return;
+        if (th_.empty() || n == 1) { for (unsigned i = 0; i < n; i++) f(i); return; }
+        std::unique_lock<std::mutex> lk(mu_);
+        job_ = &f; n_ = n; next_ = 0; gen_++;
+        cv_.notify_all();
+        while (next_ < n_) {
+            const unsigned i = next_++;
+            running_++;
+            lk.unlock();
+            f(i);
+            lk.lock();
+            running_--;
+        }
+        done_.wait(lk, [&] { return running_ == 0; });
+        job_ = nullptr; n_ = 0;
+    }
+};
+
+/* C++ exceptions (bad_alloc from the small host-side vectors) never cross the C ABI */
+template <class F>
+int guarded(F &&f) noexcept
+{
+    try { return f(); } catch (const std::bad_alloc &) { return CRYO_E_NOMEM; } catch (...) { return CRYO_E_HIP; }
+}
+} // namespace
 
 struct cryo_codec {
     int device = -1;
@@ -45,6 +132,11 @@ struct cryo_codec {
     /* side streams of the zstd batch pipeline (created on first use) */
     cryo::ZstdAux aux = {};
     bool have_aux = false;
+    /* options (cryo_codec_set_option) */
+    cryo::Lz4DecodeOpts lz4_opts = {};
+    size_t pipe_min_bytes = (size_t)64 << 20;
+    /* staging-copy workers (created by the first K-block call that is large enough to want them) */
+    WorkerPool *pool = nullptr;
 };
 
 namespace {
@@ -136,26 +228,25 @@ unsigned host_threads()
     }();
     return v;
 }
-void parallel_copy(const std::vector<CopyJob> &jobs)
+void parallel_copy(cryo_codec *c, const std::vector<CopyJob> &jobs)
 {
     size_t total = 0;
     for (const CopyJob &j : jobs) total += j.len;
-    const unsigned T = total < (4u << 20) ? 1u : host_threads();
+    if (total >= (4u << 20) && !c->pool && host_threads() > 1u) c->pool = new (std::nothrow) WorkerPool(host_threads() - 1u);
+    const unsigned T = (total < (4u << 20) || !c->pool) ? 1u : c->pool->workers() + 1u;
     if (T == 1u) { for (const CopyJob &j : jobs) memcpy(j.dst, j.src, j.len); return; }
-    /* equal byte shares: thread t takes the jobs (or parts of jobs) covering bytes [t, t+1) * total / T */
-    std::vector<std::thread> th;
-    for (unsigned t = 0; t < T; t++)
-        th.emplace_back([&, t] {
-            const size_t lo = total * t / T, hi = total * (t + 1) / T;
-            size_t pos = 0;
-            for (const CopyJob &j : jobs) {
-                const size_t a = pos > lo ? pos : lo, b = pos + j.len < hi ? pos + j.len : hi;
-                if (a < b) memcpy((uint8_t *)j.dst + (a - pos), (const uint8_t *)j.src + (a - pos), b - a);
-                pos += j.len;
-                if (pos >= hi) break;
-            }
-        });
-    for (auto &x : th) x.join();
+    /* equal byte shares: share t takes the jobs (or parts of jobs) covering bytes [t, t+1) * total / T */
+    const std::function<void(unsigned)> share = [&](unsigned t) {
+        const size_t lo = total * t / T, hi = total * (t + 1) / T;
+        size_t pos = 0;
+        for (const CopyJob &j : jobs) {
+            const size_t a = pos > lo ? pos : lo, b = pos + j.len < hi ? pos + j.len : hi;
+            if (a < b) memcpy((uint8_t *)j.dst + (a - pos), (const uint8_t *)j.src + (a - pos), b - a);
+            pos += j.len;
+            if (pos >= hi) break;
+        }
+    };
+    c->pool->run(T, share);
 }
 
 int ensure_ws(cryo_codec *c, size_t need)
@@ -194,7 +285,12 @@ int cryo_codec_open(int device, cryo_codec **out)
     cryo_codec *c = new (std::nothrow) cryo_codec;
     if (!c) return CRYO_E_NOMEM;
     c->device = device;
-    hipError_t e = hipSetDevice(device);
+    if (const char *e = getenv("CRYO_PIPE_MIN_MB")) c->pipe_min_bytes = (size_t)atoll(e) << 20; /* 0 = always, huge = never */
+    if (const char *e = getenv("CRYO_LZ4_DECODE_PATH")) c->lz4_opts.path = atoi(e);             /* tuning aids: the options' */
+    if (const char *e = getenv("CRYO_LZ4_INDEX_WALKERS")) c->lz4_opts.walkers = atoi(e);        /* initial values          */
+    DevGuard dev_(c); /* the caller's current device is restored on return */
+    hipError_t e = hipSuccess;
+    if (!dev_.switched && dev_.prev != device) e = hipSetDevice(device); /* no current device yet, or the switch failed: report it */
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreate(&c->ev0);
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
@@ -212,7 +308,9 @@ int cryo_codec_open(int device, cryo_codec **out)
 void cryo_codec_close(cryo_codec *c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DevGuard dev_(c);
+    delete c->pool;
+    c->pool = nullptr;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
@@ -243,6 +341,38 @@ void cryo_codec_close(cryo_codec *c)
 }
 
 const char *cryo_codec_last_error(const cryo_codec *c) { return c ? c->err : ""; }
+
+int cryo_codec_set_option(cryo_codec *c, int option, int64_t value)
+{
+    if (!c) return CRYO_E_ARG;
+    switch (option) {
+    case CRYO_OPT_LZ4_DECODE_PATH:
+        if (value < 0 || value > 2) return CRYO_E_ARG;
+        c->lz4_opts.path = (int)value;
+        return CRYO_OK;
+    case CRYO_OPT_LZ4_INDEX_WALKERS:
+        if (value < 0 || value > 64 || (value & (value - 1)) != 0) return CRYO_E_ARG;
+        c->lz4_opts.walkers = (int)value;
+        return CRYO_OK;
+    case CRYO_OPT_PIPE_MIN_BYTES:
+        if (value < 0) return CRYO_E_ARG;
+        c->pipe_min_bytes = (size_t)value;
+        return CRYO_OK;
+    default:
+        return CRYO_E_ARG;
+    }
+}
+
+int cryo_codec_get_option(const cryo_codec *c, int option, int64_t *value)
+{
+    if (!c || !value) return CRYO_E_ARG;
+    switch (option) {
+    case CRYO_OPT_LZ4_DECODE_PATH: *value = c->lz4_opts.path; return CRYO_OK;
+    case CRYO_OPT_LZ4_INDEX_WALKERS: *value = c->lz4_opts.walkers; return CRYO_OK;
+    case CRYO_OPT_PIPE_MIN_BYTES: *value = (int64_t)c->pipe_min_bytes; return CRYO_OK;
+    default: return CRYO_E_ARG;
+    }
+}
 void *cryo_codec_stream(cryo_codec *c) { return c ? (void *)c->stream : nullptr; }
 
 int cryo_codec_sync(cryo_codec *c)
@@ -356,14 +486,14 @@ int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
     if (!d_src || !d_src_off || !d_src_size || !d_dst || !d_status || dst_stride < block_size)
         return CRYO_E_ARG;
     if (method == CRYO_METHOD_LZ4) {
-        const size_t need = cryo::lz4_decompress_workspace(n_blocks, block_size);
+        const size_t need = cryo::lz4_decompress_workspace(n_blocks, block_size, c->lz4_opts);
         if (need != 0) {
             int rc = ensure_ws(c, need);
             if (rc != CRYO_OK) return rc;
         }
         HIP_TRY(c, cryo::launch_lz4_decompress(c->stream, (const uint8_t *)d_src, d_src_off, d_src_size,
                                                (uint8_t *)d_dst, dst_stride, block_size, n_blocks,
-                                               d_status, need ? c->d_ws : nullptr, need ? c->ws_cap : 0));
+                                               d_status, need ? c->d_ws : nullptr, need ? c->ws_cap : 0, c->lz4_opts));
     } else {
         const size_t need = cryo::zstd_decompress_workspace(n_blocks, block_size);
         int rc = ensure_ws(c, need);
@@ -493,7 +623,7 @@ static int compress_blocks_piped(cryo_codec *c, int method, int param, const uin
         const size_t lo = ch * K, hi = lo + K < n ? lo + K : n, cnt = hi - lo;
         const int b = (int)(ch & 1);
         if (ch >= 2) HIP_TRY(c, hipEventSynchronize(c->ev_in[b])); /* staging buffer b has left for the device */
-        parallel_copy({{c->pipe_pin[b], h_src + lo * block_size, cnt * block_size}});
+        parallel_copy(c, {{c->pipe_pin[b], h_src + lo * block_size, cnt * block_size}});
         HIP_TRY(c, hipMemcpyAsync(c->hb_src + lo * block_size, c->pipe_pin[b], cnt * block_size, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipEventRecord(c->ev_in[b], c->stream));
     }
@@ -523,7 +653,7 @@ static int compress_blocks_piped(cryo_codec *c, int method, int param, const uin
         const uint8_t *po = (const uint8_t *)c->pipe_pin[2 + (ch & 1)];
         std::vector<CopyJob> jobs;
         for (size_t i = lo; i < hi; i++) jobs.push_back({h_dst + i * dst_stride, po + (i - lo) * dstride, p_sz[i]});
-        parallel_copy(jobs);
+        parallel_copy(c, jobs);
     }
     return CRYO_OK;
 }
@@ -569,7 +699,7 @@ static int decompress_blocks_piped(cryo_codec *c, int method, const void *const 
     auto scatter = [&](size_t ch) -> int {
         const size_t lo = ch * K, hi = lo + K < n ? lo + K : n;
         HIP_TRY(c, hipEventSynchronize(c->ev_out[ch & 1]));
-        parallel_copy({{h_dst + lo * block_size, c->pipe_pin[2 + (ch & 1)], (hi - lo) * block_size}});
+        parallel_copy(c, {{h_dst + lo * block_size, c->pipe_pin[2 + (ch & 1)], (hi - lo) * block_size}});
         return CRYO_OK;
     };
     for (size_t ch = 0; ch < nch; ch++) {
@@ -581,7 +711,7 @@ static int decompress_blocks_piped(cryo_codec *c, int method, const void *const 
             std::vector<CopyJob> jobs;
             for (size_t i = lo; i < hi; i++)
                 if (h_src_size[i]) jobs.push_back({pi + (pos[i] - pos[lo]), h_src[i], h_src_size[i]});
-            parallel_copy(jobs);
+            parallel_copy(c, jobs);
         }
         if (pos[hi] > pos[lo])
             HIP_TRY(c, hipMemcpyAsync(c->hb_src + o_data + pos[lo], c->pipe_pin[b], pos[hi] - pos[lo], hipMemcpyHostToDevice, c->stream));
@@ -629,20 +759,24 @@ static int decompress_blocks_piped(cryo_codec *c, int method, const void *const 
     return CRYO_OK;
 }
 
-static bool pipe_worth_it(size_t n, size_t block_size)
+static bool pipe_worth_it(const cryo_codec *c, size_t n, size_t block_size)
 {
-    static const size_t min_bytes = [] {
-        const char *e = getenv("CRYO_PIPE_MIN_MB"); /* 0 = always, huge = never */
-        return (size_t)(e ? atoll(e) : 64) << 20;
-    }();
-    return n * block_size >= min_bytes && n >= 128;
+    return n * block_size >= c->pipe_min_bytes && n >= 128;
+}
+/* the four pinned staging buffers of the pipelined calls are K x block_size each: a 4096 x 1 MiB call leaves 2.3 GB of
+ * pinned host memory behind.  What exceeds this cap is given back when the call ends. */
+static void pipe_trim(cryo_codec *c)
+{
+    constexpr size_t kKeep = (size_t)256 << 20;
+    for (int i = 0; i < 4; i++)
+        if (c->pipe_pin_cap[i] > kKeep) { (void)hipHostFree(c->pipe_pin[i]); c->pipe_pin[i] = nullptr; c->pipe_pin_cap[i] = 0; }
 }
 extern "C" {
 
 /* K blocks from / to host memory.  Device buffers and the pinned staging buffer live in the handle
  * (grow-only); transfers are bulk: one H2D of the K blocks, one D2H of the K output slots. */
-int cryo_codec_compress_blocks(cryo_codec *c, int method, int param, const void *h_src, size_t block_size,
-                               size_t n, void *h_dst, size_t dst_stride, uint32_t *h_out_size)
+static int compress_blocks_body(cryo_codec *c, int method, int param, const void *h_src, size_t block_size,
+                                size_t n, void *h_dst, size_t dst_stride, uint32_t *h_out_size)
 {
     DevGuard dev_(c);
     if (!c || !method_ok(method) || block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
@@ -650,8 +784,12 @@ int cryo_codec_compress_blocks(cryo_codec *c, int method, int param, const void 
     if (!h_src || !h_dst || !h_out_size) return CRYO_E_ARG;
     const size_t bound = cryo_codec_bound(method, block_size);
     if (dst_stride < bound) return CRYO_E_DSTSIZE;
-    if (pipe_worth_it(n, block_size))
-        return compress_blocks_piped(c, method, param, (const uint8_t *)h_src, block_size, n, (uint8_t *)h_dst, dst_stride, h_out_size);
+    if (pipe_worth_it(c, n, block_size)) {
+        const int rc = compress_blocks_piped(c, method, param, (const uint8_t *)h_src, block_size, n, (uint8_t *)h_dst, dst_stride, h_out_size);
+        if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); if (c->xfer) (void)hipStreamSynchronize(c->xfer); }
+        pipe_trim(c);
+        return rc;
+    }
     /* the device slots use the caller's stride, so the output goes back in one copy (a slot may be
      * written beyond out_size[i], up to bound) */
     const bool bulk = dst_stride <= bound + 4096;
@@ -683,6 +821,12 @@ int cryo_codec_compress_blocks(cryo_codec *c, int method, int param, const void 
     return CRYO_OK;
 }
 
+int cryo_codec_compress_blocks(cryo_codec *c, int method, int param, const void *h_src, size_t block_size,
+                               size_t n, void *h_dst, size_t dst_stride, uint32_t *h_out_size)
+{
+    return guarded([&] { return compress_blocks_body(c, method, param, h_src, block_size, n, h_dst, dst_stride, h_out_size); });
+}
+
 static int decompress_blocks_impl(cryo_codec *c, int method, const void *const *h_src, const uint32_t *h_src_size,
                                   size_t n, void *h_dst, void *const *h_dst_each, size_t block_size, int32_t *h_status)
 {
@@ -690,8 +834,13 @@ static int decompress_blocks_impl(cryo_codec *c, int method, const void *const *
     if (!c || !method_ok(method) || block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
     if (n == 0) return CRYO_OK;
     if (!h_src || !h_src_size || (!h_dst && !h_dst_each) || !h_status) return CRYO_E_ARG;
-    if (h_dst && pipe_worth_it(n, block_size))
-        return decompress_blocks_piped(c, method, h_src, h_src_size, n, (uint8_t *)h_dst, block_size, h_status);
+    if (h_dst && pipe_worth_it(c, n, block_size)) {
+        const int rc = decompress_blocks_piped(c, method, h_src, h_src_size, n, (uint8_t *)h_dst, block_size, h_status);
+        /* an error return must not leave copies in flight into the handle's pinned buffers or the caller's memory */
+        if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); if (c->xfer) (void)hipStreamSynchronize(c->xfer); }
+        pipe_trim(c);
+        return rc;
+    }
     /* pinned staging: [offsets u64 x n][sizes u32 x n][compressed blocks, 16-byte aligned], sent in one copy */
     const size_t o_off = 0, o_sz = n * 8, o_data = (n * 12 + 63) & ~(size_t)63;
     size_t total = 0;
@@ -725,6 +874,21 @@ static int decompress_blocks_impl(cryo_codec *c, int method, const void *const *
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         return CRYO_OK;
     }
+    /* one destination per block: the blocks come back in ONE copy into the pinned buffer (the compressed side of it
+     * is no longer needed) and are handed to their destinations from there; a block that failed leaves its destination
+     * untouched */
+    if (ensure_pinned(c, n * block_size) == CRYO_OK) {
+        HIP_TRY(c, hipMemcpyAsync(c->pin, c->hb_dst, n * block_size, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        std::vector<CopyJob> jobs;
+        for (size_t i = 0; i < n; i++) {
+            if (h_status[i] != CRYO_OK) continue;
+            if (!h_dst_each[i]) return CRYO_E_ARG;
+            jobs.push_back({h_dst_each[i], (const uint8_t *)c->pin + i * block_size, block_size});
+        }
+        parallel_copy(c, jobs);
+        return CRYO_OK;
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < n; i++) {
         if (h_status[i] != CRYO_OK) continue;
@@ -739,19 +903,20 @@ int cryo_codec_decompress_blocks(cryo_codec *c, int method, const void *const *h
                                  size_t n, void *h_dst, size_t block_size, int32_t *h_status)
 {
     if (!h_dst) return CRYO_E_ARG;
-    return decompress_blocks_impl(c, method, h_src, h_src_size, n, h_dst, nullptr, block_size, h_status);
+    return guarded([&] { return decompress_blocks_impl(c, method, h_src, h_src_size, n, h_dst, nullptr, block_size, h_status); });
 }
 
 int cryo_codec_decompress_blocks_to(cryo_codec *c, int method, const void *const *h_src, const uint32_t *h_src_size,
                                     size_t n, void *const *h_dst, size_t block_size, int32_t *h_status)
 {
     if (!h_dst) return CRYO_E_ARG;
-    return decompress_blocks_impl(c, method, h_src, h_src_size, n, nullptr, h_dst, block_size, h_status);
+    return guarded([&] { return decompress_blocks_impl(c, method, h_src, h_src_size, n, nullptr, h_dst, block_size, h_status); });
 }
 
 /* ---- several GPUs behind one call ---- */
 struct cryo_multi {
     std::vector<cryo_codec *> h;
+    WorkerPool *pool = nullptr; /* one worker per further device */
     char err[320] = {0};
 };
 
@@ -792,21 +957,25 @@ int cryo_multi_open(const int *devices, int n_devices, cryo_multi **out)
 {
     if (!out || !devices || n_devices <= 0) return CRYO_E_ARG;
     *out = nullptr;
-    cryo_multi *m = new (std::nothrow) cryo_multi;
-    if (!m) return CRYO_E_NOMEM;
-    for (int i = 0; i < n_devices; i++) {
-        cryo_codec *c = nullptr;
-        const int rc = cryo_codec_open(devices[i], &c);
-        if (rc != CRYO_OK) { cryo_multi_close(m); return rc; }
-        m->h.push_back(c);
-    }
-    *out = m;
-    return CRYO_OK;
+    return guarded([&]() -> int {
+        cryo_multi *m = new (std::nothrow) cryo_multi;
+        if (!m) return CRYO_E_NOMEM;
+        for (int i = 0; i < n_devices; i++) {
+            cryo_codec *c = nullptr;
+            const int rc = cryo_codec_open(devices[i], &c);
+            if (rc != CRYO_OK) { cryo_multi_close(m); return rc; }
+            m->h.push_back(c);
+        }
+        if (n_devices > 1) m->pool = new (std::nothrow) WorkerPool((unsigned)n_devices - 1u); /* none: the shares run one after the other */
+        *out = m;
+        return CRYO_OK;
+    });
 }
 
 void cryo_multi_close(cryo_multi *m)
 {
     if (!m) return;
+    delete m->pool;
     for (cryo_codec *c : m->h) cryo_codec_close(c);
     delete m;
 }
@@ -815,19 +984,18 @@ int cryo_multi_count(const cryo_multi *m) { return m ? (int)m->h.size() : 0; }
 const char *cryo_multi_last_error(const cryo_multi *m) { return m ? m->err : ""; }
 
 } /* extern "C" */
-#include <functional>
-/* block i -> handle i mod G; `fn(g, idx)` runs on its own host thread with the block indices of handle g */
+/* block i -> handle i mod G; `fn(g, idx)` runs the block indices of handle g, every handle's share on its own host thread */
 static int multi_run(cryo_multi *m, size_t n, const std::function<int(size_t, const std::vector<size_t> &)> &fn)
 {
     const size_t G = m->h.size();
     std::vector<std::vector<size_t>> share(G);
     for (size_t i = 0; i < n; i++) share[i % G].push_back(i);
     std::vector<int> rc(G, CRYO_OK);
-    std::vector<std::thread> th;
-    for (size_t g = 1; g < G; g++)
-        if (!share[g].empty()) th.emplace_back([&, g] { rc[g] = fn(g, share[g]); });
-    if (!share[0].empty()) rc[0] = fn(0, share[0]);
-    for (auto &t : th) t.join();
+    const std::function<void(unsigned)> one = [&](unsigned g) {
+        if (!share[g].empty()) rc[g] = guarded([&] { return fn(g, share[g]); });
+    };
+    if (m->pool) m->pool->run((unsigned)G, one);
+    else for (unsigned g = 0; g < G; g++) one(g);
     for (size_t g = 0; g < G; g++)
         if (rc[g] != CRYO_OK) {
             snprintf(m->err, sizeof m->err, "device handle %zu: %s", g, cryo_codec_last_error(m->h[g]));
@@ -845,17 +1013,41 @@ int cryo_multi_compress_blocks(cryo_multi *m, int method, int param, const void 
     if (!h_src || !h_dst || !h_out_size) return CRYO_E_ARG;
     if (dst_stride < cryo_codec_bound(method, block_size)) return CRYO_E_DSTSIZE;
     if (m->h.size() == 1) return cryo_codec_compress_blocks(m->h[0], method, param, h_src, block_size, n, h_dst, dst_stride, h_out_size);
-    return multi_run(m, n, [&](size_t g, const std::vector<size_t> &idx) {
-        std::vector<const void *> src(idx.size());
-        std::vector<void *> dst(idx.size());
-        std::vector<uint32_t> sz(idx.size());
-        for (size_t k = 0; k < idx.size(); k++) {
-            src[k] = (const uint8_t *)h_src + idx[k] * block_size;
-            dst[k] = (uint8_t *)h_dst + idx[k] * dst_stride;
-        }
-        const int rc = compress_blocks_ptrs(m->h[g], method, param, src.data(), block_size, idx.size(), dst.data(), sz.data());
-        if (rc == CRYO_OK) for (size_t k = 0; k < idx.size(); k++) h_out_size[idx[k]] = sz[k];
-        return rc;
+    return guarded([&] {
+        return multi_run(m, n, [&](size_t g, const std::vector<size_t> &idx) {
+            std::vector<const void *> src(idx.size());
+            std::vector<void *> dst(idx.size());
+            std::vector<uint32_t> sz(idx.size());
+            for (size_t k = 0; k < idx.size(); k++) {
+                src[k] = (const uint8_t *)h_src + idx[k] * block_size;
+                dst[k] = (uint8_t *)h_dst + idx[k] * dst_stride;
+            }
+            const int rc = compress_blocks_ptrs(m->h[g], method, param, src.data(), block_size, idx.size(), dst.data(), sz.data());
+            if (rc == CRYO_OK) for (size_t k = 0; k < idx.size(); k++) h_out_size[idx[k]] = sz[k];
+            return rc;
+        });
+    });
+}
+
+/* one destination per block (h_dst_each) or one strided area (h_dst) */
+static int multi_decompress(cryo_multi *m, int method, const void *const *h_src, const uint32_t *h_src_size, size_t n,
+                            void *h_dst, void *const *h_dst_each, size_t block_size, int32_t *h_status)
+{
+    return guarded([&] {
+        return multi_run(m, n, [&](size_t g, const std::vector<size_t> &idx) {
+            std::vector<const void *> src(idx.size());
+            std::vector<void *> dst(idx.size());
+            std::vector<uint32_t> sz(idx.size());
+            std::vector<int32_t> st(idx.size());
+            for (size_t k = 0; k < idx.size(); k++) {
+                src[k] = h_src[idx[k]];
+                sz[k] = h_src_size[idx[k]];
+                dst[k] = h_dst_each ? h_dst_each[idx[k]] : (void *)((uint8_t *)h_dst + idx[k] * block_size);
+            }
+            const int rc = decompress_blocks_impl(m->h[g], method, src.data(), sz.data(), idx.size(), nullptr, dst.data(), block_size, st.data());
+            if (rc == CRYO_OK) for (size_t k = 0; k < idx.size(); k++) h_status[idx[k]] = st[k];
+            return rc;
+        });
     });
 }
 
@@ -866,20 +1058,17 @@ int cryo_multi_decompress_blocks(cryo_multi *m, int method, const void *const *h
     if (n == 0) return CRYO_OK;
     if (!h_src || !h_src_size || !h_dst || !h_status) return CRYO_E_ARG;
     if (m->h.size() == 1) return cryo_codec_decompress_blocks(m->h[0], method, h_src, h_src_size, n, h_dst, block_size, h_status);
-    return multi_run(m, n, [&](size_t g, const std::vector<size_t> &idx) {
-        std::vector<const void *> src(idx.size());
-        std::vector<void *> dst(idx.size());
-        std::vector<uint32_t> sz(idx.size());
-        std::vector<int32_t> st(idx.size());
-        for (size_t k = 0; k < idx.size(); k++) {
-            src[k] = h_src[idx[k]];
-            sz[k] = h_src_size[idx[k]];
-            dst[k] = (uint8_t *)h_dst + idx[k] * block_size;
-        }
-        const int rc = decompress_blocks_impl(m->h[g], method, src.data(), sz.data(), idx.size(), nullptr, dst.data(), block_size, st.data());
-        if (rc == CRYO_OK) for (size_t k = 0; k < idx.size(); k++) h_status[idx[k]] = st[k];
-        return rc;
-    });
+    return multi_decompress(m, method, h_src, h_src_size, n, h_dst, nullptr, block_size, h_status);
+}
+
+int cryo_multi_decompress_blocks_to(cryo_multi *m, int method, const void *const *h_src, const uint32_t *h_src_size, size_t n,
+                                    void *const *h_dst, size_t block_size, int32_t *h_status)
+{
+    if (!m || m->h.empty() || !method_ok(method) || block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
+    if (n == 0) return CRYO_OK;
+    if (!h_src || !h_src_size || !h_dst || !h_status) return CRYO_E_ARG;
+    if (m->h.size() == 1) return cryo_codec_decompress_blocks_to(m->h[0], method, h_src, h_src_size, n, h_dst, block_size, h_status);
+    return multi_decompress(m, method, h_src, h_src_size, n, nullptr, h_dst, block_size, h_status);
 }
 
 /* ---- helpers ---- */

@@ -24,21 +24,35 @@ hipError_t launch_compare(hipStream_t s, const uint8_t *d_a, uint64_t a_stride, 
                           uint64_t *d_mismatch);
 
 /* LZ4 block format */
+/* per-handle options (include/cryo_codec.h: CRYO_OPT_LZ4_DECODE_PATH, CRYO_OPT_LZ4_INDEX_WALKERS); 0 = automatic */
+struct Lz4DecodeOpts {
+    int path = 0;    /* 1: in-wave parse kernel, 2: sequence index + indexed decoder */
+    int walkers = 0; /* walkers per block of the index pass (power of two, 1..64) */
+};
 hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                  const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                  uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
-                                 size_t workspace_bytes);
-/* bytes of workspace the sequence-index pass of a batch this large wants (0: the batch is decoded without one) */
-size_t lz4_decompress_workspace(uint64_t n_blocks, uint32_t block_size);
-/* lz4_dec2.hip: sequence index (one lane per block) + the decoder that consumes it */
-uint32_t lz4_index_cap(uint32_t block_size);
-size_t lz4_index_workspace(uint64_t n_blocks, uint32_t block_size);
+                                 size_t workspace_bytes, const Lz4DecodeOpts &opts);
+/* bytes of workspace the sequence-index pass of this batch wants (0: the batch is decoded without one) */
+size_t lz4_decompress_workspace(uint64_t n_blocks, uint32_t block_size, const Lz4DecodeOpts &opts);
+/* which path a batch takes: 0 = in-wave parse kernel (k_lz4_dec_ring), else the walkers per block of the index pass */
+uint32_t lz4_decode_plan(uint64_t n_blocks, uint32_t block_size, const Lz4DecodeOpts &opts);
+/* lz4_index.hip: the sequence index.  Workspace layout: n_blocks rows of `cap` 16-bit entries; a row = S sub-rows of
+ * [ext entries: extension of the left neighbour][cap_main entries: the segment's own records]; 64 x 32 bytes of dummy
+ * slots; one uint2 descriptor per (block, segment): x = entries used in the extension | first valid own record << 16,
+ * y = valid own records */
+struct Lz4IndexLayout {
+    uint32_t logS, cap_main, ext, cap;
+    size_t dummy_off, seg_off, bytes;
+};
+Lz4IndexLayout lz4_index_layout(uint64_t n_blocks, uint32_t block_size, uint32_t walkers);
 hipError_t launch_lz4_index(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
-                            uint64_t n_blocks, uint16_t *tbl, uint32_t cap, uint32_t *tbl_n);
+                            uint64_t n_blocks, void *d_workspace, const Lz4IndexLayout &L);
+/* lz4_dec2.hip: index pass + the decoder that consumes it */
 hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                          const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                          uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
-                                         size_t workspace_bytes);
+                                         size_t workspace_bytes, uint32_t walkers);
 
 hipError_t launch_lz4_compress(hipStream_t s, const uint8_t *d_src, uint64_t src_stride,
                                uint32_t block_size, uint64_t n_blocks, uint8_t *d_dst,

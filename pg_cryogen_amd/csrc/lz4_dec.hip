@@ -546,41 +546,44 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     }
 }
 
-static uint64_t lz4_index_min_blocks()
+/* Which path a batch takes.  The indexed decoder (lz4_index.hip + lz4_dec2.hip) does half the work per sequence of
+ * the in-wave parse below, but its index pass is a serial walk per walker: with one walker per block it takes as long
+ * for 4 096 blocks as for 65 536 (and 8 x longer for 1 MiB blocks), so round 2 used it from 24 576 blocks on only.  With
+ * several walkers per block the pass shrinks with the batch: the walkers are chosen so that the batch fills the chip
+ * once (65 536 lanes = one wave per SIMD) with segments of at least 4 KiB of block.  Small blocks in small batches stay
+ * on the in-wave parse (a 4 KiB block is a few batches: the second launch costs more than the parse). */
+uint32_t lz4_decode_plan(uint64_t n_blocks, uint32_t block_size, const Lz4DecodeOpts &opts)
 {
-    /* the index walk is one lane per block: below a few thousand blocks its latency-bound pass costs more than the
-     * in-wave parse it replaces.  CRYO_LZ4_INDEX_MIN overrides (0 = always, huge = never). */
-    static const uint64_t v = [] {
-        const char *e = getenv("CRYO_LZ4_INDEX_MIN");
-        return e ? strtoull(e, nullptr, 0) : 24576ull;
-    }();
-    return v;
+    if (opts.path == 1) return 0;
+    if (opts.path == 0 && block_size < 16384u && n_blocks < 24576u) return 0;
+    if (opts.walkers > 0) return (uint32_t)opts.walkers;
+    uint32_t S = 1;
+    while (S < 64u && n_blocks * (2u * S) <= 65536u && block_size / (2u * S) >= 4096u) S *= 2u;
+    return S;
 }
-size_t lz4_decompress_workspace(uint64_t n_blocks, uint32_t block_size)
+size_t lz4_decompress_workspace(uint64_t n_blocks, uint32_t block_size, const Lz4DecodeOpts &opts)
 {
-    if (n_blocks < lz4_index_min_blocks()) return 0;
-    return lz4_index_workspace(n_blocks, block_size);
+    const uint32_t S = lz4_decode_plan(n_blocks, block_size, opts);
+    return S ? lz4_index_layout(n_blocks, block_size, S).bytes : 0;
 }
 
 hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                  const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                  uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
-                                 size_t workspace_bytes)
+                                 size_t workspace_bytes, const Lz4DecodeOpts &opts)
 {
     if (n_blocks == 0) return hipSuccess;
     const uint64_t grid = (n_blocks + 3) / 4;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    /* output ring size per wave: 4 KiB default (16 waves/CU by LDS; 2 KiB is not possible: sources a batch calls far must already be flushed, i.e. lie kTMax + one 1 KiB flush unit back); CRYO_LZ4_RING=4096|8192 for tuning */
-    static const int ring = [] {
-        const char *e = getenv("CRYO_LZ4_RING");
-        return e ? atoi(e) : 4096;
-    }();
     const dim3 g((uint32_t)grid), b(256);
-    /* large batches with a workspace: sequence index pass + the decoder built for it (lz4_dec2.hip) */
-    const size_t need = lz4_decompress_workspace(n_blocks, block_size);
-    if (need != 0 && d_workspace != nullptr && workspace_bytes >= need)
+    /* sequence index pass + the decoder built for it (lz4_dec2.hip) */
+    const uint32_t S = lz4_decode_plan(n_blocks, block_size, opts);
+    if (S != 0) {
+        if (d_workspace == nullptr) return hipErrorInvalidValue;
         return launch_lz4_decompress_indexed(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks,
-                                             d_status, d_workspace, workspace_bytes);
+                                             d_status, d_workspace, workspace_bytes, S);
+    }
+#ifdef CRYO_DEBUG
     static const bool want_stats = getenv("CRYO_LZ4_STATS") != nullptr; /* debugging aid */
     if (want_stats) {
         unsigned long long *d_st = nullptr, h_st[16];
@@ -603,11 +606,8 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
         }
         return hipGetLastError();
     }
-    if (ring == 8192)
-        hipLaunchKernelGGL((k_lz4_dec_ring<8192, false>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
-                           block_size, n_blocks, d_status, nullptr);
-    else
-        hipLaunchKernelGGL((k_lz4_dec_ring<4096, false>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
+#endif
+    hipLaunchKernelGGL((k_lz4_dec_ring<4096, false>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
                            block_size, n_blocks, d_status, nullptr);
     return hipGetLastError();
 }

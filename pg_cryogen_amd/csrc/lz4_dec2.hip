@@ -1,13 +1,13 @@
 /*
- * lz4_dec2.hip -- LZ4 block decode for large batches: sequence index pass + run-space copy engine.
+ * lz4_dec2.hip -- LZ4 block decode from a sequence index: one sequence per lane + run-space copy engine.
  *
  * Replaces LZ4_decompress_safe(compressed, out, compressed_size, CRYO_BLCKSZ) (reference
  * compression.c:84) for a batch of independent blocks, with the accept/reject rules listed at the top of
- * lz4_dec.hip (whose kernel stays the path for small batches).  Two kernels:
+ * lz4_dec.hip.  Two kernels:
  *
- *   k_lz4_index   one LANE per block: walks the token chain and writes the low 16 bits of every token
- *                 position to the block's row of the workspace (the serial part of LZ4 decoding, run
- *                 for all blocks of the batch at once);
+ *   k_lz4_index   (lz4_index.hip) one LANE per walker, one or several walkers per block: walks the token chain and
+ *                 writes the low 16 bits of every token position to the block's row of the workspace (the serial
+ *                 part of LZ4 decoding, run for all blocks of the batch at once);
  *   k_lz4_dec_seq one WAVE per block: lane i loads position i of the row, decodes "its" sequence
  *                 (literal length, offset, match length), a wave scan gives output positions, and the
  *                 bytes are moved by the run-space copy engine below.  The row is only a hint: every
@@ -29,219 +29,6 @@
 #include <cstdlib>
 
 namespace cryo {
-
-/* ---------------------------------------------------------------------------------------------
- * Sequence index.  Finding where the sequences of an LZ4 block start is a serial walk (token ->
- * literal length -> next token); done inside the decoding wave it needs speculative per-byte tables
- * (lz4_dec.hip, lz4_batch: ~7 VALU instructions and four dependent LDS passes per sequence).  Across a
- * batch the walk is embarrassingly parallel.
- *
- * k_lz4_index: 64 blocks per wave (every lane walks one block's token chain), 4 waves per CU (8 with the
- * smaller rings), so every block of a 64k-block batch has its walk in flight at once and the pass takes
- * (sequences per block) x (one hop).
- *
- * A lane that read its block straight from global memory paid ~1 us per hop (64 lanes = 64 cache lines
- * per load, every hop a dependent trip to L2 or beyond: 6.9 ms for the headline batch, measured).  So each
- * block's stream is staged through a private 512-byte LDS ring, filled 128 bytes at a time: in turn j of
- * four the wave's 64 lanes load one chunk for each of blocks 8j..8j+7 (8 lanes x 16 bytes per block, one
- * cache line) if that block has room, and store it into the ring one round of turns later, so the load's
- * latency is covered by four hops.  The walk is a small state machine per lane (token / literal-length
- * extension / match-length extension) so that one LDS read per hop serves every lane, whatever it is in.
- * --------------------------------------------------------------------------------------------- */
-constexpr uint32_t kIdxLanes = 64, kIdxChunk = 128;
-
-__device__ inline uint32_t bperm(uint32_t v, uint32_t src_lane)
-{
-    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
-}
-
-template <uint32_t kIdxRing> /* bytes of LDS ring per block: 512, or 256 (twice the waves per CU) */
-__global__ void __launch_bounds__(64)
-k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
-            const uint32_t *__restrict__ src_size, uint64_t n_blocks, uint16_t *__restrict__ tbl, uint32_t cap,
-            uint32_t *__restrict__ tbl_n)
-{
-    constexpr uint32_t kIdxStride = kIdxRing + 16u; /* bank skew between rings */
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kIdxLanes * kIdxStride];
-    /* the last 16 positions of every lane (4 groups of 4) + one slot where a lane that records nothing writes */
-    __shared__ __attribute__((aligned(8))) uint16_t s_pos[kIdxLanes][20];
-    const uint32_t lane = threadIdx.x;
-    const uint64_t blk = (uint64_t)blockIdx.x * kIdxLanes + (lane & (kIdxLanes - 1u));
-    const bool owner = blk < n_blocks;
-    /* stream of this lane's block, in "virtual" positions: vp = delta + offset in the block, so that chunk
-     * addresses are 128-byte aligned */
-    uint64_t aoff = 0;
-    uint32_t delta = 0, vend = 0;
-    if (owner) {
-        const uint64_t o = src_off[blk];
-        aoff = o & ~(uint64_t)127;     /* chunks are whole 128-byte lines: each line of the input is fetched once */
-        delta = (uint32_t)(o & 127u);
-        vend = delta + src_size[blk];
-    }
-    uint16_t *row = tbl + blk * cap;
-    uint16_t *dummy = tbl + n_blocks * cap + lane * 8u; /* 8 bytes per lane behind the rows: where lanes without a block store */
-    if (!owner) aoff = src_off[0] & ~(uint64_t)127; /* a lane past the end of the batch re-reads block 0 */
-    uint32_t pos = delta;        /* next byte to interpret */
-    uint32_t requested = 0;      /* chunks requested up to here (multiple of kIdxChunk) */
-    uint32_t filled = 0;         /* chunks stored in the ring up to here */
-    uint32_t outst = 0, drop = 0; /* chunks of this lane on their way; how many of them a restart of the ring disowned */
-    uint32_t state = 0;          /* 0 token, 1 literal-length extension, 2 match-length extension */
-    uint32_t acc = 0, tm = 0;    /* literal length being accumulated; match nibble of the current token */
-    uint32_t k = 0;
-    uint16_t *pbuf = s_pos[lane & (kIdxLanes - 1u)];
-    bool done = !owner || vend == delta;
-
-    /* what this lane serves in turn j: one 16-byte piece of the next chunk of blocks 16j + (lane >> 3) and
-     * 16j + 8 + (lane >> 3) (two loads per turn: every block has a turn every fourth hop) */
-    const uint32_t piece16 = (lane & 7u) * 16u;
-#define IDX_SRC(j) const uint64_t saoff##j = ((uint64_t)bperm((uint32_t)(aoff >> 32), 8u * j + (lane >> 3)) << 32) | bperm((uint32_t)aoff, 8u * j + (lane >> 3)); \
-                   const uint32_t svend##j = bperm(vend, 8u * j + (lane >> 3));
-    IDX_SRC(0) IDX_SRC(1) IDX_SRC(2) IDX_SRC(3) IDX_SRC(4) IDX_SRC(5) IDX_SRC(6) IDX_SRC(7)
-#undef IDX_SRC
-    const uint32_t rb = (lane & (kIdxLanes - 1u)) * kIdxStride; /* this lane's ring inside s_ring */
-
-    /* chunks on their way: two per turn, committed TWO rounds later (a lane with room in its ring requests one chunk
-     * per round, up to two outstanding; four rounds of distance bought nothing and its 32 slots spilled registers).
-     * Separate variables, not arrays: the compiler kept an indexed array in scratch memory. */
-#define IDX_SLOT(n) uint4 fd##n = make_uint4(0, 0, 0, 0), fe##n = fd##n; uint32_t fa##n = 0, fb##n = 0; bool fp##n = false, fq##n = false, fo##n = false;
-    IDX_SLOT(0) IDX_SLOT(1) IDX_SLOT(2) IDX_SLOT(3) IDX_SLOT(4) IDX_SLOT(5) IDX_SLOT(6) IDX_SLOT(7)
-#undef IDX_SLOT
-
-    auto turn = [&](const uint32_t j, uint4 &fd, uint4 &fe, uint32_t &fa, uint32_t &fb, bool &fp, bool &fq, bool &fpo,
-                    const uint64_t soff, const uint32_t sve, const uint64_t soff2, const uint32_t sve2) __attribute__((always_inline)) {
-        const bool myturn = (lane >> 4) == j; /* lanes 16j..16j+15 */
-        /* ---- commit the chunks requested four rounds ago ---- */
-        if (fp) *reinterpret_cast<uint4 *>(s_ring + fa) = fd;
-        if (fq) *reinterpret_cast<uint4 *>(s_ring + fb) = fe;
-        if (myturn && outst != 0u && fpo) { /* fpo: this lane did request in the turn being committed */
-            outst--;
-            if (drop != 0u) drop--; else filled += kIdxChunk;
-        }
-        /* the hop's two ring reads go out before the exchange below: one LDS round trip per turn, not two */
-        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(s_ring + rb + (pos & (kIdxRing - 4u)));
-        const uint32_t w1 = *reinterpret_cast<const uint32_t *>(s_ring + rb + ((pos + 4u) & (kIdxRing - 4u)));
-        const uint32_t w2 = *reinterpret_cast<const uint32_t *>(s_ring + rb + ((pos + 8u) & (kIdxRing - 4u)));
-        /* ---- request the next chunk of blocks 8j..8j+7 (one bpermute: requested | want) ---- */
-        {
-            const bool want = myturn && !done && requested < vend && pos + (kIdxRing - kIdxChunk) >= requested;
-            const uint32_t msg = requested | (want ? 1u : 0u);
-            fpo = want;
-            if (want) { requested += kIdxChunk; outst++; }
-            const uint32_t s1 = 16u * j + (lane >> 3), s2 = s1 + 8u;
-            const uint32_t m1 = bperm(msg, s1), m2 = bperm(msg, s2);
-            const uint32_t o1 = (m1 & ~1u) + piece16, o2 = (m2 & ~1u) + piece16;
-            fp = (m1 & 1u) != 0u;
-            fq = (m2 & 1u) != 0u;
-            fa = s1 * kIdxStride + (o1 & (kIdxRing - 1u));
-            fb = s2 * kIdxStride + (o2 & (kIdxRing - 1u));
-            /* always two loads per turn (a lane with nothing to fetch re-reads its block's first 16 bytes): with a
-             * fixed number of vector-memory operations per turn the compiler can wait for exactly the chunks it
-             * commits (vmcnt(N)); a conditional load made it drain the queue once per round (2.3 us a round) */
-            fd = *reinterpret_cast<const uint4 *>(src_base + (soff + ((fp && o1 < sve) ? o1 : 0u)));
-            fe = *reinterpret_cast<const uint4 *>(src_base + (soff2 + ((fq && o2 < sve2) ? o2 : 0u)));
-        }
-        /* ---- one hop, branch-free for the two common states (token, match-length extension) ---- */
-        {
-            const bool live = !done && pos < vend;
-            const bool canread = pos < requested && (pos + 8u <= filled || filled >= vend);
-            const uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, pos & 3u);
-            const bool go = live && canread && state != 1u;
-            /* token */
-            const uint32_t ll = (x >> 4) & 15u, e1 = (x >> 8) & 255u, tmn = x & 15u;
-            const bool l15 = ll == 15u;
-            const uint32_t q2 = pos + 3u + ll + (l15 ? e1 + 1u : 0u);  /* behind the literals and the offset */
-            const bool tok = go && state == 0u;
-            const bool longlit = tok && l15 && e1 == 255u;            /* 255-run: slow path below */
-            /* match-length extension bytes */
-            const uint32_t nx = ~x;
-            const uint32_t n = nx ? (uint32_t)__builtin_ctz(nx) >> 3 : 4u; /* leading 0xFF bytes */
-            const uint32_t adv = n == 4u ? 4u : n + 1u;
-            const bool ext = go && state == 2u;
-            /* record + advance */
-            const bool rec = tok;
-            pbuf[rec ? (k & 15u) : 16u] = (uint16_t)(pos - delta); /* unconditional: a store in a branch costs more than the branch saves */
-            if (rec) { k++; tm = tmn; }
-            const bool fin = tok && !longlit && q2 > vend;              /* last sequence: literals only */
-            if (tok && !longlit && !fin) { pos = q2; state = tmn == 15u ? 2u : 0u; }
-            /* a second token in the same turn when the first one leaves it inside the eight bytes just read: no or
-             * up to two literals and a short match (half of the sequences of tuple data) */
-            {
-                const bool dbl = tok && !longlit && !fin && !l15 && tmn != 15u && ll <= 2u && q2 < vend && k + 1u < cap;
-                const uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, (q2 - 3u - ll) & 3u); /* bytes 4..7 behind the first token */
-                const unsigned long long xx = ((unsigned long long)x1 << 32) | x;
-                const uint32_t y = (uint32_t)(xx >> (8u * (3u + ll)));
-                const uint32_t llb = (y >> 4) & 15u, e1b = (y >> 8) & 255u, tmb = y & 15u;
-                const bool l15b = llb == 15u;
-                const uint32_t q2b = q2 + 3u + llb + (l15b ? e1b + 1u : 0u);
-                const bool rec2 = dbl && !(l15b && e1b == 255u);
-                pbuf[rec2 ? (k & 15u) : 16u] = (uint16_t)(q2 - delta);
-                if (rec2) {
-                    k++;
-                    tm = tmb;
-                    if (q2b > vend) done = true;
-                    else { pos = q2b; state = tmb == 15u ? 2u : 0u; }
-                }
-            }
-            if (ext) { pos += adv; state = n == 4u ? 2u : 0u; }
-            if (longlit) { state = 1u; acc = 15u + 255u; pos += 2u; }
-            if (fin || (!done && !live) || k >= cap) done = true;
-            /* rare: literal-length 255-runs, and jumps over everything requested (a long literal run) */
-            const bool slow = !done && (state == 1u || pos >= requested) && !longlit;
-            if (__any(slow)) {
-                if (slow && pos < vend) {
-                    if (pos >= requested) {
-                        /* restart the ring at the chunk of pos; a chunk still in flight lands in a slot that is
-                         * rewritten before it is read */
-                        requested = filled = pos & ~(kIdxChunk - 1u);
-                        drop = outst;
-                    } else if (state == 1u && live && canread) {
-                        if (n == 4u) { acc += 1020u; pos += 4u; if (acc >= vend) done = true; }
-                        else {
-                            acc += 255u * n + ((x >> (8u * n)) & 255u);
-                            const uint32_t q = pos + n + 1u + acc;
-                            if (acc >= vend || q + 2u > vend) done = true;
-                            else { pos = q + 2u; state = tm == 15u ? 2u : 0u; }
-                        }
-                    }
-                }
-            }
-        }
-    };
-
-    /* positions go out in aligned groups of four (8 bytes): once per round the group being filled and the two before
-     * it (a lane gains at most eight positions per round, so no group is missed); a group is stored a few times while
-     * it fills, always whole and aligned, so the L2 merges the stores of a row into full lines.  (Storing "the last
-     * four entries" at a 2-byte granular address instead wrote 5.2 GB for a 0.8 GB index.)  Three unconditional
-     * stores per round, see the note on the loads.  A macro, not a lambda: captured by a lambda, the packs lived in
-     * scratch memory. */
-#define IDX_PUT()                                                                                            \
-    {                                                                                                        \
-        const uint32_t g = k ? (k - 1u) >> 2 : 0u;                                                           \
-        const uint32_t g2 = g > 1u ? g - 2u : 0u, g1 = g ? g - 1u : 0u;                                      \
-        uint16_t *r = owner ? row : dummy;                                                                   \
-        unsigned long long v2, v1, v0;                                                                       \
-        __builtin_memcpy(&v2, pbuf + 4u * (g2 & 3u), 8);                                                     \
-        __builtin_memcpy(&v1, pbuf + 4u * (g1 & 3u), 8);                                                     \
-        __builtin_memcpy(&v0, pbuf + 4u * (g & 3u), 8);                                                      \
-        __builtin_memcpy(r + 4u * g2, &v2, 8);                                                               \
-        __builtin_memcpy(r + 4u * g1, &v1, 8);                                                               \
-        __builtin_memcpy(r + 4u * g, &v0, 8);                                                                \
-    }
-#define IDX_TURN(j, n, sa, sb) turn(j, fd##n, fe##n, fa##n, fb##n, fp##n, fq##n, fo##n, saoff##sa, svend##sa, saoff##sb, svend##sb);
-#define IDX_ROUND(a, b, c, d)                                   \
-    IDX_PUT()                                                   \
-    IDX_TURN(0, a, 0, 1) IDX_TURN(1, b, 2, 3) IDX_TURN(2, c, 4, 5) IDX_TURN(3, d, 6, 7)
-    while (__any(!done)) {
-        IDX_ROUND(0, 1, 2, 3)
-        IDX_ROUND(4, 5, 6, 7)
-    }
-#undef IDX_ROUND
-#undef IDX_TURN
-    if (owner) {
-        IDX_PUT()
-        tbl_n[blk] = k;
-    }
-}
 
 /* ---------------------------------------------------------------------------------------------
  * Decoder
@@ -469,7 +256,8 @@ __global__ void __launch_bounds__(256, 6)
 k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
               const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
               uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats,
-              const uint16_t *__restrict__ tbl, uint32_t tbl_cap, const uint32_t *__restrict__ tbl_n)
+              const uint16_t *__restrict__ tbl, uint32_t tbl_cap, const uint2 *__restrict__ seg, const uint32_t logS,
+              const uint32_t cap_s, const uint32_t ext)
 {
     Stats st = {};
     st.on = STATS;
@@ -505,14 +293,33 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     bool bad = (csize == 0);
     bool done = bad;
     uint32_t skip = 0;
+    /* The block's row of the index, as the walkers left it (lz4_index.hip): per segment an "extension" piece (what the
+     * left neighbour's walker visited before the chains met) and the segment's own records from the meeting point on.
+     * Lane s holds segment s's descriptor; the pieces are consumed in order, a batch never spans two of them. */
     const uint16_t *trow = tbl + uni64(blk * (uint64_t)tbl_cap);
-    const uint32_t ntab = uni(tbl_n[blk]);
-    uint32_t n0 = 0; /* sequences decoded so far */
+    const uint32_t npieces = 2u << logS;
+    uint2 sd = make_uint2(0, 0);
+    if (lane < (1u << logS)) sd = seg[(blk << logS) + lane];
+    uint32_t pc = 0, plen = 0; /* next piece; entries of the current one */
+    uint32_t n0 = 0;           /* entries of the current piece used so far */
+    auto next_piece = [&]() {
+        plen = 0;
+        n0 = 0;
+        while (pc < npieces) {
+            const uint32_t sg = pc >> 1;
+            const uint32_t dx = lane_get(sd.x, sg), dy = lane_get(sd.y, sg);
+            const uint32_t len = (pc & 1u) ? dy : (dx & 0xffffu);
+            const uint32_t base = sg * cap_s + ((pc & 1u) ? ext + (dx >> 16) : 0u);
+            pc++;
+            if (len != 0u) { trow = tbl + uni64(blk * (uint64_t)tbl_cap) + base; plen = len; break; }
+        }
+    };
+    next_piece();
     uint32_t poor = 0;
 
     /* the first batch's index entries travel with the first input chunks (one trip to memory at the start of a block, not two) */
     uint32_t efirst = 0;
-    if (!bad && lane < ntab) efirst = trow[lane];
+    if (!bad && lane < plen) efirst = trow[lane];
     bool have_first = !bad;
     if (!bad) {
         w.prefetch();
@@ -525,16 +332,19 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
             uint32_t n;
             uint32_t epre = efirst;
             bool have_pre = have_first;
+            bool more;
             have_first = false;
             do {
+                if (plen != 0u && n0 >= plen) { next_piece(); have_pre = false; }
                 uint32_t e = epre;
-                const uint32_t navail = n0 < ntab ? (ntab - n0 < 64u ? ntab - n0 : 64u) : 0u;
+                const uint32_t navail = n0 < plen ? (plen - n0 < 64u ? plen - n0 : 64u) : 0u;
                 if (!have_pre) { e = 0; if (lane < navail) e = trow[n0 + lane]; }
-                n = lz4_seq_batch<R>(w, L, vp, B, e, navail, trow, n0, ntab, epre, st, STATS ? stats + 16 : nullptr);
+                n = lz4_seq_batch<R>(w, L, vp, B, e, navail, trow, n0, plen, epre, st, STATS ? stats + 16 : nullptr);
                 have_pre = n != 0u;
                 n0 += n;
                 if (n == 0u) st.zero_batches++;
-            } while (n >= 8u);
+                more = n >= 8u || (n != 0u && n == navail); /* a piece's last batch may be short: go on with the next piece */
+            } while (more);
             /* a batch stops in front of a sequence it cannot take (overlapping match, long run, end of block):
              * that one goes through the general path and the batches resume.  Only data that keeps yielding
              * short batches (runs of overlapping matches) stays on the general path for a while. */
@@ -544,6 +354,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
             skip--;
         }
         st.general_seqs++;
+        if (plen != 0u && n0 >= plen) next_piece();
         n0++;
         const uint32_t r = lz4_general_seq<R>(w, vp, B);
         if (r == 2u) { bad = true; break; }
@@ -569,59 +380,30 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
 }
 
 /* ---- launcher ---- */
-/* Entries per row: B/8 + 64 rounded up to 1024 entries, i.e. rows 2 KiB-granular (34 816 bytes at 128 KiB blocks).  The
- * index pass writes 64 rows at once, 8 bytes each, and is sensitive to the row stride: with 33 024 bytes (+64 entries)
- * it always runs 17 % slower (3.6 instead of 3.05 ms), with the natural 32 896 sometimes, with 33 792 / 34 816 never
- * in 30 samples each (profiles/scripts/r02_cap.sh). */
-uint32_t lz4_index_cap(uint32_t block_size)
-{
-    static const uint32_t pad = getenv("CRYO_LZ4_IDX_CAP_PAD") ? (uint32_t)atoi(getenv("CRYO_LZ4_IDX_CAP_PAD")) & ~3u : 0u; /* layout experiments */
-    return ((block_size / 8u + 64u + 1023u) & ~1023u) + pad;
-}
-
-size_t lz4_index_workspace(uint64_t n_blocks, uint32_t block_size)
-{
-    return (size_t)n_blocks * lz4_index_cap(block_size) * 2u + 1024u /* dummy slots */ + (size_t)n_blocks * 4u + 64u;
-}
-
-hipError_t launch_lz4_index(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
-                            uint64_t n_blocks, uint16_t *tbl, uint32_t cap, uint32_t *tbl_n)
-{
-    /* 512-byte rings admit four waves per CU (one per SIMD).  256-byte rings (eight waves per CU) were measured and lose:
-     * 65 536 blocks 895 -> 677 GB/s, 131 072 blocks 907 -> 657 GB/s end to end -- a chunk is requested only when the
-     * walk is within 128 bytes of the end of what it has, and waits for it.  Nor do 64-byte chunks into 256-byte rings
-     * (two request turns per round; measured 902 -> 818 and 931 -> 746 GB/s): more resident waves make this pass slower,
-     * not faster, so it is not only a lone wave's instruction issue that paces it. */
-    static const uint32_t ring_env = getenv("CRYO_LZ4_IDX_RING") ? (uint32_t)atoi(getenv("CRYO_LZ4_IDX_RING")) : 0u; /* tuning aid */
-    const uint32_t ring = ring_env ? ring_env : 512u;
-    const dim3 g((uint32_t)((n_blocks + kIdxLanes - 1) / kIdxLanes));
-    if (ring == 256u) hipLaunchKernelGGL(k_lz4_index<256>, g, dim3(64), 0, s, d_src, d_src_off, d_src_size, n_blocks, tbl, cap, tbl_n);
-    else hipLaunchKernelGGL(k_lz4_index<512>, g, dim3(64), 0, s, d_src, d_src_off, d_src_size, n_blocks, tbl, cap, tbl_n);
-    return hipGetLastError();
-}
-
 hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                          const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                          uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
-                                         size_t workspace_bytes)
+                                         size_t workspace_bytes, uint32_t walkers)
 {
     if (n_blocks == 0) return hipSuccess;
     const uint64_t grid = (n_blocks + 3) / 4;
-    if (grid > 0x7fffffffull || workspace_bytes < lz4_index_workspace(n_blocks, block_size) || !d_workspace) return hipErrorInvalidValue;
-    const uint32_t cap = lz4_index_cap(block_size);
-    uint16_t *tbl = static_cast<uint16_t *>(d_workspace);
-    uint32_t *tbl_n = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_workspace) + (((size_t)n_blocks * cap * 2u + 1024u + 15u) & ~(size_t)15u));
-    if (hipError_t e = launch_lz4_index(s, d_src, d_src_off, d_src_size, n_blocks, tbl, cap, tbl_n); e != hipSuccess) return e;
+    const Lz4IndexLayout Lx = lz4_index_layout(n_blocks, block_size, walkers);
+    if (grid > 0x7fffffffull || workspace_bytes < Lx.bytes || !d_workspace) return hipErrorInvalidValue;
+    if (hipError_t e = launch_lz4_index(s, d_src, d_src_off, d_src_size, n_blocks, d_workspace, Lx); e != hipSuccess) return e;
+    const uint16_t *tbl = static_cast<const uint16_t *>(d_workspace);
+    const uint2 *seg = reinterpret_cast<const uint2 *>(static_cast<const uint8_t *>(d_workspace) + Lx.seg_off);
     const dim3 g((uint32_t)grid), b(256);
-    static const bool want_stats = getenv("CRYO_LZ4_STATS") != nullptr; /* debugging aid */
+#ifdef CRYO_DEBUG
+    /* phase timing and ablation of the decoder (profiles/scripts): a debug build only -- an ablated run decodes wrong bytes */
+    static const bool want_stats = getenv("CRYO_LZ4_STATS") != nullptr;
     if (want_stats) {
         unsigned long long *d_st = nullptr, h_st[32];
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
-        static const unsigned long long abl = getenv("CRYO_LZ4_ABLATE") ? strtoull(getenv("CRYO_LZ4_ABLATE"), nullptr, 0) : 0ull; /* timing experiments: wrong bytes */
+        static const unsigned long long abl = getenv("CRYO_LZ4_ABLATE") ? strtoull(getenv("CRYO_LZ4_ABLATE"), nullptr, 0) : 0ull;
         (void)hipMemcpyAsync(d_st + 7, &abl, sizeof abl, hipMemcpyHostToDevice, s);
         hipLaunchKernelGGL((k_lz4_dec_seq<4096, true>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
-                           block_size, n_blocks, d_status, d_st, tbl, cap, tbl_n);
+                           block_size, n_blocks, d_status, d_st, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext);
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
         (void)hipFree(d_st);
@@ -636,8 +418,9 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
                 h_st[16], h_st[17], h_st[18], h_st[19], h_st[20], h_st[21], h_st[22], h_st[23], h_st[24], h_st[25], h_st[26]);
         return hipGetLastError();
     }
+#endif
     hipLaunchKernelGGL((k_lz4_dec_seq<4096, false>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
-                       block_size, n_blocks, d_status, nullptr, tbl, cap, tbl_n);
+                       block_size, n_blocks, d_status, nullptr, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext);
     return hipGetLastError();
 }
 

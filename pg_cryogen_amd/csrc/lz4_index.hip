@@ -1,0 +1,401 @@
+/*
+ * lz4_index.hip -- the sequence index of the LZ4 block decoder: where every sequence (token) of a block starts.
+ *
+ * Part of what replaces LZ4_decompress_safe(compressed, out, compressed_size, CRYO_BLCKSZ) (reference
+ * compression.c:84).  Finding the sequence starts of an LZ4 block is a serial walk (token -> literal length -> next
+ * token); inside the decoding wave it costs speculative per-byte tables (lz4_dec.hip), across a batch it is
+ * embarrassingly parallel.  k_lz4_index runs it with one LANE per walker and writes, per block, a row of 16-bit
+ * entries (the low 16 bits of every token's offset in the compressed block) that k_lz4_dec_seq (lz4_dec2.hip) turns
+ * into one sequence per lane.  The decoder checks every entry against the stream: a wrong row costs speed, never bytes.
+ *
+ * The walk.  A lane that read its stream straight from global memory paid a trip to L2 per hop (6.9 ms for the
+ * headline batch).  So every walker stages its stream through a private 512-byte LDS ring, filled 128 bytes (one
+ * cache line) at a time: in turn j of four the wave's 64 lanes load one 16-byte piece each for 16 walkers that have
+ * room, and store it two rounds later, so a load's latency is covered by eight hops.  The walk is a small state
+ * machine per lane (token / literal-length extension / match-length extension), one LDS read per hop serves every
+ * lane whatever it is in; a token with at most two literals and a short match leaves the next token inside the bytes
+ * just read and that one is taken in the same turn.  The pass is paced by (hops per walker) x (time of a turn): all
+ * walkers of a batch are in flight at once (one wave per SIMD, LDS-bound), so a block's walk is as long as the pass.
+ *
+ * Several walkers per block (round 3).  With one walker per block the pass takes as long for 4 096 blocks as for
+ * 65 536, and eight times longer for 1 MiB blocks than for 128 KiB ones.  With S walkers per block, walker s starts at
+ * a GUESSED token position (byte s * csize / S of the stream) and walks segment s.  Its chain is wrong at first, but two
+ * chains that ever visit the same position are identical from there on, and on real data a chain that starts anywhere
+ * runs into the true one within a few tokens (a false chain hops ~7 bytes at a time over literal bytes, a true token
+ * lies every ~16 bytes).  So after the walk each walker s keeps going past the end of its segment until it meets a
+ * position walker s+1 recorded ("extension", a handful of hops, direct reads from memory); what it visited on the way
+ * replaces the false start of walker s+1's records.  By induction from walker 0 (whose start is true) every segment is
+ * then described by two pieces: the extension of its left neighbour + its own records from the meeting point on.  A
+ * boundary where the chains do not meet within the segment (periodic data can do that) makes the block's first lane
+ * walk the whole block again, alone: never worse than one walker per block was.
+ */
+#include "lz_common.h"
+#include <cstdlib>
+
+namespace cryo {
+
+constexpr uint32_t kIdxLanes = 64, kIdxChunk = 128, kIdxRing = 512;
+constexpr uint32_t kIdxStride = kIdxRing + 16u; /* bank skew between rings */
+
+__device__ inline uint32_t bperm(uint32_t v, uint32_t src_lane)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
+}
+/* lane i gets lane i+1's value (lane 63: 0) / lane i-1's (lane 0: 0) */
+__device__ inline uint32_t from_next(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xf, 0xf, false); }
+__device__ inline uint32_t from_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+
+/* The token after the one at virtual position p, read straight from memory (the extension walk: a handful of hops per
+ * walker).  Returns a position >= vend when the token at p is the stream's last sequence (or the stream is cut). */
+__device__ inline uint32_t lz4_next_token_direct(const uint8_t *sb, const uint32_t vend, const uint32_t p)
+{
+    uint32_t x;
+    __builtin_memcpy(&x, sb + p, 4); /* up to 3 bytes beyond the stream: inside the slack every source buffer has */
+    const uint32_t t = x & 255u;
+    uint32_t ll = t >> 4, q = p + 1u;
+    if (ll == 15u) {
+        uint32_t b = (x >> 8) & 255u;
+        ll += b;
+        q++;
+        while (b == 255u) {
+            if (q >= vend) return 0xffffffffu;
+            b = sb[q++];
+            ll += b;
+            if (ll >= vend) return 0xffffffffu;
+        }
+    }
+    q += ll;
+    if (q + 2u > vend) return 0xffffffffu; /* literals only: the last sequence */
+    q += 2u;
+    if ((t & 15u) == 15u) {
+        uint32_t b;
+        do {
+            if (q >= vend) return 0xffffffffu;
+            b = sb[q++];
+        } while (b == 255u);
+    }
+    return q;
+}
+
+__global__ void __launch_bounds__(64)
+k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
+            const uint32_t *__restrict__ src_size, const uint64_t n_blocks, uint16_t *__restrict__ tbl,
+            const uint32_t logS, const uint32_t cap_main, const uint32_t ext, const uint32_t cap,
+            uint2 *__restrict__ seg, uint16_t *__restrict__ dummy_base)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kIdxLanes * kIdxStride];
+    /* the last 32 positions of every lane (two lines of 16: one being filled, one waiting for its store) + one slot
+     * where a lane that records nothing writes */
+    __shared__ __attribute__((aligned(16))) uint16_t s_pos[kIdxLanes][40];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t S = 1u << logS, cap_s = cap_main + ext;
+    const uint64_t gl = (uint64_t)blockIdx.x * kIdxLanes + lane;
+    const uint64_t blk = gl >> logS;
+    const uint32_t sw = (uint32_t)gl & (S - 1u);   /* walker number inside the block */
+    const bool owner = blk < n_blocks;
+    /* stream of this lane's block, in "virtual" positions: vp = delta + offset in the block, so that chunk
+     * addresses are 128-byte aligned */
+    uint64_t aoff = 0;
+    uint32_t delta = 0, vend = 0, seff = 1, seglen = 0;
+    if (owner) {
+        const uint64_t o = src_off[blk];
+        const uint32_t cs = src_size[blk];
+        aoff = o & ~(uint64_t)127;     /* chunks are whole 128-byte lines: each line of the input is fetched once */
+        delta = (uint32_t)(o & 127u);
+        vend = delta + cs;
+        /* segments of at least 1 KiB: a block that compressed to little is walked by fewer lanes */
+        const uint32_t kib = cs >> 10;
+        const uint32_t lg = kib ? 31u - (uint32_t)__builtin_clz(kib) : 0u;
+        const uint32_t ls_ = lg < logS ? lg : logS;
+        seff = 1u << ls_;
+        seglen = (cs + seff - 1u) >> ls_;
+    }
+    if (!owner) aoff = src_off[0] & ~(uint64_t)127; /* a lane past the end of the batch re-reads block 0 */
+    const bool walker = owner && sw < seff;
+    const uint32_t gstart = delta + sw * seglen;                                    /* guessed (walker 0: true) start */
+    uint32_t stop = (walker && sw + 1u < seff) ? delta + (sw + 1u) * seglen : vend; /* first position of the next segment */
+    uint16_t *const rowbase = tbl + blk * cap;
+    uint16_t *row = rowbase + sw * cap_s + ext;           /* this walker's own records */
+    uint16_t *const dummy = dummy_base + lane * 16u;      /* 32 bytes per lane behind the rows: where lanes with nothing to store store */
+    uint32_t kcap = cap_main;
+    uint32_t pos = gstart;                /* next byte to interpret */
+    uint32_t requested = gstart & ~(kIdxChunk - 1u); /* chunks requested up to here (multiple of kIdxChunk) */
+    uint32_t filled = requested;          /* chunks stored in the ring up to here */
+    uint32_t outst = 0, drop = 0;         /* chunks of this lane on their way; how many of them a restart of the ring disowned */
+    uint32_t state = 0;                   /* 0 token, 1 literal-length extension, 2 match-length extension */
+    uint32_t acc = 0, tm = 0;             /* literal length being accumulated; match nibble of the current token */
+    uint32_t k = 0, ls = 0;               /* positions recorded; 16-entry lines of them stored */
+    uint16_t *pbuf = s_pos[lane];
+    bool done = !walker || vend == delta;
+
+    /* what this lane serves in turn j: one 16-byte piece of the next chunk of walkers 16j + (lane >> 3) and
+     * 16j + 8 + (lane >> 3) (two loads per turn: every walker has a turn every fourth hop) */
+    const uint32_t piece16 = (lane & 7u) * 16u;
+#define IDX_SRC(j) const uint64_t saoff##j = ((uint64_t)bperm((uint32_t)(aoff >> 32), 8u * j + (lane >> 3)) << 32) | bperm((uint32_t)aoff, 8u * j + (lane >> 3)); \
+                   const uint32_t svend##j = bperm(vend, 8u * j + (lane >> 3));
+    IDX_SRC(0) IDX_SRC(1) IDX_SRC(2) IDX_SRC(3) IDX_SRC(4) IDX_SRC(5) IDX_SRC(6) IDX_SRC(7)
+#undef IDX_SRC
+    const uint32_t rb = lane * kIdxStride; /* this lane's ring inside s_ring */
+
+    /* chunks on their way: two per turn, committed TWO rounds later (a lane with room in its ring requests one chunk
+     * per round, up to two outstanding; four rounds of distance bought nothing and its 32 slots spilled registers).
+     * Separate variables, not arrays: the compiler kept an indexed array in scratch memory. */
+#define IDX_SLOT(n) uint4 fd##n = make_uint4(0, 0, 0, 0), fe##n = fd##n; uint32_t fa##n = 0, fb##n = 0; bool fp##n = false, fq##n = false, fo##n = false;
+    IDX_SLOT(0) IDX_SLOT(1) IDX_SLOT(2) IDX_SLOT(3) IDX_SLOT(4) IDX_SLOT(5) IDX_SLOT(6) IDX_SLOT(7)
+#undef IDX_SLOT
+
+    auto turn = [&](const uint32_t j, uint4 &fd, uint4 &fe, uint32_t &fa, uint32_t &fb, bool &fp, bool &fq, bool &fpo,
+                    const uint64_t soff, const uint32_t sve, const uint64_t soff2, const uint32_t sve2) __attribute__((always_inline)) {
+        const bool myturn = (lane >> 4) == j; /* lanes 16j..16j+15 */
+        /* ---- commit the chunks requested two rounds ago ---- */
+        if (fp) *reinterpret_cast<uint4 *>(s_ring + fa) = fd;
+        if (fq) *reinterpret_cast<uint4 *>(s_ring + fb) = fe;
+        if (myturn && outst != 0u && fpo) { /* fpo: this lane did request in the turn being committed */
+            outst--;
+            if (drop != 0u) drop--; else filled += kIdxChunk;
+        }
+        /* the hop's ring reads go out before the exchange below: one LDS round trip per turn, not two */
+        const uint32_t w0 = *reinterpret_cast<const uint32_t *>(s_ring + rb + (pos & (kIdxRing - 4u)));
+        const uint32_t w1 = *reinterpret_cast<const uint32_t *>(s_ring + rb + ((pos + 4u) & (kIdxRing - 4u)));
+        const uint32_t w2 = *reinterpret_cast<const uint32_t *>(s_ring + rb + ((pos + 8u) & (kIdxRing - 4u)));
+        /* ---- request the next chunk of walkers 16j..16j+15 (one bpermute each: requested | want) ---- */
+        {
+            const bool want = myturn && !done && requested < vend && pos + (kIdxRing - kIdxChunk) >= requested;
+            const uint32_t msg = requested | (want ? 1u : 0u);
+            fpo = want;
+            if (want) { requested += kIdxChunk; outst++; }
+            const uint32_t s1 = 16u * j + (lane >> 3), s2 = s1 + 8u;
+            const uint32_t m1 = bperm(msg, s1), m2 = bperm(msg, s2);
+            const uint32_t o1 = (m1 & ~1u) + piece16, o2 = (m2 & ~1u) + piece16;
+            fp = (m1 & 1u) != 0u;
+            fq = (m2 & 1u) != 0u;
+            fa = s1 * kIdxStride + (o1 & (kIdxRing - 1u));
+            fb = s2 * kIdxStride + (o2 & (kIdxRing - 1u));
+            /* always two loads per turn (a lane with nothing to fetch re-reads its stream's first 16 bytes): with a
+             * fixed number of vector-memory operations per turn the compiler can wait for exactly the chunks it
+             * commits (vmcnt(N)); a conditional load made it drain the queue once per round (2.3 us a round) */
+            fd = *reinterpret_cast<const uint4 *>(src_base + (soff + ((fp && o1 < sve) ? o1 : 0u)));
+            fe = *reinterpret_cast<const uint4 *>(src_base + (soff2 + ((fq && o2 < sve2) ? o2 : 0u)));
+        }
+        /* ---- one hop, branch-free for the two common states (token, match-length extension) ---- */
+        {
+            /* a walker ends at the first TOKEN position at or behind `stop` (the end of its segment; the stream's end
+             * for a block's last walker) */
+            const bool live = !done && pos < vend && (pos < stop || state != 0u);
+            const bool canread = pos < requested && (pos + 8u <= filled || filled >= vend);
+            const uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, pos & 3u);
+            const bool go = live && canread && state != 1u;
+            /* token */
+            const uint32_t ll = (x >> 4) & 15u, e1 = (x >> 8) & 255u, tmn = x & 15u;
+            const bool l15 = ll == 15u;
+            const uint32_t q2 = pos + 3u + ll + (l15 ? e1 + 1u : 0u);  /* behind the literals and the offset */
+            const bool tok = go && state == 0u;
+            const bool longlit = tok && l15 && e1 == 255u;            /* 255-run: slow path below */
+            /* match-length extension bytes */
+            const uint32_t nx = ~x;
+            const uint32_t n = nx ? (uint32_t)__builtin_ctz(nx) >> 3 : 4u; /* leading 0xFF bytes */
+            const uint32_t adv = n == 4u ? 4u : n + 1u;
+            const bool extb = go && state == 2u;
+            /* record + advance */
+            const bool rec = tok;
+            pbuf[rec ? (k & 31u) : 32u] = (uint16_t)(pos - delta); /* unconditional: a store in a branch costs more than the branch saves */
+            if (rec) { k++; tm = tmn; }
+            const bool fin = tok && !longlit && q2 > vend;              /* last sequence: literals only */
+            if (tok && !longlit && !fin) { pos = q2; state = tmn == 15u ? 2u : 0u; }
+            /* a second token in the same turn when the first one leaves it inside the eight bytes just read: no or
+             * up to two literals and a short match (half of the sequences of tuple data) */
+            {
+                const bool dbl = tok && !longlit && !fin && !l15 && tmn != 15u && ll <= 2u && q2 < stop && k < kcap;
+                const uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, (q2 - 3u - ll) & 3u); /* bytes 4..7 behind the first token */
+                const unsigned long long xx = ((unsigned long long)x1 << 32) | x;
+                const uint32_t y = (uint32_t)(xx >> (8u * (3u + ll)));
+                const uint32_t llb = (y >> 4) & 15u, e1b = (y >> 8) & 255u, tmb = y & 15u;
+                const bool l15b = llb == 15u;
+                const uint32_t q2b = q2 + 3u + llb + (l15b ? e1b + 1u : 0u);
+                const bool rec2 = dbl && !(l15b && e1b == 255u);
+                pbuf[rec2 ? (k & 31u) : 32u] = (uint16_t)(q2 - delta);
+                if (rec2) {
+                    k++;
+                    tm = tmb;
+                    if (q2b > vend) done = true;
+                    else { pos = q2b; state = tmb == 15u ? 2u : 0u; }
+                }
+            }
+            if (extb) { pos += adv; state = n == 4u ? 2u : 0u; }
+            if (longlit) { state = 1u; acc = 15u + 255u; pos += 2u; }
+            if (fin || (!done && !live) || k >= kcap) done = true;
+            /* rare: literal-length 255-runs, and jumps over everything requested (a long literal run) */
+            const bool slow = !done && (state == 1u || pos >= requested) && !longlit;
+            if (__any(slow)) {
+                if (slow && pos < vend) {
+                    if (pos >= requested) {
+                        /* restart the ring at the chunk of pos; a chunk still in flight lands in a slot that is
+                         * rewritten before it is read */
+                        requested = filled = pos & ~(kIdxChunk - 1u);
+                        drop = outst;
+                    } else if (state == 1u && live && canread) {
+                        if (n == 4u) { acc += 1020u; pos += 4u; if (acc >= vend) done = true; }
+                        else {
+                            acc += 255u * n + ((x >> (8u * n)) & 255u);
+                            const uint32_t q = pos + n + 1u + acc;
+                            if (acc >= vend || q + 2u > vend) done = true;
+                            else { pos = q + 2u; state = tm == 15u ? 2u : 0u; }
+                        }
+                    }
+                }
+            }
+        }
+    };
+
+    /* Positions go out in whole 32-byte lines of 16, each line stored ONCE, when it is complete (a lane gains at most
+     * eight positions per round, so one line per round keeps up; the line being filled meanwhile is the other half of
+     * pbuf).  Round 2 stored aligned groups of four, three per round, again and again while they filled: 3.47 GB
+     * reached memory for a 0.83 GB index -- the L2 does not hold 65 536 rows' open lines until they are full.  One
+     * unconditional pair of stores per round (a lane with nothing to store writes its dummy slot), see the note on
+     * the loads.  A macro, not a lambda: captured by a lambda, the packs lived in scratch memory. */
+#define IDX_PUT()                                                                                            \
+    {                                                                                                        \
+        const bool st_ = ls < (k >> 4);                                                                      \
+        const uint16_t *ps_ = pbuf + ((ls & 1u) << 4);                                                       \
+        const uint4 v0_ = *reinterpret_cast<const uint4 *>(ps_), v1_ = *reinterpret_cast<const uint4 *>(ps_ + 8); \
+        uint16_t *pd_ = st_ ? row + (ls << 4) : dummy;                                                       \
+        *reinterpret_cast<uint4 *>(pd_) = v0_;                                                               \
+        *reinterpret_cast<uint4 *>(pd_ + 8) = v1_;                                                           \
+        if (st_) ls++;                                                                                       \
+    }
+    /* what is left when a walk ends: at most one complete line and the one being filled (stored whole: the entries
+     * behind the count are never read, and a row's capacity is a multiple of 16) */
+#define IDX_FLUSH()                                                                                          \
+    {                                                                                                        \
+        IDX_PUT()                                                                                            \
+        IDX_PUT()                                                                                            \
+        if ((k & 15u) != 0u && ls == (k >> 4)) {                                                             \
+            const uint16_t *ps_ = pbuf + ((ls & 1u) << 4);                                                   \
+            const uint4 v0_ = *reinterpret_cast<const uint4 *>(ps_), v1_ = *reinterpret_cast<const uint4 *>(ps_ + 8); \
+            uint16_t *pd_ = row + (ls << 4);                                                                 \
+            *reinterpret_cast<uint4 *>(pd_) = v0_;                                                           \
+            *reinterpret_cast<uint4 *>(pd_ + 8) = v1_;                                                       \
+        }                                                                                                    \
+    }
+#define IDX_TURN(j, n, sa, sb) turn(j, fd##n, fe##n, fa##n, fb##n, fp##n, fq##n, fo##n, saoff##sa, svend##sa, saoff##sb, svend##sb);
+#define IDX_ROUND(a, b, c, d)                                   \
+    IDX_PUT()                                                   \
+    IDX_TURN(0, a, 0, 1) IDX_TURN(1, b, 2, 3) IDX_TURN(2, c, 4, 5) IDX_TURN(3, d, 6, 7)
+#define IDX_WALK()                                              \
+    while (__any(!done)) {                                      \
+        IDX_ROUND(0, 1, 2, 3)                                   \
+        IDX_ROUND(4, 5, 6, 7)                                   \
+    }                                                           \
+    if (walker) IDX_FLUSH()
+
+    /* ---- phase 1: every walker its own segment ---- */
+    IDX_WALK()
+
+    uint32_t d_ext = 0, d_skip = 0, d_cnt = walker ? k : 0u; /* this segment's descriptor */
+    if (logS != 0u) {
+        /* ---- phase 2: walker s goes on into segment s+1 until it meets a position walker s+1 recorded ---- */
+        const bool inner = walker && sw + 1u < seff;
+        /* an inner walker that did not end on a token behind its segment (its records overflowed, or the stream is
+         * cut) cannot hand over */
+        bool fail = inner && !(pos >= stop && pos < vend && state == 0u && k < kcap);
+        __threadfence(); /* the neighbour's records are read back from memory */
+        const uint32_t k_n = from_next(k), e_n = from_next(pos), stop_n = from_next(stop);
+        const uint16_t *nrec = row + cap_s;          /* walker s+1's records    */
+        uint16_t *next_ext = row + cap_s - ext;      /* segment s+1's extension */
+        const uint8_t *sb = src_base + aoff;
+        uint32_t p = pos, r = stop, j = 0, L = 0;
+        bool merging = inner && !fail;
+        while (__any(merging)) {
+            if (merging) {
+                if (p == r) merging = false;
+                else if (p < r) {
+                    if (L >= ext || p >= stop_n || p >= vend) { fail = true; merging = false; }
+                    else {
+                        next_ext[L++] = (uint16_t)(p - delta);
+                        p = lz4_next_token_direct(sb, vend, p);
+                    }
+                } else {
+                    j++;
+                    if (j < k_n) {
+                        const uint32_t e16 = __builtin_nontemporal_load(nrec + j);
+                        r += (e16 + delta - r) & 0xffffu; /* records are increasing, less than 64 KiB apart */
+                    } else if (j == k_n) r = e_n;         /* behind its last record walker s+1 stands on e_n */
+                    else { fail = true; merging = false; }
+                }
+            }
+        }
+        /* the descriptor of segment s comes from the lane on its left */
+        const uint32_t mine = fail ? 0xffffffffu : ((inner ? L : 0u) | ((inner ? j : 0u) << 16));
+        const uint32_t left = from_prev(mine);
+        const unsigned long long fm = __ballot(fail);
+        const unsigned long long gmask = (logS >= 6u ? ~0ull : ((1ull << S) - 1ull)) << (lane & ~(S - 1u));
+        const bool gfail = (fm & gmask) != 0ull;
+        if (!gfail) {
+            if (walker && sw != 0u) { d_ext = left & 0xffffu; d_skip = left >> 16; d_cnt = k - d_skip; }
+        } else {
+            /* ---- phase 3: the chains of this block did not meet: its first lane walks all of it ---- */
+            d_cnt = 0;
+        }
+        if (__any(gfail)) {
+            const bool redo = gfail && walker && sw == 0u;
+            pos = delta;
+            requested = filled = 0;
+            drop = outst;
+            state = 0; acc = 0; tm = 0; k = 0; ls = 0;
+            stop = vend;
+            kcap = S * cap_s - ext;
+            done = !redo || vend == delta;
+            {
+                const bool walker = redo; /* who flushes */
+                IDX_WALK()
+            }
+            if (redo) d_cnt = k;
+        }
+    }
+#undef IDX_WALK
+#undef IDX_ROUND
+#undef IDX_TURN
+#undef IDX_FLUSH
+#undef IDX_PUT
+    if (owner) seg[gl] = make_uint2(d_ext | (d_skip << 16), d_cnt);
+}
+
+/* ---- layout and launcher ---- */
+Lz4IndexLayout lz4_index_layout(uint64_t n_blocks, uint32_t block_size, uint32_t walkers)
+{
+    Lz4IndexLayout L;
+    uint32_t lg = 0;
+    while ((2u << lg) <= walkers && lg < 6u) lg++;
+    L.logS = lg;
+    const uint32_t S = 1u << lg;
+    /* a block of B bytes holds at most B/8 + 64 sequences the decoder's batches can use (the rest is decoded without
+     * hints); a segment is 1/S of the compressed bytes, not of the sequences: a quarter more */
+    L.ext = S > 1u ? 512u : 0u;
+    const uint32_t per = (block_size / 8u + 64u + S - 1u) / S;
+    L.cap_main = S > 1u ? ((per + per / 4u + 63u) & ~63u) : per;
+    /* rows 2 KiB-granular: the pass writes 64 rows at once and is sensitive to the row stride (33 024-byte rows always
+     * ran 17 % slower, 34 816 never: profiles/scripts/r02_cap.sh) */
+    L.cap = (S * (L.cap_main + L.ext) + 1023u) & ~1023u;
+    if (S == 1u) L.cap_main = L.cap;
+    const size_t tbl_bytes = (size_t)n_blocks * L.cap * 2u;
+    L.dummy_off = tbl_bytes;
+    L.seg_off = (tbl_bytes + 64u * 32u + 255u) & ~(size_t)255u;
+    const uint64_t lanes = ((n_blocks << lg) + 63u) & ~(uint64_t)63u;
+    L.bytes = L.seg_off + (size_t)lanes * sizeof(uint2) + 256u;
+    return L;
+}
+
+hipError_t launch_lz4_index(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
+                            uint64_t n_blocks, void *d_workspace, const Lz4IndexLayout &L)
+{
+    if (n_blocks == 0) return hipSuccess;
+    const uint64_t grid = ((n_blocks << L.logS) + kIdxLanes - 1) / kIdxLanes;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    uint8_t *ws = static_cast<uint8_t *>(d_workspace);
+    hipLaunchKernelGGL(k_lz4_index, dim3((uint32_t)grid), dim3(64), 0, s, d_src, d_src_off, d_src_size, n_blocks,
+                       reinterpret_cast<uint16_t *>(ws), L.logS, L.cap_main, L.ext, L.cap, reinterpret_cast<uint2 *>(ws + L.seg_off),
+                       reinterpret_cast<uint16_t *>(ws + L.dummy_off));
+    return hipGetLastError();
+}
+
+} // namespace cryo

@@ -37,15 +37,23 @@ class HeapTupleData(C.Structure):
     _fields_ = [("t_len", C.c_uint32), ("t_data", C.c_void_p)]
 
 
-_lib = None
+_libs = {}
+_production = None   # None: by the environment (CRYO_HOST_TEST_HOOKS=1 selects the test build)
+
+
+def use(production):
+    """Select which build lib() returns from now on: the shipped libcryo_host.so (True), the build with the
+    codec-double hook for CPU-only plumbing tests (False), or by the environment (None)."""
+    global _production
+    _production = production
 
 
 def lib():
-    global _lib
-    if _lib is not None:
-        return _lib
+    prod = _production if _production is not None else os.environ.get("CRYO_HOST_TEST_HOOKS") != "1"
+    if prod in _libs:
+        return _libs[prod]
     _loader.load()  # libcryo_codec.so + one HIP runtime first
-    path = HOST_TEST_LIB_PATH if os.environ.get("CRYO_HOST_TEST_HOOKS") == "1" else HOST_LIB_PATH
+    path = HOST_LIB_PATH if prod else HOST_TEST_LIB_PATH
     if not os.path.exists(path):
         raise ImportError("pg_cryogen_amd: %s is missing; build with `make -C pg_cryogen_amd/host`" % path)
     L = C.CDLL(path)
@@ -117,7 +125,7 @@ def lib():
     L.cryo_cache_err.restype = C.c_char_p
     for n in ("cryo_cache_hits", "cryo_cache_misses", "cryo_cache_codec_calls"):
         getattr(L, n).restype = C.c_uint64
-    _lib = L
+    _libs[prod] = L
     return L
 
 

@@ -86,7 +86,14 @@ static int hip_decompress_blocks(void *ctx, int method, const void *const *src, 
     return cryo_multi_decompress_blocks((cryo_multi *)ctx, method, src, sz, n, dst, bs, st);
 }
 
-static CryoCodecOps hip_ops = {hip_bound, hip_compress_blocks, hip_decompress_blocks, NULL, NULL};
+/* one destination per block: the decompressed-block cache hands its slots over (reference cache.c:46,178) */
+static int hip_decompress_blocks_scatter(void *ctx, int method, const void *const *src, const uint32_t *sz, size_t n,
+                                         void *const *dst, size_t bs, int32_t *st)
+{
+    return cryo_multi_decompress_blocks_to((cryo_multi *)ctx, method, src, sz, n, dst, bs, st);
+}
+
+static CryoCodecOps hip_ops = {hip_bound, hip_compress_blocks, hip_decompress_blocks, NULL, hip_decompress_blocks_scatter};
 static const CryoCodecOps *bound_ops; /* CPU-only plumbing tests bind a double here (CRYO_HOST_TEST_HOOKS builds only) */
 
 #ifdef CRYO_HOST_TEST_HOOKS

@@ -1,5 +1,5 @@
-"""GPU plumbing tests: the C host side (compression.h mirror, staging, cache) driving the real
-HIP codec through the C ABI -- no test double.  Mirrors tests/test_host_plumbing.py."""
+"""GPU plumbing tests: the SHIPPED host library (libcryo_host.so: compression.h mirror, staging, cache) driving the
+real HIP codec through the C ABI -- no test double, no test hook.  Mirrors tests/test_host_plumbing.py."""
 import ctypes as C
 import struct
 
@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture()
 def HG():
+    host.use(production=True)                  # libcryo_host.so: binds libcryo_codec.so on GPU 0, exports no hook
     L = host.lib()
-    L.cryo_host_set_codec_ops(None)            # production binding: libcryo_codec.so on GPU 0
+    assert not hasattr(L, "cryo_host_set_codec_ops")
     errors = []
     handler = host.ERROR_HANDLER(lambda lvl, msg: errors.append((lvl, msg.decode())) if lvl >= 20 else None)
     L.cryo_compat_set_error_handler(handler)
@@ -27,6 +28,7 @@ def HG():
     L.cryo_cache_shutdown()
     L.cryo_compat_set_error_handler(host.ERROR_HANDLER(0))
     host.set_block_size(1 << 20)
+    host.use(production=None)
 
 
 def test_gpu_copy_10k_int4_lz4_roundtrip(HG, oracle):

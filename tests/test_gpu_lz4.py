@@ -305,3 +305,174 @@ def test_lz4_indexed_decoder_large_batch(codec, oracle):
         assert bad > 100
         for x in (d_src, d_off, d_sz, d_dst, d_st):
             x.free()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The indexed decoder (k_lz4_index + k_lz4_dec_seq: the kernels BASELINE configs[1] is measured on) at the block sizes
+# it is measured on.  A per-handle option forces the path whatever the batch size (CRYO_OPT_LZ4_DECODE_PATH) and the
+# number of index walkers per block (CRYO_OPT_LZ4_INDEX_WALKERS): 1 = the headline configuration (one lane per
+# block), 4 / 8 = what mid-sized batches and 1 MiB blocks get, 64 = a handful of blocks.  Every decoded block is
+# compared with the oracle's block, every verdict with the oracle's verdict (reference call shape: compression.c:84).
+# ---------------------------------------------------------------------------------------------------------------
+def _indexed(codec, walkers):
+    from pg_cryogen_amd import codec as cc
+
+    class _Ctx:
+        def __enter__(self_):
+            codec.set_option(cc.OPT_LZ4_DECODE_PATH, cc.LZ4_PATH_INDEXED)
+            codec.set_option(cc.OPT_LZ4_INDEX_WALKERS, walkers)
+
+        def __exit__(self_, *a):
+            codec.set_option(cc.OPT_LZ4_DECODE_PATH, cc.LZ4_PATH_AUTO)
+            codec.set_option(cc.OPT_LZ4_INDEX_WALKERS, 0)
+    return _Ctx()
+
+
+def _decode_check(codec, comps, expect, B, tag):
+    """comps decoded as one device batch; expect[i] = the oracle's block, or None for 'must be rejected'"""
+    outs, st = codec.decompress_blocks(METHOD_LZ4, comps, B)
+    for i, e in enumerate(expect):
+        if e is None:
+            assert st[i] != 0, (tag, i)
+        else:
+            assert st[i] == 0, (tag, i, int(st[i]))
+            assert np.array_equal(outs[i], e), (tag, i)
+
+
+WALKERS = [1, 4, 64]
+
+
+@pytest.mark.parametrize("B", [131072, 1 << 20])
+@pytest.mark.parametrize("walkers", WALKERS)
+def test_indexed_decoder_distributions_at_headline_sizes(codec, oracle, B, walkers):
+    """all five synthetic distributions x accelerations 1, 7, 50 (configs[1] is `wide` at acceleration 1)"""
+    blocks, comps = [], []
+    for dist in range(5):
+        for accel in (1, 7, 50):
+            for blk in range(2 if B == 131072 else 1):
+                b = oracle.synth(17, 100 * dist + blk, B, dist)
+                blocks.append(b)
+                comps.append(oracle.lz4_compress(b, accel))
+    with _indexed(codec, walkers):
+        _decode_check(codec, comps, blocks, B, ("dist", B, walkers))
+
+
+@pytest.mark.parametrize("walkers", WALKERS)
+def test_indexed_decoder_golden_cells(codec, oracle, walkers):
+    """tests/golden/vectors.json, LZ4 cells at 128 KiB and 1 MiB: streams of liblz4 1.9.3 (hash-pinned: the oracle's
+    bytes hash to comp_sha256) decoded by the indexed path hash to raw_sha256"""
+    import hashlib
+    import json
+    import os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    cells = [c for c in json.load(open(os.path.join(G, "vectors.json")))["cells"]
+             if c["method"] == "lz4" and c["B"] in (131072, 1 << 20)]
+    assert len(cells) >= 100
+    with _indexed(codec, walkers):
+        for B in (131072, 1 << 20):
+            sub = [c for c in cells if c["B"] == B]
+            if walkers != 1:
+                sub = sub[::3]
+            comps = []
+            for c in sub:
+                k = oracle.lz4_compress(oracle.synth(0, c["block"], B, c["dist"]), c["param"])
+                assert len(k) == c["csize"] and sha(k) == c["comp_sha256"], c
+                comps.append(k)
+            outs, st = codec.decompress_blocks(METHOD_LZ4, comps, B)
+            assert (st == 0).all()
+            for c, o in zip(sub, outs):
+                assert sha(o) == c["raw_sha256"], (c, walkers)
+
+
+@pytest.mark.parametrize("walkers", WALKERS)
+def test_indexed_decoder_structured_and_stock_streams(codec, oracle, walkers):
+    """structured random blocks (tests/stress_gpu.py: repeats at any distance, runs, word mixtures, noise, short
+    periods) of 128 KiB ... 1 MiB, compressed by the STOCK liblz4 where it can be loaded (else by the oracle, which
+    is pinned to it): positions that wrap 16 bits, far matches against the 4 KiB ring, long runs, periodic data on
+    which index walkers started at guessed positions never meet the true chain (the serial re-walk)"""
+    import oracle_lib
+    from stress_gpu import make_block
+    stock = oracle_lib.StockLibs()
+    comp = stock.lz4_compress if stock.lz4 is not None else oracle.lz4_compress
+    rng = np.random.default_rng(1234 + walkers)
+    for B in (131072, 400000, 1 << 20):
+        blocks = [make_block(rng, B) for _ in range(6)]
+        # strictly periodic text: every guessed start lands in the same phase of the period
+        blocks.append(np.resize(np.frombuffer(b"0123456789abcdefghijklmnopqrstu;", np.uint8), B).copy())
+        t = np.resize(np.frombuffer(b"\x10\x10\x10\x10\x10\x10\x10A", np.uint8), B).copy()
+        t[::4099] = rng.integers(0, 256, len(t[::4099]), dtype=np.uint8)
+        blocks.append(t)
+        blocks.append(rng.integers(0, 256, B, dtype=np.uint8))                     # one literal run
+        z = np.zeros(B, np.uint8); z[B // 2] = 7
+        blocks.append(z)                                                             # two long matches
+        comps = [comp(b, int(rng.integers(1, 9))) for b in blocks]
+        with _indexed(codec, walkers):
+            _decode_check(codec, comps, blocks, B, ("structured", B, walkers))
+
+
+@pytest.mark.parametrize("B", [131072, 1 << 20])
+@pytest.mark.parametrize("walkers", WALKERS)
+def test_indexed_decoder_mutated_streams(codec, oracle, B, walkers):
+    """corrupted 128 KiB / 1 MiB streams: verdict and bytes as the oracle's (success iff liblz4 decodes exactly B bytes)"""
+    from stress_gpu import mutate
+    rng = np.random.default_rng(77 + walkers)
+    comps, expect = [], []
+    base = [oracle.lz4_compress(oracle.synth(9, d, B, d), 1 + 6 * (d & 1)) for d in (0, 1, 2, 3)]
+    n_mut = 60 if B == 131072 else 16
+    for it in range(n_mut):
+        m = mutate(rng, base[it % len(base)])
+        r, out = oracle.lz4_decompress(m, B, fill=0xA5)
+        comps.append(m)
+        expect.append(out.copy() if r == B else None)
+    comps += base
+    expect += [oracle.synth(9, d, B, d) for d in (0, 1, 2, 3)]
+    with _indexed(codec, walkers):
+        _decode_check(codec, comps, expect, B, ("mutated", B, walkers))
+    assert sum(e is None for e in expect) >= n_mut // 4
+
+
+def test_indexed_decoder_packed_offsets_and_ragged_batch(codec, oracle):
+    """streams packed at arbitrary byte offsets (the index stages whole 128-byte lines), a batch that is not a multiple
+    of the walkers' wave width, empty streams among them; walkers 8 as the 1 MiB configuration of 8192 blocks gets"""
+    from pg_cryogen_amd import codec as cc
+    B = 131072
+    blocks = [oracle.synth(23, i, B, i % 5) for i in range(11)]
+    comps = [oracle.lz4_compress(b, 1) for b in blocks] + [np.zeros(0, np.uint8)]
+    n = len(comps)
+    offs, pos = [], 77
+    for c in comps:
+        offs.append(pos)
+        pos += len(c) + 1 + (len(c) % 13)
+    packed = np.full(pos + 64, 0xEE, np.uint8)
+    for o, c in zip(offs, comps):
+        packed[o:o + len(c)] = c
+    d_src, d_off, d_sz = codec.alloc(packed.nbytes), codec.alloc(8 * n), codec.alloc(4 * n)
+    d_dst, d_st = codec.alloc(n * B), codec.alloc(4 * n)
+    d_src.upload(packed)
+    d_off.upload(np.array(offs, np.uint64))
+    d_sz.upload(np.array([len(c) for c in comps], np.uint32))
+    for walkers in (1, 2, 8, 32):
+        d_dst.memset(0x5A)
+        with _indexed(codec, walkers):
+            codec.decompress_batch(METHOD_LZ4, d_src, d_off, d_sz, d_dst, B, B, n, d_st)
+            codec.sync()
+        st = d_st.download(dtype=np.int32)
+        raw = d_dst.download().reshape(n, B)
+        for i, b in enumerate(blocks):
+            assert st[i] == 0 and np.array_equal(raw[i], b), (walkers, i)
+        assert st[n - 1] != 0
+    for x in (d_src, d_off, d_sz, d_dst, d_st):
+        x.free()
+
+
+def test_lz4_path_options_roundtrip(codec):
+    from pg_cryogen_amd import codec as cc
+    assert codec.get_option(cc.OPT_LZ4_DECODE_PATH) == 0 and codec.get_option(cc.OPT_LZ4_INDEX_WALKERS) == 0
+    codec.set_option(cc.OPT_LZ4_INDEX_WALKERS, 16)
+    assert codec.get_option(cc.OPT_LZ4_INDEX_WALKERS) == 16
+    codec.set_option(cc.OPT_LZ4_INDEX_WALKERS, 0)
+    with pytest.raises(cc.CryoError):
+        codec.set_option(cc.OPT_LZ4_INDEX_WALKERS, 3)        # not a power of two
+    with pytest.raises(cc.CryoError):
+        codec.set_option(cc.OPT_LZ4_DECODE_PATH, 9)
