@@ -55,6 +55,7 @@ def parse_args():
     ap.add_argument("--level", type=int, default=1, help="zstd level")
     ap.add_argument("--lz4-path", type=int, default=0, help="diagnostic: CRYO_OPT_LZ4_DECODE_PATH (0 auto, 1 in-wave parse, 2 indexed)")
     ap.add_argument("--lz4-walkers", type=int, default=0, help="diagnostic: CRYO_OPT_LZ4_INDEX_WALKERS (0 auto)")
+    ap.add_argument("--lz4-tiles", type=int, default=0, help="diagnostic: CRYO_OPT_LZ4_TILES (0 auto)")
     return ap.parse_args()
 
 
@@ -84,14 +85,32 @@ def self_launch(a):
 # ------------------------------------------------------------------------------------------------
 # cpu_baseline: the library the reference links, on this machine's host cores
 # ------------------------------------------------------------------------------------------------
+def physical_cores():
+    """One CPU number per physical core this process may run on (all PHYSICAL cores, pinned): the first
+    hardware thread of every distinct sibling set in sysfs, restricted to the process's affinity mask."""
+    allowed = sorted(os.sched_getaffinity(0))
+    seen, cores = set(), []
+    for c in allowed:
+        try:
+            with open("/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % c) as f:
+                sib = f.read().strip()
+        except OSError:
+            sib = str(c)
+        if sib not in seen:
+            seen.add(sib)
+            cores.append(c)
+    return cores or allowed
+
+
 def cpu_baseline(ora, np, method, encode, param, blobs, sizes, B, reps=5):
     """One pass over the sample's distinct blocks, median of `reps`: stock liblz4 / libzstd called
-    exactly as reference compression.c:70-72,84,102-104,116 calls them, 1 thread (`value`) and all hardware threads
-    (`all_cores_value`); the oracle port's 1-thread rate beside it."""
+    exactly as reference compression.c:70-72,84,102-104,116 calls them, on 1 pinned thread (`value`) and on one pinned
+    thread per physical core (`all_cores_value`, `cores_used`); the oracle port's 1-thread rate beside it."""
     fn = ora.L.cryo_oracle_cpu_pass_bench
     fn.restype = ctypes.c_double
     fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                   ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+                   ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_char_p,
+                   ctypes.c_size_t]
     n = len(sizes)
     offs = np.zeros(n, np.uint64)
     pos = 0
@@ -104,10 +123,13 @@ def cpu_baseline(ora, np, method, encode, param, blobs, sizes, B, reps=5):
     sz = np.asarray(sizes, np.uint32)
     ver = ctypes.create_string_buffer(64)
 
+    cores = physical_cores()
+    pins = (ctypes.c_int * len(cores))(*cores)
+
     def run(stock, threads, r):
-        return fn(method, 1 if encode else 0, stock, param, packed.ctypes.data, offs.ctypes.data, sz.ctypes.data, n, B, threads, r,
-                  None, ver, 64)
-    T = os.cpu_count() or 1
+        return fn(method, 1 if encode else 0, stock, param, packed.ctypes.data, offs.ctypes.data, sz.ctypes.data, n, B, threads,
+                  pins, r, None, ver, 64)
+    T = len(cores)
     lib = "liblz4" if method == 0 else "libzstd"
     call = {(0, False): "LZ4_decompress_safe(src,dst,csize,B)", (0, True): "LZ4_compress_fast(src,dst,B,bound,accel)",
             (1, False): "ZSTD_decompress(dst,B,src,csize)", (1, True): "ZSTD_compress(dst,bound,src,B,level)"}[(method, encode)]
@@ -118,8 +140,9 @@ def cpu_baseline(ora, np, method, encode, param, blobs, sizes, B, reps=5):
     if one > 0:
         allc = run(1, T, reps)
         res.update({"value": round(one, 3), "kind": "reference", "library": "%s %s via dlopen (what the reference links, Makefile:5); %s"
-                    % (lib, ver.value.decode(), call), "all_cores_value": round(allc, 3), "threads": T,
-                    "port_value": round(port, 3)})
+                    % (lib, ver.value.decode(), call), "all_cores_value": round(allc, 3), "threads": T, "cores_used": T,
+                    "pinning": "one thread per physical core (first hardware thread of each sibling set), pthread_setaffinity_np",
+                    "hardware_threads": os.cpu_count(), "port_value": round(port, 3)})
     else:   # the stock library is not on this machine: the restatement is all there is
         res.update({"value": round(port, 3), "kind": "port", "library": "oracle/ restatement (stock %s not loadable here)" % lib})
     return res
@@ -177,10 +200,11 @@ def main():
     B, n = a.block_size, a.blocks
     dist_id = DIST_NAMES.index(a.dist)
     codec = Codec(dev)
-    if a.lz4_path or a.lz4_walkers:
+    if a.lz4_path or a.lz4_walkers or a.lz4_tiles:
         from pg_cryogen_amd import codec as cc
         codec.set_option(cc.OPT_LZ4_DECODE_PATH, a.lz4_path)
         codec.set_option(cc.OPT_LZ4_INDEX_WALKERS, a.lz4_walkers)
+        codec.set_option(cc.OPT_LZ4_TILES, a.lz4_tiles)
     ora = oracle_lib.Oracle()
     job_block = lambda k: rank + k * world   # block i of the job lives on rank i mod N (pg_cryogen_amd/shard.py)
     want_cpu = world == 1 and not a.no_cpu_baseline

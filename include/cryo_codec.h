@@ -73,7 +73,10 @@ typedef enum {
     /* K-block host calls: minimum bytes of a call that is cut into pipelined chunks (default 64 MiB) */
     CRYO_OPT_PIPE_MIN_BYTES = 3,
     /* device-resident block pool (cryo_pool_*): capacity in bytes (0 = pool off, the default) */
-    CRYO_OPT_POOL_BYTES = 4
+    CRYO_OPT_POOL_BYTES = 4,
+    /* indexed LZ4 decode: tiles a large batch is cut into, the index pass of each on a side stream beside the decoder
+     * of the tile before (0 = automatic, 1 = one index pass then one decoder launch, up to 16) */
+    CRYO_OPT_LZ4_TILES = 5
 } cryo_option;
 int cryo_codec_set_option(cryo_codec *c, int option, int64_t value);
 int cryo_codec_get_option(const cryo_codec *c, int option, int64_t *value);
@@ -171,6 +174,26 @@ int cryo_codec_decompress_blocks_to(cryo_codec *c, int method,
                                     const void *const *h_src, const uint32_t *h_src_size, size_t n_blocks,
                                     void *const *h_dst, size_t block_size, int32_t *h_status);
 
+/* ---- device-resident block pool ("optional device-resident compressed/decompressed pool so
+ *      repeated scans skip PCIe"; the reference's cache is host-only: cache.c:17-50).
+ *      With CRYO_OPT_POOL_BYTES > 0 the decoded blocks of keyed calls stay in HBM (first in, first out).  A key is the
+ *      caller's identity of a block -- the host cache passes (relation oid << 32 | first block number), the key of
+ *      reference cache.c:37-47 -- and 0 means "do not keep".  A block found in the pool with the same compressed size and
+ *      fingerprint (first, middle and last 8 bytes of the stream) is copied back from HBM: nothing travels towards the
+ *      device and no kernel decodes it.  A relation that is rewritten or truncated must be dropped with
+ *      cryo_codec_pool_invalidate (reference: the relcache callback, pg_cryogen.c:163-167). ---- */
+int cryo_codec_decompress_blocks_keyed(cryo_codec *c, int method, const uint64_t *keys,
+                                       const void *const *h_src, const uint32_t *h_src_size, size_t n_blocks,
+                                       void *const *h_dst, size_t block_size, int32_t *h_status);
+/* drop the entries whose key's upper 32 bits equal key_hi; all entries when all_entries != 0 */
+int cryo_codec_pool_invalidate(cryo_codec *c, uint32_t key_hi, int all_entries);
+typedef struct {
+    uint64_t h2d_bytes, d2h_bytes;       /* bytes the host-buffer calls moved across PCIe, each direction */
+    uint64_t pool_hits, pool_misses;     /* keyed blocks served from HBM / decoded                       */
+    uint64_t pool_blocks, pool_capacity; /* blocks held now / slots                                      */
+} cryo_codec_transfer_counters;
+int cryo_codec_get_transfer_counters(const cryo_codec *c, cryo_codec_transfer_counters *out);
+
 /* ---- several GPUs behind one call: the dispatcher of BASELINE's "independent cryo blocks from a COPY multi_insert
  *      or a seq-scan shard embarrassingly across the 8 GPUs of one node (round-robin dispatch, no collective)".
  *      One codec handle per listed device (a device may be listed more than once), block i of a call goes to
@@ -193,6 +216,14 @@ int cryo_multi_decompress_blocks(cryo_multi *m, int method,
 int cryo_multi_decompress_blocks_to(cryo_multi *m, int method,
                                     const void *const *h_src, const uint32_t *h_src_size, size_t n_blocks,
                                     void *const *h_dst, size_t block_size, int32_t *h_status);
+/* keyed (pool) variant: a keyed block goes to handle (key mod G), so that it finds its pool entry again; options and
+ * invalidation reach every handle; the counters are summed */
+int cryo_multi_decompress_blocks_keyed(cryo_multi *m, int method, const uint64_t *keys,
+                                       const void *const *h_src, const uint32_t *h_src_size, size_t n_blocks,
+                                       void *const *h_dst, size_t block_size, int32_t *h_status);
+int cryo_multi_set_option(cryo_multi *m, int option, int64_t value);
+int cryo_multi_pool_invalidate(cryo_multi *m, uint32_t key_hi, int all_entries);
+int cryo_multi_get_transfer_counters(const cryo_multi *m, cryo_codec_transfer_counters *out);
 
 /* ---- batch helpers used by staging, tests and the benchmark ---- */
 

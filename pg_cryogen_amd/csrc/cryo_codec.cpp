@@ -19,6 +19,7 @@
 #include <pthread.h>
 #include <signal.h>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 /* A few host threads kept by a handle (staging copies of the K-block calls) or by the multi-GPU dispatcher (one per
@@ -132,12 +133,25 @@ struct cryo_codec {
     /* side streams of the zstd batch pipeline (created on first use) */
     cryo::ZstdAux aux = {};
     bool have_aux = false;
+    /* side stream of the tiled LZ4 decode (created on first use) */
+    cryo::Lz4Aux lz4_aux = {};
+    bool have_lz4_aux = false;
     /* options (cryo_codec_set_option) */
     cryo::Lz4DecodeOpts lz4_opts = {};
     size_t pipe_min_bytes = (size_t)64 << 20;
     /* staging-copy workers (created by the first K-block call that is large enough to want them) */
     WorkerPool *pool = nullptr;
+    /* device-resident block pool (CRYO_OPT_POOL_BYTES): decoded blocks of keyed calls, first in first out */
+    struct PoolSlot { uint64_t key = 0, fp = 0; uint32_t csize = 0; bool valid = false; };
+    size_t pool_bytes = 0, pool_block = 0;
+    uint8_t *d_pool = nullptr;
+    std::vector<PoolSlot> pool_slots;
+    std::unordered_map<uint64_t, uint32_t> pool_index; /* key -> slot */
+    uint32_t pool_head = 0;                            /* next slot to fill */
+    cryo_codec_transfer_counters xfer_ctr = {};
 };
+
+static void pool_drop(cryo_codec *c);
 
 namespace {
 
@@ -288,6 +302,7 @@ int cryo_codec_open(int device, cryo_codec **out)
     if (const char *e = getenv("CRYO_PIPE_MIN_MB")) c->pipe_min_bytes = (size_t)atoll(e) << 20; /* 0 = always, huge = never */
     if (const char *e = getenv("CRYO_LZ4_DECODE_PATH")) c->lz4_opts.path = atoi(e);             /* tuning aids: the options' */
     if (const char *e = getenv("CRYO_LZ4_INDEX_WALKERS")) c->lz4_opts.walkers = atoi(e);        /* initial values          */
+    if (const char *e = getenv("CRYO_LZ4_TILES")) c->lz4_opts.tiles = atoi(e);
     DevGuard dev_(c); /* the caller's current device is restored on return */
     hipError_t e = hipSuccess;
     if (!dev_.switched && dev_.prev != device) e = hipSetDevice(device); /* no current device yet, or the switch failed: report it */
@@ -311,6 +326,7 @@ void cryo_codec_close(cryo_codec *c)
     DevGuard dev_(c);
     delete c->pool;
     c->pool = nullptr;
+    if (c->d_pool) { if (c->stream) (void)hipStreamSynchronize(c->stream); (void)hipFree(c->d_pool); c->d_pool = nullptr; }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->d_in) (void)hipFree(c->d_in);
     if (c->d_out) (void)hipFree(c->d_out);
@@ -334,6 +350,9 @@ void cryo_codec_close(cryo_codec *c)
         if (c->aux.join[l]) (void)hipEventDestroy(c->aux.join[l]);
     }
     if (c->aux.fork) (void)hipEventDestroy(c->aux.fork);
+    if (c->lz4_aux.side) { (void)hipStreamSynchronize(c->lz4_aux.side); (void)hipStreamDestroy(c->lz4_aux.side); }
+    if (c->lz4_aux.fork) (void)hipEventDestroy(c->lz4_aux.fork);
+    for (int t = 0; t < cryo::kLz4MaxTiles; t++) if (c->lz4_aux.idx_done[t]) (void)hipEventDestroy(c->lz4_aux.idx_done[t]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -358,6 +377,17 @@ int cryo_codec_set_option(cryo_codec *c, int option, int64_t value)
         if (value < 0) return CRYO_E_ARG;
         c->pipe_min_bytes = (size_t)value;
         return CRYO_OK;
+    case CRYO_OPT_LZ4_TILES:
+        if (value < 0 || value > cryo::kLz4MaxTiles) return CRYO_E_ARG;
+        c->lz4_opts.tiles = (int)value;
+        return CRYO_OK;
+    case CRYO_OPT_POOL_BYTES: {
+        if (value < 0) return CRYO_E_ARG;
+        DevGuard dev_(c);
+        c->pool_bytes = (size_t)value;
+        if (c->pool_bytes == 0 && c->d_pool) pool_drop(c); /* a new size takes effect at the next keyed call */
+        return CRYO_OK;
+    }
     default:
         return CRYO_E_ARG;
     }
@@ -370,6 +400,8 @@ int cryo_codec_get_option(const cryo_codec *c, int option, int64_t *value)
     case CRYO_OPT_LZ4_DECODE_PATH: *value = c->lz4_opts.path; return CRYO_OK;
     case CRYO_OPT_LZ4_INDEX_WALKERS: *value = c->lz4_opts.walkers; return CRYO_OK;
     case CRYO_OPT_PIPE_MIN_BYTES: *value = (int64_t)c->pipe_min_bytes; return CRYO_OK;
+    case CRYO_OPT_LZ4_TILES: *value = c->lz4_opts.tiles; return CRYO_OK;
+    case CRYO_OPT_POOL_BYTES: *value = (int64_t)c->pool_bytes; return CRYO_OK;
     default: return CRYO_E_ARG;
     }
 }
@@ -491,9 +523,18 @@ int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
             int rc = ensure_ws(c, need);
             if (rc != CRYO_OK) return rc;
         }
+        uint32_t tiles = 1, walkers = 0;
+        if (need != 0) cryo::lz4_tile_plan(n_blocks, block_size, c->lz4_opts, &tiles, &walkers);
+        if (tiles > 1 && !c->have_lz4_aux) {
+            HIP_TRY(c, hipStreamCreateWithFlags(&c->lz4_aux.side, hipStreamNonBlocking));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->lz4_aux.fork, hipEventDisableTiming));
+            for (int t = 0; t < cryo::kLz4MaxTiles; t++) HIP_TRY(c, hipEventCreateWithFlags(&c->lz4_aux.idx_done[t], hipEventDisableTiming));
+            c->have_lz4_aux = true;
+        }
         HIP_TRY(c, cryo::launch_lz4_decompress(c->stream, (const uint8_t *)d_src, d_src_off, d_src_size,
                                                (uint8_t *)d_dst, dst_stride, block_size, n_blocks,
-                                               d_status, need ? c->d_ws : nullptr, need ? c->ws_cap : 0, c->lz4_opts));
+                                               d_status, need ? c->d_ws : nullptr, need ? c->ws_cap : 0, c->lz4_opts,
+                                               c->have_lz4_aux ? &c->lz4_aux : nullptr));
     } else {
         const size_t need = cryo::zstd_decompress_workspace(n_blocks, block_size);
         int rc = ensure_ws(c, need);
@@ -693,6 +734,8 @@ static int decompress_blocks_piped(cryo_codec *c, int method, const void *const 
     int32_t *p_st = (int32_t *)(pin + o_data);
     for (size_t i = 0; i < n; i++) { p_off[i] = o_data + pos[i]; p_sz[i] = h_src_size[i]; }
     HIP_TRY(c, hipMemcpyAsync(c->hb_src, pin, o_data, hipMemcpyHostToDevice, c->stream));
+    c->xfer_ctr.h2d_bytes += o_data + total;
+    c->xfer_ctr.d2h_bytes += n * block_size + n * sizeof(int32_t);
     int32_t *d_st = (int32_t *)c->hb_meta;
     const uint64_t *d_off = (const uint64_t *)(c->hb_src + o_off);
     const uint32_t *d_sz = (const uint32_t *)(c->hb_src + o_sz);
@@ -865,6 +908,8 @@ static int decompress_blocks_impl(cryo_codec *c, int method, const void *const *
     }
     int32_t *d_st = (int32_t *)c->hb_meta;
     HIP_TRY(c, hipMemcpyAsync(c->hb_src, pin, o_data + total, hipMemcpyHostToDevice, c->stream));
+    c->xfer_ctr.h2d_bytes += o_data + total;
+    c->xfer_ctr.d2h_bytes += n * block_size + n * sizeof(int32_t);
     rc = cryo_codec_decompress_batch(c, method, c->hb_src, (const uint64_t *)(c->hb_src + o_off), (const uint32_t *)(c->hb_src + o_sz),
                                      c->hb_dst, block_size, (uint32_t)block_size, n, d_st);
     if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
@@ -912,6 +957,193 @@ int cryo_codec_decompress_blocks_to(cryo_codec *c, int method, const void *const
     if (!h_dst) return CRYO_E_ARG;
     return guarded([&] { return decompress_blocks_impl(c, method, h_src, h_src_size, n, nullptr, h_dst, block_size, h_status); });
 }
+
+} /* extern "C" */
+
+/* ---- device-resident block pool ---- */
+static uint64_t stream_fingerprint(const void *p, uint32_t n)
+{
+    const uint8_t *b = (const uint8_t *)p;
+    uint64_t a = 0, m = 0, z = 0;
+    if (n >= 24u) {
+        memcpy(&a, b, 8);
+        memcpy(&m, b + n / 2u - 4u, 8);
+        memcpy(&z, b + n - 8u, 8);
+    } else {
+        for (uint32_t i = 0; i < n; i++) a = a * 131u + b[i];
+    }
+    return a ^ (m * 0x9E3779B97F4A7C15ull) ^ ((z << 23) | (z >> 41)) ^ ((uint64_t)n << 32);
+}
+
+static void pool_drop(cryo_codec *c)
+{
+    if (c->d_pool) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->d_pool); c->d_pool = nullptr; }
+    c->pool_slots.clear();
+    c->pool_index.clear();
+    c->pool_head = 0;
+    c->pool_block = 0;
+}
+
+/* (re)shape the pool for this block size; false: no pool (off, or the memory is not there) */
+static bool pool_ready(cryo_codec *c, size_t block_size)
+{
+    if (c->pool_bytes < block_size) { if (c->d_pool) pool_drop(c); return false; }
+    const size_t slots = c->pool_bytes / block_size;
+    if (c->d_pool && c->pool_block == block_size && c->pool_slots.size() == slots) return true;
+    pool_drop(c);
+    if (hipMalloc((void **)&c->d_pool, slots * block_size + 64) != hipSuccess) { (void)hipGetLastError(); c->d_pool = nullptr; return false; }
+    c->pool_slots.assign(slots, cryo_codec::PoolSlot());
+    c->pool_block = block_size;
+    return true;
+}
+
+static int decompress_blocks_keyed_impl(cryo_codec *c, int method, const uint64_t *keys, const void *const *h_src,
+                                        const uint32_t *h_src_size, size_t n, void *const *h_dst, size_t block_size, int32_t *h_status)
+{
+    DevGuard dev_(c);
+    if (!c || !method_ok(method) || block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
+    if (n == 0) return CRYO_OK;
+    if (!keys || !h_src || !h_src_size || !h_dst || !h_status) return CRYO_E_ARG;
+    if (!pool_ready(c, block_size)) return decompress_blocks_impl(c, method, h_src, h_src_size, n, nullptr, h_dst, block_size, h_status);
+    const uint32_t S = (uint32_t)c->pool_slots.size();
+    /* who is in the pool already */
+    std::vector<uint32_t> slot(n, 0xffffffffu), miss;
+    std::vector<uint64_t> fp(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        if (h_src_size[i] != 0 && !h_src[i]) return CRYO_E_ARG;
+        if (!h_dst[i]) return CRYO_E_ARG;
+        if (keys[i] != 0 && h_src_size[i] != 0) {
+            fp[i] = stream_fingerprint(h_src[i], h_src_size[i]);
+            auto it = c->pool_index.find(keys[i]);
+            if (it != c->pool_index.end()) {
+                const cryo_codec::PoolSlot &ps = c->pool_slots[it->second];
+                if (ps.valid && ps.csize == h_src_size[i] && ps.fp == fp[i]) { slot[i] = it->second; h_status[i] = CRYO_OK; continue; }
+            }
+        }
+        miss.push_back((uint32_t)i);
+    }
+    c->xfer_ctr.pool_hits += n - miss.size();
+    c->xfer_ctr.pool_misses += miss.size();
+    int rc;
+    if ((rc = ensure(c, &c->hb_dst, &c->hb_dst_cap, n * block_size + 64)) != CRYO_OK) return rc;
+    if ((rc = ensure_pinned(c, n * block_size + n * 16 + 64)) != CRYO_OK) return rc;
+    /* 1. the blocks that are there leave their slots first (a miss below may take a slot over) */
+    auto gather = [&](const std::vector<uint32_t> &who) -> int {
+        for (size_t a = 0; a < who.size();) {
+            /* consecutive blocks of the call, up to 64 per launch, land next to each other in the staging area */
+            cryo::GatherSlots gs;
+            uint32_t cnt = 0;
+            const uint32_t first = who[a];
+            while (a < who.size() && cnt < 64u && who[a] == first + cnt) { gs.slot[cnt++] = slot[who[a]]; a++; }
+            HIP_TRY(c, cryo::launch_gather_blocks(c->stream, c->d_pool, gs, cnt, c->hb_dst, (uint32_t)block_size, first));
+        }
+        return CRYO_OK;
+    };
+    {
+        std::vector<uint32_t> hits;
+        for (size_t i = 0; i < n; i++) if (slot[i] != 0xffffffffu) hits.push_back((uint32_t)i);
+        if ((rc = gather(hits)) != CRYO_OK) return rc;
+    }
+    /* 2. the others are decoded INTO the pool, at most one pool-full per round, then gathered like the rest */
+    std::vector<int32_t> mst(miss.size(), 0);
+    for (size_t lo = 0; lo < miss.size(); lo += S) {
+        const size_t m = miss.size() - lo < S ? miss.size() - lo : S;
+        const size_t o_off = 0, o_sz = m * 8, o_data = (m * 12 + 63) & ~(size_t)63;
+        size_t total = 0;
+        for (size_t k = 0; k < m; k++) total += ((size_t)h_src_size[miss[lo + k]] + 15) & ~(size_t)15;
+        if ((rc = ensure(c, &c->hb_src, &c->hb_src_cap, o_data + total + 64)) != CRYO_OK) return rc;
+        if ((rc = ensure(c, &c->hb_meta, &c->hb_meta_cap, m * 16 + 64)) != CRYO_OK) return rc;
+        /* staging of the compressed side lives behind the output staging in the pinned buffer */
+        if (c->pin_cap < n * block_size + o_data + total + m * 4 + 128 && (rc = ensure_pinned(c, n * block_size + o_data + total + m * 4 + 128)) != CRYO_OK) return rc;
+        uint8_t *pin = (uint8_t *)c->pin + n * block_size;
+        uint64_t *p_off = (uint64_t *)(pin + o_off);
+        uint32_t *p_sz = (uint32_t *)(pin + o_sz);
+        size_t pos = 0;
+        for (size_t k = 0; k < m; k++) {
+            const uint32_t i = miss[lo + k];
+            p_off[k] = o_data + pos;
+            p_sz[k] = h_src_size[i];
+            if (h_src_size[i]) memcpy(pin + o_data + pos, h_src[i], h_src_size[i]);
+            pos += ((size_t)h_src_size[i] + 15) & ~(size_t)15;
+        }
+        HIP_TRY(c, hipMemcpyAsync(c->hb_src, pin, o_data + total, hipMemcpyHostToDevice, c->stream));
+        c->xfer_ctr.h2d_bytes += o_data + total;
+        int32_t *d_st = (int32_t *)c->hb_meta;
+        /* ring slots head .. head+m-1 (two launches when the ring wraps) */
+        for (size_t done = 0; done < m;) {
+            const uint32_t head = c->pool_head;
+            const size_t run = (S - head) < (m - done) ? (S - head) : (m - done);
+            for (size_t k = 0; k < run; k++) {
+                cryo_codec::PoolSlot &ps = c->pool_slots[head + k];
+                if (ps.valid) { auto it = c->pool_index.find(ps.key); if (it != c->pool_index.end() && it->second == head + k) c->pool_index.erase(it); }
+                ps.valid = false;
+                slot[miss[lo + done + k]] = head + (uint32_t)k;
+            }
+            rc = cryo_codec_decompress_batch(c, method, c->hb_src, (const uint64_t *)(c->hb_src + o_off) + done, (const uint32_t *)(c->hb_src + o_sz) + done,
+                                             c->d_pool + (size_t)head * block_size, block_size, (uint32_t)block_size, run, d_st + done);
+            if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
+            c->pool_head = (uint32_t)((head + run) % S);
+            done += run;
+        }
+        HIP_TRY(c, hipMemcpyAsync(pin + o_data + total, d_st, m * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
+        {
+            std::vector<uint32_t> who(miss.begin() + lo, miss.begin() + lo + m);
+            if ((rc = gather(who)) != CRYO_OK) return rc;
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream)); /* the statuses of this round, and the compressed staging is free again */
+        const int32_t *pst = (const int32_t *)(pin + o_data + total);
+        for (size_t k = 0; k < m; k++) {
+            const uint32_t i = miss[lo + k];
+            h_status[i] = pst[k];
+            if (pst[k] == CRYO_OK && keys[i] != 0) {
+                cryo_codec::PoolSlot &ps = c->pool_slots[slot[i]];
+                ps.key = keys[i]; ps.fp = fp[i]; ps.csize = h_src_size[i]; ps.valid = true;
+                c->pool_index[keys[i]] = slot[i];
+            }
+        }
+        c->xfer_ctr.d2h_bytes += m * sizeof(int32_t);
+    }
+    /* 3. one copy back, then to the destinations */
+    HIP_TRY(c, hipMemcpyAsync(c->pin, c->hb_dst, n * block_size, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->xfer_ctr.d2h_bytes += n * block_size;
+    std::vector<CopyJob> jobs;
+    for (size_t i = 0; i < n; i++)
+        if (h_status[i] == CRYO_OK) jobs.push_back({h_dst[i], (const uint8_t *)c->pin + i * block_size, block_size});
+    parallel_copy(c, jobs);
+    return CRYO_OK;
+}
+
+extern "C" {
+int cryo_codec_decompress_blocks_keyed(cryo_codec *c, int method, const uint64_t *keys, const void *const *h_src,
+                                       const uint32_t *h_src_size, size_t n, void *const *h_dst, size_t block_size, int32_t *h_status)
+{
+    return guarded([&] { return decompress_blocks_keyed_impl(c, method, keys, h_src, h_src_size, n, h_dst, block_size, h_status); });
+}
+
+int cryo_codec_pool_invalidate(cryo_codec *c, uint32_t key_hi, int all_entries)
+{
+    if (!c) return CRYO_E_ARG;
+    return guarded([&] {
+        for (size_t k = 0; k < c->pool_slots.size(); k++) {
+            cryo_codec::PoolSlot &ps = c->pool_slots[k];
+            if (ps.valid && (all_entries || (uint32_t)(ps.key >> 32) == key_hi)) { c->pool_index.erase(ps.key); ps.valid = false; }
+        }
+        return (int)CRYO_OK;
+    });
+}
+
+int cryo_codec_get_transfer_counters(const cryo_codec *c, cryo_codec_transfer_counters *out)
+{
+    if (!c || !out) return CRYO_E_ARG;
+    *out = c->xfer_ctr;
+    out->pool_blocks = c->pool_index.size();
+    out->pool_capacity = c->pool_slots.size();
+    return CRYO_OK;
+}
+} /* extern "C" */
+
+extern "C" {
 
 /* ---- several GPUs behind one call ---- */
 struct cryo_multi {
@@ -1069,6 +1301,80 @@ int cryo_multi_decompress_blocks_to(cryo_multi *m, int method, const void *const
     if (!h_src || !h_src_size || !h_dst || !h_status) return CRYO_E_ARG;
     if (m->h.size() == 1) return cryo_codec_decompress_blocks_to(m->h[0], method, h_src, h_src_size, n, h_dst, block_size, h_status);
     return multi_decompress(m, method, h_src, h_src_size, n, nullptr, h_dst, block_size, h_status);
+}
+
+int cryo_multi_decompress_blocks_keyed(cryo_multi *m, int method, const uint64_t *keys, const void *const *h_src,
+                                       const uint32_t *h_src_size, size_t n, void *const *h_dst, size_t block_size, int32_t *h_status)
+{
+    if (!m || m->h.empty() || !method_ok(method) || block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
+    if (n == 0) return CRYO_OK;
+    if (!keys || !h_src || !h_src_size || !h_dst || !h_status) return CRYO_E_ARG;
+    if (m->h.size() == 1) return cryo_codec_decompress_blocks_keyed(m->h[0], method, keys, h_src, h_src_size, n, h_dst, block_size, h_status);
+    /* a keyed block always goes to the same handle (its pool entry lives there); unkeyed ones round-robin */
+    return guarded([&] {
+        const size_t G = m->h.size();
+        std::vector<std::vector<size_t>> share(G);
+        for (size_t i = 0; i < n; i++) share[keys[i] ? keys[i] % G : i % G].push_back(i);
+        std::vector<int> rc(G, CRYO_OK);
+        const std::function<void(unsigned)> one = [&](unsigned g) {
+            const std::vector<size_t> &idx = share[g];
+            if (idx.empty()) return;
+            rc[g] = guarded([&] {
+                std::vector<const void *> src(idx.size());
+                std::vector<void *> dst(idx.size());
+                std::vector<uint32_t> sz(idx.size());
+                std::vector<uint64_t> ky(idx.size());
+                std::vector<int32_t> st(idx.size());
+                for (size_t k = 0; k < idx.size(); k++) { src[k] = h_src[idx[k]]; sz[k] = h_src_size[idx[k]]; dst[k] = h_dst[idx[k]]; ky[k] = keys[idx[k]]; }
+                const int r = cryo_codec_decompress_blocks_keyed(m->h[g], method, ky.data(), src.data(), sz.data(), idx.size(), dst.data(), block_size, st.data());
+                if (r == CRYO_OK) for (size_t k = 0; k < idx.size(); k++) h_status[idx[k]] = st[k];
+                return r;
+            });
+        };
+        if (m->pool) m->pool->run((unsigned)G, one);
+        else for (unsigned g = 0; g < G; g++) one(g);
+        for (size_t g = 0; g < G; g++)
+            if (rc[g] != CRYO_OK) {
+                snprintf(m->err, sizeof m->err, "device handle %zu: %s", g, cryo_codec_last_error(m->h[g]));
+                return rc[g];
+            }
+        return (int)CRYO_OK;
+    });
+}
+
+int cryo_multi_set_option(cryo_multi *m, int option, int64_t value)
+{
+    if (!m || m->h.empty()) return CRYO_E_ARG;
+    /* a pool capacity is the total over the handles */
+    const int64_t v = option == CRYO_OPT_POOL_BYTES ? value / (int64_t)m->h.size() : value;
+    for (cryo_codec *c : m->h) {
+        const int rc = cryo_codec_set_option(c, option, v);
+        if (rc != CRYO_OK) return rc;
+    }
+    return CRYO_OK;
+}
+
+int cryo_multi_pool_invalidate(cryo_multi *m, uint32_t key_hi, int all_entries)
+{
+    if (!m) return CRYO_E_ARG;
+    for (cryo_codec *c : m->h) {
+        const int rc = cryo_codec_pool_invalidate(c, key_hi, all_entries);
+        if (rc != CRYO_OK) return rc;
+    }
+    return CRYO_OK;
+}
+
+int cryo_multi_get_transfer_counters(const cryo_multi *m, cryo_codec_transfer_counters *out)
+{
+    if (!m || !out) return CRYO_E_ARG;
+    memset(out, 0, sizeof *out);
+    for (const cryo_codec *c : m->h) {
+        cryo_codec_transfer_counters t;
+        if (cryo_codec_get_transfer_counters(c, &t) != CRYO_OK) return CRYO_E_ARG;
+        out->h2d_bytes += t.h2d_bytes; out->d2h_bytes += t.d2h_bytes; out->pool_hits += t.pool_hits; out->pool_misses += t.pool_misses;
+        out->pool_blocks += t.pool_blocks; out->pool_capacity += t.pool_capacity;
+    }
+    return CRYO_OK;
 }
 
 /* ---- helpers ---- */

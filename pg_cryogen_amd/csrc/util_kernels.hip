@@ -145,6 +145,32 @@ hipError_t launch_compare(hipStream_t s, const uint8_t *d_a, uint64_t a_stride, 
     return hipGetLastError();
 }
 
+/* ---------------- gather: blocks from slots of the device-resident pool into a contiguous staging area ---------------- */
+__global__ void __launch_bounds__(256)
+k_gather_blocks(const uint8_t *__restrict__ pool, const GatherSlots slots, uint8_t *__restrict__ dst, uint32_t B, uint32_t first)
+{
+    /* one workgroup per 4 KiB piece of a block: 16 bytes per lane */
+    const uint32_t pieces = (B + 4095u) >> 12;
+    const uint32_t k = blockIdx.x / pieces, pc = blockIdx.x - k * pieces;
+    const uint8_t *src = pool + (uint64_t)slots.slot[k] * B;
+    uint8_t *out = dst + (uint64_t)(first + k) * B;
+    const uint32_t o = (pc << 12) + threadIdx.x * 16u;
+    if (o + 16u <= B && (B & 15u) == 0u) {
+        *reinterpret_cast<uint4 *>(out + o) = *reinterpret_cast<const uint4 *>(src + o);
+    } else {
+        for (uint32_t i = o; i < o + 16u && i < B; i++) out[i] = src[i];
+    }
+}
+
+hipError_t launch_gather_blocks(hipStream_t s, const uint8_t *d_pool, const GatherSlots &slots, uint32_t count, uint8_t *d_dst,
+                                uint32_t block_size, uint32_t first)
+{
+    if (count == 0) return hipSuccess;
+    const uint32_t pieces = (block_size + 4095u) >> 12;
+    hipLaunchKernelGGL(k_gather_blocks, dim3(count * pieces), dim3(256), 0, s, d_pool, slots, d_dst, block_size, first);
+    return hipGetLastError();
+}
+
 } // namespace cryo
 
 /* host reference of the checksum (exported through the C ABI) */
