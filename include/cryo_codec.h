@@ -72,11 +72,8 @@ typedef enum {
     CRYO_OPT_LZ4_INDEX_WALKERS = 2,
     /* K-block host calls: minimum bytes of a call that is cut into pipelined chunks (default 64 MiB) */
     CRYO_OPT_PIPE_MIN_BYTES = 3,
-    /* device-resident block pool (cryo_pool_*): capacity in bytes (0 = pool off, the default) */
-    CRYO_OPT_POOL_BYTES = 4,
-    /* indexed LZ4 decode: tiles a large batch is cut into, the index pass of each on a side stream beside the decoder
-     * of the tile before (0 = automatic, 1 = one index pass then one decoder launch, up to 16) */
-    CRYO_OPT_LZ4_TILES = 5
+    /* device-resident block pool (cryo_codec_decompress_blocks_keyed): capacity in bytes (0 = pool off, the default) */
+    CRYO_OPT_POOL_BYTES = 4
 } cryo_option;
 int cryo_codec_set_option(cryo_codec *c, int option, int64_t value);
 int cryo_codec_get_option(const cryo_codec *c, int option, int64_t *value);

@@ -21,7 +21,9 @@
  *
  * One difference from the reference, on purpose: a page is WAL-logged and released as soon as it is complete
  * (page_done) instead of all buffers of a chain being held until the end of cryo_preserve; chains of a write-behind
- * batch can be tens of thousands of pages, more than a backend may keep pinned.
+ * batch can be tens of thousands of pages, more than a backend may keep pinned.  So that a concurrent scan never finds
+ * a valid first page in front of continuation pages that are still empty, staging.c completes the pages of a chain
+ * last page first (the first page is what makes the chain reachable).
  */
 #ifdef CRYO_HAVE_POSTGRES
 #include "postgres.h"
@@ -33,20 +35,7 @@
 #include "storage/lmgr.h"
 #include "utils/rel.h"
 
-#include "staging.h"
-
-#define CRYO_PG_PINS 8 /* pages a chain walk has pinned at once: the current one, briefly the next */
-
-typedef struct CryoPgRel
-{
-    Relation    rel;
-    /* read side: pins taken by read_page, dropped by release_page */
-    BlockNumber pin_block[CRYO_PG_PINS];
-    Buffer      pin_buf[CRYO_PG_PINS];
-    /* write side: the page being filled */
-    Buffer      wbuf;
-    GenericXLogState *xlog;
-} CryoPgRel;
+#include "cryo_pg_rel.h"
 
 static BlockNumber
 pg_nblocks(void *h)
@@ -160,8 +149,34 @@ cryo_pg_bind(Relation rel, CryoPgRel *store, CryoRel *out)
 }
 
 /*
- * How the table AM calls the batch staging (sketch of the two call sites a maintainer changes; everything else
- * of pg_cryogen.c stays):
+ * The reference's Relation-typed cache entry points (reference cache.h:25-27), so that its seven call sites in
+ * pg_cryogen.c (:117,265,389,423,873,1017; cryo_init_cache at :172) compile UNCHANGED against this repo's cache.c:
+ * bind the Relation for the duration of the call.  Every page a chain walk pins is released before the walk returns
+ * (release_page); after an elog(ERROR) the resource owner drops what is left, as for the reference's own ReadBuffer.
+ */
+CryoError
+cryo_read_data(Relation rel, SeqScanIterator *iter, BlockNumber block, CacheEntry *result)
+{
+    CryoPgRel   store;
+    CryoRel     r;
+
+    cryo_pg_bind(rel, &store, &r);
+    return cryo_read_data_rel(&r, iter, block, result);
+}
+
+CacheEntry
+cryo_cache_allocate(Relation rel, BlockNumber blockno)
+{
+    CryoPgRel   store;
+    CryoRel     r;
+
+    cryo_pg_bind(rel, &store, &r);
+    return cryo_cache_allocate_rel(&r, blockno);
+}
+
+/*
+ * Beyond the drop-in: how the table AM would call the BATCH staging (sketch of two further call-site changes a
+ * maintainer may make; nothing else of pg_cryogen.c changes):
  *
  *   write-behind, replacing the per-block cryo_preserve() of cryo_multi_insert (reference pg_cryogen.c:603-663):
  *       keep K full cryo blocks (state->data) in a backend-local array instead of compressing each when it

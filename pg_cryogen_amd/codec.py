@@ -21,7 +21,7 @@ _ERR_NAMES = {0: "CRYO_OK", -1: "CRYO_E_ARG", -2: "CRYO_E_HIP", -3: "CRYO_E_NODE
               -7: "CRYO_E_NOMEM"}
 
 # cryo_option (include/cryo_codec.h)
-OPT_LZ4_DECODE_PATH, OPT_LZ4_INDEX_WALKERS, OPT_PIPE_MIN_BYTES, OPT_POOL_BYTES, OPT_LZ4_TILES = 1, 2, 3, 4, 5
+OPT_LZ4_DECODE_PATH, OPT_LZ4_INDEX_WALKERS, OPT_PIPE_MIN_BYTES, OPT_POOL_BYTES = 1, 2, 3, 4
 LZ4_PATH_AUTO, LZ4_PATH_RING, LZ4_PATH_INDEXED = 0, 1, 2
 
 DIST_WIDE, DIST_NARROW, DIST_INT4, DIST_RANDOM, DIST_ZEROS = range(5)
@@ -38,6 +38,9 @@ ABI_SYMBOLS = [
     "cryo_codec_decompress_blocks_to",
     "cryo_multi_open", "cryo_multi_close", "cryo_multi_count", "cryo_multi_last_error",
     "cryo_multi_compress_blocks", "cryo_multi_decompress_blocks", "cryo_multi_decompress_blocks_to",
+    "cryo_multi_decompress_blocks_keyed", "cryo_multi_set_option", "cryo_multi_pool_invalidate",
+    "cryo_multi_get_transfer_counters",
+    "cryo_codec_decompress_blocks_keyed", "cryo_codec_pool_invalidate", "cryo_codec_get_transfer_counters",
     "cryo_codec_synth_batch", "cryo_codec_checksum_batch",
     "cryo_codec_compare_batch", "cryo_checksum64", "cryo_codec_timer_start",
     "cryo_codec_timer_stop", "cryo_codec_get_counters",
@@ -48,6 +51,11 @@ class CryoError(RuntimeError):
     def __init__(self, code, what="", detail=""):
         self.code = code
         super().__init__("%s failed: %s (%d) %s" % (what, _ERR_NAMES.get(code, "?"), code, detail))
+
+
+class TransferCounters(C.Structure):
+    _fields_ = [("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("pool_hits", C.c_uint64),
+                ("pool_misses", C.c_uint64), ("pool_blocks", C.c_uint64), ("pool_capacity", C.c_uint64)]
 
 
 class Counters(C.Structure):
@@ -100,6 +108,13 @@ def lib():
     L.cryo_multi_compress_blocks.argtypes = [vp, i32, i32, vp, sz, sz, vp, sz, vp]
     L.cryo_multi_decompress_blocks.argtypes = [vp, i32, vp, vp, sz, vp, sz, vp]
     L.cryo_multi_decompress_blocks_to.argtypes = [vp, i32, vp, vp, sz, vp, sz, vp]
+    L.cryo_multi_decompress_blocks_keyed.argtypes = [vp, i32, vp, vp, vp, sz, vp, sz, vp]
+    L.cryo_multi_set_option.argtypes = [vp, i32, C.c_int64]
+    L.cryo_multi_pool_invalidate.argtypes = [vp, u32, i32]
+    L.cryo_multi_get_transfer_counters.argtypes = [vp, C.POINTER(TransferCounters)]
+    L.cryo_codec_decompress_blocks_keyed.argtypes = [vp, i32, vp, vp, vp, sz, vp, sz, vp]
+    L.cryo_codec_pool_invalidate.argtypes = [vp, u32, i32]
+    L.cryo_codec_get_transfer_counters.argtypes = [vp, C.POINTER(TransferCounters)]
     L.cryo_codec_synth_batch.argtypes = [vp, u64, u64, u64, u64, u32, i32, vp, u64]
     L.cryo_codec_checksum_batch.argtypes = [vp, vp, u64, vp, u32, u64, vp]
     L.cryo_codec_compare_batch.argtypes = [vp, vp, u64, vp, u64, u32, u64, vp]
@@ -211,6 +226,29 @@ class Codec:
         ms = C.c_float()
         self._chk(self.L.cryo_codec_timer_stop(self.h, C.byref(ms)), "timer_stop")
         return ms.value
+
+    def transfer_counters(self):
+        t = TransferCounters()
+        self._chk(self.L.cryo_codec_get_transfer_counters(self.h, C.byref(t)), "get_transfer_counters")
+        return {f: getattr(t, f) for f, _ in TransferCounters._fields_}
+
+    def pool_invalidate(self, key_hi=0, everything=False):
+        self._chk(self.L.cryo_codec_pool_invalidate(self.h, key_hi, 1 if everything else 0), "pool_invalidate")
+
+    def decompress_blocks_keyed(self, method, keys, comps, block_size):
+        """host buffers in, host buffers out, through the device-resident pool; returns (list of arrays|None, statuses)"""
+        n = len(comps)
+        arrs = [np.ascontiguousarray(np.asarray(c, dtype=np.uint8)) for c in comps]
+        src = (C.c_void_p * n)(*[a.ctypes.data if a.nbytes else None for a in arrs])
+        szs = (C.c_uint32 * n)(*[a.nbytes for a in arrs])
+        outs = [np.full(block_size, 0xA5, np.uint8) for _ in range(n)]
+        dst = (C.c_void_p * n)(*[o.ctypes.data for o in outs])
+        st = (C.c_int32 * n)()
+        ks = (C.c_uint64 * n)(*[int(k) for k in keys])
+        self._chk(self.L.cryo_codec_decompress_blocks_keyed(self.h, method, ks, src, szs, n, dst, block_size, st),
+                  "decompress_blocks_keyed")
+        st = np.array(list(st), np.int32)
+        return [outs[i] if st[i] == 0 else None for i in range(n)], st
 
     def counters(self):
         c = Counters()

@@ -133,9 +133,6 @@ struct cryo_codec {
     /* side streams of the zstd batch pipeline (created on first use) */
     cryo::ZstdAux aux = {};
     bool have_aux = false;
-    /* side stream of the tiled LZ4 decode (created on first use) */
-    cryo::Lz4Aux lz4_aux = {};
-    bool have_lz4_aux = false;
     /* options (cryo_codec_set_option) */
     cryo::Lz4DecodeOpts lz4_opts = {};
     size_t pipe_min_bytes = (size_t)64 << 20;
@@ -302,7 +299,6 @@ int cryo_codec_open(int device, cryo_codec **out)
     if (const char *e = getenv("CRYO_PIPE_MIN_MB")) c->pipe_min_bytes = (size_t)atoll(e) << 20; /* 0 = always, huge = never */
     if (const char *e = getenv("CRYO_LZ4_DECODE_PATH")) c->lz4_opts.path = atoi(e);             /* tuning aids: the options' */
     if (const char *e = getenv("CRYO_LZ4_INDEX_WALKERS")) c->lz4_opts.walkers = atoi(e);        /* initial values          */
-    if (const char *e = getenv("CRYO_LZ4_TILES")) c->lz4_opts.tiles = atoi(e);
     DevGuard dev_(c); /* the caller's current device is restored on return */
     hipError_t e = hipSuccess;
     if (!dev_.switched && dev_.prev != device) e = hipSetDevice(device); /* no current device yet, or the switch failed: report it */
@@ -350,9 +346,6 @@ void cryo_codec_close(cryo_codec *c)
         if (c->aux.join[l]) (void)hipEventDestroy(c->aux.join[l]);
     }
     if (c->aux.fork) (void)hipEventDestroy(c->aux.fork);
-    if (c->lz4_aux.side) { (void)hipStreamSynchronize(c->lz4_aux.side); (void)hipStreamDestroy(c->lz4_aux.side); }
-    if (c->lz4_aux.fork) (void)hipEventDestroy(c->lz4_aux.fork);
-    for (int t = 0; t < cryo::kLz4MaxTiles; t++) if (c->lz4_aux.idx_done[t]) (void)hipEventDestroy(c->lz4_aux.idx_done[t]);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -377,10 +370,6 @@ int cryo_codec_set_option(cryo_codec *c, int option, int64_t value)
         if (value < 0) return CRYO_E_ARG;
         c->pipe_min_bytes = (size_t)value;
         return CRYO_OK;
-    case CRYO_OPT_LZ4_TILES:
-        if (value < 0 || value > cryo::kLz4MaxTiles) return CRYO_E_ARG;
-        c->lz4_opts.tiles = (int)value;
-        return CRYO_OK;
     case CRYO_OPT_POOL_BYTES: {
         if (value < 0) return CRYO_E_ARG;
         DevGuard dev_(c);
@@ -400,7 +389,6 @@ int cryo_codec_get_option(const cryo_codec *c, int option, int64_t *value)
     case CRYO_OPT_LZ4_DECODE_PATH: *value = c->lz4_opts.path; return CRYO_OK;
     case CRYO_OPT_LZ4_INDEX_WALKERS: *value = c->lz4_opts.walkers; return CRYO_OK;
     case CRYO_OPT_PIPE_MIN_BYTES: *value = (int64_t)c->pipe_min_bytes; return CRYO_OK;
-    case CRYO_OPT_LZ4_TILES: *value = c->lz4_opts.tiles; return CRYO_OK;
     case CRYO_OPT_POOL_BYTES: *value = (int64_t)c->pool_bytes; return CRYO_OK;
     default: return CRYO_E_ARG;
     }
@@ -523,18 +511,9 @@ int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
             int rc = ensure_ws(c, need);
             if (rc != CRYO_OK) return rc;
         }
-        uint32_t tiles = 1, walkers = 0;
-        if (need != 0) cryo::lz4_tile_plan(n_blocks, block_size, c->lz4_opts, &tiles, &walkers);
-        if (tiles > 1 && !c->have_lz4_aux) {
-            HIP_TRY(c, hipStreamCreateWithFlags(&c->lz4_aux.side, hipStreamNonBlocking));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->lz4_aux.fork, hipEventDisableTiming));
-            for (int t = 0; t < cryo::kLz4MaxTiles; t++) HIP_TRY(c, hipEventCreateWithFlags(&c->lz4_aux.idx_done[t], hipEventDisableTiming));
-            c->have_lz4_aux = true;
-        }
         HIP_TRY(c, cryo::launch_lz4_decompress(c->stream, (const uint8_t *)d_src, d_src_off, d_src_size,
                                                (uint8_t *)d_dst, dst_stride, block_size, n_blocks,
-                                               d_status, need ? c->d_ws : nullptr, need ? c->ws_cap : 0, c->lz4_opts,
-                                               c->have_lz4_aux ? &c->lz4_aux : nullptr));
+                                               d_status, need ? c->d_ws : nullptr, need ? c->ws_cap : 0, c->lz4_opts));
     } else {
         const size_t need = cryo::zstd_decompress_workspace(n_blocks, block_size);
         int rc = ensure_ws(c, need);

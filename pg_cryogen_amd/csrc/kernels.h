@@ -34,18 +34,11 @@ hipError_t launch_gather_blocks(hipStream_t s, const uint8_t *d_pool, const Gath
 struct Lz4DecodeOpts {
     int path = 0;    /* 1: in-wave parse kernel, 2: sequence index + indexed decoder */
     int walkers = 0; /* walkers per block of the index pass (power of two, 1..64) */
-    int tiles = 0;   /* a large batch is cut into this many tiles whose index passes run on a side stream beside the decoder of the tile before (0 = automatic, 1 = off) */
-};
-/* side stream + events of the tiled indexed decode (created by the handle on first use) */
-constexpr int kLz4MaxTiles = 16;
-struct Lz4Aux {
-    hipStream_t side;
-    hipEvent_t fork, idx_done[kLz4MaxTiles];
 };
 hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                  const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                  uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
-                                 size_t workspace_bytes, const Lz4DecodeOpts &opts, const Lz4Aux *aux);
+                                 size_t workspace_bytes, const Lz4DecodeOpts &opts);
 /* bytes of workspace the sequence-index pass of this batch wants (0: the batch is decoded without one) */
 size_t lz4_decompress_workspace(uint64_t n_blocks, uint32_t block_size, const Lz4DecodeOpts &opts);
 /* which path a batch takes: 0 = in-wave parse kernel (k_lz4_dec_ring), else the walkers per block of the index pass */
@@ -65,9 +58,7 @@ hipError_t launch_lz4_index(hipStream_t s, const uint8_t *d_src, const uint64_t 
 hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                          const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                          uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
-                                         size_t workspace_bytes, uint32_t walkers, uint32_t tiles, const Lz4Aux *aux);
-/* tiles a batch is cut into (1 = one index pass, then one decoder launch) and the walkers per block of each tile */
-void lz4_tile_plan(uint64_t n_blocks, uint32_t block_size, const Lz4DecodeOpts &opts, uint32_t *tiles, uint32_t *walkers);
+                                         size_t workspace_bytes, uint32_t walkers);
 
 hipError_t launch_lz4_compress(hipStream_t s, const uint8_t *d_src, uint64_t src_stride,
                                uint32_t block_size, uint64_t n_blocks, uint8_t *d_dst,

@@ -561,44 +561,27 @@ uint32_t lz4_decode_plan(uint64_t n_blocks, uint32_t block_size, const Lz4Decode
     while (S < 64u && n_blocks * (2u * S) <= 65536u && block_size / (2u * S) >= 4096u) S *= 2u;
     return S;
 }
-/* Tiles: the index pass of a full batch keeps one wave per SIMD busy for 3 ms at a third of the vector issue rate,
- * then the decoder runs for 6 ms with no walker in sight.  Cut into T tiles, each tile's index pass (T walkers per block,
- * so that it still fills the chip once) runs on a side stream beside the decoder of the tile before it. */
-void lz4_tile_plan(uint64_t n_blocks, uint32_t block_size, const Lz4DecodeOpts &opts, uint32_t *tiles, uint32_t *walkers)
-{
-    uint32_t T = 1;
-    if (opts.tiles > 1) T = (uint32_t)opts.tiles;
-    if (T > (uint32_t)kLz4MaxTiles) T = kLz4MaxTiles;
-    while (T > 1 && n_blocks / T < 4096u) T--;
-    const uint64_t per = (n_blocks + T - 1) / T;
-    *tiles = T;
-    *walkers = lz4_decode_plan(per, block_size, opts);
-}
 size_t lz4_decompress_workspace(uint64_t n_blocks, uint32_t block_size, const Lz4DecodeOpts &opts)
 {
-    if (lz4_decode_plan(n_blocks, block_size, opts) == 0) return 0;
-    uint32_t T, S;
-    lz4_tile_plan(n_blocks, block_size, opts, &T, &S);
-    const uint64_t per = (n_blocks + T - 1) / T;
-    return (size_t)T * ((lz4_index_layout(per, block_size, S).bytes + 255u) & ~(size_t)255u);
+    const uint32_t S = lz4_decode_plan(n_blocks, block_size, opts);
+    return S ? lz4_index_layout(n_blocks, block_size, S).bytes : 0;
 }
 
 hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                  const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                  uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
-                                 size_t workspace_bytes, const Lz4DecodeOpts &opts, const Lz4Aux *aux)
+                                 size_t workspace_bytes, const Lz4DecodeOpts &opts)
 {
     if (n_blocks == 0) return hipSuccess;
     const uint64_t grid = (n_blocks + 3) / 4;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     const dim3 g((uint32_t)grid), b(256);
     /* sequence index pass + the decoder built for it (lz4_dec2.hip) */
-    if (lz4_decode_plan(n_blocks, block_size, opts) != 0) {
+    const uint32_t S = lz4_decode_plan(n_blocks, block_size, opts);
+    if (S != 0) {
         if (d_workspace == nullptr) return hipErrorInvalidValue;
-        uint32_t T, S;
-        lz4_tile_plan(n_blocks, block_size, opts, &T, &S);
         return launch_lz4_decompress_indexed(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks,
-                                             d_status, d_workspace, workspace_bytes, S, T, aux);
+                                             d_status, d_workspace, workspace_bytes, S);
     }
 #ifdef CRYO_DEBUG
     static const bool want_stats = getenv("CRYO_LZ4_STATS") != nullptr; /* debugging aid */

@@ -393,33 +393,11 @@ static void launch_dec_seq(hipStream_t s, const uint8_t *d_src, const uint64_t *
 hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                          const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                          uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
-                                         size_t workspace_bytes, uint32_t walkers, uint32_t tiles, const Lz4Aux *aux)
+                                         size_t workspace_bytes, uint32_t walkers)
 {
     if (n_blocks == 0) return hipSuccess;
     const uint64_t grid = (n_blocks + 3) / 4;
     if (grid > 0x7fffffffull || !d_workspace) return hipErrorInvalidValue;
-    if (tiles > 1 && aux != nullptr) {
-        /* tile t: blocks [t * per, ...); its index pass on the side stream, its decoder on `s` behind it */
-        const uint64_t per = (n_blocks + tiles - 1) / tiles;
-        const Lz4IndexLayout Lt = lz4_index_layout(per, block_size, walkers);
-        const size_t wst = (Lt.bytes + 255u) & ~(size_t)255u;
-        if (workspace_bytes < wst * tiles) return hipErrorInvalidValue;
-        if (hipError_t e = hipEventRecord(aux->fork, s); e != hipSuccess) return e;
-        if (hipError_t e = hipStreamWaitEvent(aux->side, aux->fork, 0); e != hipSuccess) return e;
-        for (uint32_t t = 0; t < tiles; t++) {
-            const uint64_t lo = t * per, cnt = lo + per <= n_blocks ? per : n_blocks - lo;
-            uint8_t *ws = static_cast<uint8_t *>(d_workspace) + wst * t;
-            if (hipError_t e = launch_lz4_index(aux->side, d_src, d_src_off + lo, d_src_size + lo, cnt, ws, Lt); e != hipSuccess) return e;
-            if (hipError_t e = hipEventRecord(aux->idx_done[t], aux->side); e != hipSuccess) return e;
-        }
-        for (uint32_t t = 0; t < tiles; t++) {
-            const uint64_t lo = t * per, cnt = lo + per <= n_blocks ? per : n_blocks - lo;
-            const uint8_t *ws = static_cast<const uint8_t *>(d_workspace) + wst * t;
-            if (hipError_t e = hipStreamWaitEvent(s, aux->idx_done[t], 0); e != hipSuccess) return e;
-            launch_dec_seq(s, d_src, d_src_off + lo, d_src_size + lo, d_dst + lo * dst_stride, dst_stride, block_size, cnt, d_status + lo, ws, Lt);
-        }
-        return hipGetLastError();
-    }
     const Lz4IndexLayout Lx = lz4_index_layout(n_blocks, block_size, walkers);
     if (workspace_bytes < Lx.bytes) return hipErrorInvalidValue;
     if (hipError_t e = launch_lz4_index(s, d_src, d_src_off, d_src_size, n_blocks, d_workspace, Lx); e != hipSuccess) return e;

@@ -26,7 +26,8 @@ ERROR_HANDLER = C.CFUNCTYPE(None, C.c_int, C.c_char_p)
 
 class CryoCodecOps(C.Structure):
     _fields_ = [("bound", BOUND_FN), ("compress_blocks", COMPRESS_FN), ("decompress_blocks", DECOMPRESS_FN),
-                ("ctx", C.c_void_p), ("decompress_blocks_scatter", C.c_void_p)]  # optional member: NULL in test doubles
+                ("ctx", C.c_void_p), ("decompress_blocks_scatter", C.c_void_p),      # optional members: NULL in test doubles
+                ("decompress_blocks_keyed", C.c_void_p), ("pool_invalidate", C.c_void_p)]
 
 
 class CryoRel(C.Structure):
@@ -123,10 +124,19 @@ def lib():
     L.cryo_cache_get_xid.restype = u32
     L.cryo_cache_err.argtypes = [i32]
     L.cryo_cache_err.restype = C.c_char_p
+    L.cryo_host_transfer_counters.argtypes = [C.POINTER(C.c_uint64)] * 4
+    L.cryo_host_transfer_counters.restype = None
     for n in ("cryo_cache_hits", "cryo_cache_misses", "cryo_cache_codec_calls"):
         getattr(L, n).restype = C.c_uint64
     _libs[prod] = L
     return L
+
+
+def transfer_counters():
+    """(h2d_bytes, d2h_bytes, pool_hits, pool_misses) of the bound GPU codec"""
+    v = [C.c_uint64() for _ in range(4)]
+    lib().cryo_host_transfer_counters(*[C.byref(x) for x in v])
+    return tuple(x.value for x in v)
 
 
 def set_int(name, value):

@@ -159,17 +159,22 @@ static CryoError load_blocks(CryoRel *rel, SeqScanIterator *iter, const BlockNum
             int32_t *st = calloc((size_t)cnt, sizeof *st);
             int *idx = malloc((size_t)cnt * sizeof *idx);
             char **outs = malloc((size_t)cnt * sizeof *outs);
+            uint64_t *keys = malloc((size_t)cnt * sizeof *keys);
             int rc = -1;
-            if (srcs && sz && st && idx && outs && ops) {
+            if (srcs && sz && st && idx && outs && keys && ops) {
                 for (i = 0; i < k; i++)
                     if (slot_of[i] != InvalidCacheEntry && (int)meth[i] == m) {
-                        srcs[j] = comp[i]; sz[j] = csz[i]; idx[j] = i; outs[j] = slots[slot_of[i]].data; j++;
+                        srcs[j] = comp[i]; sz[j] = csz[i]; idx[j] = i; outs[j] = slots[slot_of[i]].data;
+                        keys[j] = ((uint64_t)rel->relid << 32) | blocks[i]; /* the cache's own key, reference cache.c:37-47 */
+                        j++;
                     }
-                /* decoded blocks land in their cache slots directly (no second copy) */
-                rc = ops->decompress_blocks_scatter
-                         ? ops->decompress_blocks_scatter(ops->ctx, m, srcs, sz, (size_t)cnt, (void *const *)outs, cryo_blcksz, st)
-                         : -1;
-                if (!ops->decompress_blocks_scatter) {
+                /* decoded blocks land in their cache slots directly (no second copy); a codec that keeps decoded
+                 * blocks in device memory is told who they are */
+                if (ops->decompress_blocks_keyed)
+                    rc = ops->decompress_blocks_keyed(ops->ctx, m, keys, srcs, sz, (size_t)cnt, (void *const *)outs, cryo_blcksz, st);
+                else if (ops->decompress_blocks_scatter)
+                    rc = ops->decompress_blocks_scatter(ops->ctx, m, srcs, sz, (size_t)cnt, (void *const *)outs, cryo_blcksz, st);
+                else {
                     char *out = malloc((size_t)cnt * cryo_blcksz);
                     if (out) {
                         rc = ops->decompress_blocks(ops->ctx, m, srcs, sz, (size_t)cnt, out, cryo_blcksz, st);
@@ -187,7 +192,7 @@ static CryoError load_blocks(CryoRel *rel, SeqScanIterator *iter, const BlockNum
                 }
                 j++;
             }
-            free(srcs); free(sz); free(st); free(idx); free(outs);
+            free(srcs); free(sz); free(st); free(idx); free(outs); free(keys);
         }
     }
     for (i = 0; i < k; i++) {
@@ -211,7 +216,7 @@ CryoError cryo_read_data_batch(CryoRel *rel, const BlockNumber *blocks, int k, C
     return load_blocks(rel, NULL, blocks, k, results, errors);
 }
 
-CryoError cryo_read_data(CryoRel *rel, void *iter, BlockNumber block, CacheEntry *result)
+CryoError cryo_read_data_rel(CryoRel *rel, void *iter, BlockNumber block, CacheEntry *result)
 {
     CryoError err = CRYO_ERR_SUCCESS;
     *result = InvalidCacheEntry;
@@ -282,7 +287,16 @@ int cryo_scan_next_batch(CryoRel *rel, void *iter_, int k, BlockNumber *starts, 
     return got;
 }
 
-CacheEntry cryo_cache_allocate(CryoRel *rel, BlockNumber blockno)
+#ifndef CRYO_HAVE_POSTGRES
+/* PostgreSQL-free builds: the reference's names on the CryoRel (a PGXS build gets Relation-typed ones, pg/cryo_pg_rel.c) */
+CryoError cryo_read_data(CryoRel *rel, void *iter, BlockNumber block, CacheEntry *result)
+{
+    return cryo_read_data_rel(rel, iter, block, result);
+}
+CacheEntry cryo_cache_allocate(CryoRel *rel, BlockNumber blockno) { return cryo_cache_allocate_rel(rel, blockno); }
+#endif
+
+CacheEntry cryo_cache_allocate_rel(CryoRel *rel, BlockNumber blockno)
 {
     int s = find_slot(rel->relid, blockno);
     if (s == InvalidCacheEntry) {
@@ -310,9 +324,11 @@ void cryo_cache_release(CacheEntry entry)
 
 void cryo_cache_invalidate_relation(Oid relid)
 {
+    const CryoCodecOps *ops = slots ? cryo_host_codec_ops() : NULL;
     int i;
     for (i = 0; i < nslots; i++)
         if (slots[i].relid == relid && !slots[i].pinned) slots[i].ts = 0;
+    if (ops && ops->pool_invalidate) ops->pool_invalidate(ops->ctx, (uint32_t)relid); /* the device-resident copies too */
 }
 
 uint32 cryo_cache_get_pg_nblocks(CacheEntry entry) { return slots[entry].nblocks; }

@@ -23,13 +23,27 @@ void cryo_init_cache(void);                 /* 16 slots of cryo_blcksz bytes */
 int cryo_cache_configure(int nslots);       /* (re)allocate; drops all content */
 void cryo_cache_shutdown(void);
 
+/* The cache works on a CryoRel (staging.h: relation oid + page access callbacks).  The reference's entry points take
+ * a PostgreSQL Relation (cache.h:25-27); in a PGXS build (-DCRYO_HAVE_POSTGRES) those exact prototypes are exported by
+ * pg/cryo_pg_rel.c as wrappers that bind the Relation to the bufmgr-backed callbacks, so that the seven call sites of
+ * reference pg_cryogen.c (:117,265,389,423,873,1017 and _PG_init :172) compile unchanged.  Without PostgreSQL the same
+ * names take the CryoRel directly (the PG-free harness of the tests). */
+CryoError cryo_read_data_rel(CryoRel *rel, void *iter, BlockNumber block, CacheEntry *result);
+CacheEntry cryo_cache_allocate_rel(CryoRel *rel, BlockNumber blockno);
+#ifdef CRYO_HAVE_POSTGRES
+#include "utils/relcache.h"
+#include "scan_iterator.h"
+CryoError cryo_read_data(Relation rel, SeqScanIterator *iter, BlockNumber block, CacheEntry *result);
+CacheEntry cryo_cache_allocate(Relation rel, BlockNumber blockno);
+#else
 CryoError cryo_read_data(CryoRel *rel, void *iter, BlockNumber block, CacheEntry *result);
+CacheEntry cryo_cache_allocate(CryoRel *rel, BlockNumber blockno);
+#endif
 CryoError cryo_read_data_batch(CryoRel *rel, const BlockNumber *blocks, int k, CacheEntry *results,
                                CryoError *errors);
 /* read-ahead in seq-scan order (iter = SeqScanIterator*, scan_iterator.h); returns blocks delivered */
 int cryo_scan_next_batch(CryoRel *rel, void *iter, int k, BlockNumber *starts, CacheEntry *entries,
                          CryoError *errors);
-CacheEntry cryo_cache_allocate(CryoRel *rel, BlockNumber blockno);
 void cryo_cache_release(CacheEntry entry);
 void cryo_cache_invalidate_relation(Oid relid);
 

@@ -28,6 +28,7 @@ int lz4_acceleration_guc = 1;
 int zstd_compression_level_guc = 1;
 int cryo_gpu_device_guc = 0;
 int cryo_gpu_count_guc = 1;
+int cryo_gpu_pool_mb_guc = 0;
 Size cryo_blcksz = (Size)1 << 20; /* CRYO_BLCKSZ, reference storage.h:18 */
 
 /* ---------------- codec binding ---------------- */
@@ -35,7 +36,7 @@ Size cryo_blcksz = (Size)1 << 20; /* CRYO_BLCKSZ, reference storage.h:18 */
  * device numbers, wrapping).  With more than one, the K-block calls of the staging and cache code go through the
  * dispatcher of include/cryo_codec.h (block i of a call -> GPU i mod G, one host thread per GPU). */
 static cryo_multi *hip_multi;
-static int hip_multi_first = -1, hip_multi_count = 0;
+static int hip_multi_first = -1, hip_multi_count = 0, hip_pool_mb = 0;
 static char codec_err[320];
 
 static size_t hip_bound(int method, size_t n) { return cryo_codec_bound(method, n); }
@@ -93,7 +94,15 @@ static int hip_decompress_blocks_scatter(void *ctx, int method, const void *cons
     return cryo_multi_decompress_blocks_to((cryo_multi *)ctx, method, src, sz, n, dst, bs, st);
 }
 
-static CryoCodecOps hip_ops = {hip_bound, hip_compress_blocks, hip_decompress_blocks, NULL, hip_decompress_blocks_scatter};
+static int hip_decompress_blocks_keyed(void *ctx, int method, const uint64_t *keys, const void *const *src, const uint32_t *sz,
+                                       size_t n, void *const *dst, size_t bs, int32_t *st)
+{
+    return cryo_multi_decompress_blocks_keyed((cryo_multi *)ctx, method, keys, src, sz, n, dst, bs, st);
+}
+static void hip_pool_invalidate(void *ctx, uint32_t relid) { (void)cryo_multi_pool_invalidate((cryo_multi *)ctx, relid, 0); }
+
+static CryoCodecOps hip_ops = {hip_bound, hip_compress_blocks, hip_decompress_blocks, NULL, hip_decompress_blocks_scatter,
+                               hip_decompress_blocks_keyed, hip_pool_invalidate};
 static const CryoCodecOps *bound_ops; /* CPU-only plumbing tests bind a double here (CRYO_HOST_TEST_HOOKS builds only) */
 
 #ifdef CRYO_HOST_TEST_HOOKS
@@ -125,9 +134,24 @@ const CryoCodecOps *cryo_host_codec_ops(void)
         }
         hip_multi_first = cryo_gpu_device_guc;
         hip_multi_count = cryo_gpu_count_guc;
+        hip_pool_mb = 0;
         hip_ops.ctx = hip_multi;
     }
+    if (hip_pool_mb != cryo_gpu_pool_mb_guc) { /* the GUC changed: resize (0 frees the pool) */
+        hip_pool_mb = cryo_gpu_pool_mb_guc;
+        (void)cryo_multi_set_option(hip_multi, CRYO_OPT_POOL_BYTES, (int64_t)(hip_pool_mb < 0 ? 0 : hip_pool_mb) << 20);
+    }
     return &hip_ops;
+}
+
+void cryo_host_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, uint64_t *pool_hits, uint64_t *pool_misses)
+{
+    cryo_codec_transfer_counters t = {0, 0, 0, 0, 0, 0};
+    if (hip_multi) (void)cryo_multi_get_transfer_counters(hip_multi, &t);
+    if (h2d_bytes) *h2d_bytes = t.h2d_bytes;
+    if (d2h_bytes) *d2h_bytes = t.d2h_bytes;
+    if (pool_hits) *pool_hits = t.pool_hits;
+    if (pool_misses) *pool_misses = t.pool_misses;
 }
 
 /* ---------------- GUCs ---------------- */
@@ -149,6 +173,8 @@ void cryo_define_compression_gucs(void)
                             NULL, &cryo_zstd_host_fallback_guc, 0, 0, 1, PGC_USERSET, 0, NULL, NULL, NULL);
     DefineCustomIntVariable("pg_cryogen.gpu_count", "Number of GPUs (from gpu_device on) the K-block calls of this backend are spread over.",
                             NULL, &cryo_gpu_count_guc, 1, 1, 64, PGC_USERSET, 0, NULL, NULL, NULL);
+    DefineCustomIntVariable("pg_cryogen.gpu_pool_mb", "Decoded blocks kept in GPU memory so that repeated scans skip the transfer and the decode (MiB, 0 = off).",
+                            NULL, &cryo_gpu_pool_mb_guc, 0, 0, 262144, PGC_USERSET, 0, NULL, NULL, NULL);
 #else
     /* no GUC machinery without PostgreSQL: the variables keep the reference's defaults */
     compression_method_guc = COMP_ZSTD;

@@ -44,6 +44,10 @@ extern Size cryo_blcksz;
 extern int cryo_gpu_device_guc;
 /* how many GPUs, from gpu_device on, the K-block calls are spread over (additive GUC pg_cryogen.gpu_count, default 1) */
 extern int cryo_gpu_count_guc;
+/* device-resident pool of decoded blocks, MiB over all GPUs of the backend (additive GUC pg_cryogen.gpu_pool_mb, default 0 = off) */
+extern int cryo_gpu_pool_mb_guc;
+/* bytes the codec moved towards the device / back, blocks served from the pool / decoded (0 when no GPU codec is bound) */
+void cryo_host_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, uint64_t *pool_hits, uint64_t *pool_misses);
 
 /* the codec entry points the host side calls; production binds them to libcryo_codec.so
  * (include/cryo_codec.h), CPU-only plumbing tests may bind a test double */
@@ -57,6 +61,13 @@ typedef struct CryoCodecOps {
     /* optional (may be NULL): one destination per block, so the cache decodes straight into its slots */
     int (*decompress_blocks_scatter)(void *ctx, int method, const void *const *src, const uint32_t *src_size, size_t n,
                                      void *const *dst, size_t block_size, int32_t *status);
+    /* optional (may be NULL): the same with a key per block (relation oid << 32 | first block number): a codec with a
+     * device-resident pool (pg_cryogen.gpu_pool_mb) serves a block it still holds from HBM -- nothing crosses PCIe towards
+     * the device, no kernel runs for it */
+    int (*decompress_blocks_keyed)(void *ctx, int method, const uint64_t *keys, const void *const *src, const uint32_t *src_size,
+                                   size_t n, void *const *dst, size_t block_size, int32_t *status);
+    /* optional (may be NULL): forget the pooled blocks of a relation (reference: relcache callback, pg_cryogen.c:163-167) */
+    void (*pool_invalidate)(void *ctx, uint32_t relid);
 } CryoCodecOps;
 #ifdef CRYO_HOST_TEST_HOOKS
 void cryo_host_set_codec_ops(const CryoCodecOps *ops); /* test builds only: bind a double; NULL restores the HIP binding */

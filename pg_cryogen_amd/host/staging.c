@@ -26,11 +26,18 @@ int cryo_stage_write_chain(CryoRel *rel, BlockNumber first_block, CompressionMet
     blocks[0] = first_block;
     for (i = 1; i < npages; i++) blocks[i] = rel->ops->extend(rel->handle);
 
-    for (i = 0; i < npages; i++) {
+    /* The pages are completed (WAL-logged, unlocked: page_done) one by one, LAST page first: the first page is what
+     * makes a chain reachable (a reader takes a page with pd_upper != 0 and first == its own number for a block
+     * start), so it is written when every continuation page already is.  The reference holds all buffers of a chain
+     * exclusively until the end of cryo_preserve (pg_cryogen.c:757-824); a write-behind batch cannot pin that many. */
+    for (i = npages - 1; i >= 0; i--) {
         char *page = rel->ops->page_for_write(rel->handle, blocks[i]);
         CryoPageHeader *hdr = (CryoPageHeader *)page;
+        const Size before = i == 0 ? 0 : FIRST_PAYLOAD + (Size)(i - 1) * NEXT_PAYLOAD; /* payload bytes on the pages before this one */
         Size hdr_size, content;
         if (!page) return -1;
+        p = compressed + before;
+        left = csize - before;
         memset(page, 0, BLCKSZ);
         hdr->first = blocks[0];
         hdr->next = (i + 1 < npages) ? blocks[i + 1] : InvalidBlockNumber;
@@ -48,8 +55,6 @@ int cryo_stage_write_chain(CryoRel *rel, BlockNumber first_block, CompressionMet
         hdr->base.pd_lower = (uint16)(hdr_size + content);
         hdr->base.pd_special = BLCKSZ;
         memcpy(page + hdr_size, p, content);
-        p += content;
-        left -= content;
         if (rel->ops->page_done) rel->ops->page_done(rel->handle, blocks[i], page);
     }
     *npages_out = npages;

@@ -34,7 +34,47 @@ def run(c, B, n, method, param, name):
           "PCIe and host copies included" % (name, n, B // 1024, n * B / (t1 - t0) / 1e9, (t1 - t0) * 1e3,
                                              n * B / (t2 - t1) / 1e9, (t2 - t1) * 1e3))
 
+def single(c, B, method, param, name):
+    """the reference's own call shape: ONE block per call (pg_cryogen.c:726, cache.c:178), next to the stock library
+    on one host core"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    stock = oracle_lib.StockLibs()
+    d = c.alloc(B)
+    c.synth_batch(0, 5, 1, B, 0, d)
+    c.sync()
+    raw = d.download()
+    d.free()
+    comp = c.compress_block(method, param, raw)
+    for _ in range(3):
+        out = c.decompress_block(method, comp, B)
+    ts = []
+    for _ in range(20):
+        t0 = time.perf_counter(); out = c.decompress_block(method, comp, B); ts.append(time.perf_counter() - t0)
+    assert np.array_equal(out, raw)
+    te = []
+    for _ in range(5):
+        t0 = time.perf_counter(); c.compress_block(method, param, raw); te.append(time.perf_counter() - t0)
+    cpu_d = cpu_e = float("nan")
+    if (stock.lz4 if method == METHOD_LZ4 else stock.zstd) is not None:
+        dec = stock.lz4_decompress if method == METHOD_LZ4 else stock.zstd_decompress
+        enc = stock.lz4_compress if method == METHOD_LZ4 else stock.zstd_compress
+        td = []
+        for _ in range(20):
+            t0 = time.perf_counter(); dec(comp, B); td.append(time.perf_counter() - t0)
+        tc = []
+        for _ in range(5):
+            t0 = time.perf_counter(); enc(raw, param); tc.append(time.perf_counter() - t0)
+        cpu_d, cpu_e = sorted(td)[len(td) // 2], sorted(tc)[len(tc) // 2]
+    print("%s ONE block of %d KiB per call (cryo_codec_{de,}compress_block, PCIe included): decompress %.3f ms, compress %.3f ms; "
+          "stock library on one host core (through ctypes): decompress %.3f ms, compress %.3f ms"
+          % (name, B // 1024, sorted(ts)[len(ts) // 2] * 1e3, sorted(te)[len(te) // 2] * 1e3, cpu_d * 1e3, cpu_e * 1e3))
+
+
 with Codec(0) as c:
     for B, n in ((131072, 4096), (1 << 20, 16), (1 << 20, 512)):
         run(c, B, n, METHOD_LZ4, 1, "lz4")
         run(c, B, n, METHOD_ZSTD, 1, "zstd")
+    for B in (131072, 1 << 20):
+        single(c, B, METHOD_LZ4, 1, "lz4")
+        single(c, B, METHOD_ZSTD, 1, "zstd")

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (ran at commit 2f6d... of round 3; the tiles option it uses was removed afterwards: the result is profiles/r03_tiles_experiment.txt)
 # tiled indexed decode: index pass of tile t+1 on a side stream beside the decoder of tile t
 cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out/r03_tiles
 O=gpurun_out/r03_tiles

@@ -16,7 +16,7 @@ SOURCES = [os.path.join(ROOT, "pg", "cryo_pg_rel.c")] + sorted(glob.glob(os.path
 def test_postgres_branch_parses(src):
     cmd = ["gcc", "-std=gnu11", "-fsyntax-only", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Werror", "-DCRYO_HAVE_POSTGRES",
            "-I" + os.path.join(ROOT, "tests", "pg_stubs"), "-I" + os.path.join(ROOT, "pg_cryogen_amd", "host"),
-           "-I" + os.path.join(ROOT, "include"), src]
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "pg"), src]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
 
