@@ -1177,22 +1177,21 @@ static size_t block_lazy(hc_state *hc, const cpar *cp, const uint8_t *base, cons
 /* ------------------------------------------------------------ parameters (ZSTD_getCParams) */
 static int get_cpar(int level, size_t n, cpar *cp)
 {
-    /* rows: level 0 (base for negatives), 1 .. 10 of the library's tables for the two size classes the cryo path
-     * uses {windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy: 1 fast 2 dfast 3 greedy
-     * 4 lazy 5 lazy2}; validated against ZSTD_getCParams by the tests */
-    static const int big[11][7] = {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2},
-                                   {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}, {21, 19, 19, 3, 5, 8, 4},
-                                   {21, 19, 19, 3, 5, 16, 5}, {21, 19, 20, 4, 5, 16, 5}, {22, 20, 21, 4, 5, 16, 5}}; /* n > 256 KiB */
-    static const int k128[11][7] = {{17, 12, 12, 1, 5, 1, 1}, {17, 12, 13, 1, 6, 0, 1}, {17, 13, 15, 1, 5, 0, 1}, {17, 15, 16, 2, 5, 0, 2},
-                                    {17, 17, 17, 2, 4, 0, 2}, {17, 16, 17, 3, 4, 2, 3}, {17, 17, 17, 3, 4, 4, 4}, {17, 17, 17, 3, 4, 8, 5},
-                                    {17, 17, 17, 4, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 5}, {17, 17, 17, 6, 4, 8, 5}}; /* 16 KiB < n <= 128 KiB */
+    /* libzstd 1.4.8's four parameter tables (ZSTD_defaultCParameters: source size > 256 KiB, <= 256 KiB, <= 128 KiB,
+     * <= 16 KiB), rows: the base row of the negative levels, then levels 1 .. 12; columns: windowLog, chainLog, hashLog,
+     * searchLog, minMatch, targetLength, strategy (1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2; 6 and up: the binary-tree
+     * strategies, no kernel).  Dumped from ZSTD_getCParams and checked against it by the tests. */
+    static const int kCParTab[4][13][7] = {
+        {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2}, {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}, {21, 19, 19, 3, 5, 8, 4}, {21, 19, 19, 3, 5, 16, 5}, {21, 19, 20, 4, 5, 16, 5}, {22, 20, 21, 4, 5, 16, 5}, {22, 21, 22, 4, 5, 16, 5}, {22, 21, 22, 5, 5, 16, 5}},
+        {{18, 12, 13, 1, 5, 1, 1}, {18, 13, 14, 1, 6, 0, 1}, {18, 14, 14, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {18, 16, 17, 2, 5, 2, 3}, {18, 18, 18, 3, 5, 2, 3}, {18, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 4, 4, 4, 4}, {18, 18, 19, 4, 4, 8, 5}, {18, 18, 19, 5, 4, 8, 5}, {18, 18, 19, 6, 4, 8, 5}, {18, 18, 19, 5, 4, 12, 6}, {18, 19, 19, 7, 4, 12, 6}},
+        {{17, 12, 12, 1, 5, 1, 1}, {17, 12, 13, 1, 6, 0, 1}, {17, 13, 15, 1, 5, 0, 1}, {17, 15, 16, 2, 5, 0, 2}, {17, 17, 17, 2, 4, 0, 2}, {17, 16, 17, 3, 4, 2, 3}, {17, 17, 17, 3, 4, 4, 4}, {17, 17, 17, 3, 4, 8, 5}, {17, 17, 17, 4, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 5}, {17, 17, 17, 6, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 6}, {17, 18, 17, 7, 4, 12, 6}},
+        {{14, 12, 13, 1, 5, 1, 1}, {14, 14, 15, 1, 5, 0, 1}, {14, 14, 15, 1, 4, 0, 1}, {14, 14, 15, 2, 4, 0, 2}, {14, 14, 14, 4, 4, 2, 3}, {14, 14, 14, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}, {14, 14, 14, 6, 4, 8, 5}, {14, 14, 14, 8, 4, 8, 5}, {14, 15, 14, 5, 4, 8, 6}, {14, 15, 14, 9, 4, 8, 6}, {14, 15, 14, 3, 4, 12, 7}, {14, 15, 14, 4, 3, 24, 7}}};
     const int (*t)[7];
     int row, srclog, strat;
     if (level == 0) level = 3;
-    if (level > 10 || level < -131072) return -1; /* other levels: bt* strategies, not restated */
-    if (n > 256u * 1024u) t = big;
-    else if (n > 16u * 1024u && n <= 128u * 1024u) t = k128;
-    else return -1;
+    if (level > 12 || level < -131072) return -1; /* higher levels: bt* strategies at every size, not restated */
+    t = kCParTab[n > 256u * 1024u ? 0 : (n > 128u * 1024u ? 1 : (n > 16u * 1024u ? 2 : 3))];
+    if (t[level < 0 ? 0 : level][6] > 5) return -1; /* a binary-tree strategy */
     row = level < 0 ? 0 : level;
     cp->wlog = t[row][0]; cp->clog = t[row][1]; cp->hlog = t[row][2]; cp->slog = t[row][3]; cp->mml = t[row][4];
     cp->tlen = level < 0 ? -level : t[row][5];
@@ -1205,6 +1204,7 @@ static int get_cpar(int level, size_t n, cpar *cp)
     if (cp->hlog > cp->wlog + 1) cp->hlog = cp->wlog + 1;
     if (cp->clog > cp->wlog) cp->clog = cp->wlog; /* cycleLog == chainLog for the non-bt strategies */
     if (cp->wlog < 10) cp->wlog = 10;
+    if (cp->hlog > 21 || cp->clog > 20) return -1; /* beyond this restatement's static tables (sources above 2 MiB at the deep levels) */
     return 0;
 }
 

@@ -141,6 +141,33 @@ def test_zstd_encode_bit_exact(codec, oracle, B):
             assert np.array_equal(got[i], exp), (B, lvl, i)
 
 
+@pytest.mark.parametrize("B", [64, 1000, 4096, 16384, 16385, 131073, 200000, 262144, 262145, 1 << 20])
+def test_zstd_encode_every_size_class_bit_exact(codec, oracle, B):
+    """libzstd picks its parameters from four tables by source size (<= 16 KiB, <= 128 KiB, <= 256 KiB, above): every
+    class, every level whose strategy is not a binary-tree one there (-5 .. 8 / 10 / 10 / 12), against the oracle
+    (pinned to libzstd 1.4.8 on these sizes by tests/test_oracle_golden.py) and, where loadable, the stock library"""
+    from stress_gpu import make_block
+    from test_oracle_golden import zstd_levels_with_kernel
+    from pg_cryogen_amd.codec import CryoError, E_UNSUPPORTED
+    stock = oracle_lib.StockLibs()
+    rng = np.random.default_rng(B + 1)
+    blocks = [make_block(rng, B), oracle.synth(6, 5, B, 0) if B >= 4096 else rng.integers(0, 4, B, dtype=np.uint8),
+              rng.integers(0, 256, B, dtype=np.uint8)]
+    levels = zstd_levels_with_kernel(B)
+    for lvl in levels:
+        got = codec.compress_blocks(METHOD_ZSTD, lvl, blocks)
+        for i, b in enumerate(blocks):
+            exp = oracle.zstd_compress(b, lvl)
+            assert len(exp) > 0 and np.array_equal(got[i], exp), (B, lvl, i, len(got[i]), len(exp))
+            if stock.zstd is not None and lvl in (levels[0], 1, levels[-1]):
+                assert np.array_equal(got[i], stock.zstd_compress(b, lvl)), (B, lvl, i)
+    outs, st = codec.decompress_blocks(METHOD_ZSTD, got, B)
+    assert (st == 0).all() and all(np.array_equal(o, b) for o, b in zip(outs, blocks))
+    with pytest.raises(CryoError) as e:
+        codec.compress_blocks(METHOD_ZSTD, levels[-1] + 1, blocks[:1])   # the class's first binary-tree level
+    assert e.value.code == E_UNSUPPORTED
+
+
 def test_zstd_encode_matches_golden_vectors(codec, oracle):
     """every golden cell of a level with a kernel (-5 .. 10), 128 KiB and 1 MiB blocks"""
     cells = [c for c in json.load(open(os.path.join(G, "vectors.json")))["cells"]

@@ -271,9 +271,34 @@ def test_zstd_encoder_oracle_vs_live_libzstd(oracle, B):
                 assert r == B and np.array_equal(out, raw)
 
 
+# every size class of libzstd's parameter tables (<= 16 KiB, <= 128 KiB, <= 256 KiB, above) and every level whose
+# strategy is not a binary-tree one there: -5 .. 8 up to 16 KiB, .. 10 up to 256 KiB, .. 12 above (round 3)
+ZSTD_CLASS_SIZES = [64, 1000, 4096, 16384, 16385, 131073, 200000, 262144, 262145, 1 << 20]
+
+
+def zstd_levels_with_kernel(B):
+    return list(range(-5, 9 if B <= 16384 else (11 if B <= 262144 else 13)))
+
+
+@pytest.mark.parametrize("B", ZSTD_CLASS_SIZES)
+def test_zstd_encoder_oracle_size_classes_vs_live_libzstd(oracle, B):
+    from stress_gpu import make_block
+    stock = oracle_lib.StockLibs()
+    if stock.zstd is None:
+        pytest.skip("libzstd.so.1 not loadable")
+    rng = np.random.default_rng(B)
+    blocks = [make_block(rng, B), oracle.synth(6, 3, B, 0) if B >= 4096 else rng.integers(0, 4, B, dtype=np.uint8)]
+    for lvl in zstd_levels_with_kernel(B):
+        for raw in blocks:
+            exp = stock.zstd_compress(raw, lvl)
+            got = oracle.zstd_compress(raw, lvl)
+            assert np.array_equal(got, exp), (B, lvl, len(got), len(exp))
+    assert len(oracle.zstd_compress(blocks[0], zstd_levels_with_kernel(B)[-1] + 1)) == 0   # the first bt* level of the class
+
+
 def test_zstd_encoder_oracle_unsupported_levels_return_empty(oracle):
     raw = oracle.synth(0, 0, 131072, 1)
-    assert len(oracle.zstd_compress(raw, 11)) == 0     # bt* strategies: not restated
+    assert len(oracle.zstd_compress(raw, 11)) == 0     # bt* strategies (from level 11 on at 128 KiB): not restated
     assert len(oracle.zstd_compress(raw, 22)) == 0
 
 
