@@ -148,7 +148,10 @@ def cpu_baseline(ora, np, method, encode, param, blobs, sizes, B, reps=5):
 
 
 def lookup_traffic(mname, n, B, dist, param):
-    """HBM bytes per launch from the PMC passes of the same workload (profiles/*_hbm_traffic.json), else None"""
+    """HBM bytes per launch of this workload and where they come from: the separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+    passes of the same command (profiles/collect.sh, corrected by profiles/summarize.py as MI355X_MICROARCH.md prescribes),
+    committed as profiles/*_hbm_traffic.json.  Counters cannot be read inside a timed run; a workload without a committed
+    pass reports null."""
     try:
         for fn in sorted(os.listdir(os.path.join(ROOT, "profiles")), reverse=True):
             if fn.endswith("_hbm_traffic.json"):
@@ -156,10 +159,10 @@ def lookup_traffic(mname, n, B, dist, param):
                 wl = t.get("workload", {})
                 if (wl.get("method", "lz4"), wl.get("blocks_per_gpu"), wl.get("block_size"), wl.get("distribution"),
                         wl.get("param", wl.get("lz4_acceleration"))) == (mname, n, B, dist, param):
-                    return t["traffic_bytes_per_launch"]
+                    return t["traffic_bytes_per_launch"], "profiles/%s (separate --pmc passes of this command, not this run)" % fn
     except OSError:
         pass
-    return None
+    return None, None
 
 
 def main():
@@ -297,9 +300,10 @@ def main():
                              "compression_ratio": round(n * B / comp_bytes, 3),
                              "bit_exact": "encode == oracle on %d sampled blocks; decode == original on all %d blocks" % (len(sample_idx), n),
                              "setup_encode_GBps": round(n * B / (enc_ms * 1e-3) / 1e9, 2)}
+            traffic, traffic_src = lookup_traffic(mname, n, B, a.dist, param)
             out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                               "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": lookup_traffic(mname, n, B, a.dist, param),
-                               "kernel": ("k_lz4_index + k_lz4_dec_seq (one decode call; below 24576 blocks: k_lz4_dec_ring)" if is_lz4
+                               "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                               "kernel": ("k_lz4_index + k_lz4_dec_seq (one decode call)" if is_lz4
                                           else "k_zplan+k_zhuf+k_zseq+k_zexec (one decode call)"),
                                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": algo_bytes}
             if want_cpu:
@@ -353,7 +357,8 @@ def main():
                              "bit_exact": "encode == oracle (libzstd 1.4.8 / liblz4 1.9.3 pinned) on sampled blocks; decode == original on all blocks"}
             out["roofline"] = {"bound": "hbm", "achieved": round(algo / ((e + d) * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": round(algo / ((e + d) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                               "traffic": lookup_traffic(mname + "_roundtrip", n, B, a.dist, param), "kernel": "encode + decode pair",
+                               "traffic": lookup_traffic(mname + "_roundtrip", n, B, a.dist, param)[0],
+                               "traffic_source": lookup_traffic(mname + "_roundtrip", n, B, a.dist, param)[1], "kernel": "encode + decode pair",
                                "encode_frac": round((n * B + comp_bytes) / (e * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                "decode_frac": round((n * B + comp_bytes) / (d * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                                "algorithmic_bytes_per_launch": algo}

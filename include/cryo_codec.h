@@ -73,7 +73,10 @@ typedef enum {
     /* K-block host calls: minimum bytes of a call that is cut into pipelined chunks (default 64 MiB) */
     CRYO_OPT_PIPE_MIN_BYTES = 3,
     /* device-resident block pool (cryo_codec_decompress_blocks_keyed): capacity in bytes (0 = pool off, the default) */
-    CRYO_OPT_POOL_BYTES = 4
+    CRYO_OPT_POOL_BYTES = 4,
+    /* zstd decode path: 0 = automatic (the four-kernel pipeline; the fused kernel for frames its planner does not take),
+     * 1 = the fused one-wave-per-frame kernel for everything, 2 = the pipeline */
+    CRYO_OPT_ZSTD_DECODE_PATH = 5
 } cryo_option;
 int cryo_codec_set_option(cryo_codec *c, int option, int64_t value);
 int cryo_codec_get_option(const cryo_codec *c, int option, int64_t *value);

@@ -16,7 +16,7 @@ import os
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcryo_codec.so")
+LIB_PATH = os.environ.get("CRYO_CODEC_LIB") or os.path.join(_HERE, "libcryo_codec.so")   # override: A/B builds of experiments
 _ROCM_RT = os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib", "libamdhip64.so")
 
 _lib = None

@@ -21,7 +21,7 @@ _ERR_NAMES = {0: "CRYO_OK", -1: "CRYO_E_ARG", -2: "CRYO_E_HIP", -3: "CRYO_E_NODE
               -7: "CRYO_E_NOMEM"}
 
 # cryo_option (include/cryo_codec.h)
-OPT_LZ4_DECODE_PATH, OPT_LZ4_INDEX_WALKERS, OPT_PIPE_MIN_BYTES, OPT_POOL_BYTES = 1, 2, 3, 4
+OPT_LZ4_DECODE_PATH, OPT_LZ4_INDEX_WALKERS, OPT_PIPE_MIN_BYTES, OPT_POOL_BYTES, OPT_ZSTD_DECODE_PATH = 1, 2, 3, 4, 5
 LZ4_PATH_AUTO, LZ4_PATH_RING, LZ4_PATH_INDEXED = 0, 1, 2
 
 DIST_WIDE, DIST_NARROW, DIST_INT4, DIST_RANDOM, DIST_ZEROS = range(5)

@@ -135,6 +135,7 @@ struct cryo_codec {
     bool have_aux = false;
     /* options (cryo_codec_set_option) */
     cryo::Lz4DecodeOpts lz4_opts = {};
+    int zstd_path = 0;
     size_t pipe_min_bytes = (size_t)64 << 20;
     /* staging-copy workers (created by the first K-block call that is large enough to want them) */
     WorkerPool *pool = nullptr;
@@ -299,6 +300,7 @@ int cryo_codec_open(int device, cryo_codec **out)
     if (const char *e = getenv("CRYO_PIPE_MIN_MB")) c->pipe_min_bytes = (size_t)atoll(e) << 20; /* 0 = always, huge = never */
     if (const char *e = getenv("CRYO_LZ4_DECODE_PATH")) c->lz4_opts.path = atoi(e);             /* tuning aids: the options' */
     if (const char *e = getenv("CRYO_LZ4_INDEX_WALKERS")) c->lz4_opts.walkers = atoi(e);        /* initial values          */
+    if (const char *e = getenv("CRYO_ZSTD_DECODE_PATH")) c->zstd_path = atoi(e);
     DevGuard dev_(c); /* the caller's current device is restored on return */
     hipError_t e = hipSuccess;
     if (!dev_.switched && dev_.prev != device) e = hipSetDevice(device); /* no current device yet, or the switch failed: report it */
@@ -370,6 +372,10 @@ int cryo_codec_set_option(cryo_codec *c, int option, int64_t value)
         if (value < 0) return CRYO_E_ARG;
         c->pipe_min_bytes = (size_t)value;
         return CRYO_OK;
+    case CRYO_OPT_ZSTD_DECODE_PATH:
+        if (value < 0 || value > 2) return CRYO_E_ARG;
+        c->zstd_path = (int)value;
+        return CRYO_OK;
     case CRYO_OPT_POOL_BYTES: {
         if (value < 0) return CRYO_E_ARG;
         DevGuard dev_(c);
@@ -390,6 +396,7 @@ int cryo_codec_get_option(const cryo_codec *c, int option, int64_t *value)
     case CRYO_OPT_LZ4_INDEX_WALKERS: *value = c->lz4_opts.walkers; return CRYO_OK;
     case CRYO_OPT_PIPE_MIN_BYTES: *value = (int64_t)c->pipe_min_bytes; return CRYO_OK;
     case CRYO_OPT_POOL_BYTES: *value = (int64_t)c->pool_bytes; return CRYO_OK;
+    case CRYO_OPT_ZSTD_DECODE_PATH: *value = c->zstd_path; return CRYO_OK;
     default: return CRYO_E_ARG;
     }
 }
@@ -515,7 +522,7 @@ int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
                                                (uint8_t *)d_dst, dst_stride, block_size, n_blocks,
                                                d_status, need ? c->d_ws : nullptr, need ? c->ws_cap : 0, c->lz4_opts));
     } else {
-        const size_t need = cryo::zstd_decompress_workspace(n_blocks, block_size);
+        const size_t need = cryo::zstd_decompress_workspace(n_blocks, block_size, c->zstd_path);
         int rc = ensure_ws(c, need);
         if (rc != CRYO_OK) return rc;
         if (!c->have_aux) {
@@ -528,7 +535,7 @@ int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
         }
         HIP_TRY(c, cryo::launch_zstd_decompress(c->stream, (const uint8_t *)d_src, d_src_off, d_src_size,
                                                 (uint8_t *)d_dst, dst_stride, block_size, n_blocks,
-                                                d_status, c->d_ws, c->ws_cap, &c->aux));
+                                                d_status, c->d_ws, c->ws_cap, &c->aux, c->zstd_path));
     }
     c->ctr.blocks_decompressed += n_blocks;
     c->ctr.bytes_out += n_blocks * (uint64_t)block_size;

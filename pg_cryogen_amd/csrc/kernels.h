@@ -78,8 +78,8 @@ struct ZstdAux {
 hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                   const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                   uint32_t block_size, uint64_t n_blocks, int32_t *d_status,
-                                  void *d_workspace, size_t workspace_bytes, const ZstdAux *aux);
-size_t zstd_decompress_workspace(uint64_t n_blocks, uint32_t block_size);
+                                  void *d_workspace, size_t workspace_bytes, const ZstdAux *aux, int path);
+size_t zstd_decompress_workspace(uint64_t n_blocks, uint32_t block_size, int path);
 /* fused one-wave-per-frame decoder (zstd_dec.hip): small batches, and the pipeline's irregular frames
  * (d_list != nullptr: decode blocks list_base + d_list[0 .. *d_list_n), n_blocks only sizes the grid) */
 hipError_t launch_zstd_fused(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,

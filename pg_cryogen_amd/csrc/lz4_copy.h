@@ -129,6 +129,7 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
     }
     LDS_FENCE();
     }
+    stamp(st, 4);
 
     /* ---- literals and independent matches: one lane per sequence ---- */
     {
@@ -148,6 +149,7 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
         }
     }
     LDS_FENCE();
+    stamp(st, 5);
     if (!(CRYO_ABL & 128)) {
         /* bits before each match-space chunk */
         static_assert(kNc <= 64, "one lane per chunk");
@@ -160,7 +162,6 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
         if (lane < kNc) L.mbm[kBmW + lane] = exc;
     }
     LDS_FENCE();
-    stamp(st, 4);
 
     /* ---- match space: chunks in order ---- */
     {

@@ -421,7 +421,7 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
                 h_st[0], h_st[1], h_st[2], h_st[3], h_st[4], h_st[5]);
         unsigned long long tot = 0;
         for (int k = 0; k < 8; k++) tot += h_st[8 + k];
-        static const char *nm[8] = {"stage", "decode+validate", "flush", "requests", "lane runs+bitmap", "-", "match space", "general+other"};
+        static const char *nm[8] = {"stage", "decode+validate", "flush", "requests", "bitmap+meta", "lane runs", "chunk bases+match space", "general+other"};
         for (int k = 0; k < 8; k++) fprintf(stderr, "[lz4 seq cycles] %-16s %5.1f%%\n", nm[k], 100.0 * (double)h_st[8 + k] / (double)(tot ? tot : 1));
         fprintf(stderr, "[lz4 seq stops] not a candidate %llu, offset outside the window %llu, chain %llu, literal 255-run %llu, match 255-run %llu, "
                         "overlapping match %llu, offset too far %llu, end of input %llu, batch full (T) %llu, end of output %llu, far and long %llu\n",

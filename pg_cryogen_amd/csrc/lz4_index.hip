@@ -11,7 +11,7 @@
  * The walk.  A lane that read its stream straight from global memory paid a trip to L2 per hop (6.9 ms for the
  * headline batch).  So every walker stages its stream through a private 512-byte LDS ring, filled 128 bytes (one
  * cache line) at a time: in turn j of four the wave's 64 lanes load one 16-byte piece each for 16 walkers that have
- * room, and store it two rounds later, so a load's latency is covered by eight hops.  The walk is a small state
+ * room, and store it one round later, so a load's latency is covered by four hops.  The walk is a small state
  * machine per lane (token / literal-length extension / match-length extension), one LDS read per hop serves every
  * lane whatever it is in; a token with at most two literals and a short match leaves the next token inside the bytes
  * just read and that one is taken in the same turn.  The pass is paced by (hops per walker) x (time of a turn): all
@@ -34,7 +34,13 @@
 
 namespace cryo {
 
-constexpr uint32_t kIdxLanes = 64, kIdxChunk = 128, kIdxRing = 512;
+#ifndef CRYO_IDX_RING
+#define CRYO_IDX_RING 512
+#endif
+#ifndef CRYO_IDX_LAT
+#define CRYO_IDX_LAT 1 /* rounds between a chunk's request and its commit (2 was round 2's: no faster, twice the slot registers) */
+#endif
+constexpr uint32_t kIdxLanes = 64, kIdxChunk = 128, kIdxRing = CRYO_IDX_RING;
 constexpr uint32_t kIdxStride = kIdxRing + 16u; /* bank skew between rings */
 
 __device__ inline uint32_t bperm(uint32_t v, uint32_t src_lane)
@@ -87,6 +93,9 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     /* the last 32 positions of every lane (two lines of 16: one being filled, one waiting for its store) + one slot
      * where a lane that records nothing writes */
     __shared__ __attribute__((aligned(16))) uint16_t s_pos[kIdxLanes][40];
+#ifdef CRYO_IDX_TRASH
+    __shared__ __attribute__((aligned(16))) uint8_t s_trash[kIdxLanes * 16u]; /* where a lane with nothing to commit stores */
+#endif
     const uint32_t lane = threadIdx.x;
     const uint32_t S = 1u << logS, cap_s = cap_main + ext;
     const uint64_t gl = (uint64_t)blockIdx.x * kIdxLanes + lane;
@@ -137,8 +146,9 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
 #undef IDX_SRC
     const uint32_t rb = lane * kIdxStride; /* this lane's ring inside s_ring */
 
-    /* chunks on their way: two per turn, committed TWO rounds later (a lane with room in its ring requests one chunk
-     * per round, up to two outstanding; four rounds of distance bought nothing and its 32 slots spilled registers).
+    /* chunks on their way: two per turn, committed one round later (a lane with room in its ring requests one chunk
+     * per round; two rounds of distance were measured equal within noise -- 8.81 against 8.94 ms per headline call --
+     * and cost twice the slot registers and predicate masks, which the compiler spilled).
      * Separate variables, not arrays: the compiler kept an indexed array in scratch memory. */
 #define IDX_SLOT(n) uint4 fd##n = make_uint4(0, 0, 0, 0), fe##n = fd##n; uint32_t fa##n = 0, fb##n = 0; bool fp##n = false, fq##n = false, fo##n = false;
     IDX_SLOT(0) IDX_SLOT(1) IDX_SLOT(2) IDX_SLOT(3) IDX_SLOT(4) IDX_SLOT(5) IDX_SLOT(6) IDX_SLOT(7)
@@ -148,8 +158,13 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
                     const uint64_t soff, const uint32_t sve, const uint64_t soff2, const uint32_t sve2) __attribute__((always_inline)) {
         const bool myturn = (lane >> 4) == j; /* lanes 16j..16j+15 */
         /* ---- commit the chunks requested two rounds ago ---- */
+#ifdef CRYO_IDX_TRASH
+        *reinterpret_cast<uint4 *>(fp ? s_ring + fa : s_trash + lane * 16u) = fd;
+        *reinterpret_cast<uint4 *>(fq ? s_ring + fb : s_trash + lane * 16u) = fe;
+#else
         if (fp) *reinterpret_cast<uint4 *>(s_ring + fa) = fd;
         if (fq) *reinterpret_cast<uint4 *>(s_ring + fb) = fe;
+#endif
         if (myturn && outst != 0u && fpo) { /* fpo: this lane did request in the turn being committed */
             outst--;
             if (drop != 0u) drop--; else filled += kIdxChunk;
@@ -281,12 +296,20 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
 #define IDX_ROUND(a, b, c, d)                                   \
     IDX_PUT()                                                   \
     IDX_TURN(0, a, 0, 1) IDX_TURN(1, b, 2, 3) IDX_TURN(2, c, 4, 5) IDX_TURN(3, d, 6, 7)
+#if CRYO_IDX_LAT == 2
 #define IDX_WALK()                                              \
     while (__any(!done)) {                                      \
         IDX_ROUND(0, 1, 2, 3)                                   \
         IDX_ROUND(4, 5, 6, 7)                                   \
     }                                                           \
     if (walker) IDX_FLUSH()
+#else
+#define IDX_WALK()                                              \
+    while (__any(!done)) {                                      \
+        IDX_ROUND(0, 1, 2, 3)                                   \
+    }                                                           \
+    if (walker) IDX_FLUSH()
+#endif
 
     /* ---- phase 1: every walker its own segment ---- */
     IDX_WALK()

@@ -442,7 +442,10 @@ __global__ void __launch_bounds__(64) k_zplan(ZPipe P)
 }
 
 /* ------------------------------------------------------------------------------------------------ K2 */
-constexpr uint32_t kHufPerWave = 16; /* blocks per wave: 16 x 4 streams = 64 lanes */
+#ifndef CRYO_ZHUF_PER_WAVE
+#define CRYO_ZHUF_PER_WAVE 16
+#endif
+constexpr uint32_t kHufPerWave = CRYO_ZHUF_PER_WAVE; /* blocks per wave: 16 x 4 streams = 64 lanes */
 constexpr uint32_t kHufL1 = 11;      /* table in LDS: 2^11 entries (4 KiB) per block -- every table libzstd's encoder emits */
 
 constexpr uint32_t kHufL2 = 128;     /* second-level entries per block */
@@ -538,11 +541,12 @@ __global__ void __launch_bounds__(64) k_zhuf(ZPipe P)
     __builtin_amdgcn_wave_barrier();
 
     const uint32_t j = lane >> 2, sid = lane & 3u;
-    bool have = base + j < nitems;
+    bool have = j < kHufPerWave && base + j < nitems;
     const uint32_t it = have ? P.hitems[base + j] : P.hitems[base];
     const ZBlk *d = P.blks + it;
     const uint32_t f = it / P.nbmax;
     const uint32_t nstreams = d->nstreams;
+    const uint32_t jt = have ? j : 0u; /* lanes without a block of their own look at the wave's first table */
     have = have && sid < nstreams;
     const uint32_t regen = d->regen, hlog = d->huf_log;
     const uint32_t l1 = hlog < kHufL1 ? hlog : kHufL1;
@@ -561,8 +565,8 @@ __global__ void __launch_bounds__(64) k_zhuf(ZPipe P)
     const bool opened = lb.init(&L.ring[0][lane], src, soff, slen, have);
     if (have && !opened) ok = false;
     HufTab h;
-    h.t = L.tbl + (j << kHufL1);
-    h.t2 = L.sub + j * kHufL2;
+    h.t = L.tbl + (jt << kHufL1);
+    h.t2 = L.sub + jt * kHufL2;
     h.gt = gt;
     h.l1 = l1; h.hlog = hlog; h.sh = hlog > kHufL1 ? hlog - kHufL1 : 0u;
     const uint32_t n8 = opened ? cnt >> 3 : 0u;
@@ -594,7 +598,10 @@ __global__ void __launch_bounds__(64) k_zhuf(ZPipe P)
 }
 
 /* ------------------------------------------------------------------------------------------------ K3 */
-constexpr uint32_t kSeqPerWave = 29; /* frames per wave: 29 x 2.5 KiB of decoding tables in LDS, 2 workgroups per CU */
+#ifndef CRYO_ZSEQ_PER_WAVE
+#define CRYO_ZSEQ_PER_WAVE 29
+#endif
+constexpr uint32_t kSeqPerWave = CRYO_ZSEQ_PER_WAVE; /* frames per wave: 29 x 2.5 KiB of decoding tables in LDS, 2 workgroups per CU */
 
 /* K3 is bound by LDS capacity (frames in flight per CU = LDS / table bytes per frame; the per-sequence chain
  * entry -> bit count -> state bits -> next entry is serial), so the tables are staged as 16-bit entries:
@@ -1001,7 +1008,8 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     const size_t budget = budget_env ? budget_env : (size_t)10 << 30; /* per tile in flight; reached only by blocks > 128 KiB,
                                                                         whose tiles would otherwise be too few frames to fill K1/K4 */
     uint64_t F = budget / per_frame;
-    if (F > 14848u) F = 14848u;
+    constexpr uint64_t kTile = 512u * kSeqPerWave; /* one full round of K3 */
+    if (F > kTile) F = kTile;
     if (F >= 464u) F -= F % 464u;
     else if (F < 16u) F = 16u;
     if (F > n_blocks) F = n_blocks;
@@ -1029,29 +1037,28 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     return y;
 }
 
-/* two tiles in flight on two side streams: pays for frames of several blocks (measured at 1 MiB: 95 -> 107
- * GB/s), where a tile has too few frames to fill the wave-per-frame kernels; nothing at 128 KiB */
+/* two tiles in flight on two side streams: the wave-per-frame kernels of one tile beside the entropy kernels of the
+ * other (measured: 1 MiB blocks 95 -> 107 GB/s, where a tile has few frames; 128 KiB blocks 167 -> 173 GB/s,
+ * profiles/r03_zstd_variants.txt) */
 bool two_lanes(uint32_t block_size)
 {
     static const char *e = getenv("CRYO_ZSTD_LANES"); /* tuning aid: 1 / 2 */
     if (e && e[0] == '1') return false;
-    if (e && e[0] == '2') return true;
-    return block_size > (256u << 10);
+    (void)block_size;
+    return true;
 }
 
-bool use_pipeline(uint64_t n_blocks)
-{
-    static const char *e = getenv("CRYO_ZSTD_PIPE"); /* 0 = always fused, 1 = always pipeline (testing) */
-    if (e && e[0] == '0') return false;
-    if (e && e[0] == '1') return true;
-    return n_blocks >= 16u;
-}
+/* path: 0 automatic, 1 the fused one-wave-per-frame kernel, 2 the pipeline (CRYO_OPT_ZSTD_DECODE_PATH).  Automatic =
+ * the pipeline for every batch: measured on 1 .. 64 blocks (profiles/r03_zstd_small_batches.txt) its lane-per-stream
+ * entropy stages beat the fused kernel's wave-serial loops even for ONE frame (128 KiB: 5.5 against 8.0 ms, 1 MiB: 12.1
+ * against 64.7 ms); the fused kernel decodes what the planner calls irregular. */
+bool use_pipeline(int path) { return path != 1; }
 
 } // namespace
 
-size_t zstd_decompress_workspace(uint64_t n_blocks, uint32_t block_size)
+size_t zstd_decompress_workspace(uint64_t n_blocks, uint32_t block_size, int path)
 {
-    if (!use_pipeline(n_blocks)) return zstd_fused_workspace(n_blocks);
+    if (!use_pipeline(path)) return zstd_fused_workspace(n_blocks);
     const Layout y = make_layout(n_blocks, block_size);
     return ((two_lanes(block_size) && n_blocks > y.F) ? 2u : 1u) * y.total + 256;
 }
@@ -1059,10 +1066,10 @@ size_t zstd_decompress_workspace(uint64_t n_blocks, uint32_t block_size)
 hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                   const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                   uint32_t block_size, uint64_t n_blocks, int32_t *d_status,
-                                  void *d_workspace, size_t workspace_bytes, const ZstdAux *aux)
+                                  void *d_workspace, size_t workspace_bytes, const ZstdAux *aux, int path)
 {
     if (n_blocks == 0) return hipSuccess;
-    if (!use_pipeline(n_blocks))
+    if (!use_pipeline(path))
         return launch_zstd_fused(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status,
                                  d_workspace, workspace_bytes, nullptr, nullptr, 0);
     const Layout y = make_layout(n_blocks, block_size);

@@ -3,7 +3,7 @@
 
 Random structured blocks (mixtures of text-like rows, runs, repeats at random distances, noise) at several
 block sizes; the device encoders must equal the stock liblz4 / libzstd byte for byte (all LZ4 accelerations,
-zstd levels -5..10), and the device decoders must reproduce the input from streams the stock libraries wrote at
+zstd levels -5..10, 11 and 12 above 256 KiB), and the device decoders must reproduce the input from streams the stock libraries wrote at
 ANY level (zstd 1..19), through both zstd decode paths (fused for small batches, pipeline for large ones)."""
 import os, sys, time
 import numpy as np
@@ -11,6 +11,16 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle_lib
 from pg_cryogen_amd import Codec, METHOD_LZ4, METHOD_ZSTD
+from pg_cryogen_amd import codec as cc
+
+
+def rotate_paths(c, rng):
+    """every round picks the decode paths anew: LZ4 in-wave parse / sequence index with 1 .. 64 walkers per block /
+    automatic; zstd fused kernel / pipeline"""
+    path = int(rng.choice([cc.LZ4_PATH_AUTO, cc.LZ4_PATH_RING, cc.LZ4_PATH_INDEXED, cc.LZ4_PATH_INDEXED]))
+    c.set_option(cc.OPT_LZ4_DECODE_PATH, path)
+    c.set_option(cc.OPT_LZ4_INDEX_WALKERS, int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64])) if path == cc.LZ4_PATH_INDEXED else 0)
+    c.set_option(cc.OPT_ZSTD_DECODE_PATH, int(rng.choice([0, 1, 2])))
 
 
 def make_block(rng, n):
@@ -82,6 +92,7 @@ def fuzz(budget, seed):
     rounds = bad_streams = 0
     with Codec(0) as c:
         while time.time() < t_end:
+            rotate_paths(c, rng)
             B = int(rng.choice([4096, 20000, 131072, 300001]))
             base = [make_block(rng, B) for _ in range(4)]
             for method, name in ((METHOD_ZSTD, "zstd"), (METHOD_LZ4, "lz4")):
@@ -117,7 +128,8 @@ def main():
     rounds = checks = 0
     with Codec(0) as c:
         while time.time() < t_end:
-            B = int(rng.choice([131072, 131072, 1 << 20, 65547, 70000, 20000, 300001]))
+            rotate_paths(c, rng)
+            B = int(rng.choice([131072, 131072, 1 << 20, 65547, 70000, 20000, 300001, 9000, 200000]))
             n = int(rng.choice([3, 20, 40]))
             blocks = [make_block(rng, B) for _ in range(n)]
             accel = int(rng.choice([1, 1, 2, 9, 50, 300]))
@@ -131,8 +143,8 @@ def main():
             outs, st = c.decompress_blocks(METHOD_LZ4, got, B)
             assert (st == 0).all() and all(np.array_equal(o, b) for o, b in zip(outs, blocks)), ("lz4 dec", seed, rounds, B)
             checks += 2 * n
-            if B > 16384 and (B <= 131072 or B > 262144):
-                level = int(rng.choice([-5, -3, -1, 1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]))
+            if True:   # every size class of libzstd's parameter tables has kernels (levels -5 .. 8 / 10 / 10 / 12)
+                level = int(rng.choice([-5, -3, -1, 1, 1, 2, 3, 4, 5, 6, 7, 8] + ([9, 10] if B > 16384 else []) + ([11, 12] if B > 262144 else [])))
                 gotz = c.compress_blocks(METHOD_ZSTD, level, blocks)
                 for i in range(n):
                     exp = stock.zstd_compress(blocks[i], level)

@@ -22,7 +22,17 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
-def test_zstd_decode_golden_streams(codec):
+@pytest.fixture(params=["pipeline", "fused"])
+def zstd_path(request, codec):
+    """both decoders, whatever the batch size: the four-kernel pipeline (what every batch takes by default) and the fused
+    one-wave-per-frame kernel (what the pipeline hands its irregular frames to)"""
+    from pg_cryogen_amd import codec as cc
+    codec.set_option(cc.OPT_ZSTD_DECODE_PATH, 2 if request.param == "pipeline" else 1)
+    yield request.param
+    codec.set_option(cc.OPT_ZSTD_DECODE_PATH, 0)
+
+
+def test_zstd_decode_golden_streams(codec, zstd_path):
     streams = json.load(open(os.path.join(G, "streams.json")))["streams"]
     by_B = {}
     for s in streams:
@@ -37,7 +47,7 @@ def test_zstd_decode_golden_streams(codec):
             assert sha(o) == s["raw_sha256"], (B, s["dist"], s["param"])
 
 
-def test_zstd_decode_adversarial_matches_oracle(codec, oracle):
+def test_zstd_decode_adversarial_matches_oracle(codec, oracle, zstd_path):
     """malformed streams: the kernel's verdict and bytes equal the oracle's (which is pinned to
     libzstd by tests/test_oracle_golden.py)"""
     adv = json.load(open(os.path.join(G, "adversarial.json")))["cases"]
@@ -58,7 +68,7 @@ def test_zstd_decode_adversarial_matches_oracle(codec, oracle):
 
 
 @pytest.mark.parametrize("B", [131072, 1 << 20, 4096, 65546, 300])
-def test_zstd_decode_all_levels_live_library(codec, oracle, B):
+def test_zstd_decode_all_levels_live_library(codec, oracle, B, zstd_path):
     stock = oracle_lib.StockLibs()
     if stock.zstd is None:
         pytest.skip("libzstd.so.1 not loadable")
@@ -78,7 +88,7 @@ def test_zstd_decode_all_levels_live_library(codec, oracle, B):
         assert np.array_equal(o, raw)
 
 
-def test_zstd_decode_fuzz_matches_oracle(codec, oracle):
+def test_zstd_decode_fuzz_matches_oracle(codec, oracle, zstd_path):
     stock = oracle_lib.StockLibs()
     if stock.zstd is None:
         pytest.skip("libzstd.so.1 not loadable")
