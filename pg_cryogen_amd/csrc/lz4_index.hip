@@ -37,9 +37,6 @@ namespace cryo {
 #ifndef CRYO_IDX_RING
 #define CRYO_IDX_RING 512
 #endif
-#ifndef CRYO_IDX_LAT
-#define CRYO_IDX_LAT 1 /* rounds between a chunk's request and its commit (2 was round 2's: no faster, twice the slot registers) */
-#endif
 constexpr uint32_t kIdxLanes = 64, kIdxChunk = 128, kIdxRing = CRYO_IDX_RING;
 constexpr uint32_t kIdxStride = kIdxRing + 16u; /* bank skew between rings */
 
@@ -89,13 +86,10 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             const uint32_t logS, const uint32_t cap_main, const uint32_t ext, const uint32_t cap,
             uint2 *__restrict__ seg, uint16_t *__restrict__ dummy_base)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kIdxLanes * kIdxStride];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kIdxLanes * kIdxStride + kIdxLanes * 16u]; /* + a 16-byte trash slot per lane */
     /* the last 32 positions of every lane (two lines of 16: one being filled, one waiting for its store) + one slot
      * where a lane that records nothing writes */
     __shared__ __attribute__((aligned(16))) uint16_t s_pos[kIdxLanes][40];
-#ifdef CRYO_IDX_TRASH
-    __shared__ __attribute__((aligned(16))) uint8_t s_trash[kIdxLanes * 16u]; /* where a lane with nothing to commit stores */
-#endif
     const uint32_t lane = threadIdx.x;
     const uint32_t S = 1u << logS, cap_s = cap_main + ext;
     const uint64_t gl = (uint64_t)blockIdx.x * kIdxLanes + lane;
@@ -130,7 +124,6 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     uint32_t pos = gstart;                /* next byte to interpret */
     uint32_t requested = gstart & ~(kIdxChunk - 1u); /* chunks requested up to here (multiple of kIdxChunk) */
     uint32_t filled = requested;          /* chunks stored in the ring up to here */
-    uint32_t outst = 0, drop = 0;         /* chunks of this lane on their way; how many of them a restart of the ring disowned */
     uint32_t state = 0;                   /* 0 token, 1 literal-length extension, 2 match-length extension */
     uint32_t acc = 0, tm = 0;             /* literal length being accumulated; match nibble of the current token */
     uint32_t k = 0, ls = 0;               /* positions recorded; 16-entry lines of them stored */
@@ -150,24 +143,27 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
      * per round; two rounds of distance were measured equal within noise -- 8.81 against 8.94 ms per headline call --
      * and cost twice the slot registers and predicate masks, which the compiler spilled).
      * Separate variables, not arrays: the compiler kept an indexed array in scratch memory. */
-#define IDX_SLOT(n) uint4 fd##n = make_uint4(0, 0, 0, 0), fe##n = fd##n; uint32_t fa##n = 0, fb##n = 0; bool fp##n = false, fq##n = false, fo##n = false;
-    IDX_SLOT(0) IDX_SLOT(1) IDX_SLOT(2) IDX_SLOT(3) IDX_SLOT(4) IDX_SLOT(5) IDX_SLOT(6) IDX_SLOT(7)
+#define IDX_SLOT(n) uint4 fd##n = make_uint4(0, 0, 0, 0), fe##n = fd##n; uint32_t fa##n = 0, fb##n = 0;
+    IDX_SLOT(0) IDX_SLOT(1) IDX_SLOT(2) IDX_SLOT(3)
 #undef IDX_SLOT
+    fa0 = fb0 = fa1 = fb1 = fa2 = fb2 = fa3 = fb3 = kIdxLanes * kIdxStride + lane * 16u; /* nothing requested yet: the trash slot */
 
-    auto turn = [&](const uint32_t j, uint4 &fd, uint4 &fe, uint32_t &fa, uint32_t &fb, bool &fp, bool &fq, bool &fpo,
+    uint32_t out128 = 0; /* 128 while a chunk of this lane is on its way (one round), else 0 */
+    constexpr uint32_t kTrash = kIdxLanes * kIdxStride; /* s_ring + kTrash + 16 * lane: where a slot that asked for nothing commits */
+    auto turn = [&](const uint32_t j, uint4 &fd, uint4 &fe, uint32_t &fa, uint32_t &fb,
                     const uint64_t soff, const uint32_t sve, const uint64_t soff2, const uint32_t sve2) __attribute__((always_inline)) {
         const bool myturn = (lane >> 4) == j; /* lanes 16j..16j+15 */
-        /* ---- commit the chunks requested two rounds ago ---- */
-#ifdef CRYO_IDX_TRASH
-        *reinterpret_cast<uint4 *>(fp ? s_ring + fa : s_trash + lane * 16u) = fd;
-        *reinterpret_cast<uint4 *>(fq ? s_ring + fb : s_trash + lane * 16u) = fe;
-#else
-        if (fp) *reinterpret_cast<uint4 *>(s_ring + fa) = fd;
-        if (fq) *reinterpret_cast<uint4 *>(s_ring + fb) = fe;
-#endif
-        if (myturn && outst != 0u && fpo) { /* fpo: this lane did request in the turn being committed */
-            outst--;
-            if (drop != 0u) drop--; else filled += kIdxChunk;
+        /* ---- commit what the slot's loads of a round ago brought (to the trash slot if they were idle re-reads) ----
+         * Everything per-lane in this turn is evaluated EAGERLY (& and | on the predicates, selects instead of ifs): with
+         * && / || / if the compiler built exec-mask branches around one- and two-instruction bodies, 450 scalar mask
+         * instructions per round of 1160; a lone wave per SIMD issues one instruction per four cycles whatever its kind,
+         * so the pass is as long as its instruction count (round 3: 3.06 -> 2.4 ms for the headline batch). */
+        *reinterpret_cast<uint4 *>(s_ring + fa) = fd;
+        *reinterpret_cast<uint4 *>(s_ring + fb) = fe;
+        {
+            const uint32_t got = myturn ? out128 : 0u; /* this lane's chunk, if it asked for one, is in its ring now */
+            filled += got;
+            out128 -= got;
         }
         /* the hop's ring reads go out before the exchange below: one LDS round trip per turn, not two */
         const uint32_t w0 = *reinterpret_cast<const uint32_t *>(s_ring + rb + (pos & (kIdxRing - 4u)));
@@ -175,79 +171,88 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
         const uint32_t w2 = *reinterpret_cast<const uint32_t *>(s_ring + rb + ((pos + 8u) & (kIdxRing - 4u)));
         /* ---- request the next chunk of walkers 16j..16j+15 (one bpermute each: requested | want) ---- */
         {
-            const bool want = myturn && !done && requested < vend && pos + (kIdxRing - kIdxChunk) >= requested;
-            const uint32_t msg = requested | (want ? 1u : 0u);
-            fpo = want;
-            if (want) { requested += kIdxChunk; outst++; }
+            const bool want = myturn & !done & (requested < vend) & (pos + (kIdxRing - kIdxChunk) >= requested);
+            const uint32_t wi = want ? 1u : 0u;
+            const uint32_t msg = requested | wi;
+            requested += wi << 7;
+            out128 |= wi << 7;
             const uint32_t s1 = 16u * j + (lane >> 3), s2 = s1 + 8u;
             const uint32_t m1 = bperm(msg, s1), m2 = bperm(msg, s2);
             const uint32_t o1 = (m1 & ~1u) + piece16, o2 = (m2 & ~1u) + piece16;
-            fp = (m1 & 1u) != 0u;
-            fq = (m2 & 1u) != 0u;
-            fa = s1 * kIdxStride + (o1 & (kIdxRing - 1u));
-            fb = s2 * kIdxStride + (o2 & (kIdxRing - 1u));
+            const bool p1 = (m1 & 1u) != 0u, p2 = (m2 & 1u) != 0u;
+            fa = p1 ? s1 * kIdxStride + (o1 & (kIdxRing - 1u)) : kTrash + lane * 16u;
+            fb = p2 ? s2 * kIdxStride + (o2 & (kIdxRing - 1u)) : kTrash + lane * 16u;
             /* always two loads per turn (a lane with nothing to fetch re-reads its stream's first 16 bytes): with a
              * fixed number of vector-memory operations per turn the compiler can wait for exactly the chunks it
              * commits (vmcnt(N)); a conditional load made it drain the queue once per round (2.3 us a round) */
-            fd = *reinterpret_cast<const uint4 *>(src_base + (soff + ((fp && o1 < sve) ? o1 : 0u)));
-            fe = *reinterpret_cast<const uint4 *>(src_base + (soff2 + ((fq && o2 < sve2) ? o2 : 0u)));
+            fd = *reinterpret_cast<const uint4 *>(src_base + (soff + ((p1 & (o1 < sve)) ? o1 : 0u)));
+            fe = *reinterpret_cast<const uint4 *>(src_base + (soff2 + ((p2 & (o2 < sve2)) ? o2 : 0u)));
         }
         /* ---- one hop, branch-free for the two common states (token, match-length extension) ---- */
         {
             /* a walker ends at the first TOKEN position at or behind `stop` (the end of its segment; the stream's end
              * for a block's last walker) */
-            const bool live = !done && pos < vend && (pos < stop || state != 0u);
-            const bool canread = pos < requested && (pos + 8u <= filled || filled >= vend);
+            const uint32_t lim = state != 0u ? vend : stop;
+            const bool live = !done & (pos < lim);
+            const bool canread = (pos + 8u <= filled) | (filled >= vend); /* filled <= requested: nothing is read ahead of the requests */
             const uint32_t x = __builtin_amdgcn_alignbyte(w1, w0, pos & 3u);
-            const bool go = live && canread && state != 1u;
+            const bool go = live & canread;
             /* token */
             const uint32_t ll = (x >> 4) & 15u, e1 = (x >> 8) & 255u, tmn = x & 15u;
             const bool l15 = ll == 15u;
             const uint32_t q2 = pos + 3u + ll + (l15 ? e1 + 1u : 0u);  /* behind the literals and the offset */
-            const bool tok = go && state == 0u;
-            const bool longlit = tok && l15 && e1 == 255u;            /* 255-run: slow path below */
+            const bool tok = go & (state == 0u);
+            /* rare token forms leave the fast path: a literal length that goes on behind its first extension byte, and
+             * the stream's last sequence (literals only) */
+            const bool rare = tok & ((l15 & (e1 == 255u)) | (q2 > vend));
+            const bool plain = tok & !rare;
             /* match-length extension bytes */
             const uint32_t nx = ~x;
             const uint32_t n = nx ? (uint32_t)__builtin_ctz(nx) >> 3 : 4u; /* leading 0xFF bytes */
-            const uint32_t adv = n == 4u ? 4u : n + 1u;
-            const bool extb = go && state == 2u;
+            const bool extb = go & (state == 2u);
             /* record + advance */
-            const bool rec = tok;
-            pbuf[rec ? (k & 31u) : 32u] = (uint16_t)(pos - delta); /* unconditional: a store in a branch costs more than the branch saves */
-            if (rec) { k++; tm = tmn; }
-            const bool fin = tok && !longlit && q2 > vend;              /* last sequence: literals only */
-            if (tok && !longlit && !fin) { pos = q2; state = tmn == 15u ? 2u : 0u; }
+            pbuf[tok ? (k & 31u) : 32u] = (uint16_t)(pos - delta); /* unconditional: a store in a branch costs more than the branch saves */
+            k += tok ? 1u : 0u;
+            tm = tok ? tmn : tm;
+            const uint32_t st_tok = tmn == 15u ? 2u : 0u;
+            uint32_t npos = plain ? q2 : pos, nstate = plain ? st_tok : state;
             /* a second token in the same turn when the first one leaves it inside the eight bytes just read: no or
              * up to two literals and a short match (half of the sequences of tuple data) */
             {
-                const bool dbl = tok && !longlit && !fin && !l15 && tmn != 15u && ll <= 2u && q2 < stop && k < kcap;
-                const uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, (q2 - 3u - ll) & 3u); /* bytes 4..7 behind the first token */
+                const bool dbl = plain & !l15 & (tmn != 15u) & (ll <= 2u) & (q2 < stop) & (k < kcap);
+                const uint32_t x1 = __builtin_amdgcn_alignbyte(w2, w1, pos & 3u); /* bytes 4..7 behind the first token */
                 const unsigned long long xx = ((unsigned long long)x1 << 32) | x;
                 const uint32_t y = (uint32_t)(xx >> (8u * (3u + ll)));
                 const uint32_t llb = (y >> 4) & 15u, e1b = (y >> 8) & 255u, tmb = y & 15u;
                 const bool l15b = llb == 15u;
                 const uint32_t q2b = q2 + 3u + llb + (l15b ? e1b + 1u : 0u);
-                const bool rec2 = dbl && !(l15b && e1b == 255u);
+                const bool rec2 = dbl & !(l15b & (e1b == 255u));
                 pbuf[rec2 ? (k & 31u) : 32u] = (uint16_t)(q2 - delta);
-                if (rec2) {
-                    k++;
-                    tm = tmb;
-                    if (q2b > vend) done = true;
-                    else { pos = q2b; state = tmb == 15u ? 2u : 0u; }
-                }
+                k += rec2 ? 1u : 0u;
+                tm = rec2 ? tmb : tm;
+                const bool last2 = rec2 & (q2b > vend); /* the second token is the stream's last sequence */
+                const bool adv2 = rec2 & !last2;
+                npos = adv2 ? q2b : npos;
+                nstate = adv2 ? (tmb == 15u ? 2u : 0u) : nstate;
+                done = done | last2;
             }
-            if (extb) { pos += adv; state = n == 4u ? 2u : 0u; }
-            if (longlit) { state = 1u; acc = 15u + 255u; pos += 2u; }
-            if (fin || (!done && !live) || k >= kcap) done = true;
-            /* rare: literal-length 255-runs, and jumps over everything requested (a long literal run) */
-            const bool slow = !done && (state == 1u || pos >= requested) && !longlit;
+            npos = extb ? pos + (n == 4u ? 4u : n + 1u) : npos;
+            nstate = extb ? (n == 4u ? 2u : 0u) : nstate;
+            done = done | !live | (k >= kcap);
+            pos = npos;
+            state = nstate;
+            /* rare: the token forms above, literal-length 255-runs, and jumps over everything requested (a long literal run) */
+            const bool slow = rare | (!done & ((state == 1u) | (pos >= requested)));
             if (__any(slow)) {
-                if (slow && pos < vend) {
+                if (rare) {
+                    if (l15 && e1 == 255u) { state = 1u; acc = 15u + 255u; pos += 2u; }
+                    else done = true; /* q2 > vend: last sequence */
+                } else if (slow && pos < vend) {
                     if (pos >= requested) {
-                        /* restart the ring at the chunk of pos; a chunk still in flight lands in a slot that is
-                         * rewritten before it is read */
+                        /* restart the ring at the chunk of pos; a chunk still on its way lands in a slot that is
+                         * rewritten before it is read, and is not counted */
                         requested = filled = pos & ~(kIdxChunk - 1u);
-                        drop = outst;
+                        out128 = 0;
                     } else if (state == 1u && live && canread) {
                         if (n == 4u) { acc += 1020u; pos += 4u; if (acc >= vend) done = true; }
                         else {
@@ -261,7 +266,6 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             }
         }
     };
-
     /* Positions go out in whole 32-byte lines of 16, each line stored ONCE, when it is complete (a lane gains at most
      * eight positions per round, so one line per round keeps up; the line being filled meanwhile is the other half of
      * pbuf).  Round 2 stored aligned groups of four, three per round, again and again while they filled: 3.47 GB
@@ -292,24 +296,15 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             *reinterpret_cast<uint4 *>(pd_ + 8) = v1_;                                                       \
         }                                                                                                    \
     }
-#define IDX_TURN(j, n, sa, sb) turn(j, fd##n, fe##n, fa##n, fb##n, fp##n, fq##n, fo##n, saoff##sa, svend##sa, saoff##sb, svend##sb);
+#define IDX_TURN(j, n, sa, sb) turn(j, fd##n, fe##n, fa##n, fb##n, saoff##sa, svend##sa, saoff##sb, svend##sb);
 #define IDX_ROUND(a, b, c, d)                                   \
     IDX_PUT()                                                   \
     IDX_TURN(0, a, 0, 1) IDX_TURN(1, b, 2, 3) IDX_TURN(2, c, 4, 5) IDX_TURN(3, d, 6, 7)
-#if CRYO_IDX_LAT == 2
-#define IDX_WALK()                                              \
-    while (__any(!done)) {                                      \
-        IDX_ROUND(0, 1, 2, 3)                                   \
-        IDX_ROUND(4, 5, 6, 7)                                   \
-    }                                                           \
-    if (walker) IDX_FLUSH()
-#else
 #define IDX_WALK()                                              \
     while (__any(!done)) {                                      \
         IDX_ROUND(0, 1, 2, 3)                                   \
     }                                                           \
     if (walker) IDX_FLUSH()
-#endif
 
     /* ---- phase 1: every walker its own segment ---- */
     IDX_WALK()
@@ -363,7 +358,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             const bool redo = gfail && walker && sw == 0u;
             pos = delta;
             requested = filled = 0;
-            drop = outst;
+            out128 = 0; /* a chunk still on its way is not counted */
             state = 0; acc = 0; tm = 0; k = 0; ls = 0;
             stop = vend;
             kcap = S * cap_s - ext;
