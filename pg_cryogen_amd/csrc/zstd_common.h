@@ -163,10 +163,17 @@ struct LaneBits {
             const bool pending = (pend >> J) & 1u;
             uint4 v = slot<J>();
             const int32_t a = o_top - 16 * (int32_t)(written + 1u);
-            if (a < o_start) { /* zero the bytes below the stream start */
-                const int32_t k = o_start - a > 16 ? 16 : o_start - a;
-                auto m = [&](int32_t q) { const int32_t nz = k - 4 * q; return nz >= 4 ? 0u : (nz <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * nz)); };
-                v.x &= m(0); v.y &= m(1); v.z &= m(2); v.w &= m(3);
+            /* a block that reaches below the stream's first byte: once per stream, so the masks sit behind a branch the
+             * WAVE takes (left to the compiler they were 28 selects in every tick; +1.8 % on the zstd decode rate.
+             * Rows 0..1 mirrored behind row 31 to save the wrap arithmetic of fill() were measured too and lost 4 %: the
+             * two extra LDS stores per tick cost a lone wave more than six address instructions per fill,
+             * profiles/r03_zstd_variants.txt) */
+            if (__any(pending & (a < o_start))) {
+                if (a < o_start) { /* zero the bytes below the stream start */
+                    const int32_t k = o_start - a > 16 ? 16 : o_start - a;
+                    auto m = [&](int32_t q) { const int32_t nz = k - 4 * q; return nz >= 4 ? 0u : (nz <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * nz)); };
+                    v.x &= m(0); v.y &= m(1); v.z &= m(2); v.w &= m(3);
+                }
             }
             const uint32_t d0 = pending ? (uint32_t)(a >> 2) & 31u : 32u;
             ring[(d0 + 0u) * NL] = v.x;
