@@ -27,7 +27,9 @@ static double now(void)
 }
 
 /* ------------------------------------------------------------------------------------------------
- * One pass over n DISTINCT blocks, repeated `reps` times, median pass time: thread t
+ * `inner` passes over n DISTINCT blocks per timed region (1 for one thread; more with many threads, whose single pass
+ * over 4096 blocks is a millisecond: thread wake-up jitter then dominated, the all-core figure moved +-15 % between
+ * runs), repeated `reps` times, median region time: thread t
  * handles blocks i = t mod T with a private output buffer; a pass is timed from a common start to the
  * last thread's finish.  direction 0 = decode (src = compressed blocks at off[i], size[i] bytes each),
  * 1 = encode (src = raw blocks at off[i], B bytes each; `param` = lz4 acceleration / zstd level).
@@ -44,7 +46,7 @@ typedef struct {
     const uint64_t *off;
     const uint32_t *size;
     uint32_t n, B;
-    int t, T, method, stock, encode, param, reps;
+    int t, T, method, stock, encode, param, reps, inner;
     lz4_dec_fn lz4d; zstd_dec_fn zstdd; lz4_enc_fn lz4e; zstd_enc_fn zstde;
     int cpu;        /* >= 0: the CPU this thread pins itself to */
     pthread_barrier_t *bar;
@@ -69,8 +71,10 @@ static void *worker2(void *arg)
     for (r = 0; r < j->reps; r++) {
         uint32_t i;
         double t0;
+        int pass;
         pthread_barrier_wait(j->bar);
         t0 = now();
+        for (pass = 0; pass < j->inner; pass++)
         for (i = (uint32_t)j->t; out && i < j->n; i += (uint32_t)j->T) {
             const uint8_t *src = j->base + j->off[i];
             long res;
@@ -86,7 +90,7 @@ static void *worker2(void *arg)
                 else res = j->method == 0 ? (long)cryo_oracle_lz4_compress(src, j->B, out, cap, j->param)
                                           : (long)cryo_oracle_zstd_compress(src, j->B, out, cap, j->param);
                 if (res <= 0 || (size_t)res > cap) j->failed = 1;
-                if (r == 0) j->out_bytes += (uint64_t)res;
+                if (r == 0 && pass == 0) j->out_bytes += (uint64_t)res;
             }
         }
         pthread_barrier_wait(j->bar);
@@ -99,7 +103,7 @@ static void *worker2(void *arg)
 static int cmp_double(const void *a, const void *b) { return (*(const double *)a > *(const double *)b) - (*(const double *)a < *(const double *)b); }
 
 double cryo_oracle_cpu_pass_bench(int method, int encode, int stock, int param, const uint8_t *base, const uint64_t *off,
-                                  const uint32_t *size, uint32_t n, uint32_t B, int threads, const int *cpus, int reps,
+                                  const uint32_t *size, uint32_t n, uint32_t B, int threads, const int *cpus, int reps, int inner,
                                   uint64_t *out_bytes, char *version, size_t version_cap)
 {
     job2 proto;
@@ -112,6 +116,7 @@ double cryo_oracle_cpu_pass_bench(int method, int encode, int stock, int param, 
     if (version && version_cap) version[0] = 0;
     if (threads < 1) threads = 1;
     if (reps < 1) reps = 1;
+    if (inner < 1) inner = 1;
     if (stock) {
         void *h = dlopen(method == 0 ? "liblz4.so.1" : "libzstd.so.1", RTLD_NOW);
         const char *(*ver)(void);
@@ -142,6 +147,7 @@ double cryo_oracle_cpu_pass_bench(int method, int encode, int stock, int param, 
         jobs[t].t = t; jobs[t].T = threads; jobs[t].method = method; jobs[t].stock = stock; jobs[t].encode = encode;
         jobs[t].param = param; jobs[t].reps = reps; jobs[t].bar = &bar; jobs[t].pass_s = pass_s;
         jobs[t].cpu = cpus ? cpus[t] : -1;
+        jobs[t].inner = inner;
         pthread_create(&th[t], NULL, worker2, &jobs[t]);
     }
     if (out_bytes) *out_bytes = 0;
@@ -155,7 +161,7 @@ double cryo_oracle_cpu_pass_bench(int method, int encode, int stock, int param, 
     med = pass_s[reps / 2];
     free(th); free(jobs); free(pass_s);
     if (failed) return -2.0;
-    return (double)n * (double)B / med / 1e9;
+    return (double)n * (double)B * (double)inner / med / 1e9;
 }
 
 /* stock-library compression of n raw blocks with T threads into fixed-stride slots (bench.py's mixed workload:

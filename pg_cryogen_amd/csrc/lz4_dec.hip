@@ -277,7 +277,7 @@ template <uint32_t R, bool STATS>
 __global__ void __launch_bounds__(256, LZ4_WAVES_PER_SIMD) /* VGPR cap matching what the LDS budget admits */
 k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
-               uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats)
+               uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats, uint32_t only_heavy)
 {
     Stats st = {};
     st.on = STATS;
@@ -298,6 +298,7 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     /* wave-uniform values are forced into SGPRs so the parse runs on the scalar unit */
     const uint8_t *base = src_base + uni64(src_off[blk]);
     const uint32_t csize = uni(src_size[blk]);
+    if (only_heavy != 0u && !lz4_literal_heavy(csize, B)) return; /* the indexed decoder has this block (kernels.h) */
 
     Wave<R> w;
     const WaveLds<R> L = {s_ring[wid], s_in[wid], s_d1[wid], s_d2[wid], s_d4[wid],
@@ -575,7 +576,6 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
     if (n_blocks == 0) return hipSuccess;
     const uint64_t grid = (n_blocks + 3) / 4;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
-    const dim3 g((uint32_t)grid), b(256);
     /* sequence index pass + the decoder built for it (lz4_dec2.hip) */
     const uint32_t S = lz4_decode_plan(n_blocks, block_size, opts);
     if (S != 0) {
@@ -586,13 +586,14 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
 #ifdef CRYO_DEBUG
     static const bool want_stats = getenv("CRYO_LZ4_STATS") != nullptr; /* debugging aid */
     if (want_stats) {
+        const dim3 g((uint32_t)grid), b(256);
         unsigned long long *d_st = nullptr, h_st[16];
         static const unsigned long long abl = getenv("CRYO_LZ4_ABLATE") ? strtoull(getenv("CRYO_LZ4_ABLATE"), nullptr, 0) : 0ull;
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
         (void)hipMemcpyAsync(d_st + 7, &abl, sizeof abl, hipMemcpyHostToDevice, s);
         hipLaunchKernelGGL((k_lz4_dec_ring<4096, true>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
-                           block_size, n_blocks, d_status, d_st);
+                           block_size, n_blocks, d_status, d_st, 0u);
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
         (void)hipFree(d_st);
@@ -607,8 +608,17 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
         return hipGetLastError();
     }
 #endif
-    hipLaunchKernelGGL((k_lz4_dec_ring<4096, false>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
-                           block_size, n_blocks, d_status, nullptr);
+    return launch_lz4_dec_ring(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, false);
+}
+
+hipError_t launch_lz4_dec_ring(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
+                               uint8_t *d_dst, uint64_t dst_stride, uint32_t block_size, uint64_t n_blocks, int32_t *d_status,
+                               bool only_literal_heavy)
+{
+    const uint64_t grid = (n_blocks + 3) / 4;
+    if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((k_lz4_dec_ring<4096, false>), dim3((uint32_t)grid), dim3(256), 0, s, d_src, d_src_off, d_src_size, d_dst,
+                       dst_stride, block_size, n_blocks, d_status, nullptr, only_literal_heavy ? 1u : 0u);
     return hipGetLastError();
 }
 

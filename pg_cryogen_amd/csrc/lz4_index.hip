@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(64)
 k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
             const uint32_t *__restrict__ src_size, const uint64_t n_blocks, uint16_t *__restrict__ tbl,
             const uint32_t logS, const uint32_t cap_main, const uint32_t ext, const uint32_t cap,
-            uint2 *__restrict__ seg, uint16_t *__restrict__ dummy_base)
+            uint2 *__restrict__ seg, uint16_t *__restrict__ dummy_base, const uint32_t block_size)
 {
     __shared__ __attribute__((aligned(16))) uint8_t s_ring[kIdxLanes * kIdxStride + kIdxLanes * 16u]; /* + a 16-byte trash slot per lane */
     /* the last 32 positions of every lane (two lines of 16: one being filled, one waiting for its store) + one slot
@@ -114,7 +114,8 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
         seglen = (cs + seff - 1u) >> ls_;
     }
     if (!owner) aoff = src_off[0] & ~(uint64_t)127; /* a lane past the end of the batch re-reads block 0 */
-    const bool walker = owner && sw < seff;
+    /* with several walkers per block, blocks of almost only literals are not indexed: the in-wave parser decodes them (kernels.h) */
+    const bool walker = owner && sw < seff && !(logS != 0u && lz4_literal_heavy(vend - delta, block_size));
     const uint32_t gstart = delta + sw * seglen;                                    /* guessed (walker 0: true) start */
     uint32_t stop = (walker && sw + 1u < seff) ? delta + (sw + 1u) * seglen : vend; /* first position of the next segment */
     uint16_t *const rowbase = tbl + blk * cap;
@@ -333,12 +334,24 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
                         p = lz4_next_token_direct(sb, vend, p);
                     }
                 } else {
-                    j++;
-                    if (j < k_n) {
-                        const uint32_t e16 = __builtin_nontemporal_load(nrec + j);
-                        r += (e16 + delta - r) & 0xffffu; /* records are increasing, less than 64 KiB apart */
-                    } else if (j == k_n) r = e_n;         /* behind its last record walker s+1 stands on e_n */
-                    else { fail = true; merging = false; }
+                    /* p is ahead of the neighbour's record j: step through its records, sixteen per trip to memory (one
+                     * record per trip made literal-heavy streams, whose false chains record a position every ~7 bytes of
+                     * a long literal run, pay 500-1000 dependent trips here: 3.2 ms for 8 192 blocks) */
+                    if (j >= k_n) { fail = true; merging = false; } /* already behind e_n: the chains did not meet */
+                    else {
+                        uint4 va, vb;
+                        __builtin_memcpy(&va, nrec + j + 1u, 16); /* records j+1 .. j+16; beyond the count: never used */
+                        __builtin_memcpy(&vb, nrec + j + 9u, 16);
+                        const uint32_t w[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+                        for (uint32_t t = 0; t < 16u; t++) {
+                            const uint32_t e16 = (w[t >> 1] >> (16u * (t & 1u))) & 0xffffu;
+                            const bool step = (r < p) & (j + 1u < k_n);
+                            r += step ? ((e16 + delta - r) & 0xffffu) : 0u; /* records are increasing, less than 64 KiB apart */
+                            j += step ? 1u : 0u;
+                        }
+                        if ((r < p) & (j + 1u == k_n)) { j = k_n; r = e_n; } /* behind its last record walker s+1 stands on e_n */
+                    }
                 }
             }
         }
@@ -404,7 +417,7 @@ Lz4IndexLayout lz4_index_layout(uint64_t n_blocks, uint32_t block_size, uint32_t
 }
 
 hipError_t launch_lz4_index(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
-                            uint64_t n_blocks, void *d_workspace, const Lz4IndexLayout &L)
+                            uint64_t n_blocks, uint32_t block_size, void *d_workspace, const Lz4IndexLayout &L)
 {
     if (n_blocks == 0) return hipSuccess;
     const uint64_t grid = ((n_blocks << L.logS) + kIdxLanes - 1) / kIdxLanes;
@@ -412,7 +425,7 @@ hipError_t launch_lz4_index(hipStream_t s, const uint8_t *d_src, const uint64_t 
     uint8_t *ws = static_cast<uint8_t *>(d_workspace);
     hipLaunchKernelGGL(k_lz4_index, dim3((uint32_t)grid), dim3(64), 0, s, d_src, d_src_off, d_src_size, n_blocks,
                        reinterpret_cast<uint16_t *>(ws), L.logS, L.cap_main, L.ext, L.cap, reinterpret_cast<uint2 *>(ws + L.seg_off),
-                       reinterpret_cast<uint16_t *>(ws + L.dummy_off));
+                       reinterpret_cast<uint16_t *>(ws + L.dummy_off), block_size);
     return hipGetLastError();
 }
 

@@ -167,7 +167,7 @@ struct LaneBits {
              * WAVE takes (left to the compiler they were 28 selects in every tick; +1.8 % on the zstd decode rate.
              * Rows 0..1 mirrored behind row 31 to save the wrap arithmetic of fill() were measured too and lost 4 %: the
              * two extra LDS stores per tick cost a lone wave more than six address instructions per fill,
-             * profiles/r03_zstd_variants.txt) */
+             * profiles/r03_variants_ab.txt) */
             if (__any(pending & (a < o_start))) {
                 if (a < o_start) { /* zero the bytes below the stream start */
                     const int32_t k = o_start - a > 16 ? 16 : o_start - a;

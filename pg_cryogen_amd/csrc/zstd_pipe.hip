@@ -1039,7 +1039,7 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
 
 /* two tiles in flight on two side streams: the wave-per-frame kernels of one tile beside the entropy kernels of the
  * other (measured: 1 MiB blocks 95 -> 107 GB/s, where a tile has few frames; 128 KiB blocks 167 -> 173 GB/s,
- * profiles/r03_zstd_variants.txt) */
+ * profiles/r03_variants_ab.txt) */
 bool two_lanes(uint32_t block_size)
 {
     static const char *e = getenv("CRYO_ZSTD_LANES"); /* tuning aid: 1 / 2 */

@@ -8,12 +8,8 @@ f=glob.glob('/tmp/abk/**/*kernel_stats.csv',recursive=True)[0]
 print(' | '.join('%s %.3f ms'%(r['Name'].split('(')[0][-22:],float(r['AverageNs'])/1e6) for r in csv.DictReader(open(f)) if 'lz4_index' in r['Name'] or 'dec_seq' in r['Name'] or 'dec_ring' in r['Name']))
 PY
 }
-cp pg_cryogen_amd/libcryo_codec.so /tmp/B.so
+# (round 3: build A is loaded through CRYO_CODEC_LIB instead of being copied over the product library)
 echo "B: $(prof "$@")"
-cp pg_cryogen_amd/libcryo_codec_A.so pg_cryogen_amd/libcryo_codec.so
-echo "A: $(prof "$@")"
-cp /tmp/B.so pg_cryogen_amd/libcryo_codec.so
+echo "A: $(CRYO_CODEC_LIB=$(pwd)/pg_cryogen_amd/libcryo_codec_A.so prof "$@")"
 echo "B: $(prof "$@")"
-cp pg_cryogen_amd/libcryo_codec_A.so pg_cryogen_amd/libcryo_codec.so
-echo "A: $(prof "$@")"
-cp /tmp/B.so pg_cryogen_amd/libcryo_codec.so
+echo "A: $(CRYO_CODEC_LIB=$(pwd)/pg_cryogen_amd/libcryo_codec_A.so prof "$@")"
