@@ -83,9 +83,13 @@ struct ZPipe {
     uint32_t *seqt, *predef;
     uint8_t *lits;
     uint4 *seqs;
+    uint2 *chain; /* k_zchain's records: unread bits before the sequence | LL, OF, ML symbols (8 bits each) */
     uint32_t *counters; /* [0] sequence pool cursor, [1] Huffman items, [2] irregular frames, [3] sequence items,
                            [60] frames with more than one sequence block */
     uint32_t *hitems;
+    uint32_t *hitems2; /* blocks k_zhufw hands back to k_zhuf (counters[61]) */
+    uint8_t *htmp;     /* k_zhufw's scratch: the walkers' symbols before they are moved to the literal pool */
+    uint64_t htmp_stride;
     uint32_t *irregular;
     uint32_t *sitems; /* blocks with sequences (f * nbmax + k) */
     uint32_t *ritems; /* frames whose later blocks need their repeat offsets resolved */
@@ -209,7 +213,7 @@ __device__ bool plan_block(PlanLds &L, const ZPipe &P, PlanState &ps, const uint
         }
         if (lit_cursor + regen > P.litcap) return false; /* the frame would decode to more than B bytes */
         d.lit_mode = 2; d.lit_src = lit_cursor;
-        lit_cursor += (regen + 15u) & ~15u;
+        lit_cursor += (regen + 31u) & ~15u; /* 16 .. 31 spare bytes: k_zhufw finishes a block's literals with a whole 16-byte store */
         used = hdr + csize;
     }
     d.regen = regen;
@@ -500,17 +504,17 @@ __device__ inline void huf_octet(LaneBits<64> &lb, const HufTab &h, uint8_t *o, 
     }
 }
 
-__global__ void __launch_bounds__(64) k_zhuf(ZPipe P)
+__global__ void __launch_bounds__(64) k_zhuf(ZPipe P, const uint32_t *__restrict__ items, const uint32_t counter)
 {
     __shared__ __attribute__((aligned(16))) HufLds L;
     const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nitems = uni(P.counters[1]);
+    const uint32_t nitems = uni(P.counters[counter]);
     const uint32_t base = blockIdx.x * kHufPerWave;
     if (base >= nitems) return;
 
     /* stage the 16 first-level tables */
     for (uint32_t j = 0; j < kHufPerWave && base + j < nitems; j++) {
-        const uint32_t it = uni(P.hitems[base + j]);
+        const uint32_t it = uni(items[base + j]);
         const ZBlk *d = P.blks + it;
         const uint32_t f = it / P.nbmax;
         const uint32_t hlog = uni(d->huf_log);
@@ -542,7 +546,7 @@ __global__ void __launch_bounds__(64) k_zhuf(ZPipe P)
 
     const uint32_t j = lane >> 2, sid = lane & 3u;
     bool have = j < kHufPerWave && base + j < nitems;
-    const uint32_t it = have ? P.hitems[base + j] : P.hitems[base];
+    const uint32_t it = have ? items[base + j] : items[base];
     const ZBlk *d = P.blks + it;
     const uint32_t f = it / P.nbmax;
     const uint32_t nstreams = d->nstreams;
@@ -595,6 +599,338 @@ __global__ void __launch_bounds__(64) k_zhuf(ZPipe P)
         ok = lb.pos == 0; /* must end exactly */
     }
     if (have && !ok) atomicOr(&P.frames[f].flags, F_BAD);
+}
+
+/* per-lane input rings fed cooperatively by the wave (k_zhufw, k_zchain) */
+constexpr uint32_t kChRing = 128, kChStride = 144; /* ring + 8-byte mirror + pad */
+__device__ inline uint32_t bperm32(uint32_t v, uint32_t src_lane)
+{
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)(src_lane << 2), (int)v);
+}
+
+/* ------------------------------------------------------------------------------------------------ K2' */
+/* k_zhufw: a WAVE per block, 16 walkers per Huffman stream.
+ *
+ * k_zhuf keeps 16 blocks' tables in LDS for 64 lanes: 4 KiB of table per 4 lanes, two waves per CU, every symbol a
+ * dependent LDS lookup on a lone wave.  A prefix code resynchronises: a decoder started at a wrong bit position
+ * lands on a true symbol boundary after a few symbols and is identical to the true decoder from there on.  So here a
+ * stream's bits are cut into up to 16 segments of equal length; walker w starts at the GUESSED position (the first bit
+ * of segment w), decodes its segment and keeps going into the first kHwWin bits of segment w+1 until it stands on a
+ * position walker w+1 visited (a bitmap of the symbol starts inside that window, kept by every walker).  By induction
+ * from walker 0, whose start is true, walker w+1's symbols are true from that position on.  Symbols go to a scratch
+ * region per walker (their final position is not known before the walkers to the left are counted) and are moved to
+ * the literal pool by the wave at the end.  One table serves 64 lanes, nine waves fit a CU, and the kernel is bound by
+ * instruction issue instead of LDS capacity.
+ *
+ * Anything unusual -- a 12-bit table, a boundary that does not synchronise inside the window, a scratch region that
+ * overflows (symbol density more than twice the stream's average), counts that do not add up, a stream that does not
+ * end on its first bit -- puts the block on a second list that k_zhuf decodes afterwards, lane per stream as before:
+ * verdicts are k_zhuf's. */
+constexpr uint32_t kHwWin = 256;   /* bits of a segment's head in which the left neighbour must synchronise */
+constexpr uint32_t kHwSlack = 400; /* scratch bytes per walker beyond twice the average */
+constexpr uint32_t kHwBlockSlack = 64u * kHwSlack + 128u; /* + alignment: no two blocks' scratch in one 128-byte line */
+
+constexpr uint32_t kHwRing = 256, kHwStride = 272; /* four half-lines per walker: eight symbols a turn can eat 11 bytes */
+
+/* decoding table, two symbols per lookup where the second one's code fits behind the first in the 11 bits looked at
+ * (libzstd's "X2" idea): symbol 1 | symbol 2 << 8 (0 if none) | length 1 << 16 | bits of both << 20 | symbols - 1 << 24 */
+struct HufwLds {
+    uint32_t tbl[1u << kHufL1];
+    uint8_t ring[64 * kHwStride + 64 * 16];
+    uint32_t bm[65][kHwWin / 32];
+    uint32_t skip[65];
+};
+
+struct HwLane {
+    int32_t s0, pos, cb, lowh, fillh;
+    uint32_t pend;
+};
+
+/* the ring feed of k_zchain for 64 walkers of ONE frame: turn J serves walkers 16 J .. 16 J + 15 */
+template <int J>
+__device__ inline void hw_feed(uint8_t *ring, HwLane &z, const uint32_t lane, const bool alive, uint4 &fd, uint32_t &fa, uint32_t &fm,
+                               const uint8_t *gsrc, const uint32_t vend)
+{
+    *reinterpret_cast<uint4 *>(ring + fa) = fd;
+    *reinterpret_cast<uint2 *>(ring + fm) = make_uint2(fd.x, fd.y);
+    const uint32_t got = (z.pend >> J) & 1u;
+    z.fillh -= (int32_t)got;
+    z.pend &= ~(1u << J);
+    /* room: the half-line this one replaces in the ring lies wholly above the reader */
+    const bool want = alive & ((lane >> 4) == (uint32_t)J) & (z.cb < 64 * (z.lowh + (int32_t)(kHwRing / 64u) - 1)) & (64 * z.lowh > z.s0);
+    const uint32_t wi = want ? 1u : 0u;
+    z.lowh -= (int32_t)wi;
+    z.pend |= wi << J;
+    const uint32_t srv = 16u * J + (lane >> 2);
+    const uint32_t m = bperm32((uint32_t)z.lowh | (wi << 31), srv);
+    const bool p = (m >> 31) != 0u;
+    const uint32_t o = ((m & 0x7FFFFFFFu) << 6) + (lane & 3u) * 16u;
+    const uint32_t tr = 64u * kHwStride + lane * 16u;
+    fa = p ? srv * kHwStride + (o & (kHwRing - 1u)) : tr;
+    fm = (p & ((o & (kHwRing - 1u)) == 0u)) ? srv * kHwStride + kHwRing : tr;
+    fd = *reinterpret_cast<const uint4 *>(gsrc + ((p & (o < vend)) ? o : 0u));
+}
+
+__device__ inline bool hw_ready(const HwLane &z) { return (z.cb - 16 >= 64 * z.fillh) | (64 * z.fillh <= z.s0); }
+
+__device__ inline uint64_t hw_window(const uint8_t *ring, const HwLane &z, const uint32_t myring)
+{
+    uint64_t r;
+    __builtin_memcpy(&r, ring + myring + ((uint32_t)(z.cb - 7) & (kHwRing - 1u)), 8);
+    return r << (7u - ((uint32_t)(z.pos - 1) & 7u));
+}
+
+/* the first n (< 16) bytes of v */
+__device__ inline void store_head(uint8_t *p, uint4 v, uint32_t n)
+{
+    if (n & 8u) { __builtin_memcpy(p, &v.x, 8); p += 8; v.x = v.z; v.y = v.w; }
+    if (n & 4u) { __builtin_memcpy(p, &v.x, 4); p += 4; v.x = v.y; }
+    if (n & 2u) { const uint16_t h = (uint16_t)v.x; __builtin_memcpy(p, &h, 2); p += 2; v.x >>= 16; }
+    if (n & 1u) *p = (uint8_t)v.x;
+}
+
+__global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
+{
+    __shared__ __attribute__((aligned(16))) HufwLds L;
+    const uint32_t lane = threadIdx.x & 63u;
+    if (blockIdx.x >= uni(P.counters[1])) return;
+    const uint32_t it = uni(P.hitems[blockIdx.x]);
+    const ZBlk *d = P.blks + it;
+    const uint32_t f = it / P.nbmax, kblk = it - f * P.nbmax;
+    const uint32_t hlog = uni(d->huf_log), nstreams = uni(d->nstreams), regen = uni(d->regen);
+    auto fallback = [&]() { if (lane == 0u) P.hitems2[atomicAdd(&P.counters[61], 1u)] = it; };
+    if (hlog > kHufL1 || hlog == 0u) { fallback(); return; }
+    {
+        /* the one-symbol table goes through the (still unused) rings */
+        const uint16_t *g = P.huf + ((uint64_t)f * P.nbmax + uni(d->huf_slot)) * kHufTblWords;
+        uint16_t *x1 = reinterpret_cast<uint16_t *>(L.ring);
+        for (uint32_t i = lane; i < (1u << hlog); i += 64u) x1[i] = g[i];
+        for (uint32_t i = lane; i < 65u * (kHwWin / 32u); i += 64u) (&L.bm[0][0])[i] = 0u;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        const uint32_t dsh = kHufL1 - hlog;
+        for (uint32_t i = lane; i < (1u << kHufL1); i += 64u) {
+            const uint32_t e1 = x1[i >> dsh], l1 = e1 >> 8;
+            const uint32_t e2 = x1[((i << l1) & ((1u << kHufL1) - 1u)) >> dsh], l2 = e2 >> 8;
+            const bool two = l1 + l2 <= kHufL1;
+            L.tbl[i] = (e1 & 255u) | (two ? (e2 & 255u) << 8 : 0u) | (l1 << 16) | ((two ? l1 + l2 : l1) << 20) | ((two ? 1u : 0u) << 24);
+        }
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+    }
+#ifdef CRYO_HW_PROF
+    uint64_t tprev = __builtin_amdgcn_s_memtime();
+#define HW_STAMP(k) do { const uint64_t tn = __builtin_amdgcn_s_memtime(); if (lane == 0u) atomicAdd(&P.counters[k], (uint32_t)((tn - tprev) >> 6)); tprev = tn; } while (0)
+#else
+#define HW_STAMP(k) do { } while (0)
+#endif
+    const uint32_t sid = lane >> 4, w = lane & 15u;
+    const uint32_t seg = (regen + 3u) / 4u;
+    uint32_t cnt, oofs;
+    if (nstreams == 1u) { cnt = regen; oofs = 0; }
+    else { cnt = sid < 3u ? seg : regen - 3u * seg; oofs = sid * seg; }
+    const uint64_t fo = uni64(P.src_off[P.first + f]);
+    const uint64_t aoff = fo & ~(uint64_t)63;
+    const uint32_t delta = (uint32_t)(fo & 63u);
+    const uint32_t vend = delta + uni(P.src_size[P.first + f]);
+    const uint8_t *gsrc = P.src_base + aoff;
+    const uint32_t soff = d->hs_off[sid < nstreams ? sid : 0u], slen = d->hs_len[sid < nstreams ? sid : 0u];
+    bool sok = sid < nstreams && slen >= 1u;
+    uint32_t last = 0;
+    if (sok) last = gsrc[delta + soff + slen - 1u];
+    if (last == 0u) sok = false;
+    if (__any(sid < nstreams && !sok)) { fallback(); return; } /* a stream without an end mark: k_zhuf says what it is */
+    /* segments */
+    const uint32_t T = sok ? (slen - 1u) * 8u + (31u - (uint32_t)__builtin_clz(last)) : 0u;
+    uint32_t se = T >> 11;
+    se = se < 1u ? 1u : (se > 16u ? 16u : se);
+    const uint32_t Lb = (T + se - 1u) / se;
+    const bool walker = sok && w < se;
+    const bool lastw = w + 1u == se;
+    const int32_t Pw = (int32_t)T - (int32_t)(w * Lb);
+    const int32_t bound = lastw ? 0 : Pw - (int32_t)Lb; /* first bit position of the next segment */
+    /* scratch: twice the average count + slack per walker */
+    const uint32_t avg = (cnt + se - 1u) / se;
+    const uint32_t cap = ((2u * avg + 15u) & ~15u) + kHwSlack - 48u;
+    uint8_t *const tbase = P.htmp + (uint64_t)f * P.htmp_stride + ((2u * (uint64_t)uni(d->lit_src) + 127u) & ~(uint64_t)127) + (uint64_t)kblk * kHwBlockSlack;
+    uint8_t *const tmp = tbase + 2u * oofs + sid * 16u * kHwSlack + w * (((2u * avg + 15u) & ~15u) + kHwSlack - 32u);
+    const uint32_t myring = lane * kHwStride;
+    HwLane z;
+    z.s0 = (int32_t)(delta + soff);
+    z.pos = walker ? Pw : 0;
+    z.cb = z.s0 + ((z.pos - 1) >> 3);
+    z.pend = 0;
+    {
+        const int32_t ht = z.cb >> 6;
+        const int32_t hl = ht >= 1 ? ht - 1 : 0;
+        if (walker)
+            for (int32_t h = hl; h <= ht; h++)
+                for (uint32_t q = 0; q < 4u; q++) {
+                    const uint32_t o = (uint32_t)h * 64u + q * 16u;
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    if (o < vend) v = *reinterpret_cast<const uint4 *>(gsrc + o);
+                    *reinterpret_cast<uint4 *>(L.ring + myring + (o & (kHwRing - 1u))) = v;
+                    if ((o & (kHwRing - 1u)) == 0u) *reinterpret_cast<uint2 *>(L.ring + myring + kHwRing) = make_uint2(v.x, v.y);
+                }
+        z.lowh = z.fillh = hl;
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    enum { MAIN = 0, EXT = 1, DONE = 2 };
+    uint32_t phase = walker ? MAIN : DONE;
+    bool okw = true;
+    uint32_t n = 0, sync_d = 0;
+    const uint32_t tr = 64u * kHwStride + lane * 16u;
+    uint4 fd0 = make_uint4(0, 0, 0, 0), fd1 = fd0, fd2 = fd0, fd3 = fd0;
+    uint32_t fa0 = tr, fa1 = tr, fa2 = tr, fa3 = tr, fm0 = tr, fm1 = tr, fm2 = tr, fm3 = tr;
+
+    /* one symbol, every check (the tail of a segment and the walk into the next one) */
+    auto slow = [&]() __attribute__((always_inline)) {
+        if (phase != DONE && hw_ready(z)) {
+            if (phase == MAIN && z.pos <= bound) { /* the symbol that starts here belongs to the next segment */
+                if (lastw) { phase = DONE; okw = z.pos == 0; }
+                else phase = EXT;
+            }
+            if (phase == EXT) {
+                const uint32_t dd = (uint32_t)(bound - z.pos);
+                if (dd >= kHwWin) { phase = DONE; okw = false; }
+                else if ((L.bm[lane + 1u][dd >> 5] >> (dd & 31u)) & 1u) { phase = DONE; sync_d = dd; }
+            }
+            if (phase != DONE) {
+                if (phase == MAIN) {
+                    const uint32_t dm = (uint32_t)(Pw - z.pos);
+                    if (dm < kHwWin) atomicOr(&L.bm[lane][dm >> 5], 1u << (dm & 31u));
+                }
+                const uint64_t c = hw_window(L.ring, z, myring);
+                const uint32_t e = L.tbl[(uint32_t)(c >> 32) >> (32u - kHufL1)];
+                z.pos -= (int32_t)((e >> 16) & 15u);
+                z.cb = z.s0 + ((z.pos - 1) >> 3);
+                if (n < cap && z.pos >= 0 && ((e >> 16) & 15u) != 0u) { tmp[n] = (uint8_t)e; n++; }
+                else { phase = DONE; okw = false; }
+            }
+        }
+    };
+    /* eight lookups = 8 .. 16 symbols, while more than 88 bits of the segment are left; MARK: inside the head window, where
+     * every symbol start is noted for the left neighbour.  Each half stores 8 bytes of which 4 .. 8 are symbols: the next
+     * store overwrites the rest. */
+    auto octet = [&](const bool mark) __attribute__((always_inline)) {
+        if (phase == MAIN && z.pos - bound > 88 && hw_ready(z)) {
+            if (n + 24u > cap) { phase = DONE; okw = false; }
+            else {
+#pragma unroll
+                for (int half = 0; half < 2; half++) {
+                    uint64_t c = hw_window(L.ring, z, myring);
+                    uint64_t acc = 0;
+                    uint32_t k = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t e = L.tbl[(uint32_t)(c >> 32) >> (32u - kHufL1)];
+                        const uint32_t lt = (e >> 20) & 15u;
+                        if (mark) {
+                            const uint32_t dm = (uint32_t)(Pw - z.pos);
+                            if (dm < kHwWin) atomicOr(&L.bm[lane][dm >> 5], 1u << (dm & 31u));
+                            const uint32_t dm2 = dm + ((e >> 16) & 15u);
+                            if ((e >> 24) != 0u && dm2 < kHwWin) atomicOr(&L.bm[lane][dm2 >> 5], 1u << (dm2 & 31u));
+                        }
+                        c <<= lt;
+                        z.pos -= (int32_t)lt;
+                        acc |= (uint64_t)(e & 0xFFFFu) << (8u * k);
+                        k += 1u + (e >> 24);
+                    }
+                    z.cb = z.s0 + ((z.pos - 1) >> 3);
+                    __builtin_memcpy(tmp + n, &acc, 8);
+                    n += k;
+                }
+            }
+        }
+    };
+#define HW_TURNS(BODY) \
+        hw_feed<0>(L.ring, z, lane, phase != DONE, fd0, fa0, fm0, gsrc, vend); BODY; \
+        hw_feed<1>(L.ring, z, lane, phase != DONE, fd1, fa1, fm1, gsrc, vend); BODY; \
+        hw_feed<2>(L.ring, z, lane, phase != DONE, fd2, fa2, fm2, gsrc, vend); BODY; \
+        hw_feed<3>(L.ring, z, lane, phase != DONE, fd3, fa3, fm3, gsrc, vend); BODY;
+    HW_STAMP(56);
+    /* ---- head: until every walker is past the window its left neighbour will search (short segments: symbol by symbol) ---- */
+    while (__any(phase == MAIN && (uint32_t)(Pw - z.pos) < kHwWin && z.pos - bound > 88)) { HW_TURNS(octet(true)) }
+    while (__any(phase == MAIN && (uint32_t)(Pw - z.pos) < kHwWin && z.pos > bound)) { HW_TURNS(slow()) }
+    HW_STAMP(57);
+    /* ---- body ---- */
+    while (__any(phase == MAIN && z.pos - bound > 88)) { HW_TURNS(octet(false)) }
+    HW_STAMP(58);
+    /* ---- tail: the rest of the segment, then on into the next one until the chains meet ---- */
+    while (__any(phase != DONE)) { HW_TURNS(slow()) }
+    HW_STAMP(59);
+#undef HW_TURNS
+    /* ---- who is true from where: walker w tells walker w+1 how many of its symbols lie before the meeting point ---- */
+    {
+        uint32_t sk = 0;
+        if (walker && !lastw && okw) {
+            for (uint32_t q = 0; q < kHwWin / 32u; q++) {
+                const uint32_t wd = L.bm[lane + 1u][q];
+                const uint32_t lo = q * 32u;
+                const uint32_t m = sync_d >= lo + 32u ? 0xFFFFFFFFu : (sync_d > lo ? (1u << (sync_d - lo)) - 1u : 0u);
+                sk += (uint32_t)__builtin_popcount(wd & m);
+            }
+        }
+        L.skip[lane + 1u] = sk;
+        if (w == 0u) L.skip[lane] = 0u; /* lane 16 k is also written by lane 16 k - 1 (a last walker: 0) */
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    const uint32_t myskip = (walker && w != 0u) ? L.skip[lane] : 0u;
+    const uint32_t ntrue = walker ? n - myskip : 0u;
+    const uint32_t incl = scan16_incl(ntrue);
+    const uint32_t total = (uint32_t)__shfl((int)incl, (int)(lane | 15u), 64);
+    const bool fine = (!walker || (okw && n >= myskip)) && (sid >= nstreams || total == cnt);
+    if (!__all(fine)) { fallback(); return; }
+    /* ---- move the walkers' symbols to the literal pool: eight segments' loads in flight ---- */
+    /* the scratch bytes other lanes of this wave stored are read below: the stores have to be done, nothing more -- no
+     * other wave touches a line of this block's scratch (an agent-scope fence writes the L2 back: 3x the kernel's time) */
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    uint8_t *const lit = P.lits + (uint64_t)f * P.litcap + uni(d->lit_src);
+    const uint32_t srcp = (uint32_t)(tmp - tbase) + myskip;
+    const uint32_t dstp = oofs + (incl - ntrue);
+    /* Whole 16-byte stores, segment after segment in the order of their destinations: what a segment's last store
+     * writes beyond its symbols is overwritten by the next segment's first store (same wave: in order), and behind a
+     * block's literals the pool has 16 spare bytes.  Four segments' loads are issued before the previous four are stored. */
+    const uint32_t o0 = lane * 16u;
+    uint4 va[4], vb[4], wa[4], wb[4];
+    auto loads = [&](uint4 (&xa)[4], uint4 (&xb)[4], const uint32_t sg) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t nn = lane_get(ntrue, sg + u);
+            const uint8_t *sp = tbase + lane_get(srcp, sg + u);
+            xa[u] = xb[u] = make_uint4(0, 0, 0, 0);
+            if (o0 < nn) __builtin_memcpy(&xa[u], sp + o0, 16); /* up to 15 bytes beyond the symbols: inside the walker's region */
+            if (o0 + 1024u < nn) __builtin_memcpy(&xb[u], sp + o0 + 1024u, 16);
+        }
+    };
+    auto stores = [&](const uint4 (&xa)[4], const uint4 (&xb)[4], const uint32_t sg) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const uint32_t nn = lane_get(ntrue, sg + u);
+            uint8_t *dp = lit + lane_get(dstp, sg + u);
+            if (o0 < nn) __builtin_memcpy(dp + o0, &xa[u], 16);
+            if (o0 + 1024u < nn) __builtin_memcpy(dp + o0 + 1024u, &xb[u], 16);
+            if (nn > 2048u) { /* rare: more than 2 KiB from one walker */
+                const uint8_t *sp = tbase + lane_get(srcp, sg + u);
+                for (uint32_t o = 2048u + o0; o < nn; o += 1024u) {
+                    uint4 v;
+                    __builtin_memcpy(&v, sp + o, 16);
+                    __builtin_memcpy(dp + o, &v, 16);
+                }
+            }
+        }
+    };
+    loads(va, vb, 0);
+#pragma unroll 1
+    for (uint32_t sg = 0; sg < 64u; sg += 8u) {
+        loads(wa, wb, sg + 4u);
+        stores(va, vb, sg);
+        if (sg + 8u < 64u) loads(va, vb, sg + 8u);
+        stores(wa, wb, sg + 4u);
+    }
+    HW_STAMP(62);
 }
 
 /* ------------------------------------------------------------------------------------------------ K3 */
@@ -813,6 +1149,352 @@ __global__ void __launch_bounds__(64) k_zrep(ZPipe P)
     }
 }
 
+/* ------------------------------------------------------------------------------------------------ K3' */
+/* k_zchain + k_zmat: the sequence stage split by what is serial in it.
+ *
+ * k_zseq does everything for a sequence on the one lane that owns the block: 321 instructions, and a lone wave per
+ * SIMD (LDS capacity: the decoding tables) issues one instruction every ~4.7 cycles -- the stage is as long as its
+ * instruction count.  What is serial in the FSE sequence stream is only the chain
+ *     three table entries -> bit counts -> position of the state bits -> next states -> next entries;
+ * the values (literal length, match length, offset = base + extra bits) and even the repeat-offset history are a
+ * function of (bit position, three symbols) per sequence and are computed afterwards, 64 sequences at a time, by a
+ * wave per frame (k_zmat) -- the history by a parallel scan over "history transforms".
+ *
+ * k_zchain, lane per block as before, 29 blocks' tables in LDS: per sequence it stores an 8-byte record (unread
+ * bits before the sequence | the three symbols), takes the state bits out of ONE 8-byte window read from the
+ * lane's ring (unaligned ds_read_b64; the rare sequence with more than 57 bits re-reads) and looks the next entries
+ * up: one LDS round trip and ~100 instructions per sequence.  The rings (128 bytes per lane, contiguous, first 8 bytes
+ * mirrored behind the end) are fed cooperatively like the LZ4 index pass's: in turn J the wave's 64 lanes load one
+ * 16-byte piece each for 16 walkers (4 lanes x 16 B = half a cache line per walker) that have room, and store it
+ * four turns later; every per-lane condition is evaluated eagerly. */
+#ifndef CRYO_ZCHAIN_PER_WAVE
+#define CRYO_ZCHAIN_PER_WAVE 29
+#endif
+constexpr uint32_t kChW = CRYO_ZCHAIN_PER_WAVE;
+static_assert(kChW <= 32, "two groups of 16 walkers");
+
+struct ChainLds {
+    uint16_t tab[kChW][kSeqTblWords];
+    uint8_t ring[32 * kChStride + 64 * 16]; /* + a 16-byte trash slot per lane */
+};
+
+struct ChainLane {
+    /* stream, in virtual byte positions (offset in the frame + delta, so that half-lines are 64-byte aligned in memory) */
+    int32_t s0;        /* first byte of the bitstream */
+    int32_t pos;       /* unread bits */
+    int32_t cb;        /* s0 + ((pos - 1) >> 3): the byte the top unread bit is in */
+    int32_t lowh, fillh; /* lowest half-line requested / in the ring */
+    uint32_t pend;     /* bit J: a request of this lane is in slot J */
+    uint32_t sl, so, sm;
+    uint32_t i, nseq;
+    uint32_t el, eo, em, sh;
+    uint64_t raw;
+};
+
+template <int J>
+__device__ inline void chain_turn(uint8_t *ring, const uint16_t *tab, ChainLane &z, const uint32_t lane, const bool mygroup,
+                                  uint4 &fd, uint32_t &fa, uint32_t &fm, const uint8_t *gsrc, const uint32_t svend,
+                                  const uint32_t srv_lane, const uint32_t srv_ring, uint2 *out, uint2 *trash,
+                                  const int32_t cl, const int32_t co, const int32_t cm, const uint32_t myring, bool &bad)
+{
+    /* ---- commit the piece slot J's load brought (to the trash slot if it was an idle re-read) ---- */
+    *reinterpret_cast<uint4 *>(ring + fa) = fd;
+    *reinterpret_cast<uint2 *>(ring + fm) = make_uint2(fd.x, fd.y);
+    {
+        const uint32_t got = (z.pend >> J) & 1u;
+        z.fillh -= (int32_t)got;
+        z.pend &= ~(1u << J);
+    }
+    /* ---- request the next half-line of the walkers of this turn's group ---- */
+    {
+        const bool want = mygroup & (z.i < z.nseq) & (z.cb < 64 * (z.lowh + 1)) & (64 * z.lowh > z.s0);
+        const uint32_t wi = want ? 1u : 0u;
+        z.lowh -= (int32_t)wi;
+        z.pend |= wi << J;
+        const uint32_t m = bperm32((uint32_t)z.lowh | (wi << 31), srv_lane);
+        const bool p = (m >> 31) != 0u;
+        const uint32_t o = ((m & 0x7FFFFFFFu) << 6) + (lane & 3u) * 16u;
+        const uint32_t slot = srv_ring + (o & (kChRing - 1u));
+        const uint32_t tr = 32u * kChStride + lane * 16u;
+        fa = p ? slot : tr;
+        fm = (p & ((o & (kChRing - 1u)) == 0u)) ? srv_ring + kChRing : tr;
+        /* always one load per turn (a lane with nothing to fetch re-reads its stream's first piece): a fixed number of
+         * vector-memory operations per turn lets the compiler wait for exactly the piece it commits */
+        fd = *reinterpret_cast<const uint4 *>(gsrc + ((p & (o < svend)) ? o : 0u));
+    }
+    /* ---- one sequence ---- */
+    {
+        const bool on = z.i < z.nseq;
+        const bool ready = (z.cb - 16 >= 64 * z.fillh) | (64 * z.fillh <= z.s0);
+        const bool go = on & ready;
+        const uint32_t el = z.el, eo = z.eo, em = z.em;
+        const uint32_t lsym = el >> 10, osym = eo >> 10, msym = em >> 10;
+        const uint32_t X = osym + ll_xbits(lsym) + ml_xbits(msym);
+        const uint32_t vl = el & 1023u, vm = em & 1023u, vo = eo & 1023u;
+        const bool lastq = z.i + 1u >= z.nseq;
+        const uint32_t nl = lastq ? 0u : (uint32_t)(__builtin_clz(vl) + cl), nm = lastq ? 0u : (uint32_t)(__builtin_clz(vm) + cm),
+                       no = lastq ? 0u : (uint32_t)(__builtin_clz(vo) + co);
+        const uint32_t N = nl + nm + no;
+        uint64_t win = z.raw << z.sh;
+        uint32_t W = (uint32_t)((win << X) >> 32);
+        const bool ovf = go & (X + N > 57u);
+        if (__any(ovf)) { /* more bits than one window holds: the state bits come from a second read */
+            if (ovf) {
+                const int32_t p2 = z.pos - (int32_t)X;
+                const int32_t cb2 = z.s0 + ((p2 - 1) >> 3);
+                uint64_t r2;
+                __builtin_memcpy(&r2, ring + myring + ((uint32_t)(cb2 - 7) & (kChRing - 1u)), 8);
+                W = (uint32_t)((r2 << (7u - ((uint32_t)(p2 - 1) & 7u))) >> 32);
+            }
+        }
+        const uint32_t bl = __builtin_amdgcn_ubfe(W, 32u - nl, nl), bm = __builtin_amdgcn_ubfe(W, 32u - nl - nm, nm),
+                       bo = __builtin_amdgcn_ubfe(W, 32u - N, no);
+        const uint32_t nsl = (vl << nl) - (1u << (cl + 31)) + bl;
+        const uint32_t nsm = (vm << nm) - (1u << (cm + 31)) + bm;
+        const uint32_t nso = (vo << no) - (1u << (co + 31)) + bo;
+        const int32_t npos = z.pos - (int32_t)(X + N);
+        uint2 *const op = go ? out + z.i : trash;
+        *op = make_uint2((uint32_t)z.pos, lsym | (osym << 8) | (msym << 16));
+        const bool keep = go & !lastq;
+        z.sl = keep ? nsl : z.sl;
+        z.sm = keep ? nsm : z.sm;
+        z.so = keep ? nso : z.so;
+        z.pos = go ? npos : z.pos;
+        z.i += go ? 1u : 0u;
+        const bool neg = go & (npos < 0); /* read past the start of the stream */
+        bad = bad | neg;
+        z.nseq = neg ? 0u : z.nseq;
+    }
+    /* ---- the next sequence's entries and window ---- */
+    {
+        z.cb = z.s0 + ((z.pos - 1) >> 3);
+        z.sh = 7u - ((uint32_t)(z.pos - 1) & 7u);
+        __builtin_memcpy(&z.raw, ring + myring + ((uint32_t)(z.cb - 7) & (kChRing - 1u)), 8);
+        z.el = tab[z.sl]; z.eo = tab[1024u + z.so]; z.em = tab[512u + z.sm];
+    }
+}
+
+__global__ void __launch_bounds__(64) k_zchain(ZPipe P)
+{
+    __shared__ __attribute__((aligned(16))) ChainLds L;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nitems = uni(P.counters[3]);
+    const uint32_t i0 = blockIdx.x * kChW;
+    if (i0 >= nitems) return;
+    for (uint32_t j = 0; j < kChW && i0 + j < nitems; j++) {
+        const uint32_t it = uni(P.sitems[i0 + j]);
+        const uint32_t fj = it / P.nbmax;
+        const ZBlk *d = P.blks + it;
+        const uint32_t slots = uni(d->slots), logs = uni(d->logs);
+#pragma unroll
+        for (int kind = 0; kind < 3; kind++) {
+            const uint32_t slot = (slots >> (8 * kind)) & 255u, lg = (logs >> (8 * kind)) & 255u;
+            const uint32_t goff = kind == 0 ? 0u : (kind == 1 ? 1024u : 512u);
+            const uint32_t *g = (slot == kPredefSlot ? P.predef : P.seqt + ((uint64_t)fj * P.nbmax + slot) * kSeqTblWords) + goff;
+            for (uint32_t q = lane; q < (1u << lg); q += 64u) { /* 25-bit workspace entry -> 16-bit LDS entry (SeqLds) */
+                const uint32_t e = g[q], nb = (e >> 10) & 15u;
+                L.tab[j][goff + q] = (uint16_t)((((e >> 14) & 63u) << 10) | (1u << (lg - nb)) | ((e & 1023u) >> nb));
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    bool act = lane < kChW && i0 + lane < nitems;
+    const uint32_t it = act ? P.sitems[i0 + lane] : P.sitems[i0];
+    const uint32_t f = it / P.nbmax;
+    const ZBlk *d = P.blks + it;
+    if (act && (P.frames[f].flags & (F_BAD | F_IRREG))) act = false;
+    const uint64_t fo = P.src_off[P.first + f];
+    const uint64_t aoff = fo & ~(uint64_t)63;
+    const uint32_t delta = (uint32_t)(fo & 63u);
+    const uint32_t vend = delta + P.src_size[P.first + f];
+    const uint32_t logs = d->logs;
+    const uint32_t sq_off = d->sq_off, sq_len = d->sq_len;
+    const uint8_t *gmine = P.src_base + aoff;
+    const uint32_t myring = (lane & 31u) * kChStride;
+    ChainLane z;
+    z.s0 = (int32_t)(delta + sq_off);
+    z.pos = 0; z.cb = z.s0; z.lowh = 0; z.fillh = 0; z.pend = 0; z.sl = z.so = z.sm = 0; z.i = 0; z.nseq = 0;
+    z.el = z.eo = z.em = 0; z.sh = 0; z.raw = 0;
+    bool bad = false;
+    bool opened = act && sq_len >= 1u;
+    uint32_t last = 0;
+    if (opened) last = gmine[delta + sq_off + sq_len - 1u];
+    if (last == 0u) opened = false;
+    if (act && !opened) bad = true;
+    const uint16_t *tab = L.tab[lane < kChW ? lane : 0u];
+    const int32_t cl = (int32_t)(logs & 255u) - 31, co = (int32_t)((logs >> 8) & 255u) - 31, cm = (int32_t)((logs >> 16) & 255u) - 31;
+    if (opened) {
+        /* the stream's top two half-lines, loaded by the lane itself */
+        const int32_t s1 = z.s0 + (int32_t)sq_len;
+        const int32_t ht = (s1 - 1) >> 6;
+        const int32_t hl = ht >= 1 ? ht - 1 : 0;
+        for (int32_t h = hl; h <= ht; h++)
+            for (uint32_t q = 0; q < 4u; q++) {
+                const uint32_t o = (uint32_t)h * 64u + q * 16u;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (o < vend) v = *reinterpret_cast<const uint4 *>(gmine + o);
+                *reinterpret_cast<uint4 *>(L.ring + myring + (o & (kChRing - 1u))) = v;
+                if ((o & (kChRing - 1u)) == 0u) *reinterpret_cast<uint2 *>(L.ring + myring + kChRing) = make_uint2(v.x, v.y);
+            }
+        z.lowh = z.fillh = hl;
+        z.nseq = d->nseq;
+        z.pos = (int32_t)(sq_len - 1u) * 8 + (31 - __builtin_clz(last));
+        /* initial states: LL, OF, ML from the top of the stream (<= 26 bits) */
+        const int32_t cb = z.s0 + ((z.pos - 1) >> 3);
+        uint64_t r;
+        __builtin_memcpy(&r, L.ring + myring + ((uint32_t)(cb - 7) & (kChRing - 1u)), 8);
+        const uint32_t W = (uint32_t)((r << (7u - ((uint32_t)(z.pos - 1) & 7u))) >> 32);
+        const uint32_t lgl = logs & 255u, lgo = (logs >> 8) & 255u, lgm = (logs >> 16) & 255u;
+        z.sl = __builtin_amdgcn_ubfe(W, 32u - lgl, lgl);
+        z.so = __builtin_amdgcn_ubfe(W, 32u - lgl - lgo, lgo);
+        z.sm = __builtin_amdgcn_ubfe(W, 32u - lgl - lgo - lgm, lgm);
+        z.pos -= (int32_t)(lgl + lgo + lgm);
+        if (z.pos < 0) { bad = true; z.nseq = 0; z.pos = 0; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    z.cb = z.s0 + ((z.pos - 1) >> 3);
+    z.sh = 7u - ((uint32_t)(z.pos - 1) & 7u);
+    __builtin_memcpy(&z.raw, L.ring + myring + ((uint32_t)(z.cb - 7) & (kChRing - 1u)), 8);
+    z.el = tab[z.sl]; z.eo = tab[1024u + z.so]; z.em = tab[512u + z.sm];
+
+    /* what this lane serves: group g = J & 1, walker 16 g + (lane >> 2), piece lane & 3 */
+    const uint32_t w0 = lane >> 2, w1 = 16u + (lane >> 2);
+    const uint64_t a0 = ((uint64_t)bperm32((uint32_t)(aoff >> 32), w0) << 32) | bperm32((uint32_t)aoff, w0);
+    const uint64_t a1 = ((uint64_t)bperm32((uint32_t)(aoff >> 32), w1) << 32) | bperm32((uint32_t)aoff, w1);
+    const uint32_t ve0 = bperm32(vend, w0), ve1 = bperm32(vend, w1);
+    const uint8_t *g0 = P.src_base + a0, *g1 = P.src_base + a1;
+    const uint32_t r0 = w0 * kChStride, r1 = w1 * kChStride;
+    const bool grp0 = lane < 16u, grp1 = (lane >> 4) == 1u;
+    uint2 *out = P.chain + (opened ? d->seq_base : 0u);
+    uint2 *trash = P.chain + P.seqcap + lane;
+    const uint32_t tr = 32u * kChStride + lane * 16u;
+    uint4 fd0 = make_uint4(0, 0, 0, 0), fd1 = fd0, fd2 = fd0, fd3 = fd0;
+    uint32_t fa0 = tr, fa1 = tr, fa2 = tr, fa3 = tr, fm0 = tr, fm1 = tr, fm2 = tr, fm3 = tr;
+    while (__any(z.i < z.nseq)) {
+        chain_turn<0>(L.ring, tab, z, lane, grp0, fd0, fa0, fm0, g0, ve0, w0, r0, out, trash, cl, co, cm, myring, bad);
+        chain_turn<1>(L.ring, tab, z, lane, grp1, fd1, fa1, fm1, g1, ve1, w1, r1, out, trash, cl, co, cm, myring, bad);
+        chain_turn<2>(L.ring, tab, z, lane, grp0, fd2, fa2, fm2, g0, ve0, w0, r0, out, trash, cl, co, cm, myring, bad);
+        chain_turn<3>(L.ring, tab, z, lane, grp1, fd3, fa3, fm3, g1, ve1, w1, r1, out, trash, cl, co, cm, myring, bad);
+    }
+    if (opened && z.pos != 0) bad = true; /* the bitstream must be consumed exactly */
+    if (bad) atomicOr(&P.frames[f].flags, F_BAD);
+}
+
+/* K3'': values and repeat offsets, one wave per frame, 64 sequences at a time.  A sequence changes the offset history
+ * (r0, r1, r2) by one of five "transforms" whose outputs are each either a constant (a fresh offset) or one of the
+ * inputs minus a small count, floored at 1 (the format's `rep0 - 1`, never 0); such transforms compose into the same
+ * shape, so the history in front of every sequence is an exclusive scan over the batch applied to the carry. */
+struct RepT { uint32_t tags, v0, v1, v2; }; /* tags: 2 bits per slot, 0..2 = input slot (v = count subtracted), 3 = constant v */
+
+__device__ inline uint32_t rep_apply(uint32_t tag, uint32_t v, uint32_t h0, uint32_t h1, uint32_t h2)
+{
+    const uint32_t h = tag == 0u ? h0 : (tag == 1u ? h1 : h2);
+    const uint32_t dec = h > v ? h - v : 1u;
+    return tag == 3u ? v : dec;
+}
+/* B after A */
+__device__ inline RepT rep_compose(const RepT &A, const RepT &B)
+{
+    RepT R;
+    uint32_t tags = 0;
+    auto one = [&](uint32_t tb, uint32_t vb, uint32_t &vout) -> uint32_t {
+        const uint32_t ta = (A.tags >> (2u * (tb & 3u))) & 3u; /* tb == 3: unused */
+        const uint32_t va = tb == 0u ? A.v0 : (tb == 1u ? A.v1 : A.v2);
+        const uint32_t cdec = va > vb ? va - vb : 1u;
+        const bool bconst = tb == 3u, aconst = ta == 3u;
+        vout = bconst ? vb : (aconst ? cdec : va + vb);
+        return bconst ? 3u : ta;
+    };
+    tags |= one(B.tags & 3u, B.v0, R.v0);
+    tags |= one((B.tags >> 2) & 3u, B.v1, R.v1) << 2;
+    tags |= one((B.tags >> 4) & 3u, B.v2, R.v2) << 4;
+    R.tags = tags;
+    return R;
+}
+
+__global__ void __launch_bounds__(64) k_zmat(ZPipe P)
+{
+    __shared__ uint32_t s_llb[36], s_mlb[53];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t f = blockIdx.x;
+    if (lane < 36u) s_llb[lane] = kLLBase[lane];
+    if (lane < 53u) s_mlb[lane] = kMLBase[lane];
+    __builtin_amdgcn_wave_barrier();
+    if (uni(P.frames[f].flags) & (F_BAD | F_IRREG)) return;
+    const uint32_t nblk = uni(P.frames[f].nblk);
+    const uint8_t *src = P.src_base + uni64(P.src_off[P.first + f]);
+    uint32_t h0 = 1, h1 = 4, h2 = 8; /* wave-uniform */
+    constexpr uint32_t kIdent = 0u | (1u << 2) | (2u << 4);
+    for (uint32_t k = 0; k < nblk; k++) {
+        const ZBlk *d = P.blks + (uint64_t)f * P.nbmax + k;
+        const uint32_t n = uni(d->nseq);
+        if (uni(d->type) != 2u || n == 0u) continue;
+        const uint2 *cr = P.chain + uni(d->seq_base);
+        uint4 *out = P.seqs + uni(d->seq_base);
+        const uint8_t *sq = src + uni(d->sq_off);
+        uint2 nx = make_uint2(0, 0);
+        if (lane < n) nx = cr[lane];
+        for (uint32_t base = 0; base < n; base += 64u) {
+            const bool on = base + lane < n;
+            const uint2 c = nx;
+            nx = make_uint2(0, 0);
+            if (base + 64u + lane < n) nx = cr[base + 64u + lane];
+            const uint32_t pos = c.x, lsym = c.y & 63u, osym = (c.y >> 8) & 31u, msym = (c.y >> 16) & 63u;
+            const uint32_t llb = ll_xbits(lsym), mlb = ml_xbits(msym);
+            const uint32_t lo = pos - osym, lo2 = lo - llb - mlb; /* valid frames: lo2 >= 0 */
+            uint32_t extra = 0, llv = 0, mlv = 0;
+            if (on) {
+                const uint64_t a = ld64v(sq + (lo >> 3)), b = ld64v(sq + (lo2 >> 3));
+                extra = (uint32_t)(a >> (lo & 7u)) & (uint32_t)((1ull << osym) - 1ull);
+                const uint32_t t = (uint32_t)(b >> (lo2 & 7u));
+                llv = t & ((1u << llb) - 1u);
+                mlv = (t >> llb) & ((1u << mlb) - 1u);
+            }
+            const uint32_t ll = s_llb[lsym < 36u ? lsym : 0u] + llv, ml = s_mlb[msym < 53u ? msym : 0u] + mlv;
+            const bool fresh = osym > 1u;
+            const uint32_t ll0 = lsym == 0u ? 1u : 0u;
+            const uint32_t idx = (osym == 1u ? 1u + extra : 0u) + ll0; /* repeat-offset index 0..3 */
+            const uint32_t v = ((1u << osym) - 3u) + extra;
+            RepT T;
+            if (!on || (!fresh && idx == 0u)) { T.tags = kIdent; T.v0 = T.v1 = T.v2 = 0; }
+            else if (fresh) { T.tags = 3u | (0u << 2) | (1u << 4); T.v0 = v; T.v1 = 0; T.v2 = 0; }
+            else if (idx == 1u) { T.tags = 1u | (0u << 2) | (2u << 4); T.v0 = T.v1 = T.v2 = 0; }
+            else if (idx == 2u) { T.tags = 2u | (0u << 2) | (1u << 4); T.v0 = T.v1 = T.v2 = 0; }
+            else { T.tags = 0u | (0u << 2) | (1u << 4); T.v0 = 1; T.v1 = 0; T.v2 = 0; }
+            /* inclusive scan */
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                RepT A;
+                A.tags = (uint32_t)__shfl_up((int)T.tags, s, 64);
+                A.v0 = (uint32_t)__shfl_up((int)T.v0, s, 64);
+                A.v1 = (uint32_t)__shfl_up((int)T.v1, s, 64);
+                A.v2 = (uint32_t)__shfl_up((int)T.v2, s, 64);
+                const RepT C = rep_compose(A, T);
+                if (lane >= (uint32_t)s) T = C;
+            }
+            /* history in front of this lane's sequence: the scan of the lanes before it applied to the carry */
+            RepT E;
+            E.tags = (uint32_t)__shfl_up((int)T.tags, 1, 64);
+            E.v0 = (uint32_t)__shfl_up((int)T.v0, 1, 64);
+            E.v1 = (uint32_t)__shfl_up((int)T.v1, 1, 64);
+            E.v2 = (uint32_t)__shfl_up((int)T.v2, 1, 64);
+            if (lane == 0u) { E.tags = kIdent; E.v0 = E.v1 = E.v2 = 0; }
+            const uint32_t p0 = rep_apply(E.tags & 3u, E.v0, h0, h1, h2);
+            const uint32_t p1 = rep_apply((E.tags >> 2) & 3u, E.v1, h0, h1, h2);
+            const uint32_t p2 = rep_apply((E.tags >> 4) & 3u, E.v2, h0, h1, h2);
+            const uint32_t cand = idx == 0u ? p0 : (idx == 1u ? p1 : (idx == 2u ? p2 : (p0 > 1u ? p0 - 1u : 1u)));
+            const uint32_t offset = fresh ? v : cand;
+            if (on) out[base + lane] = make_uint4(ll, ml, offset, 0u);
+            /* carry: the whole batch applied to the history */
+            const uint32_t tt = lane_get(T.tags, 63), t0 = lane_get(T.v0, 63), t1 = lane_get(T.v1, 63), t2 = lane_get(T.v2, 63);
+            const uint32_t n0 = rep_apply(tt & 3u, t0, h0, h1, h2), n1 = rep_apply((tt >> 2) & 3u, t1, h0, h1, h2),
+                           n2 = rep_apply((tt >> 4) & 3u, t2, h0, h1, h2);
+            h0 = uni(n0); h1 = uni(n1); h2 = uni(n2);
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------ K4 */
 namespace {
 
@@ -986,7 +1668,8 @@ namespace {
 
 struct Layout {
     uint32_t F, nbmax, litcap, seqcap;
-    size_t o_frames, o_blks, o_huf, o_seqt, o_predef, o_lits, o_seqs, o_cnt, o_hitems, o_irreg, o_sitems, o_ritems, o_fused, total;
+    size_t htmp_stride;
+    size_t o_frames, o_blks, o_huf, o_seqt, o_predef, o_lits, o_seqs, o_chain, o_cnt, o_hitems, o_hitems2, o_htmp, o_irreg, o_sitems, o_ritems, o_fused, total;
 };
 
 constexpr uint32_t kFusedGridForIrregular = 256;
@@ -998,14 +1681,15 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     Layout y;
     y.nbmax = B / kZBlockMax + 2u;
     if (y.nbmax > 254u) y.nbmax = 254u;
-    y.litcap = ((B + 15u) & ~15u) + 16u * y.nbmax;
-    const size_t per_frame = sizeof(ZFrame) + (size_t)y.nbmax * (sizeof(ZBlk) + kHufTblWords * 2u + kSeqTblWords * 4u + 4u) +
-                             y.litcap + (size_t)(B / 6u) * sizeof(uint4) /* sequence pool share */ + 4u;
+    y.litcap = ((B + 15u) & ~15u) + 32u * y.nbmax;
+    y.htmp_stride = al256(2u * (size_t)y.litcap + (size_t)y.nbmax * kHwBlockSlack);
+    const size_t per_frame = y.htmp_stride + sizeof(ZFrame) + (size_t)y.nbmax * (sizeof(ZBlk) + kHufTblWords * 2u + kSeqTblWords * 4u + 8u) +
+                             y.litcap + (size_t)(B / 6u) * (sizeof(uint4) + sizeof(uint2)) /* sequence pool share */ + 4u;
     /* Tile size.  K2 and K3 are bound by LDS capacity (two workgroups per CU, 512 per chip): 14848 frames
      * = 512 x 29 fill exactly one round of K3 (and 928 waves of 16 = two rounds of K2, the second 81 % full); the
      * workspace budget may force less. */
     static const size_t budget_env = getenv("CRYO_ZSTD_WS_MB") ? (size_t)atoll(getenv("CRYO_ZSTD_WS_MB")) << 20 : 0; /* tuning aid */
-    const size_t budget = budget_env ? budget_env : (size_t)10 << 30; /* per tile in flight; reached only by blocks > 128 KiB,
+    const size_t budget = budget_env ? budget_env : (size_t)16 << 30; /* per tile in flight; reached only by blocks > 128 KiB,
                                                                         whose tiles would otherwise be too few frames to fill K1/K4 */
     uint64_t F = budget / per_frame;
     constexpr uint64_t kTile = 512u * kSeqPerWave; /* one full round of K3 */
@@ -1027,8 +1711,11 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     y.o_predef = o; o = al256(o + kSeqTblWords * 4u);
     y.o_lits = o; o = al256(o + (size_t)y.F * y.litcap + 64u);
     y.o_seqs = o; o = al256(o + (size_t)y.seqcap * sizeof(uint4));
+    y.o_chain = o; o = al256(o + ((size_t)y.seqcap + 64u) * sizeof(uint2));
     y.o_cnt = o; o = al256(o + 256u);
     y.o_hitems = o; o = al256(o + (size_t)y.F * y.nbmax * 4u);
+    y.o_hitems2 = o; o = al256(o + (size_t)y.F * y.nbmax * 4u);
+    y.o_htmp = o; o = al256(o + (size_t)y.F * y.htmp_stride + 64u);
     y.o_irreg = o; o = al256(o + (size_t)y.F * 4u);
     y.o_sitems = o; o = al256(o + (size_t)y.F * y.nbmax * 4u);
     y.o_ritems = o; o = al256(o + (size_t)y.F * 4u);
@@ -1089,6 +1776,8 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
     static const uint32_t huf_pad = getenv("CRYO_ZHUF_PAD") ? (uint32_t)atoi(getenv("CRYO_ZHUF_PAD")) : 0u; /* tuning aid: extra LDS to cap occupancy */
     static const uint32_t seq_pad = getenv("CRYO_ZSEQ_PAD") ? (uint32_t)atoi(getenv("CRYO_ZSEQ_PAD")) : 0u;
     static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
+    static const bool old_seq = getenv("CRYO_ZSEQ_OLD") != nullptr;      /* A/B aid */
+    static const bool old_huf = getenv("CRYO_ZHUF_OLD") != nullptr;
     uint64_t t = 0;
     for (uint64_t first = 0; first < n_blocks; first += y.F, t++) {
         const int l = (int)(t % (uint64_t)nl);
@@ -1106,8 +1795,12 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
         P.predef = (uint32_t *)(ws + y.o_predef);
         P.lits = ws + y.o_lits;
         P.seqs = (uint4 *)(ws + y.o_seqs);
+        P.chain = (uint2 *)(ws + y.o_chain);
         P.counters = (uint32_t *)(ws + y.o_cnt);
         P.hitems = (uint32_t *)(ws + y.o_hitems);
+        P.hitems2 = (uint32_t *)(ws + y.o_hitems2);
+        P.htmp = ws + y.o_htmp;
+        P.htmp_stride = y.htmp_stride;
         P.irregular = (uint32_t *)(ws + y.o_irreg);
         P.sitems = (uint32_t *)(ws + y.o_sitems);
         P.ritems = (uint32_t *)(ws + y.o_ritems);
@@ -1116,9 +1809,18 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
         P.F = (uint32_t)(left < y.F ? left : y.F);
         if ((e = hipMemsetAsync(P.counters, 0, 256, st)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_zplan, dim3(P.F), dim3(64), 0, st, P);
-        hipLaunchKernelGGL(k_zhuf, dim3((P.F * P.nbmax + kHufPerWave - 1u) / kHufPerWave), dim3(64), huf_pad, st, P);
-        hipLaunchKernelGGL(k_zseq, dim3((P.F * P.nbmax + kSeqPerWave - 1u) / kSeqPerWave), dim3(64), seq_pad, st, P);
-        hipLaunchKernelGGL(k_zrep, dim3(P.F), dim3(64), 0, st, P);
+        if (old_huf) hipLaunchKernelGGL(k_zhuf, dim3((P.F * P.nbmax + kHufPerWave - 1u) / kHufPerWave), dim3(64), huf_pad, st, P, P.hitems, 1u);
+        else {
+            hipLaunchKernelGGL(k_zhufw, dim3(P.F * P.nbmax), dim3(64), huf_pad, st, P);
+            hipLaunchKernelGGL(k_zhuf, dim3((P.F * P.nbmax + kHufPerWave - 1u) / kHufPerWave), dim3(64), 0, st, P, P.hitems2, 61u);
+        }
+        if (old_seq) {
+            hipLaunchKernelGGL(k_zseq, dim3((P.F * P.nbmax + kSeqPerWave - 1u) / kSeqPerWave), dim3(64), seq_pad, st, P);
+            hipLaunchKernelGGL(k_zrep, dim3(P.F), dim3(64), 0, st, P);
+        } else {
+            hipLaunchKernelGGL(k_zchain, dim3((P.F * P.nbmax + kChW - 1u) / kChW), dim3(64), seq_pad, st, P);
+            hipLaunchKernelGGL(k_zmat, dim3(P.F), dim3(64), 0, st, P);
+        }
         hipLaunchKernelGGL(k_zexec, dim3(P.F), dim3(64), 0, st, P);
         const uint64_t fg = P.F < kFusedGridForIrregular ? P.F : kFusedGridForIrregular;
         e = launch_zstd_fused(st, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, fg, d_status,
@@ -1129,8 +1831,8 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
             uint32_t h[64];
             (void)hipMemcpyAsync(h, P.counters, sizeof h, hipMemcpyDeviceToHost, st);
             (void)hipStreamSynchronize(st);
-            fprintf(stderr, "[zstd pipe] tile %llu: frames %u seqs %u huf items %u irregular %u | huf log histogram:",
-                    (unsigned long long)first, P.F, h[0], h[1], h[2]);
+            fprintf(stderr, "[zstd pipe] tile %llu: frames %u seqs %u huf items %u (handed back by the walkers: %u) irregular %u | huf log histogram:",
+                    (unsigned long long)first, P.F, h[0], h[1], h[61], h[2]);
             for (int k = 1; k <= 12; k++) fprintf(stderr, " %d:%u", k, h[4 + k]);
             fprintf(stderr, " | LL log:");
             for (int k = 0; k <= 9; k++) fprintf(stderr, " %d:%u", k, h[20 + k]);
@@ -1138,7 +1840,7 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
             for (int k = 0; k <= 9; k++) fprintf(stderr, " %d:%u", k, h[32 + k]);
             fprintf(stderr, " | ML log:");
             for (int k = 0; k <= 9; k++) fprintf(stderr, " %d:%u", k, h[44 + k]);
-            fprintf(stderr, "\n");
+            fprintf(stderr, "\n[zstd pipe] k_zhufw wave time, units of 64 memtime ticks summed over waves: setup %u head %u body %u tail %u resolve+copy %u\n", h[56], h[57], h[58], h[59], h[62]);
         }
     }
     if (nl == 2) {
