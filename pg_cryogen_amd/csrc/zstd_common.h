@@ -421,47 +421,90 @@ __device__ int huf_read_table(LT &L, uint16_t *table, const uint8_t *src, const 
         if (nw < 0) return -1;
     }
     __builtin_amdgcn_wave_barrier();
-    /* weight statistics (wave-uniform over <= 255 weights) */
+    /* weight statistics, 64 weights at a time: how many symbols of every weight */
     uint32_t rank[kHufLogMax + 2];
 #pragma unroll
     for (int r = 0; r < kHufLogMax + 2; r++) rank[r] = 0;
-    uint32_t total = 0;
-    for (int i = 0; i < nw; i++) {
-        const uint32_t wv = uni(L.wts[i]);
-        if (wv >= (uint32_t)kHufLogMax) return -1;
+    for (int base = 0; base < nw; base += 64) {
+        const int i = base + (int)lane;
+        const bool on = i < nw;
+        const uint32_t wv = on ? L.wts[i] : 0u;
+        if (__any(on && wv >= (uint32_t)kHufLogMax)) return -1;
 #pragma unroll
-        for (int r = 0; r < kHufLogMax; r++) if (wv == (uint32_t)r) rank[r]++;
-        total += (1u << wv) >> 1;
+        for (int r = 1; r < kHufLogMax; r++) rank[r] += (uint32_t)__builtin_popcountll(__ballot(on && wv == (uint32_t)r));
     }
+    uint32_t total = 0;
+#pragma unroll
+    for (int r = 1; r < kHufLogMax; r++) total += rank[r] << (r - 1);
     if (total == 0u) return -1;
     const int log = (int)hb32(total) + 1;
     if (log > kHufLogMax) return -1;
     const uint32_t rest = (1u << log) - total;
     if ((rest & (rest - 1u)) != 0u) return -1;
     const uint32_t lastw = hb32(rest) + 1u;
-    L.wts[nw] = (uint8_t)lastw;
+    if (lane == 0u) L.wts[nw] = (uint8_t)lastw;
 #pragma unroll
     for (int r = 0; r < kHufLogMax + 1; r++) if (lastw == (uint32_t)r) rank[r]++;
     nw++;
     if (rank[1] < 2u || (rank[1] & 1u)) return -1;
-    uint32_t start[kHufLogMax + 2];
+    /* first cell and first place in the sorted symbol list of every weight class (cells: weight 1 first) */
     {
-        uint32_t nx = 0;
+        uint32_t nx = 0, ns = 0;
 #pragma unroll
-        for (int r = 1; r <= kHufLogMax; r++) { start[r] = nx; nx += rank[r] << (r - 1); }
-        start[0] = 0; start[kHufLogMax + 1] = 0;
+        for (int r = 1; r <= kHufLogMax; r++) {
+            if (lane == 0u) { L.wdt[r] = nx; L.wdt[16 + r] = ns; }
+            nx += rank[r] << (r - 1);
+            ns += rank[r];
+        }
     }
     __builtin_amdgcn_wave_barrier();
-    /* canonical fill: symbols in increasing order inside a weight; lanes cover each symbol's cells */
-    for (int i = 0; i < nw; i++) {
-        const uint32_t wv = uni(L.wts[i]);
-        if (wv == 0u) continue;
-        uint32_t st = 0;
+    asm volatile("" ::: "memory");
+    /* symbols sorted by (weight, symbol): a symbol's place = its class's first place + the symbols of its weight before it */
+    {
+        uint32_t run[kHufLogMax + 1];
+        {
+            uint32_t ns = 0;
 #pragma unroll
-        for (int r = 1; r <= kHufLogMax; r++) if (wv == (uint32_t)r) { st = start[r]; start[r] += (1u << wv) >> 1; }
-        const uint32_t len = (1u << wv) >> 1;
-        const uint16_t ent = (uint16_t)((uint32_t)i | (((uint32_t)log + 1u - wv) << 8));
-        for (uint32_t u = lane; u < len; u += 64u) table[st + u] = ent;
+            for (int r = 1; r <= kHufLogMax; r++) { run[r] = ns; ns += rank[r]; }
+        }
+        for (int base = 0; base < nw; base += 64) {
+            const int i = base + (int)lane;
+            const bool on = i < nw;
+            const uint32_t wv = on ? L.wts[i] : 0u;
+            uint32_t place = 0;
+#pragma unroll
+            for (int r = 1; r <= kHufLogMax; r++) {
+                const unsigned long long m = __ballot(on && wv == (uint32_t)r);
+                if (wv == (uint32_t)r) place = run[r] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                run[r] += (uint32_t)__builtin_popcountll(m);
+            }
+            if (on && wv != 0u) L.cell[place] = (uint8_t)i;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    /* canonical fill, two cells per lane: the cell's weight class from the class starts, the symbol from the sorted list */
+    {
+        uint32_t st[kHufLogMax + 1];
+        {
+            uint32_t nx = 0;
+#pragma unroll
+            for (int r = 1; r <= kHufLogMax; r++) { st[r] = nx; nx += rank[r] << (r - 1); }
+        }
+        uint32_t *t32 = reinterpret_cast<uint32_t *>(table);
+        for (uint32_t u0 = 2u * lane; u0 < (1u << log); u0 += 128u) {
+            uint32_t pair = 0;
+#pragma unroll
+            for (uint32_t h = 0; h < 2u; h++) {
+                const uint32_t u = u0 + h;
+                uint32_t cls = 1; /* the last non-empty class that starts at or below u */
+#pragma unroll
+                for (int q = 1; q <= kHufLogMax; q++) cls = (rank[q] != 0u && u >= st[q]) ? (uint32_t)q : cls;
+                const uint32_t sym = L.cell[L.wdt[16 + cls] + ((u - L.wdt[cls]) >> (cls - 1u))];
+                pair |= (sym | (((uint32_t)log + 1u - cls) << 8)) << (16u * h);
+            }
+            t32[u0 >> 1] = pair;
+        }
     }
     __builtin_amdgcn_wave_barrier();
     *hlog = log;

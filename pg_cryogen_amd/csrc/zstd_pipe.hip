@@ -144,12 +144,84 @@ __device__ inline void stage256(uint8_t *lds, const uint8_t *g, uint32_t avail, 
     asm volatile("" ::: "memory");
 }
 
+/* One FSE decoding table, built by the whole wave (libzstd's ZSTD_buildFSETable order: low-probability symbols from the
+ * top, then symbol after symbol at multiples of `step`; a cell's next-state number = the symbol's count + the cell's rank
+ * among the symbol's cells).  One lane per symbol for the counts, per cell for everything else; the entry goes to the
+ * workspace with the symbol's extra-bit count at bits 20..24 (copy_seq_table).  cell: 512 bytes, run / cum: 64 x u16. */
+__device__ inline bool fse_build_wave(uint8_t *cell, uint16_t *run, uint16_t *cum, const int16_t *norm, const int max_sym, const int log,
+                                      uint32_t *out, const int kind, const uint32_t lane)
+{
+    const uint32_t size = 1u << log, mask = size - 1u, step = (size >> 1) + (size >> 3) + 3u;
+    const int c = (int)lane <= max_sym ? (int)norm[lane] : 0;
+    const bool low = c == -1;
+    const uint32_t pc = c > 0 ? (uint32_t)c : 0u;
+    const unsigned long long lm = __ballot(low);
+    const uint32_t nlow = (uint32_t)__builtin_popcountll(lm);
+    const uint32_t incl = scan64_incl(pc);
+    const uint32_t total = lane_get(incl, 63);
+    if (total + nlow != size) return false;
+    const uint32_t high = size - 1u - nlow;
+    if (low) cell[size - 1u - __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u))] = (uint8_t)lane;
+    cum[lane] = (uint16_t)(incl - pc);
+    run[lane] = (uint16_t)(low ? 1u : pc);
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    uint32_t vbase = 0;
+    for (uint32_t j0 = 0; j0 < size; j0 += 64u) {
+        const uint32_t j = j0 + lane;
+        const uint32_t p = (j * step) & mask;
+        const bool valid = j < size && p <= high;
+        const unsigned long long m = __ballot(valid);
+        const uint32_t i = vbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        vbase += (uint32_t)__builtin_popcountll(m);
+        uint32_t lo = 0; /* the last symbol whose first rank is <= i: the i-th placed cell is its */
+#pragma unroll
+        for (uint32_t bstep = 32u; bstep >= 1u; bstep >>= 1) lo += cum[lo + bstep] <= i ? bstep : 0u;
+        if (valid) cell[p] = (uint8_t)lo;
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    for (uint32_t p0 = 0; p0 < size; p0 += 64u) {
+        const uint32_t p = p0 + lane;
+        const bool on = p < size;
+        const uint32_t sym = on ? cell[p] : 0xFFFFu;
+        unsigned long long rem = __ballot(on);
+        uint32_t r = 0, cnt = 1;
+        while (rem) {
+            const uint32_t s0 = lane_get(sym, (uint32_t)__builtin_ctzll(rem));
+            const unsigned long long m = __ballot(sym == s0);
+            if (sym == s0) {
+                r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                cnt = (uint32_t)__builtin_popcountll(m);
+            }
+            rem &= ~m;
+        }
+        const uint32_t ns = (on ? run[sym] : 1u) + r;
+        asm volatile("" ::: "memory");
+        if (on && r + 1u == cnt) run[sym] = (uint16_t)(ns + 1u);
+        asm volatile("" ::: "memory");
+        const uint32_t nb = (uint32_t)log - hb32(ns);
+        const uint32_t xb = kind == 0 ? kLLBits[sym < 36u ? sym : 0u] : (kind == 1 ? sym : kMLBits[sym < 53u ? sym : 0u]);
+        if (on) out[p] = ((ns << nb) - size) | (nb << 10) | (sym << 14) | (xb << 20);
+    }
+    __builtin_amdgcn_wave_barrier();
+    return true;
+}
+
+#ifdef CRYO_HW_PROF
+#define PL_STAMP(k) do { const uint64_t tn_ = __builtin_amdgcn_s_memtime(); if (lane == 0u) atomicAdd(&P.counters[k], (uint32_t)((tn_ - pl_t) >> 6)); pl_t = tn_; } while (0)
+#define PL_BEGIN() uint64_t pl_t = __builtin_amdgcn_s_memtime()
+#else
+#define PL_STAMP(k) do { } while (0)
+#define PL_BEGIN() do { } while (0)
+#endif
 /* K1: one compressed block's section headers -> descriptor + tables.  false = not plannable. */
 __device__ bool plan_block(PlanLds &L, const ZPipe &P, PlanState &ps, const uint8_t *src, const uint8_t *hs /* staged src[0..253) */,
                            uint32_t n, uint32_t boff,
                            uint32_t f, uint32_t k, uint32_t &lit_cursor, ZBlk &d, uint32_t lane)
 {
     if (n < 3u) return false;
+    PL_BEGIN();
     const uint32_t b0 = uni(hs[0]);
     const uint32_t type = b0 & 3u, fmt = (b0 >> 2) & 3u;
     uint32_t regen, used;
@@ -218,6 +290,7 @@ __device__ bool plan_block(PlanLds &L, const ZPipe &P, PlanState &ps, const uint
     }
     d.regen = regen;
 
+    PL_STAMP(17);
     /* sequences section header */
     uint32_t left = n - used;
     if (left < 1u) return false;
@@ -266,40 +339,25 @@ __device__ bool plan_block(PlanLds &L, const ZPipe &P, PlanState &ps, const uint
             } else if (!ps.fse_valid) return false; /* repeat without a previous table */
         }
         __builtin_amdgcn_wave_barrier();
-        {
-            const uint32_t kd = lane < 3u ? lane : 0u;
-            const int my_mode = kd == 0u ? bmode[0] : (kd == 1u ? bmode[1] : bmode[2]);
-            const int my_ms = kd == 0u ? bms[0] : (kd == 1u ? bms[1] : bms[2]);
-            const int my_lg = kd == 0u ? blg[0] : (kd == 1u ? blg[1] : blg[2]);
-            uint32_t *my_t = kd == 0u ? L.ll : (kd == 1u ? L.of : L.ml);
-            bool okb = true;
-            if (lane < 3u && my_mode == 2) {
-                okb = fse_spread(L.cell3[kd], L.nxt3[kd], L.norm3[kd], my_ms, my_lg);
-                if (okb) {
-                    const uint32_t size = 1u << my_lg;
-                    for (uint32_t i = 0; i < size; i++) {
-                        const uint32_t sy = L.cell3[kd][i];
-                        const uint32_t ns = L.nxt3[kd][sy];
-                        L.nxt3[kd][sy] = (uint16_t)(ns + 1u);
-                        const uint32_t nb = (uint32_t)my_lg - hb32(ns);
-                        my_t[i] = ((ns << nb) - size) | (nb << 10) | (sy << 14);
-                    }
-                }
-            }
-            if (__ballot(!okb) != 0ull) return false;
-        }
-        __builtin_amdgcn_wave_barrier();
+        PL_STAMP(18);
 #pragma unroll
         for (int kind = 0; kind < 3; kind++) {
-            if (bmode[kind] == 1 || bmode[kind] == 2) {
-                const uint32_t *lt = kind == 0 ? L.ll : (kind == 1 ? L.of : L.ml);
+            if (bmode[kind] == 2) { /* the whole wave builds the table, straight into the workspace */
                 const uint32_t goff = kind == 0 ? 0u : (kind == 1 ? 1024u : 512u);
-                copy_seq_table(gt + goff, lt, 1u << blg[kind], kind, lane);
+                if (!fse_build_wave(L.cell3[kind], L.nxt3[kind], L.nxt, L.norm3[kind], bms[kind], blg[kind], gt + goff, kind, lane)) return false;
                 ps.slot[kind] = k;
                 ps.log[kind] = (uint32_t)blg[kind];
+            } else if (bmode[kind] == 1) {
+                const uint32_t *lt = kind == 0 ? L.ll : (kind == 1 ? L.of : L.ml);
+                const uint32_t goff = kind == 0 ? 0u : (kind == 1 ? 1024u : 512u);
+                copy_seq_table(gt + goff, lt, 1u, kind, lane);
+                ps.slot[kind] = k;
+                ps.log[kind] = 0u;
             }
         }
+        PL_STAMP(19);
         __builtin_amdgcn_wave_barrier();
+        PL_STAMP(63);
         ps.fse_valid = true;
         if ((uint32_t)(ip - L.sw) > 248u) return false; /* descriptions longer than the staged window: not a layout the libraries produce */
         d.sq_off = boff + used + (uint32_t)(ip - L.sw);
@@ -626,11 +684,11 @@ __device__ inline uint32_t bperm32(uint32_t v, uint32_t src_lane)
  * overflows (symbol density more than twice the stream's average), counts that do not add up, a stream that does not
  * end on its first bit -- puts the block on a second list that k_zhuf decodes afterwards, lane per stream as before:
  * verdicts are k_zhuf's. */
-constexpr uint32_t kHwWin = 256;   /* bits of a segment's head in which the left neighbour must synchronise */
+constexpr uint32_t kHwWin = 512;   /* bits of a segment's head in which the left neighbour must synchronise (256: 1 block in 1 000 handed back) */
 constexpr uint32_t kHwSlack = 400; /* scratch bytes per walker beyond twice the average */
 constexpr uint32_t kHwBlockSlack = 64u * kHwSlack + 128u; /* + alignment: no two blocks' scratch in one 128-byte line */
 
-constexpr uint32_t kHwRing = 256, kHwStride = 272; /* four half-lines per walker: eight symbols a turn can eat 11 bytes */
+constexpr uint32_t kHwRing = 128, kHwStride = 144; /* four 32-byte units per walker; 16 bytes per turn arrive, eight lookups eat at most 11 */
 
 /* decoding table, two symbols per lookup where the second one's code fits behind the first in the 11 bits looked at
  * (libzstd's "X2" idea): symbol 1 | symbol 2 << 8 (0 if none) | length 1 << 16 | bits of both << 20 | symbols - 1 << 24 */
@@ -646,7 +704,8 @@ struct HwLane {
     uint32_t pend;
 };
 
-/* the ring feed of k_zchain for 64 walkers of ONE frame: turn J serves walkers 16 J .. 16 J + 15 */
+/* the ring feed of k_zchain for 64 walkers of ONE frame, in 32-byte units: turn J serves walkers 32 (J & 1) .. + 31, two
+ * lanes x 16 bytes each; lowh / fillh count units here */
 template <int J>
 __device__ inline void hw_feed(uint8_t *ring, HwLane &z, const uint32_t lane, const bool alive, uint4 &fd, uint32_t &fa, uint32_t &fm,
                                const uint8_t *gsrc, const uint32_t vend)
@@ -656,22 +715,22 @@ __device__ inline void hw_feed(uint8_t *ring, HwLane &z, const uint32_t lane, co
     const uint32_t got = (z.pend >> J) & 1u;
     z.fillh -= (int32_t)got;
     z.pend &= ~(1u << J);
-    /* room: the half-line this one replaces in the ring lies wholly above the reader */
-    const bool want = alive & ((lane >> 4) == (uint32_t)J) & (z.cb < 64 * (z.lowh + (int32_t)(kHwRing / 64u) - 1)) & (64 * z.lowh > z.s0);
+    /* room: the unit this one replaces in the ring lies wholly above the reader */
+    const bool want = alive & ((lane >> 5) == (uint32_t)(J & 1)) & (z.cb < 32 * (z.lowh + (int32_t)(kHwRing / 32u) - 1)) & (32 * z.lowh > z.s0);
     const uint32_t wi = want ? 1u : 0u;
     z.lowh -= (int32_t)wi;
     z.pend |= wi << J;
-    const uint32_t srv = 16u * J + (lane >> 2);
+    const uint32_t srv = 32u * (J & 1) + (lane >> 1);
     const uint32_t m = bperm32((uint32_t)z.lowh | (wi << 31), srv);
     const bool p = (m >> 31) != 0u;
-    const uint32_t o = ((m & 0x7FFFFFFFu) << 6) + (lane & 3u) * 16u;
+    const uint32_t o = ((m & 0x7FFFFFFFu) << 5) + (lane & 1u) * 16u;
     const uint32_t tr = 64u * kHwStride + lane * 16u;
     fa = p ? srv * kHwStride + (o & (kHwRing - 1u)) : tr;
     fm = (p & ((o & (kHwRing - 1u)) == 0u)) ? srv * kHwStride + kHwRing : tr;
     fd = *reinterpret_cast<const uint4 *>(gsrc + ((p & (o < vend)) ? o : 0u));
 }
 
-__device__ inline bool hw_ready(const HwLane &z) { return (z.cb - 16 >= 64 * z.fillh) | (64 * z.fillh <= z.s0); }
+__device__ inline bool hw_ready(const HwLane &z) { return (z.cb - 16 >= 32 * z.fillh) | (32 * z.fillh <= z.s0); }
 
 __device__ inline uint64_t hw_window(const uint8_t *ring, const HwLane &z, const uint32_t myring)
 {
@@ -761,12 +820,12 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
     z.cb = z.s0 + ((z.pos - 1) >> 3);
     z.pend = 0;
     {
-        const int32_t ht = z.cb >> 6;
-        const int32_t hl = ht >= 1 ? ht - 1 : 0;
+        const int32_t ht = z.cb >> 5;
+        const int32_t hl = ht >= 3 ? ht - 3 : 0;
         if (walker)
             for (int32_t h = hl; h <= ht; h++)
-                for (uint32_t q = 0; q < 4u; q++) {
-                    const uint32_t o = (uint32_t)h * 64u + q * 16u;
+                for (uint32_t q = 0; q < 2u; q++) {
+                    const uint32_t o = (uint32_t)h * 32u + q * 16u;
                     uint4 v = make_uint4(0, 0, 0, 0);
                     if (o < vend) v = *reinterpret_cast<const uint4 *>(gsrc + o);
                     *reinterpret_cast<uint4 *>(L.ring + myring + (o & (kHwRing - 1u))) = v;
@@ -1840,7 +1899,7 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
             for (int k = 0; k <= 9; k++) fprintf(stderr, " %d:%u", k, h[32 + k]);
             fprintf(stderr, " | ML log:");
             for (int k = 0; k <= 9; k++) fprintf(stderr, " %d:%u", k, h[44 + k]);
-            fprintf(stderr, "\n[zstd pipe] k_zhufw wave time, units of 64 memtime ticks summed over waves: setup %u head %u body %u tail %u resolve+copy %u\n", h[56], h[57], h[58], h[59], h[62]);
+            fprintf(stderr, "\n[zstd pipe] k_zhufw wave time, units of 64 memtime ticks summed over waves: setup %u head %u body %u tail %u resolve+copy %u\n[zstd pipe] k_zplan: literals section (Huffman table) %u, sequence headers %u, FSE tables %u, table copies %u\n", h[56], h[57], h[58], h[59], h[62], h[17], h[18], h[19], h[63]);
         }
     }
     if (nl == 2) {
