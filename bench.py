@@ -306,7 +306,7 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                                "kernel": ("k_lz4_index + k_lz4_dec_seq (one decode call)" if is_lz4
-                                          else "k_zplan+k_zhuf+k_zseq+k_zexec (one decode call)"),
+                                          else "k_zplan+k_zhufw+k_zchain+k_zmat+k_zexec (one decode call)"),
                                "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": algo_bytes}
             if want_cpu:
                 out["cpu_baseline"] = cpu_baseline(ora, np, 0 if is_lz4 else 1, False, param, cpu_comps, [len(c) for c in cpu_comps], B)

@@ -9,23 +9,25 @@
  * lane-equivalent) while the other lanes of the wave idle.  Across a batch those loops are
  * embarrassingly parallel, so here they run one LANE per stream:
  *
- *   K1 k_zplan  wave per frame   frame/block/section headers -> descriptors; Huffman and FSE decoding
- *                                tables built in LDS, stored to the workspace
- *   K2 k_zhuf   lane per stream  64 Huffman streams per wave (16 blocks x 4 streams), the 16 tables in
- *                                LDS; symbols go to the frame's literal pool
- *   K3 k_zseq   lane per block   FSE sequence decode -> (ll, ml, offset) records; 29 blocks per wave, their
- *                                tables (16-bit entries) in LDS.  Repeat offsets are resolved on the fly in a frame's first
- *                                block; k_zrep (lane per frame) resolves those of later blocks
- *   K4 k_zexec  wave per frame   sequence execution with the shared LZ copy engine (lz_common.h):
- *                                records are loaded 64 at a time, literals stream through the LDS
- *                                input ring, output ring in LDS, 1 KiB coalesced flushes
+ *   K1  k_zplan   wave per frame   frame/block/section headers -> descriptors; Huffman and FSE decoding tables built by
+ *                                  the whole wave, straight into the workspace
+ *   K2  k_zhufw   wave per block   Huffman literals, 16 walkers per stream from guessed bit positions (a prefix code
+ *                                  resynchronises), two symbols per lookup; k_zhuf (lane per stream, 16 blocks' tables
+ *                                  in LDS) takes what the walkers hand back
+ *   K3  k_zchain  lane per block   the serial part of the FSE sequence stream only: 29 blocks' tables (16-bit entries)
+ *                                  in LDS, 8 bytes per sequence out (bit position, the three states)
+ *   K3' k_zmat    wave per frame   values (base + extra bits) and repeat offsets of 512 sequences per round: the offset
+ *                                  history by a scan over "history transforms"
+ *   K4  k_zexec   wave per frame   sequence execution with the shared LZ copy engine (lz_common.h): 8-byte records
+ *                                  loaded 64 at a time, literals stream through the LDS input ring, output ring in
+ *                                  LDS, 1 KiB coalesced flushes
  *
  * Anything K1 does not recognise as "one well-formed frame of at most nbmax blocks" (concatenated or
  * skippable frames, malformed headers, pool exhaustion) is put on an irregular list and decoded by the
  * fused kernel afterwards, so coverage and error behaviour are exactly the fused decoder's.
  *
- * The batch is processed in tiles of F <= 14848 frames (one full round of K3, two of K2 on 256 CUs) so the
- * workspace stays bounded (~2.3 GiB for 128 KiB blocks).
+ * The batch is processed in tiles of F <= 14848 frames (one full round of K3 on 256 CUs), two tiles in flight, so the
+ * workspace stays bounded.
  */
 #include "zstd_common.h"
 #include "lz4_copy.h"
@@ -57,9 +59,7 @@ struct ZBlk { /* one zstd block of a frame; 128 bytes */
     uint32_t slots;          /* table slots: ll | of << 8 | ml << 16 */
     uint32_t logs;           /* table logs, same packing */
     uint32_t seq_base;       /* first record in the sequence pool */
-    uint32_t seq_first;      /* 1: first block of the frame with sequences (repeat offsets start at 1, 4, 8) */
-    uint32_t rep_out[3];     /* repeat offsets after this block (written by K3 for seq_first blocks, else by k_zrep) */
-    uint32_t pad[5];
+    uint32_t pad[9];
 };
 static_assert(sizeof(ZBlk) == 128, "descriptor size");
 
@@ -82,17 +82,16 @@ struct ZPipe {
     uint16_t *huf;
     uint32_t *seqt, *predef;
     uint8_t *lits;
-    uint4 *seqs;
-    uint2 *chain; /* k_zchain's records: unread bits before the sequence | LL, OF, ML symbols (8 bits each) */
+    uint2 *seqs;  /* offset (29 bits, larger ones as 2^29 - 1) | literal length << 29 (17 bits), match length << 14 (18 bits) */
+    uint2 *chain; /* k_zchain's records: unread bits before the sequence (20) | LL state << 20, OF state | ML state << 8 */
     uint32_t *counters; /* [0] sequence pool cursor, [1] Huffman items, [2] irregular frames, [3] sequence items,
-                           [60] frames with more than one sequence block */
+                           [61] blocks k_zhufw hands back */
     uint32_t *hitems;
     uint32_t *hitems2; /* blocks k_zhufw hands back to k_zhuf (counters[61]) */
     uint8_t *htmp;     /* k_zhufw's scratch: the walkers' symbols before they are moved to the literal pool */
     uint64_t htmp_stride;
     uint32_t *irregular;
     uint32_t *sitems; /* blocks with sequences (f * nbmax + k) */
-    uint32_t *ritems; /* frames whose later blocks need their repeat offsets resolved */
 };
 
 struct PlanLds {
@@ -480,14 +479,8 @@ __global__ void __launch_bounds__(64) k_zplan(ZPipe P)
                     P.hitems[atomicAdd(&P.counters[1], 1u)] = f * P.nbmax + k;
                     atomicAdd(&P.counters[4 + (bd[k].huf_log & 15u)], 1u); /* histogram of table logs (diagnostics) */
                 }
-            uint32_t nsb = 0;
             for (uint32_t k = 0; k < nblk; k++)
-                if (bd[k].type == 2u && bd[k].nseq) {
-                    bd[k].seq_first = nsb == 0u ? 1u : 0u;
-                    nsb++;
-                    P.sitems[atomicAdd(&P.counters[3], 1u)] = f * P.nbmax + k;
-                }
-            if (nsb > 1u) P.ritems[atomicAdd(&P.counters[60], 1u)] = f;
+                if (bd[k].type == 2u && bd[k].nseq) P.sitems[atomicAdd(&P.counters[3], 1u)] = f * P.nbmax + k;
             for (uint32_t k = 0; k < nblk; k++)
                 if (bd[k].type == 2u && bd[k].nseq) {
                     atomicAdd(&P.counters[20 + (bd[k].logs & 15u)], 1u);
@@ -993,38 +986,6 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
 }
 
 /* ------------------------------------------------------------------------------------------------ K3 */
-#ifndef CRYO_ZSEQ_PER_WAVE
-#define CRYO_ZSEQ_PER_WAVE 29
-#endif
-constexpr uint32_t kSeqPerWave = CRYO_ZSEQ_PER_WAVE; /* frames per wave: 29 x 2.5 KiB of decoding tables in LDS, 2 workgroups per CU */
-
-/* K3 is bound by LDS capacity (frames in flight per CU = LDS / table bytes per frame; the per-sequence chain
- * entry -> bit count -> state bits -> next entry is serial), so the tables are staged as 16-bit entries:
- * symbol (6 bits) | v (10 bits), v = 1 << (log - nb) | base >> nb -- a next-state base is a multiple of 2^nb by
- * construction ((nextState << nb) - size), so the position of v's top bit gives nb and the rest gives the base.
- * The extra-bit counts come from the symbol by arithmetic (seq_xbits), not from the entry. */
-struct SeqLds {
-    uint16_t tab[kSeqPerWave][kSeqTblWords];
-    uint32_t ring[36][32];
-    uint32_t llx[36], mlx[53]; /* base value | extra bits << 24 (LDS copies: a constant-memory load in the loop
-                                  would wait on the ring's in-flight global loads as well) */
-};
-
-struct SeqState {
-    uint32_t sl, so, sm, rep0, rep1, rep2;
-};
-
-/* nb <= 31 bits off the top of the container */
-__device__ inline uint32_t seq_bits(LaneBits<32> &lb, uint32_t nb)
-{
-    const uint32_t v = __builtin_amdgcn_ubfe((uint32_t)(lb.c >> 32), 32u - nb, nb);
-    lb.skip(nb);
-    return v;
-}
-
-constexpr uint32_t kRepPending = 0x80000000u; /* record.z = kRepPending | repeat index 0..3 */
-struct SeqPre { uint32_t el, eo, em; }; /* table entries of the next sequence, already on their way from LDS */
-
 /* extra bits of a literal-length / match-length code: 0 below 16 / 32, a packed nibble table for the next 9 / 11
  * codes, code - 19 / code - 36 above (the format's tables, RFC 8878 3.1.1.3.2.1.1) */
 __device__ inline uint32_t ll_xbits(uint32_t sym)
@@ -1040,178 +1001,10 @@ __device__ inline uint32_t ml_xbits(uint32_t sym)
     return sym < 32u ? 0u : (sym >= 43u ? sym - 36u : nib);
 }
 
-/* One sequence.  Entry (16 bits): symbol (6) | v (10), see SeqLds; cl / co / cm = table log - 31, so that the
- * state-bit count is clz(v) + c.
- * The serial chain is entries -> bit counts -> state bits -> next states -> next entries; the entry reads
- * and the container fill for sequence i+1 are issued as soon as the states are known, and everything else
- * (base values, repeat offsets, the record store, the ring tick) runs while they are in flight.
- * Bit budget after a fill is >= 57: offset code <= 31 bits, length extras <= 32, state updates <= 26 -- one
- * fill covers the usual sequence, two more are taken only by the lanes that need them. */
-template <int J>
-__device__ inline void seq_step(LaneBits<32> &lb, const uint16_t *tab, const uint32_t *llx, const uint32_t *mlx, SeqState &z,
-                                SeqPre &pre, uint4 *out, uint32_t i, uint32_t nseq, bool resolve, int32_t cl, int32_t co, int32_t cm)
-{
-    if (i + J < nseq) {
-        const uint32_t el = pre.el, eo = pre.eo, em = pre.em;
-        const uint32_t lsym = el >> 10, osym = eo >> 10, msym = em >> 10;
-        const uint32_t llbits = ll_xbits(lsym), mlbits = ml_xbits(msym);
-        int32_t avail = 57;
-        /* offset code: osym extra bits (the 1-bit repeat index when osym == 1, none when 0) */
-        const uint32_t extra = seq_bits(lb, osym);
-        avail -= (int32_t)osym;
-        if (avail < (int32_t)(mlbits + llbits)) { lb.fill(); avail = 57; }
-        const uint32_t mlv = seq_bits(lb, mlbits);
-        const uint32_t llv = seq_bits(lb, llbits);
-        avail -= (int32_t)(mlbits + llbits);
-        if (i + J + 1u < nseq) { /* state updates: LL, ML, OF; then start fetching the next sequence */
-            const uint32_t vl = el & 1023u, vm = em & 1023u, vo = eo & 1023u;
-            const uint32_t nl = (uint32_t)(__builtin_clz(vl) + cl), nm = (uint32_t)(__builtin_clz(vm) + cm), no = (uint32_t)(__builtin_clz(vo) + co);
-            if (avail < (int32_t)(nl + nm + no)) lb.fill();
-            /* (v << nb) - size + bits; size = 1 << (c + 31) */
-            z.sl = (vl << nl) - (1u << (cl + 31)) + seq_bits(lb, nl);
-            z.sm = (vm << nm) - (1u << (cm + 31)) + seq_bits(lb, nm);
-            z.so = (vo << no) - (1u << (co + 31)) + seq_bits(lb, no);
-            pre.el = tab[z.sl]; pre.eo = tab[1024u + z.so]; pre.em = tab[512u + z.sm];
-            lb.fill();
-        }
-        const uint32_t llbase = llx[lsym] & 0xFFFFFFu, mlbase = mlx[msym] & 0xFFFFFFu;
-        const uint32_t ll0 = lsym == 0u ? 1u : 0u; /* literal length 0 <=> code 0 */
-        const bool fresh = osym > 1u;
-        const uint32_t idx = (osym == 1u ? 1u + extra : 0u) + ll0; /* repeat-offset index 0..3 (unused when fresh) */
-        uint32_t cand = idx == 0u ? z.rep0 : (idx == 1u ? z.rep1 : (idx == 2u ? z.rep2 : z.rep0 - 1u));
-        if (cand == 0u) cand = 1u; /* 0 is not valid: forced to 1 like the library */
-        /* a later block of a frame does not know its repeat offsets yet: k_zrep fills them in */
-        const uint32_t offset = fresh ? ((1u << osym) - 3u) + extra : (resolve ? cand : (kRepPending | idx));
-        const uint32_t r0 = z.rep0, r1 = z.rep1;
-        z.rep0 = offset;
-        z.rep1 = (!fresh && idx == 0u) ? r1 : r0;
-        z.rep2 = (fresh || idx >= 2u) ? r1 : z.rep2;
-        out[i + J] = make_uint4(llbase + llv, mlbase + mlv, offset, 0u);
-    }
-    lb.tick<J>();
-}
-
-__global__ void __launch_bounds__(64) k_zseq(ZPipe P)
-{
-    __shared__ __attribute__((aligned(16))) SeqLds L;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nitems = uni(P.counters[3]);
-    const uint32_t i0 = blockIdx.x * kSeqPerWave;
-    if (i0 >= nitems) return;
-    if (lane < 36u) L.llx[lane] = kLLBase[lane] | ((uint32_t)kLLBits[lane] << 24);
-    if (lane < 53u) L.mlx[lane] = kMLBase[lane] | ((uint32_t)kMLBits[lane] << 24);
-    /* ---- stage the three decoding tables of each of the wave's 15 blocks ---- */
-    for (uint32_t j = 0; j < kSeqPerWave && i0 + j < nitems; j++) {
-        const uint32_t it = uni(P.sitems[i0 + j]);
-        const uint32_t fj = it / P.nbmax;
-        const ZBlk *d = P.blks + it;
-        const uint32_t slots = uni(d->slots), logs = uni(d->logs);
-#pragma unroll
-        for (int kind = 0; kind < 3; kind++) {
-            const uint32_t slot = (slots >> (8 * kind)) & 255u, lg = (logs >> (8 * kind)) & 255u;
-            const uint32_t goff = kind == 0 ? 0u : (kind == 1 ? 1024u : 512u);
-            const uint32_t *g = (slot == kPredefSlot ? P.predef : P.seqt + ((uint64_t)fj * P.nbmax + slot) * kSeqTblWords) + goff;
-            for (uint32_t q = lane; q < (1u << lg); q += 64u) { /* 25-bit workspace entry -> 16-bit LDS entry */
-                const uint32_t e = g[q], nb = (e >> 10) & 15u;
-                L.tab[j][goff + q] = (uint16_t)((((e >> 14) & 63u) << 10) | (1u << (lg - nb)) | ((e & 1023u) >> nb));
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    /* ---- lanes 0..14: one block each ---- */
-    bool act = lane < kSeqPerWave && i0 + lane < nitems;
-    const uint32_t it = act ? P.sitems[i0 + lane] : P.sitems[i0];
-    const uint32_t f = it / P.nbmax;
-    ZBlk *d = P.blks + it;
-    if (act && (P.frames[f].flags & (F_BAD | F_IRREG))) act = false;
-    const uint8_t *src = P.src_base + P.src_off[P.first + f];
-    const uint32_t logs = d->logs;
-    const bool resolve = d->seq_first != 0u;
-    uint32_t nseq = act ? d->nseq : 0u;
-    SeqState z;
-    z.rep0 = 1; z.rep1 = 4; z.rep2 = 8;
-    z.sl = z.so = z.sm = 0;
-    bool bad = false;
-    LaneBits<32> lb;
-    const bool opened = lb.init(&L.ring[0][lane & 31u], src, act ? d->sq_off : 0u, act ? d->sq_len : 0u, act);
-    if (act && !opened) bad = true;
-    if (!opened) nseq = 0;
-    const uint16_t *tab = L.tab[lane < kSeqPerWave ? lane : 0u];
-    const int32_t cl = (int32_t)(logs & 255u) - 31, co = (int32_t)((logs >> 8) & 255u) - 31, cm = (int32_t)((logs >> 16) & 255u) - 31;
-    uint4 *out = P.seqs + (opened ? d->seq_base : 0u);
-    SeqPre pre = {0, 0, 0};
-    if (opened) {
-        lb.fill();
-        z.sl = lb.read(logs & 255u);
-        z.so = lb.read((logs >> 8) & 255u);
-        z.sm = lb.read((logs >> 16) & 255u);
-        pre.el = tab[z.sl]; pre.eo = tab[1024u + z.so]; pre.em = tab[512u + z.sm];
-        lb.fill();
-    }
-    const uint32_t maxn = wave_max(nseq);
-    for (uint32_t i = 0; i < maxn; i += 4u) {
-        seq_step<0>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve, cl, co, cm);
-        seq_step<1>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve, cl, co, cm);
-        seq_step<2>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve, cl, co, cm);
-        seq_step<3>(lb, tab, L.llx, L.mlx, z, pre, out, i, nseq, resolve, cl, co, cm);
-    }
-    if (opened && lb.pos != 0) bad = true; /* the bitstream must be consumed exactly */
-    if (opened && resolve) { d->rep_out[0] = z.rep0; d->rep_out[1] = z.rep1; d->rep_out[2] = z.rep2; }
-    if (bad) atomicOr(&P.frames[f].flags, F_BAD);
-}
-
-/* K3b: frames of several blocks (1 MiB cryo block = 8 zstd blocks).  The blocks' bitstreams were parsed
- * independently; the repeat-offset history runs through the whole frame, so the later blocks' repeat codes
- * are resolved here, one wave per frame, in one sequential walk over their records. */
-__global__ void __launch_bounds__(64) k_zrep(ZPipe P)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    if (blockIdx.x >= uni(P.counters[60])) return;
-    const uint32_t f = uni(P.ritems[blockIdx.x]);
-    if (uni(P.frames[f].flags) & (F_BAD | F_IRREG)) return;
-    const uint32_t nblk = uni(P.frames[f].nblk);
-    uint32_t r0 = 1, r1 = 4, r2 = 8; /* wave-uniform */
-    bool started = false;
-    for (uint32_t k = 0; k < nblk; k++) {
-        ZBlk *d = P.blks + (uint64_t)f * P.nbmax + k;
-        const uint32_t n = uni(d->nseq);
-        if (uni(d->type) != 2u || n == 0u) continue;
-        if (!started) { r0 = uni(d->rep_out[0]); r1 = uni(d->rep_out[1]); r2 = uni(d->rep_out[2]); started = true; continue; }
-        uint4 *q = P.seqs + uni(d->seq_base);
-        /* 64 records at a time: one coalesced load of the offsets, the history walked with v_readlane
-         * (no memory in the serial loop), changed offsets stored back */
-        uint32_t nz = lane < n ? q[lane].z : 0u;
-        for (uint32_t base = 0; base < n; base += 64u) {
-            const uint32_t cnt = n - base < 64u ? n - base : 64u;
-            const uint32_t z = nz;
-            if (base + 64u + lane < n) nz = q[base + 64u + lane].z;
-            uint32_t mine = z;
-            for (uint32_t j = 0; j < cnt; j++) {
-                const uint32_t o = lane_get(z, j);
-                if (o & kRepPending) {
-                    const uint32_t idx = o & 3u;
-                    uint32_t cand = idx == 0u ? r0 : (idx == 1u ? r1 : (idx == 2u ? r2 : r0 - 1u));
-                    if (cand == 0u) cand = 1u;
-                    if (lane == j) mine = cand;
-                    if (idx != 0u) {
-                        const uint32_t t0 = r0, t1 = r1;
-                        r0 = cand;
-                        r1 = t0;
-                        if (idx >= 2u) r2 = t1;
-                    }
-                } else { r2 = r1; r1 = r0; r0 = o; }
-            }
-            if (lane < cnt && mine != z) q[base + lane].z = mine;
-        }
-        if (lane == 0) { d->rep_out[0] = r0; d->rep_out[1] = r1; d->rep_out[2] = r2; }
-    }
-}
-
 /* ------------------------------------------------------------------------------------------------ K3' */
 /* k_zchain + k_zmat: the sequence stage split by what is serial in it.
  *
- * k_zseq does everything for a sequence on the one lane that owns the block: 321 instructions, and a lone wave per
+ * Round 2's k_zseq did everything for a sequence on the one lane that owns the block: 321 instructions, and a lone wave per
  * SIMD (LDS capacity: the decoding tables) issues one instruction every ~4.7 cycles -- the stage is as long as its
  * instruction count.  What is serial in the FSE sequence stream is only the chain
  *     three table entries -> bit counts -> position of the state bits -> next states -> next entries;
@@ -1248,6 +1041,7 @@ struct ChainLane {
     uint32_t i, nseq;
     uint32_t el, eo, em, sh;
     uint64_t raw;
+    bool rd_ok;
 };
 
 template <int J>
@@ -1256,45 +1050,27 @@ __device__ inline void chain_turn(uint8_t *ring, const uint16_t *tab, ChainLane 
                                   const uint32_t srv_lane, const uint32_t srv_ring, uint2 *out, uint2 *trash,
                                   const int32_t cl, const int32_t co, const int32_t cm, const uint32_t myring, bool &bad)
 {
-    /* ---- commit the piece slot J's load brought (to the trash slot if it was an idle re-read) ---- */
-    *reinterpret_cast<uint4 *>(ring + fa) = fd;
-    *reinterpret_cast<uint2 *>(ring + fm) = make_uint2(fd.x, fd.y);
-    {
-        const uint32_t got = (z.pend >> J) & 1u;
-        z.fillh -= (int32_t)got;
-        z.pend &= ~(1u << J);
-    }
-    /* ---- request the next half-line of the walkers of this turn's group ---- */
-    {
-        const bool want = mygroup & (z.i < z.nseq) & (z.cb < 64 * (z.lowh + 1)) & (64 * z.lowh > z.s0);
-        const uint32_t wi = want ? 1u : 0u;
-        z.lowh -= (int32_t)wi;
-        z.pend |= wi << J;
-        const uint32_t m = bperm32((uint32_t)z.lowh | (wi << 31), srv_lane);
-        const bool p = (m >> 31) != 0u;
-        const uint32_t o = ((m & 0x7FFFFFFFu) << 6) + (lane & 3u) * 16u;
-        const uint32_t slot = srv_ring + (o & (kChRing - 1u));
-        const uint32_t tr = 32u * kChStride + lane * 16u;
-        fa = p ? slot : tr;
-        fm = (p & ((o & (kChRing - 1u)) == 0u)) ? srv_ring + kChRing : tr;
-        /* always one load per turn (a lane with nothing to fetch re-reads its stream's first piece): a fixed number of
-         * vector-memory operations per turn lets the compiler wait for exactly the piece it commits */
-        fd = *reinterpret_cast<const uint4 *>(gsrc + ((p & (o < svend)) ? o : 0u));
-    }
-    /* ---- one sequence ---- */
+    /* Order matters: a lone wave has nothing else to run while it waits, so everything that is not on the chain
+     * entries -> bit counts -> state bits -> next entries sits between the issue of the next entries' reads and their use. */
+    /* ---- the ring feed, first half: ask for the next half-line of the walkers of this turn's group ---- */
+    const bool want = mygroup & (z.i < z.nseq) & (z.cb < 64 * (z.lowh + 1)) & (64 * z.lowh > z.s0);
+    const uint32_t wi = want ? 1u : 0u;
+    z.lowh -= (int32_t)wi;
+    const uint32_t m = bperm32((uint32_t)z.lowh | (wi << 31), srv_lane);
+    /* ---- one sequence (entries and window were requested at the end of the previous turn) ---- */
+    uint2 rec;
+    bool go;
     {
         const bool on = z.i < z.nseq;
-        const bool ready = (z.cb - 16 >= 64 * z.fillh) | (64 * z.fillh <= z.s0);
-        const bool go = on & ready;
+        go = on & z.rd_ok;
         const uint32_t el = z.el, eo = z.eo, em = z.em;
-        const uint32_t lsym = el >> 10, osym = eo >> 10, msym = em >> 10;
-        const uint32_t X = osym + ll_xbits(lsym) + ml_xbits(msym);
+        const uint32_t X = (el >> 11) + (eo >> 11) + (em >> 11); /* extra bits of the three codes */
         const uint32_t vl = el & 1023u, vm = em & 1023u, vo = eo & 1023u;
         const bool lastq = z.i + 1u >= z.nseq;
         const uint32_t nl = lastq ? 0u : (uint32_t)(__builtin_clz(vl) + cl), nm = lastq ? 0u : (uint32_t)(__builtin_clz(vm) + cm),
                        no = lastq ? 0u : (uint32_t)(__builtin_clz(vo) + co);
         const uint32_t N = nl + nm + no;
-        uint64_t win = z.raw << z.sh;
+        const uint64_t win = z.raw << z.sh;
         uint32_t W = (uint32_t)((win << X) >> 32);
         const bool ovf = go & (X + N > 57u);
         if (__any(ovf)) { /* more bits than one window holds: the state bits come from a second read */
@@ -1312,24 +1088,42 @@ __device__ inline void chain_turn(uint8_t *ring, const uint16_t *tab, ChainLane 
         const uint32_t nsm = (vm << nm) - (1u << (cm + 31)) + bm;
         const uint32_t nso = (vo << no) - (1u << (co + 31)) + bo;
         const int32_t npos = z.pos - (int32_t)(X + N);
-        uint2 *const op = go ? out + z.i : trash;
-        *op = make_uint2((uint32_t)z.pos, lsym | (osym << 8) | (msym << 16));
+        rec = make_uint2((uint32_t)z.pos | (z.sl << 20), z.so | (z.sm << 8));
         const bool keep = go & !lastq;
         z.sl = keep ? nsl : z.sl;
         z.sm = keep ? nsm : z.sm;
         z.so = keep ? nso : z.so;
         z.pos = go ? npos : z.pos;
-        z.i += go ? 1u : 0u;
         const bool neg = go & (npos < 0); /* read past the start of the stream */
         bad = bad | neg;
         z.nseq = neg ? 0u : z.nseq;
     }
-    /* ---- the next sequence's entries and window ---- */
+    /* ---- the next sequence's entries and window go out now ---- */
+    z.cb = z.s0 + ((z.pos - 1) >> 3);
+    z.sh = 7u - ((uint32_t)(z.pos - 1) & 7u);
+    z.rd_ok = (z.cb - 16 >= 64 * z.fillh) | (64 * z.fillh <= z.s0); /* what the window reads is in the ring */
+    __builtin_memcpy(&z.raw, ring + myring + ((uint32_t)(z.cb - 7) & (kChRing - 1u)), 8);
+    z.el = tab[z.sl]; z.eo = tab[1024u + z.so]; z.em = tab[512u + z.sm];
+    /* ---- while they are on their way: the record, the piece slot J's load brought, the new request ---- */
+    *(go ? out + z.i : trash) = rec;
+    z.i += go ? 1u : 0u;
+    *reinterpret_cast<uint4 *>(ring + fa) = fd;
+    *reinterpret_cast<uint2 *>(ring + fm) = make_uint2(fd.x, fd.y);
     {
-        z.cb = z.s0 + ((z.pos - 1) >> 3);
-        z.sh = 7u - ((uint32_t)(z.pos - 1) & 7u);
-        __builtin_memcpy(&z.raw, ring + myring + ((uint32_t)(z.cb - 7) & (kChRing - 1u)), 8);
-        z.el = tab[z.sl]; z.eo = tab[1024u + z.so]; z.em = tab[512u + z.sm];
+        const uint32_t got = (z.pend >> J) & 1u;
+        z.fillh -= (int32_t)got;
+        z.pend = (z.pend & ~(1u << J)) | (wi << J);
+    }
+    {
+        const bool p = (m >> 31) != 0u;
+        const uint32_t o = ((m & 0x7FFFFFFFu) << 6) + (lane & 3u) * 16u;
+        const uint32_t slot = srv_ring + (o & (kChRing - 1u));
+        const uint32_t tr = 32u * kChStride + lane * 16u;
+        fa = p ? slot : tr;
+        fm = (p & ((o & (kChRing - 1u)) == 0u)) ? srv_ring + kChRing : tr;
+        /* always one load per turn (a lane with nothing to fetch re-reads its stream's first piece): a fixed number of
+         * vector-memory operations per turn lets the compiler wait for exactly the piece it commits */
+        fd = *reinterpret_cast<const uint4 *>(gsrc + ((p & (o < svend)) ? o : 0u));
     }
 }
 
@@ -1350,9 +1144,9 @@ __global__ void __launch_bounds__(64) k_zchain(ZPipe P)
             const uint32_t slot = (slots >> (8 * kind)) & 255u, lg = (logs >> (8 * kind)) & 255u;
             const uint32_t goff = kind == 0 ? 0u : (kind == 1 ? 1024u : 512u);
             const uint32_t *g = (slot == kPredefSlot ? P.predef : P.seqt + ((uint64_t)fj * P.nbmax + slot) * kSeqTblWords) + goff;
-            for (uint32_t q = lane; q < (1u << lg); q += 64u) { /* 25-bit workspace entry -> 16-bit LDS entry (SeqLds) */
+            for (uint32_t q = lane; q < (1u << lg); q += 64u) { /* 25-bit workspace entry -> 16 bits: extra-bit count (5) | v (10) */
                 const uint32_t e = g[q], nb = (e >> 10) & 15u;
-                L.tab[j][goff + q] = (uint16_t)((((e >> 14) & 63u) << 10) | (1u << (lg - nb)) | ((e & 1023u) >> nb));
+                L.tab[j][goff + q] = (uint16_t)((((e >> 20) & 31u) << 11) | (1u << (lg - nb)) | ((e & 1023u) >> nb));
             }
         }
     }
@@ -1414,6 +1208,7 @@ __global__ void __launch_bounds__(64) k_zchain(ZPipe P)
     __builtin_amdgcn_wave_barrier();
     z.cb = z.s0 + ((z.pos - 1) >> 3);
     z.sh = 7u - ((uint32_t)(z.pos - 1) & 7u);
+    z.rd_ok = true; /* the top of the stream is in the ring */
     __builtin_memcpy(&z.raw, L.ring + myring + ((uint32_t)(z.cb - 7) & (kChRing - 1u)), 8);
     z.el = tab[z.sl]; z.eo = tab[1024u + z.so]; z.em = tab[512u + z.sm];
 
@@ -1444,37 +1239,34 @@ __global__ void __launch_bounds__(64) k_zchain(ZPipe P)
  * (r0, r1, r2) by one of five "transforms" whose outputs are each either a constant (a fresh offset) or one of the
  * inputs minus a small count, floored at 1 (the format's `rep0 - 1`, never 0); such transforms compose into the same
  * shape, so the history in front of every sequence is an exclusive scan over the batch applied to the carry. */
-struct RepT { uint32_t tags, v0, v1, v2; }; /* tags: 2 bits per slot, 0..2 = input slot (v = count subtracted), 3 = constant v */
+/* one word per output slot: value << 2 | tag; tag 0..2 = input slot (value = count subtracted), 3 = constant.  Offsets
+ * of 2^30 - 1 and more are kept as 2^30 - 1: the pipeline only decodes frames of at most 254 blocks (31.75 MiB), so both
+ * are farther back than any output position and k_zexec rejects them alike. */
+struct RepT { uint32_t s0, s1, s2; };
+constexpr uint32_t kRepMax = 0x3FFFFFFFu;
 
-__device__ inline uint32_t rep_apply(uint32_t tag, uint32_t v, uint32_t h0, uint32_t h1, uint32_t h2)
+__device__ inline uint32_t rep_apply(uint32_t slot, uint32_t h0, uint32_t h1, uint32_t h2)
 {
+    const uint32_t tag = slot & 3u, v = slot >> 2;
     const uint32_t h = tag == 0u ? h0 : (tag == 1u ? h1 : h2);
     const uint32_t dec = h > v ? h - v : 1u;
     return tag == 3u ? v : dec;
 }
-/* B after A */
-__device__ inline RepT rep_compose(const RepT &A, const RepT &B)
+/* slot b of the later transform applied to the outputs A of the earlier one */
+__device__ inline uint32_t rep_compose1(const RepT &A, uint32_t b)
 {
-    RepT R;
-    uint32_t tags = 0;
-    auto one = [&](uint32_t tb, uint32_t vb, uint32_t &vout) -> uint32_t {
-        const uint32_t ta = (A.tags >> (2u * (tb & 3u))) & 3u; /* tb == 3: unused */
-        const uint32_t va = tb == 0u ? A.v0 : (tb == 1u ? A.v1 : A.v2);
-        const uint32_t cdec = va > vb ? va - vb : 1u;
-        const bool bconst = tb == 3u, aconst = ta == 3u;
-        vout = bconst ? vb : (aconst ? cdec : va + vb);
-        return bconst ? 3u : ta;
-    };
-    tags |= one(B.tags & 3u, B.v0, R.v0);
-    tags |= one((B.tags >> 2) & 3u, B.v1, R.v1) << 2;
-    tags |= one((B.tags >> 4) & 3u, B.v2, R.v2) << 4;
-    R.tags = tags;
-    return R;
+    const uint32_t tb = b & 3u, vb = b >> 2;
+    const uint32_t a = tb == 0u ? A.s0 : (tb == 1u ? A.s1 : A.s2);
+    const uint32_t ta = a & 3u, va = a >> 2;
+    const uint32_t cdec = va > vb ? va - vb : 1u;
+    const uint32_t r = ((ta == 3u ? cdec : va + vb) << 2) | ta;
+    return tb == 3u ? b : r;
 }
 
 __global__ void __launch_bounds__(64) k_zmat(ZPipe P)
 {
     __shared__ uint32_t s_llb[36], s_mlb[53];
+    __shared__ uint2 s_op[64 * 9];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t f = blockIdx.x;
     if (lane < 36u) s_llb[lane] = kLLBase[lane];
@@ -1484,71 +1276,115 @@ __global__ void __launch_bounds__(64) k_zmat(ZPipe P)
     const uint32_t nblk = uni(P.frames[f].nblk);
     const uint8_t *src = P.src_base + uni64(P.src_off[P.first + f]);
     uint32_t h0 = 1, h1 = 4, h2 = 8; /* wave-uniform */
-    constexpr uint32_t kIdent = 0u | (1u << 2) | (2u << 4);
     for (uint32_t k = 0; k < nblk; k++) {
         const ZBlk *d = P.blks + (uint64_t)f * P.nbmax + k;
         const uint32_t n = uni(d->nseq);
         if (uni(d->type) != 2u || n == 0u) continue;
         const uint2 *cr = P.chain + uni(d->seq_base);
-        uint4 *out = P.seqs + uni(d->seq_base);
+        uint2 *out = P.seqs + uni(d->seq_base);
         const uint8_t *sq = src + uni(d->sq_off);
-        uint2 nx = make_uint2(0, 0);
-        if (lane < n) nx = cr[lane];
-        for (uint32_t base = 0; base < n; base += 64u) {
-            const bool on = base + lane < n;
-            const uint2 c = nx;
-            nx = make_uint2(0, 0);
-            if (base + 64u + lane < n) nx = cr[base + 64u + lane];
-            const uint32_t pos = c.x, lsym = c.y & 63u, osym = (c.y >> 8) & 31u, msym = (c.y >> 16) & 63u;
-            const uint32_t llb = ll_xbits(lsym), mlb = ml_xbits(msym);
-            const uint32_t lo = pos - osym, lo2 = lo - llb - mlb; /* valid frames: lo2 >= 0 */
-            uint32_t extra = 0, llv = 0, mlv = 0;
-            if (on) {
-                const uint64_t a = ld64v(sq + (lo >> 3)), b = ld64v(sq + (lo2 >> 3));
-                extra = (uint32_t)(a >> (lo & 7u)) & (uint32_t)((1ull << osym) - 1ull);
-                const uint32_t t = (uint32_t)(b >> (lo2 & 7u));
-                llv = t & ((1u << llb) - 1u);
-                mlv = (t >> llb) & ((1u << mlb) - 1u);
-            }
-            const uint32_t ll = s_llb[lsym < 36u ? lsym : 0u] + llv, ml = s_mlb[msym < 53u ? msym : 0u] + mlv;
-            const bool fresh = osym > 1u;
-            const uint32_t ll0 = lsym == 0u ? 1u : 0u;
-            const uint32_t idx = (osym == 1u ? 1u + extra : 0u) + ll0; /* repeat-offset index 0..3 */
-            const uint32_t v = ((1u << osym) - 3u) + extra;
-            RepT T;
-            if (!on || (!fresh && idx == 0u)) { T.tags = kIdent; T.v0 = T.v1 = T.v2 = 0; }
-            else if (fresh) { T.tags = 3u | (0u << 2) | (1u << 4); T.v0 = v; T.v1 = 0; T.v2 = 0; }
-            else if (idx == 1u) { T.tags = 1u | (0u << 2) | (2u << 4); T.v0 = T.v1 = T.v2 = 0; }
-            else if (idx == 2u) { T.tags = 2u | (0u << 2) | (1u << 4); T.v0 = T.v1 = T.v2 = 0; }
-            else { T.tags = 0u | (0u << 2) | (1u << 4); T.v0 = 1; T.v1 = 0; T.v2 = 0; }
-            /* inclusive scan */
+        const uint32_t slots = uni(d->slots);
+        const uint32_t *tl = (slots & 255u) == kPredefSlot ? P.predef : P.seqt + ((uint64_t)f * P.nbmax + (slots & 255u)) * kSeqTblWords;
+        const uint32_t *to = (((slots >> 8) & 255u) == kPredefSlot ? P.predef : P.seqt + ((uint64_t)f * P.nbmax + ((slots >> 8) & 255u)) * kSeqTblWords) + 1024u;
+        const uint32_t *tm = (((slots >> 16) & 255u) == kPredefSlot ? P.predef : P.seqt + ((uint64_t)f * P.nbmax + ((slots >> 16) & 255u)) * kSeqTblWords) + 512u;
+        /* 512 sequences per round.  Memory is touched 64 consecutive sequences at a time (lane l: base + 64 e + l); the
+         * history needs consecutive sequences per lane (lane l: base + 8 l + e): what a sequence does to the history
+         * (kind, offset value) crosses over through LDS, the resulting offset comes back the same way.  The lane folds
+         * its eight into one transform, the wave scans the 64 transforms, the lane walks its eight with the real history. */
+        constexpr uint32_t kPer = 8;
+        for (uint32_t base = 0; base < n; base += 64u * kPer) {
+            uint32_t ll[kPer], ml[kPer];
 #pragma unroll
-            for (int s = 1; s < 64; s <<= 1) {
-                RepT A;
-                A.tags = (uint32_t)__shfl_up((int)T.tags, s, 64);
-                A.v0 = (uint32_t)__shfl_up((int)T.v0, s, 64);
-                A.v1 = (uint32_t)__shfl_up((int)T.v1, s, 64);
-                A.v2 = (uint32_t)__shfl_up((int)T.v2, s, 64);
-                const RepT C = rep_compose(A, T);
-                if (lane >= (uint32_t)s) T = C;
+            for (uint32_t e = 0; e < kPer; e++) {
+                const uint32_t q = 64u * e + lane;
+                const bool on = base + q < n;
+                uint2 c = make_uint2(0, 0);
+                if (on) c = cr[base + q];
+                /* states -> symbols, from the block's tables in the workspace (symbol at bits 14..19) */
+                const uint32_t pos = c.x & 0xFFFFFu;
+                uint32_t lsym = 0, osym = 0, msym = 0;
+                if (on) {
+                    lsym = (tl[c.x >> 20] >> 14) & 63u;
+                    osym = (to[c.y & 255u] >> 14) & 31u;
+                    msym = (tm[c.y >> 8] >> 14) & 63u;
+                }
+                const uint32_t llb = ll_xbits(lsym), mlb = ml_xbits(msym);
+                const uint32_t lo = pos - osym, lo2 = lo - llb - mlb; /* valid frames: lo2 >= 0 */
+                uint32_t extra = 0, llv = 0, mlv = 0;
+                if (on) {
+                    const uint64_t a = ld64v(sq + (lo >> 3)), b = ld64v(sq + (lo2 >> 3));
+                    extra = (uint32_t)(a >> (lo & 7u)) & (uint32_t)((1ull << osym) - 1ull);
+                    const uint32_t t = (uint32_t)(b >> (lo2 & 7u));
+                    llv = t & ((1u << llb) - 1u);
+                    mlv = (t >> llb) & ((1u << mlb) - 1u);
+                }
+                ll[e] = s_llb[lsym < 36u ? lsym : 0u] + llv;
+                ml[e] = s_mlb[msym < 53u ? msym : 0u] + mlv;
+                const bool fresh = osym > 1u;
+                const uint32_t idx = (osym == 1u ? 1u + extra : 0u) + (lsym == 0u ? 1u : 0u); /* repeat-offset index 0..3 */
+                /* kind: 0..3 repeat index, 4 fresh, 5 no sequence */
+                s_op[(q >> 3) * 9u + (q & 7u)] = make_uint2(((1u << osym) - 3u) + extra, !on ? 5u : (fresh ? 4u : idx));
             }
-            /* history in front of this lane's sequence: the scan of the lanes before it applied to the carry */
-            RepT E;
-            E.tags = (uint32_t)__shfl_up((int)T.tags, 1, 64);
-            E.v0 = (uint32_t)__shfl_up((int)T.v0, 1, 64);
-            E.v1 = (uint32_t)__shfl_up((int)T.v1, 1, 64);
-            E.v2 = (uint32_t)__shfl_up((int)T.v2, 1, 64);
-            if (lane == 0u) { E.tags = kIdent; E.v0 = E.v1 = E.v2 = 0; }
-            const uint32_t p0 = rep_apply(E.tags & 3u, E.v0, h0, h1, h2);
-            const uint32_t p1 = rep_apply((E.tags >> 2) & 3u, E.v1, h0, h1, h2);
-            const uint32_t p2 = rep_apply((E.tags >> 4) & 3u, E.v2, h0, h1, h2);
-            const uint32_t cand = idx == 0u ? p0 : (idx == 1u ? p1 : (idx == 2u ? p2 : (p0 > 1u ? p0 - 1u : 1u)));
-            const uint32_t offset = fresh ? v : cand;
-            if (on) out[base + lane] = make_uint4(ll, ml, offset, 0u);
-            /* carry: the whole batch applied to the history */
-            const uint32_t tt = lane_get(T.tags, 63), t0 = lane_get(T.v0, 63), t1 = lane_get(T.v1, 63), t2 = lane_get(T.v2, 63);
-            const uint32_t n0 = rep_apply(tt & 3u, t0, h0, h1, h2), n1 = rep_apply((tt >> 2) & 3u, t1, h0, h1, h2),
-                           n2 = rep_apply((tt >> 4) & 3u, t2, h0, h1, h2);
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            uint32_t vv[kPer], kd[kPer];
+            RepT T;
+            T.s0 = 0u; T.s1 = 1u; T.s2 = 2u;
+#pragma unroll
+            for (uint32_t e = 0; e < kPer; e++) { /* this sequence after the lane's earlier ones */
+                const uint2 o = s_op[lane * 9u + e];
+                const uint32_t v = o.x, k = o.y;
+                vv[e] = v; kd[e] = k;
+                const uint32_t vs = v < kRepMax ? v : kRepMax;
+                const uint32_t t0 = T.s0, t1 = T.s1, t2 = T.s2;
+                const uint32_t tg = t0 & 3u, tv = t0 >> 2;
+                const uint32_t dec = tg == 3u ? ((tv > 1u ? tv - 1u : 1u) << 2) | 3u : t0 + 4u; /* max(1, . - 1) */
+                T.s0 = k == 4u ? ((vs << 2) | 3u) : (k == 1u ? t1 : (k == 2u ? t2 : (k == 3u ? dec : t0)));
+                T.s1 = (k >= 1u && k <= 4u) ? t0 : t1;
+                T.s2 = (k >= 2u && k <= 4u) ? t1 : t2;
+            }
+            /* inclusive scan over the lanes */
+#pragma unroll
+            for (int st = 1; st < 64; st <<= 1) {
+                RepT A;
+                A.s0 = (uint32_t)__shfl_up((int)T.s0, st, 64);
+                A.s1 = (uint32_t)__shfl_up((int)T.s1, st, 64);
+                A.s2 = (uint32_t)__shfl_up((int)T.s2, st, 64);
+                const uint32_t c0 = rep_compose1(A, T.s0), c1 = rep_compose1(A, T.s1), c2 = rep_compose1(A, T.s2);
+                const bool take = lane >= (uint32_t)st;
+                T.s0 = take ? c0 : T.s0; T.s1 = take ? c1 : T.s1; T.s2 = take ? c2 : T.s2;
+            }
+            /* the history in front of this lane's first sequence: the lanes before it applied to the carry */
+            uint32_t e0 = (uint32_t)__shfl_up((int)T.s0, 1, 64), e1 = (uint32_t)__shfl_up((int)T.s1, 1, 64), e2 = (uint32_t)__shfl_up((int)T.s2, 1, 64);
+            e0 = lane == 0u ? 0u : e0; e1 = lane == 0u ? 1u : e1; e2 = lane == 0u ? 2u : e2;
+            uint32_t r0 = rep_apply(e0, h0, h1, h2), r1 = rep_apply(e1, h0, h1, h2), r2 = rep_apply(e2, h0, h1, h2);
+#pragma unroll
+            for (uint32_t e = 0; e < kPer; e++) {
+                const uint32_t k = kd[e];
+                const uint32_t dm = r0 > 1u ? r0 - 1u : 1u;
+                const uint32_t off = k == 4u ? vv[e] : (k == 1u ? r1 : (k == 2u ? r2 : (k == 3u ? dm : r0)));
+                /* the history itself is kept like the transforms keep it (offsets beyond 2^30 - 1 as 2^30 - 1) */
+                const uint32_t offh = k == 4u ? (vv[e] < kRepMax ? vv[e] : kRepMax) : off;
+                const uint32_t q0 = r0, q1 = r1;
+                r0 = (k >= 1u && k <= 4u) ? offh : r0;
+                r1 = (k >= 1u && k <= 4u) ? q0 : r1;
+                r2 = (k >= 2u && k <= 4u) ? q1 : r2;
+                s_op[lane * 9u + e].x = off;
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (uint32_t e = 0; e < kPer; e++) {
+                const uint32_t q = 64u * e + lane;
+                const uint32_t off = s_op[(q >> 3) * 9u + (q & 7u)].x;
+                const uint32_t o29 = off < 0x1FFFFFFFu ? off : 0x1FFFFFFFu;
+                if (base + q < n) out[base + q] = make_uint2(o29 | (ll[e] << 29), (ll[e] >> 3) | (ml[e] << 14));
+            }
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            /* carry: the whole round applied to the history */
+            const uint32_t n0 = rep_apply(lane_get(T.s0, 63), h0, h1, h2), n1 = rep_apply(lane_get(T.s1, 63), h0, h1, h2),
+                           n2 = rep_apply(lane_get(T.s2, 63), h0, h1, h2);
             h0 = uni(n0); h1 = uni(n1); h2 = uni(n2);
         }
     }
@@ -1577,10 +1413,10 @@ __device__ bool exec_block(ExecLds &L, Wave<ZR> &w, const ZPipe &P, const ZBlk *
     else if (lit_mode == 2) lvp = stream_open(w, P.lits + (uint64_t)f * P.litcap + lit_src, regen);
     const bool streamed = lit_mode != 1;
 
-    const uint4 *seqs = P.seqs + uni(d->seq_base);
+    const uint2 *seqs = P.seqs + uni(d->seq_base);
     uint32_t q_ll = 0, q_ml = 0, q_off = 0;
     uint32_t qn = 0, loaded = 0;
-    uint4 nx = make_uint4(0, 0, 0, 0); /* records loaded .. loaded+63, one per lane, in flight */
+    uint2 nx = make_uint2(0, 0); /* records loaded .. loaded+63, one per lane, in flight */
     if (lane < nseq) nx = seqs[lane];
     for (;;) {
         /* ---- top the queue up from the prefetched records ---- */
@@ -1588,12 +1424,11 @@ __device__ bool exec_block(ExecLds &L, Wave<ZR> &w, const ZPipe &P, const ZBlk *
             uint32_t take = 64u - qn;
             if (take > nseq - loaded) take = nseq - loaded;
             const int from = (int)((lane - qn) & 63u);
-            const uint32_t a = (uint32_t)__shfl((int)nx.x, from, 64), b2 = (uint32_t)__shfl((int)nx.y, from, 64),
-                           c = (uint32_t)__shfl((int)nx.z, from, 64);
-            if (lane >= qn && lane < qn + take) { q_ll = a; q_ml = b2; q_off = c; }
+            const uint32_t rx = (uint32_t)__shfl((int)nx.x, from, 64), ry = (uint32_t)__shfl((int)nx.y, from, 64);
+            if (lane >= qn && lane < qn + take) { q_ll = (rx >> 29) | ((ry & 0x3FFFu) << 3); q_ml = ry >> 14; q_off = rx & 0x1FFFFFFFu; }
             qn += take;
             loaded += take;
-            nx = make_uint4(0, 0, 0, 0);
+            nx = make_uint2(0, 0);
             if (loaded + lane < nseq) nx = seqs[loaded + lane];
         }
         if (qn == 0u) break;
@@ -1728,7 +1563,7 @@ namespace {
 struct Layout {
     uint32_t F, nbmax, litcap, seqcap;
     size_t htmp_stride;
-    size_t o_frames, o_blks, o_huf, o_seqt, o_predef, o_lits, o_seqs, o_chain, o_cnt, o_hitems, o_hitems2, o_htmp, o_irreg, o_sitems, o_ritems, o_fused, total;
+    size_t o_frames, o_blks, o_huf, o_seqt, o_predef, o_lits, o_seqs, o_chain, o_cnt, o_hitems, o_hitems2, o_htmp, o_irreg, o_sitems, o_fused, total;
 };
 
 constexpr uint32_t kFusedGridForIrregular = 256;
@@ -1743,7 +1578,7 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     y.litcap = ((B + 15u) & ~15u) + 32u * y.nbmax;
     y.htmp_stride = al256(2u * (size_t)y.litcap + (size_t)y.nbmax * kHwBlockSlack);
     const size_t per_frame = y.htmp_stride + sizeof(ZFrame) + (size_t)y.nbmax * (sizeof(ZBlk) + kHufTblWords * 2u + kSeqTblWords * 4u + 8u) +
-                             y.litcap + (size_t)(B / 6u) * (sizeof(uint4) + sizeof(uint2)) /* sequence pool share */ + 4u;
+                             y.litcap + (size_t)(B / 6u) * (sizeof(uint2) + sizeof(uint2)) /* sequence pool share */ + 4u;
     /* Tile size.  K2 and K3 are bound by LDS capacity (two workgroups per CU, 512 per chip): 14848 frames
      * = 512 x 29 fill exactly one round of K3 (and 928 waves of 16 = two rounds of K2, the second 81 % full); the
      * workspace budget may force less. */
@@ -1751,7 +1586,7 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     const size_t budget = budget_env ? budget_env : (size_t)16 << 30; /* per tile in flight; reached only by blocks > 128 KiB,
                                                                         whose tiles would otherwise be too few frames to fill K1/K4 */
     uint64_t F = budget / per_frame;
-    constexpr uint64_t kTile = 512u * kSeqPerWave; /* one full round of K3 */
+    constexpr uint64_t kTile = 512u * kChW; /* one full round of k_zchain */
     if (F > kTile) F = kTile;
     if (F >= 464u) F -= F % 464u;
     else if (F < 16u) F = 16u;
@@ -1769,7 +1604,7 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     y.o_seqt = o; o = al256(o + (size_t)y.F * y.nbmax * kSeqTblWords * 4u);
     y.o_predef = o; o = al256(o + kSeqTblWords * 4u);
     y.o_lits = o; o = al256(o + (size_t)y.F * y.litcap + 64u);
-    y.o_seqs = o; o = al256(o + (size_t)y.seqcap * sizeof(uint4));
+    y.o_seqs = o; o = al256(o + (size_t)y.seqcap * sizeof(uint2));
     y.o_chain = o; o = al256(o + ((size_t)y.seqcap + 64u) * sizeof(uint2));
     y.o_cnt = o; o = al256(o + 256u);
     y.o_hitems = o; o = al256(o + (size_t)y.F * y.nbmax * 4u);
@@ -1777,7 +1612,6 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     y.o_htmp = o; o = al256(o + (size_t)y.F * y.htmp_stride + 64u);
     y.o_irreg = o; o = al256(o + (size_t)y.F * 4u);
     y.o_sitems = o; o = al256(o + (size_t)y.F * y.nbmax * 4u);
-    y.o_ritems = o; o = al256(o + (size_t)y.F * 4u);
     y.o_fused = o; o = al256(o + zstd_fused_workspace(kFusedGridForIrregular));
     y.total = o;
     return y;
@@ -1835,7 +1669,6 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
     static const uint32_t huf_pad = getenv("CRYO_ZHUF_PAD") ? (uint32_t)atoi(getenv("CRYO_ZHUF_PAD")) : 0u; /* tuning aid: extra LDS to cap occupancy */
     static const uint32_t seq_pad = getenv("CRYO_ZSEQ_PAD") ? (uint32_t)atoi(getenv("CRYO_ZSEQ_PAD")) : 0u;
     static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
-    static const bool old_seq = getenv("CRYO_ZSEQ_OLD") != nullptr;      /* A/B aid */
     static const bool old_huf = getenv("CRYO_ZHUF_OLD") != nullptr;
     uint64_t t = 0;
     for (uint64_t first = 0; first < n_blocks; first += y.F, t++) {
@@ -1853,7 +1686,7 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
         P.seqt = (uint32_t *)(ws + y.o_seqt);
         P.predef = (uint32_t *)(ws + y.o_predef);
         P.lits = ws + y.o_lits;
-        P.seqs = (uint4 *)(ws + y.o_seqs);
+        P.seqs = (uint2 *)(ws + y.o_seqs);
         P.chain = (uint2 *)(ws + y.o_chain);
         P.counters = (uint32_t *)(ws + y.o_cnt);
         P.hitems = (uint32_t *)(ws + y.o_hitems);
@@ -1862,7 +1695,6 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
         P.htmp_stride = y.htmp_stride;
         P.irregular = (uint32_t *)(ws + y.o_irreg);
         P.sitems = (uint32_t *)(ws + y.o_sitems);
-        P.ritems = (uint32_t *)(ws + y.o_ritems);
         const uint64_t left = n_blocks - first;
         P.first = first;
         P.F = (uint32_t)(left < y.F ? left : y.F);
@@ -1873,13 +1705,8 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
             hipLaunchKernelGGL(k_zhufw, dim3(P.F * P.nbmax), dim3(64), huf_pad, st, P);
             hipLaunchKernelGGL(k_zhuf, dim3((P.F * P.nbmax + kHufPerWave - 1u) / kHufPerWave), dim3(64), 0, st, P, P.hitems2, 61u);
         }
-        if (old_seq) {
-            hipLaunchKernelGGL(k_zseq, dim3((P.F * P.nbmax + kSeqPerWave - 1u) / kSeqPerWave), dim3(64), seq_pad, st, P);
-            hipLaunchKernelGGL(k_zrep, dim3(P.F), dim3(64), 0, st, P);
-        } else {
-            hipLaunchKernelGGL(k_zchain, dim3((P.F * P.nbmax + kChW - 1u) / kChW), dim3(64), seq_pad, st, P);
-            hipLaunchKernelGGL(k_zmat, dim3(P.F), dim3(64), 0, st, P);
-        }
+        hipLaunchKernelGGL(k_zchain, dim3((P.F * P.nbmax + kChW - 1u) / kChW), dim3(64), seq_pad, st, P);
+        hipLaunchKernelGGL(k_zmat, dim3(P.F), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_zexec, dim3(P.F), dim3(64), 0, st, P);
         const uint64_t fg = P.F < kFusedGridForIrregular ? P.F : kFusedGridForIrregular;
         e = launch_zstd_fused(st, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, fg, d_status,
