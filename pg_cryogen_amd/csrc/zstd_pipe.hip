@@ -1044,7 +1044,7 @@ struct ChainLane {
     bool rd_ok;
 };
 
-template <int J>
+template <int J, bool FEED>
 __device__ inline void chain_turn(uint8_t *ring, const uint16_t *tab, ChainLane &z, const uint32_t lane, const bool mygroup,
                                   uint4 &fd, uint32_t &fa, uint32_t &fm, const uint8_t *gsrc, const uint32_t svend,
                                   const uint32_t srv_lane, const uint32_t srv_ring, uint2 *out, uint2 *trash,
@@ -1053,10 +1053,13 @@ __device__ inline void chain_turn(uint8_t *ring, const uint16_t *tab, ChainLane 
     /* Order matters: a lone wave has nothing else to run while it waits, so everything that is not on the chain
      * entries -> bit counts -> state bits -> next entries sits between the issue of the next entries' reads and their use. */
     /* ---- the ring feed, first half: ask for the next half-line of the walkers of this turn's group ---- */
-    const bool want = mygroup & (z.i < z.nseq) & (z.cb < 64 * (z.lowh + 1)) & (64 * z.lowh > z.s0);
-    const uint32_t wi = want ? 1u : 0u;
-    z.lowh -= (int32_t)wi;
-    const uint32_t m = bperm32((uint32_t)z.lowh | (wi << 31), srv_lane);
+    uint32_t wi = 0, m = 0;
+    if (FEED) { /* every other sequence: 64 bytes per eight sequences per walker, a sequence takes 3 on tuple data (11 at most: the lane waits) */
+        const bool want = mygroup & (z.i < z.nseq) & (z.cb < 64 * (z.lowh + 1)) & (64 * z.lowh > z.s0);
+        wi = want ? 1u : 0u;
+        z.lowh -= (int32_t)wi;
+        m = bperm32((uint32_t)z.lowh | (wi << 31), srv_lane);
+    }
     /* ---- one sequence (entries and window were requested at the end of the previous turn) ---- */
     uint2 rec;
     bool go;
@@ -1107,6 +1110,7 @@ __device__ inline void chain_turn(uint8_t *ring, const uint16_t *tab, ChainLane 
     /* ---- while they are on their way: the record, the piece slot J's load brought, the new request ---- */
     *(go ? out + z.i : trash) = rec;
     z.i += go ? 1u : 0u;
+    if (!FEED) return;
     *reinterpret_cast<uint4 *>(ring + fa) = fd;
     *reinterpret_cast<uint2 *>(ring + fm) = make_uint2(fd.x, fd.y);
     {
@@ -1226,10 +1230,14 @@ __global__ void __launch_bounds__(64) k_zchain(ZPipe P)
     uint4 fd0 = make_uint4(0, 0, 0, 0), fd1 = fd0, fd2 = fd0, fd3 = fd0;
     uint32_t fa0 = tr, fa1 = tr, fa2 = tr, fa3 = tr, fm0 = tr, fm1 = tr, fm2 = tr, fm3 = tr;
     while (__any(z.i < z.nseq)) {
-        chain_turn<0>(L.ring, tab, z, lane, grp0, fd0, fa0, fm0, g0, ve0, w0, r0, out, trash, cl, co, cm, myring, bad);
-        chain_turn<1>(L.ring, tab, z, lane, grp1, fd1, fa1, fm1, g1, ve1, w1, r1, out, trash, cl, co, cm, myring, bad);
-        chain_turn<2>(L.ring, tab, z, lane, grp0, fd2, fa2, fm2, g0, ve0, w0, r0, out, trash, cl, co, cm, myring, bad);
-        chain_turn<3>(L.ring, tab, z, lane, grp1, fd3, fa3, fm3, g1, ve1, w1, r1, out, trash, cl, co, cm, myring, bad);
+        chain_turn<0, true>(L.ring, tab, z, lane, grp0, fd0, fa0, fm0, g0, ve0, w0, r0, out, trash, cl, co, cm, myring, bad);
+        chain_turn<0, false>(L.ring, tab, z, lane, grp0, fd0, fa0, fm0, g0, ve0, w0, r0, out, trash, cl, co, cm, myring, bad);
+        chain_turn<1, true>(L.ring, tab, z, lane, grp1, fd1, fa1, fm1, g1, ve1, w1, r1, out, trash, cl, co, cm, myring, bad);
+        chain_turn<1, false>(L.ring, tab, z, lane, grp1, fd1, fa1, fm1, g1, ve1, w1, r1, out, trash, cl, co, cm, myring, bad);
+        chain_turn<2, true>(L.ring, tab, z, lane, grp0, fd2, fa2, fm2, g0, ve0, w0, r0, out, trash, cl, co, cm, myring, bad);
+        chain_turn<2, false>(L.ring, tab, z, lane, grp0, fd2, fa2, fm2, g0, ve0, w0, r0, out, trash, cl, co, cm, myring, bad);
+        chain_turn<3, true>(L.ring, tab, z, lane, grp1, fd3, fa3, fm3, g1, ve1, w1, r1, out, trash, cl, co, cm, myring, bad);
+        chain_turn<3, false>(L.ring, tab, z, lane, grp1, fd3, fa3, fm3, g1, ve1, w1, r1, out, trash, cl, co, cm, myring, bad);
     }
     if (opened && z.pos != 0) bad = true; /* the bitstream must be consumed exactly */
     if (bad) atomicOr(&P.frames[f].flags, F_BAD);
