@@ -1401,11 +1401,15 @@ __global__ void __launch_bounds__(64) k_zmat(ZPipe P)
 /* ------------------------------------------------------------------------------------------------ K4 */
 namespace {
 
+/* output bytes per batch: the largest T with R - T >= T + 1023 at R = 4096 (lz4_dec2.hip); a batch's literals have to
+ * fit the input ring next to the chunk being staged */
+constexpr uint32_t kZT = 1536, kZLitMax = kInRing - kInChunk - 16u;
+
 struct ExecLds {
     uint8_t ring[ZR + 16];   /* + the copy engine's 16-byte tail (lz4_copy.h) */
     uint8_t in[kInRing + 16];
     uint32_t meta[64];
-    uint32_t bm[CopyLds<ZR, kTMax>::kWords];
+    uint32_t bm[CopyLds<ZR, kZT>::kWords];
 };
 
 /* execute one compressed block's sequences; false on malformed input */
@@ -1448,9 +1452,9 @@ __device__ bool exec_block(ExecLds &L, Wave<ZR> &w, const ZPipe &P, const ZBlk *
         const uint32_t ostart = oend - outlen;
         const uint32_t litend = scan64_incl(inq ? q_ll : 0u);
         const uint32_t mabs = w.op + ostart + q_ll;
-        const bool isfar = inq && q_off >= ZR - kTMax; /* in the ring for the whole batch, or flushed before it (lz4_copy.h) */
+        const bool isfar = inq && q_off >= ZR - kZT; /* in the ring for the whole batch, or flushed before it (lz4_copy.h) */
         const bool ok = inq && streamed && (q_ml <= q_off || (q_off != 0u && q_ml <= 64u)) /* short self-overlap: a dependent match, lz4_copy.h */ && q_off <= mabs && !(isfar && q_ml > 32u) &&
-                        litend <= regen - lit_pos && oend <= kTMax && (uint64_t)w.op + oend <= cap;
+                        litend <= regen - lit_pos && litend <= kZLitMax && oend <= kZT && (uint64_t)w.op + oend <= cap;
         const unsigned long long badmask = __ballot(!ok);
         const uint32_t nb = badmask ? ctz64(badmask) : 64u;
         if (nb > 0u) {
@@ -1469,8 +1473,8 @@ __device__ bool exec_block(ExecLds &L, Wave<ZR> &w, const ZPipe &P, const ZBlk *
                 __builtin_memcpy(&xfa, g, 16);
                 __builtin_memcpy(&xfb, g + 16, 16);
             }
-            const CopyLds<ZR, kTMax> SL = {L.ring, L.in, L.meta, L.bm};
-            seq_copy<ZR, kTMax>(w, SL, nb, ostart, q_ll, q_ml, q_off, lvp + (litend - q_ll), T, isfar, xfa, xfb, st);
+            const CopyLds<ZR, kZT> SL = {L.ring, L.in, L.meta, L.bm};
+            seq_copy<ZR, kZT>(w, SL, nb, ostart, q_ll, q_ml, q_off, lvp + (litend - q_ll), T, isfar, xfa, xfb, st);
             w.flush();
             lvp += lits;
             lit_pos += lits;
