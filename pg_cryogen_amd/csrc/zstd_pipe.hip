@@ -1403,17 +1403,17 @@ namespace {
 
 /* output bytes per batch: the largest T with R - T >= T + 1023 at R = 4096 (lz4_dec2.hip); a batch's literals have to
  * fit the input ring next to the chunk being staged */
-constexpr uint32_t kZT = 1536, kZLitMax = kInRing - kInChunk - 16u;
+constexpr uint32_t kZR = ZR, kZT = (kZR - 1024u) / 2u, kZLitMax = kInRing - kInChunk - 16u; /* (the copy engine keeps positions in 11 bits: T < 2048 whatever the ring) */
 
 struct ExecLds {
-    uint8_t ring[ZR + 16];   /* + the copy engine's 16-byte tail (lz4_copy.h) */
+    uint8_t ring[kZR + 16];   /* + the copy engine's 16-byte tail (lz4_copy.h) */
     uint8_t in[kInRing + 16];
     uint32_t meta[64];
-    uint32_t bm[CopyLds<ZR, kZT>::kWords];
+    uint32_t bm[CopyLds<kZR, kZT>::kWords];
 };
 
 /* execute one compressed block's sequences; false on malformed input */
-__device__ bool exec_block(ExecLds &L, Wave<ZR> &w, const ZPipe &P, const ZBlk *d, const uint8_t *src, uint32_t f,
+__device__ bool exec_block(ExecLds &L, Wave<kZR> &w, const ZPipe &P, const ZBlk *d, const uint8_t *src, uint32_t f,
                            uint32_t cap, uint32_t lane, Stats &st)
 {
     const uint32_t regen = uni(d->regen), nseq = uni(d->nseq);
@@ -1452,7 +1452,7 @@ __device__ bool exec_block(ExecLds &L, Wave<ZR> &w, const ZPipe &P, const ZBlk *
         const uint32_t ostart = oend - outlen;
         const uint32_t litend = scan64_incl(inq ? q_ll : 0u);
         const uint32_t mabs = w.op + ostart + q_ll;
-        const bool isfar = inq && q_off >= ZR - kZT; /* in the ring for the whole batch, or flushed before it (lz4_copy.h) */
+        const bool isfar = inq && q_off >= kZR - kZT; /* in the ring for the whole batch, or flushed before it (lz4_copy.h) */
         const bool ok = inq && streamed && (q_ml <= q_off || (q_off != 0u && q_ml <= 64u)) /* short self-overlap: a dependent match, lz4_copy.h */ && q_off <= mabs && !(isfar && q_ml > 32u) &&
                         litend <= regen - lit_pos && litend <= kZLitMax && oend <= kZT && (uint64_t)w.op + oend <= cap;
         const unsigned long long badmask = __ballot(!ok);
@@ -1465,7 +1465,7 @@ __device__ bool exec_block(ExecLds &L, Wave<ZR> &w, const ZPipe &P, const ZBlk *
              * sequence, dependent matches byte per lane; the rings' first 16 bytes are mirrored behind them */
             asm volatile("" ::: "memory");
             if (lane < 2u) *reinterpret_cast<uint2 *>(L.in + kInRing + lane * 8u) = *reinterpret_cast<const uint2 *>(L.in + lane * 8u);
-            else if (lane < 4u) *reinterpret_cast<uint2 *>(L.ring + ZR + (lane - 2u) * 8u) = *reinterpret_cast<const uint2 *>(L.ring + (lane - 2u) * 8u);
+            else if (lane < 4u) *reinterpret_cast<uint2 *>(L.ring + kZR + (lane - 2u) * 8u) = *reinterpret_cast<const uint2 *>(L.ring + (lane - 2u) * 8u);
             w.flush();
             uint4 xfa = make_uint4(0, 0, 0, 0), xfb = xfa;
             if (lane < nb && isfar) {
@@ -1473,8 +1473,8 @@ __device__ bool exec_block(ExecLds &L, Wave<ZR> &w, const ZPipe &P, const ZBlk *
                 __builtin_memcpy(&xfa, g, 16);
                 __builtin_memcpy(&xfb, g + 16, 16);
             }
-            const CopyLds<ZR, kZT> SL = {L.ring, L.in, L.meta, L.bm};
-            seq_copy<ZR, kZT>(w, SL, nb, ostart, q_ll, q_ml, q_off, lvp + (litend - q_ll), T, isfar, xfa, xfb, st);
+            const CopyLds<kZR, kZT> SL = {L.ring, L.in, L.meta, L.bm};
+            seq_copy<kZR, kZT>(w, SL, nb, ostart, q_ll, q_ml, q_off, lvp + (litend - q_ll), T, isfar, xfa, xfb, st);
             w.flush();
             lvp += lits;
             lit_pos += lits;
@@ -1525,7 +1525,7 @@ __global__ void __launch_bounds__(64) k_zexec(ZPipe P)
     const uint32_t nblk = uni(P.frames[f].nblk);
     const uint32_t B = P.B;
     Stats st = {};
-    Wave<ZR> w;
+    Wave<kZR> w;
     w.ring = L.ring;
     w.in = L.in;
     w.lane = lane;
