@@ -1069,9 +1069,7 @@ __device__ inline void chain_turn(uint8_t *ring, const uint16_t *tab, ChainLane 
         const uint32_t el = z.el, eo = z.eo, em = z.em;
         const uint32_t X = (el >> 11) + (eo >> 11) + (em >> 11); /* extra bits of the three codes */
         const uint32_t vl = el & 1023u, vm = em & 1023u, vo = eo & 1023u;
-        const bool lastq = z.i + 1u >= z.nseq;
-        const uint32_t nl = lastq ? 0u : (uint32_t)(__builtin_clz(vl) + cl), nm = lastq ? 0u : (uint32_t)(__builtin_clz(vm) + cm),
-                       no = lastq ? 0u : (uint32_t)(__builtin_clz(vo) + co);
+        const uint32_t nl = (uint32_t)(__builtin_clz(vl) + cl), nm = (uint32_t)(__builtin_clz(vm) + cm), no = (uint32_t)(__builtin_clz(vo) + co);
         const uint32_t N = nl + nm + no;
         const uint64_t win = z.raw << z.sh;
         uint32_t W = (uint32_t)((win << X) >> 32);
@@ -1092,10 +1090,9 @@ __device__ inline void chain_turn(uint8_t *ring, const uint16_t *tab, ChainLane 
         const uint32_t nso = (vo << no) - (1u << (co + 31)) + bo;
         const int32_t npos = z.pos - (int32_t)(X + N);
         rec = make_uint2((uint32_t)z.pos | (z.sl << 20), z.so | (z.sm << 8));
-        const bool keep = go & !lastq;
-        z.sl = keep ? nsl : z.sl;
-        z.sm = keep ? nsm : z.sm;
-        z.so = keep ? nso : z.so;
+        z.sl = go ? nsl : z.sl;
+        z.sm = go ? nsm : z.sm;
+        z.so = go ? nso : z.so;
         z.pos = go ? npos : z.pos;
         const bool neg = go & (npos < 0); /* read past the start of the stream */
         bad = bad | neg;
@@ -1195,7 +1192,7 @@ __global__ void __launch_bounds__(64) k_zchain(ZPipe P)
                 if ((o & (kChRing - 1u)) == 0u) *reinterpret_cast<uint2 *>(L.ring + myring + kChRing) = make_uint2(v.x, v.y);
             }
         z.lowh = z.fillh = hl;
-        z.nseq = d->nseq;
+        z.nseq = d->nseq - 1u; /* the turns take every sequence that is followed by state bits; the block's last one after the loop */
         z.pos = (int32_t)(sq_len - 1u) * 8 + (31 - __builtin_clz(last));
         /* initial states: LL, OF, ML from the top of the stream (<= 26 bits) */
         const int32_t cb = z.s0 + ((z.pos - 1) >> 3);
@@ -1207,7 +1204,7 @@ __global__ void __launch_bounds__(64) k_zchain(ZPipe P)
         z.so = __builtin_amdgcn_ubfe(W, 32u - lgl - lgo, lgo);
         z.sm = __builtin_amdgcn_ubfe(W, 32u - lgl - lgo - lgm, lgm);
         z.pos -= (int32_t)(lgl + lgo + lgm);
-        if (z.pos < 0) { bad = true; z.nseq = 0; z.pos = 0; }
+        if (z.pos < 0) { bad = true; z.nseq = 0; z.pos = 0; opened = false; }
     }
     __builtin_amdgcn_wave_barrier();
     z.cb = z.s0 + ((z.pos - 1) >> 3);
@@ -1238,6 +1235,11 @@ __global__ void __launch_bounds__(64) k_zchain(ZPipe P)
         chain_turn<2, false>(L.ring, tab, z, lane, grp0, fd2, fa2, fm2, g0, ve0, w0, r0, out, trash, cl, co, cm, myring, bad);
         chain_turn<3, true>(L.ring, tab, z, lane, grp1, fd3, fa3, fm3, g1, ve1, w1, r1, out, trash, cl, co, cm, myring, bad);
         chain_turn<3, false>(L.ring, tab, z, lane, grp1, fd3, fa3, fm3, g1, ve1, w1, r1, out, trash, cl, co, cm, myring, bad);
+    }
+    if (opened && !bad) { /* the last sequence: its extra bits, no state bits */
+        const uint32_t X = (z.el >> 11) + (z.eo >> 11) + (z.em >> 11);
+        out[z.i] = make_uint2((uint32_t)z.pos | (z.sl << 20), z.so | (z.sm << 8));
+        z.pos -= (int32_t)X;
     }
     if (opened && z.pos != 0) bad = true; /* the bitstream must be consumed exactly */
     if (bad) atomicOr(&P.frames[f].flags, F_BAD);
