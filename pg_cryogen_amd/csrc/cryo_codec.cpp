@@ -343,7 +343,7 @@ void cryo_codec_close(cryo_codec *c)
         if (c->ev_k[i]) (void)hipEventDestroy(c->ev_k[i]);
         if (c->ev_out[i]) (void)hipEventDestroy(c->ev_out[i]);
     }
-    for (int l = 0; l < 2; l++) {
+    for (int l = 0; l < cryo::kZstdLanes; l++) {
         if (c->aux.lane[l]) { (void)hipStreamSynchronize(c->aux.lane[l]); (void)hipStreamDestroy(c->aux.lane[l]); }
         if (c->aux.join[l]) (void)hipEventDestroy(c->aux.join[l]);
     }
@@ -526,7 +526,7 @@ int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
         int rc = ensure_ws(c, need);
         if (rc != CRYO_OK) return rc;
         if (!c->have_aux) {
-            for (int l = 0; l < 2; l++) {
+            for (int l = 0; l < cryo::kZstdLanes; l++) {
                 HIP_TRY(c, hipStreamCreateWithFlags(&c->aux.lane[l], hipStreamNonBlocking));
                 HIP_TRY(c, hipEventCreateWithFlags(&c->aux.join[l], hipEventDisableTiming));
             }

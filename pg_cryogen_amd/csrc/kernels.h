@@ -82,9 +82,10 @@ hipError_t launch_lz4_compress_batch64(hipStream_t s, const uint8_t *d_src, uint
 
 /* zstd frames.  `aux` (optional): two side streams + events the batch pipeline alternates its tiles on;
  * the work is ordered after everything already queued on `s`, and `s` waits for it before returning. */
+constexpr int kZstdLanes = 8; /* side streams a decode call may spread its tiles over */
 struct ZstdAux {
-    hipStream_t lane[2];
-    hipEvent_t fork, join[2];
+    hipStream_t lane[kZstdLanes];
+    hipEvent_t fork, join[kZstdLanes];
 };
 hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                   const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,

@@ -1634,12 +1634,11 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
 /* two tiles in flight on two side streams: the wave-per-frame kernels of one tile beside the entropy kernels of the
  * other (measured: 1 MiB blocks 95 -> 107 GB/s, where a tile has few frames; 128 KiB blocks 167 -> 173 GB/s,
  * profiles/r03_variants_ab.txt) */
-bool two_lanes(uint32_t block_size)
+int tile_lanes(uint32_t block_size)
 {
-    static const char *e = getenv("CRYO_ZSTD_LANES"); /* tuning aid: 1 / 2 */
-    if (e && e[0] == '1') return false;
-    (void)block_size;
-    return true;
+    static const char *e = getenv("CRYO_ZSTD_LANES"); /* tuning aid: 1 .. kZstdLanes */
+    if (e && e[0] >= '1' && e[0] <= '0' + kZstdLanes) return e[0] - '0';
+    return block_size <= (256u << 10) ? 4 : 2; /* measured, profiles/r03_zstd_tiles_in_flight.txt */
 }
 
 /* path: 0 automatic, 1 the fused one-wave-per-frame kernel, 2 the pipeline (CRYO_OPT_ZSTD_DECODE_PATH).  Automatic =
@@ -1654,7 +1653,9 @@ size_t zstd_decompress_workspace(uint64_t n_blocks, uint32_t block_size, int pat
 {
     if (!use_pipeline(path)) return zstd_fused_workspace(n_blocks);
     const Layout y = make_layout(n_blocks, block_size);
-    return ((two_lanes(block_size) && n_blocks > y.F) ? 2u : 1u) * y.total + 256;
+    const uint64_t nt = (n_blocks + y.F - 1u) / y.F;
+    const uint64_t nl = nt < (uint64_t)tile_lanes(block_size) ? nt : (uint64_t)tile_lanes(block_size);
+    return (size_t)nl * y.total + 256;
 }
 
 hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
@@ -1667,17 +1668,19 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
         return launch_zstd_fused(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status,
                                  d_workspace, workspace_bytes, nullptr, nullptr, 0);
     const Layout y = make_layout(n_blocks, block_size);
-    if (workspace_bytes < ((two_lanes(block_size) && n_blocks > y.F) ? 2u : 1u) * y.total) return hipErrorInvalidValue;
+
     uint8_t *ws0 = (uint8_t *)(((uintptr_t)d_workspace + 255u) & ~(uintptr_t)255u);
-    /* Tiles may alternate between two side streams with a workspace each (two_lanes()): the wave-per-frame
+    /* Tiles alternate between side streams with a workspace each (tile_lanes()): the wave-per-frame
      * kernels of one tile fill the CUs the other tile's leave idle.  K2/K3 themselves leave < 8 KB of LDS per
      * CU, so nothing co-resides with them: at 128 KiB (7680-frame tiles) the second lane gains nothing. */
     const uint64_t ntiles = (n_blocks + y.F - 1u) / y.F;
-    const int nl = (aux && ntiles > 1u && two_lanes(block_size)) ? 2 : 1;
+    int nl = aux ? tile_lanes(block_size) : 1;
+    if ((uint64_t)nl > ntiles) nl = (int)ntiles;
+    if (workspace_bytes < (size_t)nl * y.total) return hipErrorInvalidValue;
     hipError_t e;
-    if (nl == 2) {
+    if (nl > 1) {
         if ((e = hipEventRecord(aux->fork, s)) != hipSuccess) return e;
-        for (int l = 0; l < 2; l++)
+        for (int l = 0; l < nl; l++)
             if ((e = hipStreamWaitEvent(aux->lane[l], aux->fork, 0)) != hipSuccess) return e;
     }
     static const uint32_t huf_pad = getenv("CRYO_ZHUF_PAD") ? (uint32_t)atoi(getenv("CRYO_ZHUF_PAD")) : 0u; /* tuning aid: extra LDS to cap occupancy */
@@ -1687,7 +1690,7 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
     uint64_t t = 0;
     for (uint64_t first = 0; first < n_blocks; first += y.F, t++) {
         const int l = (int)(t % (uint64_t)nl);
-        hipStream_t st = nl == 2 ? aux->lane[l] : s;
+        hipStream_t st = nl > 1 ? aux->lane[l] : s;
         uint8_t *ws = ws0 + (size_t)l * y.total;
         ZPipe P;
         P.src_base = d_src; P.src_off = d_src_off; P.src_size = d_src_size;
@@ -1743,8 +1746,8 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
             fprintf(stderr, "\n[zstd pipe] k_zhufw wave time, units of 64 memtime ticks summed over waves: setup %u head %u body %u tail %u resolve+copy %u\n[zstd pipe] k_zplan: literals section (Huffman table) %u, sequence headers %u, FSE tables %u, table copies %u\n", h[56], h[57], h[58], h[59], h[62], h[17], h[18], h[19], h[63]);
         }
     }
-    if (nl == 2) {
-        for (int l = 0; l < 2; l++) {
+    if (nl > 1) {
+        for (int l = 0; l < nl; l++) {
             if ((e = hipEventRecord(aux->join[l], aux->lane[l])) != hipSuccess) return e;
             if ((e = hipStreamWaitEvent(s, aux->join[l], 0)) != hipSuccess) return e;
         }
