@@ -1670,9 +1670,9 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
     const Layout y = make_layout(n_blocks, block_size);
 
     uint8_t *ws0 = (uint8_t *)(((uintptr_t)d_workspace + 255u) & ~(uintptr_t)255u);
-    /* Tiles alternate between side streams with a workspace each (tile_lanes()): the wave-per-frame
-     * kernels of one tile fill the CUs the other tile's leave idle.  K2/K3 themselves leave < 8 KB of LDS per
-     * CU, so nothing co-resides with them: at 128 KiB (7680-frame tiles) the second lane gains nothing. */
+    /* Tiles alternate between side streams with a workspace each (tile_lanes()): the kernels of one tile fill what
+     * another tile's leave idle (k_zchain holds the whole LDS with two waves per CU, the tail of every kernel leaves CUs
+     * empty).  65 536 x 128 KiB: 259 / 274 / 292 / 302 GB/s with 1 / 2 / 3 / 4 tiles in flight, no more beyond. */
     const uint64_t ntiles = (n_blocks + y.F - 1u) / y.F;
     int nl = aux ? tile_lanes(block_size) : 1;
     if ((uint64_t)nl > ntiles) nl = (int)ntiles;
