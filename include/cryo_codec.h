@@ -66,7 +66,9 @@ int cryo_codec_sync(cryo_codec *c);
  * Values are read at every call, so a test can flip a path between two batches of one handle. */
 typedef enum {
     /* LZ4 decode path: 0 = automatic (by the work in the batch), 1 = in-wave parse kernel (k_lz4_dec_ring),
-     * 2 = sequence index + indexed decoder (k_lz4_index* + k_lz4_dec_seq) whatever the batch size */
+     * 2 = sequence index + indexed decoder (k_lz4_index* + k_lz4_dec_seq) whatever the batch size, 3 = the few-blocks path
+     * (every output byte in parallel, k_lat_*; calls it is not made for -- more than 64 blocks or 64 MiB, blocks below
+     * 32 KiB or above 2 MiB -- take the automatic choice) */
     CRYO_OPT_LZ4_DECODE_PATH = 1,
     /* walkers per block of the sequence-index pass: 0 = automatic, else a power of two 1..64 */
     CRYO_OPT_LZ4_INDEX_WALKERS = 2,

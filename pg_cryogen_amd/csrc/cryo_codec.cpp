@@ -361,7 +361,7 @@ int cryo_codec_set_option(cryo_codec *c, int option, int64_t value)
     if (!c) return CRYO_E_ARG;
     switch (option) {
     case CRYO_OPT_LZ4_DECODE_PATH:
-        if (value < 0 || value > 2) return CRYO_E_ARG;
+        if (value < 0 || value > 3) return CRYO_E_ARG;
         c->lz4_opts.path = (int)value;
         return CRYO_OK;
     case CRYO_OPT_LZ4_INDEX_WALKERS:

@@ -32,7 +32,7 @@ hipError_t launch_gather_blocks(hipStream_t s, const uint8_t *d_pool, const Gath
 /* LZ4 block format */
 /* per-handle options (include/cryo_codec.h: CRYO_OPT_LZ4_DECODE_PATH, CRYO_OPT_LZ4_INDEX_WALKERS); 0 = automatic */
 struct Lz4DecodeOpts {
-    int path = 0;    /* 1: in-wave parse kernel, 2: sequence index + indexed decoder */
+    int path = 0;    /* 1: in-wave parse kernel, 2: sequence index + indexed decoder, 3: few blocks, every output byte in parallel (lz4_lat.hip) */
     int walkers = 0; /* walkers per block of the index pass (power of two, 1..64) */
 };
 hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
@@ -70,6 +70,14 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
                                          const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                          uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
                                          size_t workspace_bytes, uint32_t walkers);
+
+/* lz4_lat.hip: few blocks per call (the reference's own call shapes) */
+bool lz4_latency_eligible(uint64_t n_blocks, uint32_t block_size);
+size_t lz4_latency_workspace(uint64_t n_blocks, uint32_t block_size);
+hipError_t launch_lz4_decompress_latency(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
+                                         const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
+                                         uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
+                                         size_t workspace_bytes);
 
 hipError_t launch_lz4_compress(hipStream_t s, const uint8_t *d_src, uint64_t src_stride,
                                uint32_t block_size, uint64_t n_blocks, uint8_t *d_dst,

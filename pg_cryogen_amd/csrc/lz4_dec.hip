@@ -562,8 +562,16 @@ uint32_t lz4_decode_plan(uint64_t n_blocks, uint32_t block_size, const Lz4Decode
     while (S < 64u && n_blocks * (2u * S) <= 65536u && block_size / (2u * S) >= 4096u) S *= 2u;
     return S;
 }
+/* the few-blocks path (lz4_lat.hip): asked for, or automatic for what it is made for */
+static bool lz4_use_latency(uint64_t n_blocks, uint32_t block_size, const Lz4DecodeOpts &opts)
+{
+    if (!lz4_latency_eligible(n_blocks, block_size)) return false;
+    return opts.path == 3 || (opts.path == 0 && opts.walkers == 0);
+}
+
 size_t lz4_decompress_workspace(uint64_t n_blocks, uint32_t block_size, const Lz4DecodeOpts &opts)
 {
+    if (lz4_use_latency(n_blocks, block_size, opts)) return lz4_latency_workspace(n_blocks, block_size);
     const uint32_t S = lz4_decode_plan(n_blocks, block_size, opts);
     return S ? lz4_index_layout(n_blocks, block_size, S).bytes : 0;
 }
@@ -576,6 +584,9 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
     if (n_blocks == 0) return hipSuccess;
     const uint64_t grid = (n_blocks + 3) / 4;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
+    if (lz4_use_latency(n_blocks, block_size, opts))
+        return launch_lz4_decompress_latency(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status,
+                                             d_workspace, workspace_bytes);
     /* sequence index pass + the decoder built for it (lz4_dec2.hip) */
     const uint32_t S = lz4_decode_plan(n_blocks, block_size, opts);
     if (S != 0) {

@@ -257,7 +257,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
               const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
               uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats,
               const uint16_t *__restrict__ tbl, uint32_t tbl_cap, const uint2 *__restrict__ seg, const uint32_t logS,
-              const uint32_t cap_s, const uint32_t ext, const uint32_t skip_heavy)
+              const uint32_t cap_s, const uint32_t ext, const uint32_t skip_heavy, const uint32_t *__restrict__ decoded)
 {
     Stats st = {};
     st.on = STATS;
@@ -275,6 +275,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     const uint8_t *base = src_base + uni64(src_off[blk]);
     const uint32_t csize = uni(src_size[blk]);
     if (skip_heavy != 0u && lz4_literal_heavy(csize, B)) return; /* left to the in-wave parser (kernels.h) */
+    if (decoded != nullptr && uni(decoded[blk]) != 0u) return;        /* by the few-blocks path (lz4_lat.hip) */
 
     Wave<R> w;
     const CopyLds<R, kT2> L = {s_ring[wid], s_in[wid], s_mmeta[wid], s_mbm[wid]};
@@ -383,13 +384,22 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
 /* ---- launcher ---- */
 static void launch_dec_seq(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size, uint8_t *d_dst,
                            uint64_t dst_stride, uint32_t block_size, uint64_t n_blocks, int32_t *d_status, const void *ws,
-                           const Lz4IndexLayout &Lx)
+                           const Lz4IndexLayout &Lx, const uint32_t *d_done = nullptr)
 {
     const uint16_t *tbl = static_cast<const uint16_t *>(ws);
     const uint2 *seg = reinterpret_cast<const uint2 *>(static_cast<const uint8_t *>(ws) + Lx.seg_off);
     hipLaunchKernelGGL((k_lz4_dec_seq<4096, false>), dim3((uint32_t)((n_blocks + 3) / 4)), dim3(256), 0, s, d_src, d_src_off, d_src_size,
                        d_dst, dst_stride, block_size, n_blocks, d_status, nullptr, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext,
-                       Lx.logS != 0u ? 1u : 0u);
+                       Lx.logS != 0u ? 1u : 0u, d_done);
+}
+
+/* the blocks the few-blocks path did not decode (lz4_lat.hip), with the index it built */
+hipError_t launch_lz4_dec_seq_rest(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
+                                   uint8_t *d_dst, uint64_t dst_stride, uint32_t block_size, uint64_t n_blocks, int32_t *d_status,
+                                   const void *ws, const Lz4IndexLayout &Lx, const uint32_t *d_done)
+{
+    launch_dec_seq(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, ws, Lx, d_done);
+    return hipGetLastError();
 }
 
 hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
@@ -415,7 +425,7 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
         (void)hipMemcpyAsync(d_st + 7, &abl, sizeof abl, hipMemcpyHostToDevice, s);
         hipLaunchKernelGGL((k_lz4_dec_seq<4096, true>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
                            block_size, n_blocks, d_status, d_st, static_cast<const uint16_t *>(d_workspace), Lx.cap,
-                           reinterpret_cast<const uint2 *>(static_cast<const uint8_t *>(d_workspace) + Lx.seg_off), Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, 0u);
+                           reinterpret_cast<const uint2 *>(static_cast<const uint8_t *>(d_workspace) + Lx.seg_off), Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, 0u, nullptr);
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
         (void)hipFree(d_st);

@@ -1,0 +1,437 @@
+/*
+ * lz4_lat.hip -- LZ4 block decode for FEW blocks per call: every output byte in parallel.
+ *
+ * Part of what replaces LZ4_decompress_safe(compressed, out, compressed_size, CRYO_BLCKSZ) (reference
+ * compression.c:84) -- for the call shapes the reference itself has: one block per call (pg_cryogen.c:726,
+ * cache.c:178), 16 cache slots (cache.c:17).  In the batch decoder (lz4_dec2.hip) a block is one wavefront's serial job:
+ * 51 000 sequences of a 1 MiB block take 3 ms however idle the other 255 CUs are, and the copy of one block cannot be
+ * cut into independent parts (on tuple data 85 % of the offsets are below 3 KiB: every part waits for the end of the one
+ * before it).  What can be done in parallel is to resolve, for every output byte, WHERE ITS VALUE COMES FROM:
+ *
+ *   1  k_lz4_index with 64 walkers per block (lz4_index.hip) finds the sequences;
+ *   2  k_lat_parse: a thread per sequence reads its token (literal length, match length, offset, where the next token
+ *      starts) -- and checks everything LZ4_decompress_safe checks on the compressed side;
+ *   3  k_lat_scan / k_lat_place: output positions by a prefix sum of the sequence lengths; the checks on the output
+ *      side (offsets inside the block, the end-of-block rules), the chain of tokens (each one starts where the one
+ *      before says);
+ *   4  k_lat_fill: a thread per 16 output bytes finds its sequence (binary search), copies literal bytes from the
+ *      stream and writes src[b] = b for them, src[b] = b - offset for match bytes;
+ *   5  k_lat_jump, up to log2(B) + 1 rounds of pointer jumping: src[b] = src[src[b]] until every byte points at a
+ *      literal byte (a round in which nothing changed ends it: later launches return at once);
+ *   6  k_lat_gather: out[b] = out[src[b]].
+ *
+ * Anything that is not a plain valid block -- a check that fails, offset 0 (liblz4 zero-fills), an index the walkers
+ * could not complete, a block of almost only literals (left out of the index) -- leaves the block to the batch decoder,
+ * which runs afterwards over the blocks not marked done: verdicts and bytes are its.
+ */
+#include "lz_common.h"
+#include "kernels.h"
+
+namespace cryo {
+
+namespace {
+
+constexpr uint32_t kLatLogS = 6, kLatS = 64;       /* walkers per block of the index pass */
+constexpr uint32_t kMFLimit = 12, kLastLiterals = 5; /* LZ4_decompress_safe's end-of-block rules (lz4.c) */
+
+struct LatArgs {
+    const uint8_t *src_base;
+    const uint64_t *src_off;
+    const uint32_t *src_size;
+    uint8_t *dst_base;
+    uint64_t dst_stride;
+    uint32_t B, n_blocks;
+    int32_t *status;
+    /* the index (lz4_index.hip) */
+    const uint16_t *tbl;
+    const uint2 *seg;
+    uint32_t tbl_cap, cap_s, ext;
+    /* per block */
+    uint32_t nmax;      /* sequence slots per block */
+    uint32_t *segbase;  /* [n_blocks][64]: first sequence of segment s */
+    uint32_t *nseq;     /* [n_blocks] */
+    uint32_t *ok;       /* [n_blocks] 1: this path decodes the block */
+    uint32_t *done;     /* [n_blocks] 1: decoded here (the batch decoder skips it) */
+    uint32_t *pos, *opos, *ll, *lpos, *ml, *off, *nxt; /* [n_blocks][nmax] */
+    uint32_t *wgsum;    /* [n_blocks][nmax / 256] */
+    uint32_t *src;      /* [n_blocks][B rounded up to 16] */
+    uint32_t *changed;  /* [rounds + 1] */
+    uint32_t bpad;      /* B rounded up to 4096 */
+};
+
+/* segments of a block exactly as k_lz4_index cuts them (lz4_index.hip) */
+__device__ inline void lat_segments(uint32_t cs, uint32_t &seff, uint32_t &seglen)
+{
+    const uint32_t kib = cs >> 10;
+    const uint32_t lg = kib ? 31u - (uint32_t)__builtin_clz(kib) : 0u;
+    const uint32_t ls_ = lg < kLatLogS ? lg : kLatLogS;
+    seff = 1u << ls_;
+    seglen = (cs + seff - 1u) >> ls_;
+}
+
+/* sequences per segment -> first sequence of every segment, sequences of the block */
+__global__ void __launch_bounds__(64) k_lat_segs(LatArgs A)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t blk = blockIdx.x;
+    const uint2 d = A.seg[((uint64_t)blk << kLatLogS) + lane];
+    const uint32_t c = (d.x & 0xffffu) + d.y;
+    const uint32_t incl = scan64_incl(c);
+    A.segbase[blk * 64u + lane] = incl - c;
+    const uint32_t total = lane_get(incl, 63);
+    uint32_t seff, seglen;
+    lat_segments(uni(A.src_size[blk]), seff, seglen);
+    /* the walkers' chains did not all meet (the block's first lane walked all of it: positions more than 64 KiB from
+     * the segment's start cannot be told from the 16-bit entries), or the block was left out of the index */
+    const unsigned long long later = __ballot(lane != 0u && c != 0u);
+    const bool plain = total != 0u && total <= A.nmax && (seff == 1u || later != 0ull) && seglen < 0xF000u;
+    if (lane == 0u) {
+        A.nseq[blk] = total;
+        A.ok[blk] = plain ? 1u : 0u;
+        A.done[blk] = 0u;
+    }
+}
+
+/* a thread per sequence: the token */
+__global__ void __launch_bounds__(256) k_lat_parse(LatArgs A)
+{
+    __shared__ uint32_t s_base[65];
+    __shared__ uint32_t s_sum[4];
+    __shared__ uint32_t s_ok;
+    const uint32_t blk = blockIdx.y;
+    const uint32_t n = A.nseq[blk];
+    if (blockIdx.x * 256u >= n) return;
+    if (threadIdx.x < 64u) s_base[threadIdx.x] = A.segbase[blk * 64u + threadIdx.x];
+    if (threadIdx.x == 64u) s_base[64] = n;
+    if (threadIdx.x == 65u) s_ok = A.ok[blk];
+    __syncthreads();
+    if (s_ok == 0u) return;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool on = i < n;
+    uint32_t len = 0;
+    if (on) {
+        uint32_t s = 0; /* the last segment that starts at or before i */
+#pragma unroll
+        for (uint32_t st = 32u; st >= 1u; st >>= 1) s += s_base[s + st] <= i ? st : 0u;
+        const uint32_t t = i - s_base[s];
+        const uint2 d = A.seg[((uint64_t)blk << kLatLogS) + s];
+        const uint32_t ne = d.x & 0xffffu;
+        const uint16_t *row = A.tbl + (uint64_t)blk * A.tbl_cap + s * A.cap_s;
+        const uint32_t e16 = t < ne ? row[t] : row[A.ext + (d.x >> 16) + (t - ne)];
+        const uint32_t cs = A.src_size[blk];
+        uint32_t seff, seglen;
+        lat_segments(cs, seff, seglen);
+        const uint32_t g = s * seglen; /* every entry of segment s lies at or behind it, less than 64 KiB away */
+        const uint32_t p = g + ((e16 - g) & 0xffffu);
+        const uint8_t *sb = A.src_base + A.src_off[blk];
+        bool good = p < cs;
+        uint32_t ll = 0, lp = 0, ml = 0, of = 0, nx = 0;
+        if (good) {
+            /* the literal length, read as LZ4_decompress_safe reads it (lz4.c, oracle/lz4_oracle.c) */
+            const uint32_t token = sb[p];
+            uint32_t ip = p + 1u;
+            ll = token >> 4;
+            if (ll == 15u) {
+                if (ip + 15u >= cs) good = false;
+                else {
+                    uint32_t b;
+                    do {
+                        b = sb[ip++];
+                        ll += b;
+                        if (ip + 15u >= cs) break;
+                    } while (b == 255u && ll < 0x01000000u);
+                    if (ll >= 0x01000000u) good = false;
+                }
+            }
+            lp = ip;
+            if (good) {
+                if ((uint64_t)ip + ll + 8u > cs) { /* the block's last sequence: literals to the end of the stream */
+                    if (ip + ll != cs) good = false;
+                    nx = cs;
+                    ml = 0;
+                    of = 0;
+                } else {
+                    ip += ll;
+                    of = (uint32_t)sb[ip] | ((uint32_t)sb[ip + 1u] << 8);
+                    ip += 2u;
+                    ml = token & 15u;
+                    if (ml == 15u) {
+                        uint32_t b;
+                        do {
+                            b = sb[ip++];
+                            ml += b;
+                            if (ip + 4u >= cs) { good = false; break; }
+                        } while (b == 255u && ml < 0x01000000u);
+                        if (ml >= 0x01000000u) good = false;
+                    }
+                    ml += 4u;
+                    nx = ip;
+                    if (of == 0u) good = false; /* liblz4 fills with zeros: the batch decoder's business */
+                }
+            }
+        }
+        if (!good) A.ok[blk] = 0u;
+        const uint64_t q = (uint64_t)blk * A.nmax + i;
+        A.pos[q] = p; A.ll[q] = ll; A.lpos[q] = lp; A.ml[q] = ml; A.off[q] = of; A.nxt[q] = nx;
+        len = good ? ll + ml : 0u;
+    }
+    /* the workgroup's bytes */
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t incl = scan64_incl(len);
+    if (lane == 63u) s_sum[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0u) A.wgsum[blk * (A.nmax / 256u) + blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+}
+
+/* a wave per block: exclusive scan of the workgroups' bytes (in place) */
+__global__ void __launch_bounds__(64) k_lat_scan(LatArgs A)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t blk = blockIdx.x;
+    if (uni(A.ok[blk]) == 0u) return;
+    const uint32_t nw = (uni(A.nseq[blk]) + 255u) / 256u;
+    uint32_t *w = A.wgsum + blk * (A.nmax / 256u);
+    uint32_t carry = 0;
+    for (uint32_t b0 = 0; b0 < nw; b0 += 64u) {
+        const uint32_t v = b0 + lane < nw ? w[b0 + lane] : 0u;
+        const uint32_t incl = scan64_incl(v);
+        if (b0 + lane < nw) w[b0 + lane] = carry + incl - v;
+        carry += lane_get(incl, 63);
+    }
+    if (carry != A.B && lane == 0u) A.ok[blk] = 0u; /* the block does not decode to B bytes */
+}
+
+/* a thread per sequence: output position, the checks that need it, the chain of tokens */
+__global__ void __launch_bounds__(256) k_lat_place(LatArgs A)
+{
+    __shared__ uint32_t s_sum[4];
+    __shared__ uint32_t s_ok;
+    const uint32_t blk = blockIdx.y;
+    const uint32_t n = A.nseq[blk];
+    if (blockIdx.x * 256u >= n) return;
+    if (threadIdx.x == 0u) s_ok = A.ok[blk];
+    __syncthreads();
+    if (s_ok == 0u) return;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool on = i < n;
+    const uint64_t q = (uint64_t)blk * A.nmax + i;
+    uint32_t ll = 0, ml = 0;
+    if (on) { ll = A.ll[q]; ml = A.ml[q]; }
+    const uint32_t len = ll + ml;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t incl = scan64_incl(len);
+    if (lane == 63u) s_sum[wv] = incl;
+    __syncthreads();
+    uint32_t before = A.wgsum[blk * (A.nmax / 256u) + blockIdx.x];
+    for (uint32_t k = 0; k < wv; k++) before += s_sum[k];
+    const uint32_t op = before + incl - len;
+    if (on) {
+        A.opos[q] = op;
+        const uint32_t cs = A.src_size[blk];
+        bool good = true;
+        if (i == 0u) good = A.pos[q] == 0u;
+        if (i + 1u < n) {
+            /* not the last sequence: LZ4_decompress_safe must not have taken it for the last one, its match must start
+             * inside the output and end at least LASTLITERALS before the end of the block, and the next token starts
+             * where this one says */
+            good = good && ml != 0u && op + ll + kMFLimit <= A.B && A.off[q] <= op + ll && op + len + kLastLiterals <= A.B &&
+                   A.nxt[q] == A.pos[q + 1u];
+        } else {
+            good = good && ml == 0u && A.nxt[q] == cs && op + ll == A.B;
+        }
+        if (!good) A.ok[blk] = 0u;
+    }
+}
+
+/* a thread per 16 output bytes: literal bytes and where the match bytes come from */
+__global__ void __launch_bounds__(256) k_lat_fill(LatArgs A)
+{
+    const uint32_t blk = blockIdx.y;
+    if (A.ok[blk] == 0u) return;
+    const uint32_t b0 = (blockIdx.x * 256u + threadIdx.x) * 16u;
+    if (b0 >= A.B) return;
+    const uint32_t n = A.nseq[blk];
+    const uint64_t qb = (uint64_t)blk * A.nmax;
+    const uint32_t *opos = A.opos + qb;
+    /* the last sequence that starts at or before b0 */
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (opos[mid] <= b0) lo = mid; else hi = mid;
+    }
+    uint32_t i = lo;
+    uint32_t so = opos[i], sl = A.ll[qb + i], sm = A.ml[qb + i], sf = A.off[qb + i], sp = A.lpos[qb + i];
+    const uint8_t *sb = A.src_base + A.src_off[blk];
+    uint32_t *srcb = A.src + (uint64_t)blk * A.bpad;
+    uint8_t *dst = A.dst_base + (uint64_t)blk * A.dst_stride;
+    uint32_t v[4] = {0, 0, 0, 0};
+    uint32_t sx[16];
+#pragma unroll
+    for (uint32_t k = 0; k < 16u; k++) {
+        const uint32_t b = b0 + k;
+        while (b >= so + sl + sm && i + 1u < n) {
+            i++;
+            so = opos[i]; sl = A.ll[qb + i]; sm = A.ml[qb + i]; sf = A.off[qb + i]; sp = A.lpos[qb + i];
+        }
+        uint32_t from = b;
+        if (b < A.B) {
+            if (b < so + sl) v[k >> 2] |= (uint32_t)sb[sp + (b - so)] << (8u * (k & 3u));
+            else from = b - sf;
+        }
+        sx[k] = from;
+    }
+    if (b0 + 16u <= A.B) *reinterpret_cast<uint4 *>(dst + b0) = make_uint4(v[0], v[1], v[2], v[3]);
+    else for (uint32_t k = 0; k < 16u && b0 + k < A.B; k++) dst[b0 + k] = (uint8_t)(v[k >> 2] >> (8u * (k & 3u)));
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++)
+        *reinterpret_cast<uint4 *>(srcb + b0 + 4u * k) = make_uint4(sx[4 * k], sx[4 * k + 1], sx[4 * k + 2], sx[4 * k + 3]);
+}
+
+/* one round of pointer jumping over every byte of every block this path decodes */
+__global__ void __launch_bounds__(256) k_lat_jump(LatArgs A, uint32_t round)
+{
+    const uint32_t blk = blockIdx.y;
+    if (A.ok[blk] == 0u) return;
+    if (round != 0u && A.changed[round - 1u] == 0u) return; /* the round before changed nothing: done */
+    const uint32_t b0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (b0 >= A.B) return;
+    uint32_t *srcb = A.src + (uint64_t)blk * A.bpad;
+    uint4 s4 = *reinterpret_cast<const uint4 *>(srcb + b0);
+    uint32_t s[4] = {s4.x, s4.y, s4.z, s4.w};
+    uint32_t t[4];
+    bool ch = false;
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) t[k] = s[k] != b0 + k ? srcb[s[k]] : s[k];
+#pragma unroll
+    for (uint32_t k = 0; k < 4u; k++) ch = ch || t[k] != s[k];
+    if (ch) *reinterpret_cast<uint4 *>(srcb + b0) = make_uint4(t[0], t[1], t[2], t[3]);
+    if (__any(ch) && (threadIdx.x & 63u) == 0u) A.changed[round] = 1u; /* a plain store: 65 000 atomics on one word took 0.3 ms a round */
+}
+
+/* match bytes from the literal bytes they come from */
+__global__ void __launch_bounds__(256) k_lat_gather(LatArgs A)
+{
+    const uint32_t blk = blockIdx.y;
+    if (A.ok[blk] == 0u) return;
+    const uint32_t b0 = (blockIdx.x * 256u + threadIdx.x) * 16u;
+    if (b0 < A.B) {
+        const uint32_t *srcb = A.src + (uint64_t)blk * A.bpad;
+        uint8_t *dst = A.dst_base + (uint64_t)blk * A.dst_stride;
+        uint32_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (uint32_t k4 = 0; k4 < 4u; k4++) {
+            const uint4 s4 = *reinterpret_cast<const uint4 *>(srcb + b0 + 4u * k4);
+            const uint32_t s[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; k++)
+                if (b0 + 4u * k4 + k < A.B) v[k4] |= (uint32_t)dst[s[k]] << (8u * k);
+        }
+        if (b0 + 16u <= A.B) *reinterpret_cast<uint4 *>(dst + b0) = make_uint4(v[0], v[1], v[2], v[3]);
+        else for (uint32_t k = 0; k < 16u && b0 + k < A.B; k++) dst[b0 + k] = (uint8_t)(v[k >> 2] >> (8u * (k & 3u)));
+    }
+    if (blockIdx.x == 0u && threadIdx.x == 0u) {
+        A.status[blk] = CRYO_ST_OK;
+        A.done[blk] = 1u;
+    }
+}
+
+struct LatLayout {
+    Lz4IndexLayout ix;
+    uint32_t nmax, bpad, rounds;
+    size_t o_segbase, o_nseq, o_ok, o_done, o_pos, o_opos, o_ll, o_lpos, o_ml, o_off, o_nxt, o_wgsum, o_src, o_changed, bytes;
+};
+
+inline size_t al256(size_t v) { return (v + 255u) & ~(size_t)255u; }
+
+LatLayout lat_layout(uint64_t n, uint32_t B)
+{
+    LatLayout y;
+    y.ix = lz4_index_layout(n, B, kLatS);
+    y.nmax = (kLatS * (y.ix.cap_main + y.ix.ext) + 255u) & ~255u;
+    y.bpad = (B + 4095u) & ~4095u;
+    y.rounds = 2;
+    while ((1u << (y.rounds - 1u)) < B) y.rounds++; /* a chain is at most B hops long */
+    size_t o = al256(y.ix.bytes);
+    y.o_segbase = o; o = al256(o + n * 64u * 4u);
+    y.o_nseq = o; o = al256(o + n * 4u);
+    y.o_ok = o; o = al256(o + n * 4u);
+    y.o_done = o; o = al256(o + n * 4u);
+    const size_t per = (size_t)n * y.nmax * 4u;
+    y.o_pos = o; o = al256(o + per + 16u);
+    y.o_opos = o; o = al256(o + per);
+    y.o_ll = o; o = al256(o + per);
+    y.o_lpos = o; o = al256(o + per);
+    y.o_ml = o; o = al256(o + per);
+    y.o_off = o; o = al256(o + per);
+    y.o_nxt = o; o = al256(o + per);
+    y.o_wgsum = o; o = al256(o + n * (y.nmax / 256u) * 4u);
+    y.o_src = o; o = al256(o + (size_t)n * y.bpad * 4u);
+    y.o_changed = o; o = al256(o + (y.rounds + 1u) * 4u);
+    y.bytes = o;
+    return y;
+}
+
+} // namespace
+
+bool lz4_latency_eligible(uint64_t n_blocks, uint32_t block_size)
+{
+    return n_blocks >= 1u && n_blocks <= 64u && block_size >= (32u << 10) && block_size <= (2u << 20) &&
+           n_blocks * (uint64_t)block_size <= (64ull << 20);
+}
+
+size_t lz4_latency_workspace(uint64_t n_blocks, uint32_t block_size) { return lat_layout(n_blocks, block_size).bytes; }
+
+hipError_t launch_lz4_dec_seq_rest(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
+                                   uint8_t *d_dst, uint64_t dst_stride, uint32_t block_size, uint64_t n_blocks, int32_t *d_status,
+                                   const void *ws, const Lz4IndexLayout &Lx, const uint32_t *d_done);
+
+hipError_t launch_lz4_decompress_latency(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
+                                         const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
+                                         uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
+                                         size_t workspace_bytes)
+{
+    if (n_blocks == 0) return hipSuccess;
+    if (!lz4_latency_eligible(n_blocks, block_size) || !d_workspace) return hipErrorInvalidValue;
+    const LatLayout y = lat_layout(n_blocks, block_size);
+    if (workspace_bytes < y.bytes) return hipErrorInvalidValue;
+    uint8_t *ws = static_cast<uint8_t *>(d_workspace);
+    if (hipError_t e = launch_lz4_index(s, d_src, d_src_off, d_src_size, n_blocks, block_size, d_workspace, y.ix); e != hipSuccess) return e;
+    LatArgs A;
+    A.src_base = d_src; A.src_off = d_src_off; A.src_size = d_src_size;
+    A.dst_base = d_dst; A.dst_stride = dst_stride; A.B = block_size; A.n_blocks = (uint32_t)n_blocks; A.status = d_status;
+    A.tbl = reinterpret_cast<const uint16_t *>(ws);
+    A.seg = reinterpret_cast<const uint2 *>(ws + y.ix.seg_off);
+    A.tbl_cap = y.ix.cap; A.cap_s = y.ix.cap_main + y.ix.ext; A.ext = y.ix.ext;
+    A.nmax = y.nmax;
+    A.segbase = reinterpret_cast<uint32_t *>(ws + y.o_segbase);
+    A.nseq = reinterpret_cast<uint32_t *>(ws + y.o_nseq);
+    A.ok = reinterpret_cast<uint32_t *>(ws + y.o_ok);
+    A.done = reinterpret_cast<uint32_t *>(ws + y.o_done);
+    A.pos = reinterpret_cast<uint32_t *>(ws + y.o_pos);
+    A.opos = reinterpret_cast<uint32_t *>(ws + y.o_opos);
+    A.ll = reinterpret_cast<uint32_t *>(ws + y.o_ll);
+    A.lpos = reinterpret_cast<uint32_t *>(ws + y.o_lpos);
+    A.ml = reinterpret_cast<uint32_t *>(ws + y.o_ml);
+    A.off = reinterpret_cast<uint32_t *>(ws + y.o_off);
+    A.nxt = reinterpret_cast<uint32_t *>(ws + y.o_nxt);
+    A.wgsum = reinterpret_cast<uint32_t *>(ws + y.o_wgsum);
+    A.src = reinterpret_cast<uint32_t *>(ws + y.o_src);
+    A.changed = reinterpret_cast<uint32_t *>(ws + y.o_changed);
+    A.bpad = y.bpad;
+    if (hipError_t e = hipMemsetAsync(A.changed, 0, (y.rounds + 1u) * 4u, s); e != hipSuccess) return e;
+    const uint32_t nb = (uint32_t)n_blocks;
+    hipLaunchKernelGGL(k_lat_segs, dim3(nb), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(k_lat_parse, dim3(y.nmax / 256u, nb), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_lat_scan, dim3(nb), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(k_lat_place, dim3(y.nmax / 256u, nb), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_lat_fill, dim3((block_size + 4095u) / 4096u, nb), dim3(256), 0, s, A);
+    for (uint32_t r = 0; r < y.rounds; r++)
+        hipLaunchKernelGGL(k_lat_jump, dim3((block_size + 1023u) / 1024u, nb), dim3(256), 0, s, A, r);
+    hipLaunchKernelGGL(k_lat_gather, dim3((block_size + 4095u) / 4096u, nb), dim3(256), 0, s, A);
+    /* what was left: the batch decoder with the same index, the in-wave parser for blocks of almost only literals */
+    if (hipError_t e = launch_lz4_dec_seq_rest(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status,
+                                               d_workspace, y.ix, A.done); e != hipSuccess) return e;
+    return launch_lz4_dec_ring(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, true);
+}
+
+} // namespace cryo

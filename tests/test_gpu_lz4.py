@@ -466,6 +466,88 @@ def test_indexed_decoder_packed_offsets_and_ragged_batch(codec, oracle):
         x.free()
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# The few-blocks path (lz4_lat.hip: every output byte in parallel; what one block per call -- the reference's own call
+# shape, pg_cryogen.c:726, cache.c:178 -- and its 16 cache slots get).  Forced by option so that the batches below take it
+# whatever the automatic choice becomes; anything it does not decode itself goes to the batch decoder in the same call,
+# so verdicts and bytes must be the oracle's for corrupted streams too.
+# ---------------------------------------------------------------------------------------------------------------
+def _few_blocks(codec):
+    from pg_cryogen_amd import codec as cc
+
+    class _Ctx:
+        def __enter__(self_):
+            codec.set_option(cc.OPT_LZ4_DECODE_PATH, cc.LZ4_PATH_FEW_BLOCKS)
+
+        def __exit__(self_, *a):
+            codec.set_option(cc.OPT_LZ4_DECODE_PATH, cc.LZ4_PATH_AUTO)
+    return _Ctx()
+
+
+@pytest.mark.parametrize("B", [32768, 131072, 400000, 1 << 20])
+def test_few_blocks_path_distributions(codec, oracle, B):
+    """all five distributions x accelerations 1 / 7 / 50, one block per call and 15 per call"""
+    blocks, comps = [], []
+    for d in range(5):
+        for a in (1, 7, 50):
+            b = oracle.synth(31 + a, d, B, d)
+            blocks.append(b)
+            comps.append(oracle.lz4_compress(b, a))
+    with _few_blocks(codec):
+        _decode_check(codec, comps, blocks, B, ("few", B))
+        for i in (0, 4, 9):
+            _decode_check(codec, comps[i:i + 1], blocks[i:i + 1], B, ("one", B, i))
+
+
+def test_few_blocks_path_golden_cells(codec, oracle):
+    """tests/golden/vectors.json, LZ4 cells at 128 KiB and 1 MiB, 16 streams per call"""
+    import hashlib
+    import json
+    import os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+    cells = [c for c in json.load(open(os.path.join(G, "vectors.json")))["cells"]
+             if c["method"] == "lz4" and c["B"] in (131072, 1 << 20)]
+    assert len(cells) >= 100
+    with _few_blocks(codec):
+        for B in (131072, 1 << 20):
+            sub = [c for c in cells if c["B"] == B][::2]
+            for k in range(0, len(sub), 16):
+                part = sub[k:k + 16]
+                comps = []
+                for c in part:
+                    m = oracle.lz4_compress(oracle.synth(0, c["block"], B, c["dist"]), c["param"])
+                    assert len(m) == c["csize"] and sha(m) == c["comp_sha256"], c
+                    comps.append(m)
+                outs, st = codec.decompress_blocks(METHOD_LZ4, comps, B)
+                assert (st == 0).all()
+                for c, o in zip(part, outs):
+                    assert sha(o) == c["raw_sha256"], c
+
+
+@pytest.mark.parametrize("B", [131072, 1 << 20])
+def test_few_blocks_path_structured_and_mutated(codec, oracle, B):
+    """structured blocks (repeats at any distance, long runs, periodic data), stock-library streams where liblz4 is
+    there, and corrupted streams: verdict and bytes as the oracle's"""
+    from stress_gpu import make_block, mutate
+    rng = np.random.default_rng(4242 + B)
+    blocks = [make_block(rng, B) for _ in range(10)]
+    blocks.append(np.tile(np.arange(7, dtype=np.uint8), B // 7 + 1)[:B].copy())      # strictly periodic
+    blocks.append(np.zeros(B, np.uint8))
+    blocks.append(rng.integers(0, 256, B, dtype=np.uint8))                            # incompressible: left to the parser
+    comps = [oracle.lz4_compress(b, int(rng.integers(1, 40))) for b in blocks]
+    expect = list(blocks)
+    for it in range(24 if B == 131072 else 10):
+        m = mutate(rng, comps[it % 10])
+        r, out = oracle.lz4_decompress(m, B, fill=0xA5)
+        comps.append(m)
+        expect.append(out.copy() if r == B else None)
+    with _few_blocks(codec):
+        for k in range(0, len(comps), 16):
+            _decode_check(codec, comps[k:k + 16], expect[k:k + 16], B, ("few-mutated", B, k))
+    assert sum(e is None for e in expect) >= 4
+
+
 def test_lz4_path_options_roundtrip(codec):
     from pg_cryogen_amd import codec as cc
     assert codec.get_option(cc.OPT_LZ4_DECODE_PATH) == 0 and codec.get_option(cc.OPT_LZ4_INDEX_WALKERS) == 0
