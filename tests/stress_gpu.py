@@ -16,8 +16,8 @@ from pg_cryogen_amd import codec as cc
 
 def rotate_paths(c, rng):
     """every round picks the decode paths anew: LZ4 in-wave parse / sequence index with 1 .. 64 walkers per block /
-    automatic; zstd fused kernel / pipeline"""
-    path = int(rng.choice([cc.LZ4_PATH_AUTO, cc.LZ4_PATH_RING, cc.LZ4_PATH_INDEXED, cc.LZ4_PATH_INDEXED]))
+    the few-blocks path (batches it is not made for take the automatic choice) / automatic; zstd fused kernel / pipeline"""
+    path = int(rng.choice([cc.LZ4_PATH_AUTO, cc.LZ4_PATH_RING, cc.LZ4_PATH_INDEXED, cc.LZ4_PATH_INDEXED, cc.LZ4_PATH_FEW_BLOCKS]))
     c.set_option(cc.OPT_LZ4_DECODE_PATH, path)
     c.set_option(cc.OPT_LZ4_INDEX_WALKERS, int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64])) if path == cc.LZ4_PATH_INDEXED else 0)
     c.set_option(cc.OPT_ZSTD_DECODE_PATH, int(rng.choice([0, 1, 2])))
