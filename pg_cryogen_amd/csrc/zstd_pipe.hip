@@ -666,18 +666,26 @@ __device__ inline uint32_t bperm32(uint32_t v, uint32_t src_lane)
  * dependent LDS lookup on a lone wave.  A prefix code resynchronises: a decoder started at a wrong bit position
  * lands on a true symbol boundary after a few symbols and is identical to the true decoder from there on.  So here a
  * stream's bits are cut into up to 16 segments of equal length; walker w starts at the GUESSED position (the first bit
- * of segment w), decodes its segment and keeps going into the first kHwWin bits of segment w+1 until it stands on a
- * position walker w+1 visited (a bitmap of the symbol starts inside that window, kept by every walker).  By induction
- * from walker 0, whose start is true, walker w+1's symbols are true from that position on.  Symbols go to a scratch
- * region per walker (their final position is not known before the walkers to the left are counted) and are moved to
- * the literal pool by the wave at the end.  One table serves 64 lanes, nine waves fit a CU, and the kernel is bound by
- * instruction issue instead of LDS capacity.
+ * of segment w), decodes its segment and keeps going into segment w+1 until it stands on a position walker w+1 stood on
+ * too -- every walker notes where it stands (and how many symbols it has) after every fourth of its first 60 turns, and
+ * its left neighbour, once its chain has merged, passes through all of these.  By induction from walker 0, whose start
+ * is true, walker w+1's symbols are true from that mark on.  Symbols go to a scratch region per walker (their final
+ * position is not known before the walkers to the left are counted) and are moved to the literal pool by the wave at
+ * the end.  One table serves 64 lanes, seven waves fit a CU, and the kernel is bound by instruction issue and bandwidth
+ * instead of LDS capacity.
  *
- * Anything unusual -- a 12-bit table, a boundary that does not synchronise inside the window, a scratch region that
+ * How fast chains merge depends on the code: with lengths spread over 3 .. 9 bits (text) a chain merges in ~5 symbols;
+ * where nearly all symbols have ONE length (literals that are hex digits: 14 codes of 4 bits) two chains at different
+ * offsets modulo that length stay apart until a rare longer code comes by, ~80 symbols on average, so the walk into the
+ * next segment takes whole turns like the body (ext_octet) and the marks cover ~4 000 bits.  (First version: a bitmap of
+ * the symbol starts in the segment's first 512 bits and a symbol-by-symbol walk: 61 % of the blocks of 1 MiB frames of
+ * hex-heavy rows had a boundary that did not merge inside the window and were handed back.)
+ *
+ * Anything unusual -- a 12-bit table, a boundary that does not merge before the marks end, a scratch region that
  * overflows (symbol density more than twice the stream's average), counts that do not add up, a stream that does not
  * end on its first bit -- puts the block on a second list that k_zhuf decodes afterwards, lane per stream as before:
  * verdicts are k_zhuf's. */
-constexpr uint32_t kHwWin = 512;   /* bits of a segment's head in which the left neighbour must synchronise (256: 1 block in 1 000 handed back) */
+constexpr uint32_t kHwMarks = 16;  /* positions a walker notes for its left neighbour: its start and where it stands after every fourth of its first 60 turns */
 constexpr uint32_t kHwSlack = 400; /* scratch bytes per walker beyond twice the average */
 constexpr uint32_t kHwBlockSlack = 64u * kHwSlack + 128u; /* + alignment: no two blocks' scratch in one 128-byte line */
 
@@ -688,7 +696,7 @@ constexpr uint32_t kHwRing = 128, kHwStride = 144; /* four 32-byte units per wal
 struct HufwLds {
     uint32_t tbl[1u << kHufL1];
     uint8_t ring[64 * kHwStride + 64 * 16];
-    uint32_t bm[65][kHwWin / 32];
+    uint32_t hp[65][kHwMarks]; /* bits below the walker's start (0xFFFF: no mark) | symbols the walker had there << 16 */
     uint32_t skip[65];
 };
 
@@ -750,14 +758,18 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
     const ZBlk *d = P.blks + it;
     const uint32_t f = it / P.nbmax, kblk = it - f * P.nbmax;
     const uint32_t hlog = uni(d->huf_log), nstreams = uni(d->nstreams), regen = uni(d->regen);
-    auto fallback = [&]() { if (lane == 0u) P.hitems2[atomicAdd(&P.counters[61], 1u)] = it; };
-    if (hlog > kHufL1 || hlog == 0u) { fallback(); return; }
+#ifdef CRYO_HW_PROF
+    auto fallback = [&](int why = 0) { if (lane == 0u) { P.hitems2[atomicAdd(&P.counters[61], 1u)] = it; atomicAdd(&P.counters[why == 0 ? 30 : (why == 1 ? 31 : (why == 2 ? 42 : (why == 3 ? 43 : (why == 4 ? 54 : 55))))], 1u); } };
+#else
+    auto fallback = [&](int = 0) { if (lane == 0u) P.hitems2[atomicAdd(&P.counters[61], 1u)] = it; };
+#endif
+    if (hlog > kHufL1 || hlog == 0u) { fallback(0); return; }
     {
         /* the one-symbol table goes through the (still unused) rings */
         const uint16_t *g = P.huf + ((uint64_t)f * P.nbmax + uni(d->huf_slot)) * kHufTblWords;
         uint16_t *x1 = reinterpret_cast<uint16_t *>(L.ring);
         for (uint32_t i = lane; i < (1u << hlog); i += 64u) x1[i] = g[i];
-        for (uint32_t i = lane; i < 65u * (kHwWin / 32u); i += 64u) (&L.bm[0][0])[i] = 0u;
+        for (uint32_t i = lane; i < 65u * kHwMarks; i += 64u) (&L.hp[0][0])[i] = (i % kHwMarks) == 0u ? 0u : 0xFFFFu;
         __builtin_amdgcn_wave_barrier();
         asm volatile("" ::: "memory");
         const uint32_t dsh = kHufL1 - hlog;
@@ -791,7 +803,7 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
     uint32_t last = 0;
     if (sok) last = gsrc[delta + soff + slen - 1u];
     if (last == 0u) sok = false;
-    if (__any(sid < nstreams && !sok)) { fallback(); return; } /* a stream without an end mark: k_zhuf says what it is */
+    if (__any(sid < nstreams && !sok)) { fallback(1); return; } /* a stream without an end mark: k_zhuf says what it is */
     /* segments */
     const uint32_t T = sok ? (slen - 1u) * 8u + (31u - (uint32_t)__builtin_clz(last)) : 0u;
     uint32_t se = T >> 11;
@@ -831,7 +843,7 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
     enum { MAIN = 0, EXT = 1, DONE = 2 };
     uint32_t phase = walker ? MAIN : DONE;
     bool okw = true;
-    uint32_t n = 0, sync_d = 0;
+    uint32_t n = 0, sync_j = 0, hc = 1, ej = 0, tc = 0;
     const uint32_t tr = 64u * kHwStride + lane * 16u;
     uint4 fd0 = make_uint4(0, 0, 0, 0), fd1 = fd0, fd2 = fd0, fd3 = fd0;
     uint32_t fa0 = tr, fa1 = tr, fa2 = tr, fa3 = tr, fm0 = tr, fm1 = tr, fm2 = tr, fm3 = tr;
@@ -843,16 +855,14 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
                 if (lastw) { phase = DONE; okw = z.pos == 0; }
                 else phase = EXT;
             }
-            if (phase == EXT) {
+            if (phase == EXT) { /* does the right neighbour stand here after one of its first turns? */
                 const uint32_t dd = (uint32_t)(bound - z.pos);
-                if (dd >= kHwWin) { phase = DONE; okw = false; }
-                else if ((L.bm[lane + 1u][dd >> 5] >> (dd & 31u)) & 1u) { phase = DONE; sync_d = dd; }
+                uint32_t lim = L.hp[lane + 1u][ej] & 0xFFFFu;
+                if (lim < dd && ej + 1u < kHwMarks) lim = L.hp[lane + 1u][++ej] & 0xFFFFu;
+                if (lim == dd) { phase = DONE; sync_j = ej; }
+                else if (lim < dd || lim == 0xFFFFu) { phase = DONE; okw = false; } /* behind its last mark */
             }
             if (phase != DONE) {
-                if (phase == MAIN) {
-                    const uint32_t dm = (uint32_t)(Pw - z.pos);
-                    if (dm < kHwWin) atomicOr(&L.bm[lane][dm >> 5], 1u << (dm & 31u));
-                }
                 const uint64_t c = hw_window(L.ring, z, myring);
                 const uint32_t e = L.tbl[(uint32_t)(c >> 32) >> (32u - kHufL1)];
                 z.pos -= (int32_t)((e >> 16) & 15u);
@@ -862,9 +872,9 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
             }
         }
     };
-    /* eight lookups = 8 .. 16 symbols, while more than 88 bits of the segment are left; MARK: inside the head window, where
-     * every symbol start is noted for the left neighbour.  Each half stores 8 bytes of which 4 .. 8 are symbols: the next
-     * store overwrites the rest. */
+    /* eight lookups = 8 .. 16 symbols, while more than 88 bits of the segment are left.  Each half stores 8 bytes of which
+     * 4 .. 8 are symbols: the next store overwrites the rest.  After each of the first turns the walker notes where it
+     * stands and how many symbols it has: its left neighbour, walking symbol by symbol, will stand on one of these. */
     auto octet = [&](const bool mark) __attribute__((always_inline)) {
         if (phase == MAIN && z.pos - bound > 88 && hw_ready(z)) {
             if (n + 24u > cap) { phase = DONE; okw = false; }
@@ -878,12 +888,6 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
                     for (int q = 0; q < 4; q++) {
                         const uint32_t e = L.tbl[(uint32_t)(c >> 32) >> (32u - kHufL1)];
                         const uint32_t lt = (e >> 20) & 15u;
-                        if (mark) {
-                            const uint32_t dm = (uint32_t)(Pw - z.pos);
-                            if (dm < kHwWin) atomicOr(&L.bm[lane][dm >> 5], 1u << (dm & 31u));
-                            const uint32_t dm2 = dm + ((e >> 16) & 15u);
-                            if ((e >> 24) != 0u && dm2 < kHwWin) atomicOr(&L.bm[lane][dm2 >> 5], 1u << (dm2 & 31u));
-                        }
                         c <<= lt;
                         z.pos -= (int32_t)lt;
                         acc |= (uint64_t)(e & 0xFFFFu) << (8u * k);
@@ -893,8 +897,51 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
                     __builtin_memcpy(tmp + n, &acc, 8);
                     n += k;
                 }
+                if (mark) { /* every fourth turn: 15 marks over ~4 000 bits */
+                    tc++;
+                    if ((tc & 3u) == 0u && hc < kHwMarks) {
+                        L.hp[lane][hc] = (uint32_t)(Pw - z.pos) | (n << 16);
+                        hc++;
+                    }
+                }
             }
         }
+    };
+    /* the same on the walk into the next segment: before every symbol, is this where the right neighbour stood after one of
+     * its turns?  (Symbol by symbol -- slow() -- this walk was longer than the segment's body on data whose codes are
+     * nearly all of one length, hex digits: chains at different offsets modulo that length merge once in ~80 symbols.) */
+    auto ext_octet = [&]() __attribute__((always_inline)) {
+        if (n + 24u > cap) { phase = DONE; okw = false; return; }
+        bool live = true;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            uint32_t lim = L.hp[lane + 1u][ej] & 0xFFFFu;
+            if (live && lim < (uint32_t)(bound - z.pos) && ej + 1u < kHwMarks) lim = L.hp[lane + 1u][++ej] & 0xFFFFu; /* marks are 32 lookups apart: one per half at most */
+            uint64_t c = hw_window(L.ring, z, myring);
+            uint64_t acc = 0;
+            uint32_t k = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint32_t e = L.tbl[(uint32_t)(c >> 32) >> (32u - kHufL1)];
+                const uint32_t l1 = (e >> 16) & 15u, lt = (e >> 20) & 15u, two = e >> 24;
+                const uint32_t dd = (uint32_t)(bound - z.pos);
+                const bool hit1 = live & (lim == dd);
+                const bool hit2 = live & !hit1 & (two != 0u) & (lim == dd + l1);
+                acc |= (uint64_t)(e & 0xFFFFu) << (8u * k);
+                k += (live & !hit1) ? (hit2 ? 1u : 1u + two) : 0u;
+                if (hit1 | hit2) { live = false; sync_j = ej; phase = DONE; }
+                c <<= lt;
+                z.pos -= live ? (int32_t)lt : 0;
+            }
+            z.cb = z.s0 + ((z.pos - 1) >> 3);
+            __builtin_memcpy(tmp + n, &acc, 8);
+            n += k;
+            if (live && (lim == 0xFFFFu || (lim < (uint32_t)(bound - z.pos) && ej + 1u >= kHwMarks))) { live = false; phase = DONE; okw = false; } /* behind its last mark */
+        }
+    };
+    auto tail_step = [&]() __attribute__((always_inline)) {
+        if (phase == EXT && z.pos > 88 && hw_ready(z)) ext_octet();
+        else slow();
     };
 #define HW_TURNS(BODY) \
         hw_feed<0>(L.ring, z, lane, phase != DONE, fd0, fa0, fm0, gsrc, vend); BODY; \
@@ -902,28 +949,20 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
         hw_feed<2>(L.ring, z, lane, phase != DONE, fd2, fa2, fm2, gsrc, vend); BODY; \
         hw_feed<3>(L.ring, z, lane, phase != DONE, fd3, fa3, fm3, gsrc, vend); BODY;
     HW_STAMP(56);
-    /* ---- head: until every walker is past the window its left neighbour will search (short segments: symbol by symbol) ---- */
-    while (__any(phase == MAIN && (uint32_t)(Pw - z.pos) < kHwWin && z.pos - bound > 88)) { HW_TURNS(octet(true)) }
-    while (__any(phase == MAIN && (uint32_t)(Pw - z.pos) < kHwWin && z.pos > bound)) { HW_TURNS(slow()) }
+    /* ---- head: the turns that leave marks; body: the rest ---- */
+    for (uint32_t t = 0; t < 4u * kHwMarks && __any(phase == MAIN && z.pos - bound > 88); t += 4u) { HW_TURNS(octet(true)) }
     HW_STAMP(57);
-    /* ---- body ---- */
     while (__any(phase == MAIN && z.pos - bound > 88)) { HW_TURNS(octet(false)) }
     HW_STAMP(58);
     /* ---- tail: the rest of the segment, then on into the next one until the chains meet ---- */
-    while (__any(phase != DONE)) { HW_TURNS(slow()) }
+    while (__any(phase == MAIN)) { HW_TURNS(if (phase == MAIN) slow()) } /* at most 88 bits each: symbol by symbol to the segment's end */
+    while (__any(phase != DONE)) { HW_TURNS(tail_step()) }
     HW_STAMP(59);
 #undef HW_TURNS
     /* ---- who is true from where: walker w tells walker w+1 how many of its symbols lie before the meeting point ---- */
     {
         uint32_t sk = 0;
-        if (walker && !lastw && okw) {
-            for (uint32_t q = 0; q < kHwWin / 32u; q++) {
-                const uint32_t wd = L.bm[lane + 1u][q];
-                const uint32_t lo = q * 32u;
-                const uint32_t m = sync_d >= lo + 32u ? 0xFFFFFFFFu : (sync_d > lo ? (1u << (sync_d - lo)) - 1u : 0u);
-                sk += (uint32_t)__builtin_popcount(wd & m);
-            }
-        }
+        if (walker && !lastw && okw) sk = L.hp[lane + 1u][sync_j] >> 16;
         L.skip[lane + 1u] = sk;
         if (w == 0u) L.skip[lane] = 0u; /* lane 16 k is also written by lane 16 k - 1 (a last walker: 0) */
     }
@@ -934,7 +973,7 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
     const uint32_t incl = scan16_incl(ntrue);
     const uint32_t total = (uint32_t)__shfl((int)incl, (int)(lane | 15u), 64);
     const bool fine = (!walker || (okw && n >= myskip)) && (sid >= nstreams || total == cnt);
-    if (!__all(fine)) { fallback(); return; }
+    if (!__all(fine)) { fallback(__any(walker && !okw && phase == DONE && n + 24u > cap) ? 4 : (__any(walker && !okw) ? 2 : (__any(walker && n < myskip) ? 5 : 3))); return; }
     /* ---- move the walkers' symbols to the literal pool: eight segments' loads in flight ---- */
     /* the scratch bytes other lanes of this wave stored are read below: the stores have to be done, nothing more -- no
      * other wave touches a line of this block's scratch (an agent-scope fence writes the L2 back: 3x the kernel's time) */
@@ -1600,9 +1639,11 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     const size_t budget = budget_env ? budget_env : (size_t)16 << 30; /* per tile in flight; reached only by blocks > 128 KiB,
                                                                         whose tiles would otherwise be too few frames to fill K1/K4 */
     uint64_t F = budget / per_frame;
-    constexpr uint64_t kTile = 512u * kChW; /* one full round of k_zchain */
+    /* one full round of k_zchain: 512 waves x 29 zstd blocks; a frame of B bytes is ceil(B / 128 KiB) of them (round 3:
+     * 1 MiB frames in tiles of 2320 made 1.25 rounds, the second three quarters empty) */
+    const uint64_t kTile = (512u * kChW) / ((B + kZBlockMax - 1u) / kZBlockMax ? (B + kZBlockMax - 1u) / kZBlockMax : 1u);
     if (F > kTile) F = kTile;
-    if (F >= 464u) F -= F % 464u;
+    if (F >= 464u && F != kTile) F -= F % 464u;
     else if (F < 16u) F = 16u;
     if (F > n_blocks) F = n_blocks;
     y.F = (uint32_t)F;
@@ -1743,7 +1784,7 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
             for (int k = 0; k <= 9; k++) fprintf(stderr, " %d:%u", k, h[32 + k]);
             fprintf(stderr, " | ML log:");
             for (int k = 0; k <= 9; k++) fprintf(stderr, " %d:%u", k, h[44 + k]);
-            fprintf(stderr, "\n[zstd pipe] k_zhufw wave time, units of 64 memtime ticks summed over waves: setup %u head %u body %u tail %u resolve+copy %u\n[zstd pipe] k_zplan: literals section (Huffman table) %u, sequence headers %u, FSE tables %u, table copies %u\n", h[56], h[57], h[58], h[59], h[62], h[17], h[18], h[19], h[63]);
+            fprintf(stderr, "\n[zstd pipe] k_zhufw wave time, units of 64 memtime ticks summed over waves: setup %u head %u body %u tail %u resolve+copy %u\n[zstd pipe] k_zplan: literals section (Huffman table) %u, sequence headers %u, FSE tables %u, table copies %u\n[zstd pipe] handed back because: table log %u, stream without end mark %u, no meeting point / overrun %u, counts do not add up %u, scratch full %u, skip > n %u\n", h[56], h[57], h[58], h[59], h[62], h[17], h[18], h[19], h[63], h[30], h[31], h[42], h[43], h[54], h[55]);
         }
     }
     if (nl > 1) {
