@@ -88,6 +88,31 @@ def test_zstd_decode_all_levels_live_library(codec, oracle, B, zstd_path):
         assert np.array_equal(o, raw)
 
 
+@pytest.mark.parametrize("B", [131072, 1 << 20])
+def test_zstd_decode_literals_of_one_code_length(codec, oracle, B, zstd_path):
+    """Literal streams whose Huffman codes (nearly) all have one length -- hex digits, decimal digits, base64 -- are what
+    the Huffman walkers of k_zhufw synchronise slowest on (chains at different offsets modulo the code length stay apart
+    until a rarer, longer code comes by): 1 MiB frames of hex-heavy rows had 61 % of their blocks handed back to k_zhuf by
+    the first version.  Random symbols of such alphabets with a sprinkling of others, so that nothing matches and
+    (almost) everything is a literal; decoded bytes must be the input whichever kernel ends up decoding a block."""
+    rng = np.random.default_rng(B + 5)
+    alphabets = [b"0123456789abcdef", b"0123456789", b"ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/",
+                 b"01", b"0123456789abcdef-{}\":, "]
+    blocks = []
+    for k, al in enumerate(alphabets):
+        a = np.frombuffer(al, np.uint8)
+        for rare in (0.0, 0.002, 0.03):
+            b = a[rng.integers(0, len(a), B)]
+            m = rng.random(B) < rare
+            b = np.where(m, rng.integers(0, 256, B).astype(np.uint8), b).astype(np.uint8)
+            blocks.append(np.ascontiguousarray(b))
+    comps = [oracle.zstd_compress(b, 1 if i % 2 == 0 else 3) for i, b in enumerate(blocks)]
+    outs, st = codec.decompress_blocks(METHOD_ZSTD, comps, B)
+    assert (st == 0).all(), st
+    for i, (raw, o) in enumerate(zip(blocks, outs)):
+        assert np.array_equal(o, raw), i
+
+
 def test_zstd_decode_fuzz_matches_oracle(codec, oracle, zstd_path):
     stock = oracle_lib.StockLibs()
     if stock.zstd is None:
