@@ -1679,7 +1679,8 @@ int tile_lanes(uint32_t block_size)
 {
     static const char *e = getenv("CRYO_ZSTD_LANES"); /* tuning aid: 1 .. kZstdLanes */
     if (e && e[0] >= '1' && e[0] <= '0' + kZstdLanes) return e[0] - '0';
-    return block_size <= (256u << 10) ? 4 : 2; /* measured, profiles/r03_zstd_tiles_in_flight.txt */
+    (void)block_size;
+    return 4; /* measured at 128 KiB ... 1 MiB blocks, profiles/r03_zstd_tiles_in_flight.txt */
 }
 
 /* path: 0 automatic, 1 the fused one-wave-per-frame kernel, 2 the pipeline (CRYO_OPT_ZSTD_DECODE_PATH).  Automatic =
@@ -1713,7 +1714,8 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
     uint8_t *ws0 = (uint8_t *)(((uintptr_t)d_workspace + 255u) & ~(uintptr_t)255u);
     /* Tiles alternate between side streams with a workspace each (tile_lanes()): the kernels of one tile fill what
      * another tile's leave idle (k_zchain holds the whole LDS with two waves per CU, the tail of every kernel leaves CUs
-     * empty).  65 536 x 128 KiB: 259 / 274 / 292 / 302 GB/s with 1 / 2 / 3 / 4 tiles in flight, no more beyond. */
+     * empty).  65 536 x 128 KiB: 259 / 274 / 292 / 302 GB/s with 1 / 2 / 3 / 4 tiles in flight, no more beyond;
+     * 8 192 x 1 MiB: 211 / 239 / 240 with 2 / 3 / 4. */
     const uint64_t ntiles = (n_blocks + y.F - 1u) / y.F;
     int nl = aux ? tile_lanes(block_size) : 1;
     if ((uint64_t)nl > ntiles) nl = (int)ntiles;
