@@ -681,7 +681,9 @@ __device__ inline uint32_t bperm32(uint32_t v, uint32_t src_lane)
  * the symbol starts in the segment's first 512 bits and a symbol-by-symbol walk: 61 % of the blocks of 1 MiB frames of
  * hex-heavy rows had a boundary that did not merge inside the window and were handed back.)
  *
- * Anything unusual -- a 12-bit table, a boundary that does not merge before the marks end, a scratch region that
+ * A walker that runs out of its neighbour's marks knows where the neighbour's segment truly starts: the neighbour
+ * decodes its segment once more from there (the repair pass).  Anything else unusual -- a 12-bit table, two such misses
+ * in a row, a scratch region that
  * overflows (symbol density more than twice the stream's average), counts that do not add up, a stream that does not
  * end on its first bit -- puts the block on a second list that k_zhuf decodes afterwards, lane per stream as before:
  * verdicts are k_zhuf's. */
@@ -821,29 +823,34 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
     const uint32_t myring = lane * kHwStride;
     HwLane z;
     z.s0 = (int32_t)(delta + soff);
-    z.pos = walker ? Pw : 0;
-    z.cb = z.s0 + ((z.pos - 1) >> 3);
-    z.pend = 0;
-    {
+    /* the ring's four units at and below the walker's first byte, loaded by the lane itself */
+    auto prime = [&](const bool who, const int32_t from) {
+        if (!who) return;
+        z.pos = from;
+        z.cb = z.s0 + ((z.pos - 1) >> 3);
+        z.pend = 0;
         const int32_t ht = z.cb >> 5;
         const int32_t hl = ht >= 3 ? ht - 3 : 0;
-        if (walker)
-            for (int32_t h = hl; h <= ht; h++)
-                for (uint32_t q = 0; q < 2u; q++) {
-                    const uint32_t o = (uint32_t)h * 32u + q * 16u;
-                    uint4 v = make_uint4(0, 0, 0, 0);
-                    if (o < vend) v = *reinterpret_cast<const uint4 *>(gsrc + o);
-                    *reinterpret_cast<uint4 *>(L.ring + myring + (o & (kHwRing - 1u))) = v;
-                    if ((o & (kHwRing - 1u)) == 0u) *reinterpret_cast<uint2 *>(L.ring + myring + kHwRing) = make_uint2(v.x, v.y);
-                }
+        for (int32_t h = hl; h <= ht; h++)
+            for (uint32_t q = 0; q < 2u; q++) {
+                const uint32_t o = (uint32_t)h * 32u + q * 16u;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (o < vend) v = *reinterpret_cast<const uint4 *>(gsrc + o);
+                *reinterpret_cast<uint4 *>(L.ring + myring + (o & (kHwRing - 1u))) = v;
+                if ((o & (kHwRing - 1u)) == 0u) *reinterpret_cast<uint2 *>(L.ring + myring + kHwRing) = make_uint2(v.x, v.y);
+            }
         z.lowh = z.fillh = hl;
-    }
+    };
+    z.pos = 0; z.cb = z.s0 - 1; z.pend = 0; z.lowh = z.fillh = 0;
+    prime(walker, Pw);
     __builtin_amdgcn_wave_barrier();
 
     enum { MAIN = 0, EXT = 1, DONE = 2 };
     uint32_t phase = walker ? MAIN : DONE;
     bool okw = true;
-    uint32_t n = 0, sync_j = 0, hc = 1, ej = 0, tc = 0;
+    uint32_t n = 0, sync_j = 0, hc = 1, ej = 0, tc = 0, main_n = 0;
+    int32_t e_pos = 0;   /* where the walker left its segment */
+    bool nomeet = false; /* ... and did not meet its right neighbour before that one's marks ended */
     const uint32_t tr = 64u * kHwStride + lane * 16u;
     uint4 fd0 = make_uint4(0, 0, 0, 0), fd1 = fd0, fd2 = fd0, fd3 = fd0;
     uint32_t fa0 = tr, fa1 = tr, fa2 = tr, fa3 = tr, fm0 = tr, fm1 = tr, fm2 = tr, fm3 = tr;
@@ -853,14 +860,14 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
         if (phase != DONE && hw_ready(z)) {
             if (phase == MAIN && z.pos <= bound) { /* the symbol that starts here belongs to the next segment */
                 if (lastw) { phase = DONE; okw = z.pos == 0; }
-                else phase = EXT;
+                else { phase = EXT; main_n = n; e_pos = z.pos; }
             }
             if (phase == EXT) { /* does the right neighbour stand here after one of its first turns? */
                 const uint32_t dd = (uint32_t)(bound - z.pos);
                 uint32_t lim = L.hp[lane + 1u][ej] & 0xFFFFu;
                 if (lim < dd && ej + 1u < kHwMarks) lim = L.hp[lane + 1u][++ej] & 0xFFFFu;
                 if (lim == dd) { phase = DONE; sync_j = ej; }
-                else if (lim < dd || lim == 0xFFFFu) { phase = DONE; okw = false; } /* behind its last mark */
+                else if (lim < dd || lim == 0xFFFFu) { phase = DONE; okw = false; nomeet = true; } /* behind its last mark */
             }
             if (phase != DONE) {
                 const uint64_t c = hw_window(L.ring, z, myring);
@@ -936,7 +943,7 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
             z.cb = z.s0 + ((z.pos - 1) >> 3);
             __builtin_memcpy(tmp + n, &acc, 8);
             n += k;
-            if (live && (lim == 0xFFFFu || (lim < (uint32_t)(bound - z.pos) && ej + 1u >= kHwMarks))) { live = false; phase = DONE; okw = false; } /* behind its last mark */
+            if (live && (lim == 0xFFFFu || (lim < (uint32_t)(bound - z.pos) && ej + 1u >= kHwMarks))) { live = false; phase = DONE; okw = false; nomeet = true; } /* behind its last mark */
         }
     };
     auto tail_step = [&]() __attribute__((always_inline)) {
@@ -949,30 +956,63 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
         hw_feed<2>(L.ring, z, lane, phase != DONE, fd2, fa2, fm2, gsrc, vend); BODY; \
         hw_feed<3>(L.ring, z, lane, phase != DONE, fd3, fa3, fm3, gsrc, vend); BODY;
     HW_STAMP(56);
-    /* ---- head: the turns that leave marks; body: the rest ---- */
-    for (uint32_t t = 0; t < 4u * kHwMarks && __any(phase == MAIN && z.pos - bound > 88); t += 4u) { HW_TURNS(octet(true)) }
-    HW_STAMP(57);
-    while (__any(phase == MAIN && z.pos - bound > 88)) { HW_TURNS(octet(false)) }
-    HW_STAMP(58);
-    /* ---- tail: the rest of the segment, then on into the next one until the chains meet ---- */
-    while (__any(phase == MAIN)) { HW_TURNS(if (phase == MAIN) slow()) } /* at most 88 bits each: symbol by symbol to the segment's end */
+#define HW_RUN() \
+    /* head: the turns that leave marks; body: the rest */ \
+    for (uint32_t t = 0; t < 4u * kHwMarks && __any(phase == MAIN && z.pos - bound > 88); t += 4u) { HW_TURNS(octet(true)) } \
+    while (__any(phase == MAIN && z.pos - bound > 88)) { HW_TURNS(octet(false)) } \
+    /* tail: the rest of the segment (at most 88 bits each: symbol by symbol), then on into the next one until the chains meet */ \
+    while (__any(phase == MAIN)) { HW_TURNS(if (phase == MAIN) slow()) } \
     while (__any(phase != DONE)) { HW_TURNS(tail_step()) }
+    HW_RUN()
+    HW_STAMP(58);
+    /* ---- repair: a walker that did not meet its right neighbour in time knows where that one's segment truly starts
+     * (where it left its own): the neighbour decodes its segment once more from there, alone; the walker keeps the
+     * symbols of its own segment only.  (1 boundary in 7 000 on literals of one code length; a second failure in a row
+     * hands the block back.) ---- */
+    bool redone = false;
+    uint32_t ep_used = 0;
+    {
+        const bool give = walker && !lastw && !okw && nomeet;
+        if (give) { n = main_n; okw = true; }
+        L.skip[lane + 1u] = give ? (uint32_t)e_pos : 0xFFFFFFFFu;
+        if (w == 0u) L.skip[lane] = 0xFFFFFFFFu;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        const uint32_t ep = (walker && w != 0u) ? L.skip[lane] : 0xFFFFFFFFu;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+        redone = ep != 0xFFFFFFFFu;
+        ep_used = ep;
+        if (__any(redone)) {
+            fa0 = fa1 = fa2 = fa3 = fm0 = fm1 = fm2 = fm3 = tr; /* pieces on their way belong to the old positions */
+            prime(redone, (int32_t)ep);
+            if (redone) { phase = MAIN; okw = true; nomeet = false; n = 0; sync_j = 0; ej = 0; hc = kHwMarks; main_n = 0; }
+            __builtin_amdgcn_wave_barrier();
+            HW_RUN()
+        }
+    }
     HW_STAMP(59);
+#undef HW_RUN
 #undef HW_TURNS
     /* ---- who is true from where: walker w tells walker w+1 how many of its symbols lie before the meeting point ---- */
+    const bool right_redone = __shfl((int)redone, (int)((lane + 1u) & 63u), 64) != 0 && !lastw;
+    if (walker && right_redone) n = main_n; /* the right neighbour decoded its segment again from where this one left its own */
+    /* ... which must still be that place (it is not, if this walker was decoded again itself and came out elsewhere) */
+    const uint32_t left_e = (uint32_t)__shfl((int)e_pos, (int)((lane - 1u) & 63u), 64); /* by every lane: a shuffle inside `redone && ...` reads lanes that are switched off */
+    const bool stale = redone && left_e != ep_used;
     {
         uint32_t sk = 0;
-        if (walker && !lastw && okw) sk = L.hp[lane + 1u][sync_j] >> 16;
+        if (walker && !lastw && okw && !right_redone) sk = L.hp[lane + 1u][sync_j] >> 16;
         L.skip[lane + 1u] = sk;
         if (w == 0u) L.skip[lane] = 0u; /* lane 16 k is also written by lane 16 k - 1 (a last walker: 0) */
     }
     __builtin_amdgcn_wave_barrier();
     asm volatile("" ::: "memory");
-    const uint32_t myskip = (walker && w != 0u) ? L.skip[lane] : 0u;
+    const uint32_t myskip = (walker && w != 0u && !redone) ? L.skip[lane] : 0u;
     const uint32_t ntrue = walker ? n - myskip : 0u;
     const uint32_t incl = scan16_incl(ntrue);
     const uint32_t total = (uint32_t)__shfl((int)incl, (int)(lane | 15u), 64);
-    const bool fine = (!walker || (okw && n >= myskip)) && (sid >= nstreams || total == cnt);
+    const bool fine = (!walker || (okw && n >= myskip && !stale)) && (sid >= nstreams || total == cnt);
     if (!__all(fine)) { fallback(__any(walker && !okw && phase == DONE && n + 24u > cap) ? 4 : (__any(walker && !okw) ? 2 : (__any(walker && n < myskip) ? 5 : 3))); return; }
     /* ---- move the walkers' symbols to the literal pool: eight segments' loads in flight ---- */
     /* the scratch bytes other lanes of this wave stored are read below: the stores have to be done, nothing more -- no
