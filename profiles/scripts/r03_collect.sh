@@ -64,6 +64,7 @@ print('level $lvl 1MiB x512: encode %s GB/s decode %s GB/s ratio %s' % (c.get('e
 done
 cat $out
 bash profiles/scripts/r03_zshapes.sh > gpurun_out/r03_zshapes.log 2>&1; tail -n 22 gpurun_out/r03_zshapes.log
+bash profiles/scripts/r03_lat.sh > gpurun_out/r03_lat.log 2>&1; tail -n 15 gpurun_out/r03_lat.log
 # suite, smoke, soak
 out=gpurun_out/${T}_final_check.txt; : > $out
 timeout 1700 python3 -m pytest tests -x -q -m gpu 2>&1 | tail -4 | tee -a $out
