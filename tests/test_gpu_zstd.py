@@ -111,6 +111,21 @@ def test_zstd_decode_literals_of_one_code_length(codec, oracle, B, zstd_path):
     assert (st == 0).all(), st
     for i, (raw, o) in enumerate(zip(blocks, outs)):
         assert np.array_equal(o, raw), i
+    # the same streams corrupted: verdict and bytes as the oracle's (the walkers hand a block back to the lane-per-stream
+    # kernel whenever their counts do not add up, so a verdict is that kernel's)
+    from stress_gpu import mutate
+    items, expect = [], []
+    for it in range(40 if B == 131072 else 12):
+        m = mutate(rng, comps[it % len(comps)])
+        r, out = oracle.zstd_decompress(m, B, fill=0xA5)
+        items.append(m)
+        expect.append(out.copy() if r == B else None)
+    outs, st = codec.decompress_blocks(METHOD_ZSTD, items, B)
+    for i, e in enumerate(expect):
+        if e is None:
+            assert st[i] != 0, i
+        else:
+            assert st[i] == 0 and np.array_equal(outs[i], e), i
 
 
 def test_zstd_decode_fuzz_matches_oracle(codec, oracle, zstd_path):
