@@ -825,7 +825,8 @@ check:
 }
 
 /* ------------------------------------------------------------ match finder: strategy `fast` */
-typedef struct { int wlog, clog, hlog, slog, mml, tlen, dfast, lazy_depth; /* lazy_depth: -1 none, 0 greedy, 1 lazy, 2 lazy2 */ } cpar;
+typedef struct { int wlog, clog, hlog, slog, mml, tlen, dfast, lazy_depth; /* lazy_depth: -1 none, 0 greedy, 1 lazy, 2 lazy2 */
+                 int bt; /* 1: strategy btlazy2 -- the lazy2 parser over the binary-tree searcher */ } cpar;
 
 static uint32_t hash_ptr(const uint8_t *p, int hlog, int mls)
 {
@@ -1086,6 +1087,149 @@ static size_t hc_find_best(hc_state *hc, const cpar *cp, const uint8_t *base, co
     return ml;
 }
 
+/* ------------------------------------------------------------ match finder: strategy `btlazy2` (libzstd 1.4.8 zstd_lazy.c:
+ * ZSTD_updateDUBT, ZSTD_insertDUBT1, ZSTD_DUBT_findBestMatch, ZSTD_BtFindBestMatch; no dictionary).  The chain table is a
+ * binary tree of 2^(chainLog-1) nodes, two links per position (smaller / larger suffixes); positions are first chained
+ * UNSORTED (second link = the mark 1) and sorted into the tree in batches when a search runs into them. */
+#define DUBT_UNSORTED_MARK 1u
+
+static void dubt_update(hc_state *hc, const cpar *cp, const uint8_t *base, uint32_t target, int mls)
+{
+    uint32_t *const bt = hc->chain;
+    const uint32_t bt_mask = (1u << (cp->clog - 1)) - 1u;
+    uint32_t idx = hc->next_to_update;
+    for (; idx < target; idx++) {
+        const uint32_t h = hash_ptr(base + idx, cp->hlog, mls);
+        const uint32_t mi = hc->hash[h];
+        uint32_t *const next_cand = bt + 2u * (idx & bt_mask);
+        hc->hash[h] = idx;
+        next_cand[0] = mi;                /* the tree slot used like a chain link */
+        next_cand[1] = DUBT_UNSORTED_MARK;
+    }
+    hc->next_to_update = target;
+}
+
+/* sort one position that is chained but not yet in the tree */
+static void dubt_insert1(hc_state *hc, const cpar *cp, const uint8_t *base, uint32_t cur, const uint8_t *iend, uint32_t nb_compares,
+                         uint32_t bt_low)
+{
+    uint32_t *const bt = hc->chain;
+    const uint32_t bt_mask = (1u << (cp->clog - 1)) - 1u;
+    size_t common_smaller = 0, common_larger = 0;
+    const uint8_t *const ip = base + cur;
+    uint32_t *smaller_ptr = bt + 2u * (cur & bt_mask);
+    uint32_t *larger_ptr = smaller_ptr + 1;
+    uint32_t mi = *smaller_ptr; /* the next sorted candidate; *larger_ptr held the previous unsorted one (saved by the caller) */
+    uint32_t dummy;
+    const uint32_t window_valid = 1, max_dist = 1u << cp->wlog;
+    const uint32_t window_low = (cur - window_valid > max_dist) ? cur - max_dist : window_valid;
+    while (nb_compares-- && mi > window_low) {
+        uint32_t *const next_ptr = bt + 2u * (mi & bt_mask);
+        size_t ml = common_smaller < common_larger ? common_smaller : common_larger;
+        const uint8_t *const match = base + mi;
+        ml += count_match(ip + ml, match + ml, iend);
+        if (ip + ml == iend) break; /* equal: no way to know if smaller or larger: dropped */
+        if (match[ml] < ip[ml]) {
+            *smaller_ptr = mi;
+            common_smaller = ml;
+            if (mi <= bt_low) { smaller_ptr = &dummy; break; }
+            smaller_ptr = next_ptr + 1;
+            mi = next_ptr[1];
+        } else {
+            *larger_ptr = mi;
+            common_larger = ml;
+            if (mi <= bt_low) { larger_ptr = &dummy; break; }
+            larger_ptr = next_ptr;
+            mi = next_ptr[0];
+        }
+    }
+    *smaller_ptr = *larger_ptr = 0;
+}
+
+static size_t bt_find_best(hc_state *hc, const cpar *cp, const uint8_t *base, const uint8_t *ip, const uint8_t *iend,
+                           size_t *offset_ptr, int mls)
+{
+    uint32_t *const bt = hc->chain;
+    const uint32_t bt_mask = (1u << (cp->clog - 1)) - 1u;
+    const uint32_t cur = (uint32_t)(ip - base);
+    uint32_t h, mi, window_low, bt_low, unsort_limit, nb_compares, nb_candidates, previous = 0;
+    uint32_t *next_cand, *unsorted_mark;
+    if (cur < hc->next_to_update) return 0; /* skipped area */
+    dubt_update(hc, cp, base, cur, mls);
+    h = hash_ptr(ip, cp->hlog, mls);
+    mi = hc->hash[h];
+    {
+        const uint32_t max_dist = 1u << cp->wlog, lowest_valid = 1;
+        window_low = (cur - lowest_valid > max_dist) ? cur - max_dist : lowest_valid;
+    }
+    bt_low = (bt_mask >= cur) ? 0 : cur - bt_mask;
+    unsort_limit = bt_low > window_low ? bt_low : window_low;
+    next_cand = bt + 2u * (mi & bt_mask);
+    unsorted_mark = next_cand + 1;
+    nb_compares = 1u << cp->slog;
+    nb_candidates = nb_compares;
+    /* reach the end of the unsorted candidates (their marks become a reversed chain to come back by) */
+    while (mi > unsort_limit && *unsorted_mark == DUBT_UNSORTED_MARK && nb_candidates > 1) {
+        *unsorted_mark = previous;
+        previous = mi;
+        mi = *next_cand;
+        next_cand = bt + 2u * (mi & bt_mask);
+        unsorted_mark = next_cand + 1;
+        nb_candidates--;
+    }
+    /* the last candidate, if still unsorted, is dropped */
+    if (mi > unsort_limit && *unsorted_mark == DUBT_UNSORTED_MARK) *next_cand = *unsorted_mark = 0;
+    /* batch sort of the stacked candidates */
+    mi = previous;
+    while (mi) {
+        uint32_t *const next_idx_ptr = bt + 2u * (mi & bt_mask) + 1;
+        const uint32_t next_idx = *next_idx_ptr;
+        dubt_insert1(hc, cp, base, mi, iend, nb_candidates, unsort_limit);
+        mi = next_idx;
+        nb_candidates++;
+    }
+    /* the longest match, inserting the current position on the way */
+    {
+        size_t common_smaller = 0, common_larger = 0, best = 0;
+        uint32_t *smaller_ptr = bt + 2u * (cur & bt_mask);
+        uint32_t *larger_ptr = smaller_ptr + 1;
+        uint32_t match_end_idx = cur + 8 + 1;
+        uint32_t dummy;
+        mi = hc->hash[h];
+        hc->hash[h] = cur;
+        while (nb_compares-- && mi > window_low) {
+            uint32_t *const next_ptr = bt + 2u * (mi & bt_mask);
+            size_t ml = common_smaller < common_larger ? common_smaller : common_larger;
+            const uint8_t *const match = base + mi;
+            ml += count_match(ip + ml, match + ml, iend);
+            if (ml > best) {
+                if (ml > match_end_idx - mi) match_end_idx = mi + (uint32_t)ml;
+                if ((4 * (int)(ml - best)) > (int)(hb(cur - mi + 1) - hb((uint32_t)offset_ptr[0] + 1))) {
+                    best = ml;
+                    *offset_ptr = REP_MOVE + cur - mi;
+                }
+                if (ip + ml == iend) break; /* equal: dropped, to keep the tree consistent */
+            }
+            if (match[ml] < ip[ml]) {
+                *smaller_ptr = mi;
+                common_smaller = ml;
+                if (mi <= bt_low) { smaller_ptr = &dummy; break; }
+                smaller_ptr = next_ptr + 1;
+                mi = next_ptr[1];
+            } else {
+                *larger_ptr = mi;
+                common_larger = ml;
+                if (mi <= bt_low) { larger_ptr = &dummy; break; }
+                larger_ptr = next_ptr;
+                mi = next_ptr[0];
+            }
+        }
+        *smaller_ptr = *larger_ptr = 0;
+        hc->next_to_update = match_end_idx - 8; /* skip repetitive patterns */
+        return best;
+    }
+}
+
 static int hb32(uint32_t v) { return hb(v); }
 
 static size_t block_lazy(hc_state *hc, const cpar *cp, const uint8_t *base, const uint8_t *istart, size_t n, uint32_t rep[3],
@@ -1115,7 +1259,7 @@ static size_t block_lazy(hc_state *hc, const cpar *cp, const uint8_t *base, cons
         }
         {
             size_t off_found = 999999999;
-            const size_t ml2 = hc_find_best(hc, cp, base, ip, iend, &off_found, mls);
+            const size_t ml2 = cp->bt ? bt_find_best(hc, cp, base, ip, iend, &off_found, mls) : hc_find_best(hc, cp, base, ip, iend, &off_found, mls);
             if (ml2 > mlen) { mlen = ml2; start = ip; offset = off_found; }
         }
         if (mlen < 4) { ip += ((size_t)(ip - anchor) >> 8) + 1; continue; }
@@ -1130,7 +1274,7 @@ static size_t block_lazy(hc_state *hc, const cpar *cp, const uint8_t *base, cons
                 }
                 {
                     size_t off2f = 999999999;
-                    const size_t ml2 = hc_find_best(hc, cp, base, ip, iend, &off2f, mls);
+                    const size_t ml2 = cp->bt ? bt_find_best(hc, cp, base, ip, iend, &off2f, mls) : hc_find_best(hc, cp, base, ip, iend, &off2f, mls);
                     const int gain2 = (int)(ml2 * 4 - (size_t)hb32((uint32_t)off2f + 1));
                     const int gain1 = (int)(mlen * 4 - (size_t)hb32((uint32_t)offset + 1) + 4);
                     if (ml2 >= 4 && gain2 > gain1) { mlen = ml2; offset = off2f; start = ip; continue; }
@@ -1145,7 +1289,7 @@ static size_t block_lazy(hc_state *hc, const cpar *cp, const uint8_t *base, cons
                     }
                     {
                         size_t off2f = 999999999;
-                        const size_t ml2 = hc_find_best(hc, cp, base, ip, iend, &off2f, mls);
+                        const size_t ml2 = cp->bt ? bt_find_best(hc, cp, base, ip, iend, &off2f, mls) : hc_find_best(hc, cp, base, ip, iend, &off2f, mls);
                         const int gain2 = (int)(ml2 * 4 - (size_t)hb32((uint32_t)off2f + 1));
                         const int gain1 = (int)(mlen * 4 - (size_t)hb32((uint32_t)offset + 1) + 7);
                         if (ml2 >= 4 && gain2 > gain1) { mlen = ml2; offset = off2f; start = ip; continue; }
@@ -1179,39 +1323,41 @@ static int get_cpar(int level, size_t n, cpar *cp)
 {
     /* libzstd 1.4.8's four parameter tables (ZSTD_defaultCParameters: source size > 256 KiB, <= 256 KiB, <= 128 KiB,
      * <= 16 KiB), rows: the base row of the negative levels, then levels 1 .. 12; columns: windowLog, chainLog, hashLog,
-     * searchLog, minMatch, targetLength, strategy (1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2; 6 and up: the binary-tree
-     * strategies, no kernel).  Dumped from ZSTD_getCParams and checked against it by the tests. */
-    static const int kCParTab[4][13][7] = {
-        {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2}, {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}, {21, 19, 19, 3, 5, 8, 4}, {21, 19, 19, 3, 5, 16, 5}, {21, 19, 20, 4, 5, 16, 5}, {22, 20, 21, 4, 5, 16, 5}, {22, 21, 22, 4, 5, 16, 5}, {22, 21, 22, 5, 5, 16, 5}},
-        {{18, 12, 13, 1, 5, 1, 1}, {18, 13, 14, 1, 6, 0, 1}, {18, 14, 14, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {18, 16, 17, 2, 5, 2, 3}, {18, 18, 18, 3, 5, 2, 3}, {18, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 4, 4, 4, 4}, {18, 18, 19, 4, 4, 8, 5}, {18, 18, 19, 5, 4, 8, 5}, {18, 18, 19, 6, 4, 8, 5}, {18, 18, 19, 5, 4, 12, 6}, {18, 19, 19, 7, 4, 12, 6}},
-        {{17, 12, 12, 1, 5, 1, 1}, {17, 12, 13, 1, 6, 0, 1}, {17, 13, 15, 1, 5, 0, 1}, {17, 15, 16, 2, 5, 0, 2}, {17, 17, 17, 2, 4, 0, 2}, {17, 16, 17, 3, 4, 2, 3}, {17, 17, 17, 3, 4, 4, 4}, {17, 17, 17, 3, 4, 8, 5}, {17, 17, 17, 4, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 5}, {17, 17, 17, 6, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 6}, {17, 18, 17, 7, 4, 12, 6}},
-        {{14, 12, 13, 1, 5, 1, 1}, {14, 14, 15, 1, 5, 0, 1}, {14, 14, 15, 1, 4, 0, 1}, {14, 14, 15, 2, 4, 0, 2}, {14, 14, 14, 4, 4, 2, 3}, {14, 14, 14, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}, {14, 14, 14, 6, 4, 8, 5}, {14, 14, 14, 8, 4, 8, 5}, {14, 15, 14, 5, 4, 8, 6}, {14, 15, 14, 9, 4, 8, 6}, {14, 15, 14, 3, 4, 12, 7}, {14, 15, 14, 4, 3, 24, 7}}};
+     * searchLog, minMatch, targetLength, strategy (1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2, 6 btlazy2; 7 and up: the
+     * optimal-parser strategies, not restated).  Rows 13 .. 15 exist for sources above 256 KiB only (btlazy2 there; btopt and up
+     * in the other classes).  Dumped from ZSTD_getCParams and checked against it by the tests. */
+    static const int kCParTab[4][16][7] = {
+        {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2}, {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}, {21, 19, 19, 3, 5, 8, 4}, {21, 19, 19, 3, 5, 16, 5}, {21, 19, 20, 4, 5, 16, 5}, {22, 20, 21, 4, 5, 16, 5}, {22, 21, 22, 4, 5, 16, 5}, {22, 21, 22, 5, 5, 16, 5}, {22, 21, 22, 5, 5, 32, 6}, {22, 22, 23, 5, 5, 32, 6}, {22, 23, 23, 6, 5, 32, 6}},
+        {{18, 12, 13, 1, 5, 1, 1}, {18, 13, 14, 1, 6, 0, 1}, {18, 14, 14, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {18, 16, 17, 2, 5, 2, 3}, {18, 18, 18, 3, 5, 2, 3}, {18, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 4, 4, 4, 4}, {18, 18, 19, 4, 4, 8, 5}, {18, 18, 19, 5, 4, 8, 5}, {18, 18, 19, 6, 4, 8, 5}, {18, 18, 19, 5, 4, 12, 6}, {18, 19, 19, 7, 4, 12, 6}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}},
+        {{17, 12, 12, 1, 5, 1, 1}, {17, 12, 13, 1, 6, 0, 1}, {17, 13, 15, 1, 5, 0, 1}, {17, 15, 16, 2, 5, 0, 2}, {17, 17, 17, 2, 4, 0, 2}, {17, 16, 17, 3, 4, 2, 3}, {17, 17, 17, 3, 4, 4, 4}, {17, 17, 17, 3, 4, 8, 5}, {17, 17, 17, 4, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 5}, {17, 17, 17, 6, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 6}, {17, 18, 17, 7, 4, 12, 6}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}},
+        {{14, 12, 13, 1, 5, 1, 1}, {14, 14, 15, 1, 5, 0, 1}, {14, 14, 15, 1, 4, 0, 1}, {14, 14, 15, 2, 4, 0, 2}, {14, 14, 14, 4, 4, 2, 3}, {14, 14, 14, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}, {14, 14, 14, 6, 4, 8, 5}, {14, 14, 14, 8, 4, 8, 5}, {14, 15, 14, 5, 4, 8, 6}, {14, 15, 14, 9, 4, 8, 6}, {14, 15, 14, 3, 4, 12, 7}, {14, 15, 14, 4, 3, 24, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}}};
     const int (*t)[7];
     int row, srclog, strat;
     if (level == 0) level = 3;
-    if (level > 12 || level < -131072) return -1; /* higher levels: bt* strategies at every size, not restated */
+    if (level > 15 || level < -131072) return -1; /* higher levels: btopt and up at every size, not restated */
     t = kCParTab[n > 256u * 1024u ? 0 : (n > 128u * 1024u ? 1 : (n > 16u * 1024u ? 2 : 3))];
-    if (t[level < 0 ? 0 : level][6] > 5) return -1; /* a binary-tree strategy */
+    if (t[level < 0 ? 0 : level][6] > 6) return -1; /* an optimal-parser strategy */
     row = level < 0 ? 0 : level;
     cp->wlog = t[row][0]; cp->clog = t[row][1]; cp->hlog = t[row][2]; cp->slog = t[row][3]; cp->mml = t[row][4];
     cp->tlen = level < 0 ? -level : t[row][5];
     strat = t[row][6];
     cp->dfast = strat == 2;
-    cp->lazy_depth = strat >= 3 ? strat - 3 : -1;
+    cp->bt = strat == 6;
+    cp->lazy_depth = strat == 6 ? 2 : (strat >= 3 ? strat - 3 : -1);
     /* ZSTD_adjustCParams_internal: shrink the window (and hash, chain) to the source size */
     srclog = (n < 64) ? 6 : hb((uint32_t)(n - 1)) + 1;
     if (cp->wlog > srclog) cp->wlog = srclog;
     if (cp->hlog > cp->wlog + 1) cp->hlog = cp->wlog + 1;
-    if (cp->clog > cp->wlog) cp->clog = cp->wlog; /* cycleLog == chainLog for the non-bt strategies */
+    if (cp->clog - cp->bt > cp->wlog) cp->clog = cp->wlog + cp->bt; /* cycleLog = chainLog, minus one for the binary tree (two links per node) */
     if (cp->wlog < 10) cp->wlog = 10;
-    if (cp->hlog > 21 || cp->clog > 20) return -1; /* beyond this restatement's static tables (sources above 2 MiB at the deep levels) */
+    if (cp->hlog > 21 || cp->clog > 21) return -1; /* beyond this restatement's static tables (sources above 2 MiB at the deep levels) */
     return 0;
 }
 
 /* ------------------------------------------------------------ frame */
 size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int level)
 {
-    static uint32_t table[1 << 21], tshort[1 << 20]; /* hash (long) table; short table / chain table */
+    static uint32_t table[1 << 21], tshort[1 << 21]; /* hash (long) table; short table / chain table / binary tree */
     hc_state hc;
     static seq_t seqs[ZBLOCK_MAX / 3 + 8];
     static uint8_t lits[ZBLOCK_MAX + 8];
@@ -1228,7 +1374,7 @@ size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, siz
     if (get_cpar(level, n, &cp) || cap < cryo_oracle_zstd_bound(n)) return 0;
     memset(table, 0, sizeof(uint32_t) << cp.hlog);
     if (cp.dfast || cp.lazy_depth >= 0) memset(tshort, 0, sizeof(uint32_t) << cp.clog);
-    g_strategy = cp.lazy_depth >= 0 ? 3 + cp.lazy_depth : (cp.dfast ? 2 : 1);
+    g_strategy = cp.bt ? 6 : (cp.lazy_depth >= 0 ? 3 + cp.lazy_depth : (cp.dfast ? 2 : 1));
     hc.hash = table; hc.chain = tshort; hc.next_to_update = 1;
     /* frame header: content size always, no checksum, no dictionary id */
     {

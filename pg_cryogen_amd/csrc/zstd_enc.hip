@@ -972,7 +972,7 @@ __device__ uint32_t compress_sequences(EncLds &L, uint8_t *dst, uint8_t *ws, uin
 }
 
 /* ------------------------------------------------------------ match finder: strategy `fast` */
-struct CPar { int wlog, clog, hlog, slog, mml, tlen; };
+struct CPar { int wlog, clog, hlog, slog, mml, tlen, bt; /* bt: the binary-tree searcher (btlazy2) */ };
 
 __device__ inline uint32_t hash_ptr(const uint8_t *p, int hlog, int mls)
 {
@@ -1125,7 +1125,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *ws = workspace + (uint64_t)blockIdx.x * ws_stride;
     CPar cp;
-    cp.wlog = wlog; cp.clog = clog; cp.hlog = hlog; cp.slog = (int)width; cp.mml = mml; cp.tlen = tlen;
+    cp.wlog = wlog; cp.clog = clog; cp.hlog = hlog; cp.slog = (int)width; cp.mml = mml; cp.tlen = tlen; cp.bt = finder == 6 ? 1 : 0;
     const bool dfast = finder == 1;
     const bool two_tables = finder == 1 || finder >= 3;
     uint32_t *table = reinterpret_cast<uint32_t *>(ws + kWsBytes);
@@ -1185,7 +1185,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                         const uint32_t d = cur - hc.next_to_update - 384u;
                         hc.next_to_update = cur - (d < 192u ? d : 192u);
                     }
-                    last_ll = block_lazy(hc, df_mark, cp, finder - 3, base, src + ip, bs, nrep, ws, ss, lane);
+                    last_ll = block_lazy(hc, df_mark, cp, finder == 6 ? 2 : finder - 3, base, src + ip, bs, nrep, ws, ss, lane);
                 }
                 else if (finder == 0) last_ll = block_fast_gbatch(table, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, width);
                 else last_ll = block_fast(table, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane);
@@ -1251,18 +1251,19 @@ static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *
 {
     /* libzstd 1.4.8's four parameter tables (ZSTD_defaultCParameters: source size > 256 KiB, <= 256 KiB, <= 128 KiB,
      * <= 16 KiB), rows: the base row of the negative levels, then levels 1 .. 12; columns: windowLog, chainLog, hashLog,
-     * searchLog, minMatch, targetLength, strategy (1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2; 6 and up: the binary-tree
-     * strategies, no kernel).  Dumped from ZSTD_getCParams and checked against it by the tests. */
-    static const int kCParTab[4][13][7] = {
-        {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2}, {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}, {21, 19, 19, 3, 5, 8, 4}, {21, 19, 19, 3, 5, 16, 5}, {21, 19, 20, 4, 5, 16, 5}, {22, 20, 21, 4, 5, 16, 5}, {22, 21, 22, 4, 5, 16, 5}, {22, 21, 22, 5, 5, 16, 5}},
-        {{18, 12, 13, 1, 5, 1, 1}, {18, 13, 14, 1, 6, 0, 1}, {18, 14, 14, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {18, 16, 17, 2, 5, 2, 3}, {18, 18, 18, 3, 5, 2, 3}, {18, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 4, 4, 4, 4}, {18, 18, 19, 4, 4, 8, 5}, {18, 18, 19, 5, 4, 8, 5}, {18, 18, 19, 6, 4, 8, 5}, {18, 18, 19, 5, 4, 12, 6}, {18, 19, 19, 7, 4, 12, 6}},
-        {{17, 12, 12, 1, 5, 1, 1}, {17, 12, 13, 1, 6, 0, 1}, {17, 13, 15, 1, 5, 0, 1}, {17, 15, 16, 2, 5, 0, 2}, {17, 17, 17, 2, 4, 0, 2}, {17, 16, 17, 3, 4, 2, 3}, {17, 17, 17, 3, 4, 4, 4}, {17, 17, 17, 3, 4, 8, 5}, {17, 17, 17, 4, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 5}, {17, 17, 17, 6, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 6}, {17, 18, 17, 7, 4, 12, 6}},
-        {{14, 12, 13, 1, 5, 1, 1}, {14, 14, 15, 1, 5, 0, 1}, {14, 14, 15, 1, 4, 0, 1}, {14, 14, 15, 2, 4, 0, 2}, {14, 14, 14, 4, 4, 2, 3}, {14, 14, 14, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}, {14, 14, 14, 6, 4, 8, 5}, {14, 14, 14, 8, 4, 8, 5}, {14, 15, 14, 5, 4, 8, 6}, {14, 15, 14, 9, 4, 8, 6}, {14, 15, 14, 3, 4, 12, 7}, {14, 15, 14, 4, 3, 24, 7}}};
+     * searchLog, minMatch, targetLength, strategy (1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2, 6 btlazy2; 7 and up: the
+     * optimal-parser strategies, no kernel); rows 13 .. 15 for sources above 256 KiB only.  Dumped from ZSTD_getCParams and
+     * checked against it by the tests. */
+    static const int kCParTab[4][16][7] = {
+        {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2}, {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}, {21, 19, 19, 3, 5, 8, 4}, {21, 19, 19, 3, 5, 16, 5}, {21, 19, 20, 4, 5, 16, 5}, {22, 20, 21, 4, 5, 16, 5}, {22, 21, 22, 4, 5, 16, 5}, {22, 21, 22, 5, 5, 16, 5}, {22, 21, 22, 5, 5, 32, 6}, {22, 22, 23, 5, 5, 32, 6}, {22, 23, 23, 6, 5, 32, 6}},
+        {{18, 12, 13, 1, 5, 1, 1}, {18, 13, 14, 1, 6, 0, 1}, {18, 14, 14, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {18, 16, 17, 2, 5, 2, 3}, {18, 18, 18, 3, 5, 2, 3}, {18, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 4, 4, 4, 4}, {18, 18, 19, 4, 4, 8, 5}, {18, 18, 19, 5, 4, 8, 5}, {18, 18, 19, 6, 4, 8, 5}, {18, 18, 19, 5, 4, 12, 6}, {18, 19, 19, 7, 4, 12, 6}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}},
+        {{17, 12, 12, 1, 5, 1, 1}, {17, 12, 13, 1, 6, 0, 1}, {17, 13, 15, 1, 5, 0, 1}, {17, 15, 16, 2, 5, 0, 2}, {17, 17, 17, 2, 4, 0, 2}, {17, 16, 17, 3, 4, 2, 3}, {17, 17, 17, 3, 4, 4, 4}, {17, 17, 17, 3, 4, 8, 5}, {17, 17, 17, 4, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 5}, {17, 17, 17, 6, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 6}, {17, 18, 17, 7, 4, 12, 6}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}},
+        {{14, 12, 13, 1, 5, 1, 1}, {14, 14, 15, 1, 5, 0, 1}, {14, 14, 15, 1, 4, 0, 1}, {14, 14, 15, 2, 4, 0, 2}, {14, 14, 14, 4, 4, 2, 3}, {14, 14, 14, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}, {14, 14, 14, 6, 4, 8, 5}, {14, 14, 14, 8, 4, 8, 5}, {14, 15, 14, 5, 4, 8, 6}, {14, 15, 14, 9, 4, 8, 6}, {14, 15, 14, 3, 4, 12, 7}, {14, 15, 14, 4, 3, 24, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}}};
     const int (*t)[7];
     if (level == 0) level = 3;
-    if (level > 12 || level < -131072 || n == 0u) return false;
+    if (level > 15 || level < -131072 || n == 0u) return false;
     t = kCParTab[n > 256u * 1024u ? 0 : (n > 128u * 1024u ? 1 : (n > 16u * 1024u ? 2 : 3))];
-    if (t[level < 0 ? 0 : level][6] > 5) return false; /* btlazy2 ... btultra2: no kernel */
+    if (t[level < 0 ? 0 : level][6] > 6) return false; /* btopt ... btultra2: no kernel */
     const int row = level < 0 ? 0 : level;
     int cl = t[row][1];
     *wlog = t[row][0]; *hlog = t[row][2]; *mml = t[row][4];
@@ -1272,7 +1273,10 @@ static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *
     if (n < 64u) srclog = 6;
     if (*wlog > srclog) *wlog = srclog;
     if (*hlog > *wlog + 1) *hlog = *wlog + 1;
-    if (cl > *wlog) cl = *wlog;
+    {
+        const int btscale = t[row][6] == 6 ? 1 : 0; /* cycleLog = chainLog - 1 for the binary tree */
+        if (cl - btscale > *wlog) cl = *wlog + btscale;
+    }
     if (*wlog < 10) *wlog = 10;
     if (clog) *clog = cl;
     if (dfast) *dfast = t[row][6] == 2;
@@ -1322,7 +1326,7 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
     int strategy = 1, slog = 0;
     if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast, &strategy, &slog)) return hipErrorNotSupported;
     static const bool serial_only = getenv("CRYO_ZSTD_ENC") && getenv("CRYO_ZSTD_ENC")[0] == '1'; /* testing aid: the serial `fast` walk */
-    const int finder = strategy >= 3 ? strategy : (dfast ? 1 : (serial_only ? 2 : 0)); /* 3 greedy, 4 lazy, 5 lazy2 */
+    const int finder = strategy >= 3 ? strategy : (dfast ? 1 : (serial_only ? 2 : 0)); /* 3 greedy, 4 lazy, 5 lazy2, 6 btlazy2 */
     /* search positions (dfast) / iterations (fast: two positions each) per step.  Measured on text-like rows, GB/s:
      * dfast level 3  16: 6.6  32: 7.4  64: 6.9;  fast level 1  16: 14.4  32: 13.9  64: 13.1 -- wider steps read
      * table slots for positions behind the first match, narrower ones pay more trips per sequence */

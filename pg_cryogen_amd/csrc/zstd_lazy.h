@@ -1,7 +1,7 @@
 /*
- * zstd_lazy.h -- the `greedy`, `lazy` and `lazy2` strategies' match finder (libzstd 1.4.8
- * ZSTD_compressBlock_lazy_generic at depth 0, 1, 2 over the hash-chain searcher ZSTD_HcFindBestMatch, no dictionary;
- * zstd levels 5 .. 10 at cryo block sizes).  Included by zstd_enc.hip inside its namespace, after zstd_dfast.h.
+ * zstd_lazy.h -- the `greedy`, `lazy`, `lazy2` and `btlazy2` strategies' match finder (libzstd 1.4.8
+ * ZSTD_compressBlock_lazy_generic at depth 0, 1, 2 over the hash-chain searcher ZSTD_HcFindBestMatch, and at depth 2 over
+ * the binary-tree searcher ZSTD_BtFindBestMatch, no dictionary; zstd levels 5 .. 12 at cryo block sizes, .. 15 above 256 KiB).  Included by zstd_enc.hip inside its namespace, after zstd_dfast.h.
  *
  * Replaces the match-finding half of ZSTD_compress(dst, bound, src, B, level) (reference
  * compression.c:102-104); restated for the CPU in oracle/zstd_enc_oracle.c (block_lazy, hc_find_best).
@@ -83,6 +83,160 @@ __device__ inline uint32_t hc_find_best(HcState &hc, uint8_t *mark, const CPar &
     return ml;
 }
 
+/* ---- strategy `btlazy2`: the lazy2 parser over the binary-tree searcher (libzstd 1.4.8 ZSTD_updateDUBT, ZSTD_insertDUBT1,
+ * ZSTD_DUBT_findBestMatch, ZSTD_BtFindBestMatch; oracle: dubt_update, dubt_insert1, bt_find_best).  The chain table is a
+ * binary tree of 2^(chainLog-1) nodes, two links per position; positions are first chained unsorted (second link = the
+ * mark 1) and sorted into the tree in batches when a search runs into them.  Wave-uniform like the hash-chain searcher:
+ * every tree step is a dependent load of a node and a 64-bytes-per-step comparison. */
+constexpr uint32_t kDubtUnsorted = 1u;
+
+__device__ inline void dubt_update(HcState &hc, uint8_t *mark, const CPar &cp, const uint8_t *base, uint32_t target, int mls, uint32_t lane)
+{
+    const uint32_t bt_mask = (1u << (cp.clog - 1)) - 1u;
+    uint32_t idx = hc.next_to_update;
+    while (idx < target) {
+        const uint32_t my = idx + lane;
+        bool on = my < target;
+        const uint32_t h = hashs_v(on ? ld64v(base + my) : 0ull, cp.hlog, mls);
+        const uint32_t keep = distinct_prefix(mark, h & (kDfMark - 1u), on, lane);
+        on = on && lane < keep;
+        if (on) {
+            const uint32_t old = hc.hash[h];
+            hc.hash[h] = my;
+            *reinterpret_cast<uint2 *>(hc.chain + 2u * (my & bt_mask)) = make_uint2(old, kDubtUnsorted);
+        }
+        idx += (uint32_t)__builtin_popcountll(__ballot(on));
+    }
+    hc.next_to_update = target;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+}
+
+/* a[0 ..) against b[0 ..), at most up to `end` (an index like cur): common length, 64 bytes per step */
+__device__ inline uint32_t bt_count(const uint8_t *base, uint32_t a, uint32_t b, uint32_t iend, uint32_t lane)
+{
+    return count_match(base + a, base + b, base + iend, lane);
+}
+
+__device__ inline void dubt_insert1(HcState &hc, const CPar &cp, const uint8_t *base, uint32_t cur, uint32_t iend, uint32_t nb_compares,
+                                    uint32_t bt_low, uint32_t lane)
+{
+    uint32_t *const bt = hc.chain;
+    const uint32_t bt_mask = (1u << (cp.clog - 1)) - 1u;
+    uint32_t common_smaller = 0, common_larger = 0;
+    uint32_t smaller_at = 2u * (cur & bt_mask), larger_at = smaller_at + 1u; /* indexes into bt; 0xFFFFFFFF: nowhere */
+    uint32_t mi = uni(bt[smaller_at]);
+    const uint32_t max_dist = 1u << cp.wlog;
+    const uint32_t window_low = (cur - 1u > max_dist) ? cur - max_dist : 1u;
+    while (nb_compares-- && mi > window_low) {
+        const uint32_t next_at = 2u * (mi & bt_mask);
+        const uint2 nx = *reinterpret_cast<const uint2 *>(bt + next_at);
+        uint32_t ml = common_smaller < common_larger ? common_smaller : common_larger;
+        ml += bt_count(base, cur + ml, mi + ml, iend, lane);
+        if (cur + ml == iend) break; /* equal: dropped */
+        if (uni((uint32_t)base[mi + ml]) < uni((uint32_t)base[cur + ml])) {
+            if (lane == 0 && smaller_at != 0xFFFFFFFFu) bt[smaller_at] = mi;
+            common_smaller = ml;
+            if (mi <= bt_low) { smaller_at = 0xFFFFFFFFu; break; }
+            smaller_at = next_at + 1u;
+            mi = uni(nx.y);
+        } else {
+            if (lane == 0 && larger_at != 0xFFFFFFFFu) bt[larger_at] = mi;
+            common_larger = ml;
+            if (mi <= bt_low) { larger_at = 0xFFFFFFFFu; break; }
+            larger_at = next_at;
+            mi = uni(nx.x);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    if (lane == 0) {
+        if (smaller_at != 0xFFFFFFFFu) bt[smaller_at] = 0;
+        if (larger_at != 0xFFFFFFFFu) bt[larger_at] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+}
+
+__device__ inline uint32_t bt_find_best(HcState &hc, uint8_t *mark, const CPar &cp, const uint8_t *base, uint32_t cur, uint32_t iend,
+                                        uint32_t *offset_ptr, int mls, uint32_t lane)
+{
+    uint32_t *const bt = hc.chain;
+    const uint32_t bt_mask = (1u << (cp.clog - 1)) - 1u;
+    if (cur < hc.next_to_update) return 0; /* skipped area */
+    dubt_update(hc, mark, cp, base, cur, mls, lane);
+    const uint32_t h = hashs_v(ld64u(base + cur), cp.hlog, mls);
+    uint32_t mi = uni(hc.hash[h]);
+    const uint32_t max_dist = 1u << cp.wlog;
+    const uint32_t window_low = (cur - 1u > max_dist) ? cur - max_dist : 1u;
+    const uint32_t bt_low = (bt_mask >= cur) ? 0u : cur - bt_mask;
+    const uint32_t unsort_limit = bt_low > window_low ? bt_low : window_low;
+    uint32_t nb_compares = 1u << cp.slog, nb_candidates = nb_compares, previous = 0;
+    /* reach the end of the unsorted candidates (their marks become a reversed chain to come back by) */
+    uint32_t cand_at = 2u * (mi & bt_mask);
+    uint2 node = *reinterpret_cast<const uint2 *>(bt + cand_at);
+    while (mi > unsort_limit && uni(node.y) == kDubtUnsorted && nb_candidates > 1u) {
+        if (lane == 0) bt[cand_at + 1u] = previous;
+        previous = mi;
+        mi = uni(node.x);
+        cand_at = 2u * (mi & bt_mask);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        node = *reinterpret_cast<const uint2 *>(bt + cand_at);
+        nb_candidates--;
+    }
+    /* the last candidate, if still unsorted, is dropped */
+    if (mi > unsort_limit && uni(node.y) == kDubtUnsorted) {
+        if (lane == 0) *reinterpret_cast<uint2 *>(bt + cand_at) = make_uint2(0, 0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    /* batch sort of the stacked candidates */
+    mi = previous;
+    while (mi) {
+        const uint32_t next_idx = uni(bt[2u * (mi & bt_mask) + 1u]);
+        dubt_insert1(hc, cp, base, mi, iend, nb_candidates, unsort_limit, lane);
+        mi = next_idx;
+        nb_candidates++;
+    }
+    /* the longest match, inserting the current position on the way */
+    uint32_t common_smaller = 0, common_larger = 0, best = 0;
+    uint32_t smaller_at = 2u * (cur & bt_mask), larger_at = smaller_at + 1u;
+    uint32_t match_end_idx = cur + 8u + 1u;
+    mi = uni(hc.hash[h]);
+    if (lane == 0) hc.hash[h] = cur;
+    while (nb_compares-- && mi > window_low) {
+        const uint32_t next_at = 2u * (mi & bt_mask);
+        const uint2 nx = *reinterpret_cast<const uint2 *>(bt + next_at);
+        uint32_t ml = common_smaller < common_larger ? common_smaller : common_larger;
+        ml += bt_count(base, cur + ml, mi + ml, iend, lane);
+        if (ml > best) {
+            if (ml > match_end_idx - mi) match_end_idx = mi + ml;
+            if ((4 * (int)(ml - best)) > (int)(hbit(cur - mi + 1u) - hbit(*offset_ptr + 1u))) {
+                best = ml;
+                *offset_ptr = 2u + cur - mi;
+            }
+            if (cur + ml == iend) break; /* equal: dropped, to keep the tree consistent */
+        }
+        if (uni((uint32_t)base[mi + ml]) < uni((uint32_t)base[cur + ml])) {
+            if (lane == 0 && smaller_at != 0xFFFFFFFFu) bt[smaller_at] = mi;
+            common_smaller = ml;
+            if (mi <= bt_low) { smaller_at = 0xFFFFFFFFu; break; }
+            smaller_at = next_at + 1u;
+            mi = uni(nx.y);
+        } else {
+            if (lane == 0 && larger_at != 0xFFFFFFFFu) bt[larger_at] = mi;
+            common_larger = ml;
+            if (mi <= bt_low) { larger_at = 0xFFFFFFFFu; break; }
+            larger_at = next_at;
+            mi = uni(nx.x);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    }
+    if (lane == 0) {
+        if (smaller_at != 0xFFFFFFFFu) bt[smaller_at] = 0;
+        if (larger_at != 0xFFFFFFFFu) bt[larger_at] = 0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    hc.next_to_update = match_end_idx - 8u; /* skip repetitive patterns */
+    return best;
+}
+
 /* ZSTD_compressBlock_lazy_generic: depth 0 greedy, 1 lazy, 2 lazy2 (oracle: block_lazy).  Indexes are the library's
  * (base = src - 1).  The walk is wave-uniform; depth 1 / 2 search again at ip+1 (ip+2) and keep the candidate whose
  * gain estimate (4 x length - log2(offset code)) is better. */
@@ -112,7 +266,7 @@ __device__ uint32_t block_lazy(HcState &hc, uint8_t *mark, const CPar &cp, int d
         if (!have) {
             {
                 uint32_t off_found = 999999999u;
-                const uint32_t ml2 = hc_find_best(hc, mark, cp, base, ip, iend, &off_found, mls, lane);
+                const uint32_t ml2 = cp.bt ? bt_find_best(hc, mark, cp, base, ip, iend, &off_found, mls, lane) : hc_find_best(hc, mark, cp, base, ip, iend, &off_found, mls, lane);
                 if (ml2 > mlen) { mlen = ml2; start = ip; offset = off_found; }
             }
             if (mlen < 4u) { ip += ((ip - anchor) >> 8) + 1u; continue; }
@@ -127,7 +281,7 @@ __device__ uint32_t block_lazy(HcState &hc, uint8_t *mark, const CPar &cp, int d
                     }
                     {
                         uint32_t off2f = 999999999u;
-                        const uint32_t ml2 = hc_find_best(hc, mark, cp, base, ip, iend, &off2f, mls, lane);
+                        const uint32_t ml2 = cp.bt ? bt_find_best(hc, mark, cp, base, ip, iend, &off2f, mls, lane) : hc_find_best(hc, mark, cp, base, ip, iend, &off2f, mls, lane);
                         const int gain2 = (int)(ml2 * 4u - hbit(off2f + 1u));
                         const int gain1 = (int)(mlen * 4u - hbit(offset + 1u) + 4u);
                         if (ml2 >= 4u && gain2 > gain1) { mlen = ml2; offset = off2f; start = ip; continue; }
@@ -142,7 +296,7 @@ __device__ uint32_t block_lazy(HcState &hc, uint8_t *mark, const CPar &cp, int d
                         }
                         {
                             uint32_t off2f = 999999999u;
-                            const uint32_t ml2 = hc_find_best(hc, mark, cp, base, ip, iend, &off2f, mls, lane);
+                            const uint32_t ml2 = cp.bt ? bt_find_best(hc, mark, cp, base, ip, iend, &off2f, mls, lane) : hc_find_best(hc, mark, cp, base, ip, iend, &off2f, mls, lane);
                             const int gain2 = (int)(ml2 * 4u - hbit(off2f + 1u));
                             const int gain1 = (int)(mlen * 4u - hbit(offset + 1u) + 7u);
                             if (ml2 >= 4u && gain2 > gain1) { mlen = ml2; offset = off2f; start = ip; continue; }

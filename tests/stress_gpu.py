@@ -3,7 +3,7 @@
 
 Random structured blocks (mixtures of text-like rows, runs, repeats at random distances, noise) at several
 block sizes; the device encoders must equal the stock liblz4 / libzstd byte for byte (all LZ4 accelerations,
-zstd levels -5..10, 11 and 12 above 256 KiB), and the device decoders must reproduce the input from streams the stock libraries wrote at
+zstd levels -5..12, 13..15 above 256 KiB), and the device decoders must reproduce the input from streams the stock libraries wrote at
 ANY level (zstd 1..19), through both zstd decode paths (fused for small batches, pipeline for large ones)."""
 import os, sys, time
 import numpy as np
@@ -143,8 +143,8 @@ def main():
             outs, st = c.decompress_blocks(METHOD_LZ4, got, B)
             assert (st == 0).all() and all(np.array_equal(o, b) for o, b in zip(outs, blocks)), ("lz4 dec", seed, rounds, B)
             checks += 2 * n
-            if True:   # every size class of libzstd's parameter tables has kernels (levels -5 .. 8 / 10 / 10 / 12)
-                level = int(rng.choice([-5, -3, -1, 1, 1, 2, 3, 4, 5, 6, 7, 8] + ([9, 10] if B > 16384 else []) + ([11, 12] if B > 262144 else [])))
+            if True:   # every size class of libzstd's parameter tables has kernels (levels -5 .. 10 / 12 / 12 / 15)
+                level = int(rng.choice([-5, -3, -1, 1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10] + ([11, 12] if B > 16384 else []) + ([13, 15] if B > 262144 else [])))
                 gotz = c.compress_blocks(METHOD_ZSTD, level, blocks)
                 for i in range(n):
                     exp = stock.zstd_compress(blocks[i], level)

@@ -120,7 +120,7 @@ def test_gpu_compression_h_surface(HG, oracle):
     p = L.cryo_compress(host.COMP_ZSTD, raw.ctypes.data, C.byref(n))
     z9 = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value,)).copy()
     assert np.array_equal(z9, oracle.zstd_compress(raw, 9)) and not errors
-    # levels whose strategy has no kernel (btlazy2 .. btultra2, 11..22): the reference's error is raised, no CPU fallback ...
+    # levels whose strategy has no kernel (btopt .. btultra2, 13..22 at this size): the reference's error is raised, no CPU fallback ...
     host.set_int("zstd_compression_level_guc", 15)
     L.cryo_compress(host.COMP_ZSTD, raw.ctypes.data, C.byref(n))
     assert errors and errors[-1][1].startswith("pg_cryogen: compression failed") and "no GPU kernel for zstd parameter 15" in errors[-1][1]

@@ -241,7 +241,7 @@ def test_zstd_oracle_fuzz_vs_live_libzstd(oracle):
     assert n_lib - n_ok <= n // 20, (n_lib, n_ok)
 
 
-# ---------------- zstd encoder oracle (strategies `fast` .. `lazy2`: levels -5..10) ----------------
+# ---------------- zstd encoder oracle (strategies `fast` .. `btlazy2`: levels -5..12 at cryo block sizes, ..15 above 256 KiB) ----------------
 def test_zstd_encoder_oracle_matches_libzstd_golden(oracle):
     n = 0
     for c in VEC["cells"]:
@@ -277,7 +277,9 @@ ZSTD_CLASS_SIZES = [64, 1000, 4096, 16384, 16385, 131073, 200000, 262144, 262145
 
 
 def zstd_levels_with_kernel(B):
-    return list(range(-5, 9 if B <= 16384 else (11 if B <= 262144 else 13)))
+    """levels whose strategy is `fast` .. `btlazy2` at this source size: -5 .. 10 up to 16 KiB, .. 12 up to 256 KiB, .. 15 above
+    (the next level is `btopt`)"""
+    return list(range(-5, 11 if B <= 16384 else (13 if B <= 262144 else 16)))
 
 
 @pytest.mark.parametrize("B", ZSTD_CLASS_SIZES)
@@ -293,12 +295,12 @@ def test_zstd_encoder_oracle_size_classes_vs_live_libzstd(oracle, B):
             exp = stock.zstd_compress(raw, lvl)
             got = oracle.zstd_compress(raw, lvl)
             assert np.array_equal(got, exp), (B, lvl, len(got), len(exp))
-    assert len(oracle.zstd_compress(blocks[0], zstd_levels_with_kernel(B)[-1] + 1)) == 0   # the first bt* level of the class
+    assert len(oracle.zstd_compress(blocks[0], zstd_levels_with_kernel(B)[-1] + 1)) == 0   # the first optimal-parser level of the class
 
 
 def test_zstd_encoder_oracle_unsupported_levels_return_empty(oracle):
     raw = oracle.synth(0, 0, 131072, 1)
-    assert len(oracle.zstd_compress(raw, 11)) == 0     # bt* strategies (from level 11 on at 128 KiB): not restated
+    assert len(oracle.zstd_compress(raw, 13)) == 0     # btopt and up (from level 13 on at 128 KiB): not restated
     assert len(oracle.zstd_compress(raw, 22)) == 0
 
 
