@@ -1,7 +1,7 @@
 /*
  * zstd_enc.hip -- Zstandard frame encode, one wavefront per cryo block, output bytes identical
- * to libzstd 1.4.8 for the levels whose strategy is `fast`, `dfast`, `greedy`, `lazy` or `lazy2` (levels
- * -5 .. 10 at cryo block sizes; the reference's default zstd_compression_level_guc = 1 is one of them).
+ * to libzstd 1.4.8 for the levels whose strategy is `fast`, `dfast`, `greedy`, `lazy`, `lazy2` or `btlazy2` (levels
+ * -5 .. 12 at cryo block sizes, .. 15 above 256 KiB; the reference's default zstd_compression_level_guc = 1 is one of them).
  *
  * Replaces ZSTD_compress(dst, ZSTD_compressBound(B), src, B, level)
  * (reference compression.c:102-104).

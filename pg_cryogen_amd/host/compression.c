@@ -40,7 +40,7 @@ static int hip_multi_first = -1, hip_multi_count = 0, hip_pool_mb = 0;
 static char codec_err[320];
 
 static size_t hip_bound(int method, size_t n) { return cryo_codec_bound(method, n); }
-/* zstd levels whose strategy has no GPU kernel (btlazy2 ... btultra2: 11..22 at cryo block sizes; the GUC accepts them,
+/* zstd levels whose strategy has no GPU kernel (btopt ... btultra2: 13..22 up to 256 KiB, 16..22 above; the GUC accepts them,
  * reference compression.c:48-58).  Default: the call fails with the reference's ERROR.  With the additive GUC
  * pg_cryogen.zstd_host_fallback = on, such a call is served by the library the reference links, found by soname and
  * called exactly as reference compression.c:102-104 calls it, one block after the other on this backend's core --
