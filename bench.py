@@ -101,10 +101,31 @@ def physical_cores():
     return cores or allowed
 
 
+def cpu_quota():
+    """CPUs' worth of time the container's cgroup grants this process (cpu.max / cfs quota), or None: a 256-thread host
+    whose container is given 16 CPUs runs 128 pinned threads at 16 cores' pace -- and at more in the one run in nine the
+    quota bursts (profiles/r03_cpu_baseline_repeat.txt: 85-122 GB/s, once 301)."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            return max(1, int(q) // int(p))
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            return max(1, q // p)
+    except (OSError, ValueError):
+        pass
+    return None
+
+
 def cpu_baseline(ora, np, method, encode, param, blobs, sizes, B, reps=5):
     """One pass over the sample's distinct blocks, median of `reps`: stock liblz4 / libzstd called
     exactly as reference compression.c:70-72,84,102-104,116 calls them, on 1 pinned thread (`value`) and on one pinned
-    thread per physical core (`all_cores_value`, `cores_used`); the oracle port's 1-thread rate beside it."""
+    thread per physical core -- as many of them as the container's CPU quota lets run at once -- (`all_cores_value`,
+    `cores_used`); the oracle port's 1-thread rate beside it."""
     fn = ora.L.cryo_oracle_cpu_pass_bench
     fn.restype = ctypes.c_double
     fn.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
@@ -123,6 +144,9 @@ def cpu_baseline(ora, np, method, encode, param, blobs, sizes, B, reps=5):
     ver = ctypes.create_string_buffer(64)
 
     cores = physical_cores()
+    quota = cpu_quota()
+    if quota is not None and quota < len(cores):
+        cores = cores[:quota]   # no more threads than the container may run at once
     pins = (ctypes.c_int * len(cores))(*cores)
 
     def run(stock, threads, r):
@@ -142,8 +166,8 @@ def cpu_baseline(ora, np, method, encode, param, blobs, sizes, B, reps=5):
         allc = run(1, T, reps)
         res.update({"value": round(one, 3), "kind": "reference", "library": "%s %s via dlopen (what the reference links, Makefile:5); %s"
                     % (lib, ver.value.decode(), call), "all_cores_value": round(allc, 3), "threads": T, "cores_used": T,
-                    "pinning": "one thread per physical core (first hardware thread of each sibling set), pthread_setaffinity_np",
-                    "hardware_threads": os.cpu_count(), "port_value": round(port, 3)})
+                    "pinning": "one thread per physical core (first hardware thread of each sibling set), pthread_setaffinity_np; every thread decodes from its own first-touched copy of its share of the input (NUMA-local)",
+                    "hardware_threads": os.cpu_count(), "physical_cores": len(physical_cores()), "cgroup_cpu_quota": quota, "port_value": round(port, 3)})
     else:   # the stock library is not on this machine: the restatement is all there is
         res.update({"value": round(port, 3), "kind": "port", "library": "oracle/ restatement (stock %s not loadable here)" % lib})
     return res
