@@ -548,6 +548,56 @@ def test_few_blocks_path_structured_and_mutated(codec, oracle, B):
     assert sum(e is None for e in expect) >= 4
 
 
+def test_few_blocks_path_edge_streams(codec, oracle):
+    """what the few-blocks path must leave to the batch decoder, or decode at the edges of its rules: an empty stream, a
+    stream of literals only, liblz4's offset-0 zero fill, a match that ends exactly LASTLITERALS before the end, one that
+    ends one byte later (rejected), a truncated stream, trailing garbage; one block per call and all in one call"""
+    B = 32768
+
+    def lits_len(n):   # token nibble 15 + extension bytes
+        out, n = [], n - 15
+        while n >= 255:
+            out.append(255)
+            n -= 255
+        out.append(n)
+        return out
+
+    def stream(ll1, off, ml, tail):
+        """literals ll1 x 'a' | match (off, ml) | literals `tail`"""
+        b = bytearray()
+        b.append(((15 if ll1 >= 15 else ll1) << 4) | (15 if ml - 4 >= 15 else ml - 4))
+        if ll1 >= 15:
+            b += bytes(lits_len(ll1))
+        b += b"a" * ll1
+        b += bytes([off & 255, off >> 8])
+        if ml - 4 >= 15:
+            b += bytes(lits_len(ml - 4))
+        b.append((15 if tail >= 15 else tail) << 4)
+        if tail >= 15:
+            b += bytes(lits_len(tail))
+        b += bytes((i * 7 + 1) & 255 for i in range(tail))
+        return np.frombuffer(bytes(b), np.uint8).copy()
+
+    rng = np.random.default_rng(99)
+    items = [np.zeros(0, np.uint8),                                                      # empty
+             oracle.lz4_compress(rng.integers(0, 256, B, dtype=np.uint8), 1),           # literals only
+             stream(1, 0, B - 1 - 12, 12),                                               # offset 0: zero fill
+             stream(20, 3, B - 20 - 5, 5),                                               # match ends LASTLITERALS before the end
+             stream(20, 3, B - 20 - 4, 4),                                               # ... one byte later: rejected
+             stream(20, 21, B - 20 - 12, 12),                                            # offset beyond the output so far: rejected
+             oracle.lz4_compress(oracle.synth(3, 1, B, 0), 1)[:-7],                      # truncated
+             np.concatenate([oracle.lz4_compress(oracle.synth(3, 2, B, 0), 1), np.array([0, 0, 0], np.uint8)])]  # trailing bytes
+    expect = []
+    for m in items:
+        r, out = oracle.lz4_decompress(m, B, fill=0xA5)
+        expect.append(out.copy() if r == B else None)
+    assert expect[2] is not None and expect[3] is not None and expect[4] is None and expect[5] is None and expect[0] is None
+    with _few_blocks(codec):
+        _decode_check(codec, items, expect, B, "few-edges")
+        for i in range(len(items)):
+            _decode_check(codec, items[i:i + 1], expect[i:i + 1], B, ("few-edge-one", i))
+
+
 def test_lz4_path_options_roundtrip(codec):
     from pg_cryogen_amd import codec as cc
     assert codec.get_option(cc.OPT_LZ4_DECODE_PATH) == 0 and codec.get_option(cc.OPT_LZ4_INDEX_WALKERS) == 0
