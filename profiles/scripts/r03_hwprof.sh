@@ -1,10 +1,9 @@
 #!/bin/bash
-# where a k_zhufw wave spends its time (profiling build, s_memtime stamps)
+# where a k_zhufw wave and a k_zplan wave spend their time (profiling build of zstd_pipe.hip: -DCRYO_HW_PROF, s_memtime stamps
+# summed into spare counters; printed by CRYO_ZSTD_STATS=1), and why blocks are handed back to k_zhuf.
+# Build the variant first (on the build host):
+#   cd pg_cryogen_amd/csrc && hipcc --offload-arch=gfx950 -O3 -fPIC -std=c++17 -I../../include -DCRYO_HW_PROF -c zstd_pipe.hip -o /tmp/zp.o &&
+#   g++ -shared -o ../../profiles/variants_hwprof.so $(ls *.o | grep -v zstd_pipe.o) /tmp/zp.o -Wl,--no-as-needed -lstdc++ -lm
 cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out/r03_hwprof
-timeout 1500 python3 -m pytest tests/test_gpu_zstd.py -x -q -m gpu 2>&1 | tail -3
 export CRYO_CODEC_LIB=$(pwd)/profiles/variants_hwprof.so CRYO_ZSTD_STATS=1 CRYO_ZSTD_LANES=1
-timeout 300 python3 bench.py --workload zstd_decode --no-cpu-baseline --steps 1 --warmup 0 2>&1 | grep "zstd pipe" | cut -c1-250 | head -4 | tee gpurun_out/r03_hwprof/log.txt
-unset CRYO_CODEC_LIB CRYO_ZSTD_STATS
-for i in 1 2; do timeout 600 python3 bench.py --workload zstd_decode --no-cpu-baseline --steps 6 --warmup 2 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"; done
-unset CRYO_ZSTD_LANES
-timeout 600 python3 bench.py --workload zstd_decode --no-cpu-baseline --steps 6 --warmup 2 2>&1 | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+timeout 300 python3 bench.py --workload zstd_decode --no-cpu-baseline --steps 1 --warmup 0 "$@" 2>&1 | grep "zstd pipe" | cut -c1-300 | head -8 | tee gpurun_out/r03_hwprof/log.txt
