@@ -95,7 +95,7 @@ struct ZPipe {
 };
 
 struct PlanLds {
-    uint32_t ll[512], ml[512], of[256];
+    uint32_t ll[64], ml[64], of[64]; /* an RLE table (one entry) or a predefined one (log <= 6); described tables are built straight into the workspace */
     int16_t norm3[3][64];   /* per table kind (LL, OF, ML): normalized counts, next-state counters, cell symbols */
     uint16_t nxt3[3][64];
     uint8_t cell3[3][512];

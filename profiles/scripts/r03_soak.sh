@@ -3,6 +3,6 @@
 # the inputs; mutated streams against the oracle's verdicts and bytes
 cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out
 out=gpurun_out/r03_soak.txt; : > $out
-timeout 700 python3 tests/stress_gpu.py 420 77 2>&1 | tail -3 | tee -a $out
-timeout 700 python3 tests/stress_gpu.py fuzz 420 78 2>&1 | tail -3 | tee -a $out
-timeout 500 python3 tests/stress_gpu.py 240 79 2>&1 | tail -3 | tee -a $out
+timeout 700 python3 tests/stress_gpu.py 420 ${1:-77} 2>&1 | tail -3 | tee -a $out
+timeout 700 python3 tests/stress_gpu.py fuzz 420 ${2:-78} 2>&1 | tail -3 | tee -a $out
+timeout 500 python3 tests/stress_gpu.py 240 ${3:-79} 2>&1 | tail -3 | tee -a $out
