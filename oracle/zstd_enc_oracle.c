@@ -22,6 +22,8 @@
  */
 #include "cryo_oracle.h"
 #include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <math.h>
 
 #define ZBLOCK_MAX (128u * 1024u)
@@ -275,7 +277,7 @@ static uint32_t fse_encode(bitw *b, const fse_ct *ct, uint32_t state, uint32_t s
     return ct->state[(int)(state >> nb) + t.delta_find];
 }
 
-static int g_strategy = 1; /* ZSTD_fast = 1, dfast 2, greedy 3, lazy 4, lazy2 5; set by the frame driver */
+static int g_strategy = 1; /* ZSTD_fast = 1, dfast 2, greedy 3, lazy 4, lazy2 5, btlazy2 6, btopt 7, btultra 8, btultra2 9; set by the frame driver */
 
 /* ------------------------------------------------------------ Huffman (compression side) */
 typedef struct { uint16_t val; uint8_t nb; } huf_elt;
@@ -534,7 +536,7 @@ static size_t huf_compress(uint8_t *dst, const uint8_t *src, size_t n, int singl
 }
 
 /* ------------------------------------------------------------ literals section */
-static size_t min_gain(size_t n) { return (n >> 6) + 2; } /* strategies below btultra */
+static size_t min_gain(size_t n) { return (n >> (g_strategy >= 8 ? g_strategy - 1 : 6)) + 2; } /* ZSTD_minGain: btultra and btultra2 accept smaller gains */
 
 static size_t lit_raw(uint8_t *dst, const uint8_t *src, size_t n)
 {
@@ -826,7 +828,8 @@ check:
 
 /* ------------------------------------------------------------ match finder: strategy `fast` */
 typedef struct { int wlog, clog, hlog, slog, mml, tlen, dfast, lazy_depth; /* lazy_depth: -1 none, 0 greedy, 1 lazy, 2 lazy2 */
-                 int bt; /* 1: strategy btlazy2 -- the lazy2 parser over the binary-tree searcher */ } cpar;
+                 int bt;  /* 1: the binary-tree searcher (strategy btlazy2 with the lazy2 parser, and the optimal-parser strategies) */
+                 int opt; /* 0, or 1 btopt, 2 btultra, 3 btultra2 */ } cpar;
 
 static uint32_t hash_ptr(const uint8_t *p, int hlog, int mls)
 {
@@ -1044,7 +1047,8 @@ static size_t block_dfast(uint32_t *tlong, uint32_t *tshort, const cpar *cp, con
  * dictionary): every position up to the one searched is inserted into a hash table + chain table; a search
  * walks at most 2^searchLog chain links and keeps the longest match; depth 1/2 retry at ip+1 (ip+2) and keep
  * the candidate whose gain estimate is better. */
-typedef struct { uint32_t *hash, *chain; uint32_t next_to_update; } hc_state;
+typedef struct { uint32_t *hash, *chain; uint32_t next_to_update;
+                 uint32_t *hash3; int hlog3; uint32_t low; /* the optimal-parser strategies: 3-byte hash table, lowest valid index */ } hc_state;
 
 static uint32_t hc_insert_find(hc_state *hc, const cpar *cp, const uint8_t *base, uint32_t target, int mls)
 {
@@ -1318,6 +1322,414 @@ static size_t block_lazy(hc_state *hc, const cpar *cp, const uint8_t *base, cons
     return (size_t)(iend - anchor);
 }
 
+/* ------------------------------------------------------------ strategies btopt, btultra, btultra2
+ * (libzstd 1.4.8 lib/compress/zstd_opt.c: ZSTD_compressBlock_opt_generic and its helpers.)  The binary tree is filled in order
+ * (ZSTD_insertBt1), every search returns the whole ladder of matches of increasing length (ZSTD_insertBtAndGetAllMatches), and a
+ * forward pass over up to 4096 positions prices every reachable position with running symbol statistics; the cheapest path is
+ * then emitted backwards.  optlevel 0: btopt (integer log2 prices, two shortcuts); 2: btultra (fractional prices). */
+#define OPT_NUM 4096u
+#define OPT_MAX_PRICE (1 << 30)
+#define BITCOST 256u
+typedef struct { int price; uint32_t off, mlen, litlen, rep[3]; } opt_t;
+typedef struct { uint32_t off, len; } match_t;
+typedef struct {
+    uint32_t lit[256], ll[MaxLL + 1], ml[MaxML + 1], of[MaxOff + 1];
+    uint32_t lit_sum, ll_sum, ml_sum, of_sum;
+    uint32_t lit_base, ll_base, ml_base, of_base;
+    int predef;
+} opt_stats;
+
+static uint32_t opt_weight(uint32_t stat, int lvl)
+{
+    const uint32_t s = stat + 1;
+    const int h = hb(s);
+    return lvl ? (uint32_t)h * BITCOST + ((s << 8) >> h) : (uint32_t)h * BITCOST;
+}
+static void opt_set_base(opt_stats *o, int lvl)
+{
+    o->lit_base = opt_weight(o->lit_sum, lvl);
+    o->ll_base = opt_weight(o->ll_sum, lvl);
+    o->ml_base = opt_weight(o->ml_sum, lvl);
+    o->of_base = opt_weight(o->of_sum, lvl);
+}
+static uint32_t opt_downscale(uint32_t *t, uint32_t last, int malus)
+{
+    uint32_t s, sum = 0;
+    for (s = 0; s <= last; s++) { t[s] = 1 + (t[s] >> (4 + malus)); sum += t[s]; }
+    return sum;
+}
+static uint32_t opt_upscale(uint32_t *t, uint32_t last)
+{
+    uint32_t s, sum = 0;
+    for (s = 0; s <= last; s++) { t[s] <<= 4; t[s]--; sum += t[s]; }
+    return sum;
+}
+/* ZSTD_rescaleFreqs: first block of a frame: literal counts of the raw block, flat counts for the codes; later blocks:
+ * the previous statistics scaled down */
+static void opt_rescale(opt_stats *o, const uint8_t *src, size_t n, int lvl)
+{
+    o->predef = 0;
+    if (o->ll_sum == 0) {
+        uint32_t k;
+        size_t i;
+        if (n <= 1024) o->predef = 1;
+        memset(o->lit, 0, sizeof o->lit);
+        for (i = 0; i < n; i++) o->lit[src[i]]++;
+        o->lit_sum = opt_downscale(o->lit, 255, 1);
+        for (k = 0; k <= MaxLL; k++) o->ll[k] = 1;
+        o->ll_sum = MaxLL + 1;
+        for (k = 0; k <= MaxML; k++) o->ml[k] = 1;
+        o->ml_sum = MaxML + 1;
+        for (k = 0; k <= MaxOff; k++) o->of[k] = 1;
+        o->of_sum = MaxOff + 1;
+    } else {
+        o->lit_sum = opt_downscale(o->lit, 255, 1);
+        o->ll_sum = opt_downscale(o->ll, MaxLL, 0);
+        o->ml_sum = opt_downscale(o->ml, MaxML, 0);
+        o->of_sum = opt_downscale(o->of, MaxOff, 0);
+    }
+    opt_set_base(o, lvl);
+}
+static uint32_t opt_lit_cost1(const opt_stats *o, uint8_t c, int lvl)
+{
+    if (o->predef) return 6 * BITCOST;
+    return o->lit_base - opt_weight(o->lit[c], lvl);
+}
+static uint32_t opt_ll_price(const opt_stats *o, uint32_t ll, int lvl)
+{
+    if (o->predef) return opt_weight(ll, lvl);
+    {
+        const uint32_t c = ll_code(ll);
+        return LL_bits[c] * BITCOST + o->ll_base - opt_weight(o->ll[c], lvl);
+    }
+}
+static uint32_t opt_match_price(const opt_stats *o, uint32_t off, uint32_t mlen, int lvl)
+{
+    const uint32_t oc = (uint32_t)hb(off + 1);
+    const uint32_t mb = mlen - MINMATCH;
+    uint32_t price;
+    if (o->predef) return opt_weight(mb, lvl) + (16 + oc) * BITCOST;
+    price = oc * BITCOST + (o->of_base - opt_weight(o->of[oc], lvl));
+    if (lvl < 2 && oc >= 20) price += (oc - 19) * 2 * BITCOST; /* long offsets handicapped below btultra */
+    {
+        const uint32_t mc = ml_code(mb);
+        price += ML_bits[mc] * BITCOST + (o->ml_base - opt_weight(o->ml[mc], lvl));
+    }
+    return price + BITCOST / 5;
+}
+static void opt_update_stats(opt_stats *o, uint32_t ll, const uint8_t *lit, uint32_t offcode, uint32_t mlen)
+{
+    uint32_t u;
+    for (u = 0; u < ll; u++) o->lit[lit[u]] += 2;
+    o->lit_sum += ll * 2;
+    o->ll[ll_code(ll)]++; o->ll_sum++;
+    o->of[hb(offcode + 1)]++; o->of_sum++;
+    o->ml[ml_code(mlen - MINMATCH)]++; o->ml_sum++;
+}
+
+/* ZSTD_insertBt1: one position into the sorted tree; returns how many positions to advance */
+static uint32_t bt_insert1(hc_state *hc, const cpar *cp, const uint8_t *base, uint32_t cur, const uint8_t *iend, int mls)
+{
+    uint32_t *const bt = hc->chain;
+    const uint32_t bt_mask = (1u << (cp->clog - 1)) - 1u;
+    const uint8_t *const ip = base + cur;
+    const uint32_t h = hash_ptr(ip, cp->hlog, mls);
+    uint32_t mi = hc->hash[h];
+    size_t common_smaller = 0, common_larger = 0;
+    const uint32_t bt_low = bt_mask >= cur ? 0 : cur - bt_mask;
+    uint32_t *smaller_ptr = bt + 2u * (cur & bt_mask);
+    uint32_t *larger_ptr = smaller_ptr + 1;
+    uint32_t dummy;
+    uint32_t match_end = cur + 8 + 1;
+    size_t best = 8;
+    uint32_t nb = 1u << cp->slog;
+    hc->hash[h] = cur;
+    while (nb-- && mi >= hc->low) {
+        uint32_t *const next_ptr = bt + 2u * (mi & bt_mask);
+        size_t ml = common_smaller < common_larger ? common_smaller : common_larger;
+        const uint8_t *const match = base + mi;
+        ml += count_match(ip + ml, match + ml, iend);
+        if (ml > best) {
+            best = ml;
+            if (ml > match_end - mi) match_end = mi + (uint32_t)ml;
+        }
+        if (ip + ml == iend) break;
+        if (match[ml] < ip[ml]) {
+            *smaller_ptr = mi;
+            common_smaller = ml;
+            if (mi <= bt_low) { smaller_ptr = &dummy; break; }
+            smaller_ptr = next_ptr + 1;
+            mi = next_ptr[1];
+        } else {
+            *larger_ptr = mi;
+            common_larger = ml;
+            if (mi <= bt_low) { larger_ptr = &dummy; break; }
+            larger_ptr = next_ptr;
+            mi = next_ptr[0];
+        }
+    }
+    *smaller_ptr = *larger_ptr = 0;
+    {
+        uint32_t positions = 0;
+        if (best > 384) positions = (uint32_t)(best - 384) < 192u ? (uint32_t)(best - 384) : 192u;
+        return positions > match_end - (cur + 8) ? positions : match_end - (cur + 8);
+    }
+}
+static void bt_update_tree(hc_state *hc, const cpar *cp, const uint8_t *base, uint32_t target, const uint8_t *iend, int mls)
+{
+    uint32_t idx = hc->next_to_update;
+    while (idx < target) idx += bt_insert1(hc, cp, base, idx, iend, mls);
+    hc->next_to_update = target;
+}
+static uint32_t hash3_ptr(const uint8_t *p, int hlog) { return ((rd32(p) << 8) * 506832829u) >> (32 - hlog); }
+
+/* ZSTD_BtGetAllMatches + ZSTD_insertBtAndGetAllMatches: the repeat offsets, the 3-byte hash (minMatch 3), then the tree search
+ * that inserts the position; matches come out by increasing length */
+static uint32_t bt_get_all_matches(match_t *matches, hc_state *hc, const cpar *cp, const uint8_t *base, uint32_t *next3,
+                                   const uint8_t *ip, const uint8_t *iend, const uint32_t rep[3], uint32_t ll0,
+                                   uint32_t length_to_beat)
+{
+    const int mls = cp->mml;
+    const uint32_t cur = (uint32_t)(ip - base);
+    const uint32_t min_match = (mls == 3) ? 3 : 4;
+    const uint32_t sufficient = (uint32_t)cp->tlen < OPT_NUM - 1 ? (uint32_t)cp->tlen : OPT_NUM - 1;
+    uint32_t *const bt = hc->chain;
+    const uint32_t bt_mask = (1u << (cp->clog - 1)) - 1u;
+    uint32_t mnum = 0;
+    size_t best = length_to_beat - 1;
+    if (cur < hc->next_to_update) return 0; /* skipped area */
+    bt_update_tree(hc, cp, base, cur, iend, mls);
+    {
+        const uint32_t h = hash_ptr(ip, cp->hlog, mls);
+        uint32_t mi = hc->hash[h];
+        size_t common_smaller = 0, common_larger = 0;
+        const uint32_t bt_low = bt_mask >= cur ? 0 : cur - bt_mask;
+        const uint32_t max_dist = 1u << cp->wlog;
+        const uint32_t window_low = (cur - hc->low > max_dist) ? cur - max_dist : hc->low;
+        const uint32_t match_low = window_low ? window_low : 1;
+        uint32_t *smaller_ptr = bt + 2u * (cur & bt_mask);
+        uint32_t *larger_ptr = smaller_ptr + 1;
+        uint32_t match_end = cur + 8 + 1;
+        uint32_t dummy;
+        uint32_t nb = 1u << cp->slog;
+        uint32_t rc;
+        /* repeat offsets */
+        for (rc = ll0; rc < 3 + ll0; rc++) {
+            const uint32_t roff = (rc == 3) ? rep[0] - 1 : rep[rc];
+            const uint32_t rindex = cur - roff;
+            uint32_t rlen = 0;
+            if (roff - 1 < cur - hc->low) { /* discards 0 and anything reaching below the prefix start */
+                const uint32_t a = min_match == 3 ? rd32(ip) << 8 : rd32(ip);
+                const uint32_t b = min_match == 3 ? rd32(ip - roff) << 8 : rd32(ip - roff);
+                if (rindex >= window_low && a == b)
+                    rlen = (uint32_t)count_match(ip + min_match, ip + min_match - roff, iend) + min_match;
+            }
+            if (rlen > best) {
+                best = rlen;
+                matches[mnum].off = rc - ll0;
+                matches[mnum].len = rlen;
+                mnum++;
+                if (rlen > sufficient || ip + rlen == iend) return mnum;
+            }
+        }
+        /* 3-byte matches through their own hash table */
+        if (mls == 3 && best < 3) {
+            const uint32_t h3 = hash3_ptr(ip, hc->hlog3);
+            uint32_t idx = *next3, m3;
+            while (idx < cur) { hc->hash3[hash3_ptr(base + idx, hc->hlog3)] = idx; idx++; }
+            *next3 = cur;
+            m3 = hc->hash3[h3];
+            if (m3 >= match_low && cur - m3 < (1u << 18)) {
+                const size_t ml = count_match(ip, base + m3, iend);
+                if (ml >= 3) {
+                    best = ml;
+                    matches[0].off = (cur - m3) + REP_MOVE;
+                    matches[0].len = (uint32_t)ml;
+                    mnum = 1;
+                    if (ml > sufficient || ip + ml == iend) { hc->next_to_update = cur + 1; return 1; }
+                }
+            }
+        }
+        hc->hash[h] = cur;
+        while (nb-- && mi >= match_low) {
+            uint32_t *const next_ptr = bt + 2u * (mi & bt_mask);
+            size_t ml = common_smaller < common_larger ? common_smaller : common_larger;
+            const uint8_t *const match = base + mi;
+            ml += count_match(ip + ml, match + ml, iend);
+            if (ml > best) {
+                if (ml > match_end - mi) match_end = mi + (uint32_t)ml;
+                best = ml;
+                matches[mnum].off = (cur - mi) + REP_MOVE;
+                matches[mnum].len = (uint32_t)ml;
+                mnum++;
+                if (ml > OPT_NUM || ip + ml == iend) break;
+            }
+            if (match[ml] < ip[ml]) {
+                *smaller_ptr = mi;
+                common_smaller = ml;
+                if (mi <= bt_low) { smaller_ptr = &dummy; break; }
+                smaller_ptr = next_ptr + 1;
+                mi = next_ptr[1];
+            } else {
+                *larger_ptr = mi;
+                common_larger = ml;
+                if (mi <= bt_low) { larger_ptr = &dummy; break; }
+                larger_ptr = next_ptr;
+                mi = next_ptr[0];
+            }
+        }
+        *smaller_ptr = *larger_ptr = 0;
+        hc->next_to_update = match_end - 8;
+    }
+    return mnum;
+}
+
+static void opt_update_rep(uint32_t out[3], const uint32_t rep[3], uint32_t off, uint32_t ll0)
+{
+    if (off >= 3) { out[2] = rep[1]; out[1] = rep[0]; out[0] = off - REP_MOVE; }
+    else {
+        const uint32_t rc = off + ll0;
+        if (rc > 0) {
+            const uint32_t cur_off = (rc == 3) ? rep[0] - 1 : rep[rc];
+            const uint32_t r1 = rep[1], r0 = rep[0], r2 = rep[2];
+            out[2] = (rc >= 2) ? r1 : r2;
+            out[1] = r0;
+            out[0] = cur_off;
+        } else { out[0] = rep[0]; out[1] = rep[1]; out[2] = rep[2]; }
+    }
+}
+
+static size_t block_opt(hc_state *hc, const cpar *cp, opt_stats *o, const uint8_t *base, const uint8_t *istart, size_t n,
+                        uint32_t rep[3], seqstore *ss, int lvl)
+{
+    static opt_t opt[OPT_NUM + 2];
+    static match_t matches[OPT_NUM + 2];
+    const uint8_t *ip = istart, *anchor = istart;
+    const uint8_t *const iend = istart + n, *const ilimit = iend - 8;
+    const uint32_t sufficient = (uint32_t)cp->tlen < OPT_NUM - 1 ? (uint32_t)cp->tlen : OPT_NUM - 1;
+    const uint32_t min_match = (cp->mml == 3) ? 3 : 4;
+    uint32_t next3 = hc->next_to_update;
+    opt_t last_seq;
+    memset(&last_seq, 0, sizeof last_seq);
+    opt_rescale(o, istart, n, lvl);
+    ip += (ip == base + hc->low);
+    while (ip < ilimit) {
+        uint32_t cur, last_pos = 0;
+        {
+            const uint32_t litlen = (uint32_t)(ip - anchor);
+            const uint32_t ll0 = !litlen;
+            const uint32_t nbm = bt_get_all_matches(matches, hc, cp, base, &next3, ip, iend, rep, ll0, min_match);
+            if (!nbm) { ip++; continue; }
+            opt[0].rep[0] = rep[0]; opt[0].rep[1] = rep[1]; opt[0].rep[2] = rep[2];
+            opt[0].mlen = 0;
+            opt[0].litlen = litlen;
+            opt[0].price = (int)opt_ll_price(o, litlen, lvl);
+            {
+                const uint32_t max_ml = matches[nbm - 1].len, max_off = matches[nbm - 1].off;
+                if (max_ml > sufficient) {
+                    last_seq.litlen = litlen; last_seq.mlen = max_ml; last_seq.off = max_off;
+                    cur = 0;
+                    last_pos = litlen + max_ml;
+                    goto shortest_path;
+                }
+            }
+            {
+                const uint32_t lit_price = (uint32_t)opt[0].price + opt_ll_price(o, 0, lvl);
+                uint32_t pos, k;
+                for (pos = 1; pos < min_match; pos++) opt[pos].price = OPT_MAX_PRICE;
+                for (k = 0; k < nbm; k++) {
+                    const uint32_t off = matches[k].off, end = matches[k].len;
+                    for (; pos <= end; pos++) {
+                        opt[pos].mlen = pos; opt[pos].off = off; opt[pos].litlen = litlen;
+                        opt[pos].price = (int)(lit_price + opt_match_price(o, off, pos, lvl));
+                    }
+                }
+                last_pos = pos - 1;
+            }
+        }
+        for (cur = 1; cur <= last_pos; cur++) {
+            const uint8_t *const inr = ip + cur;
+            {
+                const uint32_t litlen = (opt[cur - 1].mlen == 0) ? opt[cur - 1].litlen + 1 : 1;
+                const int price = opt[cur - 1].price + (int)opt_lit_cost1(o, ip[cur - 1], lvl) + (int)opt_ll_price(o, litlen, lvl)
+                                  - (int)opt_ll_price(o, litlen - 1, lvl);
+                if (price <= opt[cur].price) {
+                    opt[cur].mlen = 0; opt[cur].off = 0; opt[cur].litlen = litlen; opt[cur].price = price;
+                }
+            }
+            if (opt[cur].mlen != 0) {
+                const uint32_t prev = cur - opt[cur].mlen;
+                opt_update_rep(opt[cur].rep, opt[prev].rep, opt[cur].off, opt[cur].litlen == 0);
+            } else
+                memcpy(opt[cur].rep, opt[cur - 1].rep, sizeof opt[cur].rep);
+            if (inr > ilimit) continue; /* the last match starts at least 8 bytes before the end */
+            if (cur == last_pos) break;
+            if (lvl == 0 && opt[cur + 1].price <= opt[cur].price + (int)(BITCOST / 2)) continue; /* btopt skips unpromising positions */
+            {
+                const uint32_t ll0 = (opt[cur].mlen != 0);
+                const uint32_t litlen = (opt[cur].mlen == 0) ? opt[cur].litlen : 0;
+                const uint32_t base_price = (uint32_t)opt[cur].price + opt_ll_price(o, 0, lvl);
+                const uint32_t nbm = bt_get_all_matches(matches, hc, cp, base, &next3, inr, iend, opt[cur].rep, ll0, min_match);
+                uint32_t k;
+                if (!nbm) continue;
+                {
+                    const uint32_t max_ml = matches[nbm - 1].len;
+                    if (max_ml > sufficient || cur + max_ml >= OPT_NUM) {
+                        last_seq.mlen = max_ml; last_seq.off = matches[nbm - 1].off; last_seq.litlen = litlen;
+                        cur -= (opt[cur].mlen == 0) ? opt[cur].litlen : 0; /* may wrap: then it is the first sequence */
+                        last_pos = cur + last_seq.litlen + last_seq.mlen;
+                        if (cur > OPT_NUM) cur = 0;
+                        goto shortest_path;
+                    }
+                }
+                for (k = 0; k < nbm; k++) {
+                    const uint32_t off = matches[k].off, last_ml = matches[k].len;
+                    const uint32_t start_ml = k > 0 ? matches[k - 1].len + 1 : min_match;
+                    uint32_t mlen;
+                    for (mlen = last_ml; mlen >= start_ml; mlen--) {
+                        const uint32_t pos = cur + mlen;
+                        const int price = (int)(base_price + opt_match_price(o, off, mlen, lvl));
+                        if (pos > last_pos || price < opt[pos].price) {
+                            while (last_pos < pos) { opt[last_pos + 1].price = OPT_MAX_PRICE; last_pos++; }
+                            opt[pos].mlen = mlen; opt[pos].off = off; opt[pos].litlen = litlen; opt[pos].price = price;
+                        } else if (lvl == 0)
+                            break; /* btopt: early abort of the downward scan */
+                    }
+                }
+            }
+        }
+        last_seq = opt[last_pos];
+        cur = last_pos > last_seq.litlen + last_seq.mlen ? last_pos - (last_seq.litlen + last_seq.mlen) : 0;
+    shortest_path:
+        if (last_seq.mlen != 0) {
+            uint32_t r[3];
+            opt_update_rep(r, opt[cur].rep, last_seq.off, last_seq.litlen == 0);
+            rep[0] = r[0]; rep[1] = r[1]; rep[2] = r[2];
+        } else { rep[0] = opt[cur].rep[0]; rep[1] = opt[cur].rep[1]; rep[2] = opt[cur].rep[2]; }
+        {
+            const uint32_t store_end = cur + 1;
+            uint32_t store_start = store_end, seq_pos = cur, sp;
+            opt[store_end] = last_seq;
+            while (seq_pos > 0) {
+                const uint32_t back = opt[seq_pos].litlen + opt[seq_pos].mlen;
+                store_start--;
+                opt[store_start] = opt[seq_pos];
+                seq_pos = (seq_pos > back) ? seq_pos - back : 0;
+            }
+            for (sp = store_start; sp <= store_end; sp++) {
+                const uint32_t llen = opt[sp].litlen, mlen = opt[sp].mlen, offcode = opt[sp].off;
+                if (mlen == 0) { ip = anchor + llen; continue; } /* only literals: the last entry, starts the next stretch */
+                opt_update_stats(o, llen, anchor, offcode, mlen);
+                store_seq(ss, llen, anchor, offcode, mlen - MINMATCH);
+                anchor += llen + mlen;
+                ip = anchor;
+            }
+            opt_set_base(o, lvl);
+        }
+    }
+    return (size_t)(iend - anchor);
+}
+
 /* ------------------------------------------------------------ parameters (ZSTD_getCParams) */
 static int get_cpar(int level, size_t n, cpar *cp)
 {
@@ -1326,24 +1738,24 @@ static int get_cpar(int level, size_t n, cpar *cp)
      * searchLog, minMatch, targetLength, strategy (1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2, 6 btlazy2; 7 and up: the
      * optimal-parser strategies, not restated).  Rows 13 .. 15 exist for sources above 256 KiB only (btlazy2 there; btopt and up
      * in the other classes).  Dumped from ZSTD_getCParams and checked against it by the tests. */
-    static const int kCParTab[4][16][7] = {
-        {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2}, {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}, {21, 19, 19, 3, 5, 8, 4}, {21, 19, 19, 3, 5, 16, 5}, {21, 19, 20, 4, 5, 16, 5}, {22, 20, 21, 4, 5, 16, 5}, {22, 21, 22, 4, 5, 16, 5}, {22, 21, 22, 5, 5, 16, 5}, {22, 21, 22, 5, 5, 32, 6}, {22, 22, 23, 5, 5, 32, 6}, {22, 23, 23, 6, 5, 32, 6}},
-        {{18, 12, 13, 1, 5, 1, 1}, {18, 13, 14, 1, 6, 0, 1}, {18, 14, 14, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {18, 16, 17, 2, 5, 2, 3}, {18, 18, 18, 3, 5, 2, 3}, {18, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 4, 4, 4, 4}, {18, 18, 19, 4, 4, 8, 5}, {18, 18, 19, 5, 4, 8, 5}, {18, 18, 19, 6, 4, 8, 5}, {18, 18, 19, 5, 4, 12, 6}, {18, 19, 19, 7, 4, 12, 6}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}},
-        {{17, 12, 12, 1, 5, 1, 1}, {17, 12, 13, 1, 6, 0, 1}, {17, 13, 15, 1, 5, 0, 1}, {17, 15, 16, 2, 5, 0, 2}, {17, 17, 17, 2, 4, 0, 2}, {17, 16, 17, 3, 4, 2, 3}, {17, 17, 17, 3, 4, 4, 4}, {17, 17, 17, 3, 4, 8, 5}, {17, 17, 17, 4, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 5}, {17, 17, 17, 6, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 6}, {17, 18, 17, 7, 4, 12, 6}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}},
-        {{14, 12, 13, 1, 5, 1, 1}, {14, 14, 15, 1, 5, 0, 1}, {14, 14, 15, 1, 4, 0, 1}, {14, 14, 15, 2, 4, 0, 2}, {14, 14, 14, 4, 4, 2, 3}, {14, 14, 14, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}, {14, 14, 14, 6, 4, 8, 5}, {14, 14, 14, 8, 4, 8, 5}, {14, 15, 14, 5, 4, 8, 6}, {14, 15, 14, 9, 4, 8, 6}, {14, 15, 14, 3, 4, 12, 7}, {14, 15, 14, 4, 3, 24, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}}};
+    static const int kCParTab[4][23][7] = {
+        {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2}, {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}, {21, 19, 19, 3, 5, 8, 4}, {21, 19, 19, 3, 5, 16, 5}, {21, 19, 20, 4, 5, 16, 5}, {22, 20, 21, 4, 5, 16, 5}, {22, 21, 22, 4, 5, 16, 5}, {22, 21, 22, 5, 5, 16, 5}, {22, 21, 22, 5, 5, 32, 6}, {22, 22, 23, 5, 5, 32, 6}, {22, 23, 23, 6, 5, 32, 6}, {22, 22, 22, 5, 5, 48, 7}, {23, 23, 22, 5, 4, 64, 7}, {23, 23, 22, 6, 3, 64, 8}, {23, 24, 22, 7, 3, 256, 9}, {25, 25, 23, 7, 3, 256, 9}, {26, 26, 24, 7, 3, 512, 9}, {27, 27, 25, 9, 3, 999, 9}},
+        {{18, 12, 13, 1, 5, 1, 1}, {18, 13, 14, 1, 6, 0, 1}, {18, 14, 14, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {18, 16, 17, 2, 5, 2, 3}, {18, 18, 18, 3, 5, 2, 3}, {18, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 4, 4, 4, 4}, {18, 18, 19, 4, 4, 8, 5}, {18, 18, 19, 5, 4, 8, 5}, {18, 18, 19, 6, 4, 8, 5}, {18, 18, 19, 5, 4, 12, 6}, {18, 19, 19, 7, 4, 12, 6}, {18, 18, 19, 4, 4, 16, 7}, {18, 18, 19, 4, 3, 32, 7}, {18, 18, 19, 6, 3, 128, 7}, {18, 19, 19, 6, 3, 128, 8}, {18, 19, 19, 8, 3, 256, 8}, {18, 19, 19, 6, 3, 128, 9}, {18, 19, 19, 8, 3, 256, 9}, {18, 19, 19, 10, 3, 512, 9}, {18, 19, 19, 12, 3, 512, 9}, {18, 19, 19, 13, 3, 999, 9}},
+        {{17, 12, 12, 1, 5, 1, 1}, {17, 12, 13, 1, 6, 0, 1}, {17, 13, 15, 1, 5, 0, 1}, {17, 15, 16, 2, 5, 0, 2}, {17, 17, 17, 2, 4, 0, 2}, {17, 16, 17, 3, 4, 2, 3}, {17, 17, 17, 3, 4, 4, 4}, {17, 17, 17, 3, 4, 8, 5}, {17, 17, 17, 4, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 5}, {17, 17, 17, 6, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 6}, {17, 18, 17, 7, 4, 12, 6}, {17, 18, 17, 3, 4, 12, 7}, {17, 18, 17, 4, 3, 32, 7}, {17, 18, 17, 6, 3, 256, 7}, {17, 18, 17, 6, 3, 128, 8}, {17, 18, 17, 8, 3, 256, 8}, {17, 18, 17, 10, 3, 512, 8}, {17, 18, 17, 5, 3, 256, 9}, {17, 18, 17, 7, 3, 512, 9}, {17, 18, 17, 9, 3, 512, 9}, {17, 18, 17, 11, 3, 999, 9}},
+        {{14, 12, 13, 1, 5, 1, 1}, {14, 14, 15, 1, 5, 0, 1}, {14, 14, 15, 1, 4, 0, 1}, {14, 14, 15, 2, 4, 0, 2}, {14, 14, 14, 4, 4, 2, 3}, {14, 14, 14, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}, {14, 14, 14, 6, 4, 8, 5}, {14, 14, 14, 8, 4, 8, 5}, {14, 15, 14, 5, 4, 8, 6}, {14, 15, 14, 9, 4, 8, 6}, {14, 15, 14, 3, 4, 12, 7}, {14, 15, 14, 4, 3, 24, 7}, {14, 15, 14, 5, 3, 32, 8}, {14, 15, 15, 6, 3, 64, 8}, {14, 15, 15, 7, 3, 256, 8}, {14, 15, 15, 5, 3, 48, 9}, {14, 15, 15, 6, 3, 128, 9}, {14, 15, 15, 7, 3, 256, 9}, {14, 15, 15, 8, 3, 256, 9}, {14, 15, 15, 8, 3, 512, 9}, {14, 15, 15, 9, 3, 512, 9}, {14, 15, 15, 10, 3, 999, 9}}};
     const int (*t)[7];
     int row, srclog, strat;
     if (level == 0) level = 3;
-    if (level > 15 || level < -131072) return -1; /* higher levels: btopt and up at every size, not restated */
+    if (level > 22 || level < -131072) return -1;
     t = kCParTab[n > 256u * 1024u ? 0 : (n > 128u * 1024u ? 1 : (n > 16u * 1024u ? 2 : 3))];
-    if (t[level < 0 ? 0 : level][6] > 6) return -1; /* an optimal-parser strategy */
     row = level < 0 ? 0 : level;
     cp->wlog = t[row][0]; cp->clog = t[row][1]; cp->hlog = t[row][2]; cp->slog = t[row][3]; cp->mml = t[row][4];
     cp->tlen = level < 0 ? -level : t[row][5];
     strat = t[row][6];
     cp->dfast = strat == 2;
-    cp->bt = strat == 6;
-    cp->lazy_depth = strat == 6 ? 2 : (strat >= 3 ? strat - 3 : -1);
+    cp->bt = strat >= 6;
+    cp->opt = strat >= 7 ? strat - 6 : 0;
+    cp->lazy_depth = strat >= 7 ? -1 : (strat == 6 ? 2 : (strat >= 3 ? strat - 3 : -1));
     /* ZSTD_adjustCParams_internal: shrink the window (and hash, chain) to the source size */
     srclog = (n < 64) ? 6 : hb((uint32_t)(n - 1)) + 1;
     if (cp->wlog > srclog) cp->wlog = srclog;
@@ -1358,6 +1770,8 @@ static int get_cpar(int level, size_t n, cpar *cp)
 size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int level)
 {
     static uint32_t table[1 << 21], tshort[1 << 21]; /* hash (long) table; short table / chain table / binary tree */
+    static uint32_t table3[1 << 17];                 /* ZSTD_HASHLOG3_MAX */
+    static opt_stats ostats;
     hc_state hc;
     static seq_t seqs[ZBLOCK_MAX / 3 + 8];
     static uint8_t lits[ZBLOCK_MAX + 8];
@@ -1365,7 +1779,7 @@ size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, siz
     size_t op = 0, ip = 0;
     uint32_t rep[3] = {1, 4, 8};
     uint32_t dict_limit = 1;
-    const uint8_t *base = src - 1;
+    const uint8_t *base = src - 1; /* moves once for btultra2 (below) */
     int first = 1;
     static huf_state hprev, hnext;
     static fse_state fprev, fnext;
@@ -1373,9 +1787,12 @@ size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, siz
     fprev.rep_ll = fprev.rep_of = fprev.rep_ml = 0;
     if (get_cpar(level, n, &cp) || cap < cryo_oracle_zstd_bound(n)) return 0;
     memset(table, 0, sizeof(uint32_t) << cp.hlog);
-    if (cp.dfast || cp.lazy_depth >= 0) memset(tshort, 0, sizeof(uint32_t) << cp.clog);
-    g_strategy = cp.bt ? 6 : (cp.lazy_depth >= 0 ? 3 + cp.lazy_depth : (cp.dfast ? 2 : 1));
+    if (cp.dfast || cp.lazy_depth >= 0 || cp.opt) memset(tshort, 0, sizeof(uint32_t) << cp.clog);
+    g_strategy = cp.bt ? 6 + cp.opt : (cp.lazy_depth >= 0 ? 3 + cp.lazy_depth : (cp.dfast ? 2 : 1));
     hc.hash = table; hc.chain = tshort; hc.next_to_update = 1;
+    hc.hash3 = table3; hc.hlog3 = cp.wlog < 17 ? cp.wlog : 17; hc.low = 1;
+    if (cp.opt && cp.mml == 3) memset(table3, 0, sizeof(uint32_t) << hc.hlog3);
+    ostats.ll_sum = 0; /* ZSTD_reset_matchState: a frame starts without statistics */
     /* frame header: content size always, no checksum, no dictionary id */
     {
         const uint64_t wsize = 1ull << cp.wlog;
@@ -1404,13 +1821,33 @@ size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, siz
             size_t last_ll;
             ss.seqs = seqs; ss.nseq = 0; ss.lits = lits; ss.nlit = 0; ss.long_pos = 0; ss.long_kind = 0;
             nrep[0] = rep[0]; nrep[1] = rep[1]; nrep[2] = rep[2];
-            if (cp.lazy_depth >= 0) {
+            if (cp.lazy_depth >= 0 || cp.opt) {
                 /* ZSTD_buildSeqStore: limited catch-up after a very long match */
-                const uint32_t cur = (uint32_t)(ip + 1);
+                const uint32_t cur = (uint32_t)(src + ip - base);
                 if (cur > hc.next_to_update + 384u) {
                     const uint32_t d = cur - hc.next_to_update - 384u;
                     hc.next_to_update = cur - (d < 192u ? d : 192u);
                 }
+            }
+            if (cp.opt) {
+                if (cp.opt == 3 && ostats.ll_sum == 0 && ip == 0 && bs > 1024) {
+                    /* ZSTD_compressBlock_btultra2 -> ZSTD_initStats_ultra: the first block of a frame is parsed twice.  The
+                     * first pass only collects statistics; it is then forgotten by moving the window base, so that every
+                     * index it left in the tables lies below the lowest valid one */
+                    uint32_t trep[3];
+                    trep[0] = rep[0]; trep[1] = rep[1]; trep[2] = rep[2];
+                    block_opt(&hc, &cp, &ostats, base, src + ip, bs, trep, &ss, 2);
+                    ss.nseq = 0; ss.nlit = 0; ss.long_pos = 0; ss.long_kind = 0;
+                    base -= bs;
+                    hc.low += (uint32_t)bs;
+                    hc.next_to_update = hc.low;
+                    ostats.lit_sum = opt_upscale(ostats.lit, 255);
+                    ostats.ll_sum = opt_upscale(ostats.ll, MaxLL);
+                    ostats.ml_sum = opt_upscale(ostats.ml, MaxML);
+                    ostats.of_sum = opt_upscale(ostats.of, MaxOff);
+                }
+                last_ll = block_opt(&hc, &cp, &ostats, base, src + ip, bs, nrep, &ss, cp.opt == 1 ? 0 : 2);
+            } else if (cp.lazy_depth >= 0) {
                 last_ll = block_lazy(&hc, &cp, base, src + ip, bs, nrep, &ss);
             } else
                 last_ll = cp.dfast ? block_dfast(table, tshort, &cp, base, src + ip, bs, nrep, &ss, dict_limit)
@@ -1418,7 +1855,7 @@ size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, siz
             memcpy(lits + ss.nlit, src + ip + bs - last_ll, last_ll);
             ss.nlit += last_ll;
             csize = compress_sequences(dst + op + 3, seqs, ss.nseq, lits, ss.nlit, bs, ss.long_pos, ss.long_kind, &hprev, &hnext,
-                                       &fprev, &fnext, cp.lazy_depth < 0 && !cp.dfast && cp.tlen > 0);
+                                       &fprev, &fnext, cp.lazy_depth < 0 && !cp.dfast && !cp.opt && cp.tlen > 0);
             if (!first && csize < 25) { /* RLE block for constant non-first blocks */
                 size_t k = 1;
                 while (k < bs && src[ip + k] == src[ip]) k++;

@@ -271,15 +271,20 @@ def test_zstd_encoder_oracle_vs_live_libzstd(oracle, B):
                 assert r == B and np.array_equal(out, raw)
 
 
-# every size class of libzstd's parameter tables (<= 16 KiB, <= 128 KiB, <= 256 KiB, above) and every level whose
-# strategy is not a binary-tree one there: -5 .. 8 up to 16 KiB, .. 10 up to 256 KiB, .. 12 above (round 3)
+# every size class of libzstd's parameter tables (<= 16 KiB, <= 128 KiB, <= 256 KiB, above) and every level: the strategies
+# fast .. btlazy2 (round 3: -5 .. 10 up to 16 KiB, .. 12 up to 256 KiB, .. 15 above) and the optimal-parser strategies
+# btopt / btultra / btultra2 above them, up to level 22
 ZSTD_CLASS_SIZES = [64, 1000, 4096, 16384, 16385, 131073, 200000, 262144, 262145, 1 << 20]
 
 
-def zstd_levels_with_kernel(B):
+def zstd_levels_below_btopt(B):
     """levels whose strategy is `fast` .. `btlazy2` at this source size: -5 .. 10 up to 16 KiB, .. 12 up to 256 KiB, .. 15 above
     (the next level is `btopt`)"""
     return list(range(-5, 11 if B <= 16384 else (13 if B <= 262144 else 16)))
+
+
+def zstd_levels_with_kernel(B):
+    return zstd_levels_below_btopt(B)
 
 
 @pytest.mark.parametrize("B", ZSTD_CLASS_SIZES)
@@ -290,18 +295,39 @@ def test_zstd_encoder_oracle_size_classes_vs_live_libzstd(oracle, B):
         pytest.skip("libzstd.so.1 not loadable")
     rng = np.random.default_rng(B)
     blocks = [make_block(rng, B), oracle.synth(6, 3, B, 0) if B >= 4096 else rng.integers(0, 4, B, dtype=np.uint8)]
-    for lvl in zstd_levels_with_kernel(B):
+    levels = zstd_levels_below_btopt(B)
+    top = levels[-1]
+    # the optimal-parser levels: all of them on the small sizes; on the large ones the first of each strategy and the last
+    levels += list(range(top + 1, 23)) if B <= 16385 else sorted({top + 1, 16, 17, 18, 19, 22})
+    for lvl in levels:
         for raw in blocks:
             exp = stock.zstd_compress(raw, lvl)
             got = oracle.zstd_compress(raw, lvl)
             assert np.array_equal(got, exp), (B, lvl, len(got), len(exp))
-    assert len(oracle.zstd_compress(blocks[0], zstd_levels_with_kernel(B)[-1] + 1)) == 0   # the first optimal-parser level of the class
+
+
+@pytest.mark.parametrize("B", [131072, 20000, 1500])
+def test_zstd_encoder_oracle_optimal_parser_vs_live_libzstd(oracle, B):
+    """btopt, btultra and btultra2 (the latter parses the first block of a frame twice) on the five distributions: the
+    restatement of zstd_opt.c equals libzstd 1.4.8 byte for byte, and decodes"""
+    stock = oracle_lib.StockLibs()
+    if stock.zstd is None:
+        pytest.skip("libzstd.so.1 not loadable")
+    for dist in range(5):
+        raw = oracle.synth(6, 9, B, dist)
+        for lvl in range(11 if B <= 16384 else 13, 23):
+            exp = stock.zstd_compress(raw, lvl)
+            got = oracle.zstd_compress(raw, lvl)
+            assert np.array_equal(got, exp), (B, dist, lvl, len(got), len(exp))
+        r, out = oracle.zstd_decompress(got, B)
+        assert r == B and np.array_equal(out, raw)
 
 
 def test_zstd_encoder_oracle_unsupported_levels_return_empty(oracle):
     raw = oracle.synth(0, 0, 131072, 1)
-    assert len(oracle.zstd_compress(raw, 13)) == 0     # btopt and up (from level 13 on at 128 KiB): not restated
-    assert len(oracle.zstd_compress(raw, 22)) == 0
+    assert len(oracle.zstd_compress(raw, 23)) == 0     # above ZSTD_maxCLevel
+    big = np.zeros((1 << 21) + 1, dtype=np.uint8)
+    assert len(oracle.zstd_compress(big, 19)) == 0     # tables beyond 2^21 entries (sources above 2 MiB at the deep levels)
 
 
 def test_zstd_oracle_huffman_log12_crafted(oracle):
