@@ -682,7 +682,7 @@ __device__ uint32_t compress_literals(EncLds &L, uint8_t *dst, const uint8_t *sr
         }
     }
     zprof(hs, 5);
-    const uint32_t gain = (n >> 6) + 2u;
+    const uint32_t gain = (n >> (hs.strat >= 8u ? hs.strat - 1u : 6u)) + 2u; /* ZSTD_minGain: btultra, btultra2 accept smaller gains */
     if (c == 0u || c >= n - gain) { hs.next_new = false; return raw(); }
     if (c == 1u) {
         hs.next_new = false;
@@ -879,7 +879,7 @@ __device__ uint32_t compress_sequences(EncLds &L, uint8_t *dst, uint8_t *ws, uin
         else { dst[op] = 0xFF; dst[op + 1] = (uint8_t)(nseq - 0x7F00u); dst[op + 2] = (uint8_t)((nseq - 0x7F00u) >> 8); }
     }
     op += nseq < 128u ? 1u : (nseq < 0x7F00u ? 2u : 3u);
-    const uint32_t gain = (src_size >> 6) + 2u;
+    const uint32_t gain = (src_size >> (hs.strat >= 8u ? hs.strat - 1u : 6u)) + 2u;
     if (nseq == 0u) return (op >= src_size - gain) ? 0u : op;
     const uint32_t seq_head = op++;
     for (uint32_t i = lane; i < nseq; i += 64u) {
@@ -1102,6 +1102,7 @@ __device__ uint32_t block_fast(uint32_t *table, const CPar &cp, const uint8_t *b
 
 #include "zstd_dfast.h"
 #include "zstd_lazy.h"
+#include "zstd_opt.h"
 
 } // namespace
 
@@ -1110,7 +1111,7 @@ __device__ uint32_t block_fast(uint32_t *table, const CPar &cp, const uint8_t *b
  * iterations per step (block_fast_gbatch); 1 = `dfast` (block_dfast_batch); 2 = `fast`, the serial walk
  * (block_fast: the plain restatement, CRYO_ZSTD_ENC=1); 3 = `greedy` (block_greedy: hash table, then chain table;
  * `width` carries searchLog). */
-template <bool PROF> /* PROF: CRYO_ZSTD_STATS counters */
+template <bool PROF, bool OPT> /* PROF: CRYO_ZSTD_STATS counters; OPT: the optimal-parser strategies (finder 7 btopt, 8 btultra, 9 btultra2) */
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t n_blocks,
            uint8_t *__restrict__ dst_base, uint64_t dst_stride, int wlog, int hlog, int clog, int mml, int tlen,
@@ -1125,17 +1126,23 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *ws = workspace + (uint64_t)blockIdx.x * ws_stride;
     CPar cp;
-    cp.wlog = wlog; cp.clog = clog; cp.hlog = hlog; cp.slog = (int)width; cp.mml = mml; cp.tlen = tlen; cp.bt = finder == 6 ? 1 : 0;
+    cp.wlog = wlog; cp.clog = clog; cp.hlog = hlog; cp.slog = (int)width; cp.mml = mml; cp.tlen = tlen; cp.bt = finder >= 6 ? 1 : 0;
     const bool dfast = finder == 1;
     const bool two_tables = finder == 1 || finder >= 3;
     uint32_t *table = reinterpret_cast<uint32_t *>(ws + kWsBytes);
     uint32_t *tshort = table + (1u << hlog); /* dfast only */
+    /* optimal parser: the 3-byte hash table (minMatch 3), the price table, the match ladder, the statistics between blocks */
+    const int hlog3 = (OPT && mml == 3) ? (wlog < 17 ? wlog : 17) : 0;
+    uint32_t *table3 = tshort + (1u << clog);
+    OptT *opt_tab = reinterpret_cast<OptT *>(table3 + (hlog3 ? 1u << hlog3 : 0u));
+    uint2 *opt_matches = reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(opt_tab) + kOptTabBytes);
+    uint32_t *opt_saved = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(opt_matches) + kOptMatchBytes);
 
     for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         const uint8_t *src = src_base + blk * src_stride;
         uint8_t *dst = dst_base + blk * dst_stride;
         {
-            const uint32_t quads = ((1u << hlog) + (two_tables ? 1u << clog : 0u)) / 4u;
+            const uint32_t quads = ((1u << hlog) + (two_tables ? 1u << clog : 0u) + (hlog3 ? 1u << hlog3 : 0u)) / 4u;
             for (uint32_t i = lane; i < quads; i += 64u) reinterpret_cast<uint4 *>(table)[i] = make_uint4(0, 0, 0, 0);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1157,11 +1164,15 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         }
         uint32_t rep[3] = {1, 4, 8};
         uint32_t dict_limit = 1;
-        const uint8_t *base = src - 1;
+        const uint8_t *base = src - 1; /* moves once for btultra2 (below) */
         bool first = true;
+        OptStats ost;
+        ost.f = reinterpret_cast<uint32_t *>(&L);
+        ost.lit_sum = ost.ll_sum = ost.ml_sum = ost.of_sum = 0; /* a frame starts without statistics */
+        ost.lit_base = ost.ll_base = ost.ml_base = ost.of_base = 0; ost.predef = false;
         HufState hs;
         hs.prev_valid = false; hs.next_new = false; hs.prof = PROF ? stats : nullptr; hs.t = 0; hs.strat = finder >= 3 ? (uint32_t)finder : (dfast ? 2u : 1u);
-        HcState hc = {table, tshort, 1u};
+        HcState hc = {table, tshort, 1u, table3, hlog3, 1u};
         SeqTabs tb;
         tb.prev = reinterpret_cast<FseCt *>(ws + kWsTabs);
         tb.rep[0] = tb.rep[1] = tb.rep[2] = 0;
@@ -1178,7 +1189,36 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 uint32_t nrep[3] = {rep[0], rep[1], rep[2]};
                 if constexpr (PROF) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_other += t - t_prev; t_prev = t; }
                 uint32_t last_ll;
-                if (finder == 1) last_ll = block_dfast_batch<PROF>(table, tshort, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, width, stats);
+                if constexpr (OPT) {
+                    const uint32_t cur = (uint32_t)(src + ip - base); /* ZSTD_buildSeqStore: limited catch-up after a very long match */
+                    if (cur > hc.next_to_update + 384u) {
+                        const uint32_t d = cur - hc.next_to_update - 384u;
+                        hc.next_to_update = cur - (d < 192u ? d : 192u);
+                    }
+                    if (!first) { /* the statistics of the previous blocks come back into LDS */
+                        for (uint32_t i = lane; i < kOsWords; i += 64u) ost.f[i] = opt_saved[i];
+                        lds_sync();
+                    }
+                    if (finder == 9 && first && bs > 1024u) {
+                        /* ZSTD_compressBlock_btultra2 -> ZSTD_initStats_ultra: the first block of a frame is parsed twice.  The
+                         * first pass only collects statistics; it is then forgotten by moving the window base, so that every
+                         * index it left in the tables lies below the lowest valid one */
+                        uint32_t trep[3] = {rep[0], rep[1], rep[2]};
+                        (void)block_opt(hc, cp, ost, opt_tab, opt_matches, base, src + ip, bs, trep, ws, ss, 2, lane);
+                        ss.nseq = 0; ss.nlit = 0; ss.long_pos = 0; ss.long_kind = 0;
+                        base -= bs;
+                        hc.low += bs;
+                        hc.next_to_update = hc.low;
+                        ost.lit_sum = opt_upscale(ost.f + kOsLit, 255u, lane);
+                        ost.ll_sum = opt_upscale(ost.f + kOsLL, kMaxLL, lane);
+                        ost.ml_sum = opt_upscale(ost.f + kOsML, kMaxML, lane);
+                        ost.of_sum = opt_upscale(ost.f + kOsOF, kMaxOff, lane);
+                    }
+                    last_ll = block_opt(hc, cp, ost, opt_tab, opt_matches, base, src + ip, bs, nrep, ws, ss, finder == 7 ? 0 : 2, lane);
+                    for (uint32_t i = lane; i < kOsWords; i += 64u) opt_saved[i] = ost.f[i];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                }
+                else if (finder == 1) last_ll = block_dfast_batch<PROF>(table, tshort, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, width, stats);
                 else if (finder >= 3) {
                     const uint32_t cur = ip + 1u; /* ZSTD_buildSeqStore: limited catch-up after a very long match */
                     if (cur > hc.next_to_update + 384u) {
@@ -1254,16 +1294,15 @@ static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *
      * searchLog, minMatch, targetLength, strategy (1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2, 6 btlazy2; 7 and up: the
      * optimal-parser strategies, no kernel); rows 13 .. 15 for sources above 256 KiB only.  Dumped from ZSTD_getCParams and
      * checked against it by the tests. */
-    static const int kCParTab[4][16][7] = {
-        {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2}, {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}, {21, 19, 19, 3, 5, 8, 4}, {21, 19, 19, 3, 5, 16, 5}, {21, 19, 20, 4, 5, 16, 5}, {22, 20, 21, 4, 5, 16, 5}, {22, 21, 22, 4, 5, 16, 5}, {22, 21, 22, 5, 5, 16, 5}, {22, 21, 22, 5, 5, 32, 6}, {22, 22, 23, 5, 5, 32, 6}, {22, 23, 23, 6, 5, 32, 6}},
-        {{18, 12, 13, 1, 5, 1, 1}, {18, 13, 14, 1, 6, 0, 1}, {18, 14, 14, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {18, 16, 17, 2, 5, 2, 3}, {18, 18, 18, 3, 5, 2, 3}, {18, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 4, 4, 4, 4}, {18, 18, 19, 4, 4, 8, 5}, {18, 18, 19, 5, 4, 8, 5}, {18, 18, 19, 6, 4, 8, 5}, {18, 18, 19, 5, 4, 12, 6}, {18, 19, 19, 7, 4, 12, 6}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}},
-        {{17, 12, 12, 1, 5, 1, 1}, {17, 12, 13, 1, 6, 0, 1}, {17, 13, 15, 1, 5, 0, 1}, {17, 15, 16, 2, 5, 0, 2}, {17, 17, 17, 2, 4, 0, 2}, {17, 16, 17, 3, 4, 2, 3}, {17, 17, 17, 3, 4, 4, 4}, {17, 17, 17, 3, 4, 8, 5}, {17, 17, 17, 4, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 5}, {17, 17, 17, 6, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 6}, {17, 18, 17, 7, 4, 12, 6}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}},
-        {{14, 12, 13, 1, 5, 1, 1}, {14, 14, 15, 1, 5, 0, 1}, {14, 14, 15, 1, 4, 0, 1}, {14, 14, 15, 2, 4, 0, 2}, {14, 14, 14, 4, 4, 2, 3}, {14, 14, 14, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}, {14, 14, 14, 6, 4, 8, 5}, {14, 14, 14, 8, 4, 8, 5}, {14, 15, 14, 5, 4, 8, 6}, {14, 15, 14, 9, 4, 8, 6}, {14, 15, 14, 3, 4, 12, 7}, {14, 15, 14, 4, 3, 24, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}, {0, 0, 0, 0, 0, 0, 7}}};
+    static const int kCParTab[4][23][7] = {
+        {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2}, {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}, {21, 19, 19, 3, 5, 8, 4}, {21, 19, 19, 3, 5, 16, 5}, {21, 19, 20, 4, 5, 16, 5}, {22, 20, 21, 4, 5, 16, 5}, {22, 21, 22, 4, 5, 16, 5}, {22, 21, 22, 5, 5, 16, 5}, {22, 21, 22, 5, 5, 32, 6}, {22, 22, 23, 5, 5, 32, 6}, {22, 23, 23, 6, 5, 32, 6}, {22, 22, 22, 5, 5, 48, 7}, {23, 23, 22, 5, 4, 64, 7}, {23, 23, 22, 6, 3, 64, 8}, {23, 24, 22, 7, 3, 256, 9}, {25, 25, 23, 7, 3, 256, 9}, {26, 26, 24, 7, 3, 512, 9}, {27, 27, 25, 9, 3, 999, 9}},
+        {{18, 12, 13, 1, 5, 1, 1}, {18, 13, 14, 1, 6, 0, 1}, {18, 14, 14, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {18, 16, 17, 2, 5, 2, 3}, {18, 18, 18, 3, 5, 2, 3}, {18, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 4, 4, 4, 4}, {18, 18, 19, 4, 4, 8, 5}, {18, 18, 19, 5, 4, 8, 5}, {18, 18, 19, 6, 4, 8, 5}, {18, 18, 19, 5, 4, 12, 6}, {18, 19, 19, 7, 4, 12, 6}, {18, 18, 19, 4, 4, 16, 7}, {18, 18, 19, 4, 3, 32, 7}, {18, 18, 19, 6, 3, 128, 7}, {18, 19, 19, 6, 3, 128, 8}, {18, 19, 19, 8, 3, 256, 8}, {18, 19, 19, 6, 3, 128, 9}, {18, 19, 19, 8, 3, 256, 9}, {18, 19, 19, 10, 3, 512, 9}, {18, 19, 19, 12, 3, 512, 9}, {18, 19, 19, 13, 3, 999, 9}},
+        {{17, 12, 12, 1, 5, 1, 1}, {17, 12, 13, 1, 6, 0, 1}, {17, 13, 15, 1, 5, 0, 1}, {17, 15, 16, 2, 5, 0, 2}, {17, 17, 17, 2, 4, 0, 2}, {17, 16, 17, 3, 4, 2, 3}, {17, 17, 17, 3, 4, 4, 4}, {17, 17, 17, 3, 4, 8, 5}, {17, 17, 17, 4, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 5}, {17, 17, 17, 6, 4, 8, 5}, {17, 17, 17, 5, 4, 8, 6}, {17, 18, 17, 7, 4, 12, 6}, {17, 18, 17, 3, 4, 12, 7}, {17, 18, 17, 4, 3, 32, 7}, {17, 18, 17, 6, 3, 256, 7}, {17, 18, 17, 6, 3, 128, 8}, {17, 18, 17, 8, 3, 256, 8}, {17, 18, 17, 10, 3, 512, 8}, {17, 18, 17, 5, 3, 256, 9}, {17, 18, 17, 7, 3, 512, 9}, {17, 18, 17, 9, 3, 512, 9}, {17, 18, 17, 11, 3, 999, 9}},
+        {{14, 12, 13, 1, 5, 1, 1}, {14, 14, 15, 1, 5, 0, 1}, {14, 14, 15, 1, 4, 0, 1}, {14, 14, 15, 2, 4, 0, 2}, {14, 14, 14, 4, 4, 2, 3}, {14, 14, 14, 3, 4, 4, 4}, {14, 14, 14, 4, 4, 8, 5}, {14, 14, 14, 6, 4, 8, 5}, {14, 14, 14, 8, 4, 8, 5}, {14, 15, 14, 5, 4, 8, 6}, {14, 15, 14, 9, 4, 8, 6}, {14, 15, 14, 3, 4, 12, 7}, {14, 15, 14, 4, 3, 24, 7}, {14, 15, 14, 5, 3, 32, 8}, {14, 15, 15, 6, 3, 64, 8}, {14, 15, 15, 7, 3, 256, 8}, {14, 15, 15, 5, 3, 48, 9}, {14, 15, 15, 6, 3, 128, 9}, {14, 15, 15, 7, 3, 256, 9}, {14, 15, 15, 8, 3, 256, 9}, {14, 15, 15, 8, 3, 512, 9}, {14, 15, 15, 9, 3, 512, 9}, {14, 15, 15, 10, 3, 999, 9}}};
     const int (*t)[7];
     if (level == 0) level = 3;
-    if (level > 15 || level < -131072 || n == 0u) return false;
+    if (level > 22 || level < -131072 || n == 0u) return false;
     t = kCParTab[n > 256u * 1024u ? 0 : (n > 128u * 1024u ? 1 : (n > 16u * 1024u ? 2 : 3))];
-    if (t[level < 0 ? 0 : level][6] > 6) return false; /* btopt ... btultra2: no kernel */
     const int row = level < 0 ? 0 : level;
     int cl = t[row][1];
     *wlog = t[row][0]; *hlog = t[row][2]; *mml = t[row][4];
@@ -1274,7 +1313,7 @@ static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *
     if (*wlog > srclog) *wlog = srclog;
     if (*hlog > *wlog + 1) *hlog = *wlog + 1;
     {
-        const int btscale = t[row][6] == 6 ? 1 : 0; /* cycleLog = chainLog - 1 for the binary tree */
+        const int btscale = t[row][6] >= 6 ? 1 : 0; /* cycleLog = chainLog - 1 for the binary tree */
         if (cl - btscale > *wlog) cl = *wlog + btscale;
     }
     if (*wlog < 10) *wlog = 10;
@@ -1298,7 +1337,12 @@ static uint32_t zstd_enc_grid(uint64_t n_blocks, size_t stride)
     return (uint32_t)(n_blocks < cap ? n_blocks : cap);
 }
 /* per workgroup: sequences, literals, codes (kWsBytes), then the match finder's table(s) */
-static size_t zstd_enc_stride(int hlog, int clog, bool two_tables) { return kWsBytes + (((size_t)4u << hlog) + (two_tables ? (size_t)4u << clog : 0u)); }
+static size_t zstd_enc_stride(int hlog, int clog, bool two_tables, int strategy = 0, int mml = 0, int wlog = 0)
+{
+    size_t b = kWsBytes + (((size_t)4u << hlog) + (two_tables ? (size_t)4u << clog : 0u));
+    if (strategy >= 7) b += (mml == 3 ? (size_t)4u << (wlog < 17 ? wlog : 17) : 0u) + kOptExtraBytes; /* zstd_opt.h */
+    return b;
+}
 
 size_t zstd_compress_workspace(uint64_t n_blocks, int level, uint32_t block_size)
 {
@@ -1306,7 +1350,7 @@ size_t zstd_compress_workspace(uint64_t n_blocks, int level, uint32_t block_size
     bool dfast = false;
     int strategy = 1;
     if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast, &strategy)) return 256;
-    const size_t stride = zstd_enc_stride(hlog, clog, strategy >= 2);
+    const size_t stride = zstd_enc_stride(hlog, clog, strategy >= 2, strategy, mml, wlog);
     return (size_t)zstd_enc_grid(n_blocks, stride) * stride + 256;
 }
 
@@ -1332,10 +1376,11 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
      * table slots for positions behind the first match, narrower ones pay more trips per sequence */
     static const uint32_t w_env = getenv("CRYO_ZSTD_ENC_WIDTH") ? (uint32_t)atoi(getenv("CRYO_ZSTD_ENC_WIDTH")) : 0u; /* tuning aid */
     const uint32_t width = strategy >= 3 ? (uint32_t)slog : (w_env ? w_env : (dfast ? 32u : 16u));
-    const size_t stride = zstd_enc_stride(hlog, clog, strategy >= 2);
+    const size_t stride = zstd_enc_stride(hlog, clog, strategy >= 2, strategy, mml, wlog);
     const uint32_t grid = zstd_enc_grid(n_blocks, stride);
     if (workspace_bytes < (size_t)grid * stride) return hipErrorInvalidValue;
-    static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
+    static const bool stats_env = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
+    const bool want_stats = stats_env && strategy < 7;
     unsigned long long *d_st = nullptr, h_st[24] = {0};
     if (want_stats) {
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
@@ -1343,11 +1388,14 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
     }
     /* one kernel for all finders, chosen at run time: instantiating it per finder makes the compiler inline each
      * finder into the frame loop and spill three times as much */
-    if (want_stats)
-        hipLaunchKernelGGL(k_zstd_enc<true>, dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride, wlog,
+    if (strategy >= 7)
+        hipLaunchKernelGGL((k_zstd_enc<false, true>), dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride, wlog,
+                           hlog, clog, mml, tlen, finder, width, d_out_size, d_status, (uint8_t *)d_workspace, (uint64_t)stride, d_st);
+    else if (want_stats)
+        hipLaunchKernelGGL((k_zstd_enc<true, false>), dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride, wlog,
                            hlog, clog, mml, tlen, finder, width, d_out_size, d_status, (uint8_t *)d_workspace, (uint64_t)stride, d_st);
     else
-        hipLaunchKernelGGL(k_zstd_enc<false>, dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride, wlog,
+        hipLaunchKernelGGL((k_zstd_enc<false, false>), dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride, wlog,
                            hlog, clog, mml, tlen, finder, width, d_out_size, d_status, (uint8_t *)d_workspace, (uint64_t)stride, d_st);
     if (want_stats) {
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);

@@ -16,7 +16,8 @@
  */
 #pragma once
 
-struct HcState { uint32_t *hash, *chain; uint32_t next_to_update; };
+struct HcState { uint32_t *hash, *chain; uint32_t next_to_update;
+                 uint32_t *hash3; int hlog3; uint32_t low; /* zstd_opt.h: 3-byte hash table, lowest valid index */ };
 
 /* how many bytes before a and b are equal, at most lim (the library's catch-up loop, 64 bytes per step) */
 __device__ inline uint32_t count_back(const uint8_t *a, const uint8_t *b, uint32_t lim, uint32_t lane)
