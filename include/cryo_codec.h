@@ -118,9 +118,9 @@ int cryo_dev_memset(cryo_codec *c, void *d_dst, int value, size_t bytes);       
  *                output bytes identical to liblz4 1.9.3.
  *   method ZSTD: replaces ZSTD_compress(dst,bound,src,B,level) (compression.c:102-104);
  *                param = zstd_compression_level_guc (-5..22).  Output bytes identical to
- *                libzstd 1.4.8 for every level whose strategy at the block's size is fast, dfast, greedy,
- *                lazy, lazy2 or btlazy2: -5..10 up to 16 KiB, -5..12 up to 256 KiB, -5..15 above; the levels
- *                beyond (btopt ... btultra2) return CRYO_E_UNSUPPORTED (no CPU fallback).
+ *                libzstd 1.4.8 at every level (strategies fast ... btlazy2 and the optimal parsers
+ *                btopt, btultra, btultra2) and every block size; a level above 22 returns
+ *                CRYO_E_UNSUPPORTED (no CPU fallback).
  */
 int cryo_codec_compress_batch(cryo_codec *c, int method, int param,
                               const void *d_src, uint64_t src_stride,

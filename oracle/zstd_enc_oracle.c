@@ -2,28 +2,27 @@
  * zstd_enc_oracle.c -- CPU ORACLE (test infrastructure, see cryo_oracle.h).
  *
  * Restates ZSTD_compress(dst, ZSTD_compressBound(B), src, B, level) as libzstd 1.4.8 runs it
- * for the reference's call shape (compression.c:102-104), for the levels whose strategy is
- * `fast` (levels -5 .. 2 at cryo block sizes; the reference's default
- * level 1 is one of them), `dfast` (levels 3 and 4) or `greedy` / `lazy` / `lazy2` (levels 5 .. 10).  Output bytes are identical to the library's; pinned by
- * tests/golden/vectors.json (libzstd 1.4.8 == 1.4.9) and by a live differential test.
+ * for the reference's call shape (compression.c:102-104), at every level (-5 .. 22): the strategies `fast` (levels -5 .. 2 at
+ * cryo block sizes; the reference's default level 1 is one of them), `dfast`, `greedy`, `lazy`, `lazy2`,
+ * `btlazy2`, and the optimal parsers `btopt`, `btultra`, `btultra2`.  Output bytes are identical to the library's; pinned by
+ * tests/golden/vectors.json (libzstd 1.4.8 == 1.4.9) and by live differential tests on every size class.
  *
  * Pipeline restated (all integer arithmetic):
  *   parameters by level and size -> frame header -> per 128 KiB block:
  *     greedy 2-position hash-table match finder with repeat-offset checks ("fast" strategy), or
  *     the two-table (8-byte long hash + short hash) finder of the "dfast" strategy, or the hash-chain
- *     searcher with the greedy / lazy (depth 1, 2) parsers
+ *     searcher with the greedy / lazy (depth 1, 2) parsers, or the binary tree with the lazy2 parser or the optimal parser
+ *     (prices from running symbol statistics, cheapest path over up to 4096 positions)
  *     -> sequences (literal length, match length, offset code) + literal bytes
  *     -> literals: raw / RLE / Huffman (length-limited tree, FSE-compressed or raw weights,
  *        1 or 4 backward bitstreams), with the library's "worth it" heuristics
  *     -> sequences: per-field encoding type (predefined / RLE / FSE / repeat of the previous block's
  *        table) by thresholds below `lazy`, by estimated costs from `lazy` on, FSE table normalisation + description, interleaved backward bitstream
- *     -> raw block fallback when the gain is below srcSize/64 + 2; RLE block for constant
+ *     -> raw block fallback when the gain is below srcSize/64 + 2 (/128, /256 for btultra, btultra2); RLE block for constant
  *        non-first blocks
  */
 #include "cryo_oracle.h"
 #include <string.h>
-#include <stdio.h>
-#include <stdlib.h>
 #include <math.h>
 
 #define ZBLOCK_MAX (128u * 1024u)
@@ -1734,10 +1733,9 @@ static size_t block_opt(hc_state *hc, const cpar *cp, opt_stats *o, const uint8_
 static int get_cpar(int level, size_t n, cpar *cp)
 {
     /* libzstd 1.4.8's four parameter tables (ZSTD_defaultCParameters: source size > 256 KiB, <= 256 KiB, <= 128 KiB,
-     * <= 16 KiB), rows: the base row of the negative levels, then levels 1 .. 12; columns: windowLog, chainLog, hashLog,
-     * searchLog, minMatch, targetLength, strategy (1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2, 6 btlazy2; 7 and up: the
-     * optimal-parser strategies, not restated).  Rows 13 .. 15 exist for sources above 256 KiB only (btlazy2 there; btopt and up
-     * in the other classes).  Dumped from ZSTD_getCParams and checked against it by the tests. */
+     * <= 16 KiB), rows: the base row of the negative levels, then levels 1 .. 22; columns: windowLog, chainLog, hashLog,
+     * searchLog, minMatch, targetLength, strategy (1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2, 6 btlazy2, 7 btopt, 8 btultra,
+     * 9 btultra2).  Dumped from ZSTD_getCParams and checked against it by the tests. */
     static const int kCParTab[4][23][7] = {
         {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2}, {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}, {21, 19, 19, 3, 5, 8, 4}, {21, 19, 19, 3, 5, 16, 5}, {21, 19, 20, 4, 5, 16, 5}, {22, 20, 21, 4, 5, 16, 5}, {22, 21, 22, 4, 5, 16, 5}, {22, 21, 22, 5, 5, 16, 5}, {22, 21, 22, 5, 5, 32, 6}, {22, 22, 23, 5, 5, 32, 6}, {22, 23, 23, 6, 5, 32, 6}, {22, 22, 22, 5, 5, 48, 7}, {23, 23, 22, 5, 4, 64, 7}, {23, 23, 22, 6, 3, 64, 8}, {23, 24, 22, 7, 3, 256, 9}, {25, 25, 23, 7, 3, 256, 9}, {26, 26, 24, 7, 3, 512, 9}, {27, 27, 25, 9, 3, 999, 9}},
         {{18, 12, 13, 1, 5, 1, 1}, {18, 13, 14, 1, 6, 0, 1}, {18, 14, 14, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {18, 16, 17, 2, 5, 2, 3}, {18, 18, 18, 3, 5, 2, 3}, {18, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 4, 4, 4, 4}, {18, 18, 19, 4, 4, 8, 5}, {18, 18, 19, 5, 4, 8, 5}, {18, 18, 19, 6, 4, 8, 5}, {18, 18, 19, 5, 4, 12, 6}, {18, 19, 19, 7, 4, 12, 6}, {18, 18, 19, 4, 4, 16, 7}, {18, 18, 19, 4, 3, 32, 7}, {18, 18, 19, 6, 3, 128, 7}, {18, 19, 19, 6, 3, 128, 8}, {18, 19, 19, 8, 3, 256, 8}, {18, 19, 19, 6, 3, 128, 9}, {18, 19, 19, 8, 3, 256, 9}, {18, 19, 19, 10, 3, 512, 9}, {18, 19, 19, 12, 3, 512, 9}, {18, 19, 19, 13, 3, 999, 9}},

@@ -1,14 +1,15 @@
 /*
  * zstd_enc.hip -- Zstandard frame encode, one wavefront per cryo block, output bytes identical
- * to libzstd 1.4.8 for the levels whose strategy is `fast`, `dfast`, `greedy`, `lazy`, `lazy2` or `btlazy2` (levels
- * -5 .. 12 at cryo block sizes, .. 15 above 256 KiB; the reference's default zstd_compression_level_guc = 1 is one of them).
+ * to libzstd 1.4.8 at every level (-5 .. 22: the strategies `fast`, `dfast`, `greedy`, `lazy`, `lazy2`, `btlazy2`, and the
+ * optimal parsers `btopt`, `btultra`, `btultra2` of zstd_opt.h; the reference's default zstd_compression_level_guc is 1).
  *
  * Replaces ZSTD_compress(dst, ZSTD_compressBound(B), src, B, level)
  * (reference compression.c:102-104).
  *
  * Pipeline per 128 KiB zstd block (a 1 MiB cryo block is a frame of 8 dependent blocks):
  *   match finder  : strategy `fast` (levels -5..2) or `dfast` (3, 4), zstd_dfast.h (and `greedy` / `lazy` /
- *                   `lazy2`, levels 5..10, zstd_lazy.h: a wave-uniform hash-chain walk): the walk is a serial
+ *                   `lazy2` / `btlazy2`, levels 5..15, zstd_lazy.h, and the optimal parsers above, zstd_opt.h:
+ *                   wave-uniform walks over a hash chain or a binary tree): the walk is a serial
  *                   recurrence over hash tables that do not fit LDS next to the entropy stage, so the
  *                   tables live in global memory and a step takes the next 16-32 search positions at
  *                   once, one per lane, paying the trips to memory (table slots, candidates, match
@@ -1284,16 +1285,16 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
 }
 
 /* ZSTD_getCParams + ZSTD_adjustCParams for the levels with a kernel at cryo block sizes (oracle-checked): `fast`
- * (-5..2), `dfast` (3, 4), `greedy` (5; 6 above 256 KiB), `lazy` / `lazy2` (up to 10).  *clog: dfast's short table /
- * the chain table; *strategy: 1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2; *slog: the hash-chain searchLog. */
+ * (-5..2), `dfast` (3, 4), `greedy` (5; 6 above 256 KiB), `lazy` / `lazy2`, `btlazy2`, `btopt` / `btultra` / `btultra2` (up to
+ * 22).  *clog: dfast's short table / the chain table / the binary tree; *strategy: 1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2,
+ * 6 btlazy2, 7 btopt, 8 btultra, 9 btultra2; *slog: searchLog. */
 static bool zstd_fast_cparams(int level, uint32_t n, int *wlog, int *hlog, int *mml, int *tlen, int *clog = nullptr,
                               bool *dfast = nullptr, int *strategy = nullptr, int *slog = nullptr)
 {
     /* libzstd 1.4.8's four parameter tables (ZSTD_defaultCParameters: source size > 256 KiB, <= 256 KiB, <= 128 KiB,
      * <= 16 KiB), rows: the base row of the negative levels, then levels 1 .. 12; columns: windowLog, chainLog, hashLog,
-     * searchLog, minMatch, targetLength, strategy (1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2, 6 btlazy2; 7 and up: the
-     * optimal-parser strategies, no kernel); rows 13 .. 15 for sources above 256 KiB only.  Dumped from ZSTD_getCParams and
-     * checked against it by the tests. */
+     * searchLog, minMatch, targetLength, strategy (1 fast, 2 dfast, 3 greedy, 4 lazy, 5 lazy2, 6 btlazy2, 7 btopt, 8 btultra,
+     * 9 btultra2).  Dumped from ZSTD_getCParams and checked against it by the tests. */
     static const int kCParTab[4][23][7] = {
         {{19, 12, 13, 1, 6, 1, 1}, {19, 13, 14, 1, 7, 0, 1}, {20, 15, 16, 1, 6, 0, 1}, {21, 16, 17, 1, 5, 0, 2}, {21, 18, 18, 1, 5, 0, 2}, {21, 18, 19, 2, 5, 2, 3}, {21, 19, 19, 3, 5, 4, 3}, {21, 19, 19, 3, 5, 8, 4}, {21, 19, 19, 3, 5, 16, 5}, {21, 19, 20, 4, 5, 16, 5}, {22, 20, 21, 4, 5, 16, 5}, {22, 21, 22, 4, 5, 16, 5}, {22, 21, 22, 5, 5, 16, 5}, {22, 21, 22, 5, 5, 32, 6}, {22, 22, 23, 5, 5, 32, 6}, {22, 23, 23, 6, 5, 32, 6}, {22, 22, 22, 5, 5, 48, 7}, {23, 23, 22, 5, 4, 64, 7}, {23, 23, 22, 6, 3, 64, 8}, {23, 24, 22, 7, 3, 256, 9}, {25, 25, 23, 7, 3, 256, 9}, {26, 26, 24, 7, 3, 512, 9}, {27, 27, 25, 9, 3, 999, 9}},
         {{18, 12, 13, 1, 5, 1, 1}, {18, 13, 14, 1, 6, 0, 1}, {18, 14, 14, 1, 5, 0, 2}, {18, 16, 16, 1, 4, 0, 2}, {18, 16, 17, 2, 5, 2, 3}, {18, 18, 18, 3, 5, 2, 3}, {18, 18, 19, 3, 5, 4, 4}, {18, 18, 19, 4, 4, 4, 4}, {18, 18, 19, 4, 4, 8, 5}, {18, 18, 19, 5, 4, 8, 5}, {18, 18, 19, 6, 4, 8, 5}, {18, 18, 19, 5, 4, 12, 6}, {18, 19, 19, 7, 4, 12, 6}, {18, 18, 19, 4, 4, 16, 7}, {18, 18, 19, 4, 3, 32, 7}, {18, 18, 19, 6, 3, 128, 7}, {18, 19, 19, 6, 3, 128, 8}, {18, 19, 19, 8, 3, 256, 8}, {18, 19, 19, 6, 3, 128, 9}, {18, 19, 19, 8, 3, 256, 9}, {18, 19, 19, 10, 3, 512, 9}, {18, 19, 19, 12, 3, 512, 9}, {18, 19, 19, 13, 3, 999, 9}},

@@ -19,7 +19,6 @@
 #include "utils/guc.h" /* DefineCustom*Variable, config_enum_entry, PGC_USERSET (reference compression.c:4) */
 #endif
 
-#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -40,46 +39,10 @@ static int hip_multi_first = -1, hip_multi_count = 0, hip_pool_mb = 0;
 static char codec_err[320];
 
 static size_t hip_bound(int method, size_t n) { return cryo_codec_bound(method, n); }
-/* zstd levels whose strategy has no GPU kernel (btopt ... btultra2: 13..22 up to 256 KiB, 16..22 above; the GUC accepts them,
- * reference compression.c:48-58).  Default: the call fails with the reference's ERROR.  With the additive GUC
- * pg_cryogen.zstd_host_fallback = on, such a call is served by the library the reference links, found by soname and
- * called exactly as reference compression.c:102-104 calls it, one block after the other on this backend's core --
- * the reference's own path and speed.  Never the test oracle; counted (cryo_host_fallback_blocks()); off in every
- * parity test. */
-int cryo_zstd_host_fallback_guc = 0;
-static uint64_t host_fallback_blocks;
-uint64_t cryo_host_fallback_blocks(void) { return host_fallback_blocks; }
-
-static int stock_zstd_compress_blocks(int level, const void *src, size_t bs, size_t n, void *dst, size_t stride, uint32_t *out)
-{
-    typedef size_t (*zstd_compress_fn)(void *, size_t, const void *, size_t, int);
-    typedef unsigned (*zstd_iserr_fn)(size_t);
-    static zstd_compress_fn zc;
-    static zstd_iserr_fn zerr;
-    size_t i;
-    if (!zc) {
-        void *h = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
-        if (!h) return CRYO_E_UNSUPPORTED;
-        zc = (zstd_compress_fn)dlsym(h, "ZSTD_compress");
-        zerr = (zstd_iserr_fn)dlsym(h, "ZSTD_isError");
-        if (!zc || !zerr) { zc = NULL; return CRYO_E_UNSUPPORTED; }
-    }
-    for (i = 0; i < n; i++) {
-        const size_t r = zc((char *)dst + i * stride, stride, (const char *)src + i * bs, bs, level);
-        if (zerr(r) || r == 0 || r > 0xFFFFFFFFu) return CRYO_E_HIP;
-        out[i] = (uint32_t)r;
-    }
-    host_fallback_blocks += n;
-    return CRYO_OK;
-}
-
 static int hip_compress_blocks(void *ctx, int method, int param, const void *src, size_t bs, size_t n, void *dst,
                                size_t stride, uint32_t *out)
 {
-    const int rc = cryo_multi_compress_blocks((cryo_multi *)ctx, method, param, src, bs, n, dst, stride, out);
-    if (rc == CRYO_E_UNSUPPORTED && method == CRYO_METHOD_ZSTD && cryo_zstd_host_fallback_guc)
-        return stock_zstd_compress_blocks(param, src, bs, n, dst, stride, out);
-    return rc;
+    return cryo_multi_compress_blocks((cryo_multi *)ctx, method, param, src, bs, n, dst, stride, out);
 }
 static int hip_decompress_blocks(void *ctx, int method, const void *const *src, const uint32_t *sz, size_t n,
                                  void *dst, size_t bs, int32_t *st)
@@ -169,8 +132,6 @@ void cryo_define_compression_gucs(void)
                             &zstd_compression_level_guc, 1, -5, 22, PGC_USERSET, 0, NULL, NULL, NULL);
     DefineCustomIntVariable("pg_cryogen.gpu_device", "GPU used by this backend.", NULL, &cryo_gpu_device_guc, 0,
                             0, 63, PGC_USERSET, 0, NULL, NULL, NULL);
-    DefineCustomIntVariable("pg_cryogen.zstd_host_fallback", "1: compress zstd levels that have no GPU kernel with libzstd on the host (default 0: error).",
-                            NULL, &cryo_zstd_host_fallback_guc, 0, 0, 1, PGC_USERSET, 0, NULL, NULL, NULL);
     DefineCustomIntVariable("pg_cryogen.gpu_count", "Number of GPUs (from gpu_device on) the K-block calls of this backend are spread over.",
                             NULL, &cryo_gpu_count_guc, 1, 1, 64, PGC_USERSET, 0, NULL, NULL, NULL);
     DefineCustomIntVariable("pg_cryogen.gpu_pool_mb", "Decoded blocks kept in GPU memory so that repeated scans skip the transfer and the decode (MiB, 0 = off).",

@@ -74,8 +74,5 @@ void cryo_host_set_codec_ops(const CryoCodecOps *ops); /* test builds only: bind
 #endif
 const CryoCodecOps *cryo_host_codec_ops(void);         /* lazily opens the GPU codec */
 const char *cryo_host_codec_error(void);
-/* opt-in (default off): zstd levels without a GPU kernel are compressed by the stock library on the host, see compression.c */
-extern int cryo_zstd_host_fallback_guc;
-uint64_t cryo_host_fallback_blocks(void);
 
 #endif /* __COMPRESSION_H__ */

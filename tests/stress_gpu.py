@@ -3,7 +3,7 @@
 
 Random structured blocks (mixtures of text-like rows, runs, repeats at random distances, noise) at several
 block sizes; the device encoders must equal the stock liblz4 / libzstd byte for byte (all LZ4 accelerations,
-zstd levels -5..12, 13..15 above 256 KiB), and the device decoders must reproduce the input from streams the stock libraries wrote at
+zstd levels -5..22, the optimal-parser ones on a few blocks per round), and the device decoders must reproduce the input from streams the stock libraries wrote at
 ANY level (zstd 1..19), through both zstd decode paths (fused for small batches, pipeline for large ones)."""
 import os, sys, time
 import numpy as np
@@ -143,9 +143,19 @@ def main():
             outs, st = c.decompress_blocks(METHOD_LZ4, got, B)
             assert (st == 0).all() and all(np.array_equal(o, b) for o, b in zip(outs, blocks)), ("lz4 dec", seed, rounds, B)
             checks += 2 * n
-            if True:   # every size class of libzstd's parameter tables has kernels (levels -5 .. 10 / 12 / 12 / 15)
+            if True:   # every size class of libzstd's parameter tables has kernels for every level
                 level = int(rng.choice([-5, -3, -1, 1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10] + ([11, 12] if B > 16384 else []) + ([13, 15] if B > 262144 else [])))
                 gotz = c.compress_blocks(METHOD_ZSTD, level, blocks)
+                if rounds % 4 == 0:   # an optimal-parser level (btopt / btultra / btultra2) on two blocks: seconds per block at 1 MiB
+                    olevel = int(rng.choice([13, 16, 17, 19, 22] if B > 16384 else [11, 13, 17, 20, 22]))
+                    goto = c.compress_blocks(METHOD_ZSTD, olevel, blocks[:2])
+                    for i in range(min(n, 2)):
+                        exp = stock.zstd_compress(blocks[i], olevel)
+                        if not np.array_equal(goto[i], exp):
+                            os.makedirs("gpurun_out", exist_ok=True)
+                            np.save("gpurun_out/fail_zstd_opt_block.npy", blocks[i])
+                            raise AssertionError(("zstd opt enc", seed, rounds, B, olevel, i, len(goto[i]), len(exp)))
+                    checks += min(n, 2)
                 for i in range(n):
                     exp = stock.zstd_compress(blocks[i], level)
                     if not np.array_equal(gotz[i], exp):

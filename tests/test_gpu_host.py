@@ -120,31 +120,17 @@ def test_gpu_compression_h_surface(HG, oracle):
     p = L.cryo_compress(host.COMP_ZSTD, raw.ctypes.data, C.byref(n))
     z9 = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value,)).copy()
     assert np.array_equal(z9, oracle.zstd_compress(raw, 9)) and not errors
-    # levels whose strategy has no kernel (btopt .. btultra2, 13..22 at this size): the reference's error is raised, no CPU fallback ...
-    host.set_int("zstd_compression_level_guc", 15)
-    L.cryo_compress(host.COMP_ZSTD, raw.ctypes.data, C.byref(n))
-    assert errors and errors[-1][1].startswith("pg_cryogen: compression failed") and "no GPU kernel for zstd parameter 15" in errors[-1][1]
-    # ... unless the operator opts in (pg_cryogen.zstd_host_fallback, default off): then the stock library the reference
-    # links serves the call on the host, counted, with the library's own bytes -- and the GPU decodes them
-    L.cryo_host_fallback_blocks.restype = C.c_uint64
+    # the optimal-parser levels (btopt .. btultra2, 13..22 at this size) have kernels too: the GUC's whole range compresses
+    # on the GPU, with the library's own bytes
     stock = oracle_lib.StockLibs()
-    if stock.zstd is not None:
-        del errors[:]
-        before = L.cryo_host_fallback_blocks()
-        host.set_int("cryo_zstd_host_fallback_guc", 1)
-        for lvl in (15, 22):
-            host.set_int("zstd_compression_level_guc", lvl)
-            p = L.cryo_compress(host.COMP_ZSTD, raw.ctypes.data, C.byref(n))
-            z = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value,)).copy()
-            exp = np.empty(stock.zstd.ZSTD_compressBound(131072), np.uint8)
-            r = stock.zstd.ZSTD_compress(exp.ctypes.data, exp.nbytes, raw.ctypes.data, 131072, lvl)
-            assert np.array_equal(z, exp[:r])
-            assert L.cryo_decompress(host.COMP_ZSTD, z.ctypes.data, len(z), out.ctypes.data) is True and np.array_equal(out, raw)
-        assert L.cryo_host_fallback_blocks() == before + 2 and not errors
-        host.set_int("zstd_compression_level_guc", 1)      # a level with a kernel never takes the host path
-        L.cryo_compress(host.COMP_ZSTD, raw.ctypes.data, C.byref(n))
-        assert L.cryo_host_fallback_blocks() == before + 2
-        host.set_int("cryo_zstd_host_fallback_guc", 0)
+    for lvl in (13, 22):
+        host.set_int("zstd_compression_level_guc", lvl)
+        p = L.cryo_compress(host.COMP_ZSTD, raw.ctypes.data, C.byref(n))
+        z = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value,)).copy()
+        assert np.array_equal(z, oracle.zstd_compress(raw, lvl)) and not errors
+        if stock.zstd is not None:
+            assert np.array_equal(z, stock.zstd_compress(raw, lvl))
+        assert L.cryo_decompress(host.COMP_ZSTD, z.ctypes.data, len(z), out.ctypes.data) is True and np.array_equal(out, raw)
     host.set_int("zstd_compression_level_guc", 1)
 
 

@@ -178,7 +178,7 @@ def test_zstd_single_block_host_api(codec, oracle):
     assert codec.decompress_block(METHOD_ZSTD, c[:-3], B) is None
 
 
-# ---------------- zstd encode (strategies `fast`, `dfast`, `greedy`, `lazy`, `lazy2`, `btlazy2`: levels -5..12, ..15 above 256 KiB), reference compression.c:102-104 ----------------
+# ---------------- zstd encode (every strategy, `fast` .. `btultra2`: levels -5..22), reference compression.c:102-104 ----------------
 @pytest.mark.parametrize("B", [131072, 1 << 20, 65546, 20000])
 def test_zstd_encode_bit_exact(codec, oracle, B):
     blocks = [oracle.synth(3, blk, B, dist) for dist in range(5) for blk in range(2)]
@@ -194,8 +194,9 @@ def test_zstd_encode_bit_exact(codec, oracle, B):
 @pytest.mark.parametrize("B", [64, 1000, 4096, 16384, 16385, 131073, 200000, 262144, 262145, 1 << 20])
 def test_zstd_encode_every_size_class_bit_exact(codec, oracle, B):
     """libzstd picks its parameters from four tables by source size (<= 16 KiB, <= 128 KiB, <= 256 KiB, above): every
-    class, every level below the optimal-parser strategies there (-5 .. 10 / 12 / 12 / 15), against the oracle
-    (pinned to libzstd 1.4.8 on these sizes by tests/test_oracle_golden.py) and, where loadable, the stock library"""
+    class, every level below the optimal-parser strategies there (-5 .. 10 / 12 / 12 / 15) and btopt / btultra / btultra2
+    above them (all of them up to 16 KiB, a sample on the larger sizes), against the oracle (pinned to libzstd 1.4.8 on these
+    sizes by tests/test_oracle_golden.py) and, where loadable, the stock library"""
     from stress_gpu import make_block
     from test_oracle_golden import zstd_levels_with_kernel
     from pg_cryogen_amd.codec import CryoError, E_UNSUPPORTED
@@ -209,12 +210,12 @@ def test_zstd_encode_every_size_class_bit_exact(codec, oracle, B):
         for i, b in enumerate(blocks):
             exp = oracle.zstd_compress(b, lvl)
             assert len(exp) > 0 and np.array_equal(got[i], exp), (B, lvl, i, len(got[i]), len(exp))
-            if stock.zstd is not None and lvl in (levels[0], 1, levels[-1]):
+            if stock.zstd is not None and (lvl in (levels[0], 1) or lvl >= 11):
                 assert np.array_equal(got[i], stock.zstd_compress(b, lvl)), (B, lvl, i)
     outs, st = codec.decompress_blocks(METHOD_ZSTD, got, B)
     assert (st == 0).all() and all(np.array_equal(o, b) for o, b in zip(outs, blocks))
     with pytest.raises(CryoError) as e:
-        codec.compress_blocks(METHOD_ZSTD, levels[-1] + 1, blocks[:1])   # the class's first optimal-parser level (btopt)
+        codec.compress_blocks(METHOD_ZSTD, 23, blocks[:1])   # above ZSTD_maxCLevel
     assert e.value.code == E_UNSUPPORTED
 
 
@@ -241,7 +242,7 @@ def test_zstd_roundtrip_on_device_and_unsupported_levels(codec, oracle):
     for b, o in zip(blocks, outs):
         assert np.array_equal(b, o)
     with pytest.raises(CryoError) as e:
-        codec.compress_blocks(METHOD_ZSTD, 13, blocks[:1])     # btopt .. btultra2: no kernel (no CPU fallback)
+        codec.compress_blocks(METHOD_ZSTD, 23, blocks[:1])     # above ZSTD_maxCLevel (no CPU fallback)
     assert e.value.code == E_UNSUPPORTED
 
 

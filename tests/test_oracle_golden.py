@@ -284,7 +284,11 @@ def zstd_levels_below_btopt(B):
 
 
 def zstd_levels_with_kernel(B):
-    return zstd_levels_below_btopt(B)
+    """every level has a kernel; the GPU suite runs all of them up to 16 KiB and a sample of the optimal-parser levels
+    above (they take 0.1 .. 0.4 s per 128 KiB block and wave)"""
+    lv = zstd_levels_below_btopt(B)
+    top = lv[-1]
+    return lv + (list(range(top + 1, 23)) if B <= 16385 else sorted({top + 1, 17, 19, 22}))
 
 
 @pytest.mark.parametrize("B", ZSTD_CLASS_SIZES)
