@@ -190,44 +190,3 @@ double cryo_oracle_cpu_pass_bench(int method, int encode, int stock, int param, 
     if (failed) return -2.0;
     return (double)n * (double)B * (double)inner / med / 1e9;
 }
-
-/* stock-library compression of n raw blocks with T threads into fixed-stride slots (bench.py's mixed workload:
- * zstd level-22 streams are produced on the host, untimed) */
-typedef struct { const uint8_t *src; uint8_t *dst; uint32_t *csize; uint32_t n, B; size_t stride; int t, T, method, param; lz4_enc_fn lz4e; zstd_enc_fn zstde; int failed; } job3;
-static void *worker3(void *arg)
-{
-    job3 *j = arg;
-    uint32_t i;
-    for (i = (uint32_t)j->t; i < j->n; i += (uint32_t)j->T) {
-        long r = j->method == 0 ? (long)j->lz4e((const char *)(j->src + (size_t)i * j->B), (char *)(j->dst + (size_t)i * j->stride), (int)j->B, (int)j->stride, j->param)
-                                : (long)j->zstde(j->dst + (size_t)i * j->stride, j->stride, j->src + (size_t)i * j->B, j->B, j->param);
-        if (r <= 0 || (size_t)r > j->stride) { j->failed = 1; r = 0; }
-        j->csize[i] = (uint32_t)r;
-    }
-    return NULL;
-}
-int cryo_oracle_stock_compress_many(int method, int param, const uint8_t *src, uint32_t n, uint32_t B, uint8_t *dst, size_t stride,
-                                    uint32_t *csize, int threads)
-{
-    void *h = dlopen(method == 0 ? "liblz4.so.1" : "libzstd.so.1", RTLD_NOW);
-    pthread_t *th;
-    job3 *jobs;
-    int t, failed = 0;
-    if (!h) return -1;
-    if (threads < 1) threads = 1;
-    th = calloc((size_t)threads, sizeof *th);
-    jobs = calloc((size_t)threads, sizeof *jobs);
-    if (!th || !jobs) return -1;
-    for (t = 0; t < threads; t++) {
-        job3 *j = &jobs[t];
-        j->src = src; j->dst = dst; j->csize = csize; j->n = n; j->B = B; j->stride = stride; j->t = t; j->T = threads;
-        j->method = method; j->param = param;
-        j->lz4e = (lz4_enc_fn)dlsym(h, "LZ4_compress_fast");
-        j->zstde = (zstd_enc_fn)dlsym(h, "ZSTD_compress");
-        if ((method == 0 && !j->lz4e) || (method != 0 && !j->zstde)) return -1;
-        pthread_create(&th[t], NULL, worker3, j);
-    }
-    for (t = 0; t < threads; t++) { pthread_join(th[t], NULL); failed |= jobs[t].failed; }
-    free(th); free(jobs);
-    return failed ? -2 : 0;
-}

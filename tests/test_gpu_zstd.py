@@ -220,10 +220,11 @@ def test_zstd_encode_every_size_class_bit_exact(codec, oracle, B):
 
 
 def test_zstd_encode_matches_golden_vectors(codec, oracle):
-    """every golden cell of a level with a kernel (-5 .. 10), 128 KiB and 1 MiB blocks"""
+    """every golden zstd cell (levels -5 .. 7 and 22), every size; of the level-22 cells at 1 MiB (seconds per block) one block
+    per distribution"""
     cells = [c for c in json.load(open(os.path.join(G, "vectors.json")))["cells"]
-             if c["method"] == "zstd" and c["param"] <= 10 and c["B"] in (131072, 1 << 20)]
-    assert len(cells) >= 320
+             if c["method"] == "zstd" and not (c["param"] == 22 and c["B"] > 131072 and c["block"] > 0)]
+    assert len(cells) >= 360 and sum(c["param"] == 22 for c in cells) >= 30
     for B, lvl in sorted(set((c["B"], c["param"]) for c in cells)):
         sub = [c for c in cells if c["param"] == lvl and c["B"] == B]
         blocks = [oracle.synth(0, c["block"], c["B"], c["dist"]) for c in sub]

@@ -241,18 +241,21 @@ def test_zstd_oracle_fuzz_vs_live_libzstd(oracle):
     assert n_lib - n_ok <= n // 20, (n_lib, n_ok)
 
 
-# ---------------- zstd encoder oracle (strategies `fast` .. `btlazy2`: levels -5..12 at cryo block sizes, ..15 above 256 KiB) ----------------
+# ---------------- zstd encoder oracle (every strategy: levels -5..22) ----------------
 def test_zstd_encoder_oracle_matches_libzstd_golden(oracle):
-    n = 0
+    """every golden zstd cell, level 22 (btultra2: the optimal parser, two passes over the first block) included, at every
+    size; of the 1 MiB cells one block per distribution"""
+    n = n22 = 0
     for c in VEC["cells"]:
-        if c["method"] != "zstd" or c["param"] > 10 or c["B"] < 20000 or (c["B"] > 131072 and c["block"] > 0):
+        if c["method"] != "zstd" or (c["B"] > 131072 and c["block"] > 0):
             continue
+        n22 += c["param"] == 22
         raw = oracle.synth(VEC["seed"], c["block"], c["B"], c["dist"])
         comp = oracle.zstd_compress(raw, c["param"])
         assert len(comp) == c["csize"], c
         assert sha(comp) == c["comp_sha256"], c
         n += 1
-    assert n >= 190
+    assert n >= 240 and n22 >= 30
 
 
 @pytest.mark.parametrize("B", [131072, 1 << 20, 65546, 20000])
