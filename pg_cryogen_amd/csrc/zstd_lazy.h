@@ -117,6 +117,25 @@ __device__ inline uint32_t bt_count(const uint8_t *base, uint32_t a, uint32_t b,
 {
     return count_match(base + a, base + b, base + iend, lane);
 }
+/* the same, and which side is smaller at the first difference (*b_less: b's byte < a's byte), taken from the bytes the
+ * comparison already holds instead of a second trip to memory; meaningless when the count ran into `iend` */
+__device__ inline uint32_t bt_count_cmp(const uint8_t *base, uint32_t a, uint32_t b, uint32_t iend, bool *b_less, uint32_t lane)
+{
+    const uint8_t *pa = base + a, *pb = base + b, *end = base + iend;
+    uint32_t done = 0;
+    for (;;) {
+        const bool inb = pa + done + lane < end;
+        const uint32_t va = inb ? pa[done + lane] : 0u, vb = inb ? pb[done + lane] : 0u;
+        const unsigned long long neq = __ballot(!(inb && va == vb));
+        if (neq != 0ull) {
+            const uint32_t l = ctz64(neq);
+            const uint32_t pair = (uint32_t)__builtin_amdgcn_readlane((int)(va | (vb << 8)), (int)l);
+            *b_less = (pair >> 8) < (pair & 0xFFu);
+            return done + l;
+        }
+        done += 64u;
+    }
+}
 
 __device__ inline void dubt_insert1(HcState &hc, const CPar &cp, const uint8_t *base, uint32_t cur, uint32_t iend, uint32_t nb_compares,
                                     uint32_t bt_low, uint32_t lane)
@@ -132,9 +151,10 @@ __device__ inline void dubt_insert1(HcState &hc, const CPar &cp, const uint8_t *
         const uint32_t next_at = 2u * (mi & bt_mask);
         const uint2 nx = *reinterpret_cast<const uint2 *>(bt + next_at);
         uint32_t ml = common_smaller < common_larger ? common_smaller : common_larger;
-        ml += bt_count(base, cur + ml, mi + ml, iend, lane);
+        bool m_less;
+        ml += bt_count_cmp(base, cur + ml, mi + ml, iend, &m_less, lane);
         if (cur + ml == iend) break; /* equal: dropped */
-        if (uni((uint32_t)base[mi + ml]) < uni((uint32_t)base[cur + ml])) {
+        if (m_less) {
             if (lane == 0 && smaller_at != 0xFFFFFFFFu) bt[smaller_at] = mi;
             common_smaller = ml;
             if (mi <= bt_low) { smaller_at = 0xFFFFFFFFu; break; }
@@ -205,7 +225,8 @@ __device__ inline uint32_t bt_find_best(HcState &hc, uint8_t *mark, const CPar &
         const uint32_t next_at = 2u * (mi & bt_mask);
         const uint2 nx = *reinterpret_cast<const uint2 *>(bt + next_at);
         uint32_t ml = common_smaller < common_larger ? common_smaller : common_larger;
-        ml += bt_count(base, cur + ml, mi + ml, iend, lane);
+        bool m_less;
+        ml += bt_count_cmp(base, cur + ml, mi + ml, iend, &m_less, lane);
         if (ml > best) {
             if (ml > match_end_idx - mi) match_end_idx = mi + ml;
             if ((4 * (int)(ml - best)) > (int)(hbit(cur - mi + 1u) - hbit(*offset_ptr + 1u))) {
@@ -214,7 +235,7 @@ __device__ inline uint32_t bt_find_best(HcState &hc, uint8_t *mark, const CPar &
             }
             if (cur + ml == iend) break; /* equal: dropped, to keep the tree consistent */
         }
-        if (uni((uint32_t)base[mi + ml]) < uni((uint32_t)base[cur + ml])) {
+        if (m_less) {
             if (lane == 0 && smaller_at != 0xFFFFFFFFu) bt[smaller_at] = mi;
             common_smaller = ml;
             if (mi <= bt_low) { smaller_at = 0xFFFFFFFFu; break; }

@@ -147,13 +147,14 @@ __device__ inline uint32_t bt_insert1(HcState &hc, const CPar &cp, const uint8_t
         const uint32_t next_at = 2u * (mi & bt_mask);
         const uint2 nx = *reinterpret_cast<const uint2 *>(bt + next_at);
         uint32_t ml = common_smaller < common_larger ? common_smaller : common_larger;
-        ml += bt_count(base, cur + ml, mi + ml, iend, lane);
+        bool m_less;
+        ml += bt_count_cmp(base, cur + ml, mi + ml, iend, &m_less, lane);
         if (ml > best) {
             best = ml;
             if (ml > match_end - mi) match_end = mi + ml;
         }
         if (cur + ml == iend) break; /* equal: dropped */
-        if (uni((uint32_t)base[mi + ml]) < uni((uint32_t)base[cur + ml])) {
+        if (m_less) {
             if (lane == 0 && smaller_at != 0xFFFFFFFFu) bt[smaller_at] = mi;
             common_smaller = ml;
             if (mi <= bt_low) { smaller_at = 0xFFFFFFFFu; break; }
@@ -254,7 +255,8 @@ __device__ uint32_t bt_get_all_matches(uint2 *matches, HcState &hc, const CPar &
         const uint32_t next_at = 2u * (mi & bt_mask);
         const uint2 nx = *reinterpret_cast<const uint2 *>(bt + next_at);
         uint32_t ml = common_smaller < common_larger ? common_smaller : common_larger;
-        ml += bt_count(base, cur + ml, mi + ml, iend, lane);
+        bool m_less;
+        ml += bt_count_cmp(base, cur + ml, mi + ml, iend, &m_less, lane);
         if (ml > best) {
             if (ml > match_end - mi) match_end = mi + ml;
             best = ml;
@@ -262,7 +264,7 @@ __device__ uint32_t bt_get_all_matches(uint2 *matches, HcState &hc, const CPar &
             mnum++;
             if (ml > kOptNum || cur + ml == iend) break; /* dropped, to keep the tree consistent */
         }
-        if (uni((uint32_t)base[mi + ml]) < uni((uint32_t)base[cur + ml])) {
+        if (m_less) {
             if (lane == 0 && smaller_at != 0xFFFFFFFFu) bt[smaller_at] = mi;
             common_smaller = ml;
             if (mi <= bt_low) { smaller_at = 0xFFFFFFFFu; break; }
