@@ -83,10 +83,13 @@ static int fse_min_log(size_t n, uint32_t max_sym)
 }
 static int fse_optimal_log(int max_log, size_t n, uint32_t max_sym, int minus)
 {
+    /* FSE_optimalTableLog_internal computes highbit32(srcSize - 1) - minus in unsigned arithmetic: below 2^minus + 1 symbols it
+     * wraps and limits nothing (found by the soak on a block of four sequences: the library kept tableLog 8, priced a new
+     * offset table higher than the predefined one, and chose the latter) */
     int max_src = hb((uint32_t)(n - 1)) - minus;
     int log = max_log, min_bits = fse_min_log(n, max_sym);
     if (log == 0) log = 11;
-    if (max_src < log) log = max_src;
+    if (max_src >= 0 && max_src < log) log = max_src;
     if (min_bits > log) log = min_bits;
     if (log < 5) log = 5;
     if (log > 12) log = 12;

@@ -117,10 +117,11 @@ __device__ inline int fse_min_log(uint32_t n, uint32_t max_sym)
 }
 __device__ inline int fse_optimal_log(int max_log, uint32_t n, uint32_t max_sym, int minus)
 {
-    const int max_src = (int)hbit(n - 1u) - minus;
+    /* the library's highbit32(srcSize - 1) - minus is unsigned: below 2^minus + 1 symbols it wraps and limits nothing */
+    const int max_src = (n > 1u ? (int)hbit(n - 1u) : 0) - minus;
     int log = max_log;
     const int min_bits = fse_min_log(n, max_sym);
-    if (max_src < log) log = max_src;
+    if (max_src >= 0 && max_src < log) log = max_src;
     if (min_bits > log) log = min_bits;
     if (log < 5) log = 5;
     if (log > 12) log = 12;

@@ -84,6 +84,55 @@ __device__ inline uint32_t hc_find_best(HcState &hc, uint8_t *mark, const CPar &
     return ml;
 }
 
+/* After a search that found nothing, the parser moves on one position and searches again; in a literal run that is a chain
+ * of searches that all find nothing.  This takes the next positions of such a run at once, one per lane, and returns how
+ * many of them, from `ip` on, are *proven* to find nothing -- the parser then skips them and runs its unchanged search at
+ * the first position that may find something, so the result is the serial walk's.  A position finds nothing when the repeat
+ * offset does not match at ip+1 and no link of its chain (as many as the serial search would visit) starts with the
+ * position's four bytes.  A lane must see the tables as its serial search would: every earlier position inserted.  Those
+ * below `ip` are inserted first; the batch's own positions are kept out of each other's chains by cutting the batch in
+ * front of the first lane whose hash slot an earlier lane shares (the mark array), and a chain slot an earlier lane would
+ * overwrite is older than the chain table's reach, where the walk stops anyway.  Only while the step is one position
+ * (the first 256 bytes of a literal run). */
+constexpr uint32_t kSkipWidth = 32u;
+__device__ inline uint32_t hc_skip_misses(HcState &hc, uint8_t *mark, const CPar &cp, const uint8_t *base, uint32_t ip, uint32_t anchor,
+                                          uint32_t ilimit, uint32_t off1, int mls, uint32_t lane)
+{
+    if ((ip - anchor) >> 8) return 0u;
+    const uint32_t csize = 1u << cp.clog, cmask = csize - 1u;
+    const uint32_t max_dist = 1u << cp.wlog;
+    const uint32_t p = ip + lane;
+    bool on = lane < kSkipWidth && p < ilimit && (p - anchor) < 256u;
+    (void)hc_insert_find(hc, mark, cp, base, ip, mls, lane);
+    const uint64_t v8 = on ? ld64v(base + p) : 0ull;
+    const uint32_t h = hashs_v(v8, cp.hlog, mls);
+    const uint32_t keep = distinct_prefix(mark, h & (kDfMark - 1u), on, lane);
+    on = on && lane < keep;
+    const uint32_t here = (uint32_t)v8;
+    bool hit = on && off1 > 0u && ld32v(base + (on ? p + 1u - off1 : ip)) == (uint32_t)(v8 >> 8);
+    uint32_t mi = on ? hc.hash[h] : 0u;
+    const uint32_t low_limit = (p - 1u > max_dist) ? p - max_dist : 1u;
+    const uint32_t min_chain = p > csize ? p - csize : 0u;
+    uint32_t attempts = 1u << cp.slog;
+    bool walking = on && !hit;
+    for (;;) {
+        const bool active = walking && mi >= low_limit && attempts > 0u;
+        if (!__any(active)) break;
+        const uint32_t nxt = active ? hc.chain[mi & cmask] : 0u;
+        const uint32_t theirs = ld32v(base + (active ? mi : ip));
+        if (active) {
+            if (theirs == here) { hit = true; walking = false; }   /* at least 8 bytes are left: four equal bytes are a match */
+            else if (mi <= min_chain) walking = false;
+            else { mi = nxt; attempts--; }
+        } else
+            walking = false;
+    }
+    const unsigned long long stop = __ballot(!(on && !hit));
+    const uint32_t n = stop ? ctz64(stop) : 64u;
+    if (n > 1u) (void)hc_insert_find(hc, mark, cp, base, ip + n - 1u, mls, lane); /* what the last skipped search would have inserted */
+    return n;
+}
+
 /* ---- strategy `btlazy2`: the lazy2 parser over the binary-tree searcher (libzstd 1.4.8 ZSTD_updateDUBT, ZSTD_insertDUBT1,
  * ZSTD_DUBT_findBestMatch, ZSTD_BtFindBestMatch; oracle: dubt_update, dubt_insert1, bt_find_best).  The chain table is a
  * binary tree of 2^(chainLog-1) nodes, two links per position; positions are first chained unsorted (second link = the
@@ -291,7 +340,11 @@ __device__ uint32_t block_lazy(HcState &hc, uint8_t *mark, const CPar &cp, int d
                 const uint32_t ml2 = cp.bt ? bt_find_best(hc, mark, cp, base, ip, iend, &off_found, mls, lane) : hc_find_best(hc, mark, cp, base, ip, iend, &off_found, mls, lane);
                 if (ml2 > mlen) { mlen = ml2; start = ip; offset = off_found; }
             }
-            if (mlen < 4u) { ip += ((ip - anchor) >> 8) + 1u; continue; }
+            if (mlen < 4u) {
+                ip += ((ip - anchor) >> 8) + 1u;
+                if (!cp.bt && ip < ilimit) ip += hc_skip_misses(hc, mark, cp, base, ip, anchor, ilimit, off1, mls, lane);
+                continue;
+            }
             if (depth >= 1)
                 while (ip < ilimit) {
                     ip++;

@@ -219,6 +219,25 @@ def test_zstd_encode_every_size_class_bit_exact(codec, oracle, B):
     assert e.value.code == E_UNSUPPORTED
 
 
+def test_zstd_encode_blocks_of_few_sequences(codec, oracle):
+    """the soak's block of four sequences (tests/golden/soak_block_four_sequences.npy) and periodic blocks like it: sequence
+    tables over very few symbols, every strategy from `greedy` up"""
+    from test_oracle_golden import few_sequence_blocks
+    b = np.load(os.path.join(G, "soak_block_four_sequences.npy"))
+    for lvl in (5, 7, 10, 13, 22):
+        got = codec.compress_blocks(METHOD_ZSTD, lvl, [b])
+        assert np.array_equal(got[0], oracle.zstd_compress(b, lvl)), lvl
+    blocks = few_sequence_blocks(321, 60)
+    by_size = {}
+    for blk in blocks:
+        by_size.setdefault(len(blk), []).append(blk)
+    for lvl in (5, 9, 12, 13, 17, 22):
+        for n, group in by_size.items():
+            got = codec.compress_blocks(METHOD_ZSTD, lvl, group)
+            for g, blk in zip(got, group):
+                assert np.array_equal(g, oracle.zstd_compress(blk, lvl)), (n, lvl)
+
+
 def test_zstd_encode_matches_golden_vectors(codec, oracle):
     """every golden zstd cell (levels -5 .. 7 and 22), every size; of the level-22 cells at 1 MiB (seconds per block) one block
     per distribution"""

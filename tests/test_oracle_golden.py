@@ -330,6 +330,39 @@ def test_zstd_encoder_oracle_optimal_parser_vs_live_libzstd(oracle, B):
         assert r == B and np.array_equal(out, raw)
 
 
+def few_sequence_blocks(seed, count):
+    """periodic blocks with a few disturbed bytes: one to five sequences per block, where the sequence tables are chosen among
+    predefined / RLE / a new table on very few symbols"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(count):
+        per = int(rng.choice([1, 2, 3, 4, 8, 13, 64]))
+        n = int(rng.integers(200, 12000))
+        blk = np.tile(rng.integers(0, 256, per, dtype=np.uint8), (n + per - 1) // per)[:n].copy()
+        for _ in range(int(rng.integers(0, 5))):
+            blk[int(rng.integers(0, n))] ^= int(rng.integers(1, 256))
+        out.append(blk)
+    return out
+
+
+def test_zstd_encoder_oracle_blocks_of_few_sequences(oracle):
+    """found by the GPU soak: a 9 000-byte block of four sequences, where FSE_optimalTableLog's `highbit32(n - 1) - 2` wraps
+    (unsigned) and the library prices a new offset table with tableLog 8, not 5 -- and keeps the predefined one.  The block is
+    kept as a fixture with the library's output hashes; periodic blocks of a few sequences, live, next to it."""
+    b = np.load(os.path.join(G, "soak_block_four_sequences.npy"))
+    for lvl, h in ((7, "ae7d9a03f9fa56df0401829548c43ff0ced46b20ed4c06cde78fd40e87019e20"),
+                   (13, "bfab88c041889945323eb62f5627cd658599729b567007d0e5205b70ddf04024"),
+                   (22, "bfab88c041889945323eb62f5627cd658599729b567007d0e5205b70ddf04024")):
+        c = oracle.zstd_compress(b, lvl)
+        assert len(c) == 1576 and sha(c) == h, lvl
+    stock = oracle_lib.StockLibs()
+    if stock.zstd is None:
+        pytest.skip("libzstd.so.1 not loadable")
+    for blk in few_sequence_blocks(123, 120):
+        for lvl in (5, 7, 10, 12, 13, 17, 22):
+            assert np.array_equal(oracle.zstd_compress(blk, lvl), stock.zstd_compress(blk, lvl)), (len(blk), lvl)
+
+
 def test_zstd_encoder_oracle_unsupported_levels_return_empty(oracle):
     raw = oracle.synth(0, 0, 131072, 1)
     assert len(oracle.zstd_compress(raw, 23)) == 0     # above ZSTD_maxCLevel
