@@ -44,26 +44,26 @@ static uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v;
 static uint64_t rd64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
 
 /* ------------------------------------------------------------ forward LSB-first bit writer */
-typedef struct { uint8_t *p; uint64_t acc; int n; size_t len; } bitw;
-static void bw_init(bitw *b, uint8_t *p) { b->p = p; b->acc = 0; b->n = 0; b->len = 0; }
+typedef struct { uint8_t *p; uint64_t acc; int n; size_t len; size_t cap; /* bytes that may be written; len counts on */ } bitw;
+static void bw_init(bitw *b, uint8_t *p) { b->p = p; b->acc = 0; b->n = 0; b->len = 0; b->cap = (size_t)-1; }
 static void bw_add(bitw *b, uint64_t v, int nb)
 {
     if (nb == 0) return;
     b->acc |= (v & ((nb >= 64) ? ~0ull : ((1ull << nb) - 1))) << b->n;
     b->n += nb;
-    while (b->n >= 8) { b->p[b->len++] = (uint8_t)b->acc; b->acc >>= 8; b->n -= 8; }
+    while (b->n >= 8) { if (b->len < b->cap) b->p[b->len] = (uint8_t)b->acc; b->len++; b->acc >>= 8; b->n -= 8; }
 }
 /* end mark + padding, as BIT_closeCStream */
 static size_t bw_close(bitw *b)
 {
     bw_add(b, 1, 1);
-    if (b->n > 0) { b->p[b->len++] = (uint8_t)b->acc; b->n = 0; b->acc = 0; }
+    if (b->n > 0) { if (b->len < b->cap) b->p[b->len] = (uint8_t)b->acc; b->len++; b->n = 0; b->acc = 0; }
     return b->len;
 }
 /* flush without end mark (FSE table descriptions) */
 static size_t bw_flush(bitw *b)
 {
-    if (b->n > 0) { b->p[b->len++] = (uint8_t)b->acc; b->n = 0; b->acc = 0; }
+    if (b->n > 0) { if (b->len < b->cap) b->p[b->len] = (uint8_t)b->acc; b->len++; b->n = 0; b->acc = 0; }
     return b->len;
 }
 
@@ -473,6 +473,21 @@ static size_t huf_encode_1x(uint8_t *dst, const uint8_t *src, size_t n, const hu
 static size_t huf_encode_streams(uint8_t *dst, size_t hsz, const uint8_t *src, size_t n, const huf_elt *tree, int single)
 {
     size_t op = hsz;
+    {
+        /* the size first: a table of another block (repeat mode) can expand the literals beyond the output buffer, where the
+         * library's bit writer stops at the buffer's end and reports "not compressible".  Same verdict here, before any write
+         * (found by running the differential hunt under AddressSanitizer). */
+        const size_t seg = single ? n : (n + 3) / 4;
+        size_t total = hsz + (single ? 0 : 6), k, i;
+        for (k = 0; k < (single ? 1u : 4u); k++) {
+            const size_t beg = k * seg, end = (single || k == 3) ? n : beg + seg;
+            size_t bits = 1; /* end mark */
+            for (i = beg; i < end && i < n; i++) bits += tree[src[i]].nb;
+            total += (bits + 7) >> 3;
+        }
+        if (!single && n < 12) return 0;
+        if (total >= n - 1) return 0;
+    }
     if (single) {
         op += huf_encode_1x(dst + op, src, n, tree);
     } else {
@@ -799,6 +814,7 @@ static size_t compress_sequences(uint8_t *dst, const seq_t *seqs, size_t nseq, c
         uint32_t sm, so, sl;
         size_t n = nseq - 1, bs;
         bw_init(&b, dst + op);
+        b.cap = src_size + 32 > op ? src_size + 32 - op : 0; /* the library's writer stops at the end of its buffer; the size test below gives the same verdict */
         sm = fse_init_state(&ct_ml, mlc[n]);
         so = fse_init_state(&ct_of, ofc[n]);
         sl = fse_init_state(&ct_ll, llc[n]);

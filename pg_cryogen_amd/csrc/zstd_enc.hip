@@ -92,17 +92,18 @@ struct BitW {
     uint64_t acc;
     uint32_t n;
     uint32_t len;
-    __device__ inline void init(uint8_t *dst) { p = dst; acc = 0; n = 0; len = 0; }
+    uint32_t cap; /* bytes that may be written; `len` keeps counting beyond (the caller then drops the result) */
+    __device__ inline void init(uint8_t *dst, uint32_t capacity = 0xFFFFFFFFu) { p = dst; acc = 0; n = 0; len = 0; cap = capacity; }
     __device__ inline void add(uint64_t v, uint32_t nb)
     {
         if (nb == 0u) return;
         acc |= (v & ((1ull << nb) - 1ull)) << n;
         n += nb;
-        if (n >= 32u) { const uint32_t w = (uint32_t)acc; __builtin_memcpy(p + len, &w, 4); len += 4u; acc >>= 32; n -= 32u; }
+        if (n >= 32u) { const uint32_t w = (uint32_t)acc; if (len + 4u <= cap) __builtin_memcpy(p + len, &w, 4); len += 4u; acc >>= 32; n -= 32u; }
     }
     __device__ inline uint32_t flush()
     {
-        while (n > 0u) { p[len++] = (uint8_t)acc; acc >>= 8; n = n > 8u ? n - 8u : 0u; }
+        while (n > 0u) { if (len < cap) p[len] = (uint8_t)acc; len++; acc >>= 8; n = n > 8u ? n - 8u : 0u; }
         acc = 0;
         return len;
     }
@@ -925,7 +926,10 @@ __device__ uint32_t compress_sequences(EncLds &L, uint8_t *dst, uint8_t *ws, uin
      * values, per-symbol table entries) and the loop reads them with v_readlane. */
     {
         BitW b;
-        b.init(dst + op);
+        /* a block of many short matches at far offsets can cost more than it covers: the library's writer stops at the end of
+         * its buffer and the block goes out raw; here nothing is written beyond the block's own size (+ the slack every
+         * output slot has), and the size test below gives the same verdict */
+        b.init(dst + op, src_size + 32u > op ? src_size + 32u - op : 0u);
         uint32_t sm = 0, so = 0, sl = 0;
         for (uint32_t c1 = nseq; c1 > 0u;) {
             const uint32_t cnt = c1 < 64u ? c1 : 64u;

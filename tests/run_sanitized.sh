@@ -5,7 +5,7 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
-cp -r "$ROOT"/pg_cryogen_amd "$ROOT"/oracle "$ROOT"/include "$ROOT"/tests "$T"/
+cp -r "$ROOT"/pg_cryogen_amd "$ROOT"/oracle "$ROOT"/include "$ROOT"/tests "$ROOT"/pg "$T"/
 cd "$T"
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer"
 make -s -C oracle clean
@@ -16,4 +16,8 @@ make -s -C pg_cryogen_amd/host CFLAGS="-O1 -g -fPIC -Wall -std=gnu11 -I../../inc
 ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
 LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) \
 python -m pytest tests -x -q -m "not gpu" -p no:cacheprovider
+# the encoder oracle against the live libzstd on random blocks, every level, with the sanitizers watching
+ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1 \
+LD_PRELOAD=$(gcc -print-file-name=libasan.so):$(gcc -print-file-name=libubsan.so) \
+python tests/hunt_oracle.py ${HUNT_SECONDS:-60} 1
 rm -rf "$T"
