@@ -1,5 +1,6 @@
-"""Differential hunt on the CPU (not collected by pytest: `python tests/hunt_oracle.py [seconds] [seed]`): the zstd encoder oracle
-against the live libzstd.so.1 at random levels (-5 .. 22) on random blocks of every kind the GPU soak found trouble with --
+"""Differential hunt on the CPU (not collected by pytest: `python tests/hunt_oracle.py [seconds] [seed] [zstd|lz4]`): the zstd encoder
+oracle against the live libzstd.so.1 at random levels (-5 .. 22) -- or the LZ4 encoder oracle against liblz4.so.1 at random
+accelerations -- on random blocks of every kind the GPU soak found trouble with --
 tiny and small blocks, the size-class boundaries, structured blocks, periodic blocks of a few sequences, sparse alphabets and
 runs.  Run it under AddressSanitizer too (tests/run_sanitized.sh does, briefly): that is how the unbounded Huffman write of
 the restatement was found."""
@@ -38,11 +39,12 @@ def make_case(rng, make_block, few_sequence_blocks):
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    lz4 = len(sys.argv) > 3 and sys.argv[3] == "lz4"
     from stress_gpu import make_block
     from test_oracle_golden import few_sequence_blocks
     o = oracle_lib.Oracle()
     st = oracle_lib.StockLibs()
-    assert st.zstd is not None, "libzstd.so.1 needed"
+    assert (st.lz4 if lz4 else st.zstd) is not None, "the stock library is needed"
     rng = np.random.default_rng(seed)
     t_end = time.time() + budget
     n = bad = 0
@@ -50,10 +52,13 @@ def main():
         blk = make_case(rng, make_block, few_sequence_blocks)
         if len(blk) == 0:
             continue
-        for lvl in rng.choice(np.arange(-5, 23), 4, replace=False):
+        params = rng.choice([0, 1, 2, 3, 7, 9, 50, 300, 65537], 4, replace=False) if lz4 else rng.choice(np.arange(-5, 23), 4, replace=False)
+        for lvl in params:
             lvl = int(lvl)
             n += 1
-            if not np.array_equal(st.zstd_compress(blk, lvl), o.zstd_compress(blk, lvl)):
+            same = (np.array_equal(st.lz4_compress(blk, lvl), o.lz4_compress(blk, lvl)) if lz4
+                    else np.array_equal(st.zstd_compress(blk, lvl), o.zstd_compress(blk, lvl)))
+            if not same:
                 bad += 1
                 np.save("hunt_fail_%d_%d_level%d.npy" % (seed, n, lvl), blk)
                 print("MISMATCH seed", seed, "case", n, "len", len(blk), "level", lvl, flush=True)
