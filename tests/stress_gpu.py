@@ -2,7 +2,7 @@
 `python tests/stress_gpu.py fuzz [seconds] [seed]` for malformed streams).
 
 Random structured blocks (mixtures of text-like rows, runs, repeats at random distances, noise) at several
-block sizes; the device encoders must equal the stock liblz4 / libzstd byte for byte (all LZ4 accelerations,
+block sizes, and every third round tiny / boundary-size / few-sequence / sparse blocks (odd_block); the device encoders must equal the stock liblz4 / libzstd byte for byte (all LZ4 accelerations,
 zstd levels -5..22, the optimal-parser ones on a few blocks per round), and the device decoders must reproduce the input from streams the stock libraries wrote at
 ANY level (zstd 1..19), through both zstd decode paths (fused for small batches, pipeline for large ones)."""
 import os, sys, time
@@ -12,6 +12,25 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import oracle_lib
 from pg_cryogen_amd import Codec, METHOD_LZ4, METHOD_ZSTD
 from pg_cryogen_amd import codec as cc
+
+
+def odd_block(rng, n):
+    """what the structured generator does not make: periodic blocks with a few disturbed bytes (one to five sequences), sparse
+    alphabets, stretched runs, uniform noise over a small alphabet"""
+    kind = int(rng.integers(0, 4))
+    if kind == 0:
+        per = int(rng.choice([1, 2, 3, 4, 8, 13, 64]))
+        blk = np.tile(rng.integers(0, 256, per, dtype=np.uint8), (n + per - 1) // per)[:n].copy()
+        for _ in range(int(rng.integers(0, 5))):
+            blk[int(rng.integers(0, n))] ^= int(rng.integers(1, 256))
+        return blk
+    if kind == 1:
+        a = rng.integers(0, int(rng.choice([2, 3, 5, 17])), n, dtype=np.uint8)
+        r = int(rng.integers(2, 40))
+        return np.repeat(a[:(n + r - 1) // r], r)[:n].copy()
+    if kind == 2:
+        return rng.integers(0, int(rng.choice([2, 4, 16, 256])), n, dtype=np.uint8)
+    return make_block(rng, n)
 
 
 def rotate_paths(c, rng):
@@ -131,7 +150,11 @@ def main():
             rotate_paths(c, rng)
             B = int(rng.choice([131072, 131072, 1 << 20, 65547, 70000, 20000, 300001, 9000, 200000]))
             n = int(rng.choice([3, 20, 40]))
-            blocks = [make_block(rng, B) for _ in range(n)]
+            if rounds % 3 == 2:   # odd blocks: tiny ones, the size-class boundaries, few sequences, sparse alphabets, runs
+                B = int(rng.choice([int(rng.integers(1, 600)), int(rng.integers(600, 20000)), 16384, 16385, 131073, 262145]))
+                blocks = [odd_block(rng, B) for _ in range(n)]
+            else:
+                blocks = [make_block(rng, B) for _ in range(n)]
             accel = int(rng.choice([1, 1, 2, 9, 50, 300]))
             got = c.compress_blocks(METHOD_LZ4, accel, blocks)
             for i in range(n):
