@@ -118,6 +118,17 @@ def main():
                     streams["streams"].append({"method": "zstd", "param": lvl, "B": B, "dist": dist, "block": 0,
                                                "raw_sha256": sha(raw), "data": b64(z)})
 
+    # the deep zstd levels (round 3: lazy2 at 10, btlazy2 at 12 / 15, btopt at 13 / 16, btultra at 16 / 18, btultra2 at 19): sizes
+    # and hashes only, after the older cells so that those keep their order
+    for B, levels, blks in ((131072, (10, 12, 13, 16, 19), (0, 1)), (1 << 20, (12, 15, 16, 18, 19), (0,))):
+        for dist in DISTS:
+            for blk in blks:
+                raw = ora.synth(SEED, blk, B, dist)
+                for lvl in levels:
+                    c = stock.zstd_compress(raw, lvl)
+                    vectors["cells"].append({"method": "zstd", "param": lvl, "B": B, "dist": dist, "block": blk,
+                                             "raw_sha256": sha(raw), "csize": int(len(c)), "comp_sha256": sha(c)})
+
     # ---- adversarial decode vectors: verdict of the real library on malformed input ----
     adv = {"note": "ok = library returned exactly B bytes; out_sha256 then pins the decoded bytes "
                    "(dst pre-filled with 0xA5)", "cases": []}
