@@ -35,3 +35,17 @@ def test_zstd_oracle_roundtrip_synthetic(seed, dist, level):
     c = ORA.zstd_compress(raw, level)
     r, out = ORA.zstd_decompress(c, 20000)
     assert r == 20000 and np.array_equal(out, raw)
+
+
+def test_short_differential_hunt_of_the_encoder_oracles():
+    """a few seconds of tests/hunt_oracle.py inside the suite (zstd at random levels -5 .. 22, LZ4 at random accelerations, on
+    tiny / boundary-size / structured / few-sequence / sparse blocks): the oracle equals the live libraries"""
+    import subprocess, sys, os
+    import oracle_lib
+    st = oracle_lib.StockLibs()
+    if st.zstd is None or st.lz4 is None:
+        pytest.skip("stock libraries not loadable")
+    here = os.path.dirname(os.path.abspath(__file__))
+    for mode in ("zstd", "lz4"):
+        r = subprocess.run([sys.executable, os.path.join(here, "hunt_oracle.py"), "4", "7", mode], capture_output=True, text=True, cwd="/tmp")
+        assert r.returncode == 0 and "hunt ok" in r.stdout, r.stdout + r.stderr
