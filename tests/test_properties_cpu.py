@@ -41,6 +41,7 @@ def test_short_differential_hunt_of_the_encoder_oracles():
     """a few seconds of tests/hunt_oracle.py inside the suite (zstd at random levels -5 .. 22, LZ4 at random accelerations, on
     tiny / boundary-size / structured / few-sequence / sparse blocks): the oracle equals the live libraries"""
     import subprocess, sys, os
+    import pytest
     import oracle_lib
     st = oracle_lib.StockLibs()
     if st.zstd is None or st.lz4 is None:
