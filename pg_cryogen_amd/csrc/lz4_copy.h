@@ -83,6 +83,86 @@ __device__ inline void lane_runs(uint8_t *ring, const uint8_t *sbase, uint32_t r
     }
 }
 
+#ifndef CRYO_COPY_V2
+#define CRYO_COPY_V2 0 /* round 4 experiment: all lane-run reads of a batch before its first write (loses 6 %, profiles/r04_lz4_decode_ab.txt) */
+#endif
+#ifndef CRYO_MS_V2
+#define CRYO_MS_V2 0   /* round 4 experiment: match space resolved four chunks at a time by fixed-point rounds (loses: chains are deep) */
+#endif
+
+/* the 8/4/2/1-byte pieces of a run shorter than 16 bytes, from registers (exact to the byte) */
+template <uint32_t R>
+__device__ inline void lane_tail_pieces(uint8_t *ring, uint4 v, const uint32_t rem, uint32_t di, uint32_t &spill)
+{
+    if (di + rem > R) spill = di + rem - R;
+    if (rem & 8u) { __builtin_memcpy(ring + di, &v.x, 8); di += 8u; v.x = v.z; v.y = v.w; }
+    if (rem & 4u) { __builtin_memcpy(ring + di, &v.x, 4); di += 4u; v.x = v.y; }
+    if (rem & 2u) { const uint16_t h = (uint16_t)v.x; __builtin_memcpy(ring + di, &h, 2); di += 2u; v.x >>= 16; }
+    if (rem & 1u) ring[di] = (uint8_t)v.x;
+}
+template <uint32_t R, uint32_t N, typename T>
+__device__ inline void lane_store(uint8_t *ring, const uint32_t dv, const T &v, uint32_t &spill)
+{
+    const uint32_t di = dv & (R - 1u);
+    __builtin_memcpy(ring + di, &v, N);
+    if (di + N > R) spill = di + N - R;
+}
+
+/*
+ * The lane-per-sequence copies of a batch, round 4 form.  A wave's time per batch is a chain of dependent LDS round
+ * trips (~300 cycles each with 24 waves per CU on the LDS), not instructions: the loop below it (lane_runs: read 16,
+ * wait, write 16, again; then the same for the matches) took three to five trips for runs of 20-32 bytes and matches of
+ * 5-12.  Here every read of the common shapes -- a literal run's first 16 bytes, its last 16 when it has 17..32, an
+ * independent match's first 16 -- is issued before the first write: one trip.  Writes are exact to the byte: a run of
+ * 17..32 is two 16-byte stores that overlap, a match of 8..15 two 8-byte stores, of 4..7 two 4-byte stores (LZ4 has no
+ * shorter match; zstd's 3-byte ones take the piece ladder).  Whatever is longer goes on from byte 16 in lane_runs.
+ */
+template <uint32_t R>
+__device__ inline void lane_copies_v2(uint8_t *ring, const uint8_t *in, const uint32_t L, const uint32_t lpos, const uint32_t dl,
+                                      const uint32_t ML, const uint32_t msrc, const uint32_t dm, const bool isfar,
+                                      const uint4 xfa, const uint4 xfb, uint32_t &spill)
+{
+    uint4 la = make_uint4(0, 0, 0, 0), lc = la, ma = xfa;
+    const bool l2 = L > 16u && L <= 32u;
+    if (L != 0u) __builtin_memcpy(&la, in + (lpos & kInMask), 16);
+    if (l2) __builtin_memcpy(&lc, in + ((lpos + L - 16u) & kInMask), 16);
+    if (ML != 0u && !isfar) __builtin_memcpy(&ma, ring + (msrc & (R - 1u)), 16);
+    /* literals */
+    if (L >= 16u) lane_store<R, 16>(ring, dl, la, spill);
+    if (l2) lane_store<R, 16>(ring, dl + L - 16u, lc, spill);
+    /* matches */
+    if (ML == 16u || (ML > 16u && isfar)) lane_store<R, 16>(ring, dm, ma, spill);
+    if (ML >= 8u && ML < 16u) {
+        const uint32_t s = ML - 8u; /* bytes s .. s+7 of the sixteen */
+        const bool hi = s >= 4u;
+        const uint32_t a = hi ? ma.y : ma.x, b = hi ? ma.z : ma.y, c = hi ? ma.w : ma.z;
+        const uint2 head = make_uint2(ma.x, ma.y);
+        const uint2 tail = make_uint2(__builtin_amdgcn_alignbyte(b, a, s), __builtin_amdgcn_alignbyte(c, b, s));
+        lane_store<R, 8>(ring, dm, head, spill);
+        lane_store<R, 8>(ring, dm + s, tail, spill);
+    }
+    if (ML >= 4u && ML < 8u) {
+        const uint32_t s = ML - 4u;
+        const uint32_t tail = __builtin_amdgcn_alignbyte(ma.y, ma.x, s);
+        lane_store<R, 4>(ring, dm, ma.x, spill);
+        lane_store<R, 4>(ring, dm + s, tail, spill);
+    }
+    /* the rare shapes */
+    const bool lshort = L != 0u && L < 16u, mshort = ML != 0u && ML < 4u;
+    if (__any(lshort | mshort)) {
+        if (lshort) lane_tail_pieces<R>(ring, la, L, dl & (R - 1u), spill);
+        if (mshort) lane_tail_pieces<R>(ring, ma, ML, dm & (R - 1u), spill);
+    }
+    if (__any(L > 32u)) {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        lane_runs<R, kInMask>(ring, in, L > 32u ? L - 16u : 0u, lpos + 16u, dl + 16u, false, z, z, spill);
+    }
+    if (__any(ML > 16u)) { /* a far match is at most 32 bytes: its second half is xfb; a near one starts over (16-byte steps) */
+        const uint32_t done = isfar ? 16u : 0u;
+        lane_runs<R, R - 1u>(ring, ring, ML > 16u ? ML - done : 0u, msrc + done, dm + done, isfar, xfb, xfb, spill);
+    }
+}
+
 /*
  * Copy the bytes of up to 64 sequences (lane i < nseq holds sequence i).
  *   ostart: first output byte of the sequence inside the batch; ll literal bytes from virtual input position
@@ -135,11 +215,16 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
     {
         uint32_t spill = 0; /* bytes this lane wrote beyond the ring's end */
         const uint4 z = make_uint4(0, 0, 0, 0);
+#if CRYO_COPY_V2
+        (void)z;
+        lane_copies_v2<R>(L.ring, L.in, act ? ll : 0u, lpos, op0 + ostart, indep ? ml : 0u, op0 + mrel - off, op0 + mrel, isfar, xfa, xfb, spill);
+#else
         if (!(CRYO_ABL & 8))
         lane_runs<R, kInMask>(L.ring, L.in, act ? ll : 0u, lpos, op0 + ostart, false, z, z, spill);
         /* (the 16 bytes behind the ring mirror its first 16 for reads that start in its last 15: lz4_seq_batch) */
         if (!(CRYO_ABL & 16))
         lane_runs<R, R - 1u>(L.ring, L.ring, indep ? ml : 0u, op0 + mrel - off, op0 + mrel, isfar, xfa, xfb, spill);
+#endif
         /* a batch crosses the ring's end at most once: fold the bytes that ran over back to the start */
         const unsigned long long sm = __ballot(spill != 0u);
         if (sm != 0ull) {
@@ -193,6 +278,42 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
                     pendv[u] = a && ra[u] >= d0;
                 }
             }
+#if CRYO_MS_V2
+            /* The group's four chunks together (round 4).  Taken one after the other, each chunk cost a trip for its
+             * first copy and one per frontier round (1.94): twelve trips per batch.  Now: one copy of all 256 bytes,
+             * then the bytes whose source lies inside the group's own span are copied again, all of them, until a round
+             * changes nothing.  Sources lie strictly below their destinations, so after round r every byte whose chain
+             * of sources is r links deep is final and stays so, and a round without a change is the fixed point: rounds
+             * = the deepest chain inside the group + 1, whatever the chunk boundaries. */
+            {
+                const uint32_t D0 = uni(da[0]);
+                uint8_t *dp[U];
+                const uint8_t *sp[U];
+                uint32_t x[U];
+                bool pend[U];
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) {
+                    dp[u] = &L.ring[da[u] & (R - 1u)];
+                    sp[u] = &L.ring[ra[u] & (R - 1u)];
+                    pend[u] = actv[u] && ra[u] >= D0;
+                    if ((c0 + u) * 64u < MT) st.chunks++;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) x[u] = *sp[u];
+#pragma unroll
+                for (uint32_t u = 0; u < U; u++) if (actv[u]) *dp[u] = (uint8_t)x[u];
+                bool more = pend[0] | pend[1] | pend[2] | pend[3];
+                while (__any(more)) {
+                    st.rounds++;
+                    uint32_t y[U];
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) { y[u] = x[u]; if (pend[u]) y[u] = *sp[u]; }
+                    more = (y[0] != x[0]) | (y[1] != x[1]) | (y[2] != x[2]) | (y[3] != x[3]);
+#pragma unroll
+                    for (uint32_t u = 0; u < U; u++) { if (pend[u]) *dp[u] = (uint8_t)y[u]; x[u] = y[u]; }
+                }
+            }
+#else
 #pragma unroll
             for (uint32_t u = 0; u < U; u++) {
                 if ((c0 + u) * 64u < MT) {
@@ -217,6 +338,7 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
                     }
                 }
             }
+#endif
         }
     }
     stamp(st, 6);

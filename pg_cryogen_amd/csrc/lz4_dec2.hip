@@ -28,6 +28,15 @@
 #include <cstdio>
 #include <cstdlib>
 
+#ifndef CRYO_DEC_R
+#define CRYO_DEC_R 4096   /* output ring of a decoding wave */
+#endif
+#ifndef CRYO_DEC_WPB
+#define CRYO_DEC_WPB 4    /* waves (blocks) per workgroup */
+#endif
+#ifndef CRYO_DEC_OCC
+#define CRYO_DEC_OCC 6
+#endif
 namespace cryo {
 
 /* ---------------------------------------------------------------------------------------------
@@ -130,7 +139,10 @@ __device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const CopyLds<R, kT2> &L, u
     /* the next batch's positions are requested now: their trip to memory hides behind this batch's copy */
     epre = 0;
     if (n0 + nseq + lane < ntab) epre = trow[n0 + nseq + lane];
-    /* ... and so are the sources of its far matches (flushed output: off >= T + 1023 behind a match) */
+    /* ... and so are the sources of its far matches (flushed output: off >= T + 1023 behind a match).  (Round 4 tried
+     * them first, as assembly loads with a counted wait behind the literal copy instead of the compiler's vmcnt(0):
+     * 3 % slower -- the kernel is bound by instruction issue and LDS cycles, not by this wait;
+     * profiles/r04_lz4_decode_ab.txt.) */
     uint4 xfa = make_uint4(0, 0, 0, 0), xfb = xfa;
     if (lane < nseq && isfar && !(st.ablate & 1u)) {
         const uint8_t *g = w.dst + (mabs - off);
@@ -251,8 +263,10 @@ __device__ inline uint32_t lz4_general_seq(Wave<R> &w, uint32_t &vp, const uint3
     return 0u;
 }
 
-template <uint32_t R, bool STATS>
-__global__ void __launch_bounds__(256, 6)
+constexpr uint32_t kDecR = CRYO_DEC_R, kDecWpb = CRYO_DEC_WPB;
+
+template <uint32_t R, bool STATS, uint32_t WPB>
+__global__ void __launch_bounds__(64 * WPB, CRYO_DEC_OCC)
 k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
               const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
               uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats,
@@ -262,10 +276,10 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     Stats st = {};
     st.on = STATS;
     if (STATS) { st.ablate = (uint32_t)stats[7]; st.t0 = __builtin_amdgcn_s_memtime(); }
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[4][R + 16];
-    __shared__ __attribute__((aligned(16))) uint8_t s_in[4][kInRing + 16];
-    __shared__ __attribute__((aligned(8))) uint32_t s_mmeta[4][64]; /* packed: 26 880 bytes per workgroup, six per CU */
-    __shared__ __attribute__((aligned(8))) uint32_t s_mbm[4][CopyLds<R, kT2>::kWords];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[WPB][R + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t s_in[WPB][kInRing + 16];
+    __shared__ __attribute__((aligned(8))) uint32_t s_mmeta[WPB][64]; /* packed: 26 880 bytes per workgroup of four waves at R = 4096, six per CU */
+    __shared__ __attribute__((aligned(8))) uint32_t s_mbm[WPB][CopyLds<R, kT2>::kWords];
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = uni(threadIdx.x >> 6);
@@ -388,7 +402,7 @@ static void launch_dec_seq(hipStream_t s, const uint8_t *d_src, const uint64_t *
 {
     const uint16_t *tbl = static_cast<const uint16_t *>(ws);
     const uint2 *seg = reinterpret_cast<const uint2 *>(static_cast<const uint8_t *>(ws) + Lx.seg_off);
-    hipLaunchKernelGGL((k_lz4_dec_seq<4096, false>), dim3((uint32_t)((n_blocks + 3) / 4)), dim3(256), 0, s, d_src, d_src_off, d_src_size,
+    hipLaunchKernelGGL((k_lz4_dec_seq<kDecR, false, kDecWpb>), dim3((uint32_t)((n_blocks + kDecWpb - 1) / kDecWpb)), dim3(64 * kDecWpb), 0, s, d_src, d_src_off, d_src_size,
                        d_dst, dst_stride, block_size, n_blocks, d_status, nullptr, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext,
                        Lx.logS != 0u ? 1u : 0u, d_done);
 }
@@ -408,12 +422,12 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
                                          size_t workspace_bytes, uint32_t walkers)
 {
     if (n_blocks == 0) return hipSuccess;
-    const uint64_t grid = (n_blocks + 3) / 4;
+    const uint64_t grid = (n_blocks + kDecWpb - 1) / kDecWpb;
     if (grid > 0x7fffffffull || !d_workspace) return hipErrorInvalidValue;
     const Lz4IndexLayout Lx = lz4_index_layout(n_blocks, block_size, walkers);
     if (workspace_bytes < Lx.bytes) return hipErrorInvalidValue;
     if (hipError_t e = launch_lz4_index(s, d_src, d_src_off, d_src_size, n_blocks, block_size, d_workspace, Lx); e != hipSuccess) return e;
-    const dim3 g((uint32_t)grid), b(256);
+    const dim3 g((uint32_t)grid), b(64 * kDecWpb);
 #ifdef CRYO_DEBUG
     /* phase timing and ablation of the decoder (profiles/scripts): a debug build only -- an ablated run decodes wrong bytes */
     static const bool want_stats = getenv("CRYO_LZ4_STATS") != nullptr;
@@ -423,7 +437,7 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
         static const unsigned long long abl = getenv("CRYO_LZ4_ABLATE") ? strtoull(getenv("CRYO_LZ4_ABLATE"), nullptr, 0) : 0ull;
         (void)hipMemcpyAsync(d_st + 7, &abl, sizeof abl, hipMemcpyHostToDevice, s);
-        hipLaunchKernelGGL((k_lz4_dec_seq<4096, true>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
+        hipLaunchKernelGGL((k_lz4_dec_seq<kDecR, true, kDecWpb>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
                            block_size, n_blocks, d_status, d_st, static_cast<const uint16_t *>(d_workspace), Lx.cap,
                            reinterpret_cast<const uint2 *>(static_cast<const uint8_t *>(d_workspace) + Lx.seg_off), Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, 0u, nullptr);
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);

@@ -37,6 +37,9 @@ namespace cryo {
 #ifndef CRYO_IDX_RING
 #define CRYO_IDX_RING 512
 #endif
+#ifndef CRYO_IDX_DIST
+#define CRYO_IDX_DIST 2 /* rounds between the request of a chunk and its store into the ring (1 or 2) */
+#endif
 constexpr uint32_t kIdxLanes = 64, kIdxChunk = 128, kIdxRing = CRYO_IDX_RING;
 constexpr uint32_t kIdxStride = kIdxRing + 16u; /* bank skew between rings */
 
@@ -140,18 +143,26 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
 #undef IDX_SRC
     const uint32_t rb = lane * kIdxStride; /* this lane's ring inside s_ring */
 
-    /* chunks on their way: two per turn, committed one round later (a lane with room in its ring requests one chunk
-     * per round; two rounds of distance were measured equal within noise -- 8.81 against 8.94 ms per headline call --
-     * and cost twice the slot registers and predicate masks, which the compiler spilled).
+    /* Chunks on their way: two per turn, committed kIdxDist rounds later.  The loads are inline assembly with the
+     * waits written by hand (round 4).  Written as plain C++ loads the compiler kept the eight chunks of a round in one
+     * set of registers and copied them into a second set at the top of the loop -- and a copy needs the data, so it put
+     * s_waitcnt vmcnt(7) ... vmcnt(0) in front of the copies: every round began by draining the loads the previous turn
+     * had issued a few hundred cycles earlier, a whole trip to memory exposed per round on a wave that has its SIMD to
+     * itself (39 % of the wave's cycles were SQ_WAIT_ANY, profiles/r03_lz4_dec_sq.json).  vmcnt counts in issue order:
+     * a round issues 2 stores (IDX_PUT) + 4 x 2 loads, so when turn j commits what it requested kIdxDist rounds ago,
+     * exactly 10 * kIdxDist - 2 younger operations may still be in flight.
      * Separate variables, not arrays: the compiler kept an indexed array in scratch memory. */
-#define IDX_SLOT(n) uint4 fd##n = make_uint4(0, 0, 0, 0), fe##n = fd##n; uint32_t fa##n = 0, fb##n = 0;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#define IDX_SLOT(n) u32x4 fd##n = {0, 0, 0, 0}, fe##n = fd##n; uint32_t fa##n = kIdxLanes * kIdxStride + lane * 16u, fb##n = fa##n; /* nothing requested yet: the trash slot */
     IDX_SLOT(0) IDX_SLOT(1) IDX_SLOT(2) IDX_SLOT(3)
+#if CRYO_IDX_DIST == 2
+    IDX_SLOT(4) IDX_SLOT(5) IDX_SLOT(6) IDX_SLOT(7)
+#endif
 #undef IDX_SLOT
-    fa0 = fb0 = fa1 = fb1 = fa2 = fb2 = fa3 = fb3 = kIdxLanes * kIdxStride + lane * 16u; /* nothing requested yet: the trash slot */
 
-    uint32_t out128 = 0; /* 128 while a chunk of this lane is on its way (one round), else 0 */
+    uint32_t outA = 0, outB = 0; /* 128 while a chunk of this lane is on its way in slot set A / B, else 0 */
     constexpr uint32_t kTrash = kIdxLanes * kIdxStride; /* s_ring + kTrash + 16 * lane: where a slot that asked for nothing commits */
-    auto turn = [&](const uint32_t j, uint4 &fd, uint4 &fe, uint32_t &fa, uint32_t &fb,
+    auto turn = [&](const uint32_t j, u32x4 &fd, u32x4 &fe, uint32_t &fa, uint32_t &fb, uint32_t &out128,
                     const uint64_t soff, const uint32_t sve, const uint64_t soff2, const uint32_t sve2) __attribute__((always_inline)) {
         const bool myturn = (lane >> 4) == j; /* lanes 16j..16j+15 */
         /* ---- commit what the slot's loads of a round ago brought (to the trash slot if they were idle re-reads) ----
@@ -159,8 +170,9 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
          * && / || / if the compiler built exec-mask branches around one- and two-instruction bodies, 450 scalar mask
          * instructions per round of 1160; a lone wave per SIMD issues one instruction per four cycles whatever its kind,
          * so the pass is as long as its instruction count (round 3: 3.06 -> 2.4 ms for the headline batch). */
-        *reinterpret_cast<uint4 *>(s_ring + fa) = fd;
-        *reinterpret_cast<uint4 *>(s_ring + fb) = fe;
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 * CRYO_IDX_DIST - 2) : "memory");
+        *reinterpret_cast<u32x4 *>(s_ring + fa) = fd;
+        *reinterpret_cast<u32x4 *>(s_ring + fb) = fe;
         {
             const uint32_t got = myturn ? out128 : 0u; /* this lane's chunk, if it asked for one, is in its ring now */
             filled += got;
@@ -186,8 +198,10 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             /* always two loads per turn (a lane with nothing to fetch re-reads its stream's first 16 bytes): with a
              * fixed number of vector-memory operations per turn the compiler can wait for exactly the chunks it
              * commits (vmcnt(N)); a conditional load made it drain the queue once per round (2.3 us a round) */
-            fd = *reinterpret_cast<const uint4 *>(src_base + (soff + ((p1 & (o1 < sve)) ? o1 : 0u)));
-            fe = *reinterpret_cast<const uint4 *>(src_base + (soff2 + ((p2 & (o2 < sve2)) ? o2 : 0u)));
+            const uint8_t *g1 = src_base + (soff + ((p1 & (o1 < sve)) ? o1 : 0u));
+            const uint8_t *g2 = src_base + (soff2 + ((p2 & (o2 < sve2)) ? o2 : 0u));
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(fd) : "v"(g1)); /* "+": the slot keeps its registers round after round (see above) */
+            asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(fe) : "v"(g2));
         }
         /* ---- one hop, branch-free for the two common states (token, match-length extension) ---- */
         {
@@ -253,7 +267,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
                         /* restart the ring at the chunk of pos; a chunk still on its way lands in a slot that is
                          * rewritten before it is read, and is not counted */
                         requested = filled = pos & ~(kIdxChunk - 1u);
-                        out128 = 0;
+                        outA = outB = 0;
                     } else if (state == 1u && live && canread) {
                         if (n == 4u) { acc += 1020u; pos += 4u; if (acc >= vend) done = true; }
                         else {
@@ -297,14 +311,23 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             *reinterpret_cast<uint4 *>(pd_ + 8) = v1_;                                                       \
         }                                                                                                    \
     }
-#define IDX_TURN(j, n, sa, sb) turn(j, fd##n, fe##n, fa##n, fb##n, saoff##sa, svend##sa, saoff##sb, svend##sb);
-#define IDX_ROUND(a, b, c, d)                                   \
+#define IDX_TURN(j, n, o, sa, sb) turn(j, fd##n, fe##n, fa##n, fb##n, o, saoff##sa, svend##sa, saoff##sb, svend##sb);
+#define IDX_ROUND(a, b, c, d, o)                                \
     IDX_PUT()                                                   \
-    IDX_TURN(0, a, 0, 1) IDX_TURN(1, b, 2, 3) IDX_TURN(2, c, 4, 5) IDX_TURN(3, d, 6, 7)
+    IDX_TURN(0, a, o, 0, 1) IDX_TURN(1, b, o, 2, 3) IDX_TURN(2, c, o, 4, 5) IDX_TURN(3, d, o, 6, 7)
+#if CRYO_IDX_DIST == 2
+#define IDX_ROUNDS() IDX_ROUND(0, 1, 2, 3, outA) IDX_ROUND(4, 5, 6, 7, outB)
+#else
+#define IDX_ROUNDS() IDX_ROUND(0, 1, 2, 3, outA)
+#endif
+    /* (the compiler does not see the assembly loads: nothing it generates behind a walk may meet one still in flight) */
 #define IDX_WALK()                                              \
-    while (__any(!done)) {                                      \
-        IDX_ROUND(0, 1, 2, 3)                                   \
+    if (__any(!done)) {                                         \
+        do {                                                    \
+            IDX_ROUNDS()                                        \
+        } while (__any(!done));                                 \
     }                                                           \
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            \
     if (walker) IDX_FLUSH()
 
     /* ---- phase 1: every walker its own segment ---- */
@@ -371,7 +394,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             const bool redo = gfail && walker && sw == 0u;
             pos = delta;
             requested = filled = 0;
-            out128 = 0; /* a chunk still on its way is not counted */
+            outA = outB = 0; /* a chunk still on its way is not counted */
             state = 0; acc = 0; tm = 0; k = 0; ls = 0;
             stop = vend;
             kcap = S * cap_s - ext;
@@ -384,6 +407,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
         }
     }
 #undef IDX_WALK
+#undef IDX_ROUNDS
 #undef IDX_ROUND
 #undef IDX_TURN
 #undef IDX_FLUSH
