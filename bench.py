@@ -469,6 +469,21 @@ def main():
                                "frac": round(algo / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), "traffic": None,
                                "kernel": "zstd decode pipeline + lz4 decode (one step)", "avg_launch_ms": round(avg_ms, 4),
                                "algorithmic_bytes_per_launch": algo}
+            if want_cpu:   # the stock libraries over a sample of each half: the rate of a host decoding such a mixed batch
+                kz = list(range(0, ne, max(1, ne // max(1, ncpu // 2))))[:max(1, ncpu // 2)]
+                kl = list(range(0, no, max(1, no // max(1, ncpu // 2))))[:max(1, ncpu // 2)]
+                zc = [d_zs.download(int(zsz[k]), offset=k * stride) for k in kz]
+                lc = [d_lz.download(int(lzsz[k]), offset=k * stride) for k in kl]
+                dz = cpu_baseline(ora, np, 1, False, zl, zc, [len(c) for c in zc], B)
+                dl = cpu_baseline(ora, np, 0, False, acc, lc, [len(c) for c in lc], B)
+                pair = lambda x, y: round(2.0 / (1.0 / x + 1.0 / y), 3)   # equal uncompressed bytes in both halves
+                cb = {"unit": "GB/s", "cores": 1, "kind": dz["kind"], "value": pair(dz["value"], dl["value"]),
+                      "sample": "%d zstd-22 + %d lz4-50 streams of the batch, each half decoded by its stock library; harmonic mean (equal bytes)" % (len(zc), len(lc)),
+                      "zstd": dz, "lz4": dl}
+                if "all_cores_value" in dz and "all_cores_value" in dl:
+                    cb["all_cores_value"] = pair(dz["all_cores_value"], dl["all_cores_value"])
+                    cb["threads"] = dz["threads"]
+                out["cpu_baseline"] = cb
             print(json.dumps(out), flush=True)
 
     for b in bufs:

@@ -180,7 +180,7 @@ int cryo_codec_decompress_blocks_to(cryo_codec *c, int method,
  *      With CRYO_OPT_POOL_BYTES > 0 the decoded blocks of keyed calls stay in HBM (first in, first out).  A key is the
  *      caller's identity of a block -- the host cache passes (relation oid << 32 | first block number), the key of
  *      reference cache.c:37-47 -- and 0 means "do not keep".  A block found in the pool with the same compressed size and
- *      fingerprint (first, middle and last 8 bytes of the stream) is copied back from HBM: nothing travels towards the
+ *      the same 64-bit hash of its whole compressed stream is copied back from HBM: nothing travels towards the
  *      device and no kernel decodes it.  A relation that is rewritten or truncated must be dropped with
  *      cryo_codec_pool_invalidate (reference: the relcache callback, pg_cryogen.c:163-167). ---- */
 int cryo_codec_decompress_blocks_keyed(cryo_codec *c, int method, const uint64_t *keys,

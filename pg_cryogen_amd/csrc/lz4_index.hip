@@ -378,7 +378,10 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
                 }
             }
         }
-        /* the descriptor of segment s comes from the lane on its left */
+        /* the descriptor of segment s comes from the lane on its left.  The skip count travels in 16 bits: a hand-over
+         * deeper than 65 535 records into the neighbour's segment (two walkers on a 1 MiB block of dense sequences can get
+         * there) counts as a boundary that did not meet, and phase 3 walks the block with one walker */
+        fail = fail || (inner && j > 0xffffu);
         const uint32_t mine = fail ? 0xffffffffu : ((inner ? L : 0u) | ((inner ? j : 0u) << 16));
         const uint32_t left = from_prev(mine);
         const unsigned long long fm = __ballot(fail);

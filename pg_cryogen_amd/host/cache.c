@@ -30,10 +30,10 @@ void cryo_cache_shutdown(void)
 
 int cryo_cache_configure(int n)
 {
-    const CryoCodecOps *ops = cryo_host_codec_ops();
-    Size worst = cryo_blcksz + cryo_blcksz / 255 + 16; /* >= either codec's bound */
+    /* sized at _PG_init (cryo_init_cache): nothing here may open the GPU */
+    const Size ba = cryo_host_codec_bound(COMP_LZ4, cryo_blcksz), bb = cryo_host_codec_bound(COMP_ZSTD, cryo_blcksz);
+    const Size worst = ba > bb ? ba : bb;
     int i;
-    if (ops) { Size a = ops->bound(COMP_LZ4, cryo_blcksz), b = ops->bound(COMP_ZSTD, cryo_blcksz); worst = a > b ? a : b; }
     cryo_cache_shutdown();
     if (n < 1) return -1;
     slots = calloc((size_t)n, sizeof *slots);
@@ -322,12 +322,15 @@ void cryo_cache_release(CacheEntry entry)
     slots[entry].pinned = false;
 }
 
+/* The relcache callback of reference pg_cryogen.c:163-167.  relid == InvalidOid is what PostgreSQL passes after a
+ * sinval-queue reset ("anything may have changed"): every unpinned slot, and every entry of the device pool.  Uses the
+ * codec binding only if this backend has one already (never opens the GPU from inside an invalidation). */
 void cryo_cache_invalidate_relation(Oid relid)
 {
-    const CryoCodecOps *ops = slots ? cryo_host_codec_ops() : NULL;
+    const CryoCodecOps *ops = cryo_host_codec_ops_if_open();
     int i;
     for (i = 0; i < nslots; i++)
-        if (slots[i].relid == relid && !slots[i].pinned) slots[i].ts = 0;
+        if ((relid == InvalidOid || slots[i].relid == relid) && !slots[i].pinned) slots[i].ts = 0;
     if (ops && ops->pool_invalidate) ops->pool_invalidate(ops->ctx, (uint32_t)relid); /* the device-resident copies too */
 }
 

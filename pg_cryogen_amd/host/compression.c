@@ -36,6 +36,7 @@ Size cryo_blcksz = (Size)1 << 20; /* CRYO_BLCKSZ, reference storage.h:18 */
  * dispatcher of include/cryo_codec.h (block i of a call -> GPU i mod G, one host thread per GPU). */
 static cryo_multi *hip_multi;
 static int hip_multi_first = -1, hip_multi_count = 0, hip_pool_mb = 0;
+static int hip_open_failed, hip_failed_first = -1, hip_failed_count = 0; /* a failed open is remembered until the GUCs change */
 static char codec_err[320];
 
 static size_t hip_bound(int method, size_t n) { return cryo_codec_bound(method, n); }
@@ -62,7 +63,8 @@ static int hip_decompress_blocks_keyed(void *ctx, int method, const uint64_t *ke
 {
     return cryo_multi_decompress_blocks_keyed((cryo_multi *)ctx, method, keys, src, sz, n, dst, bs, st);
 }
-static void hip_pool_invalidate(void *ctx, uint32_t relid) { (void)cryo_multi_pool_invalidate((cryo_multi *)ctx, relid, 0); }
+/* relid 0 (InvalidOid): PostgreSQL's relcache callback after a sinval-queue reset -- "anything may have changed": every entry */
+static void hip_pool_invalidate(void *ctx, uint32_t relid) { (void)cryo_multi_pool_invalidate((cryo_multi *)ctx, relid, relid == 0u); }
 
 static CryoCodecOps hip_ops = {hip_bound, hip_compress_blocks, hip_decompress_blocks, NULL, hip_decompress_blocks_scatter,
                                hip_decompress_blocks_keyed, hip_pool_invalidate};
@@ -81,8 +83,14 @@ const CryoCodecOps *cryo_host_codec_ops(void)
         hip_multi = NULL;
     }
     if (!hip_multi) {
-        int devs[64], i, ndev = cryo_codec_device_count(), rc;
+        int devs[64], i, ndev, rc;
         int cnt = cryo_gpu_count_guc < 1 ? 1 : (cryo_gpu_count_guc > 64 ? 64 : cryo_gpu_count_guc);
+        /* not again for every call of a backend that cannot have a GPU (codec_err still says why) */
+        if (hip_open_failed && hip_failed_first == cryo_gpu_device_guc && hip_failed_count == cryo_gpu_count_guc) return NULL;
+        hip_open_failed = 1;
+        hip_failed_first = cryo_gpu_device_guc;
+        hip_failed_count = cryo_gpu_count_guc;
+        ndev = cryo_codec_device_count();
         if (ndev <= 0) {
             snprintf(codec_err, sizeof codec_err, "no GPU visible to the HIP runtime (%d; no CPU fallback)", ndev);
             return NULL;
@@ -95,6 +103,7 @@ const CryoCodecOps *cryo_host_codec_ops(void)
             hip_multi = NULL;
             return NULL;
         }
+        hip_open_failed = 0;
         hip_multi_first = cryo_gpu_device_guc;
         hip_multi_count = cryo_gpu_count_guc;
         hip_pool_mb = 0;
@@ -105,6 +114,23 @@ const CryoCodecOps *cryo_host_codec_ops(void)
         (void)cryo_multi_set_option(hip_multi, CRYO_OPT_POOL_BYTES, (int64_t)(hip_pool_mb < 0 ? 0 : hip_pool_mb) << 20);
     }
     return &hip_ops;
+}
+
+/* worst-case compressed size of a block: pure arithmetic (cryo_codec_bound), no GPU -- the cache sizes its chain lists with
+ * it at _PG_init (cryo_init_cache, reference pg_cryogen.c:172), long before a backend may ever touch a cryo table */
+size_t cryo_host_codec_bound(int method, size_t n)
+{
+    if (bound_ops) return bound_ops->bound(method, n);
+    return cryo_codec_bound(method, n);
+}
+
+/* The binding if this backend has one already -- never opens the GPU.  For the relcache invalidation callback
+ * (cryo_cache_invalidate_relation), which PostgreSQL fires for every invalidation of any relation in every backend that
+ * loaded the extension: a backend that never touched a cryo table must not pay a HIP context for a sinval message. */
+const CryoCodecOps *cryo_host_codec_ops_if_open(void)
+{
+    if (bound_ops) return bound_ops;
+    return hip_multi ? &hip_ops : NULL;
 }
 
 void cryo_host_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, uint64_t *pool_hits, uint64_t *pool_misses)

@@ -73,6 +73,8 @@ typedef struct CryoCodecOps {
 void cryo_host_set_codec_ops(const CryoCodecOps *ops); /* test builds only: bind a double; NULL restores the HIP binding */
 #endif
 const CryoCodecOps *cryo_host_codec_ops(void);         /* lazily opens the GPU codec */
+size_t cryo_host_codec_bound(int method, size_t n);      /* cryo_codec_bound (or the bound double's): never opens the GPU */
+const CryoCodecOps *cryo_host_codec_ops_if_open(void); /* the binding if there is one already; never opens the GPU */
 const char *cryo_host_codec_error(void);
 
 #endif /* __COMPRESSION_H__ */

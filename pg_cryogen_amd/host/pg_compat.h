@@ -24,6 +24,7 @@ typedef uint64_t uint64;
 typedef uint32 BlockNumber;
 typedef uint32 TransactionId;
 typedef unsigned int Oid;
+#define InvalidOid ((Oid)0)
 
 #define InvalidBlockNumber ((BlockNumber)0xFFFFFFFF)
 #define BlockNumberIsValid(b) ((BlockNumber)(b) != InvalidBlockNumber)

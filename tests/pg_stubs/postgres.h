@@ -16,6 +16,7 @@ typedef uint64_t uint64;
 typedef uint32 BlockNumber;
 typedef uint32 TransactionId;
 typedef unsigned int Oid;
+#define InvalidOid ((Oid)0)
 typedef char *Pointer;
 typedef Pointer Page;
 #define InvalidBlockNumber ((BlockNumber)0xFFFFFFFF)

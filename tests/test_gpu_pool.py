@@ -79,6 +79,21 @@ def test_pool_wraps_replaces_and_never_keeps_bad_blocks(pooled, oracle):
     outs, st = c.decompress_blocks_keyed(METHOD_LZ4, [keys[9]], [other], B)
     assert st[0] == 0 and np.array_equal(outs[0], oracle.synth(44, 0, B, 0))
     assert c.transfer_counters()["pool_hits"] == h0
+    # a rewrite of the SAME compressed size that shares the stream's first, middle and last 8 bytes (what round 3's
+    # 24-byte fingerprint sampled) is a different stream: the whole stream is hashed now, it is decoded again
+    base = oracle.synth(45, 0, B, 3)                                      # incompressible: stored as one literal run
+    twin = base.copy()
+    twin[B // 3] ^= 0x5A
+    cb, ct = oracle.lz4_compress(base, 1), oracle.lz4_compress(twin, 1)
+    n_ = len(cb)
+    assert len(ct) == n_ and np.array_equal(cb[:8], ct[:8]) and np.array_equal(cb[n_ // 2 - 4:n_ // 2 + 4], ct[n_ // 2 - 4:n_ // 2 + 4]) \
+        and np.array_equal(cb[-8:], ct[-8:]) and not np.array_equal(cb, ct)
+    kk = (9 << 32) | 555
+    outs, st = c.decompress_blocks_keyed(METHOD_LZ4, [kk], [cb], B)
+    assert st[0] == 0 and np.array_equal(outs[0], base)
+    h1 = c.transfer_counters()["pool_hits"]
+    outs, st = c.decompress_blocks_keyed(METHOD_LZ4, [kk], [ct], B)
+    assert st[0] == 0 and np.array_equal(outs[0], twin) and c.transfer_counters()["pool_hits"] == h1
     # a corrupt stream is reported, leaves its destination alone and is not kept
     bad = comps[2][:len(comps[2]) // 2].copy()
     outs, st = c.decompress_blocks_keyed(METHOD_LZ4, [(9 << 32) | 77, keys[9]], [bad, other], B)
@@ -136,6 +151,17 @@ def test_host_cache_rescan_served_from_the_device_pool(oracle):
         ids3 = scan()
         d = host.transfer_counters()
         assert ids3 == ids1 and d[3] - c_[3] == k and d[0] > c_[0]
+        # InvalidOid: what PostgreSQL's relcache callback passes after a sinval-queue reset ("anything may have changed"):
+        # every entry of the pool goes (round 3 forwarded it as "relation 0" and dropped nothing)
+        L.cryo_cache_configure(40)
+        ids4 = scan()
+        e_ = host.transfer_counters()
+        assert ids4 == ids1 and e_[2] - d[2] == k and e_[0] == d[0]   # pool hits again
+        L.cryo_cache_invalidate_relation(0)
+        L.cryo_cache_configure(40)
+        ids5 = scan()
+        f_ = host.transfer_counters()
+        assert ids5 == ids1 and f_[3] - e_[3] == k and f_[0] > e_[0], "InvalidOid did not empty the device pool"
         L.cryo_memrel_destroy(mem)
     finally:
         host.set_int("cryo_gpu_pool_mb_guc", 0)

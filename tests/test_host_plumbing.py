@@ -398,3 +398,29 @@ def test_failed_probe_leaves_the_cache_untouched(H):
     assert L.cryo_cache_get_pg_nblocks(e.value) == npg and L.cryo_cache_get_xid(e.value) == xid
     assert fetch_rows(L, L.cryo_cache_get_data(e.value)) == rows
     L.cryo_memrel_destroy(mem)
+
+
+def test_invalidation_callback_never_opens_the_codec():
+    """cryo_cache_invalidate_relation is PostgreSQL's relcache callback (reference pg_cryogen.c:163-167): it fires for
+    every invalidation of any relation in every backend that loaded the extension.  It must use the codec binding only
+    if the backend has one already -- in a fresh process with no GPU the lazy open would fail and leave its message in
+    cryo_host_codec_error(); nothing may have tried."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import os, sys, ctypes as C
+        sys.path.insert(0, %r)
+        os.environ.pop("CRYO_HOST_TEST_HOOKS", None)
+        from pg_cryogen_amd import host
+        host.use(production=True)
+        L = host.lib()
+        L.cryo_host_codec_error.restype = C.c_char_p
+        L.cryo_host_codec_ops_if_open.restype = C.c_void_p
+        L.cryo_cache_configure(4)
+        L.cryo_cache_invalidate_relation(1234)
+        L.cryo_cache_invalidate_relation(0)
+        assert L.cryo_host_codec_error() == b"", L.cryo_host_codec_error()
+        assert not L.cryo_host_codec_ops_if_open()
+        print("ok")
+    """ % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout + r.stderr
