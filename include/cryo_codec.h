@@ -78,9 +78,22 @@ typedef enum {
     CRYO_OPT_POOL_BYTES = 4,
     /* zstd decode path: 0 = automatic (the four-kernel pipeline; the fused kernel for frames its planner does not take),
      * 1 = the fused one-wave-per-frame kernel for everything, 2 = the pipeline */
-    CRYO_OPT_ZSTD_DECODE_PATH = 5
+    CRYO_OPT_ZSTD_DECODE_PATH = 5,
+    /* device workspace kept between calls (the LZ4 sequence index: 2.1 GB for 65 536 x 128 KiB blocks; the zstd decode
+     * tiles: up to 12.8 GiB each, four in flight): the host-buffer calls (cryo_codec_*_blocks*), which end synchronised,
+     * give back what exceeds this many bytes when they return; -1 = keep everything (the default of a bare handle: a
+     * benchmark loop must not reallocate; host/compression.c sets pg_cryogen.gpu_workspace_keep_mb, default 1 GiB) */
+    CRYO_OPT_WORKSPACE_KEEP_BYTES = 6,
+    /* the most device workspace one call may allocate: 0 = automatic (70 % of what hipMemGetInfo reports free plus what
+     * the handle already holds); the zstd decode pipeline runs fewer tiles at once to fit (1 tile at least) */
+    CRYO_OPT_WORKSPACE_MAX_BYTES = 7
 } cryo_option;
 int cryo_codec_set_option(cryo_codec *c, int option, int64_t value);
+/* a long-lived backend between bursts: waits for the handle's queued work, then frees its device workspace, the device and
+ * pinned staging buffers of the host-buffer calls and the single-block scratch (they are grow-only otherwise and come
+ * back with the next call that needs them).  The device-resident pool stays (CRYO_OPT_POOL_BYTES = 0 frees it).
+ * Reference contrast: the CPU libraries hold nothing between calls (compression.c:70-72,102-104 are one-shot). */
+int cryo_codec_trim(cryo_codec *c);
 int cryo_codec_get_option(const cryo_codec *c, int option, int64_t *value);
 
 /* ---- sizes ---- */
@@ -224,6 +237,7 @@ int cryo_multi_decompress_blocks_keyed(cryo_multi *m, int method, const uint64_t
                                        void *const *h_dst, size_t block_size, int32_t *h_status);
 int cryo_multi_set_option(cryo_multi *m, int option, int64_t value);
 int cryo_multi_pool_invalidate(cryo_multi *m, uint32_t key_hi, int all_entries);
+int cryo_multi_trim(cryo_multi *m);
 int cryo_multi_get_transfer_counters(const cryo_multi *m, cryo_codec_transfer_counters *out);
 
 /* ---- batch helpers used by staging, tests and the benchmark ---- */

@@ -22,6 +22,7 @@ _ERR_NAMES = {0: "CRYO_OK", -1: "CRYO_E_ARG", -2: "CRYO_E_HIP", -3: "CRYO_E_NODE
 
 # cryo_option (include/cryo_codec.h)
 OPT_LZ4_DECODE_PATH, OPT_LZ4_INDEX_WALKERS, OPT_PIPE_MIN_BYTES, OPT_POOL_BYTES, OPT_ZSTD_DECODE_PATH = 1, 2, 3, 4, 5
+OPT_WORKSPACE_KEEP_BYTES, OPT_WORKSPACE_MAX_BYTES = 6, 7
 LZ4_PATH_AUTO, LZ4_PATH_RING, LZ4_PATH_INDEXED, LZ4_PATH_FEW_BLOCKS = 0, 1, 2, 3
 
 DIST_WIDE, DIST_NARROW, DIST_INT4, DIST_RANDOM, DIST_ZEROS = range(5)
@@ -41,6 +42,7 @@ ABI_SYMBOLS = [
     "cryo_multi_decompress_blocks_keyed", "cryo_multi_set_option", "cryo_multi_pool_invalidate",
     "cryo_multi_get_transfer_counters",
     "cryo_codec_decompress_blocks_keyed", "cryo_codec_pool_invalidate", "cryo_codec_get_transfer_counters",
+    "cryo_codec_trim", "cryo_multi_trim",
     "cryo_codec_synth_batch", "cryo_codec_checksum_batch",
     "cryo_codec_compare_batch", "cryo_checksum64", "cryo_codec_timer_start",
     "cryo_codec_timer_stop", "cryo_codec_get_counters",
@@ -111,6 +113,8 @@ def lib():
     L.cryo_multi_decompress_blocks_keyed.argtypes = [vp, i32, vp, vp, vp, sz, vp, sz, vp]
     L.cryo_multi_set_option.argtypes = [vp, i32, C.c_int64]
     L.cryo_multi_pool_invalidate.argtypes = [vp, u32, i32]
+    L.cryo_codec_trim.argtypes = [vp]
+    L.cryo_multi_trim.argtypes = [vp]
     L.cryo_multi_get_transfer_counters.argtypes = [vp, C.POINTER(TransferCounters)]
     L.cryo_codec_decompress_blocks_keyed.argtypes = [vp, i32, vp, vp, vp, sz, vp, sz, vp]
     L.cryo_codec_pool_invalidate.argtypes = [vp, u32, i32]
@@ -231,6 +235,9 @@ class Codec:
         t = TransferCounters()
         self._chk(self.L.cryo_codec_get_transfer_counters(self.h, C.byref(t)), "get_transfer_counters")
         return {f: getattr(t, f) for f, _ in TransferCounters._fields_}
+
+    def trim(self):
+        self._chk(self.L.cryo_codec_trim(self.h), "cryo_codec_trim")
 
     def pool_invalidate(self, key_hi=0, everything=False):
         self._chk(self.L.cryo_codec_pool_invalidate(self.h, key_hi, 1 if everything else 0), "pool_invalidate")

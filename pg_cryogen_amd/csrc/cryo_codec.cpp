@@ -137,6 +137,8 @@ struct cryo_codec {
     cryo::Lz4DecodeOpts lz4_opts = {};
     int zstd_path = 0;
     size_t pipe_min_bytes = (size_t)64 << 20;
+    int64_t ws_keep = -1;   /* CRYO_OPT_WORKSPACE_KEEP_BYTES: -1 = keep everything between calls */
+    size_t ws_max = 0;      /* CRYO_OPT_WORKSPACE_MAX_BYTES: 0 = automatic */
     /* staging-copy workers (created by the first K-block call that is large enough to want them) */
     WorkerPool *pool = nullptr;
     /* device-resident block pool (CRYO_OPT_POOL_BYTES): decoded blocks of keyed calls, first in first out */
@@ -261,6 +263,25 @@ void parallel_copy(cryo_codec *c, const std::vector<CopyJob> &jobs)
     c->pool->run(T, share);
 }
 
+/* the most workspace a call may plan for: the option, or 70 % of the free device memory plus what the handle holds */
+size_t ws_budget(cryo_codec *c)
+{
+    if (c->ws_max) return c->ws_max;
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return ~(size_t)0; }
+    return fr / 10u * 7u + c->ws_cap;
+}
+/* host-buffer calls end synchronised: give back the workspace beyond CRYO_OPT_WORKSPACE_KEEP_BYTES */
+void ws_trim_after_call(cryo_codec *c)
+{
+    if (c->ws_keep >= 0 && c->d_ws && c->ws_cap > (size_t)c->ws_keep) {
+        (void)hipStreamSynchronize(c->stream);
+        (void)hipFree(c->d_ws);
+        c->d_ws = nullptr;
+        c->ws_cap = 0;
+    }
+}
+
 int ensure_ws(cryo_codec *c, size_t need)
 {
     if (c->ws_cap >= need) return CRYO_OK;
@@ -297,10 +318,10 @@ int cryo_codec_open(int device, cryo_codec **out)
     cryo_codec *c = new (std::nothrow) cryo_codec;
     if (!c) return CRYO_E_NOMEM;
     c->device = device;
-    if (const char *e = getenv("CRYO_PIPE_MIN_MB")) c->pipe_min_bytes = (size_t)atoll(e) << 20; /* 0 = always, huge = never */
-    if (const char *e = getenv("CRYO_LZ4_DECODE_PATH")) c->lz4_opts.path = atoi(e);             /* tuning aids: the options' */
-    if (const char *e = getenv("CRYO_LZ4_INDEX_WALKERS")) c->lz4_opts.walkers = atoi(e);        /* initial values          */
-    if (const char *e = getenv("CRYO_ZSTD_DECODE_PATH")) c->zstd_path = atoi(e);
+    if (const char *e = cryo_tuning_env("CRYO_PIPE_MIN_MB")) c->pipe_min_bytes = (size_t)atoll(e) << 20; /* 0 = always, huge = never */
+    if (const char *e = cryo_tuning_env("CRYO_LZ4_DECODE_PATH")) c->lz4_opts.path = atoi(e);             /* tuning aids: the options' */
+    if (const char *e = cryo_tuning_env("CRYO_LZ4_INDEX_WALKERS")) c->lz4_opts.walkers = atoi(e);        /* initial values          */
+    if (const char *e = cryo_tuning_env("CRYO_ZSTD_DECODE_PATH")) c->zstd_path = atoi(e);
     DevGuard dev_(c); /* the caller's current device is restored on return */
     hipError_t e = hipSuccess;
     if (!dev_.switched && dev_.prev != device) e = hipSetDevice(device); /* no current device yet, or the switch failed: report it */
@@ -356,6 +377,28 @@ void cryo_codec_close(cryo_codec *c)
 
 const char *cryo_codec_last_error(const cryo_codec *c) { return c ? c->err : ""; }
 
+int cryo_codec_trim(cryo_codec *c)
+{
+    if (!c) return CRYO_E_ARG;
+    DevGuard dev_(c);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->xfer) HIP_TRY(c, hipStreamSynchronize(c->xfer));
+    if (c->have_aux)
+        for (int l = 0; l < cryo::kZstdLanes; l++)
+            if (c->aux.lane[l]) HIP_TRY(c, hipStreamSynchronize(c->aux.lane[l]));
+    auto drop = [](auto *&p, size_t &cap) { if (p) (void)hipFree(p); p = nullptr; cap = 0; };
+    { void *w = c->d_ws; if (w) (void)hipFree(w); c->d_ws = nullptr; c->ws_cap = 0; }
+    drop(c->d_in, c->in_cap);
+    drop(c->d_out, c->out_cap);
+    drop(c->hb_src, c->hb_src_cap);
+    drop(c->hb_dst, c->hb_dst_cap);
+    drop(c->hb_meta, c->hb_meta_cap);
+    if (c->pin) { (void)hipHostFree(c->pin); c->pin = nullptr; c->pin_cap = 0; }
+    for (int i = 0; i < 4; i++)
+        if (c->pipe_pin[i]) { (void)hipHostFree(c->pipe_pin[i]); c->pipe_pin[i] = nullptr; c->pipe_pin_cap[i] = 0; }
+    return CRYO_OK;
+}
+
 int cryo_codec_set_option(cryo_codec *c, int option, int64_t value)
 {
     if (!c) return CRYO_E_ARG;
@@ -375,6 +418,14 @@ int cryo_codec_set_option(cryo_codec *c, int option, int64_t value)
     case CRYO_OPT_ZSTD_DECODE_PATH:
         if (value < 0 || value > 2) return CRYO_E_ARG;
         c->zstd_path = (int)value;
+        return CRYO_OK;
+    case CRYO_OPT_WORKSPACE_KEEP_BYTES:
+        if (value < -1) return CRYO_E_ARG;
+        c->ws_keep = value;
+        return CRYO_OK;
+    case CRYO_OPT_WORKSPACE_MAX_BYTES:
+        if (value < 0) return CRYO_E_ARG;
+        c->ws_max = (size_t)value;
         return CRYO_OK;
     case CRYO_OPT_POOL_BYTES: {
         if (value < 0) return CRYO_E_ARG;
@@ -397,6 +448,8 @@ int cryo_codec_get_option(const cryo_codec *c, int option, int64_t *value)
     case CRYO_OPT_PIPE_MIN_BYTES: *value = (int64_t)c->pipe_min_bytes; return CRYO_OK;
     case CRYO_OPT_POOL_BYTES: *value = (int64_t)c->pool_bytes; return CRYO_OK;
     case CRYO_OPT_ZSTD_DECODE_PATH: *value = c->zstd_path; return CRYO_OK;
+    case CRYO_OPT_WORKSPACE_KEEP_BYTES: *value = c->ws_keep; return CRYO_OK;
+    case CRYO_OPT_WORKSPACE_MAX_BYTES: *value = (int64_t)c->ws_max; return CRYO_OK;
     default: return CRYO_E_ARG;
     }
 }
@@ -522,7 +575,7 @@ int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
                                                (uint8_t *)d_dst, dst_stride, block_size, n_blocks,
                                                d_status, need ? c->d_ws : nullptr, need ? c->ws_cap : 0, c->lz4_opts));
     } else {
-        const size_t need = cryo::zstd_decompress_workspace(n_blocks, block_size, c->zstd_path);
+        const size_t need = cryo::zstd_decompress_workspace(n_blocks, block_size, c->zstd_path, ws_budget(c));
         int rc = ensure_ws(c, need);
         if (rc != CRYO_OK) return rc;
         if (!c->have_aux) {
@@ -853,7 +906,11 @@ static int compress_blocks_body(cryo_codec *c, int method, int param, const void
 int cryo_codec_compress_blocks(cryo_codec *c, int method, int param, const void *h_src, size_t block_size,
                                size_t n, void *h_dst, size_t dst_stride, uint32_t *h_out_size)
 {
-    return guarded([&] { return compress_blocks_body(c, method, param, h_src, block_size, n, h_dst, dst_stride, h_out_size); });
+    return guarded([&] {
+        const int rc = compress_blocks_body(c, method, param, h_src, block_size, n, h_dst, dst_stride, h_out_size);
+        if (c) ws_trim_after_call(c);
+        return rc;
+    });
 }
 
 static int decompress_blocks_impl(cryo_codec *c, int method, const void *const *h_src, const uint32_t *h_src_size,
@@ -934,14 +991,22 @@ int cryo_codec_decompress_blocks(cryo_codec *c, int method, const void *const *h
                                  size_t n, void *h_dst, size_t block_size, int32_t *h_status)
 {
     if (!h_dst) return CRYO_E_ARG;
-    return guarded([&] { return decompress_blocks_impl(c, method, h_src, h_src_size, n, h_dst, nullptr, block_size, h_status); });
+    return guarded([&] {
+        const int rc = decompress_blocks_impl(c, method, h_src, h_src_size, n, h_dst, nullptr, block_size, h_status);
+        if (c) ws_trim_after_call(c);
+        return rc;
+    });
 }
 
 int cryo_codec_decompress_blocks_to(cryo_codec *c, int method, const void *const *h_src, const uint32_t *h_src_size,
                                     size_t n, void *const *h_dst, size_t block_size, int32_t *h_status)
 {
     if (!h_dst) return CRYO_E_ARG;
-    return guarded([&] { return decompress_blocks_impl(c, method, h_src, h_src_size, n, nullptr, h_dst, block_size, h_status); });
+    return guarded([&] {
+        const int rc = decompress_blocks_impl(c, method, h_src, h_src_size, n, nullptr, h_dst, block_size, h_status);
+        if (c) ws_trim_after_call(c);
+        return rc;
+    });
 }
 
 } /* extern "C" */
@@ -1124,7 +1189,11 @@ extern "C" {
 int cryo_codec_decompress_blocks_keyed(cryo_codec *c, int method, const uint64_t *keys, const void *const *h_src,
                                        const uint32_t *h_src_size, size_t n, void *const *h_dst, size_t block_size, int32_t *h_status)
 {
-    return guarded([&] { return decompress_blocks_keyed_impl(c, method, keys, h_src, h_src_size, n, h_dst, block_size, h_status); });
+    return guarded([&] {
+        const int rc = decompress_blocks_keyed_impl(c, method, keys, h_src, h_src_size, n, h_dst, block_size, h_status);
+        if (c) ws_trim_after_call(c);
+        return rc;
+    });
 }
 
 int cryo_codec_pool_invalidate(cryo_codec *c, uint32_t key_hi, int all_entries)
@@ -1355,6 +1424,16 @@ int cryo_multi_set_option(cryo_multi *m, int option, int64_t value)
     const int64_t v = option == CRYO_OPT_POOL_BYTES ? value / (int64_t)m->h.size() : value;
     for (cryo_codec *c : m->h) {
         const int rc = cryo_codec_set_option(c, option, v);
+        if (rc != CRYO_OK) return rc;
+    }
+    return CRYO_OK;
+}
+
+int cryo_multi_trim(cryo_multi *m)
+{
+    if (!m) return CRYO_E_ARG;
+    for (cryo_codec *c : m->h) {
+        const int rc = cryo_codec_trim(c);
         if (rc != CRYO_OK) return rc;
     }
     return CRYO_OK;

@@ -8,6 +8,20 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+
+/* Tuning and debugging switches read from the environment exist in -DCRYO_DEBUG builds only (the A/B builds under
+ * profiles/): the product library reads no environment variable but CRYO_HOST_THREADS (cryo_codec.cpp); what a
+ * deployment may change is a per-handle option (cryo_codec_set_option). */
+static inline const char *cryo_tuning_env(const char *name)
+{
+#ifdef CRYO_DEBUG
+    return getenv(name);
+#else
+    (void)name;
+    return nullptr;
+#endif
+}
 
 namespace cryo {
 
@@ -99,7 +113,8 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
                                   const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                   uint32_t block_size, uint64_t n_blocks, int32_t *d_status,
                                   void *d_workspace, size_t workspace_bytes, const ZstdAux *aux, int path);
-size_t zstd_decompress_workspace(uint64_t n_blocks, uint32_t block_size, int path);
+/* max_bytes: the most the call may use; the pipeline plans fewer tiles in flight to fit (one at least) */
+size_t zstd_decompress_workspace(uint64_t n_blocks, uint32_t block_size, int path, size_t max_bytes = ~(size_t)0);
 /* fused one-wave-per-frame decoder (zstd_dec.hip): small batches, and the pipeline's irregular frames
  * (d_list != nullptr: decode blocks list_base + d_list[0 .. *d_list_n), n_blocks only sizes the grid) */
 hipError_t launch_zstd_fused(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,

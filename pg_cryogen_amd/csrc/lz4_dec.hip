@@ -595,11 +595,11 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
                                              d_status, d_workspace, workspace_bytes, S);
     }
 #ifdef CRYO_DEBUG
-    static const bool want_stats = getenv("CRYO_LZ4_STATS") != nullptr; /* debugging aid */
+    static const bool want_stats = cryo_tuning_env("CRYO_LZ4_STATS") != nullptr; /* debugging aid */
     if (want_stats) {
         const dim3 g((uint32_t)grid), b(256);
         unsigned long long *d_st = nullptr, h_st[16];
-        static const unsigned long long abl = getenv("CRYO_LZ4_ABLATE") ? strtoull(getenv("CRYO_LZ4_ABLATE"), nullptr, 0) : 0ull;
+        static const unsigned long long abl = cryo_tuning_env("CRYO_LZ4_ABLATE") ? strtoull(cryo_tuning_env("CRYO_LZ4_ABLATE"), nullptr, 0) : 0ull;
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
         (void)hipMemcpyAsync(d_st + 7, &abl, sizeof abl, hipMemcpyHostToDevice, s);
@@ -608,9 +608,9 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
         (void)hipFree(d_st);
-        if (!getenv("CRYO_LZ4_QUIET")) fprintf(stderr, "[lz4 stats] batches %llu batch_seqs %llu general_seqs %llu chunks %llu rounds %llu zero_batches %llu\n",
+        if (!cryo_tuning_env("CRYO_LZ4_QUIET")) fprintf(stderr, "[lz4 stats] batches %llu batch_seqs %llu general_seqs %llu chunks %llu rounds %llu zero_batches %llu\n",
                 h_st[0], h_st[1], h_st[2], h_st[3], h_st[4], h_st[5]);
-        if (!getenv("CRYO_LZ4_QUIET")) {
+        if (!cryo_tuning_env("CRYO_LZ4_QUIET")) {
             unsigned long long tot = 0;
             for (int k = 0; k < 8; k++) tot += h_st[8 + k];
             static const char *nm[8] = {"stage+flush", "phase1 tables", "chase+fill", "phase2 meta", "phase3 bitmap", "passA", "passB", "general+other"};

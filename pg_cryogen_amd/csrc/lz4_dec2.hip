@@ -430,12 +430,12 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
     const dim3 g((uint32_t)grid), b(64 * kDecWpb);
 #ifdef CRYO_DEBUG
     /* phase timing and ablation of the decoder (profiles/scripts): a debug build only -- an ablated run decodes wrong bytes */
-    static const bool want_stats = getenv("CRYO_LZ4_STATS") != nullptr;
+    static const bool want_stats = cryo_tuning_env("CRYO_LZ4_STATS") != nullptr;
     if (want_stats) {
         unsigned long long *d_st = nullptr, h_st[32];
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
-        static const unsigned long long abl = getenv("CRYO_LZ4_ABLATE") ? strtoull(getenv("CRYO_LZ4_ABLATE"), nullptr, 0) : 0ull;
+        static const unsigned long long abl = cryo_tuning_env("CRYO_LZ4_ABLATE") ? strtoull(cryo_tuning_env("CRYO_LZ4_ABLATE"), nullptr, 0) : 0ull;
         (void)hipMemcpyAsync(d_st + 7, &abl, sizeof abl, hipMemcpyHostToDevice, s);
         hipLaunchKernelGGL((k_lz4_dec_seq<kDecR, true, kDecWpb>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
                            block_size, n_blocks, d_status, d_st, static_cast<const uint16_t *>(d_workspace), Lx.cap,

@@ -183,7 +183,7 @@ hipError_t launch_lz4_compress(hipStream_t s, const uint8_t *d_src, uint64_t src
 {
     if (n_blocks == 0) return hipSuccess;
     /* liblz4's byU32 table mode, positions below 2^24: the 64-probes-per-step kernel (lz4_enc2.hip) */
-    static const bool serial_only = getenv("CRYO_LZ4_ENC") && getenv("CRYO_LZ4_ENC")[0] == '1'; /* testing aid */
+    static const bool serial_only = cryo_tuning_env("CRYO_LZ4_ENC") && cryo_tuning_env("CRYO_LZ4_ENC")[0] == '1'; /* testing aid */
     if (!serial_only && block_size >= kLimit64k && block_size <= (16u << 20))
         return launch_lz4_compress_batch64(s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride, accel,
                                            d_out_size, d_status);

@@ -296,7 +296,7 @@ hipError_t launch_lz4_compress_batch64(hipStream_t s, const uint8_t *d_src, uint
                                        uint64_t dst_stride, int accel, uint32_t *d_out_size, int32_t *d_status)
 {
     if (n_blocks > 0x7fffffffull) return hipErrorInvalidValue;
-    static const int wkb = getenv("CRYO_LZ4_ENC_WINDOW") ? atoi(getenv("CRYO_LZ4_ENC_WINDOW")) : 2; /* KiB; tuning aid */
+    static const int wkb = cryo_tuning_env("CRYO_LZ4_ENC_WINDOW") ? atoi(cryo_tuning_env("CRYO_LZ4_ENC_WINDOW")) : 2; /* KiB; tuning aid */
     const dim3 grid((uint32_t)n_blocks), wg(64);
     if (wkb >= 64)
         hipLaunchKernelGGL((k_lz4_enc2<65536, 8>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,

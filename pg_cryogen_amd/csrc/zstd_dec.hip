@@ -435,7 +435,7 @@ hipError_t launch_zstd_fused(hipStream_t s, const uint8_t *d_src, const uint64_t
     if (n_blocks == 0) return hipSuccess;
     const uint32_t grid = zstd_grid(n_blocks);
     if (workspace_bytes < (size_t)grid * kLitBuf) return hipErrorInvalidValue;
-    static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
+    static const bool want_stats = cryo_tuning_env("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
     unsigned long long *d_st = nullptr, h_st[8];
     if (want_stats) {
         if (hipMalloc((void **)&d_st, sizeof h_st) != hipSuccess) return hipErrorOutOfMemory;

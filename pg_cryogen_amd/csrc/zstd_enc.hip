@@ -1335,7 +1335,7 @@ static uint32_t zstd_enc_grid(uint64_t n_blocks, size_t stride)
 {
     uint64_t per_cu = (160u * 1024u) / (sizeof(EncLds) + 64u);
     if (per_cu > 16) per_cu = 16;
-    static const uint64_t grid_env = getenv("CRYO_ZSTD_ENC_GRID") ? (uint64_t)atoll(getenv("CRYO_ZSTD_ENC_GRID")) : 0; /* tuning aid */
+    static const uint64_t grid_env = cryo_tuning_env("CRYO_ZSTD_ENC_GRID") ? (uint64_t)atoll(cryo_tuning_env("CRYO_ZSTD_ENC_GRID")) : 0; /* tuning aid */
     uint64_t cap = grid_env ? grid_env : 256u * per_cu;
     /* the deep levels' tables reach 12 MiB per workgroup: keep the workspace under 24 GiB, at least one workgroup per CU */
     const uint64_t fit = ((uint64_t)24 << 30) / stride;
@@ -1375,17 +1375,17 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
     bool dfast = false;
     int strategy = 1, slog = 0;
     if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast, &strategy, &slog)) return hipErrorNotSupported;
-    static const bool serial_only = getenv("CRYO_ZSTD_ENC") && getenv("CRYO_ZSTD_ENC")[0] == '1'; /* testing aid: the serial `fast` walk */
+    static const bool serial_only = cryo_tuning_env("CRYO_ZSTD_ENC") && cryo_tuning_env("CRYO_ZSTD_ENC")[0] == '1'; /* testing aid: the serial `fast` walk */
     const int finder = strategy >= 3 ? strategy : (dfast ? 1 : (serial_only ? 2 : 0)); /* 3 greedy, 4 lazy, 5 lazy2, 6 btlazy2 */
     /* search positions (dfast) / iterations (fast: two positions each) per step.  Measured on text-like rows, GB/s:
      * dfast level 3  16: 6.6  32: 7.4  64: 6.9;  fast level 1  16: 14.4  32: 13.9  64: 13.1 -- wider steps read
      * table slots for positions behind the first match, narrower ones pay more trips per sequence */
-    static const uint32_t w_env = getenv("CRYO_ZSTD_ENC_WIDTH") ? (uint32_t)atoi(getenv("CRYO_ZSTD_ENC_WIDTH")) : 0u; /* tuning aid */
+    static const uint32_t w_env = cryo_tuning_env("CRYO_ZSTD_ENC_WIDTH") ? (uint32_t)atoi(cryo_tuning_env("CRYO_ZSTD_ENC_WIDTH")) : 0u; /* tuning aid */
     const uint32_t width = strategy >= 3 ? (uint32_t)slog : (w_env ? w_env : (dfast ? 32u : 16u));
     const size_t stride = zstd_enc_stride(hlog, clog, strategy >= 2, strategy, mml, wlog);
     const uint32_t grid = zstd_enc_grid(n_blocks, stride);
     if (workspace_bytes < (size_t)grid * stride) return hipErrorInvalidValue;
-    static const bool stats_env = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
+    static const bool stats_env = cryo_tuning_env("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
     const bool want_stats = stats_env && strategy < 7;
     unsigned long long *d_st = nullptr, h_st[24] = {0};
     if (want_stats) {

@@ -1675,7 +1675,7 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     /* Tile size.  K2 and K3 are bound by LDS capacity (two workgroups per CU, 512 per chip): 14848 frames
      * = 512 x 29 fill exactly one round of K3 (and 928 waves of 16 = two rounds of K2, the second 81 % full); the
      * workspace budget may force less. */
-    static const size_t budget_env = getenv("CRYO_ZSTD_WS_MB") ? (size_t)atoll(getenv("CRYO_ZSTD_WS_MB")) << 20 : 0; /* tuning aid */
+    static const size_t budget_env = cryo_tuning_env("CRYO_ZSTD_WS_MB") ? (size_t)atoll(cryo_tuning_env("CRYO_ZSTD_WS_MB")) << 20 : 0; /* tuning aid */
     const size_t budget = budget_env ? budget_env : (size_t)16 << 30; /* per tile in flight; reached only by blocks > 128 KiB,
                                                                         whose tiles would otherwise be too few frames to fill K1/K4 */
     uint64_t F = budget / per_frame;
@@ -1717,7 +1717,7 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
  * profiles/r03_variants_ab.txt) */
 int tile_lanes(uint32_t block_size)
 {
-    static const char *e = getenv("CRYO_ZSTD_LANES"); /* tuning aid: 1 .. kZstdLanes */
+    static const char *e = cryo_tuning_env("CRYO_ZSTD_LANES"); /* tuning aid: 1 .. kZstdLanes */
     if (e && e[0] >= '1' && e[0] <= '0' + kZstdLanes) return e[0] - '0';
     (void)block_size;
     return 4; /* measured at 128 KiB ... 1 MiB blocks, profiles/r03_zstd_tiles_in_flight.txt */
@@ -1731,12 +1731,13 @@ bool use_pipeline(int path) { return path != 1; }
 
 } // namespace
 
-size_t zstd_decompress_workspace(uint64_t n_blocks, uint32_t block_size, int path)
+size_t zstd_decompress_workspace(uint64_t n_blocks, uint32_t block_size, int path, size_t max_bytes)
 {
     if (!use_pipeline(path)) return zstd_fused_workspace(n_blocks);
     const Layout y = make_layout(n_blocks, block_size);
     const uint64_t nt = (n_blocks + y.F - 1u) / y.F;
-    const uint64_t nl = nt < (uint64_t)tile_lanes(block_size) ? nt : (uint64_t)tile_lanes(block_size);
+    uint64_t nl = nt < (uint64_t)tile_lanes(block_size) ? nt : (uint64_t)tile_lanes(block_size);
+    while (nl > 1u && (size_t)nl * y.total + 256u > max_bytes) nl--; /* fewer tiles in flight; the launcher takes what it is given */
     return (size_t)nl * y.total + 256;
 }
 
@@ -1759,17 +1760,21 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
     const uint64_t ntiles = (n_blocks + y.F - 1u) / y.F;
     int nl = aux ? tile_lanes(block_size) : 1;
     if ((uint64_t)nl > ntiles) nl = (int)ntiles;
-    if (workspace_bytes < (size_t)nl * y.total) return hipErrorInvalidValue;
+    {   /* as many tiles in flight as the workspace holds (zstd_decompress_workspace planned it under the caller's cap) */
+        const size_t room = workspace_bytes - (size_t)(ws0 - (uint8_t *)d_workspace);
+        if (workspace_bytes < (size_t)(ws0 - (uint8_t *)d_workspace) || room < y.total) return hipErrorInvalidValue;
+        if ((size_t)nl * y.total > room) nl = (int)(room / y.total);
+    }
     hipError_t e;
     if (nl > 1) {
         if ((e = hipEventRecord(aux->fork, s)) != hipSuccess) return e;
         for (int l = 0; l < nl; l++)
             if ((e = hipStreamWaitEvent(aux->lane[l], aux->fork, 0)) != hipSuccess) return e;
     }
-    static const uint32_t huf_pad = getenv("CRYO_ZHUF_PAD") ? (uint32_t)atoi(getenv("CRYO_ZHUF_PAD")) : 0u; /* tuning aid: extra LDS to cap occupancy */
-    static const uint32_t seq_pad = getenv("CRYO_ZSEQ_PAD") ? (uint32_t)atoi(getenv("CRYO_ZSEQ_PAD")) : 0u;
-    static const bool want_stats = getenv("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
-    static const bool old_huf = getenv("CRYO_ZHUF_OLD") != nullptr;
+    static const uint32_t huf_pad = cryo_tuning_env("CRYO_ZHUF_PAD") ? (uint32_t)atoi(cryo_tuning_env("CRYO_ZHUF_PAD")) : 0u; /* tuning aid: extra LDS to cap occupancy */
+    static const uint32_t seq_pad = cryo_tuning_env("CRYO_ZSEQ_PAD") ? (uint32_t)atoi(cryo_tuning_env("CRYO_ZSEQ_PAD")) : 0u;
+    static const bool want_stats = cryo_tuning_env("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
+    static const bool old_huf = cryo_tuning_env("CRYO_ZHUF_OLD") != nullptr;
     uint64_t t = 0;
     for (uint64_t first = 0; first < n_blocks; first += y.F, t++) {
         const int l = (int)(t % (uint64_t)nl);

@@ -28,6 +28,7 @@ int zstd_compression_level_guc = 1;
 int cryo_gpu_device_guc = 0;
 int cryo_gpu_count_guc = 1;
 int cryo_gpu_pool_mb_guc = 0;
+int cryo_gpu_workspace_keep_mb_guc = 1024; /* device workspace a backend keeps between calls (-1: everything) */
 Size cryo_blcksz = (Size)1 << 20; /* CRYO_BLCKSZ, reference storage.h:18 */
 
 /* ---------------- codec binding ---------------- */
@@ -35,7 +36,7 @@ Size cryo_blcksz = (Size)1 << 20; /* CRYO_BLCKSZ, reference storage.h:18 */
  * device numbers, wrapping).  With more than one, the K-block calls of the staging and cache code go through the
  * dispatcher of include/cryo_codec.h (block i of a call -> GPU i mod G, one host thread per GPU). */
 static cryo_multi *hip_multi;
-static int hip_multi_first = -1, hip_multi_count = 0, hip_pool_mb = 0;
+static int hip_multi_first = -1, hip_multi_count = 0, hip_pool_mb = 0, hip_keep_mb = -2;
 static int hip_open_failed, hip_failed_first = -1, hip_failed_count = 0; /* a failed open is remembered until the GUCs change */
 static char codec_err[320];
 
@@ -107,7 +108,12 @@ const CryoCodecOps *cryo_host_codec_ops(void)
         hip_multi_first = cryo_gpu_device_guc;
         hip_multi_count = cryo_gpu_count_guc;
         hip_pool_mb = 0;
+        hip_keep_mb = -2;
         hip_ops.ctx = hip_multi;
+    }
+    if (hip_keep_mb != cryo_gpu_workspace_keep_mb_guc) { /* a backend is long-lived: one large call must not pin its workspace for good */
+        hip_keep_mb = cryo_gpu_workspace_keep_mb_guc;
+        (void)cryo_multi_set_option(hip_multi, CRYO_OPT_WORKSPACE_KEEP_BYTES, hip_keep_mb < 0 ? -1 : (int64_t)hip_keep_mb << 20);
     }
     if (hip_pool_mb != cryo_gpu_pool_mb_guc) { /* the GUC changed: resize (0 frees the pool) */
         hip_pool_mb = cryo_gpu_pool_mb_guc;
@@ -143,6 +149,12 @@ void cryo_host_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, uint6
     if (pool_misses) *pool_misses = t.pool_misses;
 }
 
+/* idle backend: give the GPU memory of the binding back (device workspace, staging buffers; not the pool) */
+void cryo_host_codec_trim(void)
+{
+    if (hip_multi) (void)cryo_multi_trim(hip_multi);
+}
+
 /* ---------------- GUCs ---------------- */
 void cryo_define_compression_gucs(void)
 {
@@ -162,6 +174,8 @@ void cryo_define_compression_gucs(void)
                             NULL, &cryo_gpu_count_guc, 1, 1, 64, PGC_USERSET, 0, NULL, NULL, NULL);
     DefineCustomIntVariable("pg_cryogen.gpu_pool_mb", "Decoded blocks kept in GPU memory so that repeated scans skip the transfer and the decode (MiB, 0 = off).",
                             NULL, &cryo_gpu_pool_mb_guc, 0, 0, 262144, PGC_USERSET, 0, NULL, NULL, NULL);
+    DefineCustomIntVariable("pg_cryogen.gpu_workspace_keep_mb", "GPU workspace this backend keeps between codec calls (MiB; -1 = everything a call ever needed).",
+                            NULL, &cryo_gpu_workspace_keep_mb_guc, 1024, -1, 262144, PGC_USERSET, 0, NULL, NULL, NULL);
 #else
     /* no GUC machinery without PostgreSQL: the variables keep the reference's defaults */
     compression_method_guc = COMP_ZSTD;

@@ -46,6 +46,7 @@ extern int cryo_gpu_device_guc;
 extern int cryo_gpu_count_guc;
 /* device-resident pool of decoded blocks, MiB over all GPUs of the backend (additive GUC pg_cryogen.gpu_pool_mb, default 0 = off) */
 extern int cryo_gpu_pool_mb_guc;
+extern int cryo_gpu_workspace_keep_mb_guc; /* pg_cryogen.gpu_workspace_keep_mb (default 1024, -1 = keep everything) */
 /* bytes the codec moved towards the device / back, blocks served from the pool / decoded (0 when no GPU codec is bound) */
 void cryo_host_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, uint64_t *pool_hits, uint64_t *pool_misses);
 
@@ -73,6 +74,7 @@ typedef struct CryoCodecOps {
 void cryo_host_set_codec_ops(const CryoCodecOps *ops); /* test builds only: bind a double; NULL restores the HIP binding */
 #endif
 const CryoCodecOps *cryo_host_codec_ops(void);         /* lazily opens the GPU codec */
+void cryo_host_codec_trim(void);                         /* idle backend: free the binding's device workspace and staging buffers */
 size_t cryo_host_codec_bound(int method, size_t n);      /* cryo_codec_bound (or the bound double's): never opens the GPU */
 const CryoCodecOps *cryo_host_codec_ops_if_open(void); /* the binding if there is one already; never opens the GPU */
 const char *cryo_host_codec_error(void);

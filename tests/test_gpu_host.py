@@ -252,3 +252,38 @@ def test_c_host_batch_api_pipelined_path(codec, oracle):
                 assert st[i] != 0, i
             else:
                 assert st[i] == 0 and np.array_equal(dec[i * B:(i + 1) * B], uniq[i % 24]), (method, i)
+
+
+def test_workspace_options_and_trim(oracle):
+    """A long-lived backend: the device workspace is bounded per call (CRYO_OPT_WORKSPACE_MAX_BYTES: the zstd pipeline
+    runs fewer tiles at once), given back after host-buffer calls beyond CRYO_OPT_WORKSPACE_KEEP_BYTES, and
+    cryo_codec_trim frees everything a handle holds between bursts -- bytes are the same every time."""
+    import torch
+    from pg_cryogen_amd import Codec, METHOD_LZ4, METHOD_ZSTD, codec as cc
+    B, n = 131072, 96
+    raws = [oracle.synth(12, i, B, i % 5) for i in range(n)]
+    zc = [oracle.zstd_compress(r, 1 + (i % 3)) for i, r in enumerate(raws)]
+    lc = [oracle.lz4_compress(r, 1) for r in raws]
+
+    def check(c):
+        for method, comps in ((METHOD_ZSTD, zc), (METHOD_LZ4, lc)):
+            outs, st = c.decompress_blocks(method, comps, B)
+            assert (st == 0).all() and all(np.array_equal(o, r) for o, r in zip(outs, raws))
+    with Codec(0) as c:
+        assert c.get_option(cc.OPT_WORKSPACE_KEEP_BYTES) == -1 and c.get_option(cc.OPT_WORKSPACE_MAX_BYTES) == 0
+        check(c)
+        free0 = torch.cuda.mem_get_info(0)[0]
+        c.trim()
+        free1 = torch.cuda.mem_get_info(0)[0]
+        assert free1 > free0, "cryo_codec_trim gave nothing back"
+        check(c)                                           # everything comes back with the next call
+        c.set_option(cc.OPT_WORKSPACE_KEEP_BYTES, 0)       # host-buffer calls return their workspace when they end
+        c.set_option(cc.OPT_LZ4_DECODE_PATH, cc.LZ4_PATH_INDEXED)
+        check(c)
+        check(c)
+        c.set_option(cc.OPT_WORKSPACE_KEEP_BYTES, -1)
+        c.set_option(cc.OPT_WORKSPACE_MAX_BYTES, 64 << 20)  # below one zstd tile of this batch: one tile in flight, still decodes
+        check(c)
+        c.set_option(cc.OPT_WORKSPACE_MAX_BYTES, 0)
+        c.set_option(cc.OPT_LZ4_DECODE_PATH, cc.LZ4_PATH_AUTO)
+        check(c)
