@@ -559,7 +559,7 @@ uint32_t lz4_decode_plan(uint64_t n_blocks, uint32_t block_size, const Lz4Decode
     if (opts.path == 0 && block_size < 16384u && n_blocks < 24576u) return 0;
     if (opts.walkers > 0) return (uint32_t)opts.walkers;
     uint32_t S = 1;
-    while (S < 64u && n_blocks * (2u * S) <= 65536u && block_size / (2u * S) >= 4096u) S *= 2u;
+    while (S < 64u && n_blocks * (2u * S) <= kLz4IndexResidentLanes && block_size / (2u * S) >= 4096u) S *= 2u;
     return S;
 }
 /* the few-blocks path (lz4_lat.hip): asked for, or automatic for what it is made for */

@@ -35,12 +35,29 @@
 namespace cryo {
 
 #ifndef CRYO_IDX_RING
-#define CRYO_IDX_RING 512
+#define CRYO_IDX_RING (CRYO_IDX_V2 ? 256 : 512)
 #endif
 #ifndef CRYO_IDX_DIST
 #define CRYO_IDX_DIST 2 /* rounds between the request of a chunk and its store into the ring (1 or 2) */
 #endif
-constexpr uint32_t kIdxLanes = 64, kIdxChunk = 128, kIdxRing = CRYO_IDX_RING;
+/* Geometry.  A chunk is what one walker is fed at a time: kIdxLpw lanes x 16 bytes.  A turn issues two loads, each serving
+ * 64 / kIdxLpw walkers; a round is four turns.  Production (CRYO_IDX_V2 = 0): 128-byte chunks (a cache line) into 512-byte
+ * rings, every walker served once per round -- 39 KB of LDS per wave, one wave per SIMD.
+ * Round 4 tried to get two waves per SIMD (CRYO_IDX_V2 = 1: 64-byte chunks, every walker served twice per round, 256-byte
+ * rings, one shared trash slot, positions buffered in lines of 8: 19.5 KB per wave, and two walkers per block on a full
+ * batch so that all of them are resident).  It loses (profiles/r04_lz4_decode_ab.txt, r04_ab9: 2.24 -> 3.09 ms; 2.87 with
+ * one walker per block): a walker uses 0 .. 70 bytes of its stream per turn, and with 256 bytes of ring minus what is in
+ * flight it runs dry where 512 bytes carry it through; smaller rings with 128-byte chunks starve outright (r04_ab6).  The
+ * ring a walker needs is set by the variance of its appetite, not by the latency to cover: LDS per walker does not shrink
+ * with more waves per SIMD. */
+constexpr uint32_t kIdxLanes = 64, kIdxRing = CRYO_IDX_RING;
+constexpr uint32_t kIdxLpw = CRYO_IDX_V2 ? 4u : 8u;          /* lanes that load one walker's chunk */
+constexpr uint32_t kIdxChunk = kIdxLpw * 16u;                /* 64 / 128 bytes */
+constexpr uint32_t kIdxWpl = kIdxLanes / kIdxLpw;            /* walkers per load: 16 / 8 */
+constexpr uint32_t kIdxGroups = kIdxLanes / (2u * kIdxWpl);  /* walker groups, one per turn in rotation: 2 / 4 */
+constexpr uint32_t kIdxLine = CRYO_IDX_V2 ? 8u : 16u;        /* positions per stored line (16 / 32 bytes) */
+constexpr uint32_t kIdxPutStores = kIdxLine / 8u;            /* 16-byte stores of IDX_PUT per round */
+constexpr uint32_t kIdxTrashPerLane = CRYO_IDX_V2 ? 0u : 1u; /* v1: a trash slot per lane; v2: one for the wave */
 constexpr uint32_t kIdxStride = kIdxRing + 16u; /* bank skew between rings */
 
 __device__ inline uint32_t bperm(uint32_t v, uint32_t src_lane)
@@ -89,10 +106,11 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             const uint32_t logS, const uint32_t cap_main, const uint32_t ext, const uint32_t cap,
             uint2 *__restrict__ seg, uint16_t *__restrict__ dummy_base, const uint32_t block_size)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kIdxLanes * kIdxStride + kIdxLanes * 16u]; /* + a 16-byte trash slot per lane */
-    /* the last 32 positions of every lane (two lines of 16: one being filled, one waiting for its store) + one slot
-     * where a lane that records nothing writes */
-    __shared__ __attribute__((aligned(16))) uint16_t s_pos[kIdxLanes][40];
+    __shared__ __attribute__((aligned(16))) uint8_t s_ring[kIdxLanes * kIdxStride + (kIdxTrashPerLane ? kIdxLanes * 16u : 16u)]; /* + trash */
+    /* the last positions of every lane (two lines: one being filled, one waiting for its store) + a slot where a lane
+     * that records nothing writes (per lane in the round-3 geometry, one for the wave now) */
+    __shared__ __attribute__((aligned(16))) uint16_t s_pos[kIdxLanes][2u * kIdxLine + (kIdxTrashPerLane ? 8u : 0u)];
+    __shared__ __attribute__((aligned(16))) uint16_t s_ptrash[8];
     const uint32_t lane = threadIdx.x;
     const uint32_t S = 1u << logS, cap_s = cap_main + ext;
     const uint64_t gl = (uint64_t)blockIdx.x * kIdxLanes + lane;
@@ -132,14 +150,19 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     uint32_t acc = 0, tm = 0;             /* literal length being accumulated; match nibble of the current token */
     uint32_t k = 0, ls = 0;               /* positions recorded; 16-entry lines of them stored */
     uint16_t *pbuf = s_pos[lane];
+    uint16_t *const ptrash = kIdxTrashPerLane ? pbuf + 2u * kIdxLine : s_ptrash;
     bool done = !walker || vend == delta;
 
-    /* what this lane serves in turn j: one 16-byte piece of the next chunk of walkers 16j + (lane >> 3) and
-     * 16j + 8 + (lane >> 3) (two loads per turn: every walker has a turn every fourth hop) */
-    const uint32_t piece16 = (lane & 7u) * 16u;
-#define IDX_SRC(j) const uint64_t saoff##j = ((uint64_t)bperm((uint32_t)(aoff >> 32), 8u * j + (lane >> 3)) << 32) | bperm((uint32_t)aoff, 8u * j + (lane >> 3)); \
-                   const uint32_t svend##j = bperm(vend, 8u * j + (lane >> 3));
-    IDX_SRC(0) IDX_SRC(1) IDX_SRC(2) IDX_SRC(3) IDX_SRC(4) IDX_SRC(5) IDX_SRC(6) IDX_SRC(7)
+    /* what this lane serves: one 16-byte piece of the next chunk of walker (lane / kIdxLpw) of the load's set of kIdxWpl
+     * walkers; turn j feeds group j % kIdxGroups = sets 2 (j % kIdxGroups) and 2 (j % kIdxGroups) + 1 */
+    const uint32_t piece16 = (lane & (kIdxLpw - 1u)) * 16u;
+    const uint32_t wil = lane / kIdxLpw; /* walker inside a load's set */
+#define IDX_SRC(q) const uint64_t saoff##q = ((uint64_t)bperm((uint32_t)(aoff >> 32), kIdxWpl * q + wil) << 32) | bperm((uint32_t)aoff, kIdxWpl * q + wil); \
+                   const uint32_t svend##q = bperm(vend, kIdxWpl * q + wil);
+    IDX_SRC(0) IDX_SRC(1) IDX_SRC(2) IDX_SRC(3)
+#if !CRYO_IDX_V2
+    IDX_SRC(4) IDX_SRC(5) IDX_SRC(6) IDX_SRC(7)
+#endif
 #undef IDX_SRC
     const uint32_t rb = lane * kIdxStride; /* this lane's ring inside s_ring */
 
@@ -153,24 +176,28 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
      * exactly 10 * kIdxDist - 2 younger operations may still be in flight.
      * Separate variables, not arrays: the compiler kept an indexed array in scratch memory. */
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-#define IDX_SLOT(n) u32x4 fd##n = {0, 0, 0, 0}, fe##n = fd##n; uint32_t fa##n = kIdxLanes * kIdxStride + lane * 16u, fb##n = fa##n; /* nothing requested yet: the trash slot */
+    constexpr uint32_t kTrash = kIdxLanes * kIdxStride; /* where a slot that asked for nothing commits */
+    const uint32_t mytrash = kTrash + (kIdxTrashPerLane ? lane * 16u : 0u);
+#define IDX_SLOT(n) u32x4 fd##n = {0, 0, 0, 0}, fe##n = fd##n; uint32_t fa##n = mytrash, fb##n = fa##n; /* nothing requested yet */
     IDX_SLOT(0) IDX_SLOT(1) IDX_SLOT(2) IDX_SLOT(3)
 #if CRYO_IDX_DIST == 2
     IDX_SLOT(4) IDX_SLOT(5) IDX_SLOT(6) IDX_SLOT(7)
 #endif
 #undef IDX_SLOT
 
-    uint32_t outA = 0, outB = 0; /* 128 while a chunk of this lane is on its way in slot set A / B, else 0 */
-    constexpr uint32_t kTrash = kIdxLanes * kIdxStride; /* s_ring + kTrash + 16 * lane: where a slot that asked for nothing commits */
+    /* a chunk's size while a chunk of this lane is on its way, else 0: per slot set (A / B) and per visit of the round
+     * (the round-4 geometry serves a walker twice per round: turns g and g + kIdxGroups) */
+    uint32_t outA0 = 0, outA1 = 0, outB0 = 0, outB1 = 0;
     auto turn = [&](const uint32_t j, u32x4 &fd, u32x4 &fe, uint32_t &fa, uint32_t &fb, uint32_t &out128,
                     const uint64_t soff, const uint32_t sve, const uint64_t soff2, const uint32_t sve2) __attribute__((always_inline)) {
-        const bool myturn = (lane >> 4) == j; /* lanes 16j..16j+15 */
+        const uint32_t grp = j % kIdxGroups;
+        const bool myturn = lane / (2u * kIdxWpl) == grp; /* this lane's walker is in the group the turn feeds */
         /* ---- commit what the slot's loads of a round ago brought (to the trash slot if they were idle re-reads) ----
          * Everything per-lane in this turn is evaluated EAGERLY (& and | on the predicates, selects instead of ifs): with
          * && / || / if the compiler built exec-mask branches around one- and two-instruction bodies, 450 scalar mask
          * instructions per round of 1160; a lone wave per SIMD issues one instruction per four cycles whatever its kind,
          * so the pass is as long as its instruction count (round 3: 3.06 -> 2.4 ms for the headline batch). */
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(10 * CRYO_IDX_DIST - 2) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((8 + kIdxPutStores) * (CRYO_IDX_DIST - 1) + 6 + kIdxPutStores) : "memory");
         *reinterpret_cast<u32x4 *>(s_ring + fa) = fd;
         *reinterpret_cast<u32x4 *>(s_ring + fb) = fe;
         {
@@ -187,14 +214,14 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             const bool want = myturn & !done & (requested < vend) & (pos + (kIdxRing - kIdxChunk) >= requested);
             const uint32_t wi = want ? 1u : 0u;
             const uint32_t msg = requested | wi;
-            requested += wi << 7;
-            out128 |= wi << 7;
-            const uint32_t s1 = 16u * j + (lane >> 3), s2 = s1 + 8u;
+            requested += wi * kIdxChunk;
+            out128 |= wi * kIdxChunk;
+            const uint32_t s1 = 2u * kIdxWpl * grp + wil, s2 = s1 + kIdxWpl;
             const uint32_t m1 = bperm(msg, s1), m2 = bperm(msg, s2);
             const uint32_t o1 = (m1 & ~1u) + piece16, o2 = (m2 & ~1u) + piece16;
             const bool p1 = (m1 & 1u) != 0u, p2 = (m2 & 1u) != 0u;
-            fa = p1 ? s1 * kIdxStride + (o1 & (kIdxRing - 1u)) : kTrash + lane * 16u;
-            fb = p2 ? s2 * kIdxStride + (o2 & (kIdxRing - 1u)) : kTrash + lane * 16u;
+            fa = p1 ? s1 * kIdxStride + (o1 & (kIdxRing - 1u)) : mytrash;
+            fb = p2 ? s2 * kIdxStride + (o2 & (kIdxRing - 1u)) : mytrash;
             /* always two loads per turn (a lane with nothing to fetch re-reads its stream's first 16 bytes): with a
              * fixed number of vector-memory operations per turn the compiler can wait for exactly the chunks it
              * commits (vmcnt(N)); a conditional load made it drain the queue once per round (2.3 us a round) */
@@ -226,7 +253,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             const uint32_t n = nx ? (uint32_t)__builtin_ctz(nx) >> 3 : 4u; /* leading 0xFF bytes */
             const bool extb = go & (state == 2u);
             /* record + advance */
-            pbuf[tok ? (k & 31u) : 32u] = (uint16_t)(pos - delta); /* unconditional: a store in a branch costs more than the branch saves */
+            *(tok ? pbuf + (k & (2u * kIdxLine - 1u)) : ptrash) = (uint16_t)(pos - delta); /* unconditional: a store in a branch costs more than the branch saves */
             k += tok ? 1u : 0u;
             tm = tok ? tmn : tm;
             const uint32_t st_tok = tmn == 15u ? 2u : 0u;
@@ -242,7 +269,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
                 const bool l15b = llb == 15u;
                 const uint32_t q2b = q2 + 3u + llb + (l15b ? e1b + 1u : 0u);
                 const bool rec2 = dbl & !(l15b & (e1b == 255u));
-                pbuf[rec2 ? (k & 31u) : 32u] = (uint16_t)(q2 - delta);
+                *(rec2 ? pbuf + (k & (2u * kIdxLine - 1u)) : ptrash) = (uint16_t)(q2 - delta);
                 k += rec2 ? 1u : 0u;
                 tm = rec2 ? tmb : tm;
                 const bool last2 = rec2 & (q2b > vend); /* the second token is the stream's last sequence */
@@ -267,7 +294,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
                         /* restart the ring at the chunk of pos; a chunk still on its way lands in a slot that is
                          * rewritten before it is read, and is not counted */
                         requested = filled = pos & ~(kIdxChunk - 1u);
-                        outA = outB = 0;
+                        outA0 = outA1 = outB0 = outB1 = 0;
                     } else if (state == 1u && live && canread) {
                         if (n == 4u) { acc += 1020u; pos += 4u; if (acc >= vend) done = true; }
                         else {
@@ -287,14 +314,21 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
      * reached memory for a 0.83 GB index -- the L2 does not hold 65 536 rows' open lines until they are full.  One
      * unconditional pair of stores per round (a lane with nothing to store writes its dummy slot), see the note on
      * the loads.  A macro, not a lambda: captured by a lambda, the packs lived in scratch memory. */
+#define IDX_LINE_COPY(ps_, pd_)                                                                               \
+    {                                                                                                        \
+        const uint4 v0_ = *reinterpret_cast<const uint4 *>(ps_);                                             \
+        *reinterpret_cast<uint4 *>(pd_) = v0_;                                                               \
+        if (kIdxLine == 16u) {                                                                               \
+            const uint4 v1_ = *reinterpret_cast<const uint4 *>((ps_) + 8);                                   \
+            *reinterpret_cast<uint4 *>((pd_) + 8) = v1_;                                                     \
+        }                                                                                                    \
+    }
 #define IDX_PUT()                                                                                            \
     {                                                                                                        \
-        const bool st_ = ls < (k >> 4);                                                                      \
-        const uint16_t *ps_ = pbuf + ((ls & 1u) << 4);                                                       \
-        const uint4 v0_ = *reinterpret_cast<const uint4 *>(ps_), v1_ = *reinterpret_cast<const uint4 *>(ps_ + 8); \
-        uint16_t *pd_ = st_ ? row + (ls << 4) : dummy;                                                       \
-        *reinterpret_cast<uint4 *>(pd_) = v0_;                                                               \
-        *reinterpret_cast<uint4 *>(pd_ + 8) = v1_;                                                           \
+        const bool st_ = ls < k / kIdxLine;                                                                  \
+        const uint16_t *ps_ = pbuf + (ls & 1u) * kIdxLine;                                                   \
+        uint16_t *pd_ = st_ ? row + ls * kIdxLine : dummy;                                                   \
+        IDX_LINE_COPY(ps_, pd_)                                                                              \
         if (st_) ls++;                                                                                       \
     }
     /* what is left when a walk ends: at most one complete line and the one being filled (stored whole: the entries
@@ -303,22 +337,26 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     {                                                                                                        \
         IDX_PUT()                                                                                            \
         IDX_PUT()                                                                                            \
-        if ((k & 15u) != 0u && ls == (k >> 4)) {                                                             \
-            const uint16_t *ps_ = pbuf + ((ls & 1u) << 4);                                                   \
-            const uint4 v0_ = *reinterpret_cast<const uint4 *>(ps_), v1_ = *reinterpret_cast<const uint4 *>(ps_ + 8); \
-            uint16_t *pd_ = row + (ls << 4);                                                                 \
-            *reinterpret_cast<uint4 *>(pd_) = v0_;                                                           \
-            *reinterpret_cast<uint4 *>(pd_ + 8) = v1_;                                                       \
+        if ((k & (kIdxLine - 1u)) != 0u && ls == k / kIdxLine) {                                             \
+            const uint16_t *ps_ = pbuf + (ls & 1u) * kIdxLine;                                               \
+            uint16_t *pd_ = row + ls * kIdxLine;                                                             \
+            IDX_LINE_COPY(ps_, pd_)                                                                          \
         }                                                                                                    \
     }
 #define IDX_TURN(j, n, o, sa, sb) turn(j, fd##n, fe##n, fa##n, fb##n, o, saoff##sa, svend##sa, saoff##sb, svend##sb);
-#define IDX_ROUND(a, b, c, d, o)                                \
+#if CRYO_IDX_V2
+#define IDX_ROUND(a, b, c, d, o0, o1)                           \
     IDX_PUT()                                                   \
-    IDX_TURN(0, a, o, 0, 1) IDX_TURN(1, b, o, 2, 3) IDX_TURN(2, c, o, 4, 5) IDX_TURN(3, d, o, 6, 7)
-#if CRYO_IDX_DIST == 2
-#define IDX_ROUNDS() IDX_ROUND(0, 1, 2, 3, outA) IDX_ROUND(4, 5, 6, 7, outB)
+    IDX_TURN(0, a, o0, 0, 1) IDX_TURN(1, b, o0, 2, 3) IDX_TURN(2, c, o1, 0, 1) IDX_TURN(3, d, o1, 2, 3)
 #else
-#define IDX_ROUNDS() IDX_ROUND(0, 1, 2, 3, outA)
+#define IDX_ROUND(a, b, c, d, o0, o1)                           \
+    IDX_PUT()                                                   \
+    IDX_TURN(0, a, o0, 0, 1) IDX_TURN(1, b, o0, 2, 3) IDX_TURN(2, c, o0, 4, 5) IDX_TURN(3, d, o0, 6, 7)
+#endif
+#if CRYO_IDX_DIST == 2
+#define IDX_ROUNDS() IDX_ROUND(0, 1, 2, 3, outA0, outA1) IDX_ROUND(4, 5, 6, 7, outB0, outB1)
+#else
+#define IDX_ROUNDS() IDX_ROUND(0, 1, 2, 3, outA0, outA1)
 #endif
     /* (the compiler does not see the assembly loads: nothing it generates behind a walk may meet one still in flight) */
 #define IDX_WALK()                                              \
@@ -397,7 +435,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             const bool redo = gfail && walker && sw == 0u;
             pos = delta;
             requested = filled = 0;
-            outA = outB = 0; /* a chunk still on its way is not counted */
+            outA0 = outA1 = outB0 = outB1 = 0; /* a chunk still on its way is not counted */
             state = 0; acc = 0; tm = 0; k = 0; ls = 0;
             stop = vend;
             kcap = S * cap_s - ext;
