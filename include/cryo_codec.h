@@ -86,7 +86,12 @@ typedef enum {
     CRYO_OPT_WORKSPACE_KEEP_BYTES = 6,
     /* the most device workspace one call may allocate: 0 = automatic (70 % of what hipMemGetInfo reports free plus what
      * the handle already holds); the zstd decode pipeline runs fewer tiles at once to fit (1 tile at least) */
-    CRYO_OPT_WORKSPACE_MAX_BYTES = 7
+    CRYO_OPT_WORKSPACE_MAX_BYTES = 7,
+    /* 1 (default): the staging worker threads, the pinned staging buffers and -- for the duration of a K-block call of
+     * 8 MiB or more -- the calling thread are placed on the cpus of the NUMA node the handle's GPU hangs on (sysfs
+     * local_cpulist of its PCI function, cut to the process's affinity mask; the caller's mask is restored on return);
+     * 0: wherever the scheduler puts them.  get_option reports 0 when the node could not be determined. */
+    CRYO_OPT_NUMA_LOCAL = 8
 } cryo_option;
 int cryo_codec_set_option(cryo_codec *c, int option, int64_t value);
 /* a long-lived backend between bursts: waits for the handle's queued work, then frees its device workspace, the device and

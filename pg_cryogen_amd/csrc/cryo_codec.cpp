@@ -58,13 +58,15 @@ class WorkerPool {
     }
 
 public:
-    explicit WorkerPool(unsigned workers) noexcept
+    /* cpus: where the workers may run (the GPU's NUMA node for the staging workers; nullptr: anywhere) */
+    explicit WorkerPool(unsigned workers, const cpu_set_t *cpus = nullptr) noexcept
     {
         sigset_t all, old;
         sigfillset(&all);
         const bool masked = pthread_sigmask(SIG_SETMASK, &all, &old) == 0;
         for (unsigned i = 0; i < workers; i++) {
             try { th_.emplace_back([this] { loop(); }); } catch (...) { break; } /* EAGAIN, bad_alloc: fewer workers */
+            if (cpus) (void)pthread_setaffinity_np(th_.back().native_handle(), sizeof *cpus, cpus);
         }
         if (masked) (void)pthread_sigmask(SIG_SETMASK, &old, nullptr);
     }
@@ -137,6 +139,11 @@ struct cryo_codec {
     cryo::Lz4DecodeOpts lz4_opts = {};
     int zstd_path = 0;
     size_t pipe_min_bytes = (size_t)64 << 20;
+    /* NUMA: the cpus of the node this GPU hangs on (sysfs local_cpulist of its PCI function, cut to what the process may
+     * use); the staging workers run there and the pinned buffers are allocated from there */
+    cpu_set_t local_cpus;
+    bool have_local_cpus = false;
+    int numa_local = 1;     /* CRYO_OPT_NUMA_LOCAL */
     int64_t ws_keep = -1;   /* CRYO_OPT_WORKSPACE_KEEP_BYTES: -1 = keep everything between calls */
     size_t ws_max = 0;      /* CRYO_OPT_WORKSPACE_MAX_BYTES: 0 = automatic */
     /* staging-copy workers (created by the first K-block call that is large enough to want them) */
@@ -193,11 +200,26 @@ int ensure(cryo_codec *c, uint8_t **p, size_t *cap, size_t need)
     return CRYO_OK;
 }
 
+/* the calling thread on the GPU's node for the lifetime of the object (restored afterwards): a pinned buffer is placed
+ * where the thread that allocates it runs, and a K-block call's share of the staging copies runs on the caller */
+struct ScopedLocalCpus {
+    cpu_set_t old;
+    bool active = false;
+    explicit ScopedLocalCpus(const cryo_codec *c)
+    {
+        if (!c || !c->have_local_cpus || !c->numa_local) return;
+        if (pthread_getaffinity_np(pthread_self(), sizeof old, &old) != 0) return;
+        active = pthread_setaffinity_np(pthread_self(), sizeof c->local_cpus, &c->local_cpus) == 0;
+    }
+    ~ScopedLocalCpus() { if (active) (void)pthread_setaffinity_np(pthread_self(), sizeof old, &old); }
+};
+
 int ensure_pinned(cryo_codec *c, size_t need)
 {
     if (c->pin_cap >= need) return CRYO_OK;
     if (c->pin) { HIP_TRY(c, hipHostFree(c->pin)); c->pin = nullptr; c->pin_cap = 0; }
     need += need / 4; /* grow-only, with head room */
+    ScopedLocalCpus numa_(c);
     hipError_t e = hipHostMalloc(&c->pin, need, hipHostMallocDefault);
     if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return CRYO_E_NOMEM; }
     if (e != hipSuccess) return fail(c, e, "hipHostMalloc");
@@ -210,6 +232,7 @@ int ensure_pipe(cryo_codec *c, int which, size_t need)
     if (c->pipe_pin_cap[which] >= need) return CRYO_OK;
     if (c->pipe_pin[which]) { HIP_TRY(c, hipHostFree(c->pipe_pin[which])); c->pipe_pin[which] = nullptr; c->pipe_pin_cap[which] = 0; }
     need += need / 8;
+    ScopedLocalCpus numa_(c);
     hipError_t e = hipHostMalloc(&c->pipe_pin[which], need, hipHostMallocDefault);
     if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); return CRYO_E_NOMEM; }
     if (e != hipSuccess) return fail(c, e, "hipHostMalloc");
@@ -246,7 +269,8 @@ void parallel_copy(cryo_codec *c, const std::vector<CopyJob> &jobs)
 {
     size_t total = 0;
     for (const CopyJob &j : jobs) total += j.len;
-    if (total >= (4u << 20) && !c->pool && host_threads() > 1u) c->pool = new (std::nothrow) WorkerPool(host_threads() - 1u);
+    if (total >= (4u << 20) && !c->pool && host_threads() > 1u)
+        c->pool = new (std::nothrow) WorkerPool(host_threads() - 1u, c->have_local_cpus && c->numa_local ? &c->local_cpus : nullptr);
     const unsigned T = (total < (4u << 20) || !c->pool) ? 1u : c->pool->workers() + 1u;
     if (T == 1u) { for (const CopyJob &j : jobs) memcpy(j.dst, j.src, j.len); return; }
     /* equal byte shares: share t takes the jobs (or parts of jobs) covering bytes [t, t+1) * total / T */
@@ -300,6 +324,42 @@ const char *cryo_codec_version(void)
     return "cryo-codec 0.2 gfx950 (lz4 block format as liblz4 1.9.3; zstd frames as libzstd 1.4.8)";
 }
 
+} /* extern "C" */
+/* the cpus of the NUMA node the handle's GPU hangs on: /sys/bus/pci/devices/<bus id>/local_cpulist, cut to what the process
+ * may use.  Measured on the 2-socket bench host (profiles/r04_host_api.txt): a 4 096 x 128 KiB decompress call moved between
+ * 25 and 32 GB/s from call to call with its staging threads and pinned buffers wherever the scheduler put them. */
+static void discover_local_cpus(cryo_codec *c)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, c->device) != hipSuccess) { (void)hipGetLastError(); return; }
+    for (char *p = bus; *p; p++) if (*p >= 'A' && *p <= 'F') *p = (char)(*p - 'A' + 'a');
+    char path[160];
+    snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/local_cpulist", bus);
+    FILE *f = fopen(path, "r");
+    if (!f) return;
+    char line[1024] = {0};
+    const bool got = fgets(line, sizeof line, f) != nullptr;
+    fclose(f);
+    if (!got) return;
+    cpu_set_t allowed, want;
+    if (pthread_getaffinity_np(pthread_self(), sizeof allowed, &allowed) != 0) return;
+    CPU_ZERO(&want);
+    int n = 0;
+    for (char *p = line; *p;) { /* "64-127,192-255" */
+        char *end;
+        const long a = strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        if (*end == '-') { p = end + 1; b = strtol(p, &end, 10); }
+        for (long k = a; k <= b && k < CPU_SETSIZE; k++)
+            if (k >= 0 && CPU_ISSET((int)k, &allowed)) { CPU_SET((int)k, &want); n++; }
+        p = *end == ',' ? end + 1 : end;
+        if (*end != ',') break;
+    }
+    if (n > 0 && n < CPU_COUNT(&allowed)) { c->local_cpus = want; c->have_local_cpus = true; } /* one node only: nothing to choose */
+}
+extern "C" {
+
 int cryo_codec_device_count(void)
 {
     int n = 0;
@@ -335,6 +395,7 @@ int cryo_codec_open(int device, cryo_codec **out)
         cryo_codec_close(c);
         return CRYO_E_HIP;
     }
+    discover_local_cpus(c);
     *out = c;
     return CRYO_OK;
 }
@@ -427,6 +488,10 @@ int cryo_codec_set_option(cryo_codec *c, int option, int64_t value)
         if (value < 0) return CRYO_E_ARG;
         c->ws_max = (size_t)value;
         return CRYO_OK;
+    case CRYO_OPT_NUMA_LOCAL:
+        if (value != 0 && value != 1) return CRYO_E_ARG;
+        c->numa_local = (int)value; /* workers already started keep their placement */
+        return CRYO_OK;
     case CRYO_OPT_POOL_BYTES: {
         if (value < 0) return CRYO_E_ARG;
         DevGuard dev_(c);
@@ -450,6 +515,7 @@ int cryo_codec_get_option(const cryo_codec *c, int option, int64_t *value)
     case CRYO_OPT_ZSTD_DECODE_PATH: *value = c->zstd_path; return CRYO_OK;
     case CRYO_OPT_WORKSPACE_KEEP_BYTES: *value = c->ws_keep; return CRYO_OK;
     case CRYO_OPT_WORKSPACE_MAX_BYTES: *value = (int64_t)c->ws_max; return CRYO_OK;
+    case CRYO_OPT_NUMA_LOCAL: *value = c->numa_local && c->have_local_cpus ? 1 : 0; return CRYO_OK;
     default: return CRYO_E_ARG;
     }
 }
@@ -678,8 +744,11 @@ static bool pipe_kernel_per_chunk(size_t chunk_blocks, int method, bool encode)
     return !encode && method == CRYO_METHOD_LZ4 && chunk_blocks >= 512;
 }
 
-static int compress_blocks_piped(cryo_codec *c, int method, int param, const uint8_t *h_src, size_t block_size, size_t n,
-                                 uint8_t *h_dst, size_t dst_stride, uint32_t *h_out_size)
+/* h_src / h_dst: contiguous K-block buffers; or (multi-GPU shares, where a handle's blocks are every G-th of the call)
+ * one pointer per block in h_src_each / h_dst_each */
+static int compress_blocks_piped(cryo_codec *c, int method, int param, const uint8_t *h_src, const void *const *h_src_each,
+                                 size_t block_size, size_t n, uint8_t *h_dst, void *const *h_dst_each, size_t dst_stride,
+                                 uint32_t *h_out_size)
 {
     const size_t bound = cryo_codec_bound(method, block_size);
     const size_t dstride = (bound + 15) & ~(size_t)15;
@@ -703,7 +772,12 @@ static int compress_blocks_piped(cryo_codec *c, int method, int param, const uin
         const size_t lo = ch * K, hi = lo + K < n ? lo + K : n, cnt = hi - lo;
         const int b = (int)(ch & 1);
         if (ch >= 2) HIP_TRY(c, hipEventSynchronize(c->ev_in[b])); /* staging buffer b has left for the device */
-        parallel_copy(c, {{c->pipe_pin[b], h_src + lo * block_size, cnt * block_size}});
+        if (h_src) parallel_copy(c, {{c->pipe_pin[b], h_src + lo * block_size, cnt * block_size}});
+        else {
+            std::vector<CopyJob> jobs;
+            for (size_t i = lo; i < hi; i++) jobs.push_back({(uint8_t *)c->pipe_pin[b] + (i - lo) * block_size, h_src_each[i], block_size});
+            parallel_copy(c, jobs);
+        }
         HIP_TRY(c, hipMemcpyAsync(c->hb_src + lo * block_size, c->pipe_pin[b], cnt * block_size, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipEventRecord(c->ev_in[b], c->stream));
     }
@@ -732,14 +806,16 @@ static int compress_blocks_piped(cryo_codec *c, int method, int param, const uin
         HIP_TRY(c, hipEventSynchronize(c->ev_out[ch & 1]));
         const uint8_t *po = (const uint8_t *)c->pipe_pin[2 + (ch & 1)];
         std::vector<CopyJob> jobs;
-        for (size_t i = lo; i < hi; i++) jobs.push_back({h_dst + i * dst_stride, po + (i - lo) * dstride, p_sz[i]});
+        for (size_t i = lo; i < hi; i++) jobs.push_back({h_dst ? (void *)(h_dst + i * dst_stride) : h_dst_each[i], po + (i - lo) * dstride, p_sz[i]});
         parallel_copy(c, jobs);
     }
     return CRYO_OK;
 }
 
+/* h_dst: one contiguous K-block buffer; or one destination per block in h_dst_each (the cache's slots, a multi-GPU share):
+ * then a block that failed leaves its destination untouched -- the statuses of a chunk travel with its blocks */
 static int decompress_blocks_piped(cryo_codec *c, int method, const void *const *h_src, const uint32_t *h_src_size, size_t n,
-                                   uint8_t *h_dst, size_t block_size, int32_t *h_status)
+                                   uint8_t *h_dst, void *const *h_dst_each, size_t block_size, int32_t *h_status)
 {
     const size_t K = pipe_chunk_blocks(n, block_size, method), nch = (n + K - 1) / K;
     const bool per_chunk = pipe_kernel_per_chunk(K, method, false);
@@ -781,7 +857,14 @@ static int decompress_blocks_piped(cryo_codec *c, int method, const void *const 
     auto scatter = [&](size_t ch) -> int {
         const size_t lo = ch * K, hi = lo + K < n ? lo + K : n;
         HIP_TRY(c, hipEventSynchronize(c->ev_out[ch & 1]));
-        parallel_copy(c, {{h_dst + lo * block_size, c->pipe_pin[2 + (ch & 1)], (hi - lo) * block_size}});
+        if (h_dst) { parallel_copy(c, {{h_dst + lo * block_size, c->pipe_pin[2 + (ch & 1)], (hi - lo) * block_size}}); return CRYO_OK; }
+        std::vector<CopyJob> jobs;
+        for (size_t i = lo; i < hi; i++) {
+            if (p_st[i] != CRYO_OK) continue;
+            if (!h_dst_each[i]) return CRYO_E_ARG;
+            jobs.push_back({h_dst_each[i], (const uint8_t *)c->pipe_pin[2 + (ch & 1)] + (i - lo) * block_size, block_size});
+        }
+        parallel_copy(c, jobs);
         return CRYO_OK;
     };
     for (size_t ch = 0; ch < nch; ch++) {
@@ -806,6 +889,7 @@ static int decompress_blocks_piped(cryo_codec *c, int method, const void *const 
         if (ch >= 2 && (rc = scatter(ch - 2)) != CRYO_OK) return rc; /* frees output buffer b */
         HIP_TRY(c, hipStreamWaitEvent(c->xfer, c->ev_k[b], 0));
         HIP_TRY(c, hipMemcpyAsync(c->pipe_pin[2 + b], c->hb_dst + lo * block_size, cnt * block_size, hipMemcpyDeviceToHost, c->xfer));
+        if (!h_dst) HIP_TRY(c, hipMemcpyAsync(p_st + lo, d_st + lo, cnt * 4, hipMemcpyDeviceToHost, c->xfer)); /* the scatter skips failed blocks */
         HIP_TRY(c, hipEventRecord(c->ev_out[b], c->xfer));
     }
     if (!per_chunk) {
@@ -814,6 +898,7 @@ static int decompress_blocks_piped(cryo_codec *c, int method, const void *const 
         if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
         HIP_TRY(c, hipEventRecord(c->ev_k[0], c->stream));
         HIP_TRY(c, hipStreamWaitEvent(c->xfer, c->ev_k[0], 0));
+        if (!h_dst) HIP_TRY(c, hipMemcpyAsync(p_st, d_st, n * 4, hipMemcpyDeviceToHost, c->xfer)); /* before the first chunk's event */
         auto d2h = [&](size_t ch) -> int {
             const size_t lo = ch * K, hi = lo + K < n ? lo + K : n;
             HIP_TRY(c, hipMemcpyAsync(c->pipe_pin[2 + (ch & 1)], c->hb_dst + lo * block_size, (hi - lo) * block_size, hipMemcpyDeviceToHost, c->xfer));
@@ -866,8 +951,9 @@ static int compress_blocks_body(cryo_codec *c, int method, int param, const void
     if (!h_src || !h_dst || !h_out_size) return CRYO_E_ARG;
     const size_t bound = cryo_codec_bound(method, block_size);
     if (dst_stride < bound) return CRYO_E_DSTSIZE;
+    ScopedLocalCpus numa_(n * block_size >= ((size_t)8 << 20) ? c : nullptr); /* the caller's share of the copies next to the GPU */
     if (pipe_worth_it(c, n, block_size)) {
-        const int rc = compress_blocks_piped(c, method, param, (const uint8_t *)h_src, block_size, n, (uint8_t *)h_dst, dst_stride, h_out_size);
+        const int rc = compress_blocks_piped(c, method, param, (const uint8_t *)h_src, nullptr, block_size, n, (uint8_t *)h_dst, nullptr, dst_stride, h_out_size);
         if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); if (c->xfer) (void)hipStreamSynchronize(c->xfer); }
         pipe_trim(c);
         return rc;
@@ -920,8 +1006,9 @@ static int decompress_blocks_impl(cryo_codec *c, int method, const void *const *
     if (!c || !method_ok(method) || block_size == 0 || block_size > 0x7E000000u) return CRYO_E_ARG;
     if (n == 0) return CRYO_OK;
     if (!h_src || !h_src_size || (!h_dst && !h_dst_each) || !h_status) return CRYO_E_ARG;
-    if (h_dst && pipe_worth_it(c, n, block_size)) {
-        const int rc = decompress_blocks_piped(c, method, h_src, h_src_size, n, (uint8_t *)h_dst, block_size, h_status);
+    ScopedLocalCpus numa_(n * block_size >= ((size_t)8 << 20) ? c : nullptr);
+    if (pipe_worth_it(c, n, block_size)) {
+        const int rc = decompress_blocks_piped(c, method, h_src, h_src_size, n, (uint8_t *)h_dst, h_dst_each, block_size, h_status);
         /* an error return must not leave copies in flight into the handle's pinned buffers or the caller's memory */
         if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); if (c->xfer) (void)hipStreamSynchronize(c->xfer); }
         pipe_trim(c);
@@ -1235,28 +1322,46 @@ static int compress_blocks_ptrs(cryo_codec *c, int method, int param, const void
     if (n == 0) return CRYO_OK;
     const size_t bound = cryo_codec_bound(method, block_size);
     const size_t dstride = (bound + 15) & ~(size_t)15;
+    ScopedLocalCpus numa_(n * block_size >= ((size_t)8 << 20) ? c : nullptr);
+    if (pipe_worth_it(c, n, block_size)) { /* the single-handle path's staging: pinned double buffers, second stream, worker threads */
+        const int rc = compress_blocks_piped(c, method, param, nullptr, h_src, block_size, n, nullptr, h_dst, dstride, out_size);
+        if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); if (c->xfer) (void)hipStreamSynchronize(c->xfer); }
+        pipe_trim(c);
+        return rc;
+    }
     int rc;
     if ((rc = ensure(c, &c->hb_src, &c->hb_src_cap, n * block_size + 64)) != CRYO_OK) return rc;
     if ((rc = ensure(c, &c->hb_dst, &c->hb_dst_cap, n * dstride + 64)) != CRYO_OK) return rc;
     if ((rc = ensure(c, &c->hb_meta, &c->hb_meta_cap, n * 16 + 64)) != CRYO_OK) return rc;
-    if ((rc = ensure_pinned(c, n * block_size + n * 8)) != CRYO_OK) return rc;
+    if ((rc = ensure_pinned(c, n * dstride + n * 8 + 64)) != CRYO_OK) return rc; /* dstride >= block_size: both directions fit */
     uint8_t *pin = (uint8_t *)c->pin;
-    for (size_t i = 0; i < n; i++) memcpy(pin + i * block_size, h_src[i], block_size);
-    int32_t *h_st = (int32_t *)(pin + n * block_size);
+    {
+        std::vector<CopyJob> jobs;
+        for (size_t i = 0; i < n; i++) jobs.push_back({pin + i * block_size, h_src[i], block_size});
+        parallel_copy(c, jobs);
+    }
     uint32_t *d_sz = (uint32_t *)c->hb_meta;
     int32_t *d_st = (int32_t *)(c->hb_meta + ((n * 4 + 15) & ~(size_t)15));
     HIP_TRY(c, hipMemcpyAsync(c->hb_src, pin, n * block_size, hipMemcpyHostToDevice, c->stream));
     rc = cryo_codec_compress_batch(c, method, param, c->hb_src, block_size, (uint32_t)block_size, n, c->hb_dst, dstride, d_sz, d_st);
     if (rc != CRYO_OK) { (void)hipStreamSynchronize(c->stream); return rc; }
-    HIP_TRY(c, hipMemcpyAsync(out_size, d_sz, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    int32_t *h_st = (int32_t *)(pin + n * dstride);
+    uint32_t *h_sz = (uint32_t *)(pin + n * dstride + n * 4);
+    HIP_TRY(c, hipMemcpyAsync(h_sz, d_sz, n * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipMemcpyAsync(h_st, d_st, n * sizeof(int32_t), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (size_t i = 0; i < n; i++) {
         if (h_st[i] != CRYO_OK) return h_st[i];
-        if (out_size[i] == 0 || out_size[i] > bound) return CRYO_E_HIP;
-        HIP_TRY(c, hipMemcpyAsync(h_dst[i], c->hb_dst + i * dstride, out_size[i], hipMemcpyDeviceToHost, c->stream));
+        if (h_sz[i] == 0 || h_sz[i] > bound) return CRYO_E_HIP;
+        out_size[i] = h_sz[i];
     }
+    /* the compressed blocks come back in ONE copy into the pinned buffer (its input side is no longer needed) and go to
+     * their destinations from there on the worker threads; round 3 copied block by block into pageable memory */
+    HIP_TRY(c, hipMemcpyAsync(pin, c->hb_dst, (n - 1) * dstride + out_size[n - 1], hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<CopyJob> jobs;
+    for (size_t i = 0; i < n; i++) jobs.push_back({h_dst[i], pin + i * dstride, out_size[i]});
+    parallel_copy(c, jobs);
     return CRYO_OK;
 }
 
