@@ -298,7 +298,11 @@ def main():
         barrier()
         t0 = time.perf_counter()
         kernel_ms = []
+        touch = os.environ.get("CRYO_BENCH_TOUCH")   # diagnostic: another kernel sweeps 17 GB of other buffers between the steps
         for _ in range(a.steps):
+            if touch:
+                codec.compare_batch(d_raw, B, d_raw, B, B, n, d_mis)
+                codec.sync()
             codec.timer_start()          # HIP events on the codec's own stream
             step()
             kernel_ms.append(codec.timer_stop())
@@ -341,15 +345,23 @@ def main():
         stride = (bound(method, B) + 15) & ~15
         d_comp, d_sizes, d_off = alloc(n * stride), alloc(4 * n), alloc(8 * n)
         d_off.upload(np.arange(n, dtype=np.uint64) * np.uint64(stride))
-        enc_ms, dec_ms = [], []
+        enc_ms, dec_ms, dec2_ms = [], [], []
+        gap_ms = float(os.environ.get("CRYO_BENCH_GAP_MS", "0"))
 
         def step(timed):
             codec.timer_start()
             codec.compress_batch(method, param, d_raw, B, B, n, d_comp, stride, d_sizes, d_status)
             t1 = codec.timer_stop()
+            if gap_ms:   # diagnostic (CRYO_BENCH_GAP_MS): idle time between the passes, outside both timed regions
+                codec.sync()
+                time.sleep(gap_ms * 1e-3)
             codec.timer_start()
             codec.decompress_batch(method, d_comp, d_off, d_sizes, d_out, B, B, n, d_status)
             t2 = codec.timer_stop()
+            if os.environ.get("CRYO_BENCH_DEC_AGAIN"):   # diagnostic: the same decode once more, right behind the first
+                codec.timer_start()
+                codec.decompress_batch(method, d_comp, d_off, d_sizes, d_out, B, B, n, d_status)
+                dec2_ms.append(codec.timer_stop())
             if timed:
                 enc_ms.append(t1)
                 dec_ms.append(t2)
@@ -364,6 +376,11 @@ def main():
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
         verify_all()
+        if rank == 0 and os.environ.get("CRYO_BENCH_TRACE"):
+            print("[bench trace] encode ms: %s" % " ".join("%.2f" % x for x in enc_ms), file=sys.stderr)
+            print("[bench trace] decode ms: %s" % " ".join("%.2f" % x for x in dec_ms), file=sys.stderr)
+            if dec2_ms:
+                print("[bench trace] decode again ms: %s" % " ".join("%.2f" % x for x in dec2_ms), file=sys.stderr)
         sizes = d_sizes.download(dtype=np.uint32)
         for i in sorted(set(list(range(0, n, max(1, n // 8)))[:8] + [n - 1])):
             c = d_comp.download(int(sizes[i]), offset=i * stride)

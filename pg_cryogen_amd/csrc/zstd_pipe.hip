@@ -90,6 +90,8 @@ struct ZPipe {
     uint32_t *hitems2; /* blocks k_zhufw hands back to k_zhuf (counters[61]) */
     uint8_t *htmp;     /* k_zhufw's scratch: the walkers' symbols before they are moved to the literal pool */
     uint64_t htmp_stride;
+    uint4 *hsegs;      /* per block 64 entries, one per walker: scratch offset of its true symbols, their count, pool offset (k_zmove) */
+    uint32_t *mitems;  /* blocks whose symbols k_zmove moves (counters[60]) */
     uint32_t *irregular;
     uint32_t *sitems; /* blocks with sequences (f * nbmax + k) */
 };
@@ -1014,16 +1016,33 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
     const uint32_t total = (uint32_t)__shfl((int)incl, (int)(lane | 15u), 64);
     const bool fine = (!walker || (okw && n >= myskip && !stale)) && (sid >= nstreams || total == cnt);
     if (!__all(fine)) { fallback(__any(walker && !okw && phase == DONE && n + 24u > cap) ? 4 : (__any(walker && !okw) ? 2 : (__any(walker && n < myskip) ? 5 : 3))); return; }
-    /* ---- move the walkers' symbols to the literal pool: eight segments' loads in flight ---- */
-    /* the scratch bytes other lanes of this wave stored are read below: the stores have to be done, nothing more -- no
-     * other wave touches a line of this block's scratch (an agent-scope fence writes the L2 back: 3x the kernel's time) */
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    /* ---- the move of the walkers' symbols to the literal pool is k_zmove's (round 4): here it was 35 % of this
+     * kernel's wave time at seven waves per CU (22 KB of LDS per wave); a kernel that does nothing else runs it with the
+     * chip full of waves ---- */
+    {
+        const uint32_t srcp = (uint32_t)(tmp - tbase) + myskip;
+        const uint32_t dstp = oofs + (incl - ntrue);
+        P.hsegs[(uint64_t)it * 64u + lane] = make_uint4(srcp, ntrue, dstp, 0u);
+        if (lane == 0u) P.mitems[atomicAdd(&P.counters[60], 1u)] = it;
+    }
+    HW_STAMP(62);
+}
+
+/* k_zmove: a wave per block k_zhufw decoded: its walkers' true symbols, scratch -> literal pool.  Whole 16-byte stores,
+ * segment after segment in the order of their destinations: what a segment's last store writes beyond its symbols is
+ * overwritten by the next segment's first store (same wave: in order), and behind a block's literals the pool has 16
+ * spare bytes.  Four segments' loads are issued before the previous four are stored. */
+__global__ void __launch_bounds__(64) k_zmove(ZPipe P)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    if (blockIdx.x >= uni(P.counters[60])) return;
+    const uint32_t it = uni(P.mitems[blockIdx.x]);
+    const ZBlk *d = P.blks + it;
+    const uint32_t f = it / P.nbmax, kblk = it - f * P.nbmax;
+    const uint8_t *const tbase = P.htmp + (uint64_t)f * P.htmp_stride + ((2u * (uint64_t)uni(d->lit_src) + 127u) & ~(uint64_t)127) + (uint64_t)kblk * kHwBlockSlack;
     uint8_t *const lit = P.lits + (uint64_t)f * P.litcap + uni(d->lit_src);
-    const uint32_t srcp = (uint32_t)(tmp - tbase) + myskip;
-    const uint32_t dstp = oofs + (incl - ntrue);
-    /* Whole 16-byte stores, segment after segment in the order of their destinations: what a segment's last store
-     * writes beyond its symbols is overwritten by the next segment's first store (same wave: in order), and behind a
-     * block's literals the pool has 16 spare bytes.  Four segments' loads are issued before the previous four are stored. */
+    const uint4 sg4 = P.hsegs[(uint64_t)it * 64u + lane];
+    const uint32_t srcp = sg4.x, ntrue = sg4.y, dstp = sg4.z;
     const uint32_t o0 = lane * 16u;
     uint4 va[4], vb[4], wa[4], wb[4];
     auto loads = [&](uint4 (&xa)[4], uint4 (&xb)[4], const uint32_t sg) __attribute__((always_inline)) {
@@ -1061,7 +1080,6 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
         if (sg + 8u < 64u) loads(va, vb, sg + 8u);
         stores(wa, wb, sg + 4u);
     }
-    HW_STAMP(62);
 }
 
 /* ------------------------------------------------------------------------------------------------ K3 */
@@ -1656,7 +1674,7 @@ namespace {
 struct Layout {
     uint32_t F, nbmax, litcap, seqcap;
     size_t htmp_stride;
-    size_t o_frames, o_blks, o_huf, o_seqt, o_predef, o_lits, o_seqs, o_chain, o_cnt, o_hitems, o_hitems2, o_htmp, o_irreg, o_sitems, o_fused, total;
+    size_t o_frames, o_blks, o_huf, o_seqt, o_predef, o_lits, o_seqs, o_chain, o_cnt, o_hitems, o_hitems2, o_htmp, o_irreg, o_sitems, o_hsegs, o_mitems, o_fused, total;
 };
 
 constexpr uint32_t kFusedGridForIrregular = 256;
@@ -1671,7 +1689,8 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     y.litcap = ((B + 15u) & ~15u) + 32u * y.nbmax;
     y.htmp_stride = al256(2u * (size_t)y.litcap + (size_t)y.nbmax * kHwBlockSlack);
     const size_t per_frame = y.htmp_stride + sizeof(ZFrame) + (size_t)y.nbmax * (sizeof(ZBlk) + kHufTblWords * 2u + kSeqTblWords * 4u + 8u) +
-                             y.litcap + (size_t)(B / 6u) * (sizeof(uint2) + sizeof(uint2)) /* sequence pool share */ + 4u;
+                             y.litcap + (size_t)(B / 6u) * (sizeof(uint2) + sizeof(uint2)) /* sequence pool share */ + 4u +
+                             (size_t)y.nbmax * (64u * sizeof(uint4) + 4u) /* k_zmove's segment lists */;
     /* Tile size.  K2 and K3 are bound by LDS capacity (two workgroups per CU, 512 per chip): 14848 frames
      * = 512 x 29 fill exactly one round of K3 (and 928 waves of 16 = two rounds of K2, the second 81 % full); the
      * workspace budget may force less. */
@@ -1707,6 +1726,8 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     y.o_htmp = o; o = al256(o + (size_t)y.F * y.htmp_stride + 64u);
     y.o_irreg = o; o = al256(o + (size_t)y.F * 4u);
     y.o_sitems = o; o = al256(o + (size_t)y.F * y.nbmax * 4u);
+    y.o_hsegs = o; o = al256(o + (size_t)y.F * y.nbmax * 64u * sizeof(uint4));
+    y.o_mitems = o; o = al256(o + (size_t)y.F * y.nbmax * 4u);
     y.o_fused = o; o = al256(o + zstd_fused_workspace(kFusedGridForIrregular));
     y.total = o;
     return y;
@@ -1800,6 +1821,8 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
         P.htmp_stride = y.htmp_stride;
         P.irregular = (uint32_t *)(ws + y.o_irreg);
         P.sitems = (uint32_t *)(ws + y.o_sitems);
+        P.hsegs = (uint4 *)(ws + y.o_hsegs);
+        P.mitems = (uint32_t *)(ws + y.o_mitems);
         const uint64_t left = n_blocks - first;
         P.first = first;
         P.F = (uint32_t)(left < y.F ? left : y.F);
@@ -1808,6 +1831,7 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
         if (old_huf) hipLaunchKernelGGL(k_zhuf, dim3((P.F * P.nbmax + kHufPerWave - 1u) / kHufPerWave), dim3(64), huf_pad, st, P, P.hitems, 1u);
         else {
             hipLaunchKernelGGL(k_zhufw, dim3(P.F * P.nbmax), dim3(64), huf_pad, st, P);
+            hipLaunchKernelGGL(k_zmove, dim3(P.F * P.nbmax), dim3(64), 0, st, P);
             hipLaunchKernelGGL(k_zhuf, dim3((P.F * P.nbmax + kHufPerWave - 1u) / kHufPerWave), dim3(64), 0, st, P, P.hitems2, 61u);
         }
         hipLaunchKernelGGL(k_zchain, dim3((P.F * P.nbmax + kChW - 1u) / kChW), dim3(64), seq_pad, st, P);
