@@ -20,9 +20,9 @@ pre = os.path.join(root, "profiles", "%s_%s" % (tag, wl))
 bench = json.loads([l for l in open(os.path.join(src, "bench.json")) if l.startswith("{")][-1])
 KERNELS = {
     "lz4_decode": ("k_lz4_index", "k_lz4_dec_seq", "k_lz4_dec_ring"),
-    "zstd_decode": ("k_zplan", "k_zhuf", "k_zchain", "k_zmat", "k_zexec", "k_zstd_dec"),
+    "zstd_decode": ("k_zplan", "k_zhuf", "k_zmove", "k_zchain", "k_zmat", "k_zexec", "k_zstd_dec"),
     "lz4": ("k_lz4_index", "k_lz4_dec_seq", "k_lz4_dec_ring", "k_lz4_enc"),
-    "zstd": ("k_zplan", "k_zhuf", "k_zchain", "k_zmat", "k_zexec", "k_zstd_dec", "k_zstd_enc"),
+    "zstd": ("k_zplan", "k_zhuf", "k_zmove", "k_zchain", "k_zmat", "k_zexec", "k_zstd_dec", "k_zstd_enc"),
 }[wl]
 
 stats = glob.glob(os.path.join(src, "stats", "**", "*kernel_stats.csv"), recursive=True)[0]
