@@ -287,3 +287,58 @@ def test_workspace_options_and_trim(oracle):
         c.set_option(cc.OPT_WORKSPACE_MAX_BYTES, 0)
         c.set_option(cc.OPT_LZ4_DECODE_PATH, cc.LZ4_PATH_AUTO)
         check(c)
+
+
+def test_pipelined_pointer_forms(codec, oracle):
+    """Round 4: the one-destination-per-block decode (the cache's scatter call) and a handle's share of a multi-GPU call
+    take the pipelined staging too.  97 MiB calls: a destination per block in shuffled order, a corrupt and an empty
+    block that must leave their destinations untouched; two handles on one GPU through cryo_multi_* (block i -> handle
+    i mod 2, every share pipelined), bytes and sizes equal to the oracle's."""
+    import ctypes as C
+    from pg_cryogen_amd import METHOD_LZ4, METHOD_ZSTD, bound, codec as cc
+    L = codec.L
+    B, n = 131072, 777
+    uniq = [oracle.synth(10, i, B, i % 5) for i in range(24)]
+    raw = np.concatenate([uniq[i % 24] for i in range(n)])
+    rng = np.random.default_rng(5)
+    for method, param in ((METHOD_LZ4, 1), (METHOD_ZSTD, 1)):
+        enc = (oracle.lz4_compress if method == METHOD_LZ4 else oracle.zstd_compress)
+        exp = [enc(u, param) for u in uniq]
+        comps = [exp[i % 24] for i in range(n)]
+        comps[123] = comps[123][:150].copy()
+        comps[124] = np.zeros(0, np.uint8)
+        ptrs = (C.c_void_p * n)(*[c.ctypes.data if len(c) else None for c in comps])
+        csz = np.array([len(c) for c in comps], np.uint32)
+        # scatter: destinations in a shuffled order inside one big buffer
+        perm = rng.permutation(n)
+        dec = np.full(n * B, 0x5A, np.uint8)
+        dsts = (C.c_void_p * n)(*[dec.ctypes.data + int(perm[i]) * B for i in range(n)])
+        st = np.zeros(n, np.int32)
+        assert L.cryo_codec_decompress_blocks_to(codec.h, method, ptrs, csz.ctypes.data, n, dsts, B, st.ctypes.data) == 0
+        for i in range(n):
+            got = dec[int(perm[i]) * B:(int(perm[i]) + 1) * B]
+            if i in (123, 124):
+                assert st[i] != 0 and (got == 0x5A).all(), i          # failed: destination untouched
+            else:
+                assert st[i] == 0 and np.array_equal(got, uniq[i % 24]), (method, i)
+        # two handles behind one call
+        h = C.c_void_p()
+        assert L.cryo_multi_open((C.c_int * 2)(0, 0), 2, C.byref(h)) == 0
+        try:
+            stride = bound(method, B) + 24
+            out = np.zeros(n * stride, np.uint8)
+            sizes = np.zeros(n, np.uint32)
+            assert L.cryo_multi_compress_blocks(h, method, param, raw.ctypes.data, B, n, out.ctypes.data, stride, sizes.ctypes.data) == 0
+            for i in range(n):
+                e = exp[i % 24]
+                assert int(sizes[i]) == len(e) and np.array_equal(out[i * stride:i * stride + len(e)], e), (method, i)
+            dec2 = np.full(n * B, 0xA5, np.uint8)
+            st2 = np.zeros(n, np.int32)
+            assert L.cryo_multi_decompress_blocks(h, method, ptrs, csz.ctypes.data, n, dec2.ctypes.data, B, st2.ctypes.data) == 0
+            for i in range(n):
+                if i in (123, 124):
+                    assert st2[i] != 0 and (dec2[i * B:(i + 1) * B] == 0xA5).all(), i
+                else:
+                    assert st2[i] == 0 and np.array_equal(dec2[i * B:(i + 1) * B], uniq[i % 24]), (method, i)
+        finally:
+            L.cryo_multi_close(h)
