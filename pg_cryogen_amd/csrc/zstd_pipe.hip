@@ -1119,6 +1119,9 @@ __device__ inline uint32_t ml_xbits(uint32_t sym)
 #ifndef CRYO_ZCHAIN_PER_WAVE
 #define CRYO_ZCHAIN_PER_WAVE 29
 #endif
+#ifndef CRYO_ZCHAIN_QUAD
+#define CRYO_ZCHAIN_QUAD 1 /* round 4: a quad of lanes per block (k_zchain4); 0: a lane per block (k_zchain) */
+#endif
 constexpr uint32_t kChW = CRYO_ZCHAIN_PER_WAVE;
 static_assert(kChW <= 32, "two groups of 16 walkers");
 
@@ -1340,6 +1343,237 @@ __global__ void __launch_bounds__(64) k_zchain(ZPipe P)
     }
     if (opened && z.pos != 0) bad = true; /* the bitstream must be consumed exactly */
     if (bad) atomicOr(&P.frames[f].flags, F_BAD);
+}
+
+/* k_zchain4 (round 4): the same chain with a QUAD of lanes per block -- lane 0 the literal-length state, lane 1 the match-
+ * length state, lane 2 the offset state, lane 3 none (it helps with the ring and holds its tongue).  With a lane per block a
+ * sequence cost 114 wave-instructions, three table entries decoded one after the other on one lane, and 29 lanes of 64 were
+ * in use (LDS: 2.5 KB of tables per block; every block of the headline data carries tables of the format's maximum logs).
+ * The kernel holds 156 of a CU's 160 KB of LDS while it runs -- nothing else of the pipeline fits beside it -- so its length
+ * is the call's: 5 tiles x 3.6 ms of 27 ms.  Here the three lanes decode their entries at once; what crosses lanes is the
+ * number of extra bits (to skip) and the state-bit counts in front of a lane's own (DPP quad broadcasts, no LDS); the
+ * stream position, the window and the ring bookkeeping are computed by all four lanes alike, and the quad loads its own
+ * half-line of input (four 16-byte pieces: no exchange with other lanes).  16 blocks per wave, 43 KB of LDS, three waves per
+ * CU; records, checks and verdicts are k_zchain's bit for bit. */
+constexpr uint32_t kCqW = 16;
+struct ChainQLds {
+    uint16_t tab[kCqW][kSeqTblWords];
+    uint8_t ring[kCqW * kChStride + 16]; /* + one trash slot for the wave */
+};
+
+template <int CTRL>
+__device__ inline uint32_t quad_get(uint32_t v) /* lane CTRL / 0x55 of this lane's quad */
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+struct ChainQuad {
+    int32_t s0, pos, cb, lowh, fillh;
+    uint32_t pend;
+    uint32_t st;   /* this lane's FSE state */
+    uint32_t e;    /* ... and its table entry */
+    uint32_t i, nseq, sh;
+    uint64_t raw;
+    bool rd_ok;
+};
+
+typedef uint32_t cq_u32x4 __attribute__((ext_vector_type(4)));
+template <int J, bool FEED>
+__device__ inline void chainq_turn(uint8_t *ring, const uint16_t *tab, ChainQuad &z, const uint32_t k, const bool mine, const int32_t c,
+                                   const uint32_t m1, const uint32_t m2, cq_u32x4 &fd, uint32_t &fa, uint32_t &fm, const uint8_t *gsrc,
+                                   const uint32_t vend, const uint32_t myring, const uint32_t trash_lds, uint2 *out, uint2 *trash, bool &bad)
+{
+    uint32_t wi = 0;
+    if (FEED) { /* the quad asks for the next half-line of its own stream */
+        const bool want = (z.i < z.nseq) & (z.cb < 64 * (z.lowh + 1)) & (64 * z.lowh > z.s0);
+        wi = want ? 1u : 0u;
+        z.lowh -= (int32_t)wi;
+    }
+    uint2 rec;
+    bool go;
+    {
+        const bool on = z.i < z.nseq;
+        go = on & z.rd_ok;
+        const uint32_t e = z.e;
+        const uint32_t x = e >> 11, v = e & 1023u;
+        const uint32_t n = mine ? (uint32_t)(__builtin_clz(v) + c) : 0u;
+        const uint32_t x0 = quad_get<0x00>(x), x1 = quad_get<0x55>(x), x2 = quad_get<0xAA>(x);
+        const uint32_t n0 = quad_get<0x00>(n), n1 = quad_get<0x55>(n), n2 = quad_get<0xAA>(n);
+        const uint32_t X = x0 + x1 + x2, N = n0 + n1 + n2;
+        const uint32_t pre = (n0 & m1) + (n1 & m2); /* state bits in front of this lane's: LL, then ML, then OF */
+        const uint64_t win = z.raw << z.sh;
+        uint32_t W = (uint32_t)((win << X) >> 32);
+        const bool ovf = go & (X + N > 57u);
+        if (__any(ovf)) { /* more bits than one window holds: the state bits come from a second read */
+            if (ovf) {
+                const int32_t p2 = z.pos - (int32_t)X;
+                const int32_t cb2 = z.s0 + ((p2 - 1) >> 3);
+                uint64_t r2;
+                __builtin_memcpy(&r2, ring + myring + ((uint32_t)(cb2 - 7) & (kChRing - 1u)), 8);
+                W = (uint32_t)((r2 << (7u - ((uint32_t)(p2 - 1) & 7u))) >> 32);
+            }
+        }
+        const uint32_t b = __builtin_amdgcn_ubfe(W, 32u - pre - n, n);
+        const uint32_t ns = mine ? (v << n) - (1u << (c + 31)) + b : 0u;
+        const int32_t npos = z.pos - (int32_t)(X + N);
+        /* the record, as k_zchain writes it: unread bits | LL state << 20, OF state | ML state << 8 (lane 0's is stored) */
+        const uint32_t sm = quad_get<0x55>(z.st), so = quad_get<0xAA>(z.st);
+        rec = make_uint2((uint32_t)z.pos | (z.st << 20), so | (sm << 8));
+        z.st = go ? ns : z.st;
+        z.pos = go ? npos : z.pos;
+        const bool neg = go & (npos < 0); /* read past the start of the stream */
+        bad = bad | neg;
+        z.nseq = neg ? 0u : z.nseq;
+    }
+    z.cb = z.s0 + ((z.pos - 1) >> 3);
+    z.sh = 7u - ((uint32_t)(z.pos - 1) & 7u);
+    z.rd_ok = (z.cb - 16 >= 64 * z.fillh) | (64 * z.fillh <= z.s0);
+    __builtin_memcpy(&z.raw, ring + myring + ((uint32_t)(z.cb - 7) & (kChRing - 1u)), 8);
+    z.e = tab[z.st];
+    *((go & (k == 0u)) ? out + z.i : trash) = rec;
+    z.i += go ? 1u : 0u;
+    if (!FEED) return;
+    /* The piece slot J's load brought an iteration ago.  The load is inline assembly and its wait is written by hand (as in
+     * lz4_index.hip): left to the compiler, the four slots were copied between register sets at the loop's latch, behind
+     * s_waitcnt vmcnt(9) / (6) / (3) / (0) -- every iteration of eight sequences drained the load issued a turn earlier, a
+     * trip to memory on the chain of a wave that has its SIMD to itself.  An iteration issues 8 record stores and 4 loads;
+     * between slot J's load and its commit lie exactly 11 younger operations. */
+    asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
+    *reinterpret_cast<cq_u32x4 *>(ring + fa) = fd;
+    *reinterpret_cast<uint2 *>(ring + fm) = make_uint2(fd[0], fd[1]);
+    {
+        const uint32_t got = (z.pend >> J) & 1u;
+        z.fillh -= (int32_t)got;
+        z.pend = (z.pend & ~(1u << J)) | (wi << J);
+    }
+    {
+        const bool p = wi != 0u;
+        const uint32_t o = ((uint32_t)z.lowh << 6) + k * 16u;
+        fa = p ? myring + (o & (kChRing - 1u)) : trash_lds;
+        fm = (p & ((o & (kChRing - 1u)) == 0u)) ? myring + kChRing : trash_lds;
+        const uint8_t *g = gsrc + ((p & (o < vend)) ? o : 0u); /* always one load per turn (k_zchain) */
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(fd) : "v"(g));
+    }
+}
+
+__global__ void __launch_bounds__(64) k_zchain4(ZPipe P)
+{
+    __shared__ __attribute__((aligned(16))) ChainQLds L;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t nitems = uni(P.counters[3]);
+    const uint32_t i0 = blockIdx.x * kCqW;
+    if (i0 >= nitems) return;
+    for (uint32_t j = 0; j < kCqW && i0 + j < nitems; j++) {
+        const uint32_t it = uni(P.sitems[i0 + j]);
+        const uint32_t fj = it / P.nbmax;
+        const ZBlk *d = P.blks + it;
+        const uint32_t slots = uni(d->slots), logs = uni(d->logs);
+#pragma unroll
+        for (int kind = 0; kind < 3; kind++) {
+            const uint32_t slot = (slots >> (8 * kind)) & 255u, lg = (logs >> (8 * kind)) & 255u;
+            const uint32_t goff = kind == 0 ? 0u : (kind == 1 ? 1024u : 512u);
+            const uint32_t *g = (slot == kPredefSlot ? P.predef : P.seqt + ((uint64_t)fj * P.nbmax + slot) * kSeqTblWords) + goff;
+            for (uint32_t q = lane; q < (1u << lg); q += 64u) { /* 25-bit workspace entry -> 16 bits: extra-bit count (5) | v (10) */
+                const uint32_t e = g[q], nb = (e >> 10) & 15u;
+                L.tab[j][goff + q] = (uint16_t)((((e >> 20) & 31u) << 11) | (1u << (lg - nb)) | ((e & 1023u) >> nb));
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    const uint32_t q = lane >> 2, k = lane & 3u;
+    bool act = i0 + q < nitems;
+    const uint32_t it = act ? P.sitems[i0 + q] : P.sitems[i0];
+    const uint32_t f = it / P.nbmax;
+    const ZBlk *d = P.blks + it;
+    if (act && (P.frames[f].flags & (F_BAD | F_IRREG))) act = false;
+    const uint64_t fo = P.src_off[P.first + f];
+    const uint64_t aoff = fo & ~(uint64_t)63;
+    const uint32_t delta = (uint32_t)(fo & 63u);
+    const uint32_t vend = delta + P.src_size[P.first + f];
+    const uint32_t logs = d->logs;
+    const uint32_t sq_off = d->sq_off, sq_len = d->sq_len;
+    const uint8_t *gmine = P.src_base + aoff;
+    const uint32_t myring = q * kChStride;
+    const uint32_t trash_lds = kCqW * kChStride;
+    /* kinds in the order their state bits lie in the stream: LL (lane 0), ML (lane 1), OF (lane 2) */
+    const uint32_t lgl = logs & 255u, lgo = (logs >> 8) & 255u, lgm = (logs >> 16) & 255u;
+    const bool mine = k < 3u;
+    const uint32_t lgk = k == 0u ? lgl : (k == 1u ? lgm : lgo);
+    const int32_t c = (int32_t)lgk - 31;
+    const uint32_t m1 = k >= 1u ? ~0u : 0u, m2 = k >= 2u ? ~0u : 0u;
+    const uint16_t *tab = L.tab[q] + (k == 0u ? 0u : (k == 1u ? 512u : (k == 2u ? 1024u : 0u)));
+    ChainQuad z;
+    z.s0 = (int32_t)(delta + sq_off);
+    z.pos = 0; z.cb = z.s0; z.lowh = 0; z.fillh = 0; z.pend = 0; z.st = 0; z.e = 0; z.i = 0; z.nseq = 0; z.sh = 0; z.raw = 0;
+    bool bad = false;
+    bool opened = act && sq_len >= 1u;
+    uint32_t last = 0;
+    if (opened) last = gmine[delta + sq_off + sq_len - 1u];
+    if (last == 0u) opened = false;
+    if (act && !opened) bad = true;
+    if (opened) {
+        /* the stream's top two half-lines: each lane of the quad its piece */
+        const int32_t s1 = z.s0 + (int32_t)sq_len;
+        const int32_t ht = (s1 - 1) >> 6;
+        const int32_t hl = ht >= 1 ? ht - 1 : 0;
+        for (int32_t h = hl; h <= ht; h++) {
+            const uint32_t o = (uint32_t)h * 64u + k * 16u;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (o < vend) v = *reinterpret_cast<const uint4 *>(gmine + o);
+            *reinterpret_cast<uint4 *>(L.ring + myring + (o & (kChRing - 1u))) = v;
+            if ((o & (kChRing - 1u)) == 0u) *reinterpret_cast<uint2 *>(L.ring + myring + kChRing) = make_uint2(v.x, v.y);
+        }
+        z.lowh = z.fillh = hl;
+        z.nseq = d->nseq - 1u; /* the turns take every sequence that is followed by state bits; the block's last one after the loop */
+        z.pos = (int32_t)(sq_len - 1u) * 8 + (31 - __builtin_clz(last));
+    }
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    if (opened) {
+        /* initial states: LL, OF, ML from the top of the stream (<= 26 bits) */
+        const int32_t cb = z.s0 + ((z.pos - 1) >> 3);
+        uint64_t r;
+        __builtin_memcpy(&r, L.ring + myring + ((uint32_t)(cb - 7) & (kChRing - 1u)), 8);
+        const uint32_t W = (uint32_t)((r << (7u - ((uint32_t)(z.pos - 1) & 7u))) >> 32);
+        const uint32_t sl = __builtin_amdgcn_ubfe(W, 32u - lgl, lgl);
+        const uint32_t so = __builtin_amdgcn_ubfe(W, 32u - lgl - lgo, lgo);
+        const uint32_t sm = __builtin_amdgcn_ubfe(W, 32u - lgl - lgo - lgm, lgm);
+        z.st = k == 0u ? sl : (k == 1u ? sm : (k == 2u ? so : 0u));
+        z.pos -= (int32_t)(lgl + lgo + lgm);
+        if (z.pos < 0) { bad = true; z.nseq = 0; z.pos = 0; opened = false; }
+    }
+    __builtin_amdgcn_wave_barrier();
+    z.cb = z.s0 + ((z.pos - 1) >> 3);
+    z.sh = 7u - ((uint32_t)(z.pos - 1) & 7u);
+    z.rd_ok = true; /* the top of the stream is in the ring */
+    __builtin_memcpy(&z.raw, L.ring + myring + ((uint32_t)(z.cb - 7) & (kChRing - 1u)), 8);
+    z.e = mine ? tab[z.st] : 0u;
+
+    uint2 *out = P.chain + (opened ? d->seq_base : 0u);
+    uint2 *trash = P.chain + P.seqcap + lane;
+    cq_u32x4 fd0 = {0, 0, 0, 0}, fd1 = fd0, fd2 = fd0, fd3 = fd0;
+    uint32_t fa0 = trash_lds, fa1 = trash_lds, fa2 = trash_lds, fa3 = trash_lds, fm0 = trash_lds, fm1 = trash_lds, fm2 = trash_lds, fm3 = trash_lds;
+#define CQ_TURN(J, FEED, FD, FA, FM) chainq_turn<J, FEED>(L.ring, tab, z, k, mine, c, m1, m2, FD, FA, FM, gmine, vend, myring, trash_lds, out, trash, bad);
+    if (__any(z.i < z.nseq)) {
+        do { /* (do-while: with `while` the register allocator copies the slots at the top of the loop, lz4_index.hip) */
+            CQ_TURN(0, true, fd0, fa0, fm0) CQ_TURN(0, false, fd0, fa0, fm0)
+            CQ_TURN(1, true, fd1, fa1, fm1) CQ_TURN(1, false, fd1, fa1, fm1)
+            CQ_TURN(2, true, fd2, fa2, fm2) CQ_TURN(2, false, fd2, fa2, fm2)
+            CQ_TURN(3, true, fd3, fa3, fm3) CQ_TURN(3, false, fd3, fa3, fm3)
+        } while (__any(z.i < z.nseq));
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the compiler does not know of the assembly loads */
+#undef CQ_TURN
+    if (opened && !bad) { /* the last sequence: its extra bits, no state bits */
+        const uint32_t x = z.e >> 11;
+        const uint32_t X = quad_get<0x00>(x) + quad_get<0x55>(x) + quad_get<0xAA>(x);
+        const uint32_t sm = quad_get<0x55>(z.st), so = quad_get<0xAA>(z.st);
+        if (k == 0u) out[z.i] = make_uint2((uint32_t)z.pos | (z.st << 20), so | (sm << 8));
+        z.pos -= (int32_t)X;
+    }
+    if (opened && z.pos != 0) bad = true; /* the bitstream must be consumed exactly */
+    if (bad && k == 0u) atomicOr(&P.frames[f].flags, F_BAD);
 }
 
 /* K3'': values and repeat offsets, one wave per frame, 64 sequences at a time.  A sequence changes the offset history
@@ -1700,7 +1934,8 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     uint64_t F = budget / per_frame;
     /* one full round of k_zchain: 512 waves x 29 zstd blocks; a frame of B bytes is ceil(B / 128 KiB) of them (round 3:
      * 1 MiB frames in tiles of 2320 made 1.25 rounds, the second three quarters empty) */
-    const uint64_t kTile = (512u * kChW) / ((B + kZBlockMax - 1u) / kZBlockMax ? (B + kZBlockMax - 1u) / kZBlockMax : 1u);
+    /* (k_zchain4: 768 waves x 16 blocks, three waves per CU) */
+    const uint64_t kTile = ((CRYO_ZCHAIN_QUAD ? 768u * kCqW : 512u * kChW)) / ((B + kZBlockMax - 1u) / kZBlockMax ? (B + kZBlockMax - 1u) / kZBlockMax : 1u);
     if (F > kTile) F = kTile;
     if (F >= 464u && F != kTile) F -= F % 464u;
     else if (F < 16u) F = 16u;
@@ -1834,7 +2069,11 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
             hipLaunchKernelGGL(k_zmove, dim3(P.F * P.nbmax), dim3(64), 0, st, P);
             hipLaunchKernelGGL(k_zhuf, dim3((P.F * P.nbmax + kHufPerWave - 1u) / kHufPerWave), dim3(64), 0, st, P, P.hitems2, 61u);
         }
+#if CRYO_ZCHAIN_QUAD
+        hipLaunchKernelGGL(k_zchain4, dim3((P.F * P.nbmax + kCqW - 1u) / kCqW), dim3(64), seq_pad, st, P);
+#else
         hipLaunchKernelGGL(k_zchain, dim3((P.F * P.nbmax + kChW - 1u) / kChW), dim3(64), seq_pad, st, P);
+#endif
         hipLaunchKernelGGL(k_zmat, dim3(P.F), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_zexec, dim3(P.F), dim3(64), 0, st, P);
         const uint64_t fg = P.F < kFusedGridForIrregular ? P.F : kFusedGridForIrregular;

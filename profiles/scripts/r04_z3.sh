@@ -1,0 +1,12 @@
+#!/bin/bash
+# round 4: k_zchain4 (a quad of lanes per block, 3 waves per CU) against k_zchain (a lane per block) = variant zlane
+cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out/r04_z3
+{
+timeout 1500 python3 -m pytest tests/test_gpu_zstd.py -x -q 2>&1 | tail -3
+python3 profiles/scripts/ab.py --prof --steps 8 --args="--workload zstd_decode" zlane prod
+python3 profiles/scripts/ab.py --steps 8 --args="--workload zstd_decode" zlane prod zlane prod
+python3 profiles/scripts/ab.py --steps 6 --args="--workload zstd_decode --blocks 8192 --block-size 1048576" zlane prod
+python3 profiles/scripts/ab.py --steps 6 --args="--workload zstd_decode --level 5 --blocks 16384" zlane prod
+python3 profiles/scripts/ab.py --steps 6 --args="--workload zstd_decode --blocks 4096" zlane prod
+python3 profiles/scripts/ab.py --steps 6 --args="--workload zstd_decode --blocks 64" zlane prod
+} 2>&1 | tee gpurun_out/r04_z3/out.txt
