@@ -283,6 +283,9 @@ def main():
         assert (d_status.download(dtype=np.int32) == 0).all(), "encode status"
         sizes = d_sizes.download(dtype=np.uint32)
         d_off.upload(np.arange(n, dtype=np.uint64) * np.uint64(stride))
+        if os.environ.get("CRYO_BENCH_SAME_BLOCK"):   # diagnostic (with --no-verify): every block decodes block 0's stream -- the
+            d_off.upload(np.zeros(n, dtype=np.uint64))   # input and its index rows come from cache, the work per block is unchanged
+            d_sizes.upload(np.full(n, sizes[0], dtype=np.uint32))
         comp_bytes = int(sizes.astype(np.uint64).sum())
         sample_idx = sorted(set(list(range(0, n, max(1, n // 16)))[:16] + [n - 1]))
         for i in sample_idx:   # spot check vs the CPU oracle
