@@ -1937,6 +1937,8 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     /* (k_zchain4: 768 waves x 16 blocks, three waves per CU) */
     const uint64_t kTile = ((CRYO_ZCHAIN_QUAD ? 768u * kCqW : 512u * kChW)) / ((B + kZBlockMax - 1u) / kZBlockMax ? (B + kZBlockMax - 1u) / kZBlockMax : 1u);
     if (F > kTile) F = kTile;
+    static const uint64_t tile_env = cryo_tuning_env("CRYO_ZSTD_TILE") ? (uint64_t)atoll(cryo_tuning_env("CRYO_ZSTD_TILE")) : 0; /* tuning aid (debug builds) */
+    if (tile_env) F = tile_env;
     if (F >= 464u && F != kTile) F -= F % 464u;
     else if (F < 16u) F = 16u;
     if (F > n_blocks) F = n_blocks;
