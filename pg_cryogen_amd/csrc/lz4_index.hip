@@ -358,14 +358,23 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
 #else
 #define IDX_ROUNDS() IDX_ROUND(0, 1, 2, 3, outA0, outA1)
 #endif
-    /* (the compiler does not see the assembly loads: nothing it generates behind a walk may meet one still in flight) */
+    /* (the compiler does not see the assembly loads: nothing it generates behind a walk may meet one still in flight.  The
+     * drain names every slot: their registers are dead to the compiler once the loop is left, and without the operands it
+     * may hand them to something else in FRONT of the drain -- k_zchain4 of zstd_pipe.hip did, and a late load overwrote
+     * an address) */
+#if CRYO_IDX_DIST == 2
+#define IDX_DRAIN() asm volatile("s_waitcnt vmcnt(0)" : "+v"(fd0), "+v"(fe0), "+v"(fd1), "+v"(fe1), "+v"(fd2), "+v"(fe2), "+v"(fd3), "+v"(fe3), \
+                                 "+v"(fd4), "+v"(fe4), "+v"(fd5), "+v"(fe5), "+v"(fd6), "+v"(fe6), "+v"(fd7), "+v"(fe7) : : "memory");
+#else
+#define IDX_DRAIN() asm volatile("s_waitcnt vmcnt(0)" : "+v"(fd0), "+v"(fe0), "+v"(fd1), "+v"(fe1), "+v"(fd2), "+v"(fe2), "+v"(fd3), "+v"(fe3) : : "memory");
+#endif
 #define IDX_WALK()                                              \
     if (__any(!done)) {                                         \
         do {                                                    \
             IDX_ROUNDS()                                        \
         } while (__any(!done));                                 \
     }                                                           \
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            \
+    IDX_DRAIN()                                                 \
     if (walker) IDX_FLUSH()
 
     /* ---- phase 1: every walker its own segment ---- */
@@ -448,6 +457,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
         }
     }
 #undef IDX_WALK
+#undef IDX_DRAIN
 #undef IDX_ROUNDS
 #undef IDX_ROUND
 #undef IDX_TURN

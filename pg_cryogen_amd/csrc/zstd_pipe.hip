@@ -562,8 +562,11 @@ __global__ void __launch_bounds__(64) k_zhuf(ZPipe P, const uint32_t *__restrict
     __shared__ __attribute__((aligned(16))) HufLds L;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nitems = uni(P.counters[counter]);
-    const uint32_t base = blockIdx.x * kHufPerWave;
-    if (base >= nitems) return;
+    /* grid-stride (round 4): as the walkers' fallback this kernel usually has nothing to do, and 2 304 workgroups that each
+     * need 70 KB of LDS before they can find that out took 0.7 ms per tile to come and go, in the tile's stream, in front of
+     * k_zchain; the launcher sizes the grid for the chip (two of these fit a CU), not for the worst case */
+    for (uint32_t base = blockIdx.x * kHufPerWave; base < nitems; base += gridDim.x * kHufPerWave) {
+    if (base != blockIdx.x * kHufPerWave) { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
 
     /* stage the 16 first-level tables */
     for (uint32_t j = 0; j < kHufPerWave && base + j < nitems; j++) {
@@ -652,6 +655,7 @@ __global__ void __launch_bounds__(64) k_zhuf(ZPipe P, const uint32_t *__restrict
         ok = lb.pos == 0; /* must end exactly */
     }
     if (have && !ok) atomicOr(&P.frames[f].flags, F_BAD);
+    }
 }
 
 /* per-lane input rings fed cooperatively by the wave (k_zhufw, k_zchain) */
@@ -753,12 +757,10 @@ __device__ inline void store_head(uint8_t *p, uint4 v, uint32_t n)
     if (n & 1u) *p = (uint8_t)v.x;
 }
 
-__global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
+__device__ __attribute__((always_inline)) inline void zhufw_item(const ZPipe &P, HufwLds &L, const uint32_t item)
 {
-    __shared__ __attribute__((aligned(16))) HufwLds L;
     const uint32_t lane = threadIdx.x & 63u;
-    if (blockIdx.x >= uni(P.counters[1])) return;
-    const uint32_t it = uni(P.hitems[blockIdx.x]);
+    const uint32_t it = uni(P.hitems[item]);
     const ZBlk *d = P.blks + it;
     const uint32_t f = it / P.nbmax, kblk = it - f * P.nbmax;
     const uint32_t hlog = uni(d->huf_log), nstreams = uni(d->nstreams), regen = uni(d->regen);
@@ -1026,6 +1028,19 @@ __global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
         if (lane == 0u) P.mitems[atomicAdd(&P.counters[60], 1u)] = it;
     }
     HW_STAMP(62);
+}
+
+/* grid-stride over the tile's Huffman blocks (round 4): the grid used to be one workgroup per descriptor SLOT (frames x
+ * blocks a frame may have: three times the blocks there are at 128 KiB), and a workgroup needs its 22 KB of LDS before it
+ * can find out that it has no block */
+__global__ void __launch_bounds__(64) k_zhufw(ZPipe P)
+{
+    __shared__ __attribute__((aligned(16))) HufwLds L;
+    const uint32_t n = uni(P.counters[1]);
+    for (uint32_t item = blockIdx.x; item < n; item += gridDim.x) {
+        if (item != blockIdx.x) { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
+        zhufw_item(P, L, item);
+    }
 }
 
 /* k_zmove: a wave per block k_zhufw decoded: its walkers' true symbols, scratch -> literal pool.  Whole 16-byte stores,
@@ -1461,8 +1476,9 @@ __global__ void __launch_bounds__(64) k_zchain4(ZPipe P)
     __shared__ __attribute__((aligned(16))) ChainQLds L;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t nitems = uni(P.counters[3]);
-    const uint32_t i0 = blockIdx.x * kCqW;
-    if (i0 >= nitems) return;
+    /* grid-stride: the grid is sized for the chip (768 waves), not for frames x blocks-a-frame-may-have descriptor slots */
+    for (uint32_t i0 = blockIdx.x * kCqW; i0 < nitems; i0 += gridDim.x * kCqW) {
+    if (i0 != blockIdx.x * kCqW) { __builtin_amdgcn_wave_barrier(); asm volatile("" ::: "memory"); }
     for (uint32_t j = 0; j < kCqW && i0 + j < nitems; j++) {
         const uint32_t it = uni(P.sitems[i0 + j]);
         const uint32_t fj = it / P.nbmax;
@@ -1563,7 +1579,10 @@ __global__ void __launch_bounds__(64) k_zchain4(ZPipe P)
             CQ_TURN(3, true, fd3, fa3, fm3) CQ_TURN(3, false, fd3, fa3, fm3)
         } while (__any(z.i < z.nseq));
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* the compiler does not know of the assembly loads */
+    /* the compiler does not know of the assembly loads: the drain names the slots, or their registers -- dead to the
+     * compiler once the loop is left -- are handed to something else while a load is still on its way into them (seen: an
+     * address computed into two of them in front of the drain, overwritten by the late load: a store into the wild) */
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(fd0), "+v"(fd1), "+v"(fd2), "+v"(fd3) : : "memory");
 #undef CQ_TURN
     if (opened && !bad) { /* the last sequence: its extra bits, no state bits */
         const uint32_t x = z.e >> 11;
@@ -1574,6 +1593,7 @@ __global__ void __launch_bounds__(64) k_zchain4(ZPipe P)
     }
     if (opened && z.pos != 0) bad = true; /* the bitstream must be consumed exactly */
     if (bad && k == 0u) atomicOr(&P.frames[f].flags, F_BAD);
+    }
 }
 
 /* K3'': values and repeat offsets, one wave per frame, 64 sequences at a time.  A sequence changes the offset history
@@ -2065,14 +2085,23 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
         P.F = (uint32_t)(left < y.F ? left : y.F);
         if ((e = hipMemsetAsync(P.counters, 0, 256, st)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_zplan, dim3(P.F), dim3(64), 0, st, P);
-        if (old_huf) hipLaunchKernelGGL(k_zhuf, dim3((P.F * P.nbmax + kHufPerWave - 1u) / kHufPerWave), dim3(64), huf_pad, st, P, P.hitems, 1u);
+        const uint32_t zhuf_all = (P.F * P.nbmax + kHufPerWave - 1u) / kHufPerWave;
+#ifndef CRYO_GS
+#define CRYO_GS 7 /* grids sized for the chip: 1 k_zhuf, 2 k_zhufw, 4 k_zchain4 (0: one workgroup per descriptor slot, as in round 3) */
+#endif
+        if (old_huf) hipLaunchKernelGGL(k_zhuf, dim3((CRYO_GS & 1) && zhuf_all > 1024u ? 1024u : zhuf_all), dim3(64), huf_pad, st, P, P.hitems, 1u);
         else {
-            hipLaunchKernelGGL(k_zhufw, dim3(P.F * P.nbmax), dim3(64), huf_pad, st, P);
+            /* 1 792 of these are resident (seven per CU); a frame has one Huffman block per 128 KiB */
+            const uint32_t zhufw_all = P.F * P.nbmax, zhufw_want = P.F * ((P.B + kZBlockMax - 1u) / kZBlockMax) < 3584u ? 3584u : P.F * ((P.B + kZBlockMax - 1u) / kZBlockMax);
+            hipLaunchKernelGGL(k_zhufw, dim3((CRYO_GS & 2) && zhufw_all > zhufw_want ? zhufw_want : zhufw_all), dim3(64), huf_pad, st, P);
             hipLaunchKernelGGL(k_zmove, dim3(P.F * P.nbmax), dim3(64), 0, st, P);
-            hipLaunchKernelGGL(k_zhuf, dim3((P.F * P.nbmax + kHufPerWave - 1u) / kHufPerWave), dim3(64), 0, st, P, P.hitems2, 61u);
+            hipLaunchKernelGGL(k_zhuf, dim3((CRYO_GS & 1) && zhuf_all > 256u ? 256u : zhuf_all), dim3(64), 0, st, P, P.hitems2, 61u); /* the walkers' hand-backs: rarely any */
         }
 #if CRYO_ZCHAIN_QUAD
-        hipLaunchKernelGGL(k_zchain4, dim3((P.F * P.nbmax + kCqW - 1u) / kCqW), dim3(64), seq_pad, st, P);
+        {
+            const uint32_t zc_all = (P.F * P.nbmax + kCqW - 1u) / kCqW;
+            hipLaunchKernelGGL(k_zchain4, dim3((CRYO_GS & 4) && zc_all > 768u ? 768u : zc_all), dim3(64), seq_pad, st, P);
+        }
 #else
         hipLaunchKernelGGL(k_zchain, dim3((P.F * P.nbmax + kChW - 1u) / kChW), dim3(64), seq_pad, st, P);
 #endif
