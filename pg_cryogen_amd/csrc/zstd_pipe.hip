@@ -2095,6 +2095,8 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
             const uint32_t zhufw_all = P.F * P.nbmax, zhufw_want = P.F * ((P.B + kZBlockMax - 1u) / kZBlockMax) < 3584u ? 3584u : P.F * ((P.B + kZBlockMax - 1u) / kZBlockMax);
             hipLaunchKernelGGL(k_zhufw, dim3((CRYO_GS & 2) && zhufw_all > zhufw_want ? zhufw_want : zhufw_all), dim3(64), huf_pad, st, P);
             hipLaunchKernelGGL(k_zmove, dim3(P.F * P.nbmax), dim3(64), 0, st, P);
+            static const bool skip_fallbacks = cryo_tuning_env("CRYO_ZSTD_SKIP_FALLBACKS") != nullptr; /* timing experiment (debug builds): wrong if anything was handed back */
+            if (!skip_fallbacks)
             hipLaunchKernelGGL(k_zhuf, dim3((CRYO_GS & 1) && zhuf_all > 256u ? 256u : zhuf_all), dim3(64), 0, st, P, P.hitems2, 61u); /* the walkers' hand-backs: rarely any */
         }
 #if CRYO_ZCHAIN_QUAD
@@ -2108,6 +2110,8 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
         hipLaunchKernelGGL(k_zmat, dim3(P.F), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_zexec, dim3(P.F), dim3(64), 0, st, P);
         const uint64_t fg = P.F < kFusedGridForIrregular ? P.F : kFusedGridForIrregular;
+        static const bool skip_fused = cryo_tuning_env("CRYO_ZSTD_SKIP_FALLBACKS") != nullptr;
+        if (!skip_fused)
         e = launch_zstd_fused(st, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, fg, d_status,
                               ws + y.o_fused, zstd_fused_workspace(kFusedGridForIrregular), P.irregular,
                               P.counters + 2, first);

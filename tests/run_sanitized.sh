@@ -5,7 +5,7 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 T=$(mktemp -d)
-cp -r "$ROOT"/pg_cryogen_amd "$ROOT"/oracle "$ROOT"/include "$ROOT"/tests "$ROOT"/pg "$T"/
+cp -r "$ROOT"/pg_cryogen_amd "$ROOT"/oracle "$ROOT"/include "$ROOT"/tests "$ROOT"/pg "$ROOT"/tools "$T"/
 cd "$T"
 SAN="-fsanitize=address,undefined -fno-omit-frame-pointer"
 make -s -C oracle clean

@@ -16,5 +16,7 @@ def test_index_kernel_assembly_loads_are_not_copied():
     slot register handed to something else in front of the drain is overwritten by a load still on its way (k_zchain4
     stored into the wild that way before its drain named the slots; in k_lz4_index either only costs speed -- the decoder
     validates every index entry).  tools/check_index_isa.py inspects the generated assembly of both."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_index_isa.py")], capture_output=True, text=True, timeout=600)
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)   # tests/run_sanitized.sh preloads the sanitizer runtimes: not into the compiler
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_index_isa.py")], capture_output=True, text=True, timeout=900, env=env)
     assert r.returncode == 0, r.stdout + r.stderr

@@ -357,6 +357,28 @@ def test_indexed_decoder_distributions_at_headline_sizes(codec, oracle, B, walke
         _decode_check(codec, comps, blocks, B, ("dist", B, walkers))
 
 
+def test_indexed_decoder_two_walkers_on_1mib_blocks(codec, oracle):
+    """Two walkers per 1 MiB block: a segment holds up to 81 984 records, more than the 16 bits in which a hand-over's skip
+    count travels (lz4_index.hip: such a hand-over counts as a boundary that did not meet and the block is walked again by
+    one walker) -- dense sequences (`wide`: ~51 000 per block), literal-heavy and highly compressible blocks alike."""
+    B = 1 << 20
+    blocks, comps = [], []
+    for dist in range(5):
+        for accel in (1, 50):
+            b = oracle.synth(23, 10 * dist + accel, B, dist)
+            blocks.append(b)
+            comps.append(oracle.lz4_compress(b, accel))
+    rng = np.random.default_rng(77)
+    a = rng.integers(0, 256, B, dtype=np.uint8)        # a sequence every ~8 bytes: 4-byte matches at random near offsets
+    for p_ in range(64, B - 8, 8):
+        o = int(rng.integers(4, 60))
+        a[p_:p_ + 4] = a[p_ - o:p_ - o + 4]
+    blocks.append(a)
+    comps.append(oracle.lz4_compress(a, 1))
+    with _indexed(codec, 2):
+        _decode_check(codec, comps, blocks, B, ("two walkers", B))
+
+
 @pytest.mark.parametrize("walkers", WALKERS)
 def test_indexed_decoder_golden_cells(codec, oracle, walkers):
     """tests/golden/vectors.json, LZ4 cells at 128 KiB and 1 MiB: streams of liblz4 1.9.3 (hash-pinned: the oracle's
