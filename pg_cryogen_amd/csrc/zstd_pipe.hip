@@ -1379,7 +1379,7 @@ struct ChainQLds {
 template <int CTRL>
 __device__ inline uint32_t quad_get(uint32_t v) /* lane CTRL / 0x55 of this lane's quad */
 {
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true); /* (update_dpp with a zero `old` costs a v_mov per use) */
 }
 
 struct ChainQuad {
@@ -1419,14 +1419,12 @@ __device__ inline void chainq_turn(uint8_t *ring, const uint16_t *tab, ChainQuad
         const uint64_t win = z.raw << z.sh;
         uint32_t W = (uint32_t)((win << X) >> 32);
         const bool ovf = go & (X + N > 57u);
-        if (__any(ovf)) { /* more bits than one window holds: the state bits come from a second read */
-            if (ovf) {
-                const int32_t p2 = z.pos - (int32_t)X;
-                const int32_t cb2 = z.s0 + ((p2 - 1) >> 3);
-                uint64_t r2;
-                __builtin_memcpy(&r2, ring + myring + ((uint32_t)(cb2 - 7) & (kChRing - 1u)), 8);
-                W = (uint32_t)((r2 << (7u - ((uint32_t)(p2 - 1) & 7u))) >> 32);
-            }
+        if (ovf) { /* more bits than one window holds: the state bits come from a second read */
+            const int32_t p2 = z.pos - (int32_t)X;
+            const int32_t cb2 = z.s0 + ((p2 - 1) >> 3);
+            uint64_t r2;
+            __builtin_memcpy(&r2, ring + myring + ((uint32_t)(cb2 - 7) & (kChRing - 1u)), 8);
+            W = (uint32_t)((r2 << (7u - ((uint32_t)(p2 - 1) & 7u))) >> 32);
         }
         const uint32_t b = __builtin_amdgcn_ubfe(W, 32u - pre - n, n);
         const uint32_t ns = mine ? (v << n) - (1u << (c + 31)) + b : 0u;
