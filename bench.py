@@ -54,6 +54,7 @@ def parse_args():
     ap.add_argument("--level", type=int, default=1, help="zstd level")
     ap.add_argument("--lz4-path", type=int, default=0, help="diagnostic: CRYO_OPT_LZ4_DECODE_PATH (0 auto, 1 in-wave parse, 2 indexed)")
     ap.add_argument("--lz4-walkers", type=int, default=0, help="diagnostic: CRYO_OPT_LZ4_INDEX_WALKERS (0 auto)")
+    ap.add_argument("--lz4-waves", type=int, default=0, help="diagnostic: CRYO_OPT_LZ4_DECODE_WAVES (0 auto, 1 one wave per block, 2 two)")
     return ap.parse_args()
 
 
@@ -227,10 +228,11 @@ def main():
     B, n = a.block_size, a.blocks
     dist_id = DIST_NAMES.index(a.dist)
     codec = Codec(dev)
-    if a.lz4_path or a.lz4_walkers:
+    if a.lz4_path or a.lz4_walkers or a.lz4_waves:
         from pg_cryogen_amd import codec as cc
         codec.set_option(cc.OPT_LZ4_DECODE_PATH, a.lz4_path)
         codec.set_option(cc.OPT_LZ4_INDEX_WALKERS, a.lz4_walkers)
+        codec.set_option(cc.OPT_LZ4_DECODE_WAVES, a.lz4_waves)
     ora = oracle_lib.Oracle()
     job_block = lambda k: rank + k * world   # block i of the job lives on rank i mod N (pg_cryogen_amd/shard.py)
     want_cpu = world == 1 and not a.no_cpu_baseline

@@ -22,6 +22,7 @@ _ERR_NAMES = {0: "CRYO_OK", -1: "CRYO_E_ARG", -2: "CRYO_E_HIP", -3: "CRYO_E_NODE
 
 # cryo_option (include/cryo_codec.h)
 OPT_LZ4_DECODE_PATH, OPT_LZ4_INDEX_WALKERS, OPT_PIPE_MIN_BYTES, OPT_POOL_BYTES, OPT_ZSTD_DECODE_PATH = 1, 2, 3, 4, 5
+OPT_LZ4_DECODE_WAVES = 9
 OPT_WORKSPACE_KEEP_BYTES, OPT_WORKSPACE_MAX_BYTES, OPT_NUMA_LOCAL = 6, 7, 8
 LZ4_PATH_AUTO, LZ4_PATH_RING, LZ4_PATH_INDEXED, LZ4_PATH_FEW_BLOCKS = 0, 1, 2, 3
 

@@ -472,6 +472,10 @@ int cryo_codec_set_option(cryo_codec *c, int option, int64_t value)
         if (value < 0 || value > 64 || (value & (value - 1)) != 0) return CRYO_E_ARG;
         c->lz4_opts.walkers = (int)value;
         return CRYO_OK;
+    case CRYO_OPT_LZ4_DECODE_WAVES:
+        if (value < 0 || value > 2) return CRYO_E_ARG;
+        c->lz4_opts.waves = (int)value;
+        return CRYO_OK;
     case CRYO_OPT_PIPE_MIN_BYTES:
         if (value < 0) return CRYO_E_ARG;
         c->pipe_min_bytes = (size_t)value;
@@ -510,6 +514,7 @@ int cryo_codec_get_option(const cryo_codec *c, int option, int64_t *value)
     switch (option) {
     case CRYO_OPT_LZ4_DECODE_PATH: *value = c->lz4_opts.path; return CRYO_OK;
     case CRYO_OPT_LZ4_INDEX_WALKERS: *value = c->lz4_opts.walkers; return CRYO_OK;
+    case CRYO_OPT_LZ4_DECODE_WAVES: *value = c->lz4_opts.waves; return CRYO_OK;
     case CRYO_OPT_PIPE_MIN_BYTES: *value = (int64_t)c->pipe_min_bytes; return CRYO_OK;
     case CRYO_OPT_POOL_BYTES: *value = (int64_t)c->pool_bytes; return CRYO_OK;
     case CRYO_OPT_ZSTD_DECODE_PATH: *value = c->zstd_path; return CRYO_OK;

@@ -170,7 +170,9 @@ __device__ inline void lane_copies_v2(uint8_t *ring, const uint8_t *in, const ui
  *   and the frontier rounds take it off bytes at a time; callers keep those short); T = total bytes <= TMAX.
  *   isfar: the match's source is no longer in the ring; its bytes are in xfa/xfb (requested by the caller).
  */
-template <uint32_t R, uint32_t TMAX>
+/*   NOLIT: the literal runs are somebody else's (the dual-wave decoder, lz4_dec2.hip: the block's other wave copies them
+ *   while this one still works on the batch before); ll only places the matches. */
+template <uint32_t R, uint32_t TMAX, bool NOLIT = false>
 __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uint32_t nseq, const uint32_t ostart,
                                 const uint32_t ll, const uint32_t ml, const uint32_t off, const uint32_t lpos,
                                 const uint32_t T, const bool isfar, const uint4 xfa, const uint4 xfb, Stats &st)
@@ -219,7 +221,7 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
         (void)z;
         lane_copies_v2<R>(L.ring, L.in, act ? ll : 0u, lpos, op0 + ostart, indep ? ml : 0u, op0 + mrel - off, op0 + mrel, isfar, xfa, xfb, spill);
 #else
-        if (!(CRYO_ABL & 8))
+        if (!(CRYO_ABL & 8) && !NOLIT)
         lane_runs<R, kInMask>(L.ring, L.in, act ? ll : 0u, lpos, op0 + ostart, false, z, z, spill);
         /* (the 16 bytes behind the ring mirror its first 16 for reads that start in its last 15: lz4_seq_batch) */
         if (!(CRYO_ABL & 16))

@@ -37,6 +37,9 @@
 #ifndef CRYO_DEC_OCC
 #define CRYO_DEC_OCC 6
 #endif
+#ifndef CRYO_DEC_DUAL
+#define CRYO_DEC_DUAL 1   /* batches of at most kDualMaxBlocks blocks: two waves per block (k_lz4_dec_dual) */
+#endif
 namespace cryo {
 
 /* ---------------------------------------------------------------------------------------------
@@ -395,13 +398,293 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     }
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * The same decoder with TWO waves per block (round 4), for batches that do not fill the chip.
+ *
+ * A block is one wave's chain: 4.7 us per batch of 64 sequences with the SIMD to itself (profiles/r04_lz4_decode_ab.txt,
+ * r04_ab8), whatever else runs -- so 1 024 blocks decode no faster than 6 144, and 512 x 1 MiB take 3 ms on an idle chip.
+ * The chain has two halves that touch different memory: staging, token decode, validation, requests and the LITERAL runs
+ * read the input ring and write output bytes no match of the batch before can touch; the independent matches and match
+ * space read and write the output ring.  So wave A does the first half of batch n+1 while wave B does the second half of
+ * batch n:
+ *
+ *   A:  stage, decode, validate, request, literal runs of n+1;  publish the batch (LDS);  barrier;  flush what B finished
+ *   B:  barrier;  far sources, independent matches, match space of n (seq_copy<NOLIT>)
+ *
+ * One barrier per batch: A arrives with batch n+1 published, B with batch n done.  What makes the overlap safe:
+ *   - the ring is 8 KiB and a match is "far" (read back from the flushed output) from R - 2T on: a source B reads for batch n
+ *     is never a ring slot A's literals of batch n+1 overwrite;
+ *   - A flushes only up to the start of the batch B is working on (everything below is complete), and far sources are
+ *     older than that by construction;
+ *   - the 16 bytes behind the ring serve as the landing strip of a run that crosses the ring's end (A's literals, B's
+ *     matches) and as the mirror of the ring's first bytes for B's 16-byte source reads: a source run of batch n can
+ *     cross the ring's end only when batch n+1 does not, so B refreshes the mirror only when a source needs it;
+ *   - a sequence the batches cannot take (the general path) runs on A with B parked at the barrier.
+ * Verdicts and bytes are the single-wave decoder's: the same validation, the same copy engine.
+ * --------------------------------------------------------------------------------------------- */
+constexpr uint32_t kDualR = 8192;
+constexpr uint32_t kDualNear = kDualR - 2u * kT2; /* 5120 */
+constexpr uint32_t kDualMaxBlocks = 3328;         /* 13 workgroups of two waves per CU */
+
+struct DualLds {
+    uint8_t ring[kDualR + 16];
+    uint8_t in[kInRing + 16];
+    uint32_t mmeta[64];
+    uint32_t mbm[CopyLds<kDualR, kT2>::kWords];
+    uint32_t da[2][64], db[2][64]; /* per sequence: ll | ml << 16;  off | ostart << 16 | far << 31 */
+    uint32_t u[2][4];              /* op0, sequences, bytes, mode (0 nothing for B, 1 a batch, 2 the block is done) */
+};
+
+/* wave A: one batch up to and including its literal runs; publishes it in buffer `buf`.  Returns the sequences taken. */
+__device__ inline uint32_t lz4_dual_front(Wave<kDualR> &w, DualLds &D, uint32_t &vp, const uint32_t B, const uint32_t epos,
+                                          const uint32_t navail, const uint16_t *__restrict__ trow, const uint32_t n0,
+                                          const uint32_t ntab, uint32_t &epre, const uint32_t buf)
+{
+    constexpr uint32_t R = kDualR;
+    const uint32_t lane = w.lane;
+    const uint32_t vend = w.vend;
+    if (vend < 32u || B < 32u || navail == 0u) return 0;
+    const uint32_t vsafe = vend - 16u;
+    if (vp + 64u > vsafe || w.op + 64u > B) return 0;
+    while (w.in_hi < vend && w.in_hi < vp + kSeqWin) w.refill_deferred();
+    LDS_FENCE();
+    uint2 mir = make_uint2(0, 0);
+    if (lane < 2u) mir = *reinterpret_cast<const uint2 *>(D.in + lane * 8u);
+    const uint32_t pos = vp + ((epos + w.delta - vp) & 0xffffu);
+    const bool cand = lane < navail && pos + 8u <= vp + kSeqWin;
+    const uint32_t rp = cand ? pos : vp;
+    const uint32_t t = D.in[rp & kInMask];
+    const uint32_t e1 = D.in[(rp + 1u) & kInMask];
+    uint32_t ll = t >> 4;
+    uint32_t k = 1u;
+    if (ll == 15u) { ll += e1; k = 2u; }
+    const uint32_t q = rp + k + ll;
+    const bool inwin = q + 8u <= vp + kSeqWin;
+    const uint32_t rq = inwin ? q : vp;
+    const uint32_t off = (uint32_t)D.in[rq & kInMask] | ((uint32_t)D.in[(rq + 1u) & kInMask] << 8);
+    const uint32_t e2 = D.in[(rq + 2u) & kInMask];
+    if (lane < 2u) *reinterpret_cast<uint2 *>(D.in + kInRing + lane * 8u) = mir;
+    uint32_t ml = (t & 15u) + 4u;
+    uint32_t dlen = k + ll + 2u;
+    const bool hasM = (t & 15u) == 15u;
+    if (hasM) { ml += e2; dlen += 1u; }
+    const uint32_t outlen = cand ? ll + ml : 0u;
+    const uint32_t oend = scan64_incl(outlen);
+    const uint32_t ostart = oend - outlen;
+    const uint32_t mabs = w.op + ostart + ll;
+    const uint32_t npos = lane_next(pos);
+    const bool chain = (lane == 0u ? pos == vp : true) && (lane + 1u >= navail || lane == 63u || npos == pos + dlen);
+    constexpr uint32_t kOvlMax = 64;
+    const bool isfar = cand && off >= kDualNear;
+    const bool ok = cand && inwin && chain && !(t >= 0xf0u && e1 == 255u) && !(hasM && e2 == 255u) && (off >= ml || (off != 0u && ml <= kOvlMax)) && off <= mabs &&
+                    pos + dlen <= vsafe && oend <= kT2 && w.op + oend + 16u <= B && !(isfar && ml > 32u);
+    const unsigned long long badmask = __ballot(!ok);
+    const uint32_t nseq = badmask ? ctz64(badmask) : 64u;
+    w.top_up();
+    if (nseq == 0u) return 0;
+    const uint32_t T = lane_get(oend, nseq - 1u);
+    const uint32_t used = lane_get(pos + dlen, nseq - 1u) - vp;
+    epre = 0;
+    if (n0 + nseq + lane < ntab) epre = trow[n0 + nseq + lane];
+    /* the literal runs: nothing the other wave is doing can touch their destinations */
+    {
+        uint32_t spill = 0;
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        lane_runs<R, kInMask>(D.ring, D.in, lane < nseq ? ll : 0u, pos + k, w.op + ostart, false, z, z, spill);
+        const unsigned long long sm = __ballot(spill != 0u);
+        if (sm != 0ull) {
+            LDS_FENCE();
+            const uint32_t kk = lane_get(spill, ctz64(sm));
+            if (lane < kk) D.ring[lane] = D.ring[R + lane];
+        }
+    }
+    D.da[buf][lane] = ll | (ml << 16);
+    D.db[buf][lane] = off | (ostart << 16) | (isfar ? 0x80000000u : 0u);
+    if (lane == 0u) { D.u[buf][0] = w.op; D.u[buf][1] = nseq; D.u[buf][2] = T; D.u[buf][3] = 1u; }
+    w.op += T;
+    vp += used;
+    return nseq;
+}
+
+__global__ void __launch_bounds__(128)
+k_lz4_dec_dual(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
+               const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
+               uint64_t n_blocks, int32_t *__restrict__ status, const uint16_t *__restrict__ tbl, uint32_t tbl_cap,
+               const uint2 *__restrict__ seg, const uint32_t logS, const uint32_t cap_s, const uint32_t ext,
+               const uint32_t skip_heavy, const uint32_t *__restrict__ decoded)
+{
+    constexpr uint32_t R = kDualR;
+    __shared__ __attribute__((aligned(16))) DualLds D;
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t role = uni(threadIdx.x >> 6); /* 0: wave A, 1: wave B */
+    const uint64_t blk = blockIdx.x;
+    if (blk >= n_blocks) return;
+    const uint8_t *base = src_base + uni64(src_off[blk]);
+    const uint32_t csize = uni(src_size[blk]);
+    if (skip_heavy != 0u && lz4_literal_heavy(csize, B)) return;
+    if (decoded != nullptr && uni(decoded[blk]) != 0u) return;
+
+    Wave<R> w;
+    w.ring = D.ring;
+    w.in = D.in;
+    w.lane = lane;
+    w.delta = (uint32_t)(reinterpret_cast<uintptr_t>(base) & 127u);
+    w.abase = base - w.delta;
+    w.vend = w.delta + csize;
+    w.in_hi = 0;
+    w.dst = dst_base + uni64(blk * dst_stride);
+    w.dst_aligned = (reinterpret_cast<uintptr_t>(w.dst) & 15u) == 0;
+    w.op = 0;
+    w.flushed = 0;
+    w.pre = w.pre2 = w.pre3 = make_uint2(0, 0);
+    w.nstale = 0;
+    Stats st = {};
+
+    if (role == 1u) {
+        /* ---- wave B: the output-ring half of every batch ---- */
+        const CopyLds<R, kT2> L = {D.ring, D.in, D.mmeta, D.mbm};
+        uint32_t buf = 0;
+        for (;;) {
+            __syncthreads();
+            const uint32_t mode = uni(D.u[buf][3]);
+            if (mode == 2u) break;
+            if (mode == 1u) {
+                const uint32_t op0 = uni(D.u[buf][0]), nseq = uni(D.u[buf][1]), T = uni(D.u[buf][2]);
+                const uint32_t a = D.da[buf][lane], b = D.db[buf][lane];
+                const uint32_t ll = a & 0xffffu, ml = a >> 16, off = b & 0xffffu, ostart = (b >> 16) & 0x7fffu;
+                const bool isfar = (b >> 31) != 0u;
+                const bool act = lane < nseq;
+                uint4 xfa = make_uint4(0, 0, 0, 0), xfb = xfa;
+                if (act && isfar) {
+                    const uint8_t *g = w.dst + (op0 + ostart + ll - off);
+                    __builtin_memcpy(&xfa, g, 16);
+                    __builtin_memcpy(&xfb, g + 16, 16);
+                }
+                /* the ring's first bytes behind its end, for a 16-byte source read that starts in its last 15 -- only when a
+                 * source run of this batch crosses the end: that end lies below the batch, more than R - 2T behind it, so
+                 * neither this batch nor the other wave's crosses the ring's end and the 16 bytes are nobody's landing strip.
+                 * (A read that crosses without its run doing so fetches bytes nobody uses.) */
+                const uint32_t mrel = ostart + ll;
+                const bool near_indep = act && !isfar && off >= mrel + ml;
+                if (__any(near_indep && ((op0 + mrel - off) & (R - 1u)) + ml > R)) {
+                    uint2 mir = make_uint2(0, 0);
+                    if (lane < 2u) mir = *reinterpret_cast<const uint2 *>(D.ring + lane * 8u);
+                    LDS_FENCE();
+                    if (lane < 2u) *reinterpret_cast<uint2 *>(D.ring + R + lane * 8u) = mir;
+                    LDS_FENCE();
+                }
+                w.op = op0;
+                seq_copy<R, kT2, true>(w, L, nseq, ostart, ll, ml, off, 0u, T, isfar, xfa, xfb, st);
+            }
+            buf ^= 1u;
+        }
+        return;
+    }
+
+    /* ---- wave A ---- */
+    uint32_t vp = w.delta;
+    bool bad = (csize == 0);
+    bool done = bad;
+    uint32_t skip = 0;
+    const uint16_t *trow = tbl + uni64(blk * (uint64_t)tbl_cap);
+    const uint32_t npieces = 2u << logS;
+    uint2 sd = make_uint2(0, 0);
+    if (lane < (1u << logS)) sd = seg[(blk << logS) + lane];
+    uint32_t pc = 0, plen = 0, n0 = 0;
+    auto next_piece = [&]() {
+        plen = 0;
+        n0 = 0;
+        while (pc < npieces) {
+            const uint32_t sg = pc >> 1;
+            const uint32_t dx = lane_get(sd.x, sg), dy = lane_get(sd.y, sg);
+            const uint32_t len = (pc & 1u) ? dy : (dx & 0xffffu);
+            const uint32_t pbase = sg * cap_s + ((pc & 1u) ? ext + (dx >> 16) : 0u);
+            pc++;
+            if (len != 0u) { trow = tbl + uni64(blk * (uint64_t)tbl_cap) + pbase; plen = len; break; }
+        }
+    };
+    next_piece();
+    uint32_t poor = 0;
+    uint32_t efirst = 0;
+    if (!bad && lane < plen) efirst = trow[lane];
+    bool have_first = !bad;
+    if (!bad) {
+        w.prefetch();
+        w.refill();
+        if (w.in_hi < w.vend) w.refill();
+    }
+    uint32_t buf = 0;
+    /* a step = publish + barrier: B starts on what was published, and has finished the step before */
+    auto step_batch = [&](const uint32_t op0) {
+        __syncthreads();
+        buf ^= 1u;
+        /* everything below the batch B is starting on is complete: store whole chunks of it */
+        const uint32_t op_now = w.op;
+        w.op = op0;
+        w.flush();
+        w.op = op_now;
+    };
+    auto park_b = [&]() { /* nothing for B: it reads the mode and waits at the next barrier; the ring is A's until then */
+        if (lane == 0u) D.u[buf][3] = 0u;
+        __syncthreads();
+        buf ^= 1u;
+    };
+
+    while (!done) {
+        if (skip == 0u) {
+            uint32_t n;
+            uint32_t epre = efirst;
+            bool have_pre = have_first;
+            bool more;
+            have_first = false;
+            do {
+                if (plen != 0u && n0 >= plen) { next_piece(); have_pre = false; }
+                uint32_t e = epre;
+                const uint32_t navail = n0 < plen ? (plen - n0 < 64u ? plen - n0 : 64u) : 0u;
+                if (!have_pre) { e = 0; if (lane < navail) e = trow[n0 + lane]; }
+                const uint32_t op0 = w.op;
+                n = lz4_dual_front(w, D, vp, B, e, navail, trow, n0, plen, epre, buf);
+                if (n != 0u) step_batch(op0);
+                have_pre = n != 0u;
+                n0 += n;
+                more = n >= 8u || (n != 0u && n == navail);
+            } while (more);
+            poor = n < 4u ? poor + 1u : 0u;
+            if (poor >= 3u) { skip = 8u; poor = 0u; }
+        } else {
+            skip--;
+        }
+        if (plen != 0u && n0 >= plen) next_piece();
+        n0++;
+        park_b(); /* B has finished the batch before; the general path owns the ring */
+        const uint32_t r = lz4_general_seq<R>(w, vp, B);
+        if (r == 2u) { bad = true; break; }
+        if (r == 1u) done = true;
+    }
+    if (lane == 0u) D.u[buf][3] = 2u;
+    __syncthreads();
+    if (!bad && w.op != B) bad = true;
+    if (!bad) {
+        w.flush();
+        w.flush_tail();
+    }
+    if (lane == 0) status[blk] = bad ? CRYO_ST_CORRUPT : CRYO_ST_OK;
+}
+
 /* ---- launcher ---- */
 static void launch_dec_seq(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size, uint8_t *d_dst,
                            uint64_t dst_stride, uint32_t block_size, uint64_t n_blocks, int32_t *d_status, const void *ws,
-                           const Lz4IndexLayout &Lx, const uint32_t *d_done = nullptr)
+                           const Lz4IndexLayout &Lx, const uint32_t *d_done = nullptr, const int waves = 0)
 {
     const uint16_t *tbl = static_cast<const uint16_t *>(ws);
     const uint2 *seg = reinterpret_cast<const uint2 *>(static_cast<const uint8_t *>(ws) + Lx.seg_off);
+#if CRYO_DEC_DUAL
+    if (waves == 2 || (waves == 0 && n_blocks <= kDualMaxBlocks)) { /* a batch that leaves most of the chip idle: two waves per block */
+        hipLaunchKernelGGL(k_lz4_dec_dual, dim3((uint32_t)n_blocks), dim3(128), 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size,
+                           n_blocks, d_status, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, Lx.logS != 0u ? 1u : 0u, d_done);
+        return;
+    }
+#endif
     hipLaunchKernelGGL((k_lz4_dec_seq<kDecR, false, kDecWpb>), dim3((uint32_t)((n_blocks + kDecWpb - 1) / kDecWpb)), dim3(64 * kDecWpb), 0, s, d_src, d_src_off, d_src_size,
                        d_dst, dst_stride, block_size, n_blocks, d_status, nullptr, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext,
                        Lx.logS != 0u ? 1u : 0u, d_done);
@@ -419,7 +702,7 @@ hipError_t launch_lz4_dec_seq_rest(hipStream_t s, const uint8_t *d_src, const ui
 hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                          const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                          uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
-                                         size_t workspace_bytes, uint32_t walkers)
+                                         size_t workspace_bytes, uint32_t walkers, int waves)
 {
     if (n_blocks == 0) return hipSuccess;
     const uint64_t grid = (n_blocks + kDecWpb - 1) / kDecWpb;
@@ -456,7 +739,7 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
     }
 #endif
     (void)g; (void)b;
-    launch_dec_seq(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, d_workspace, Lx);
+    launch_dec_seq(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, d_workspace, Lx, nullptr, waves);
     if (Lx.logS != 0u) /* the blocks the index and its decoder left out (almost all literals): the in-wave parser */
         return launch_lz4_dec_ring(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, true);
     return hipGetLastError();

@@ -39,6 +39,7 @@ def rotate_paths(c, rng):
     path = int(rng.choice([cc.LZ4_PATH_AUTO, cc.LZ4_PATH_RING, cc.LZ4_PATH_INDEXED, cc.LZ4_PATH_INDEXED, cc.LZ4_PATH_FEW_BLOCKS]))
     c.set_option(cc.OPT_LZ4_DECODE_PATH, path)
     c.set_option(cc.OPT_LZ4_INDEX_WALKERS, int(rng.choice([0, 1, 2, 4, 8, 16, 32, 64])) if path == cc.LZ4_PATH_INDEXED else 0)
+    c.set_option(cc.OPT_LZ4_DECODE_WAVES, int(rng.choice([0, 1, 2])))  # indexed decoder: one wave per block / two
     c.set_option(cc.OPT_ZSTD_DECODE_PATH, int(rng.choice([0, 1, 2])))
 
 
