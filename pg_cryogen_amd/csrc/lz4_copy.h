@@ -48,17 +48,23 @@ template <uint32_t R, uint32_t SMASK>
 __device__ inline void lane_runs(uint8_t *ring, const uint8_t *sbase, uint32_t rem, uint32_t sv, uint32_t dv, const bool far,
                                  const uint4 xa, const uint4 xb, uint32_t &spill)
 {
-    uint32_t it = 0;
-    while (__any(rem >= 16u)) {
-        if (rem >= 16u) {
-            uint4 v = it == 0u ? xa : xb;
-            if (!far) __builtin_memcpy(&v, sbase + (sv & SMASK), 16);
+    /* (the loop's variables advance by a selected step, outside the `if`: with the updates inside it the compiler carried two
+     * sets of register copies through every turn, 10 of its 22 vector instructions; k_lz4_dec_seq is bound by their issue) */
+    uint32_t it = 0; /* bytes moved so far */
+    bool go = rem >= 16u;
+    if (wave_any(go)) {
+        do {
             const uint32_t di = dv & (R - 1u);
-            __builtin_memcpy(ring + di, &v, 16);
-            if (di + 16u > R) spill = di + 16u - R;
-            sv += 16u; dv += 16u; rem -= 16u;
-            it++;
-        }
+            if (go) {
+                uint4 v = it == 0u ? xa : xb;
+                if (!far) __builtin_memcpy(&v, sbase + (sv & SMASK), 16);
+                __builtin_memcpy(ring + di, &v, 16);
+            }
+            if (go && di + 16u > R) spill = di + 16u - R;
+            const uint32_t step = go ? 16u : 0u;
+            sv += step; dv += step; rem -= step; it += step;
+            go = rem >= 16u;
+        } while (wave_any(go));
     }
     /* what is left of a run that already moved 16 bytes: one more 16-byte copy that ends where the run ends (it
      * rewrites a few bytes with the same data) instead of up to four exact pieces */
@@ -149,15 +155,15 @@ __device__ inline void lane_copies_v2(uint8_t *ring, const uint8_t *in, const ui
     }
     /* the rare shapes */
     const bool lshort = L != 0u && L < 16u, mshort = ML != 0u && ML < 4u;
-    if (__any(lshort | mshort)) {
+    if (wave_any(lshort | mshort)) {
         if (lshort) lane_tail_pieces<R>(ring, la, L, dl & (R - 1u), spill);
         if (mshort) lane_tail_pieces<R>(ring, ma, ML, dm & (R - 1u), spill);
     }
-    if (__any(L > 32u)) {
+    if (wave_any(L > 32u)) {
         const uint4 z = make_uint4(0, 0, 0, 0);
         lane_runs<R, kInMask>(ring, in, L > 32u ? L - 16u : 0u, lpos + 16u, dl + 16u, false, z, z, spill);
     }
-    if (__any(ML > 16u)) { /* a far match is at most 32 bytes: its second half is xfb; a near one starts over (16-byte steps) */
+    if (wave_any(ML > 16u)) { /* a far match is at most 32 bytes: its second half is xfb; a near one starts over (16-byte steps) */
         const uint32_t done = isfar ? 16u : 0u;
         lane_runs<R, R - 1u>(ring, ring, ML > 16u ? ML - done : 0u, msrc + done, dm + done, isfar, xfb, xfb, spill);
     }
@@ -195,7 +201,7 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
     const uint32_t mend = scan64_incl(mlx);
     const uint32_t mcum = mend - mlx;                            /* dependent match bytes before this sequence's */
     const uint32_t MT = lane_get(mend, 63u);
-    const unsigned long long depm = __ballot(dep);
+    const unsigned long long depm = wave_ballot(dep);
     const uint32_t drank = __builtin_amdgcn_mbcnt_hi((uint32_t)(depm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)depm, 0u));
 
     if (!(CRYO_ABL & 128)) {
@@ -228,7 +234,7 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
         lane_runs<R, R - 1u>(L.ring, L.ring, indep ? ml : 0u, op0 + mrel - off, op0 + mrel, isfar, xfa, xfb, spill);
 #endif
         /* a batch crosses the ring's end at most once: fold the bytes that ran over back to the start */
-        const unsigned long long sm = __ballot(spill != 0u);
+        const unsigned long long sm = wave_ballot(spill != 0u);
         if (sm != 0ull) {
             LDS_FENCE();
             const uint32_t k = lane_get(spill, ctz64(sm));
@@ -257,6 +263,8 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
         for (uint32_t c0 = 0; c0 < nM; c0 += U) {
             uint32_t da[U], ra[U];
             bool pendv[U], actv[U];
+            unsigned long long pmv[U]; /* pendv as a lane mask, built from the votes of the plain compares: a vote on a
+                                        * combined predicate costs two vector instructions more (v_cndmask + v_cmp) */
             {
                 uint32_t idx[U];
                 uint32_t mt[U];
@@ -276,8 +284,10 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
                     da[u] = op0 + m + (mt[u] & 2047u);    /* absolute output position of this byte */
                     ra[u] = da[u] - (mt[u] >> 11);            /* ... and of its source                  */
                     const uint32_t d0 = uni(da[u]);       /* first byte of the chunk               */
+                    const bool ge = ra[u] >= d0;
                     actv[u] = a;
-                    pendv[u] = a && ra[u] >= d0;
+                    pendv[u] = a && ge;
+                    pmv[u] = wave_ballot(a) & wave_ballot(ge);
                 }
             }
 #if CRYO_MS_V2
@@ -305,7 +315,7 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) if (actv[u]) *dp[u] = (uint8_t)x[u];
                 bool more = pend[0] | pend[1] | pend[2] | pend[3];
-                while (__any(more)) {
+                while (wave_any(more)) {
                     st.rounds++;
                     uint32_t y[U];
 #pragma unroll
@@ -328,15 +338,15 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
                      * everything below the first pending byte is final, so a pending byte whose source lies below
                      * it can be taken; the first pending byte itself always can */
                     bool pend = pendv[u];
-                    unsigned long long pm = __ballot(pend);
+                    unsigned long long pm = pmv[u];
                     while (pm != 0ull) {
                         st.rounds++;
-                        const uint32_t f = ctz64(pm);
-                        const uint32_t F = lane_get(da[u], f);
-                        const bool rdy = pend && (ra[u] < F || lane == f);
-                        if (rdy) *dp = *sp;
-                        pm &= ~__ballot(rdy);
-                        pend = pend && !rdy;
+                        const uint32_t F = lane_get(da[u], ctz64(pm));
+                        const bool lt = ra[u] < F; /* the first pending lane too: its source lies below itself */
+                        const unsigned long long ltm = wave_ballot(lt); /* right behind the compare: it is the compare's mask then */
+                        if (pend && lt) *dp = *sp;
+                        pm &= ~ltm;
+                        pend = pend && !lt;
                     }
                 }
             }

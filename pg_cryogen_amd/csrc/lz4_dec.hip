@@ -247,7 +247,7 @@ __device__ inline uint32_t lz4_batch(Wave<R> &w, const WaveLds<R> &L, uint32_t &
     const bool isfar = cand && off >= R - kTMax; /* R - T >= T + 1023: in the ring for the whole batch, or flushed before it */
     const bool ok = cand && !(hasM && e2 == 255u) && (off >= ml || (off != 0u && ml <= 64u)) /* short self-overlap: a dependent match, lz4_copy.h */ && off <= mabs &&
                     pos + dlen <= vsafe && oend <= kTMax && w.op + oend + 16u <= B && !(isfar && ml > 32u);
-    const unsigned long long badmask = __ballot(!ok);
+    const unsigned long long badmask = wave_ballot(!ok);
     const uint32_t nseq = badmask ? ctz64(badmask) : 64u;
     /* the output ring's first 16 bytes are mirrored behind it, like the input ring's (16-byte reads of the copy
      * engine that start in a ring's last 15 bytes) */
@@ -381,7 +381,7 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
             /* extension bytes: 255 ... 255 x ; find the terminating byte with a ballot */
             uint32_t wbase = vp;
             for (;;) {
-                const unsigned long long m = __ballot(win != 255u) & ~((1ull << k) - 1ull);
+                const unsigned long long m = wave_ballot(win != 255u) & ~((1ull << k) - 1ull);
                 if (m != 0ull) {
                     const uint32_t f = ctz64(m);
                     ll += (f - k) * 255u + lane_get(win, f);
@@ -443,7 +443,7 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
         if (ml == 15u) {
             uint32_t wbase = vp;
             for (;;) {
-                const unsigned long long m = (k < 64u) ? (__ballot(win != 255u) & ~((1ull << k) - 1ull)) : 0ull;
+                const unsigned long long m = (k < 64u) ? (wave_ballot(win != 255u) & ~((1ull << k) - 1ull)) : 0ull;
                 if (m != 0ull) {
                     const uint32_t f = ctz64(m);
                     ml += (f - k) * 255u + lane_get(win, f);

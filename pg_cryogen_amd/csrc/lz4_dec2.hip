@@ -123,7 +123,7 @@ __device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const CopyLds<R, kT2> &L, u
     const bool isfar = cand && off >= kNear;
     const bool ok = cand && inwin && chain && !(t >= 0xf0u && e1 == 255u) && !(hasM && e2 == 255u) && (off >= ml || (off != 0u && ml <= kOvlMax)) && off <= mabs &&
                     pos + dlen <= vsafe && oend <= kT2 && w.op + oend + 16u <= B && !(isfar && ml > 32u);
-    const unsigned long long badmask = __ballot(!ok);
+    const unsigned long long badmask = wave_ballot(!ok);
     const uint32_t nseq = badmask ? ctz64(badmask) : 64u;
     if (st.on && stop_hist && badmask && nseq < navail && lane == nseq) { /* why the batch stops in front of this sequence */
         const int why = !cand ? 0 : !inwin ? 1 : !chain ? 2 : (t >= 0xf0u && e1 == 255u) ? 3 : (hasM && e2 == 255u) ? 4 : (off < ml && (off == 0u || ml > kOvlMax)) ? 5 : off > mabs ? 6
@@ -146,7 +146,8 @@ __device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const CopyLds<R, kT2> &L, u
      * them first, as assembly loads with a counted wait behind the literal copy instead of the compiler's vmcnt(0):
      * 3 % slower -- the kernel is bound by instruction issue and LDS cycles, not by this wait;
      * profiles/r04_lz4_decode_ab.txt.) */
-    uint4 xfa = make_uint4(0, 0, 0, 0), xfb = xfa;
+    uint4 xfa, xfb; /* only a far lane's are looked at: whatever the registers hold will do for the others (eight moves less) */
+    asm volatile("" : "=v"(xfa.x), "=v"(xfa.y), "=v"(xfa.z), "=v"(xfa.w), "=v"(xfb.x), "=v"(xfb.y), "=v"(xfb.z), "=v"(xfb.w));
     if (lane < nseq && isfar && !(st.ablate & 1u)) {
         const uint8_t *g = w.dst + (mabs - off);
         __builtin_memcpy(&xfa, g, 16);
@@ -180,7 +181,7 @@ __device__ inline uint32_t lz4_general_seq(Wave<R> &w, uint32_t &vp, const uint3
         /* extension bytes: 255 ... 255 x ; find the terminating byte with a ballot */
         uint32_t wbase = vp;
         for (;;) {
-            const unsigned long long m = __ballot(win != 255u) & ~((1ull << k) - 1ull);
+            const unsigned long long m = wave_ballot(win != 255u) & ~((1ull << k) - 1ull);
             if (m != 0ull) {
                 const uint32_t f = ctz64(m);
                 ll += (f - k) * 255u + lane_get(win, f);
@@ -241,7 +242,7 @@ __device__ inline uint32_t lz4_general_seq(Wave<R> &w, uint32_t &vp, const uint3
     if (ml == 15u) {
         uint32_t wbase = vp;
         for (;;) {
-            const unsigned long long m = (k < 64u) ? (__ballot(win != 255u) & ~((1ull << k) - 1ull)) : 0ull;
+            const unsigned long long m = (k < 64u) ? (wave_ballot(win != 255u) & ~((1ull << k) - 1ull)) : 0ull;
             if (m != 0ull) {
                 const uint32_t f = ctz64(m);
                 ml += (f - k) * 255u + lane_get(win, f);
@@ -401,27 +402,45 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
 /* ---------------------------------------------------------------------------------------------
  * The same decoder with TWO waves per block (round 4), for batches that do not fill the chip.
  *
- * A block is one wave's chain: 4.7 us per batch of 64 sequences with the SIMD to itself (profiles/r04_lz4_decode_ab.txt,
- * r04_ab8), whatever else runs -- so 1 024 blocks decode no faster than 6 144, and 512 x 1 MiB take 3 ms on an idle chip.
- * The chain has two halves that touch different memory: staging, token decode, validation, requests and the LITERAL runs
- * read the input ring and write output bytes no match of the batch before can touch; the independent matches and match
- * space read and write the output ring.  So wave A does the first half of batch n+1 while wave B does the second half of
- * batch n:
+ * A block is one wave's chain: 4.7 us per batch of 64 sequences with the SIMD to itself (profiles/r04_lz4_decode_ab.txt),
+ * whatever else runs -- so 1 024 blocks decode no faster than 6 144, and 512 x 1 MiB take 3 ms on an idle chip.
+ * The chain has two halves that touch different memory: staging, token decode, validation, requests, the LITERAL runs and
+ * the FAR matches read the input ring and flushed output and write bytes no match of the batch before can touch; the near
+ * independent matches and match space read and write the output ring only.  So wave A does the first half of batch n+1
+ * while wave B does the second half of batch n:
  *
- *   A:  stage, decode, validate, request, literal runs of n+1;  publish the batch (LDS);  barrier;  flush what B finished
- *   B:  barrier;  far sources, independent matches, match space of n (seq_copy<NOLIT>)
+ *   A:  stage, decode, validate, request, far sources, literal runs, far matches of n+1;  publish the batch (LDS);
+ *       barrier;  store what B finished (whole 1 KiB chunks below batch n+1)
+ *   B:  barrier;  near independent matches and match space of n+1 (seq_copy<NOLIT>); never touches global memory
  *
  * One barrier per batch: A arrives with batch n+1 published, B with batch n done.  What makes the overlap safe:
- *   - the ring is 8 KiB and a match is "far" (read back from the flushed output) from R - 2T on: a source B reads for batch n
- *     is never a ring slot A's literals of batch n+1 overwrite;
- *   - A flushes only up to the start of the batch B is working on (everything below is complete), and far sources are
- *     older than that by construction;
- *   - the 16 bytes behind the ring serve as the landing strip of a run that crosses the ring's end (A's literals, B's
- *     matches) and as the mirror of the ring's first bytes for B's 16-byte source reads: a source run of batch n can
- *     cross the ring's end only when batch n+1 does not, so B refreshes the mirror only when a source needs it;
+ *   - the ring is 8 KiB and a match is "far" (read back from the flushed output) from R - 2T on: a ring slot B reads for
+ *     batch n is never one A's batch n+1 overwrites;
+ *   - A stores only what lies below the batch B is working on (complete: B arrived at the barrier), and a far source is older
+ *     than that by construction (it ends 3 584 bytes or more below the batch, the stores reach to within 2 559) -- stores and
+ *     far loads are the same wave's, in program order;
+ *   - the 16 bytes behind the ring are the landing strip of a run that crosses the ring's end (A's literals and far matches,
+ *     B's matches: two adjacent batches span less than R, so only one of them crosses) and the mirror of the ring's first
+ *     bytes for B's 16-byte source reads: B refreshes it only when a source run crosses the end, which then lies below
+ *     both batches;
  *   - a sequence the batches cannot take (the general path) runs on A with B parked at the barrier.
  * Verdicts and bytes are the single-wave decoder's: the same validation, the same copy engine.
+ *
+ * Measured (profiles/r04_lz4_dual.txt): 1 024 x 128 KiB 0.475 -> 0.34 ms, 512 x 1 MiB 2.97 -> 1.83 ms.  Each wave waits at the
+ * barrier for 18-20 % of the time: a batch is as long as its longer half and the halves vary (A: 600 k busy ticks, B: 587 k,
+ * lock-step total 731 k).  Moving match space's preparation from B to A (then 610 k / 606 k busy) changed nothing -- the
+ * variance, not the balance, is what is left; a queue two batches deep would need a 16 KiB ring (far sources must be below
+ * what is stored) and is not built.
  * --------------------------------------------------------------------------------------------- */
+#ifndef CRYO_DUAL_PROF
+#define CRYO_DUAL_PROF 0 /* variant builds only: block 0 prints how long each of its waves waited at the barriers */
+#endif
+#if CRYO_DUAL_PROF
+#define DUAL_BARRIER() do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+        const unsigned long long t1_ = __builtin_amdgcn_s_memtime(); __syncthreads(); t_wait += __builtin_amdgcn_s_memtime() - t1_; t_vm += t1_ - t_; n_bar++; } while (0)
+#else
+#define DUAL_BARRIER() __syncthreads()
+#endif
 constexpr uint32_t kDualR = 8192;
 constexpr uint32_t kDualNear = kDualR - 2u * kT2; /* 5120 */
 constexpr uint32_t kDualMaxBlocks = 3328;         /* 13 workgroups of two waves per CU */
@@ -478,7 +497,7 @@ __device__ inline uint32_t lz4_dual_front(Wave<kDualR> &w, DualLds &D, uint32_t 
     const bool isfar = cand && off >= kDualNear;
     const bool ok = cand && inwin && chain && !(t >= 0xf0u && e1 == 255u) && !(hasM && e2 == 255u) && (off >= ml || (off != 0u && ml <= kOvlMax)) && off <= mabs &&
                     pos + dlen <= vsafe && oend <= kT2 && w.op + oend + 16u <= B && !(isfar && ml > 32u);
-    const unsigned long long badmask = __ballot(!ok);
+    const unsigned long long badmask = wave_ballot(!ok);
     const uint32_t nseq = badmask ? ctz64(badmask) : 64u;
     w.top_up();
     if (nseq == 0u) return 0;
@@ -486,20 +505,30 @@ __device__ inline uint32_t lz4_dual_front(Wave<kDualR> &w, DualLds &D, uint32_t 
     const uint32_t used = lane_get(pos + dlen, nseq - 1u) - vp;
     epre = 0;
     if (n0 + nseq + lane < ntab) epre = trow[n0 + nseq + lane];
+    /* far matches are this wave's too: their sources are output it has flushed itself (everything below the batch the other
+     * wave is working on), their destinations bytes of this batch; the trip to memory hides behind the literal runs */
+    const bool farm = lane < nseq && isfar;
+    uint4 xfa = make_uint4(0, 0, 0, 0), xfb = xfa;
+    if (farm) {
+        const uint8_t *g = w.dst + (mabs - off);
+        __builtin_memcpy(&xfa, g, 16);
+        __builtin_memcpy(&xfb, g + 16, 16);
+    }
     /* the literal runs: nothing the other wave is doing can touch their destinations */
     {
         uint32_t spill = 0;
         const uint4 z = make_uint4(0, 0, 0, 0);
         lane_runs<R, kInMask>(D.ring, D.in, lane < nseq ? ll : 0u, pos + k, w.op + ostart, false, z, z, spill);
-        const unsigned long long sm = __ballot(spill != 0u);
+        lane_runs<R, R - 1u>(D.ring, D.ring, farm ? ml : 0u, 0u, mabs, true, xfa, xfb, spill);
+        const unsigned long long sm = wave_ballot(spill != 0u);
         if (sm != 0ull) {
             LDS_FENCE();
             const uint32_t kk = lane_get(spill, ctz64(sm));
             if (lane < kk) D.ring[lane] = D.ring[R + lane];
         }
     }
-    D.da[buf][lane] = ll | (ml << 16);
-    D.db[buf][lane] = off | (ostart << 16) | (isfar ? 0x80000000u : 0u);
+    D.da[buf][lane] = ll | ((isfar ? 0u : ml) << 16); /* a far match is done: nothing of it for the other wave */
+    D.db[buf][lane] = off | (ostart << 16);
     if (lane == 0u) { D.u[buf][0] = w.op; D.u[buf][1] = nseq; D.u[buf][2] = T; D.u[buf][3] = 1u; }
     w.op += T;
     vp += used;
@@ -539,34 +568,31 @@ k_lz4_dec_dual(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     w.pre = w.pre2 = w.pre3 = make_uint2(0, 0);
     w.nstale = 0;
     Stats st = {};
+#if CRYO_DUAL_PROF
+    unsigned long long t_wait = 0, t_vm = 0, n_bar = 0;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+#endif
 
     if (role == 1u) {
         /* ---- wave B: the output-ring half of every batch ---- */
         const CopyLds<R, kT2> L = {D.ring, D.in, D.mmeta, D.mbm};
         uint32_t buf = 0;
         for (;;) {
-            __syncthreads();
+            DUAL_BARRIER();
             const uint32_t mode = uni(D.u[buf][3]);
             if (mode == 2u) break;
             if (mode == 1u) {
                 const uint32_t op0 = uni(D.u[buf][0]), nseq = uni(D.u[buf][1]), T = uni(D.u[buf][2]);
                 const uint32_t a = D.da[buf][lane], b = D.db[buf][lane];
-                const uint32_t ll = a & 0xffffu, ml = a >> 16, off = b & 0xffffu, ostart = (b >> 16) & 0x7fffu;
-                const bool isfar = (b >> 31) != 0u;
+                const uint32_t ll = a & 0xffffu, ml = a >> 16, off = b & 0xffffu, ostart = b >> 16;
                 const bool act = lane < nseq;
-                uint4 xfa = make_uint4(0, 0, 0, 0), xfb = xfa;
-                if (act && isfar) {
-                    const uint8_t *g = w.dst + (op0 + ostart + ll - off);
-                    __builtin_memcpy(&xfa, g, 16);
-                    __builtin_memcpy(&xfb, g + 16, 16);
-                }
                 /* the ring's first bytes behind its end, for a 16-byte source read that starts in its last 15 -- only when a
                  * source run of this batch crosses the end: that end lies below the batch, more than R - 2T behind it, so
                  * neither this batch nor the other wave's crosses the ring's end and the 16 bytes are nobody's landing strip.
                  * (A read that crosses without its run doing so fetches bytes nobody uses.) */
                 const uint32_t mrel = ostart + ll;
-                const bool near_indep = act && !isfar && off >= mrel + ml;
-                if (__any(near_indep && ((op0 + mrel - off) & (R - 1u)) + ml > R)) {
+                const bool near_indep = act && ml != 0u && off >= mrel + ml;
+                if (wave_any(near_indep && ((op0 + mrel - off) & (R - 1u)) + ml > R)) {
                     uint2 mir = make_uint2(0, 0);
                     if (lane < 2u) mir = *reinterpret_cast<const uint2 *>(D.ring + lane * 8u);
                     LDS_FENCE();
@@ -574,10 +600,14 @@ k_lz4_dec_dual(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
                     LDS_FENCE();
                 }
                 w.op = op0;
-                seq_copy<R, kT2, true>(w, L, nseq, ostart, ll, ml, off, 0u, T, isfar, xfa, xfb, st);
+                const uint4 z = make_uint4(0, 0, 0, 0);
+                seq_copy<R, kT2, true>(w, L, nseq, ostart, ll, ml, off, 0u, T, false, z, z, st);
             }
             buf ^= 1u;
         }
+#if CRYO_DUAL_PROF
+        if (blk == 0 && lane == 0) printf("[dual] B: %llu barriers, memory %llu, waited %llu of %llu ticks\n", n_bar, t_vm, t_wait, __builtin_amdgcn_s_memtime() - t_start);
+#endif
         return;
     }
 
@@ -616,7 +646,7 @@ k_lz4_dec_dual(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     uint32_t buf = 0;
     /* a step = publish + barrier: B starts on what was published, and has finished the step before */
     auto step_batch = [&](const uint32_t op0) {
-        __syncthreads();
+        DUAL_BARRIER();
         buf ^= 1u;
         /* everything below the batch B is starting on is complete: store whole chunks of it */
         const uint32_t op_now = w.op;
@@ -626,7 +656,7 @@ k_lz4_dec_dual(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     };
     auto park_b = [&]() { /* nothing for B: it reads the mode and waits at the next barrier; the ring is A's until then */
         if (lane == 0u) D.u[buf][3] = 0u;
-        __syncthreads();
+        DUAL_BARRIER();
         buf ^= 1u;
     };
 
@@ -662,13 +692,16 @@ k_lz4_dec_dual(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
         if (r == 1u) done = true;
     }
     if (lane == 0u) D.u[buf][3] = 2u;
-    __syncthreads();
+    DUAL_BARRIER();
     if (!bad && w.op != B) bad = true;
     if (!bad) {
         w.flush();
         w.flush_tail();
     }
     if (lane == 0) status[blk] = bad ? CRYO_ST_CORRUPT : CRYO_ST_OK;
+#if CRYO_DUAL_PROF
+    if (blk == 0 && lane == 0) printf("[dual] A: %llu barriers, memory %llu, waited %llu of %llu ticks\n", n_bar, t_vm, t_wait, __builtin_amdgcn_s_memtime() - t_start);
+#endif
 }
 
 /* ---- launcher ---- */

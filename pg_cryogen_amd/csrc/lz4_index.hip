@@ -285,7 +285,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             state = nstate;
             /* rare: the token forms above, literal-length 255-runs, and jumps over everything requested (a long literal run) */
             const bool slow = rare | (!done & ((state == 1u) | (pos >= requested)));
-            if (__any(slow)) {
+            if (wave_any(slow)) {
                 if (rare) {
                     if (l15 && e1 == 255u) { state = 1u; acc = 15u + 255u; pos += 2u; }
                     else done = true; /* q2 > vend: last sequence */
@@ -369,10 +369,10 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
 #define IDX_DRAIN() asm volatile("s_waitcnt vmcnt(0)" : "+v"(fd0), "+v"(fe0), "+v"(fd1), "+v"(fe1), "+v"(fd2), "+v"(fe2), "+v"(fd3), "+v"(fe3) : : "memory");
 #endif
 #define IDX_WALK()                                              \
-    if (__any(!done)) {                                         \
+    if (wave_any(!done)) {                                         \
         do {                                                    \
             IDX_ROUNDS()                                        \
-        } while (__any(!done));                                 \
+        } while (wave_any(!done));                                 \
     }                                                           \
     IDX_DRAIN()                                                 \
     if (walker) IDX_FLUSH()
@@ -394,7 +394,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
         const uint8_t *sb = src_base + aoff;
         uint32_t p = pos, r = stop, j = 0, L = 0;
         bool merging = inner && !fail;
-        while (__any(merging)) {
+        while (wave_any(merging)) {
             if (merging) {
                 if (p == r) merging = false;
                 else if (p < r) {
@@ -431,7 +431,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
         fail = fail || (inner && j > 0xffffu);
         const uint32_t mine = fail ? 0xffffffffu : ((inner ? L : 0u) | ((inner ? j : 0u) << 16));
         const uint32_t left = from_prev(mine);
-        const unsigned long long fm = __ballot(fail);
+        const unsigned long long fm = wave_ballot(fail);
         const unsigned long long gmask = (logS >= 6u ? ~0ull : ((1ull << S) - 1ull)) << (lane & ~(S - 1u));
         const bool gfail = (fm & gmask) != 0ull;
         if (!gfail) {
@@ -440,7 +440,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             /* ---- phase 3: the chains of this block did not meet: its first lane walks all of it ---- */
             d_cnt = 0;
         }
-        if (__any(gfail)) {
+        if (wave_any(gfail)) {
             const bool redo = gfail && walker && sw == 0u;
             pos = delta;
             requested = filled = 0;

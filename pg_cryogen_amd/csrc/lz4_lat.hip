@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(64) k_lat_segs(LatArgs A)
     lat_segments(uni(A.src_size[blk]), seff, seglen);
     /* the walkers' chains did not all meet (the block's first lane walked all of it: positions more than 64 KiB from
      * the segment's start cannot be told from the 16-bit entries), or the block was left out of the index */
-    const unsigned long long later = __ballot(lane != 0u && c != 0u);
+    const unsigned long long later = wave_ballot(lane != 0u && c != 0u);
     const bool plain = total != 0u && total <= A.nmax && (seff == 1u || later != 0ull) && seglen < 0xF000u;
     if (lane == 0u) {
         A.nseq[blk] = total;
@@ -305,7 +305,7 @@ __global__ void __launch_bounds__(256) k_lat_jump(LatArgs A, uint32_t round)
 #pragma unroll
     for (uint32_t k = 0; k < 4u; k++) ch = ch || t[k] != s[k];
     if (ch) *reinterpret_cast<uint4 *>(srcb + b0) = make_uint4(t[0], t[1], t[2], t[3]);
-    if (__any(ch) && (threadIdx.x & 63u) == 0u) A.changed[round] = 1u; /* a plain store: 65 000 atomics on one word took 0.3 ms a round */
+    if (wave_any(ch) && (threadIdx.x & 63u) == 0u) A.changed[round] = 1u; /* a plain store: 65 000 atomics on one word took 0.3 ms a round */
 }
 
 /* match bytes from the literal bytes they come from */

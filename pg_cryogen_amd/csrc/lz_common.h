@@ -22,6 +22,12 @@ constexpr uint32_t kChunk = 1024;   /* bytes per output flush: 64 lanes x 16 B *
 constexpr uint32_t kInChunk = 512;  /* bytes per input refill: 64 lanes x 8 B (leaves room for a 1 KiB parse window) */
 
 __device__ inline uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
+/* votes: HIP's __ballot / __any turn the predicate into 0/1 in a register and compare that again (v_cndmask + v_cmp per vote);
+ * the builtin takes the compare's lane mask as it stands.  The decoders are bound by vector instruction issue at full
+ * occupancy (k_lz4_dec_seq: 88 % of the SIMDs' cycles), and a batch holds some twenty votes. */
+__device__ inline unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
+__device__ inline bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }
 /* NOTE: never rebuild a pointer from integers (it becomes a FLAT pointer and every access then
  * also counts on lgkmcnt, serialising LDS traffic behind HBM traffic); make the OFFSET uniform. */
 __device__ inline uint64_t uni64(uint64_t v)
@@ -341,7 +347,7 @@ __device__ inline void count_both(const uint8_t *fa, const uint8_t *fb, const ui
     uint32_t x0 = 0, x1 = 1, y0 = 0, y1 = 1;
     if (fin) { x0 = fa[lane]; x1 = fb[lane]; }
     if (bin) { y0 = ba[-1 - (int)lane]; y1 = bb[-1 - (int)lane]; }
-    const unsigned long long fne = __ballot(x0 != x1), bne = __ballot(y0 != y1);
+    const unsigned long long fne = wave_ballot(x0 != x1), bne = wave_ballot(y0 != y1);
     fwd = fne ? ctz64(fne) : 64u;
     back = bne ? ctz64(bne) : 64u;
     if (!fne) {
@@ -349,7 +355,7 @@ __device__ inline void count_both(const uint8_t *fa, const uint8_t *fb, const ui
         for (;;) {
             const bool inb = fa + done + lane < end;
             const bool eq = inb && fa[done + lane] == fb[done + lane];
-            const unsigned long long neq = __ballot(!eq);
+            const unsigned long long neq = wave_ballot(!eq);
             if (neq != 0ull) { fwd = done + ctz64(neq); break; }
             done += 64u;
         }
@@ -359,7 +365,7 @@ __device__ inline void count_both(const uint8_t *fa, const uint8_t *fb, const ui
         for (;;) {
             const uint32_t k = done + lane;
             const bool eq = k < blim && ba[-1 - (int)k] == bb[-1 - (int)k];
-            const unsigned long long neq = __ballot(!eq);
+            const unsigned long long neq = wave_ballot(!eq);
             if (neq != 0ull) { back = done + ctz64(neq); break; }
             done += 64u;
         }

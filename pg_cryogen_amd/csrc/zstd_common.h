@@ -168,7 +168,7 @@ struct LaneBits {
              * Rows 0..1 mirrored behind row 31 to save the wrap arithmetic of fill() were measured too and lost 4 %: the
              * two extra LDS stores per tick cost a lone wave more than six address instructions per fill,
              * profiles/r03_variants_ab.txt) */
-            if (__any(pending & (a < o_start))) {
+            if (wave_any(pending & (a < o_start))) {
                 if (a < o_start) { /* zero the bytes below the stream start */
                     const int32_t k = o_start - a > 16 ? 16 : o_start - a;
                     auto m = [&](int32_t q) { const int32_t nz = k - 4 * q; return nz >= 4 ? 0u : (nz <= 0 ? 0xFFFFFFFFu : 0xFFFFFFFFu << (8 * nz)); };
@@ -429,9 +429,9 @@ __device__ int huf_read_table(LT &L, uint16_t *table, const uint8_t *src, const 
         const int i = base + (int)lane;
         const bool on = i < nw;
         const uint32_t wv = on ? L.wts[i] : 0u;
-        if (__any(on && wv >= (uint32_t)kHufLogMax)) return -1;
+        if (wave_any(on && wv >= (uint32_t)kHufLogMax)) return -1;
 #pragma unroll
-        for (int r = 1; r < kHufLogMax; r++) rank[r] += (uint32_t)__builtin_popcountll(__ballot(on && wv == (uint32_t)r));
+        for (int r = 1; r < kHufLogMax; r++) rank[r] += (uint32_t)__builtin_popcountll(wave_ballot(on && wv == (uint32_t)r));
     }
     uint32_t total = 0;
 #pragma unroll
@@ -474,7 +474,7 @@ __device__ int huf_read_table(LT &L, uint16_t *table, const uint8_t *src, const 
             uint32_t place = 0;
 #pragma unroll
             for (int r = 1; r <= kHufLogMax; r++) {
-                const unsigned long long m = __ballot(on && wv == (uint32_t)r);
+                const unsigned long long m = wave_ballot(on && wv == (uint32_t)r);
                 if (wv == (uint32_t)r) place = run[r] + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 run[r] += (uint32_t)__builtin_popcountll(m);
             }

@@ -84,7 +84,7 @@ __device__ bool huf_decode_streams(const ZLds &L, int hlog, uint8_t *lit, uint32
             ok = (b.pos == 0) && !b.over; /* must end exactly */
         }
     }
-    return __ballot(!ok) == 0ull;
+    return wave_ballot(!ok) == 0ull;
 }
 
 struct FrameState {
@@ -235,7 +235,7 @@ __device__ bool decode_block(ZLds &L, Wave<ZR> &w, FrameState &fs, const uint8_t
             const bool isfar = inq && q_off >= ZR - kTMax;
             const bool ok = inq && lit_mode == 0 && (q_ml <= q_off || (q_off != 0u && q_ml <= 64u)) /* short self-overlap: a dependent match, lz4_copy.h */ && q_off <= mabs && !(isfar && q_ml > 32u) &&
                             litend <= regen - lit_pos && oend <= kTMax && (uint64_t)w.op + oend <= cap;
-            const unsigned long long badmask = __ballot(!ok);
+            const unsigned long long badmask = wave_ballot(!ok);
             const uint32_t nb = badmask ? ctz64(badmask) : 64u;
             if (nb > 0u) {
                 const uint32_t T = lane_get(oend, nb - 1u);

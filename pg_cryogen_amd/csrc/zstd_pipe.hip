@@ -156,7 +156,7 @@ __device__ inline bool fse_build_wave(uint8_t *cell, uint16_t *run, uint16_t *cu
     const int c = (int)lane <= max_sym ? (int)norm[lane] : 0;
     const bool low = c == -1;
     const uint32_t pc = c > 0 ? (uint32_t)c : 0u;
-    const unsigned long long lm = __ballot(low);
+    const unsigned long long lm = wave_ballot(low);
     const uint32_t nlow = (uint32_t)__builtin_popcountll(lm);
     const uint32_t incl = scan64_incl(pc);
     const uint32_t total = lane_get(incl, 63);
@@ -172,7 +172,7 @@ __device__ inline bool fse_build_wave(uint8_t *cell, uint16_t *run, uint16_t *cu
         const uint32_t j = j0 + lane;
         const uint32_t p = (j * step) & mask;
         const bool valid = j < size && p <= high;
-        const unsigned long long m = __ballot(valid);
+        const unsigned long long m = wave_ballot(valid);
         const uint32_t i = vbase + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         vbase += (uint32_t)__builtin_popcountll(m);
         uint32_t lo = 0; /* the last symbol whose first rank is <= i: the i-th placed cell is its */
@@ -186,11 +186,11 @@ __device__ inline bool fse_build_wave(uint8_t *cell, uint16_t *run, uint16_t *cu
         const uint32_t p = p0 + lane;
         const bool on = p < size;
         const uint32_t sym = on ? cell[p] : 0xFFFFu;
-        unsigned long long rem = __ballot(on);
+        unsigned long long rem = wave_ballot(on);
         uint32_t r = 0, cnt = 1;
         while (rem) {
             const uint32_t s0 = lane_get(sym, (uint32_t)__builtin_ctzll(rem));
-            const unsigned long long m = __ballot(sym == s0);
+            const unsigned long long m = wave_ballot(sym == s0);
             if (sym == s0) {
                 r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                 cnt = (uint32_t)__builtin_popcountll(m);
@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(64) k_zhuf(ZPipe P, const uint32_t *__restrict
             for (uint32_t i = lane; i < (1u << kHufL1); i += 64u) {
                 uint32_t e = g[i << sh];
                 const bool lng = (e >> 8) > kHufL1;
-                const unsigned long long m = __ballot(lng);
+                const unsigned long long m = wave_ballot(lng);
                 if (lng) {
                     const uint32_t rank = running + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                     if (rank < cap) {
@@ -809,7 +809,7 @@ __device__ __attribute__((always_inline)) inline void zhufw_item(const ZPipe &P,
     uint32_t last = 0;
     if (sok) last = gsrc[delta + soff + slen - 1u];
     if (last == 0u) sok = false;
-    if (__any(sid < nstreams && !sok)) { fallback(1); return; } /* a stream without an end mark: k_zhuf says what it is */
+    if (wave_any(sid < nstreams && !sok)) { fallback(1); return; } /* a stream without an end mark: k_zhuf says what it is */
     /* segments */
     const uint32_t T = sok ? (slen - 1u) * 8u + (31u - (uint32_t)__builtin_clz(last)) : 0u;
     uint32_t se = T >> 11;
@@ -962,11 +962,13 @@ __device__ __attribute__((always_inline)) inline void zhufw_item(const ZPipe &P,
     HW_STAMP(56);
 #define HW_RUN() \
     /* head: the turns that leave marks; body: the rest */ \
-    for (uint32_t t = 0; t < 4u * kHwMarks && __any(phase == MAIN && z.pos - bound > 88); t += 4u) { HW_TURNS(octet(true)) } \
-    while (__any(phase == MAIN && z.pos - bound > 88)) { HW_TURNS(octet(false)) } \
+    for (uint32_t t = 0; t < 4u * kHwMarks && wave_any(phase == MAIN && z.pos - bound > 88); t += 4u) { HW_TURNS(octet(true)) } \
+    while (wave_any(phase == MAIN && z.pos - bound > 88)) { HW_TURNS(octet(false)) } \
     /* tail: the rest of the segment (at most 88 bits each: symbol by symbol), then on into the next one until the chains meet */ \
-    while (__any(phase == MAIN)) { HW_TURNS(if (phase == MAIN) slow()) } \
-    while (__any(phase != DONE)) { HW_TURNS(tail_step()) }
+    /* (round 4 tried these four loops in their rotated form, test at the bottom, which rid lane_runs of its register copies: \
+     * here the body shrank by 8 % and the kernel took 9 % longer, 3.17 -> 3.45 ms per tile; profiles/r04_valu.txt) */ \
+    while (wave_any(phase == MAIN)) { HW_TURNS(if (phase == MAIN) slow()) } \
+    while (wave_any(phase != DONE)) { HW_TURNS(tail_step()) }
     HW_RUN()
     HW_STAMP(58);
     /* ---- repair: a walker that did not meet its right neighbour in time knows where that one's segment truly starts
@@ -987,7 +989,7 @@ __device__ __attribute__((always_inline)) inline void zhufw_item(const ZPipe &P,
         asm volatile("" ::: "memory");
         redone = ep != 0xFFFFFFFFu;
         ep_used = ep;
-        if (__any(redone)) {
+        if (wave_any(redone)) {
             fa0 = fa1 = fa2 = fa3 = fm0 = fm1 = fm2 = fm3 = tr; /* pieces on their way belong to the old positions */
             prime(redone, (int32_t)ep);
             if (redone) { phase = MAIN; okw = true; nomeet = false; n = 0; sync_j = 0; ej = 0; hc = kHwMarks; main_n = 0; }
@@ -1017,7 +1019,7 @@ __device__ __attribute__((always_inline)) inline void zhufw_item(const ZPipe &P,
     const uint32_t incl = scan16_incl(ntrue);
     const uint32_t total = (uint32_t)__shfl((int)incl, (int)(lane | 15u), 64);
     const bool fine = (!walker || (okw && n >= myskip && !stale)) && (sid >= nstreams || total == cnt);
-    if (!__all(fine)) { fallback(__any(walker && !okw && phase == DONE && n + 24u > cap) ? 4 : (__any(walker && !okw) ? 2 : (__any(walker && n < myskip) ? 5 : 3))); return; }
+    if (!wave_all(fine)) { fallback(wave_any(walker && !okw && phase == DONE && n + 24u > cap) ? 4 : (wave_any(walker && !okw) ? 2 : (wave_any(walker && n < myskip) ? 5 : 3))); return; }
     /* ---- the move of the walkers' symbols to the literal pool is k_zmove's (round 4): here it was 35 % of this
      * kernel's wave time at seven waves per CU (22 KB of LDS per wave); a kernel that does nothing else runs it with the
      * chip full of waves ---- */
@@ -1189,7 +1191,7 @@ __device__ inline void chain_turn(uint8_t *ring, const uint16_t *tab, ChainLane 
         const uint64_t win = z.raw << z.sh;
         uint32_t W = (uint32_t)((win << X) >> 32);
         const bool ovf = go & (X + N > 57u);
-        if (__any(ovf)) { /* more bits than one window holds: the state bits come from a second read */
+        if (wave_any(ovf)) { /* more bits than one window holds: the state bits come from a second read */
             if (ovf) {
                 const int32_t p2 = z.pos - (int32_t)X;
                 const int32_t cb2 = z.s0 + ((p2 - 1) >> 3);
@@ -1341,7 +1343,7 @@ __global__ void __launch_bounds__(64) k_zchain(ZPipe P)
     const uint32_t tr = 32u * kChStride + lane * 16u;
     uint4 fd0 = make_uint4(0, 0, 0, 0), fd1 = fd0, fd2 = fd0, fd3 = fd0;
     uint32_t fa0 = tr, fa1 = tr, fa2 = tr, fa3 = tr, fm0 = tr, fm1 = tr, fm2 = tr, fm3 = tr;
-    while (__any(z.i < z.nseq)) {
+    while (wave_any(z.i < z.nseq)) {
         chain_turn<0, true>(L.ring, tab, z, lane, grp0, fd0, fa0, fm0, g0, ve0, w0, r0, out, trash, cl, co, cm, myring, bad);
         chain_turn<0, false>(L.ring, tab, z, lane, grp0, fd0, fa0, fm0, g0, ve0, w0, r0, out, trash, cl, co, cm, myring, bad);
         chain_turn<1, true>(L.ring, tab, z, lane, grp1, fd1, fa1, fm1, g1, ve1, w1, r1, out, trash, cl, co, cm, myring, bad);
@@ -1569,13 +1571,13 @@ __global__ void __launch_bounds__(64) k_zchain4(ZPipe P)
     cq_u32x4 fd0 = {0, 0, 0, 0}, fd1 = fd0, fd2 = fd0, fd3 = fd0;
     uint32_t fa0 = trash_lds, fa1 = trash_lds, fa2 = trash_lds, fa3 = trash_lds, fm0 = trash_lds, fm1 = trash_lds, fm2 = trash_lds, fm3 = trash_lds;
 #define CQ_TURN(J, FEED, FD, FA, FM) chainq_turn<J, FEED>(L.ring, tab, z, k, mine, c, m1, m2, FD, FA, FM, gmine, vend, myring, trash_lds, out, trash, bad);
-    if (__any(z.i < z.nseq)) {
+    if (wave_any(z.i < z.nseq)) {
         do { /* (do-while: with `while` the register allocator copies the slots at the top of the loop, lz4_index.hip) */
             CQ_TURN(0, true, fd0, fa0, fm0) CQ_TURN(0, false, fd0, fa0, fm0)
             CQ_TURN(1, true, fd1, fa1, fm1) CQ_TURN(1, false, fd1, fa1, fm1)
             CQ_TURN(2, true, fd2, fa2, fm2) CQ_TURN(2, false, fd2, fa2, fm2)
             CQ_TURN(3, true, fd3, fa3, fm3) CQ_TURN(3, false, fd3, fa3, fm3)
-        } while (__any(z.i < z.nseq));
+        } while (wave_any(z.i < z.nseq));
     }
     /* the compiler does not know of the assembly loads: the drain names the slots, or their registers -- dead to the
      * compiler once the loop is left -- are handed to something else while a load is still on its way into them (seen: an
@@ -1806,7 +1808,7 @@ __device__ bool exec_block(ExecLds &L, Wave<kZR> &w, const ZPipe &P, const ZBlk 
         const bool isfar = inq && q_off >= kZR - kZT; /* in the ring for the whole batch, or flushed before it (lz4_copy.h) */
         const bool ok = inq && streamed && (q_ml <= q_off || (q_off != 0u && q_ml <= 64u)) /* short self-overlap: a dependent match, lz4_copy.h */ && q_off <= mabs && !(isfar && q_ml > 32u) &&
                         litend <= regen - lit_pos && litend <= kZLitMax && oend <= kZT && (uint64_t)w.op + oend <= cap;
-        const unsigned long long badmask = __ballot(!ok);
+        const unsigned long long badmask = wave_ballot(!ok);
         const uint32_t nb = badmask ? ctz64(badmask) : 64u;
         if (nb > 0u) {
             const uint32_t T = lane_get(oend, nb - 1u);
