@@ -378,7 +378,14 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     if (walker) IDX_FLUSH()
 
     /* ---- phase 1: every walker its own segment ---- */
+#ifdef CRYO_IDX_PROF
+    const unsigned long long t_p0 = __builtin_amdgcn_s_memtime();
+#endif
     IDX_WALK()
+#ifdef CRYO_IDX_PROF
+    const unsigned long long t_p1 = __builtin_amdgcn_s_memtime();
+    uint32_t prof_steps = 0;
+#endif
 
     uint32_t d_ext = 0, d_skip = 0, d_cnt = walker ? k : 0u; /* this segment's descriptor */
     if (logS != 0u) {
@@ -395,6 +402,9 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
         uint32_t p = pos, r = stop, j = 0, L = 0;
         bool merging = inner && !fail;
         while (wave_any(merging)) {
+#ifdef CRYO_IDX_PROF
+            prof_steps++;
+#endif
             if (merging) {
                 if (p == r) merging = false;
                 else if (p < r) {
@@ -464,6 +474,10 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
 #undef IDX_FLUSH
 #undef IDX_PUT
     if (owner) seg[gl] = make_uint2(d_ext | (d_skip << 16), d_cnt);
+#ifdef CRYO_IDX_PROF
+    if ((blockIdx.x & 63u) == 0u && lane == 0u)
+        printf("[index] wave %u: walk %llu ticks, hand-over and the rest %llu ticks, %u merge steps\n", blockIdx.x, t_p1 - t_p0, __builtin_amdgcn_s_memtime() - t_p1, prof_steps);
+#endif
 }
 
 /* ---- layout and launcher ---- */
