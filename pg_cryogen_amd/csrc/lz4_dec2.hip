@@ -50,6 +50,76 @@ constexpr uint32_t kSeqWin = 1536;  /* compressed bytes a batch may span (in_hi 
 constexpr uint32_t kT2 = 1536;      /* output bytes per batch: the largest T with R - T >= T + 1023 at R = 4096, i.e. every
                                      * offset is either still in the ring (off < R - T) or flushed (off >= T + 1023) */
 
+/*
+ * The block's row of the index, as the walkers left it (lz4_index.hip): per segment an "extension" piece (what the left
+ * neighbour's walker visited before the chains met) and the segment's own records from the meeting point on.  Lane s
+ * holds segment s's descriptor; the pieces are consumed in order.  A batch takes its 64 entries from the current piece and,
+ * where that ends, from the two behind it -- the tail of a segment's records, the (short) extension into the next segment
+ * and that segment's own records (round 4: a batch used to stop at every piece's end -- with 32 walkers per block that is 64
+ * short batches on top of a 128 KiB block's 100, and the reason mid-sized batches could not use more walkers).
+ */
+template <bool MULTI> /* false: one walker per block, the row is one piece (the headline batch: nothing of the window below) */
+struct IndexRow {
+    const uint16_t *base;      /* the block's row */
+    uint2 sd;                  /* lane s: descriptor of segment s */
+    uint32_t cap_s, ext, npieces, pc; /* pc: the next piece to look at */
+    const uint16_t *t0, *t1, *t2; /* the current piece and the next two that are not empty */
+    uint32_t len0, len1, len2, n0; /* their entries; entries of the current piece used so far */
+
+    __device__ inline void find(const uint16_t *&t, uint32_t &len)
+    {
+        len = 0;
+        t = base;
+        while (pc < npieces) {
+            const uint32_t sg = pc >> 1;
+            const uint32_t dx = lane_get(sd.x, sg), dy = lane_get(sd.y, sg);
+            const uint32_t l = (pc & 1u) ? dy : (dx & 0xffffu);
+            const uint32_t b = sg * cap_s + ((pc & 1u) ? ext + (dx >> 16) : 0u);
+            pc++;
+            if (l != 0u) { t = base + b; len = l; break; }
+        }
+    }
+    __device__ inline void open(const uint16_t *row, const uint2 *seg, const uint64_t blk, const uint32_t logS, const uint32_t cap_s_,
+                                const uint32_t ext_, const uint32_t lane)
+    {
+        base = row;
+        cap_s = cap_s_; ext = ext_;
+        npieces = 2u << logS;
+        sd = make_uint2(0, 0);
+        if (lane < (1u << logS)) sd = seg[(blk << logS) + lane];
+        pc = 0; n0 = 0;
+        find(t0, len0);
+        t1 = t2 = base; len1 = len2 = 0;
+        if (MULTI) { find(t1, len1); find(t2, len2); }
+    }
+    /* entries from position k behind the cursor on: how many there are (64 at most), and this lane's */
+    __device__ inline uint32_t avail(const uint32_t k) const
+    {
+        const uint32_t have = MULTI ? len0 + len1 + len2 : len0, at = n0 + k;
+        return at < have ? (have - at < 64u ? have - at : 64u) : 0u;
+    }
+    __device__ inline uint32_t entry(const uint32_t k, const uint32_t lane) const
+    {
+        const uint32_t i = n0 + k + lane;
+        uint32_t e = 0;
+        if (MULTI) {
+            const uint16_t *q = i < len0 ? t0 + i : (i < len0 + len1 ? t1 + (i - len0) : t2 + (i - len0 - len1));
+            if (i < len0 + len1 + len2) e = *q;
+        } else if (i < len0) e = t0[i];
+        return e;
+    }
+    __device__ inline void advance(const uint32_t n)
+    {
+        n0 += n;
+        while (MULTI && len0 != 0u && n0 >= len0) { /* the current piece is used up: the next one becomes it */
+            n0 -= len0;
+            t0 = t1; len0 = len1;
+            t1 = t2; len1 = len2;
+            find(t2, len2);
+        }
+    }
+};
+
 /* lane i gets lane i+1's value (lane 63: 0) */
 __device__ inline uint32_t lane_next(uint32_t v)
 {
@@ -60,10 +130,9 @@ __device__ inline uint32_t lane_next(uint32_t v)
  * One batch: sequences n0 .. n0+63 of the block start at the positions in the index row (epos = this lane's
  * entry).  Returns the number of sequences decoded (0: the caller takes one sequence through the general path).
  */
-template <uint32_t R>
+template <uint32_t R, bool MULTI>
 __device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const CopyLds<R, kT2> &L, uint32_t &vp, const uint32_t B,
-                                         const uint32_t epos, const uint32_t navail, const uint16_t *__restrict__ trow,
-                                         const uint32_t n0, const uint32_t ntab, uint32_t &epre, Stats &st,
+                                         const uint32_t epos, const uint32_t navail, const IndexRow<MULTI> &ix, uint32_t &epre, Stats &st,
                                          unsigned long long *stop_hist = nullptr)
 {
     const uint32_t lane = w.lane;
@@ -140,8 +209,7 @@ __device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const CopyLds<R, kT2> &L, u
     const uint32_t T = lane_get(oend, nseq - 1u);
     const uint32_t used = lane_get(pos + dlen, nseq - 1u) - vp;
     /* the next batch's positions are requested now: their trip to memory hides behind this batch's copy */
-    epre = 0;
-    if (n0 + nseq + lane < ntab) epre = trow[n0 + nseq + lane];
+    epre = ix.entry(nseq, lane);
     /* ... and so are the sources of its far matches (flushed output: off >= T + 1023 behind a match).  (Round 4 tried
      * them first, as assembly loads with a counted wait behind the literal copy instead of the compiler's vmcnt(0):
      * 3 % slower -- the kernel is bound by instruction issue and LDS cycles, not by this wait;
@@ -269,7 +337,7 @@ __device__ inline uint32_t lz4_general_seq(Wave<R> &w, uint32_t &vp, const uint3
 
 constexpr uint32_t kDecR = CRYO_DEC_R, kDecWpb = CRYO_DEC_WPB;
 
-template <uint32_t R, bool STATS, uint32_t WPB>
+template <uint32_t R, bool STATS, uint32_t WPB, bool MULTI>
 __global__ void __launch_bounds__(64 * WPB, CRYO_DEC_OCC)
 k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
               const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
@@ -313,39 +381,20 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
     bool bad = (csize == 0);
     bool done = bad;
     uint32_t skip = 0;
-    /* The block's row of the index, as the walkers left it (lz4_index.hip): per segment an "extension" piece (what the
-     * left neighbour's walker visited before the chains met) and the segment's own records from the meeting point on.
-     * Lane s holds segment s's descriptor; the pieces are consumed in order, a batch never spans two of them. */
-    const uint16_t *trow = tbl + uni64(blk * (uint64_t)tbl_cap);
-    const uint32_t npieces = 2u << logS;
-    uint2 sd = make_uint2(0, 0);
-    if (lane < (1u << logS)) sd = seg[(blk << logS) + lane];
-    uint32_t pc = 0, plen = 0; /* next piece; entries of the current one */
-    uint32_t n0 = 0;           /* entries of the current piece used so far */
-    auto next_piece = [&]() {
-        plen = 0;
-        n0 = 0;
-        while (pc < npieces) {
-            const uint32_t sg = pc >> 1;
-            const uint32_t dx = lane_get(sd.x, sg), dy = lane_get(sd.y, sg);
-            const uint32_t len = (pc & 1u) ? dy : (dx & 0xffffu);
-            const uint32_t base = sg * cap_s + ((pc & 1u) ? ext + (dx >> 16) : 0u);
-            pc++;
-            if (len != 0u) { trow = tbl + uni64(blk * (uint64_t)tbl_cap) + base; plen = len; break; }
-        }
-    };
-    next_piece();
+    IndexRow<MULTI> ix;
+    ix.open(tbl + uni64(blk * (uint64_t)tbl_cap), seg, blk, logS, cap_s, ext, lane);
     uint32_t poor = 0;
 
     /* the first batch's index entries travel with the first input chunks (one trip to memory at the start of a block, not two) */
     uint32_t efirst = 0;
-    if (!bad && lane < plen) efirst = trow[lane];
+    if (!bad) efirst = ix.entry(0, lane);
     bool have_first = !bad;
     if (!bad) {
         w.prefetch();
         w.refill();
         if (w.in_hi < w.vend) w.refill();
     }
+    uint32_t npre = ix.avail(0); /* entries the request on its way covers */
 
     while (!done) {
         if (skip == 0u) {
@@ -355,15 +404,14 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
             bool more;
             have_first = false;
             do {
-                if (plen != 0u && n0 >= plen) { next_piece(); have_pre = false; }
-                uint32_t e = epre;
-                const uint32_t navail = n0 < plen ? (plen - n0 < 64u ? plen - n0 : 64u) : 0u;
-                if (!have_pre) { e = 0; if (lane < navail) e = trow[n0 + lane]; }
-                n = lz4_seq_batch<R>(w, L, vp, B, e, navail, trow, n0, plen, epre, st, STATS ? stats + 16 : nullptr);
+                uint32_t e = epre, navail = npre;
+                if (!have_pre) { navail = ix.avail(0); e = ix.entry(0, lane); }
+                n = lz4_seq_batch<R, MULTI>(w, L, vp, B, e, navail, ix, epre, st, STATS ? stats + 16 : nullptr);
                 have_pre = n != 0u;
-                n0 += n;
+                npre = ix.avail(n);
+                ix.advance(n);
                 if (n == 0u) st.zero_batches++;
-                more = n >= 8u || (n != 0u && n == navail); /* a piece's last batch may be short: go on with the next piece */
+                more = n >= 8u || (n != 0u && n == navail); /* a batch that took all the window held may be short: go on */
             } while (more);
             /* a batch stops in front of a sequence it cannot take (overlapping match, long run, end of block):
              * that one goes through the general path and the batches resume.  Only data that keeps yielding
@@ -374,8 +422,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
             skip--;
         }
         st.general_seqs++;
-        if (plen != 0u && n0 >= plen) next_piece();
-        n0++;
+        ix.advance(1u);
         const uint32_t r = lz4_general_seq<R>(w, vp, B);
         if (r == 2u) { bad = true; break; }
         if (r == 1u) done = true;
@@ -456,8 +503,7 @@ struct DualLds {
 
 /* wave A: one batch up to and including its literal runs; publishes it in buffer `buf`.  Returns the sequences taken. */
 __device__ inline uint32_t lz4_dual_front(Wave<kDualR> &w, DualLds &D, uint32_t &vp, const uint32_t B, const uint32_t epos,
-                                          const uint32_t navail, const uint16_t *__restrict__ trow, const uint32_t n0,
-                                          const uint32_t ntab, uint32_t &epre, const uint32_t buf)
+                                          const uint32_t navail, const IndexRow<true> &ix, uint32_t &epre, const uint32_t buf)
 {
     constexpr uint32_t R = kDualR;
     const uint32_t lane = w.lane;
@@ -503,8 +549,7 @@ __device__ inline uint32_t lz4_dual_front(Wave<kDualR> &w, DualLds &D, uint32_t 
     if (nseq == 0u) return 0;
     const uint32_t T = lane_get(oend, nseq - 1u);
     const uint32_t used = lane_get(pos + dlen, nseq - 1u) - vp;
-    epre = 0;
-    if (n0 + nseq + lane < ntab) epre = trow[n0 + nseq + lane];
+    epre = ix.entry(nseq, lane);
     /* far matches are this wave's too: their sources are output it has flushed itself (everything below the batch the other
      * wave is working on), their destinations bytes of this batch; the trip to memory hides behind the literal runs */
     const bool farm = lane < nseq && isfar;
@@ -616,33 +661,18 @@ k_lz4_dec_dual(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     bool bad = (csize == 0);
     bool done = bad;
     uint32_t skip = 0;
-    const uint16_t *trow = tbl + uni64(blk * (uint64_t)tbl_cap);
-    const uint32_t npieces = 2u << logS;
-    uint2 sd = make_uint2(0, 0);
-    if (lane < (1u << logS)) sd = seg[(blk << logS) + lane];
-    uint32_t pc = 0, plen = 0, n0 = 0;
-    auto next_piece = [&]() {
-        plen = 0;
-        n0 = 0;
-        while (pc < npieces) {
-            const uint32_t sg = pc >> 1;
-            const uint32_t dx = lane_get(sd.x, sg), dy = lane_get(sd.y, sg);
-            const uint32_t len = (pc & 1u) ? dy : (dx & 0xffffu);
-            const uint32_t pbase = sg * cap_s + ((pc & 1u) ? ext + (dx >> 16) : 0u);
-            pc++;
-            if (len != 0u) { trow = tbl + uni64(blk * (uint64_t)tbl_cap) + pbase; plen = len; break; }
-        }
-    };
-    next_piece();
+    IndexRow<true> ix;
+    ix.open(tbl + uni64(blk * (uint64_t)tbl_cap), seg, blk, logS, cap_s, ext, lane);
     uint32_t poor = 0;
     uint32_t efirst = 0;
-    if (!bad && lane < plen) efirst = trow[lane];
+    if (!bad) efirst = ix.entry(0, lane);
     bool have_first = !bad;
     if (!bad) {
         w.prefetch();
         w.refill();
         if (w.in_hi < w.vend) w.refill();
     }
+    uint32_t npre = ix.avail(0);
     uint32_t buf = 0;
     /* a step = publish + barrier: B starts on what was published, and has finished the step before */
     auto step_batch = [&](const uint32_t op0) {
@@ -668,15 +698,14 @@ k_lz4_dec_dual(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
             bool more;
             have_first = false;
             do {
-                if (plen != 0u && n0 >= plen) { next_piece(); have_pre = false; }
-                uint32_t e = epre;
-                const uint32_t navail = n0 < plen ? (plen - n0 < 64u ? plen - n0 : 64u) : 0u;
-                if (!have_pre) { e = 0; if (lane < navail) e = trow[n0 + lane]; }
+                uint32_t e = epre, navail = npre;
+                if (!have_pre) { navail = ix.avail(0); e = ix.entry(0, lane); }
                 const uint32_t op0 = w.op;
-                n = lz4_dual_front(w, D, vp, B, e, navail, trow, n0, plen, epre, buf);
+                n = lz4_dual_front(w, D, vp, B, e, navail, ix, epre, buf);
                 if (n != 0u) step_batch(op0);
                 have_pre = n != 0u;
-                n0 += n;
+                npre = ix.avail(n);
+                ix.advance(n);
                 more = n >= 8u || (n != 0u && n == navail);
             } while (more);
             poor = n < 4u ? poor + 1u : 0u;
@@ -684,8 +713,7 @@ k_lz4_dec_dual(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
         } else {
             skip--;
         }
-        if (plen != 0u && n0 >= plen) next_piece();
-        n0++;
+        ix.advance(1u);
         park_b(); /* B has finished the batch before; the general path owns the ring */
         const uint32_t r = lz4_general_seq<R>(w, vp, B);
         if (r == 2u) { bad = true; break; }
@@ -718,9 +746,13 @@ static void launch_dec_seq(hipStream_t s, const uint8_t *d_src, const uint64_t *
         return;
     }
 #endif
-    hipLaunchKernelGGL((k_lz4_dec_seq<kDecR, false, kDecWpb>), dim3((uint32_t)((n_blocks + kDecWpb - 1) / kDecWpb)), dim3(64 * kDecWpb), 0, s, d_src, d_src_off, d_src_size,
-                       d_dst, dst_stride, block_size, n_blocks, d_status, nullptr, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext,
-                       Lx.logS != 0u ? 1u : 0u, d_done);
+    const dim3 g((uint32_t)((n_blocks + kDecWpb - 1) / kDecWpb)), b(64 * kDecWpb);
+    if (Lx.logS != 0u)
+        hipLaunchKernelGGL((k_lz4_dec_seq<kDecR, false, kDecWpb, true>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks,
+                           d_status, nullptr, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, 1u, d_done);
+    else
+        hipLaunchKernelGGL((k_lz4_dec_seq<kDecR, false, kDecWpb, false>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks,
+                           d_status, nullptr, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, 0u, d_done);
 }
 
 /* the blocks the few-blocks path did not decode (lz4_lat.hip), with the index it built */
@@ -753,7 +785,7 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
         static const unsigned long long abl = cryo_tuning_env("CRYO_LZ4_ABLATE") ? strtoull(cryo_tuning_env("CRYO_LZ4_ABLATE"), nullptr, 0) : 0ull;
         (void)hipMemcpyAsync(d_st + 7, &abl, sizeof abl, hipMemcpyHostToDevice, s);
-        hipLaunchKernelGGL((k_lz4_dec_seq<kDecR, true, kDecWpb>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
+        hipLaunchKernelGGL((k_lz4_dec_seq<kDecR, true, kDecWpb, true>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
                            block_size, n_blocks, d_status, d_st, static_cast<const uint16_t *>(d_workspace), Lx.cap,
                            reinterpret_cast<const uint2 *>(static_cast<const uint8_t *>(d_workspace) + Lx.seg_off), Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, 0u, nullptr);
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
