@@ -63,3 +63,17 @@ def test_production_host_library_has_no_test_hook():
     assert not hasattr(prod, "cryo_host_set_codec_ops")
     assert hasattr(prod, "cryo_compress") and hasattr(prod, "cryo_decompress") and hasattr(prod, "cryo_scan_next_batch")
     assert hasattr(ctypes.CDLL(host.HOST_TEST_LIB_PATH), "cryo_host_set_codec_ops")
+
+
+def test_option_numbers_match_the_header():
+    """the Python mirror's OPT_* constants are the header's cryo_option values (a test that flips an option by number
+    must flip the one it names)"""
+    import re
+    from pg_cryogen_amd import codec as cc
+    text = open(os.path.join(ROOT, "include", "cryo_codec.h")).read()
+    body = text[text.index("typedef enum {", text.index("per-handle options")):text.index("} cryo_option;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    enum = {m.group(1): int(m.group(2)) for m in re.finditer(r"CRYO_OPT_(\w+)\s*=\s*(\d+)", body)}
+    assert len(enum) >= 9 and len(set(enum.values())) == len(enum)
+    for name, value in enum.items():
+        assert getattr(cc, "OPT_" + name) == value, name
