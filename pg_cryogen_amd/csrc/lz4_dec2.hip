@@ -476,8 +476,8 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
  * Measured (profiles/r04_lz4_dual.txt): 1 024 x 128 KiB 0.475 -> 0.34 ms, 512 x 1 MiB 2.97 -> 1.83 ms.  Each wave waits at the
  * barrier for 18-20 % of the time: a batch is as long as its longer half and the halves vary (A: 600 k busy ticks, B: 587 k,
  * lock-step total 731 k).  Moving match space's preparation from B to A (then 610 k / 606 k busy) changed nothing -- the
- * variance, not the balance, is what is left; a queue two batches deep would need a 16 KiB ring (far sources must be below
- * what is stored) and is not built.
+ * variance, not the balance, is what is left.  A queue two batches deep between the waves (16 KiB ring, counts in LDS polled
+ * with s_sleep) was built and is slower everywhere: profiles/r04_lz4_dualq.txt, the patch is profiles/scripts/r04_dualq.patch.
  * --------------------------------------------------------------------------------------------- */
 #ifndef CRYO_DUAL_PROF
 #define CRYO_DUAL_PROF 0 /* variant builds only: block 0 prints how long each of its waves waited at the barriers */
