@@ -659,6 +659,11 @@ __global__ void __launch_bounds__(64) k_zhuf(ZPipe P, const uint32_t *__restrict
 }
 
 /* per-lane input rings fed cooperatively by the wave (k_zhufw, k_zchain) */
+#ifndef CRYO_ZEXEC_OCC
+#define CRYO_ZEXEC_OCC 6 /* waves per SIMD the register allocator aims at: k_zexec takes 94 registers = 5 waves without a hint; with 80
+                          * (32 bytes of scratch) 1.91 -> 1.82 ms per tile, the call 1 % (profiles/r04_zstd_decode_ab.txt); k_zmove at 8
+                          * waves (64 registers, 92 bytes of scratch) and k_zmat at 7 / 8 (72 / 64 registers) lose */
+#endif
 constexpr uint32_t kChRing = 128, kChStride = 144; /* ring + 8-byte mirror + pad */
 __device__ inline uint32_t bperm32(uint32_t v, uint32_t src_lane)
 {
@@ -1862,7 +1867,7 @@ __device__ bool exec_block(ExecLds &L, Wave<kZR> &w, const ZPipe &P, const ZBlk 
 
 } // namespace
 
-__global__ void __launch_bounds__(64) k_zexec(ZPipe P)
+__global__ void __launch_bounds__(64, CRYO_ZEXEC_OCC) k_zexec(ZPipe P)
 {
     __shared__ __attribute__((aligned(16))) ExecLds L;
     const uint32_t lane = threadIdx.x & 63u;
