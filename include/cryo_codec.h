@@ -93,7 +93,7 @@ typedef enum {
      * 0: wherever the scheduler puts them.  get_option reports 0 when the node could not be determined. */
     CRYO_OPT_NUMA_LOCAL = 8,
     /* waves per block of the indexed LZ4 decoder: 0 = automatic (two for batches that leave most of the chip idle: up to
-     * 3 328 blocks; one otherwise), 1 = k_lz4_dec_seq, 2 = k_lz4_dec_dual whatever the batch size */
+     * 3 072 blocks; one otherwise), 1 = k_lz4_dec_seq, 2 = k_lz4_dec_dual whatever the batch size */
     CRYO_OPT_LZ4_DECODE_WAVES = 9
 } cryo_option;
 int cryo_codec_set_option(cryo_codec *c, int option, int64_t value);

@@ -490,7 +490,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
 #endif
 constexpr uint32_t kDualR = 8192;
 constexpr uint32_t kDualNear = kDualR - 2u * kT2; /* 5120 */
-constexpr uint32_t kDualMaxBlocks = 3328;         /* 13 workgroups of two waves per CU */
+constexpr uint32_t kDualMaxBlocks = 3072;         /* 12 workgroups of two waves per CU (13 fit by the LDS, but 3 328 blocks run slower than on one wave: profiles/r04_lz4_dual_threshold.txt) */
 
 struct DualLds {
     uint8_t ring[kDualR + 16];

@@ -331,7 +331,7 @@ def _indexed(codec, walkers):
 def _decode_check(codec, comps, expect, B, tag):
     """comps decoded as one device batch; expect[i] = the oracle's block, or None for 'must be rejected'.  The indexed
     decoder has two forms (CRYO_OPT_LZ4_DECODE_WAVES: one wave per block, k_lz4_dec_seq -- what big batches get; two waves
-    per block, k_lz4_dec_dual -- what batches up to 3 328 blocks get): the batch goes through both."""
+    per block, k_lz4_dec_dual -- what batches up to 3 072 blocks get): the batch goes through both."""
     from pg_cryogen_amd import codec as cc
     for waves in (1, 2):
         codec.set_option(cc.OPT_LZ4_DECODE_WAVES, waves)
