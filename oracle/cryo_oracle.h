@@ -48,7 +48,8 @@ long cryo_oracle_lz4_decompress(const uint8_t *src, size_t csize, uint8_t *dst, 
 size_t cryo_oracle_zstd_bound(size_t n);
 /* returns decoded size or -1 on malformed input, like ZSTD_decompress */
 long cryo_oracle_zstd_decompress(const uint8_t *src, size_t csize, uint8_t *dst, size_t cap);
-/* returns frame size; levels with strategy `fast` only (see zstd_enc_oracle.c), 0 if unsupported */
+/* returns frame size; every level -5…22 (all nine strategies, see zstd_enc_oracle.c; sources up to 1 MiB at the
+ * optimal-parser levels), 0 if unsupported */
 size_t cryo_oracle_zstd_compress(const uint8_t *src, size_t n, uint8_t *dst, size_t cap, int level);
 
 #ifdef __cplusplus
