@@ -235,7 +235,9 @@ def main():
         codec.set_option(cc.OPT_LZ4_DECODE_WAVES, a.lz4_waves)
     ora = oracle_lib.Oracle()
     job_block = lambda k: rank + k * world   # block i of the job lives on rank i mod N (pg_cryogen_amd/shard.py)
-    want_cpu = world == 1 and not a.no_cpu_baseline
+    # cpu_baseline: rank 0, at every world size, after the timed region (north_star: the host's stock libraries timed "in the
+    # same run" at 1, 2, 4 and 8 GPUs).  The other ranks are past their last barrier by then and only free their buffers.
+    want_cpu = rank == 0 and not a.no_cpu_baseline
     bufs = []
 
     def alloc(nbytes):

@@ -295,14 +295,31 @@ size_t ws_budget(cryo_codec *c)
     if (hipMemGetInfo(&fr, &tot) != hipSuccess) { (void)hipGetLastError(); return ~(size_t)0; }
     return fr / 10u * 7u + c->ws_cap;
 }
-/* host-buffer calls end synchronised: give back the workspace beyond CRYO_OPT_WORKSPACE_KEEP_BYTES */
+/* host-buffer calls end synchronised: give back what the handle holds on the device beyond CRYO_OPT_WORKSPACE_KEEP_BYTES --
+ * the kernels' workspace first (LZ4 sequence index, zstd tiles), then the staging areas of the host-buffer calls themselves
+ * (n x block_size each: round 4 left those out, and a backend kept GiBs of them after one large call).  Every path that ends
+ * a host-buffer call comes through here: the public wrappers and each handle's share of a cryo_multi_* call (multi_run). */
 void ws_trim_after_call(cryo_codec *c)
 {
-    if (c->ws_keep >= 0 && c->d_ws && c->ws_cap > (size_t)c->ws_keep) {
-        (void)hipStreamSynchronize(c->stream);
+    if (c->ws_keep < 0) return;
+    const size_t keep = (size_t)c->ws_keep;
+    const size_t hb = c->hb_src_cap + c->hb_dst_cap + c->hb_meta_cap;
+    const bool drop_ws = c->d_ws && c->ws_cap > keep;
+    const bool drop_hb = hb != 0 && hb + (drop_ws ? 0 : c->ws_cap) > keep;
+    if (!drop_ws && !drop_hb) return;
+    DevGuard dev_(c);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->xfer) (void)hipStreamSynchronize(c->xfer);
+    if (drop_ws) {
         (void)hipFree(c->d_ws);
         c->d_ws = nullptr;
         c->ws_cap = 0;
+    }
+    if (drop_hb) {
+        auto drop = [](uint8_t *&p, size_t &cap) { if (p) (void)hipFree(p); p = nullptr; cap = 0; };
+        drop(c->hb_src, c->hb_src_cap);
+        drop(c->hb_dst, c->hb_dst_cap);
+        drop(c->hb_meta, c->hb_meta_cap);
     }
 }
 
@@ -923,9 +940,11 @@ static int decompress_blocks_piped(cryo_codec *c, int method, const void *const 
         memcpy(h_status, p_st, n * 4);
         return CRYO_OK;
     }
-    HIP_TRY(c, hipMemcpyAsync(p_st, d_st, n * 4, hipMemcpyDeviceToHost, c->stream));
+    /* the trailing scatters read p_st on the host (which blocks failed): the whole-call status copy goes out behind them,
+     * not under them */
     for (size_t ch = nch >= 2 ? nch - 2 : 0; ch < nch; ch++)
         if ((rc = scatter(ch)) != CRYO_OK) return rc;
+    HIP_TRY(c, hipMemcpyAsync(p_st, d_st, n * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     memcpy(h_status, p_st, n * 4);
     return CRYO_OK;
@@ -1409,7 +1428,10 @@ static int multi_run(cryo_multi *m, size_t n, const std::function<int(size_t, co
     for (size_t i = 0; i < n; i++) share[i % G].push_back(i);
     std::vector<int> rc(G, CRYO_OK);
     const std::function<void(unsigned)> one = [&](unsigned g) {
-        if (!share[g].empty()) rc[g] = guarded([&] { return fn(g, share[g]); });
+        if (!share[g].empty()) {
+            rc[g] = guarded([&] { return fn(g, share[g]); });
+            ws_trim_after_call(m->h[g]); /* the keep limit holds per handle, whoever dispatched the call */
+        }
     };
     if (m->pool) m->pool->run((unsigned)G, one);
     else for (unsigned g = 0; g < G; g++) one(g);

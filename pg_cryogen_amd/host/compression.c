@@ -21,6 +21,7 @@
 
 #include <stdarg.h>
 #include <stdio.h>
+#include <time.h>
 
 int compression_method_guc = COMP_ZSTD;
 int lz4_acceleration_guc = 1;
@@ -37,7 +38,12 @@ Size cryo_blcksz = (Size)1 << 20; /* CRYO_BLCKSZ, reference storage.h:18 */
  * dispatcher of include/cryo_codec.h (block i of a call -> GPU i mod G, one host thread per GPU). */
 static cryo_multi *hip_multi;
 static int hip_multi_first = -1, hip_multi_count = 0, hip_pool_mb = 0, hip_keep_mb = -2;
-static int hip_open_failed, hip_failed_first = -1, hip_failed_count = 0; /* a failed open is remembered until the GUCs change */
+/* A failed open is remembered until the GUCs change -- for good when the machine has no GPU (deterministic), for
+ * CRYO_OPEN_RETRY_SECONDS when devices exist but cryo_multi_open failed (out of device memory, a busy device: transient;
+ * a pooled backend must not refuse every cryo table for the rest of its life because of one bad moment). */
+#define CRYO_OPEN_RETRY_SECONDS 5
+static int hip_open_failed, hip_failed_first = -1, hip_failed_count = 0;
+static time_t hip_failed_at; /* 0: the failure was deterministic */
 static char codec_err[320];
 
 static size_t hip_bound(int method, size_t n) { return cryo_codec_bound(method, n); }
@@ -87,8 +93,11 @@ const CryoCodecOps *cryo_host_codec_ops(void)
         int devs[64], i, ndev, rc;
         int cnt = cryo_gpu_count_guc < 1 ? 1 : (cryo_gpu_count_guc > 64 ? 64 : cryo_gpu_count_guc);
         /* not again for every call of a backend that cannot have a GPU (codec_err still says why) */
-        if (hip_open_failed && hip_failed_first == cryo_gpu_device_guc && hip_failed_count == cryo_gpu_count_guc) return NULL;
+        if (hip_open_failed && hip_failed_first == cryo_gpu_device_guc && hip_failed_count == cryo_gpu_count_guc &&
+            (hip_failed_at == 0 || time(NULL) - hip_failed_at < CRYO_OPEN_RETRY_SECONDS))
+            return NULL;
         hip_open_failed = 1;
+        hip_failed_at = 0;
         hip_failed_first = cryo_gpu_device_guc;
         hip_failed_count = cryo_gpu_count_guc;
         ndev = cryo_codec_device_count();
@@ -102,6 +111,8 @@ const CryoCodecOps *cryo_host_codec_ops(void)
             snprintf(codec_err, sizeof codec_err, "cryo_multi_open(first %d, count %d) failed with %d (no CPU fallback)",
                      cryo_gpu_device_guc, cnt, rc);
             hip_multi = NULL;
+            hip_failed_at = time(NULL); /* devices exist: try again in a while */
+            if (hip_failed_at == 0) hip_failed_at = 1;
             return NULL;
         }
         hip_open_failed = 0;

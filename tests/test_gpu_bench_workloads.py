@@ -48,6 +48,20 @@ def test_bench_workload_line(workload, metric, blocks):
     assert c["unit"] == "GB/s" and c["value"] > 0 and c["cores"] == 1 and c["kind"] in ("reference", "port") and c["sample"]
 
 
+@pytest.mark.parametrize("workload,blocks", [
+    ("zstd", 65536),     # BASELINE configs[2] at its full size: zstd level 1 compress + decompress of the 64 Ki-block batch
+    ("mixed", 16384),    # BASELINE configs[4] at the per-GPU size bench.py defaults to (level-22 encode on the GPU: seconds)
+])
+def test_bench_full_size_configs(workload, blocks):
+    """configs[2] and configs[4] at FULL size through bench.py, so that the driver's GPU run -- not only the builder's --
+    has seen them.  bench.py verifies the bytes itself: encode == oracle on sampled blocks, every
+    decoded block == its original on the device."""
+    j = run_bench("--workload", workload, "--blocks", str(blocks), "--steps", "2", "--warmup", "1", "--cpu-blocks", "128")
+    assert j["config"]["blocks_per_gpu"] == blocks and j["value"] > 0
+    assert "== oracle" in j["config"]["bit_exact"] and "original on all blocks" in j["config"]["bit_exact"]
+    assert 0 < j["roofline"]["frac"] < 1 and j["cpu_baseline"]["value"] > 0
+
+
 def test_automatic_walkers_batch_against_oracle(codec, oracle):
     """A 16 384-block batch takes the index pass at its AUTOMATIC setting (four walkers per block, lz4_decode_plan) --
     the other tests force the walker count on a few dozen blocks.  Blocks are generated and compressed on the device;

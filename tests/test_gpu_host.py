@@ -287,6 +287,29 @@ def test_workspace_options_and_trim(oracle):
         c.set_option(cc.OPT_WORKSPACE_MAX_BYTES, 0)
         c.set_option(cc.OPT_LZ4_DECODE_PATH, cc.LZ4_PATH_AUTO)
         check(c)
+    # the same limit through the multi-GPU dispatcher (two handles on this GPU): each handle's share of a call gives its
+    # workspace AND its staging areas back when the limit says so (round 4 trimmed only single-handle calls)
+    import ctypes as C
+    L = cc.lib()
+    h = C.c_void_p()
+    assert L.cryo_multi_open((C.c_int * 2)(0, 0), 2, C.byref(h)) == 0
+    try:
+        def multi_check():
+            for method, comps in ((METHOD_ZSTD, zc), (METHOD_LZ4, lc)):
+                ptrs = (C.c_void_p * n)(*[x.ctypes.data for x in comps])
+                csz = np.array([len(x) for x in comps], np.uint32)
+                dec = np.zeros(n * B, np.uint8)
+                st = np.ones(n, np.int32)
+                assert L.cryo_multi_decompress_blocks(h, method, ptrs, csz.ctypes.data, n, dec.ctypes.data, B, st.ctypes.data) == 0
+                assert (st == 0).all() and all(np.array_equal(dec[i * B:(i + 1) * B], raws[i]) for i in range(n))
+        multi_check()                                          # keep = -1 (a bare handle): everything stays
+        held = torch.cuda.mem_get_info(0)[0]
+        assert L.cryo_multi_set_option(h, cc.OPT_WORKSPACE_KEEP_BYTES, 0) == 0
+        multi_check()                                          # every share ends by giving back what it holds
+        after = torch.cuda.mem_get_info(0)[0]
+        assert after > held + (n // 2) * B, "the dispatcher's handles kept their staging areas (%d -> %d bytes free)" % (held, after)
+    finally:
+        L.cryo_multi_close(h)
 
 
 def test_pipelined_pointer_forms(codec, oracle):

@@ -19,12 +19,16 @@ def test_bench_two_ranks_share_one_gpu():
     env.pop("WORLD_SIZE", None)
     env.pop("RANK", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-                          "--blocks", "1024"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+                          "--blocks", "1024", "--cpu-blocks", "128"], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["total_blocks"] == 2048 and j["value"] > 0
     assert "decode == original on all 1024 blocks" in j["config"]["bit_exact"]
+    # the measurement contract's two objects are there at N > 1 too
+    r, c = j["roofline"], j["cpu_baseline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and "traffic" in r
+    assert c["unit"] == "GB/s" and c["value"] > 0 and c["cores"] == 1 and c["kind"] in ("reference", "port") and c["sample"]
 
 
 def test_two_handles_one_process(oracle):
