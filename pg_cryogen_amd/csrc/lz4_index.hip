@@ -227,8 +227,13 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
              * commits (vmcnt(N)); a conditional load made it drain the queue once per round (2.3 us a round) */
             const uint8_t *g1 = src_base + (soff + ((p1 & (o1 < sve)) ? o1 : 0u));
             const uint8_t *g2 = src_base + (soff2 + ((p2 & (o2 < sve2)) ? o2 : 0u));
+#if CRYO_NT_LOADS
+            asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(fd) : "v"(g1));
+            asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(fe) : "v"(g2));
+#else
             asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(fd) : "v"(g1)); /* "+": the slot keeps its registers round after round (see above) */
             asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(fe) : "v"(g2));
+#endif
         }
         /* ---- one hop, branch-free for the two common states (token, match-length extension) ---- */
         {

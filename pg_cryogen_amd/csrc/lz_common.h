@@ -37,7 +37,32 @@ __device__ inline uint64_t uni64(uint64_t v)
     return ((uint64_t)hi << 32) | lo;
 }
 __device__ inline uint32_t lane_get(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ inline uint32_t ctz64(unsigned long long m) { return (uint32_t)__builtin_ctzll(m); }
+/* 16 bytes per lane of decoded output on their way to memory, for the LONG runs (a literal run or a pattern streamed 1 KiB
+ * per instruction for tens of KiB: the zero gap of a cryo block).  A wave stores into its own block: with
+ * plain stores 65 536 such streams reach 3.5 TB/s, with non-temporal ones 5.65 (profiles/r05_store_bw.txt; a grid-stride fill
+ * reaches 5.0-5.7 either way, hipMemsetAsync 6.3) -- `zeros` 3 287 -> 5 258 GB/s, `narrow` 2 077 -> 3 191, `int4` 2 424 -> 3 537
+ * (profiles/r05_nt_ab.txt).  The line stays in the XCD's L2 all the same (MI355X_MICROARCH.md, "stores of each flavour").
+ * The batches' 1 KiB flushes stay plain stores: non-temporal ones there made the headline batch 1-4 % slower (same file). */
+#ifndef CRYO_NT_STREAM
+#define CRYO_NT_STREAM 1
+#endif
+#ifndef CRYO_NT_FLUSH
+#define CRYO_NT_FLUSH 0
+#endif
+#ifndef CRYO_NT_LOADS
+#define CRYO_NT_LOADS 0 /* experiment: the compressed input (read once) with non-temporal loads: no gain (profiles/r05_nt_ab.txt) */
+#endif
+template <bool NT>
+__device__ inline void store16_out(uint8_t *p, const uint4 v)
+{
+    if constexpr (NT) {
+        typedef uint32_t u32x4_ __attribute__((ext_vector_type(4)));
+        const u32x4_ y = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(y, reinterpret_cast<u32x4_ *>(p));
+    } else {
+        *reinterpret_cast<uint4 *>(p) = v;
+    }
+}
 
 template <uint32_t R>
 struct Wave {
@@ -62,7 +87,12 @@ struct Wave {
     {
         const uint32_t o = at + lane * 8u;
         uint2 v = make_uint2(0, 0);
+#if CRYO_NT_LOADS
+        typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
+        if (o < vend) { const u32x2_ y = __builtin_nontemporal_load(reinterpret_cast<const u32x2_ *>(abase + o)); v = make_uint2(y.x, y.y); }
+#else
         if (o < vend) v = *reinterpret_cast<const uint2 *>(abase + o);
+#endif
         return v;
     }
     __device__ inline void prefetch()
@@ -114,7 +144,7 @@ struct Wave {
         while (op - flushed >= kChunk) {
             if (dst_aligned) {
                 const uint4 x = *reinterpret_cast<const uint4 *>(ring + ((flushed + lane * 16u) & (R - 1)));
-                *reinterpret_cast<uint4 *>(dst + flushed + lane * 16u) = x;
+                store16_out<CRYO_NT_FLUSH != 0>(dst + flushed + lane * 16u, x);
             } else {
                 for (uint32_t i = lane; i < kChunk; i += 64u) dst[flushed + i] = ring[(flushed + i) & (R - 1)];
             }
@@ -177,7 +207,7 @@ __device__ inline bool wave_stream_literals(Wave<R> &w, uint32_t &p, uint32_t &r
     for (uint32_t c = 0; c < nch; c++) {
         uint4 v;
         __builtin_memcpy(&v, w.abase + p + c * kChunk + w.lane * 16u, 16);
-        *reinterpret_cast<uint4 *>(w.dst + w.op + c * kChunk + w.lane * 16u) = v;
+        store16_out<CRYO_NT_STREAM != 0>(w.dst + w.op + c * kChunk + w.lane * 16u, v);
         if (c + R / kChunk >= nch) *reinterpret_cast<uint4 *>(w.ring + ((w.op + c * kChunk + w.lane * 16u) & (R - 1))) = v;
     }
     w.op += nch * kChunk;
@@ -229,7 +259,7 @@ __device__ inline bool wave_stream_pattern(Wave<R> &w, uint32_t &rem, bool zero)
 #pragma unroll
     for (uint32_t k = 0; k < R / kChunk; k++) *reinterpret_cast<uint4 *>(w.ring + ((k * kChunk + w.lane * 16u) & (R - 1))) = v;
     const uint32_t nch = rem / kChunk;
-    for (uint32_t c = 0; c < nch; c++) *reinterpret_cast<uint4 *>(w.dst + w.op + c * kChunk + w.lane * 16u) = v;
+    for (uint32_t c = 0; c < nch; c++) store16_out<CRYO_NT_STREAM != 0>(w.dst + w.op + c * kChunk + w.lane * 16u, v);
     w.op += nch * kChunk;
     w.flushed = w.op;
     rem -= nch * kChunk;

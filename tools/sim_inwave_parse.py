@@ -16,6 +16,8 @@ from oracle_lib import Oracle  # noqa: E402
 
 def next_token(c, p, n):
     """position of the token after the one at p (None: last sequence / cut / 255-run that leaves the fast path)"""
+    if p >= n:
+        return None
     t = c[p]
     ll = t >> 4
     q = p + 1
