@@ -37,6 +37,8 @@ __device__ inline uint64_t uni64(uint64_t v)
     return ((uint64_t)hi << 32) | lo;
 }
 __device__ inline uint32_t lane_get(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ inline uint32_t ctz64(unsigned long long m) { return (uint32_t)__builtin_ctzll(m); }
+
 /* 16 bytes per lane of decoded output on their way to memory, for the LONG runs (a literal run or a pattern streamed 1 KiB
  * per instruction for tens of KiB: the zero gap of a cryo block).  A wave stores into its own block: with
  * plain stores 65 536 such streams reach 3.5 TB/s, with non-temporal ones 5.65 (profiles/r05_store_bw.txt; a grid-stride fill
