@@ -313,7 +313,11 @@ __device__ inline uint32_t distinct_prefix2(uint8_t *mark, uint32_t slot0, uint3
  * slots, then writes both) and tests the repeat offset at ip0 + 2, then ip0, then ip1; no hit: both advance by
  * ((ip0 - anchor) >> 7) + stepSize.  (zstd_enc.hip's block_fast_batch does the same over an LDS table for
  * hashLog <= 14.) */
-__device__ uint32_t block_fast_gbatch(uint32_t *table, uint8_t *mark, const CPar &cp, const uint8_t *base,
+/* TAB: uint32_t (the table in the workgroup's global workspace) or lds_u32_t (round 5 experiment: a 2^13-entry table in LDS,
+ * k_zstd_enc<.., .., true>; profiles/r05_zstd_enc_lds.txt) */
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+template <typename TAB>
+__device__ uint32_t block_fast_gbatch(TAB *table, uint8_t *mark, const CPar &cp, const uint8_t *base,
                                       const uint8_t *istart, uint32_t n, uint32_t *rep, uint8_t *ws, SeqStore &ss,
                                       uint32_t dict_limit, uint32_t lane, uint32_t W)
 {

@@ -1117,7 +1117,7 @@ __device__ uint32_t block_fast(uint32_t *table, const CPar &cp, const uint8_t *b
  * iterations per step (block_fast_gbatch); 1 = `dfast` (block_dfast_batch); 2 = `fast`, the serial walk
  * (block_fast: the plain restatement, CRYO_ZSTD_ENC=1); 3 = `greedy` (block_greedy: hash table, then chain table;
  * `width` carries searchLog). */
-template <bool PROF, bool OPT> /* PROF: CRYO_ZSTD_STATS counters; OPT: the optimal-parser strategies (finder 7 btopt, 8 btultra, 9 btultra2) */
+template <bool PROF, bool OPT, bool LT = false> /* PROF: CRYO_ZSTD_STATS counters; OPT: the optimal-parser strategies (finder 7 btopt, 8 btultra, 9 btultra2); LT: `fast` with its table (hashLog <= 13) in LDS */
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
 k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t n_blocks,
            uint8_t *__restrict__ dst_base, uint64_t dst_stride, int wlog, int hlog, int clog, int mml, int tlen,
@@ -1125,6 +1125,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
            uint8_t *workspace, uint64_t ws_stride, unsigned long long *stats)
 {
     __shared__ __attribute__((aligned(16))) EncLds L;
+    __shared__ __attribute__((aligned(16))) uint32_t s_ftab[LT ? (1u << 13) : 4u];
     /* the finders' mark array lies over the entropy stage's scratch (histogram + tree nodes: dead while a finder runs) */
     static_assert(offsetof(EncLds, nbyte) >= kDfMark, "mark array must stay inside the scratch part of EncLds");
     uint8_t *df_mark = reinterpret_cast<uint8_t *>(&L);
@@ -1147,7 +1148,9 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
     for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
         const uint8_t *src = src_base + blk * src_stride;
         uint8_t *dst = dst_base + blk * dst_stride;
-        {
+        if constexpr (LT) {
+            for (uint32_t i = lane; i < (1u << hlog) / 4u; i += 64u) reinterpret_cast<uint4 *>(s_ftab)[i] = make_uint4(0, 0, 0, 0);
+        } else {
             const uint32_t quads = ((1u << hlog) + (two_tables ? 1u << clog : 0u) + (hlog3 ? 1u << hlog3 : 0u)) / 4u;
             for (uint32_t i = lane; i < quads; i += 64u) reinterpret_cast<uint4 *>(table)[i] = make_uint4(0, 0, 0, 0);
         }
@@ -1195,7 +1198,10 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 uint32_t nrep[3] = {rep[0], rep[1], rep[2]};
                 if constexpr (PROF) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_other += t - t_prev; t_prev = t; }
                 uint32_t last_ll;
-                if constexpr (OPT) {
+                if constexpr (LT) {
+                    last_ll = block_fast_gbatch((lds_u32_t *)s_ftab, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, width);
+                }
+                else if constexpr (OPT) {
                     const uint32_t cur = (uint32_t)(src + ip - base); /* ZSTD_buildSeqStore: limited catch-up after a very long match */
                     if (cur > hc.next_to_update + 384u) {
                         const uint32_t d = cur - hc.next_to_update - 384u;
@@ -1383,8 +1389,18 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
     static const uint32_t w_env = cryo_tuning_env("CRYO_ZSTD_ENC_WIDTH") ? (uint32_t)atoi(cryo_tuning_env("CRYO_ZSTD_ENC_WIDTH")) : 0u; /* tuning aid */
     const uint32_t width = strategy >= 3 ? (uint32_t)slog : (w_env ? w_env : (dfast ? 32u : 16u));
     const size_t stride = zstd_enc_stride(hlog, clog, strategy >= 2, strategy, mml, wlog);
-    const uint32_t grid = zstd_enc_grid(n_blocks, stride);
+    uint32_t grid = zstd_enc_grid(n_blocks, stride);
     if (workspace_bytes < (size_t)grid * stride) return hipErrorInvalidValue;
+    /* round 5 experiment (debug builds): `fast` with its table in LDS -- 32 KiB of u32 entries beside the entropy stage's 9 KiB:
+     * three workgroups per CU */
+    static const bool lds_tab_env = cryo_tuning_env("CRYO_ZSTD_ENC_LDS") != nullptr;
+    if (lds_tab_env && finder == 0 && hlog <= 13) {
+        const uint32_t cap = 256u * 3u;
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL((k_zstd_enc<false, false, true>), dim3(grid), dim3(64), 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride, wlog,
+                           hlog, clog, mml, tlen, finder, width, d_out_size, d_status, (uint8_t *)d_workspace, (uint64_t)stride, nullptr);
+        return hipGetLastError();
+    }
     static const bool stats_env = cryo_tuning_env("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
     const bool want_stats = stats_env && strategy < 7;
     unsigned long long *d_st = nullptr, h_st[24] = {0};

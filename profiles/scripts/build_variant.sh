@@ -5,7 +5,7 @@
 # but travels to the GPU box).  Run `make -C pg_cryogen_amd/csrc` first.
 set -e
 NAME=$1; EXTRA=$2; shift; shift
-ROOT=$(cd "$(dirname "$0")/../.." && pwd); C=$ROOT/pg_cryogen_amd/csrc; T=/tmp/cryo_variants/$NAME; mkdir -p $T
+ROOT=$(cd "$(dirname "$0")/../.." && pwd); C=$ROOT/pg_cryogen_amd/csrc; T=$ROOT/build/variants/$NAME; mkdir -p $T
 OBJS=""
 for o in $C/*.o; do
   b=$(basename $o .o); use=$o
