@@ -444,7 +444,10 @@ void cryo_codec_close(cryo_codec *c)
     }
     for (int l = 0; l < cryo::kZstdLanes; l++) {
         if (c->aux.lane[l]) { (void)hipStreamSynchronize(c->aux.lane[l]); (void)hipStreamDestroy(c->aux.lane[l]); }
+        if (c->aux.side[l]) { (void)hipStreamSynchronize(c->aux.side[l]); (void)hipStreamDestroy(c->aux.side[l]); }
         if (c->aux.join[l]) (void)hipEventDestroy(c->aux.join[l]);
+        if (c->aux.planned[l]) (void)hipEventDestroy(c->aux.planned[l]);
+        if (c->aux.seqs_done[l]) (void)hipEventDestroy(c->aux.seqs_done[l]);
     }
     if (c->aux.fork) (void)hipEventDestroy(c->aux.fork);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
@@ -464,6 +467,9 @@ int cryo_codec_trim(cryo_codec *c)
     if (c->have_aux)
         for (int l = 0; l < cryo::kZstdLanes; l++)
             if (c->aux.lane[l]) HIP_TRY(c, hipStreamSynchronize(c->aux.lane[l]));
+    if (c->have_aux)
+        for (int l = 0; l < cryo::kZstdLanes; l++)
+            if (c->aux.side[l]) HIP_TRY(c, hipStreamSynchronize(c->aux.side[l]));
     auto drop = [](auto *&p, size_t &cap) { if (p) (void)hipFree(p); p = nullptr; cap = 0; };
     { void *w = c->d_ws; if (w) (void)hipFree(w); c->d_ws = nullptr; c->ws_cap = 0; }
     drop(c->d_in, c->in_cap);
@@ -670,6 +676,9 @@ int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
             for (int l = 0; l < cryo::kZstdLanes; l++) {
                 HIP_TRY(c, hipStreamCreateWithFlags(&c->aux.lane[l], hipStreamNonBlocking));
                 HIP_TRY(c, hipEventCreateWithFlags(&c->aux.join[l], hipEventDisableTiming));
+                HIP_TRY(c, hipStreamCreateWithFlags(&c->aux.side[l], hipStreamNonBlocking));
+                HIP_TRY(c, hipEventCreateWithFlags(&c->aux.planned[l], hipEventDisableTiming));
+                HIP_TRY(c, hipEventCreateWithFlags(&c->aux.seqs_done[l], hipEventDisableTiming));
             }
             HIP_TRY(c, hipEventCreateWithFlags(&c->aux.fork, hipEventDisableTiming));
             c->have_aux = true;

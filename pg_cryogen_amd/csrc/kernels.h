@@ -115,6 +115,10 @@ constexpr int kZstdLanes = 8; /* side streams a decode call may spread its tiles
 struct ZstdAux {
     hipStream_t lane[kZstdLanes];
     hipEvent_t fork, join[kZstdLanes];
+    /* inside a tile the Huffman stage (k_zhufw, k_zmove, k_zhuf) and the sequence stage (k_zchain4, k_zmat) depend on
+     * k_zplan only and meet in k_zexec: calls of few tiles run them side by side (round 5) */
+    hipStream_t side[kZstdLanes];
+    hipEvent_t planned[kZstdLanes], seqs_done[kZstdLanes];
 };
 hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                   const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,

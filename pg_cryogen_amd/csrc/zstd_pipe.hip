@@ -2058,6 +2058,10 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
     static const uint32_t seq_pad = cryo_tuning_env("CRYO_ZSEQ_PAD") ? (uint32_t)atoi(cryo_tuning_env("CRYO_ZSEQ_PAD")) : 0u;
     static const bool want_stats = cryo_tuning_env("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
     static const bool old_huf = cryo_tuning_env("CRYO_ZHUF_OLD") != nullptr;
+    /* calls of at most this many zstd blocks (frames x blocks per frame) run a tile's two entropy stages side by side: 3-6 %
+     * less time from 1 to 4 096 frames, 5 % MORE at a full tile of 12 288 (profiles/r05_zstd_fork.txt; tuning aid:
+     * CRYO_ZSTD_FORK_ZBLOCKS) */
+    static const uint64_t fork_max_zblocks = cryo_tuning_env("CRYO_ZSTD_FORK_ZBLOCKS") ? (uint64_t)atoll(cryo_tuning_env("CRYO_ZSTD_FORK_ZBLOCKS")) : 8192u;
     uint64_t t = 0;
     for (uint64_t first = 0; first < n_blocks; first += y.F, t++) {
         const int l = (int)(t % (uint64_t)nl);
@@ -2090,10 +2094,36 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
         P.F = (uint32_t)(left < y.F ? left : y.F);
         if ((e = hipMemsetAsync(P.counters, 0, 256, st)) != hipSuccess) return e;
         hipLaunchKernelGGL(k_zplan, dim3(P.F), dim3(64), 0, st, P);
+        /* Inside a tile the Huffman stage and the sequence stage depend on k_zplan only and meet in k_zexec.  With many tiles
+         * in flight other tiles' kernels fill what one stage leaves idle; a call that leaves the chip mostly empty (a read-ahead of a
+         * few hundred blocks, ONE frame: the reference's own call shape, cache.c:178) ran them one after the other.  There
+         * the sequence stage goes to a side stream (round 5, profiles/r05_zstd_fork.txt). */
+        hipStream_t sq = st;
+        const bool fork_stages = aux != nullptr && n_blocks * ((block_size + kZBlockMax - 1u) / kZBlockMax) <= (uint64_t)fork_max_zblocks;
+        if (fork_stages) {
+            sq = aux->side[l];
+            if ((e = hipEventRecord(aux->planned[l], st)) != hipSuccess) return e;
+            if ((e = hipStreamWaitEvent(sq, aux->planned[l], 0)) != hipSuccess) return e;
+        }
         const uint32_t zhuf_all = (P.F * P.nbmax + kHufPerWave - 1u) / kHufPerWave;
 #ifndef CRYO_GS
 #define CRYO_GS 7 /* grids sized for the chip: 1 k_zhuf, 2 k_zhufw, 4 k_zchain4 (0: one workgroup per descriptor slot, as in round 3) */
 #endif
+        /* ---- sequence stage (its own stream when forked; issued first so that it is not queued behind the Huffman kernels) ---- */
+        auto seq_stage = [&](hipStream_t q) {
+#if CRYO_ZCHAIN_QUAD
+            const uint32_t zc_all = (P.F * P.nbmax + kCqW - 1u) / kCqW;
+            hipLaunchKernelGGL(k_zchain4, dim3((CRYO_GS & 4) && zc_all > 768u ? 768u : zc_all), dim3(64), seq_pad, q, P);
+#else
+            hipLaunchKernelGGL(k_zchain, dim3((P.F * P.nbmax + kChW - 1u) / kChW), dim3(64), seq_pad, q, P);
+#endif
+            hipLaunchKernelGGL(k_zmat, dim3(P.F), dim3(64), 0, q, P);
+        };
+        if (fork_stages) {
+            seq_stage(sq);
+            if ((e = hipEventRecord(aux->seqs_done[l], sq)) != hipSuccess) return e;
+        }
+        /* ---- Huffman stage ---- */
         if (old_huf) hipLaunchKernelGGL(k_zhuf, dim3((CRYO_GS & 1) && zhuf_all > 1024u ? 1024u : zhuf_all), dim3(64), huf_pad, st, P, P.hitems, 1u);
         else {
             /* 1 792 of these are resident (seven per CU); a frame has one Huffman block per 128 KiB */
@@ -2104,15 +2134,11 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
             if (!skip_fallbacks)
             hipLaunchKernelGGL(k_zhuf, dim3((CRYO_GS & 1) && zhuf_all > 256u ? 256u : zhuf_all), dim3(64), 0, st, P, P.hitems2, 61u); /* the walkers' hand-backs: rarely any */
         }
-#if CRYO_ZCHAIN_QUAD
-        {
-            const uint32_t zc_all = (P.F * P.nbmax + kCqW - 1u) / kCqW;
-            hipLaunchKernelGGL(k_zchain4, dim3((CRYO_GS & 4) && zc_all > 768u ? 768u : zc_all), dim3(64), seq_pad, st, P);
+        if (fork_stages) {
+            if ((e = hipStreamWaitEvent(st, aux->seqs_done[l], 0)) != hipSuccess) return e;
+        } else {
+            seq_stage(st);
         }
-#else
-        hipLaunchKernelGGL(k_zchain, dim3((P.F * P.nbmax + kChW - 1u) / kChW), dim3(64), seq_pad, st, P);
-#endif
-        hipLaunchKernelGGL(k_zmat, dim3(P.F), dim3(64), 0, st, P);
         hipLaunchKernelGGL(k_zexec, dim3(P.F), dim3(64), 0, st, P);
         const uint64_t fg = P.F < kFusedGridForIrregular ? P.F : kFusedGridForIrregular;
         static const bool skip_fused = cryo_tuning_env("CRYO_ZSTD_SKIP_FALLBACKS") != nullptr;
