@@ -75,6 +75,11 @@ struct Lz4IndexLayout {
 Lz4IndexLayout lz4_index_layout(uint64_t n_blocks, uint32_t block_size, uint32_t walkers);
 hipError_t launch_lz4_index(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
                             uint64_t n_blocks, uint32_t block_size, void *d_workspace, const Lz4IndexLayout &L);
+/* few blocks per call: a workgroup of up to 1 024 walkers per block, direct loads (lz4_index.hip, k_lz4_index_few) */
+Lz4IndexLayout lz4_index_layout_few(uint64_t n_blocks, uint32_t block_size);
+const uint32_t *lz4_index_few_failed(const void *d_workspace, const Lz4IndexLayout &L, uint64_t n_blocks); /* one word per block: 1 = no index */
+hipError_t launch_lz4_index_few(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
+                                uint64_t n_blocks, uint32_t block_size, void *d_workspace, const Lz4IndexLayout &L);
 /* Per-block routing of batches indexed with several walkers per block: a block that compressed to more than 15/16 of
  * its size is almost all literal runs -- a walker that starts at a guessed position inside one hops through it ~7 bytes at
  * a time where the true chain takes one hop, and the copy is one long run either way -- so such blocks are left to the
@@ -85,7 +90,7 @@ hipError_t launch_lz4_index(hipStream_t s, const uint8_t *d_src, const uint64_t 
 __host__ __device__ inline bool lz4_literal_heavy(uint32_t csize, uint32_t block_size) { return csize > block_size - (block_size >> 4); }
 hipError_t launch_lz4_dec_ring(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
                                uint8_t *d_dst, uint64_t dst_stride, uint32_t block_size, uint64_t n_blocks, int32_t *d_status,
-                               bool only_literal_heavy);
+                               bool only_literal_heavy, const uint32_t *d_done = nullptr /* blocks marked there are skipped */);
 /* lz4_dec2.hip: index pass + the decoder that consumes it */
 hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                          const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,

@@ -277,7 +277,8 @@ template <uint32_t R, bool STATS>
 __global__ void __launch_bounds__(256, LZ4_WAVES_PER_SIMD) /* VGPR cap matching what the LDS budget admits */
 k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
                const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
-               uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats, uint32_t only_heavy)
+               uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats, uint32_t only_heavy,
+               const uint32_t *__restrict__ decoded)
 {
     Stats st = {};
     st.on = STATS;
@@ -299,6 +300,7 @@ k_lz4_dec_ring(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     const uint8_t *base = src_base + uni64(src_off[blk]);
     const uint32_t csize = uni(src_size[blk]);
     if (only_heavy != 0u && !lz4_literal_heavy(csize, B)) return; /* the indexed decoder has this block (kernels.h) */
+    if (decoded != nullptr && uni(decoded[blk]) != 0u) return;        /* by the few-blocks path (lz4_lat.hip) */
 
     Wave<R> w;
     const WaveLds<R> L = {s_ring[wid], s_in[wid], s_d1[wid], s_d2[wid], s_d4[wid],
@@ -604,7 +606,7 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
         (void)hipMemsetAsync(d_st, 0, sizeof h_st, s);
         (void)hipMemcpyAsync(d_st + 7, &abl, sizeof abl, hipMemcpyHostToDevice, s);
         hipLaunchKernelGGL((k_lz4_dec_ring<4096, true>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
-                           block_size, n_blocks, d_status, d_st, 0u);
+                           block_size, n_blocks, d_status, d_st, 0u, nullptr);
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
         (void)hipFree(d_st);
@@ -624,12 +626,12 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
 
 hipError_t launch_lz4_dec_ring(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
                                uint8_t *d_dst, uint64_t dst_stride, uint32_t block_size, uint64_t n_blocks, int32_t *d_status,
-                               bool only_literal_heavy)
+                               bool only_literal_heavy, const uint32_t *d_done)
 {
     const uint64_t grid = (n_blocks + 3) / 4;
     if (grid > 0x7fffffffull) return hipErrorInvalidValue;
     hipLaunchKernelGGL((k_lz4_dec_ring<4096, false>), dim3((uint32_t)grid), dim3(256), 0, s, d_src, d_src_off, d_src_size, d_dst,
-                       dst_stride, block_size, n_blocks, d_status, nullptr, only_literal_heavy ? 1u : 0u);
+                       dst_stride, block_size, n_blocks, d_status, nullptr, only_literal_heavy ? 1u : 0u, d_done);
     return hipGetLastError();
 }
 

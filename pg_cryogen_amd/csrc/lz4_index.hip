@@ -69,35 +69,64 @@ __device__ inline uint32_t from_next(uint32_t v) { return (uint32_t)__builtin_am
 __device__ inline uint32_t from_prev(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
 
 /* The token after the one at virtual position p, read straight from memory (the extension walk: a handful of hops per
- * walker).  Returns a position >= vend when the token at p is the stream's last sequence (or the stream is cut). */
-__device__ inline uint32_t lz4_next_token_direct(const uint8_t *sb, const uint32_t vend, const uint32_t p)
+ * walker; every hop of k_lz4_index_few).  x = the four bytes at p (up to 3 bytes beyond the stream: inside the slack every
+ * source buffer has), loaded by the caller so that it can put its own stores BEHIND the load: vmcnt counts in order, and a
+ * store issued in front of the load is waited for with it -- a trip to memory more on every hop.  Returns a position >= vend
+ * when the token at p is the stream's last sequence (or the stream is cut).  255-runs are skipped eight bytes per load (the
+ * zero gap of a cryo block is one match of ~100 KB ... 1 MB: 400 ... 4 000 extension bytes). */
+__device__ inline uint32_t lz4_skip_255(const uint8_t *sb, const uint32_t vend, uint32_t q, uint32_t *sum)
 {
-    uint32_t x;
-    __builtin_memcpy(&x, sb + p, 4); /* up to 3 bytes beyond the stream: inside the slack every source buffer has */
+    /* q: first extension byte not looked at yet, known to follow a 255; returns the position behind the terminating byte
+     * (0xffffffff: the stream ends first), adds the bytes' values to *sum */
+    for (;;) {
+        if (q >= vend) return 0xffffffffu;
+        if (q + 8u <= vend) {
+            unsigned long long v;
+            __builtin_memcpy(&v, sb + q, 8);
+            const unsigned long long nv = ~v;
+            const uint32_t n = nv ? (uint32_t)__builtin_ctzll(nv) >> 3 : 8u; /* leading 0xFF bytes */
+            if (sum) *sum += 255u * n;
+            if (n < 8u) {
+                if (sum) *sum += (uint32_t)(v >> (8u * n)) & 255u;
+                return q + n + 1u;
+            }
+            q += 8u;
+            if (sum && *sum >= 0x40000000u) return 0xffffffffu;
+        } else {
+            const uint32_t b = sb[q++];
+            if (sum) *sum += b;
+            if (b != 255u) return q;
+        }
+    }
+}
+__device__ inline uint32_t lz4_next_token_word(const uint8_t *sb, const uint32_t vend, const uint32_t p, const uint32_t x)
+{
     const uint32_t t = x & 255u;
     uint32_t ll = t >> 4, q = p + 1u;
     if (ll == 15u) {
-        uint32_t b = (x >> 8) & 255u;
+        const uint32_t b = (x >> 8) & 255u;
         ll += b;
         q++;
-        while (b == 255u) {
-            if (q >= vend) return 0xffffffffu;
-            b = sb[q++];
-            ll += b;
-            if (ll >= vend) return 0xffffffffu;
+        if (b == 255u) {
+            q = lz4_skip_255(sb, vend, q, &ll);
+            if (q == 0xffffffffu || ll >= vend) return 0xffffffffu;
         }
     }
     q += ll;
     if (q + 2u > vend) return 0xffffffffu; /* literals only: the last sequence */
     q += 2u;
     if ((t & 15u) == 15u) {
-        uint32_t b;
-        do {
-            if (q >= vend) return 0xffffffffu;
-            b = sb[q++];
-        } while (b == 255u);
+        if (q >= vend) return 0xffffffffu;
+        const uint32_t b = sb[q++];
+        if (b == 255u) q = lz4_skip_255(sb, vend, q, nullptr);
     }
     return q;
+}
+__device__ inline uint32_t lz4_next_token_direct(const uint8_t *sb, const uint32_t vend, const uint32_t p)
+{
+    uint32_t x;
+    __builtin_memcpy(&x, sb + p, 4);
+    return lz4_next_token_word(sb, vend, p, x);
 }
 
 __global__ void __launch_bounds__(64)
@@ -485,6 +514,119 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
 #endif
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * Few blocks per call (round 5): up to 1 024 walkers per block, reading the stream straight from memory.
+ *
+ * k_lz4_index above is built for full batches: 65 536 streams come from HBM, so every walker stages its stream through an
+ * LDS ring, and the rings cap a block at 64 walkers (one wave; LDS: 39 KB per wave).  For the call shapes of the unmodified
+ * reference -- ONE block per call, 16 cache slots (pg_cryogen.c:726, cache.c:17,178) -- that is the wrong machine: the chip is
+ * empty, a block's stream sits in the caches after its first touch, and the walk of 64 walkers x 16 KiB is the call (0.30 of
+ * the 0.41 ms of one 1 MiB block, profiles/r03_lz4_few_blocks.txt).  Here a lane walks a segment of 1-2 KiB with direct
+ * loads (a hop = a trip to the L2), records go straight to its row; a block's walkers are S / 64 independent waves spread
+ * over the CUs (as ONE workgroup of 1 024 lanes they shared a CU's address path and instruction issue: 0.16 ms per 1 MiB block
+ * against 0.27 with the rings; profiles/r05_lz4_few_blocks.txt), and what k_lz4_index exchanges between neighbouring lanes
+ * with DPP shifts goes through memory and a kernel boundary:
+ *   k_lz4_few_walk  every walker its own segment from a guessed start; its record count and the position it ends on -> kk, ee
+ *   k_lz4_few_join  walker s takes the walk of its LEFT neighbour from where that one ended into its own segment until it
+ *                   stands on one of its own records: the positions on the way are segment s's extension, the records in
+ *                   front of the meeting point are skipped -- the same two pieces per segment, the same descriptors as
+ *                   k_lz4_index writes (lz4_lat.hip reads them).
+ * A boundary whose chains do not meet, or a segment with more tokens than its row holds, marks the block (failed[blk]): the
+ * caller's other decoder takes it.
+ * --------------------------------------------------------------------------------------------- */
+struct FewGeom {
+    uint32_t cs, seff, seglen;
+    bool indexed;
+};
+__device__ inline FewGeom few_geom(const uint32_t cs, const uint32_t logS, const uint32_t block_size)
+{
+    FewGeom g;
+    g.cs = cs;
+    const uint32_t kib = cs >> 10; /* segments exactly as k_lz4_index cuts them: at least 1 KiB each */
+    const uint32_t lg = kib ? 31u - (uint32_t)__builtin_clz(kib) : 0u;
+    const uint32_t ls_ = lg < logS ? lg : logS;
+    g.seff = 1u << ls_;
+    g.seglen = (cs + g.seff - 1u) >> ls_;
+    g.indexed = cs != 0u && !lz4_literal_heavy(cs, block_size);
+    return g;
+}
+
+__global__ void __launch_bounds__(64)
+k_lz4_few_walk(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off, const uint32_t *__restrict__ src_size,
+               uint16_t *__restrict__ tbl, const uint32_t logS, const uint32_t cap_main, const uint32_t ext, const uint32_t cap,
+               uint32_t *__restrict__ kk, uint32_t *__restrict__ ee, uint32_t *__restrict__ failed, const uint32_t block_size)
+{
+    const uint64_t blk = blockIdx.y;
+    const uint32_t sw = blockIdx.x * 64u + threadIdx.x, cap_s = cap_main + ext;
+    const FewGeom g = few_geom(src_size[blk], logS, block_size);
+    const uint8_t *sb = src_base + src_off[blk];
+    if (sw == 0u) failed[blk] = 0u;
+    const bool walker = g.indexed && sw < g.seff;
+    const uint32_t gstart = sw * g.seglen;
+    const uint32_t stop = (walker && sw + 1u < g.seff) ? (sw + 1u) * g.seglen : g.cs;
+    uint16_t *row = tbl + blk * cap + sw * cap_s + ext;
+    uint32_t p = gstart, k = 0;
+    if (walker) {
+        /* every line of the segment is asked for at once (the walk would take the misses one after the other) */
+        uint32_t warm = 0;
+        for (uint32_t o = gstart & ~127u; o < stop; o += 128u) warm += sb[o < g.cs ? o : 0u];
+        asm volatile("" ::"v"(warm));
+        while (p < stop) {
+            if (k >= cap_main) { p = 0xfffffffeu; break; } /* more tokens than the row holds: the join sees a walker that did not end on a token */
+            uint32_t x;
+            __builtin_memcpy(&x, sb + p, 4);         /* the hop's load first, the record's store behind it (lz4_next_token_word) */
+            asm volatile("" ::: "memory");
+            row[k++] = (uint16_t)p;
+            p = lz4_next_token_word(sb, g.cs, p, x); /* >= cs behind the stream's last sequence */
+        }
+    }
+    kk[(blk << logS) + sw] = walker ? k : 0u;
+    ee[(blk << logS) + sw] = p;
+}
+
+__global__ void __launch_bounds__(64)
+k_lz4_few_join(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off, const uint32_t *__restrict__ src_size,
+               uint16_t *__restrict__ tbl, const uint32_t logS, const uint32_t cap_main, const uint32_t ext, const uint32_t cap,
+               const uint32_t *__restrict__ kk, const uint32_t *__restrict__ ee, uint32_t *__restrict__ failed,
+               uint2 *__restrict__ seg, const uint32_t block_size)
+{
+    const uint64_t blk = blockIdx.y;
+    const uint32_t sw = blockIdx.x * 64u + threadIdx.x, cap_s = cap_main + ext;
+    const FewGeom g = few_geom(src_size[blk], logS, block_size);
+    const uint8_t *sb = src_base + src_off[blk];
+    const bool walker = g.indexed && sw < g.seff;
+    const uint32_t k = kk[(blk << logS) + sw], e = ee[(blk << logS) + sw];
+    const uint32_t gstart = sw * g.seglen;
+    const uint32_t stop = (walker && sw + 1u < g.seff) ? (sw + 1u) * g.seglen : g.cs;
+    /* this walker's own walk must have ended on a token behind its segment (an inner one) or behind the stream (the last) */
+    bool fail = walker && (e == 0xfffffffeu || (sw + 1u < g.seff && !(e >= stop && e < g.cs)));
+    uint32_t L = 0, j = 0;
+    if (walker && sw != 0u && !fail) {
+        const uint16_t *rec = tbl + blk * cap + sw * cap_s + ext; /* this walker's records: the first one is its guessed start */
+        uint16_t *my_ext = tbl + blk * cap + sw * cap_s;          /* ... and the extension in front of them                 */
+        uint32_t pp = ee[(blk << logS) + sw - 1u], r = gstart;    /* the left neighbour's chain; record j of this walker    */
+        if (!(pp >= gstart && pp < g.cs)) fail = true;            /* the left neighbour did not end on a token in here (it reports that itself too) */
+        while (!fail) {
+            if (pp == r) break;
+            if (pp < r) {
+                if (L >= ext || pp >= stop || pp >= g.cs) { fail = true; break; }
+                uint32_t x;
+                __builtin_memcpy(&x, sb + pp, 4);
+                asm volatile("" ::: "memory");
+                my_ext[L++] = (uint16_t)pp;
+                pp = lz4_next_token_word(sb, g.cs, pp, x);
+            } else {
+                if (j >= k) { fail = true; break; }          /* already behind e: the chains did not meet */
+                if (j + 1u < k) { j++; r += ((uint32_t)rec[j] - r) & 0xffffu; } /* records are increasing, less than 64 KiB apart */
+                else { j = k; r = e; }                        /* behind its last record the walker stands on e */
+            }
+        }
+        fail = fail || j > 0xffffu;
+    }
+    if (fail) failed[blk] = 1u;
+    seg[(blk << logS) + sw] = (walker && !fail) ? make_uint2(L | (j << 16), k - j) : make_uint2(0u, 0u);
+}
+
 /* ---- layout and launcher ---- */
 Lz4IndexLayout lz4_index_layout(uint64_t n_blocks, uint32_t block_size, uint32_t walkers)
 {
@@ -508,6 +650,48 @@ Lz4IndexLayout lz4_index_layout(uint64_t n_blocks, uint32_t block_size, uint32_t
     const uint64_t lanes = ((n_blocks << lg) + 63u) & ~(uint64_t)63u;
     L.bytes = L.seg_off + (size_t)lanes * sizeof(uint2) + 256u;
     return L;
+}
+
+/* the few-blocks form: S = up to 1 024 walkers per block (segments of 1-2 KiB); a segment's row holds what 2 KiB of stream can
+ * hold at three bytes per sequence, its extension 128 entries */
+Lz4IndexLayout lz4_index_layout_few(uint64_t n_blocks, uint32_t block_size)
+{
+    Lz4IndexLayout L;
+    uint32_t lg = 6;
+    while (lg < 10u && (block_size >> (lg + 1u)) >= 1024u) lg++; /* no more walkers than KiB of block */
+    L.logS = lg;
+    const uint32_t S = 1u << lg;
+    L.ext = 128u;
+    L.cap_main = 704u; /* >= 2047 / 3 + 1, a multiple of 64 */
+    L.cap = S * (L.cap_main + L.ext);
+    const size_t tbl_bytes = (size_t)n_blocks * L.cap * 2u;
+    L.dummy_off = tbl_bytes;
+    L.seg_off = (tbl_bytes + 64u * 32u + 255u) & ~(size_t)255u;
+    /* behind the descriptors: record counts and end positions of the walkers (k_lz4_few_walk -> k_lz4_few_join), the blocks' flags */
+    L.bytes = L.seg_off + ((size_t)n_blocks << lg) * (sizeof(uint2) + 8u) + n_blocks * 4u + 256u;
+    return L;
+}
+/* where the few-blocks index keeps "this block has no index" (the walkers' chains did not meet): one word per block */
+const uint32_t *lz4_index_few_failed(const void *d_workspace, const Lz4IndexLayout &L, uint64_t n_blocks)
+{
+    return reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(d_workspace) + L.seg_off + ((size_t)n_blocks << L.logS) * (sizeof(uint2) + 8u));
+}
+
+hipError_t launch_lz4_index_few(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
+                                uint64_t n_blocks, uint32_t block_size, void *d_workspace, const Lz4IndexLayout &L)
+{
+    if (n_blocks == 0) return hipSuccess;
+    if (n_blocks > 65535u || L.logS < 6u || L.logS > 10u) return hipErrorInvalidValue;
+    uint8_t *ws = static_cast<uint8_t *>(d_workspace);
+    uint16_t *tbl = reinterpret_cast<uint16_t *>(ws);
+    uint2 *seg = reinterpret_cast<uint2 *>(ws + L.seg_off);
+    uint32_t *kk = reinterpret_cast<uint32_t *>(ws + L.seg_off + ((size_t)n_blocks << L.logS) * sizeof(uint2));
+    uint32_t *ee = kk + ((size_t)n_blocks << L.logS);
+    uint32_t *failed = ee + ((size_t)n_blocks << L.logS);
+    const dim3 grid(1u << (L.logS - 6u), (uint32_t)n_blocks);
+    hipLaunchKernelGGL(k_lz4_few_walk, grid, dim3(64), 0, s, d_src, d_src_off, d_src_size, tbl, L.logS, L.cap_main, L.ext, L.cap, kk, ee, failed, block_size);
+    hipLaunchKernelGGL(k_lz4_few_join, grid, dim3(64), 0, s, d_src, d_src_off, d_src_size, tbl, L.logS, L.cap_main, L.ext, L.cap, kk, ee, failed, seg, block_size);
+    return hipGetLastError();
 }
 
 hipError_t launch_lz4_index(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,

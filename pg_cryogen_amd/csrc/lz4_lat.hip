@@ -31,7 +31,10 @@ namespace cryo {
 
 namespace {
 
-constexpr uint32_t kLatLogS = 6, kLatS = 64;       /* walkers per block of the index pass */
+#ifndef CRYO_LAT_FEW
+#define CRYO_LAT_FEW 1 /* 1: k_lz4_index_few (up to 1 024 walkers per block, direct loads; round 5), 0: k_lz4_index with 64 */
+#endif
+constexpr uint32_t kLatMaxS = 1024;                   /* walkers per block of the index pass, at most */
 constexpr uint32_t kMFLimit = 12, kLastLiterals = 5; /* LZ4_decompress_safe's end-of-block rules (lz4.c) */
 
 struct LatArgs {
@@ -45,10 +48,11 @@ struct LatArgs {
     /* the index (lz4_index.hip) */
     const uint16_t *tbl;
     const uint2 *seg;
-    uint32_t tbl_cap, cap_s, ext;
+    uint32_t tbl_cap, cap_s, ext, logS; /* S = 1 << logS walkers (descriptors) per block */
+    const uint32_t *ixfailed;           /* k_lz4_few_join: 1 = the block has no index (nullptr: k_lz4_index repairs its own) */
     /* per block */
     uint32_t nmax;      /* sequence slots per block */
-    uint32_t *segbase;  /* [n_blocks][64]: first sequence of segment s */
+    uint32_t *segbase;  /* [n_blocks][S]: first sequence of segment s */
     uint32_t *nseq;     /* [n_blocks] */
     uint32_t *ok;       /* [n_blocks] 1: this path decodes the block */
     uint32_t *done;     /* [n_blocks] 1: decoded here (the batch decoder skips it) */
@@ -60,32 +64,40 @@ struct LatArgs {
 };
 
 /* segments of a block exactly as k_lz4_index cuts them (lz4_index.hip) */
-__device__ inline void lat_segments(uint32_t cs, uint32_t &seff, uint32_t &seglen)
+__device__ inline void lat_segments(uint32_t cs, uint32_t logS, uint32_t &seff, uint32_t &seglen)
 {
     const uint32_t kib = cs >> 10;
     const uint32_t lg = kib ? 31u - (uint32_t)__builtin_clz(kib) : 0u;
-    const uint32_t ls_ = lg < kLatLogS ? lg : kLatLogS;
+    const uint32_t ls_ = lg < logS ? lg : logS;
     seff = 1u << ls_;
     seglen = (cs + seff - 1u) >> ls_;
 }
 
-/* sequences per segment -> first sequence of every segment, sequences of the block */
-__global__ void __launch_bounds__(64) k_lat_segs(LatArgs A)
+/* sequences per segment -> first sequence of every segment, sequences of the block; a workgroup of S lanes per block */
+__global__ void __launch_bounds__(1024) k_lat_segs(LatArgs A)
 {
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t blk = blockIdx.x;
-    const uint2 d = A.seg[((uint64_t)blk << kLatLogS) + lane];
+    __shared__ uint32_t s_w[17];
+    __shared__ uint32_t s_later;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const uint32_t blk = blockIdx.x, S = 1u << A.logS;
+    if (threadIdx.x == 0u) s_later = 0u;
+    __syncthreads();
+    const uint2 d = A.seg[((uint64_t)blk << A.logS) + threadIdx.x];
     const uint32_t c = (d.x & 0xffffu) + d.y;
     const uint32_t incl = scan64_incl(c);
-    A.segbase[blk * 64u + lane] = incl - c;
-    const uint32_t total = lane_get(incl, 63);
+    if (lane == 63u) s_w[wv] = incl;
+    if (threadIdx.x != 0u && c != 0u) s_later = 1u;
+    __syncthreads();
+    uint32_t before = 0, total = 0;
+    for (uint32_t k = 0; k < nw; k++) { before += k < wv ? s_w[k] : 0u; total += s_w[k]; }
+    A.segbase[blk * S + threadIdx.x] = before + incl - c;
     uint32_t seff, seglen;
-    lat_segments(uni(A.src_size[blk]), seff, seglen);
+    lat_segments(A.src_size[blk], A.logS, seff, seglen);
     /* the walkers' chains did not all meet (the block's first lane walked all of it: positions more than 64 KiB from
      * the segment's start cannot be told from the 16-bit entries), or the block was left out of the index */
-    const unsigned long long later = wave_ballot(lane != 0u && c != 0u);
-    const bool plain = total != 0u && total <= A.nmax && (seff == 1u || later != 0ull) && seglen < 0xF000u;
-    if (lane == 0u) {
+    const bool plain = total != 0u && total <= A.nmax && (seff == 1u || s_later != 0u) && seglen < 0xF000u &&
+                       (A.ixfailed == nullptr || A.ixfailed[blk] == 0u);
+    if (threadIdx.x == 0u) {
         A.nseq[blk] = total;
         A.ok[blk] = plain ? 1u : 0u;
         A.done[blk] = 0u;
@@ -95,15 +107,15 @@ __global__ void __launch_bounds__(64) k_lat_segs(LatArgs A)
 /* a thread per sequence: the token */
 __global__ void __launch_bounds__(256) k_lat_parse(LatArgs A)
 {
-    __shared__ uint32_t s_base[65];
+    __shared__ uint32_t s_base[kLatMaxS + 1u];
     __shared__ uint32_t s_sum[4];
     __shared__ uint32_t s_ok;
     const uint32_t blk = blockIdx.y;
     const uint32_t n = A.nseq[blk];
     if (blockIdx.x * 256u >= n) return;
-    if (threadIdx.x < 64u) s_base[threadIdx.x] = A.segbase[blk * 64u + threadIdx.x];
-    if (threadIdx.x == 64u) s_base[64] = n;
-    if (threadIdx.x == 65u) s_ok = A.ok[blk];
+    const uint32_t S = 1u << A.logS;
+    for (uint32_t t = threadIdx.x; t < S; t += 256u) s_base[t] = A.segbase[blk * S + t];
+    if (threadIdx.x == 0u) { s_base[S] = n; s_ok = A.ok[blk]; }
     __syncthreads();
     if (s_ok == 0u) return;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -111,16 +123,15 @@ __global__ void __launch_bounds__(256) k_lat_parse(LatArgs A)
     uint32_t len = 0;
     if (on) {
         uint32_t s = 0; /* the last segment that starts at or before i */
-#pragma unroll
-        for (uint32_t st = 32u; st >= 1u; st >>= 1) s += s_base[s + st] <= i ? st : 0u;
+        for (uint32_t st = S >> 1; st >= 1u; st >>= 1) s += s_base[s + st] <= i ? st : 0u;
         const uint32_t t = i - s_base[s];
-        const uint2 d = A.seg[((uint64_t)blk << kLatLogS) + s];
+        const uint2 d = A.seg[((uint64_t)blk << A.logS) + s];
         const uint32_t ne = d.x & 0xffffu;
         const uint16_t *row = A.tbl + (uint64_t)blk * A.tbl_cap + s * A.cap_s;
         const uint32_t e16 = t < ne ? row[t] : row[A.ext + (d.x >> 16) + (t - ne)];
         const uint32_t cs = A.src_size[blk];
         uint32_t seff, seglen;
-        lat_segments(cs, seff, seglen);
+        lat_segments(cs, A.logS, seff, seglen);
         const uint32_t g = s * seglen; /* every entry of segment s lies at or behind it, less than 64 KiB away */
         const uint32_t p = g + ((e16 - g) & 0xffffu);
         const uint8_t *sb = A.src_base + A.src_off[blk];
@@ -287,7 +298,10 @@ __global__ void __launch_bounds__(256) k_lat_fill(LatArgs A)
         *reinterpret_cast<uint4 *>(srcb + b0 + 4u * k) = make_uint4(sx[4 * k], sx[4 * k + 1], sx[4 * k + 2], sx[4 * k + 3]);
 }
 
-/* one round of pointer jumping over every byte of every block this path decodes */
+/* one round of pointer jumping over every byte of every block this path decodes: THREE hops per round (round 5).  A source
+ * only ever moves towards the literal byte it ends at, so a value another thread has already shortened is as good as the old
+ * one -- the hops need no synchronisation between them, and a chain of depth d is at most ceil(d / 4) deep after a round:
+ * half the launches of one hop per round (a launch costs ~4 us whatever it does, and a call is ~30 of them). */
 __global__ void __launch_bounds__(256) k_lat_jump(LatArgs A, uint32_t round)
 {
     const uint32_t blk = blockIdx.y;
@@ -299,9 +313,17 @@ __global__ void __launch_bounds__(256) k_lat_jump(LatArgs A, uint32_t round)
     uint4 s4 = *reinterpret_cast<const uint4 *>(srcb + b0);
     uint32_t s[4] = {s4.x, s4.y, s4.z, s4.w};
     uint32_t t[4];
-    bool ch = false;
 #pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) t[k] = s[k] != b0 + k ? srcb[s[k]] : s[k];
+    for (uint32_t k = 0; k < 4u; k++) t[k] = s[k];
+#pragma unroll
+    for (uint32_t hop = 0; hop < 3u; hop++) {
+        uint32_t u[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) u[k] = t[k] != b0 + k ? srcb[t[k]] : t[k]; /* a byte that points at itself is a literal */
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; k++) t[k] = u[k];
+    }
+    bool ch = false;
 #pragma unroll
     for (uint32_t k = 0; k < 4u; k++) ch = ch || t[k] != s[k];
     if (ch) *reinterpret_cast<uint4 *>(srcb + b0) = make_uint4(t[0], t[1], t[2], t[3]);
@@ -346,13 +368,21 @@ inline size_t al256(size_t v) { return (v + 255u) & ~(size_t)255u; }
 LatLayout lat_layout(uint64_t n, uint32_t B)
 {
     LatLayout y;
-    y.ix = lz4_index_layout(n, B, kLatS);
-    y.nmax = (kLatS * (y.ix.cap_main + y.ix.ext) + 255u) & ~255u;
+#if CRYO_LAT_FEW
+    y.ix = lz4_index_layout_few(n, B);
+    {   /* sequence slots per block: what the rows hold, and no more than a block of B bytes can have (three bytes a sequence) */
+        const uint64_t rows = ((uint64_t)y.ix.cap_main + y.ix.ext) << y.ix.logS, most = (uint64_t)B / 3u + 256u;
+        y.nmax = (uint32_t)(((rows < most ? rows : most) + 255u) & ~(uint64_t)255u);
+    }
+#else
+    y.ix = lz4_index_layout(n, B, 64u);
+    y.nmax = (64u * (y.ix.cap_main + y.ix.ext) + 255u) & ~255u;
+#endif
     y.bpad = (B + 4095u) & ~4095u;
     y.rounds = 2;
-    while ((1u << (y.rounds - 1u)) < B) y.rounds++; /* a chain is at most B hops long */
+    while ((1ull << (2u * (y.rounds - 1u))) < B) y.rounds++; /* a chain is at most B hops long and shrinks four times per round (k_lat_jump) */
     size_t o = al256(y.ix.bytes);
-    y.o_segbase = o; o = al256(o + n * 64u * 4u);
+    y.o_segbase = o; o = al256(o + ((size_t)n << y.ix.logS) * 4u);
     y.o_nseq = o; o = al256(o + n * 4u);
     y.o_ok = o; o = al256(o + n * 4u);
     y.o_done = o; o = al256(o + n * 4u);
@@ -395,13 +425,22 @@ hipError_t launch_lz4_decompress_latency(hipStream_t s, const uint8_t *d_src, co
     const LatLayout y = lat_layout(n_blocks, block_size);
     if (workspace_bytes < y.bytes) return hipErrorInvalidValue;
     uint8_t *ws = static_cast<uint8_t *>(d_workspace);
+#if CRYO_LAT_FEW
+    if (hipError_t e = launch_lz4_index_few(s, d_src, d_src_off, d_src_size, n_blocks, block_size, d_workspace, y.ix); e != hipSuccess) return e;
+#else
     if (hipError_t e = launch_lz4_index(s, d_src, d_src_off, d_src_size, n_blocks, block_size, d_workspace, y.ix); e != hipSuccess) return e;
+#endif
     LatArgs A;
     A.src_base = d_src; A.src_off = d_src_off; A.src_size = d_src_size;
     A.dst_base = d_dst; A.dst_stride = dst_stride; A.B = block_size; A.n_blocks = (uint32_t)n_blocks; A.status = d_status;
     A.tbl = reinterpret_cast<const uint16_t *>(ws);
     A.seg = reinterpret_cast<const uint2 *>(ws + y.ix.seg_off);
-    A.tbl_cap = y.ix.cap; A.cap_s = y.ix.cap_main + y.ix.ext; A.ext = y.ix.ext;
+    A.tbl_cap = y.ix.cap; A.cap_s = y.ix.cap_main + y.ix.ext; A.ext = y.ix.ext; A.logS = y.ix.logS;
+#if CRYO_LAT_FEW
+    A.ixfailed = lz4_index_few_failed(d_workspace, y.ix, n_blocks);
+#else
+    A.ixfailed = nullptr;
+#endif
     A.nmax = y.nmax;
     A.segbase = reinterpret_cast<uint32_t *>(ws + y.o_segbase);
     A.nseq = reinterpret_cast<uint32_t *>(ws + y.o_nseq);
@@ -420,7 +459,7 @@ hipError_t launch_lz4_decompress_latency(hipStream_t s, const uint8_t *d_src, co
     A.bpad = y.bpad;
     if (hipError_t e = hipMemsetAsync(A.changed, 0, (y.rounds + 1u) * 4u, s); e != hipSuccess) return e;
     const uint32_t nb = (uint32_t)n_blocks;
-    hipLaunchKernelGGL(k_lat_segs, dim3(nb), dim3(64), 0, s, A);
+    hipLaunchKernelGGL(k_lat_segs, dim3(nb), dim3(1u << y.ix.logS), 0, s, A);
     hipLaunchKernelGGL(k_lat_parse, dim3(y.nmax / 256u, nb), dim3(256), 0, s, A);
     hipLaunchKernelGGL(k_lat_scan, dim3(nb), dim3(64), 0, s, A);
     hipLaunchKernelGGL(k_lat_place, dim3(y.nmax / 256u, nb), dim3(256), 0, s, A);
@@ -428,10 +467,16 @@ hipError_t launch_lz4_decompress_latency(hipStream_t s, const uint8_t *d_src, co
     for (uint32_t r = 0; r < y.rounds; r++)
         hipLaunchKernelGGL(k_lat_jump, dim3((block_size + 1023u) / 1024u, nb), dim3(256), 0, s, A, r);
     hipLaunchKernelGGL(k_lat_gather, dim3((block_size + 4095u) / 4096u, nb), dim3(256), 0, s, A);
+#if CRYO_LAT_FEW
+    /* what was left (a failed check, offset 0, an index the walkers could not complete, blocks of almost only literals): the
+     * decoder that parses in the wave -- it needs no index, and verdicts and bytes are its */
+    return launch_lz4_dec_ring(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, false, A.done);
+#else
     /* what was left: the batch decoder with the same index, the in-wave parser for blocks of almost only literals */
     if (hipError_t e = launch_lz4_dec_seq_rest(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status,
                                                d_workspace, y.ix, A.done); e != hipSuccess) return e;
     return launch_lz4_dec_ring(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, true);
+#endif
 }
 
 } // namespace cryo

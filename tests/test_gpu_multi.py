@@ -31,6 +31,23 @@ def test_bench_two_ranks_share_one_gpu():
     assert c["unit"] == "GB/s" and c["value"] > 0 and c["cores"] == 1 and c["kind"] in ("reference", "port") and c["sample"]
 
 
+def test_bench_two_ranks_full_per_gpu_share():
+    """BASELINE configs[3] at its real per-GPU share: two ranks of 131 072 blocks (16 GiB of output each) sharing this GPU --
+    block i of the job on rank i mod 2, every decoded block compared on the device, rank 0 prints roofline and cpu_baseline
+    (VERDICT r04 weak #1b: the 8-GPU configs had only run at 1 024 blocks per rank)."""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--cpu-blocks", "128"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["config"]["blocks_per_gpu"] == 131072 and j["config"]["total_blocks"] == 262144
+    assert "decode == original on all 131072 blocks" in j["config"]["bit_exact"]
+    assert j["roofline"]["traffic"] is not None, "the 131 072-block shape has a committed counter pass (profiles/r05n_*)"
+    assert j["cpu_baseline"]["value"] > 0
+
+
 def test_two_handles_one_process(oracle):
     """two codec handles in one process (the product dispatcher opens one per device): interleaved calls, each with
     its own stream, workspace and staging buffers"""
