@@ -80,6 +80,16 @@ __device__ inline uint32_t lz4_skip_255(const uint8_t *sb, const uint32_t vend, 
      * (0xffffffff: the stream ends first), adds the bytes' values to *sum */
     for (;;) {
         if (q >= vend) return 0xffffffffu;
+        if (q + 64u <= vend) { /* a long run: 64 bytes per trip while they are all 255 */
+            uint4 a, b, c, d;
+            __builtin_memcpy(&a, sb + q, 16); __builtin_memcpy(&b, sb + q + 16u, 16);
+            __builtin_memcpy(&c, sb + q + 32u, 16); __builtin_memcpy(&d, sb + q + 48u, 16);
+            if ((a.x & a.y & a.z & a.w & b.x & b.y & b.z & b.w & c.x & c.y & c.z & c.w & d.x & d.y & d.z & d.w) == 0xffffffffu) {
+                if (sum) { *sum += 255u * 64u; if (*sum >= 0x40000000u) return 0xffffffffu; }
+                q += 64u;
+                continue;
+            }
+        }
         if (q + 8u <= vend) {
             unsigned long long v;
             __builtin_memcpy(&v, sb + q, 8);
