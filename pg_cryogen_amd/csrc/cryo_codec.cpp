@@ -450,6 +450,9 @@ void cryo_codec_close(cryo_codec *c)
         if (c->aux.seqs_done[l]) (void)hipEventDestroy(c->aux.seqs_done[l]);
     }
     if (c->aux.fork) (void)hipEventDestroy(c->aux.fork);
+    if (c->lz4_opts.side) { (void)hipStreamSynchronize(c->lz4_opts.side); (void)hipStreamDestroy(c->lz4_opts.side); }
+    if (c->lz4_opts.fork) (void)hipEventDestroy(c->lz4_opts.fork);
+    if (c->lz4_opts.join) (void)hipEventDestroy(c->lz4_opts.join);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -664,6 +667,13 @@ int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
         if (need != 0) {
             int rc = ensure_ws(c, need);
             if (rc != CRYO_OK) return rc;
+        }
+        if (!c->lz4_opts.side) { /* the side stream of the decoder's last round (lz4_dec2.hip): lowest priority, made once */
+            int least = 0, greatest = 0;
+            (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+            HIP_TRY(c, hipStreamCreateWithPriority(&c->lz4_opts.side, hipStreamNonBlocking, least));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->lz4_opts.fork, hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->lz4_opts.join, hipEventDisableTiming));
         }
         HIP_TRY(c, cryo::launch_lz4_decompress(c->stream, (const uint8_t *)d_src, d_src_off, d_src_size,
                                                (uint8_t *)d_dst, dst_stride, block_size, n_blocks,

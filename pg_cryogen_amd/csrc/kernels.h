@@ -55,6 +55,10 @@ struct Lz4DecodeOpts {
     int path = 0;    /* 1: in-wave parse kernel, 2: sequence index + indexed decoder, 3: few blocks, every output byte in parallel (lz4_lat.hip) */
     int walkers = 0; /* walkers per block of the index pass (power of two, 1..64) */
     int waves = 0;   /* waves per block of the indexed decoder: 1 = k_lz4_dec_seq, 2 = k_lz4_dec_dual, 0 = by the batch size */
+    /* a low-priority side stream with its events (created by the handle, may be null): the last, partial round of a batch
+     * that fills the chip once or a few times is decoded there with two waves per block (lz4_dec2.hip, launch_dec_seq) */
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
 };
 hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                  const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
@@ -95,7 +99,7 @@ hipError_t launch_lz4_dec_ring(hipStream_t s, const uint8_t *d_src, const uint64
 hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                          const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                          uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
-                                         size_t workspace_bytes, uint32_t walkers, int waves = 0);
+                                         size_t workspace_bytes, uint32_t walkers, int waves = 0, const Lz4DecodeOpts *opts = nullptr);
 
 /* lz4_lat.hip: few blocks per call (the reference's own call shapes) */
 bool lz4_latency_eligible(uint64_t n_blocks, uint32_t block_size);

@@ -594,7 +594,7 @@ hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint
     if (S != 0) {
         if (d_workspace == nullptr) return hipErrorInvalidValue;
         return launch_lz4_decompress_indexed(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks,
-                                             d_status, d_workspace, workspace_bytes, S, opts.waves);
+                                             d_status, d_workspace, workspace_bytes, S, opts.waves, &opts);
     }
 #ifdef CRYO_DEBUG
     static const bool want_stats = cryo_tuning_env("CRYO_LZ4_STATS") != nullptr; /* debugging aid */

@@ -343,7 +343,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
               const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
               uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats,
               const uint16_t *__restrict__ tbl, uint32_t tbl_cap, const uint2 *__restrict__ seg, const uint32_t logS,
-              const uint32_t cap_s, const uint32_t ext, const uint32_t skip_heavy, const uint32_t *__restrict__ decoded)
+              const uint32_t cap_s, const uint32_t ext, const uint32_t skip_heavy, const uint32_t *__restrict__ decoded, const uint64_t blk0)
 {
     Stats st = {};
     st.on = STATS;
@@ -355,7 +355,7 @@ k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wid = uni(threadIdx.x >> 6);
-    const uint64_t blk = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid;
+    const uint64_t blk = blk0 + (uint64_t)blockIdx.x * (blockDim.x >> 6) + wid; /* blocks blk0 .. n_blocks - 1 are this launch's */
     if (blk >= n_blocks) return;
 
     const uint8_t *base = src_base + uni64(src_off[blk]);
@@ -585,13 +585,13 @@ k_lz4_dec_dual(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
                const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
                uint64_t n_blocks, int32_t *__restrict__ status, const uint16_t *__restrict__ tbl, uint32_t tbl_cap,
                const uint2 *__restrict__ seg, const uint32_t logS, const uint32_t cap_s, const uint32_t ext,
-               const uint32_t skip_heavy, const uint32_t *__restrict__ decoded)
+               const uint32_t skip_heavy, const uint32_t *__restrict__ decoded, const uint64_t blk0)
 {
     constexpr uint32_t R = kDualR;
     __shared__ __attribute__((aligned(16))) DualLds D;
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t role = uni(threadIdx.x >> 6); /* 0: wave A, 1: wave B */
-    const uint64_t blk = blockIdx.x;
+    const uint64_t blk = blk0 + blockIdx.x;
     if (blk >= n_blocks) return;
     const uint8_t *base = src_base + uni64(src_off[blk]);
     const uint32_t csize = uni(src_size[blk]);
@@ -733,26 +733,57 @@ k_lz4_dec_dual(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
 }
 
 /* ---- launcher ---- */
+/* blocks one round of k_lz4_dec_seq holds: 24 waves per CU (LDS, 6 720 bytes per wave) on 256 CUs */
+constexpr uint64_t kSeqResident = 256u * 6u * kDecWpb;
 static void launch_dec_seq(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size, uint8_t *d_dst,
                            uint64_t dst_stride, uint32_t block_size, uint64_t n_blocks, int32_t *d_status, const void *ws,
-                           const Lz4IndexLayout &Lx, const uint32_t *d_done = nullptr, const int waves = 0)
+                           const Lz4IndexLayout &Lx, const uint32_t *d_done = nullptr, const int waves = 0, const Lz4DecodeOpts *opts = nullptr)
 {
     const uint16_t *tbl = static_cast<const uint16_t *>(ws);
     const uint2 *seg = reinterpret_cast<const uint2 *>(static_cast<const uint8_t *>(ws) + Lx.seg_off);
+    const uint32_t heavy = Lx.logS != 0u ? 1u : 0u;
+    auto dual = [&](hipStream_t q, uint64_t first) {
+        hipLaunchKernelGGL(k_lz4_dec_dual, dim3((uint32_t)(n_blocks - first)), dim3(128), 0, q, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size,
+                           n_blocks, d_status, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, heavy, d_done, first);
+    };
 #if CRYO_DEC_DUAL
     if (waves == 2 || (waves == 0 && n_blocks <= kDualMaxBlocks)) { /* a batch that leaves most of the chip idle: two waves per block */
-        hipLaunchKernelGGL(k_lz4_dec_dual, dim3((uint32_t)n_blocks), dim3(128), 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size,
-                           n_blocks, d_status, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, Lx.logS != 0u ? 1u : 0u, d_done);
+        dual(s, 0);
         return;
     }
 #endif
-    const dim3 g((uint32_t)((n_blocks + kDecWpb - 1) / kDecWpb)), b(64 * kDecWpb);
+    /* The last round (round 5).  A block is its wave's chain, so a batch of 1.33 rounds -- 8 192 blocks of 1 MiB, the reference's
+     * block size -- takes two rounds' time: the last 2 048 blocks run on a chip that is two thirds empty at the pace of a full
+     * one.  Those blocks go to a low-priority side stream with two waves each (1.4-1.7 x per block, k_lz4_dec_dual): its
+     * workgroups are placed as the first part's retire.  Measured (profiles/r05_lz4_tail_round.txt): 7 168 x 1 MiB 8.26 -> 7.50 ms,
+     * 8 192 x 1 MiB 8.58 -> 8.13, 7 000 x 128 KiB 1.25 -> 1.16; with more than two rounds, or a last round of more than a third,
+     * it loses 1-6 % (the two-wave workgroups wait for LDS the one-wave ones hold): only between one and two rounds, and for
+     * a last round of at most 2 048 blocks. */
+    uint64_t head = n_blocks;
+#if CRYO_DEC_DUAL
+    if (waves == 0 && opts != nullptr && opts->side != nullptr && n_blocks > kSeqResident && n_blocks <= 2u * kSeqResident) {
+        const uint64_t rest = n_blocks % kSeqResident;
+        if (rest != 0u && rest <= 2048u) head = n_blocks - rest;
+    }
+#endif
+    const dim3 g((uint32_t)((head + kDecWpb - 1) / kDecWpb)), b(64 * kDecWpb);
+    if (head != n_blocks) {
+        (void)hipEventRecord(opts->fork, s); /* behind the index pass */
+        (void)hipStreamWaitEvent(opts->side, opts->fork, 0);
+    }
+    /* (the first part's kernel is told where its blocks end by its grid: a workgroup's four blocks never straddle `head`,
+     * a multiple of the residency) */
     if (Lx.logS != 0u)
-        hipLaunchKernelGGL((k_lz4_dec_seq<kDecR, false, kDecWpb, true>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks,
-                           d_status, nullptr, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, 1u, d_done);
+        hipLaunchKernelGGL((k_lz4_dec_seq<kDecR, false, kDecWpb, true>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, head,
+                           d_status, nullptr, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, 1u, d_done, (uint64_t)0);
     else
-        hipLaunchKernelGGL((k_lz4_dec_seq<kDecR, false, kDecWpb, false>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks,
-                           d_status, nullptr, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, 0u, d_done);
+        hipLaunchKernelGGL((k_lz4_dec_seq<kDecR, false, kDecWpb, false>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, head,
+                           d_status, nullptr, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, 0u, d_done, (uint64_t)0);
+    if (head != n_blocks) {
+        dual(opts->side, head);
+        (void)hipEventRecord(opts->join, opts->side);
+        (void)hipStreamWaitEvent(s, opts->join, 0);
+    }
 }
 
 /* the blocks the few-blocks path did not decode (lz4_lat.hip), with the index it built */
@@ -767,7 +798,7 @@ hipError_t launch_lz4_dec_seq_rest(hipStream_t s, const uint8_t *d_src, const ui
 hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                          const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,
                                          uint32_t block_size, uint64_t n_blocks, int32_t *d_status, void *d_workspace,
-                                         size_t workspace_bytes, uint32_t walkers, int waves)
+                                         size_t workspace_bytes, uint32_t walkers, int waves, const Lz4DecodeOpts *opts)
 {
     if (n_blocks == 0) return hipSuccess;
     const uint64_t grid = (n_blocks + kDecWpb - 1) / kDecWpb;
@@ -787,7 +818,7 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
         (void)hipMemcpyAsync(d_st + 7, &abl, sizeof abl, hipMemcpyHostToDevice, s);
         hipLaunchKernelGGL((k_lz4_dec_seq<kDecR, true, kDecWpb, true>), g, b, 0, s, d_src, d_src_off, d_src_size, d_dst, dst_stride,
                            block_size, n_blocks, d_status, d_st, static_cast<const uint16_t *>(d_workspace), Lx.cap,
-                           reinterpret_cast<const uint2 *>(static_cast<const uint8_t *>(d_workspace) + Lx.seg_off), Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, 0u, nullptr);
+                           reinterpret_cast<const uint2 *>(static_cast<const uint8_t *>(d_workspace) + Lx.seg_off), Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, 0u, nullptr, (uint64_t)0);
         (void)hipMemcpyAsync(h_st, d_st, sizeof h_st, hipMemcpyDeviceToHost, s);
         (void)hipStreamSynchronize(s);
         (void)hipFree(d_st);
@@ -804,7 +835,7 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
     }
 #endif
     (void)g; (void)b;
-    launch_dec_seq(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, d_workspace, Lx, nullptr, waves);
+    launch_dec_seq(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, d_workspace, Lx, nullptr, waves, opts);
     if (Lx.logS != 0u) /* the blocks the index and its decoder left out (almost all literals): the in-wave parser */
         return launch_lz4_dec_ring(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, true);
     return hipGetLastError();
