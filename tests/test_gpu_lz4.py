@@ -628,6 +628,101 @@ def test_few_blocks_path_edge_streams(codec, oracle):
             _decode_check(codec, items[i:i + 1], expect[i:i + 1], B, ("few-edge-one", i))
 
 
+def test_few_blocks_path_many_walkers_corners(codec, oracle):
+    """Round 5: the few-blocks index runs up to 1 024 direct-read walkers per block in two kernels (k_lz4_few_walk /
+    k_lz4_few_join).  Corners of ITS rules at 1 MiB and 2 MiB blocks: compressed sizes around the powers of two that set the
+    number of walkers, a block whose sequences are all three bytes long (more tokens per segment than a row holds: the block
+    must fall back whole), segments that lie inside one long literal run or one long 255-run (chains that cannot meet), and
+    a stream cut in the middle of a segment.  Verdicts and bytes as the oracle's, one block per call and together."""
+    rng = np.random.default_rng(20261004)
+    for B in (1 << 20, 2 << 20):
+        blocks = []
+        # 3-byte sequences: a 4-byte pattern repeated with one byte changed every 7 bytes -> tokens every 3-4 bytes of stream
+        a = np.tile(np.array([1, 2, 3, 4, 5, 6, 7], np.uint8), B // 7 + 1)[:B].copy()
+        a[::11] ^= rng.integers(1, 255, len(a[::11]), dtype=np.uint8)
+        blocks.append(a)
+        # a long literal run in the middle of compressible data, and a long run of one byte (a 255-run of match length)
+        b = oracle.synth(77, 1, B, 0).copy()
+        b[B // 3:B // 3 + 40000] = rng.integers(0, 256, 40000, dtype=np.uint8)
+        blocks.append(b)
+        c = oracle.synth(77, 2, B, 0).copy()
+        c[B // 2:B // 2 + 300000] = 0x5A
+        blocks.append(c)
+        blocks.append(oracle.synth(77, 3, B, 1))                      # narrow rows: 84 % zero gap
+        comps = [oracle.lz4_compress(x, 1) for x in blocks]
+        expect = list(blocks)
+        # compressed sizes right at the walker-count steps: cut a valid stream's INPUT so that it compresses to about 2^k KiB
+        wide78 = oracle.synth(78, 0, B, 0)
+        for target in (1 << 19, (1 << 19) + 1024):
+            lo, hi = 1000, B
+            while hi - lo > 64:                                        # bisection on the number of `wide` bytes kept
+                mid = (lo + hi) // 2
+                x = np.zeros(B, np.uint8)
+                x[:mid] = wide78[:mid]
+                if len(oracle.lz4_compress(x, 1)) < target:
+                    lo = mid
+                else:
+                    hi = mid
+            x = np.zeros(B, np.uint8)
+            x[:lo] = wide78[:lo]
+            comps.append(oracle.lz4_compress(x, 1))
+            expect.append(x)
+        cut = comps[1][:len(comps[1]) // 2 + 123].copy()               # truncated inside a segment
+        r, out = oracle.lz4_decompress(cut, B, fill=0xA5)
+        comps.append(cut)
+        expect.append(out.copy() if r == B else None)
+        assert expect[-1] is None
+        with _few_blocks(codec):
+            _decode_check(codec, comps, expect, B, ("few-corners", B))
+            for i in range(len(comps)):
+                _decode_check(codec, comps[i:i + 1], expect[i:i + 1], B, ("few-corner-one", B, i))
+
+
+def test_indexed_decoder_last_round_on_the_side_stream(codec, oracle):
+    """Round 5: a batch of between one and two rounds of the one-wave decoder (6 144 blocks are resident) sends its last,
+    partial round to a low-priority side stream with two waves per block.  7 000 blocks of 32 KiB made and compressed on the
+    device; streams corrupted in the first part, at the seam and in the last part; every block compared with its original on
+    the device, the corrupted ones' verdicts with the oracle's, 40 sampled blocks byte for byte with the oracle."""
+    from pg_cryogen_amd import bound
+    B, n = 32768, 7000
+    stride = (bound(METHOD_LZ4, B) + 15) & ~15
+    d_raw, d_comp, d_out = codec.alloc(n * B), codec.alloc(n * stride), codec.alloc(n * B)
+    d_sizes, d_off, d_st, d_mis = codec.alloc(4 * n), codec.alloc(8 * n), codec.alloc(4 * n), codec.alloc(8)
+    try:
+        codec.synth_batch(13, 0, n, B, 0, d_raw)
+        codec.compress_batch(METHOD_LZ4, 1, d_raw, B, B, n, d_comp, stride, d_sizes, d_st)
+        assert (d_st.download(dtype=np.int32) == 0).all()
+        sizes = d_sizes.download(dtype=np.uint32)
+        d_off.upload(np.arange(n, dtype=np.uint64) * np.uint64(stride))
+        bad = [5, 3071, 6143, 6144, 6145, 6999]
+        for i in bad:                                                   # an offset beyond the output so far, early in the stream
+            c = d_comp.download(int(sizes[i]), offset=i * stride)
+            c[40:48] = 0xFF
+            r, _ = oracle.lz4_decompress(c, B)
+            assert r != B
+            d_comp.upload(c, offset=i * stride)
+        d_out.memset(0xEE)
+        codec.decompress_batch(METHOD_LZ4, d_comp, d_off, d_sizes, d_out, B, B, n, d_st)
+        codec.sync()
+        st = d_st.download(dtype=np.int32)
+        assert all(st[i] != 0 for i in bad) and int((st != 0).sum()) == len(bad), np.nonzero(st)[0][:20]
+        for i in sorted(set(list(range(0, n, n // 32)) + [6142, 6146, 6998])):
+            if i in bad:
+                continue
+            raw = oracle.synth(13, i, B, 0)
+            comp = d_comp.download(int(sizes[i]), offset=i * stride)
+            r, exp = oracle.lz4_decompress(comp, B)
+            assert r == B and np.array_equal(exp, raw) and np.array_equal(d_out.download(B, offset=i * B), exp), i
+        # everything else against the originals, on the device: the corrupted blocks are the only mismatches
+        d_mis.memset(0)
+        codec.compare_batch(d_raw, B, d_out, B, B, n, d_mis)
+        codec.sync()
+        assert 0 < int(d_mis.download(dtype=np.uint64)[0]) <= len(bad) * B
+    finally:
+        for x in (d_raw, d_comp, d_out, d_sizes, d_off, d_st, d_mis):
+            x.free()
+
+
 def test_lz4_path_options_roundtrip(codec):
     from pg_cryogen_amd import codec as cc
     assert codec.get_option(cc.OPT_LZ4_DECODE_PATH) == 0 and codec.get_option(cc.OPT_LZ4_INDEX_WALKERS) == 0
