@@ -92,6 +92,12 @@ hipError_t launch_lz4_index_few(hipStream_t s, const uint8_t *d_src, const uint6
  * against 378 at 8 192 blocks; the headline data (ratio 1.29, a token every 16 bytes) 920 against 529
  * (profiles/r03_lz4_decode_batch_shapes.txt). */
 __host__ __device__ inline bool lz4_literal_heavy(uint32_t csize, uint32_t block_size) { return csize > block_size - (block_size >> 4); }
+/* A stream of less than 16 KiB gets ONE index walker whatever the batch: it is walked in ~0.3 ms at most, and such streams are
+ * the highly periodic ones (blocks of fixed-width rows: a token every 3-5 bytes, every sequence alike) on which chains started
+ * at guessed positions run beside the true one for ever -- the hand-over fails and the block is walked again by one walker
+ * anyway (8 192 x 1 MiB `int4`: 1.0-1.1 ms of index pass; profiles/r05_index_run255.txt).  Used by k_lz4_index, k_lz4_few_* and
+ * lz4_lat.hip alike: they must cut a block into the same segments. */
+__host__ __device__ inline bool lz4_index_one_walker(uint32_t csize) { return csize < 16384u; }
 hipError_t launch_lz4_dec_ring(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
                                uint8_t *d_dst, uint64_t dst_stride, uint32_t block_size, uint64_t n_blocks, int32_t *d_status,
                                bool only_literal_heavy, const uint32_t *d_done = nullptr /* blocks marked there are skipped */);

@@ -169,7 +169,8 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
         /* segments of at least 1 KiB: a block that compressed to little is walked by fewer lanes */
         const uint32_t kib = cs >> 10;
         const uint32_t lg = kib ? 31u - (uint32_t)__builtin_clz(kib) : 0u;
-        const uint32_t ls_ = lg < logS ? lg : logS;
+        const bool cs_small = lz4_index_one_walker(cs);
+        const uint32_t ls_ = cs_small ? 0u : (lg < logS ? lg : logS);
         seff = 1u << ls_;
         seglen = (cs + seff - 1u) >> ls_;
     }
@@ -181,11 +182,15 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     uint16_t *const rowbase = tbl + blk * cap;
     uint16_t *row = rowbase + sw * cap_s + ext;           /* this walker's own records */
     uint16_t *const dummy = dummy_base + lane * 16u;      /* 32 bytes per lane behind the rows: where lanes with nothing to store store */
-    uint32_t kcap = cap_main;
+    uint32_t kcap = (logS != 0u && seff == 1u) ? S * cap_s - ext : cap_main; /* a block's only walker has the whole row (as the redo of phase 3 has) */
     uint32_t pos = gstart;                /* next byte to interpret */
     uint32_t requested = gstart & ~(kIdxChunk - 1u); /* chunks requested up to here (multiple of kIdxChunk) */
     uint32_t filled = requested;          /* chunks stored in the ring up to here */
-    uint32_t state = 0;                   /* 0 token, 1 literal-length extension, 2 match-length extension */
+    /* 0 token, 1 literal-length extension, 2 match-length extension.  A walker with a guessed start begins in state 2: if the
+     * guess lies inside a run of 255s (the match-length bytes of a cryo block's zero gap: 4 100 of them at 1 MiB, several
+     * segments long) it skips to the byte behind the run's end -- a true token there --; read as a token, a 255 would send
+     * it through a literal length of megabytes and out of the stream.  Anywhere else state 2 just moves the guess by a byte. */
+    uint32_t state = (walker && sw != 0u) ? 2u : 0u;
     uint32_t acc = 0, tm = 0;             /* literal length being accumulated; match nibble of the current token */
     uint32_t k = 0, ls = 0;               /* positions recorded; 16-entry lines of them stored */
     uint16_t *pbuf = s_pos[lane];
@@ -327,6 +332,26 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             done = done | !live | (k >= kcap);
             pos = npos;
             state = nstate;
+            /* a long match-length run (round 5): the zero gap of a cryo block is ONE match of 100 KB ... 1 MB = 400 ... 4 100
+             * extension bytes, four per turn above: 1 025 turns for a 1 MiB block of narrow rows, and the pass over 8 192 such
+             * blocks took 1.0-1.6 ms of a 2.6-3.3 ms call (profiles/r05_stream_rot.txt).  When the four bytes just taken were all
+             * 255, up to seven more dwords of the ring are looked at: 28 bytes per turn, as much as the ring is fed. */
+            {
+                const bool longm = extb & (n == 4u) & !done;
+                if (wave_any(longm)) {
+                    const uint32_t a0 = pos & ~3u; /* the dword that holds the first byte not looked at: what lies before it in there is 255 */
+                    uint32_t m = 0;
+                    bool run = longm;
+#pragma unroll
+                    for (uint32_t kq = 0; kq < 7u; kq++) {
+                        const uint32_t dq = *reinterpret_cast<const uint32_t *>(s_ring + rb + ((a0 + 4u * kq) & (kIdxRing - 4u)));
+                        run = run & (dq == 0xffffffffu) & (a0 + 4u * kq + 4u <= filled);
+                        m += run ? 1u : 0u;
+                    }
+                    const uint32_t far = a0 + 4u * m;
+                    pos = (longm & (far > pos)) ? far : pos;
+                }
+            }
             /* rare: the token forms above, literal-length 255-runs, and jumps over everything requested (a long literal run) */
             const bool slow = rare | (!done & ((state == 1u) | (pos >= requested)));
             if (wave_any(slow)) {
@@ -433,18 +458,47 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
 
     uint32_t d_ext = 0, d_skip = 0, d_cnt = walker ? k : 0u; /* this segment's descriptor */
     if (logS != 0u) {
-        /* ---- phase 2: walker s goes on into segment s+1 until it meets a position walker s+1 recorded ---- */
-        const bool inner = walker && sw + 1u < seff;
-        /* an inner walker that did not end on a token behind its segment (its records overflowed, or the stream is
-         * cut) cannot hand over */
-        bool fail = inner && !(pos >= stop && pos < vend && state == 0u && k < kcap);
-        __threadfence(); /* the neighbour's records are read back from memory */
-        const uint32_t k_n = from_next(k), e_n = from_next(pos), stop_n = from_next(stop);
-        const uint16_t *nrec = row + cap_s;          /* walker s+1's records    */
-        uint16_t *next_ext = row + cap_s - ext;      /* segment s+1's extension */
+        /* ---- phase 2 (round 5 form): which walkers lie on the true chain, and each of those takes the chain of the one before it
+         * into its own segment until it stands on one of its own records.
+         *
+         * Rounds 3-4 let walker s walk on into segment s+1 and failed the block when its chain jumped over that segment -- which
+         * is what the chain of a cryo block of narrow rows does: the zero gap is ONE sequence whose match-length bytes alone
+         * (4 100 of them for 1 MiB) span several 1 KiB segments, every such block took the one-walker redo, and the pass was
+         * half of the call on those shapes (profiles/r05_index_run255.txt).  Now: a walker's chain leaves its segment at
+         * `pos` = the first token behind it, in segment nseg > s.  Walker 0 is true; if walker u is true (from its meeting
+         * point on), so is where it ends, hence walker nseg(u) is the next one on the chain and the segments in between hold
+         * no token at all.  One sweep over the wave's lanes in order (a chain only goes forward) marks the walkers on the chain
+         * and their predecessors; the others describe nothing. ---- */
+        const bool lastw = walker && sw + 1u == seff;
+        /* an inner walker must have ended on a token behind its segment (not: records overflowed, stream cut, 255-run) */
+        const bool endok = walker && (lastw || (pos >= stop && pos < vend && state == 0u && k < kcap));
+        uint32_t nlane = 64u; /* the lane of the walker whose segment this walker's chain enters (64: none) */
+        if (endok && !lastw) {
+            const uint32_t t = (pos - delta) / seglen; /* pos < vend: t < seff */
+            nlane = lane - sw + (t < seff ? t : seff - 1u);
+        }
+        unsigned long long lm = wave_ballot(walker && sw == 0u);
+        uint32_t pred = 0;
+        for (uint32_t u = 0; u < 64u; u++) {
+            if ((lm >> u) & 1ull) {
+                const uint32_t tu = lane_get(nlane, u);
+                if (tu < 64u) {
+                    lm |= 1ull << tu;
+                    pred = lane == tu ? u : pred;
+                }
+            }
+        }
+        const bool live = walker && ((lm >> lane) & 1ull) != 0ull;
+        bool fail = live && !endok;
+        __threadfence(); /* records are read back from memory */
+        const uint32_t pin = bperm(pos, pred); /* where the chain enters this segment */
+        const uint16_t *rec = row;             /* this walker's records: the first one is its guessed start */
+        uint16_t *my_ext = row - ext;          /* ... and the segment's extension in front of them */
         const uint8_t *sb = src_base + aoff;
-        uint32_t p = pos, r = stop, j = 0, L = 0;
-        bool merging = inner && !fail;
+        uint32_t p = pin, r = gstart, j = 0, L = 0;
+        bool merging = live && sw != 0u && !fail;
+        if (merging && (k == 0u || !(p >= gstart && p < stop))) { fail = true; merging = false; } /* (a walker on the chain has records) */
+        if (merging) r = gstart + (((uint32_t)rec[0] + delta - gstart) & 0xffffu); /* its first record: at or behind the guessed start (state 2) */
         while (wave_any(merging)) {
 #ifdef CRYO_IDX_PROF
             prof_steps++;
@@ -452,44 +506,44 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
             if (merging) {
                 if (p == r) merging = false;
                 else if (p < r) {
-                    if (L >= ext || p >= stop_n || p >= vend) { fail = true; merging = false; }
+                    if (L >= ext || p >= stop || p >= vend) { fail = true; merging = false; }
                     else {
-                        next_ext[L++] = (uint16_t)(p - delta);
+                        my_ext[L++] = (uint16_t)(p - delta);
                         p = lz4_next_token_direct(sb, vend, p);
                     }
                 } else {
-                    /* p is ahead of the neighbour's record j: step through its records, sixteen per trip to memory (one
-                     * record per trip made literal-heavy streams, whose false chains record a position every ~7 bytes of
-                     * a long literal run, pay 500-1000 dependent trips here: 3.2 ms for 8 192 blocks) */
-                    if (j >= k_n) { fail = true; merging = false; } /* already behind e_n: the chains did not meet */
+                    /* p is ahead of record j: step through the records, sixteen per trip to memory (one record per trip made
+                     * literal-heavy streams, whose false chains record a position every ~7 bytes of a long literal run, pay
+                     * 500-1000 dependent trips here: 3.2 ms for 8 192 blocks) */
+                    if (j >= k) { fail = true; merging = false; } /* already behind the walker's end: the chains did not meet */
                     else {
                         uint4 va, vb;
-                        __builtin_memcpy(&va, nrec + j + 1u, 16); /* records j+1 .. j+16; beyond the count: never used */
-                        __builtin_memcpy(&vb, nrec + j + 9u, 16);
+                        __builtin_memcpy(&va, rec + j + 1u, 16); /* records j+1 .. j+16; beyond the count: never used */
+                        __builtin_memcpy(&vb, rec + j + 9u, 16);
                         const uint32_t w[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
 #pragma unroll
                         for (uint32_t t = 0; t < 16u; t++) {
                             const uint32_t e16 = (w[t >> 1] >> (16u * (t & 1u))) & 0xffffu;
-                            const bool step = (r < p) & (j + 1u < k_n);
+                            const bool step = (r < p) & (j + 1u < k);
                             r += step ? ((e16 + delta - r) & 0xffffu) : 0u; /* records are increasing, less than 64 KiB apart */
                             j += step ? 1u : 0u;
                         }
-                        if ((r < p) & (j + 1u == k_n)) { j = k_n; r = e_n; } /* behind its last record walker s+1 stands on e_n */
+                        if ((r < p) & (j + 1u == k)) { j = k; r = pos; } /* behind its last record the walker stands on its end */
                     }
                 }
             }
         }
-        /* the descriptor of segment s comes from the lane on its left.  The skip count travels in 16 bits: a hand-over
-         * deeper than 65 535 records into the neighbour's segment (two walkers on a 1 MiB block of dense sequences can get
-         * there) counts as a boundary that did not meet, and phase 3 walks the block with one walker */
-        fail = fail || (inner && j > 0xffffu);
-        const uint32_t mine = fail ? 0xffffffffu : ((inner ? L : 0u) | ((inner ? j : 0u) << 16));
-        const uint32_t left = from_prev(mine);
+        /* The skip count travels in 16 bits: a hand-over deeper than 65 535 records into the segment (two walkers on a 1 MiB
+         * block of dense sequences can get there) counts as a boundary that did not meet, and phase 3 walks the block with one
+         * walker */
+        fail = fail || (live && j > 0xffffu);
+        const uint32_t left = L | (j << 16);
         const unsigned long long fm = wave_ballot(fail);
         const unsigned long long gmask = (logS >= 6u ? ~0ull : ((1ull << S) - 1ull)) << (lane & ~(S - 1u));
         const bool gfail = (fm & gmask) != 0ull;
+        if (!gfail && walker && !live) d_cnt = 0; /* not on the chain: the segment holds no token */
         if (!gfail) {
-            if (walker && sw != 0u) { d_ext = left & 0xffffu; d_skip = left >> 16; d_cnt = k - d_skip; }
+            if (live && sw != 0u) { d_ext = left & 0xffffu; d_skip = left >> 16; d_cnt = k - d_skip; }
         } else {
             /* ---- phase 3: the chains of this block did not meet: its first lane walks all of it ---- */
             d_cnt = 0;
@@ -554,7 +608,8 @@ __device__ inline FewGeom few_geom(const uint32_t cs, const uint32_t logS, const
     g.cs = cs;
     const uint32_t kib = cs >> 10; /* segments exactly as k_lz4_index cuts them: at least 1 KiB each */
     const uint32_t lg = kib ? 31u - (uint32_t)__builtin_clz(kib) : 0u;
-    const uint32_t ls_ = lg < logS ? lg : logS;
+    const bool cs_small = lz4_index_one_walker(cs);
+    const uint32_t ls_ = cs_small ? 0u : (lg < logS ? lg : logS);
     g.seff = 1u << ls_;
     g.seglen = (cs + g.seff - 1u) >> ls_;
     g.indexed = cs != 0u && !lz4_literal_heavy(cs, block_size);
@@ -581,8 +636,12 @@ k_lz4_few_walk(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
         uint32_t warm = 0;
         for (uint32_t o = gstart & ~127u; o < stop; o += 128u) warm += sb[o < g.cs ? o : 0u];
         asm volatile("" ::"v"(warm));
+        /* a guessed start inside a run of 255s (the match-length bytes of the zero gap, several segments long) moves behind the
+         * run's end: a true token there.  (Read as a token, a 255 is a literal length of megabytes: out of the stream.) */
+        if (sw != 0u && sb[p] == 255u) p = lz4_skip_255(sb, g.cs, p + 1u, nullptr);
+        const uint32_t kcap = g.seff == 1u ? (cap_s << logS) - ext : cap_main; /* a block's only walker has the whole row */
         while (p < stop) {
-            if (k >= cap_main) { p = 0xfffffffeu; break; } /* more tokens than the row holds: the join sees a walker that did not end on a token */
+            if (k >= kcap) { p = 0xfffffffeu; break; } /* more tokens than the row holds: the join sees a walker that did not end on a token */
             uint32_t x;
             __builtin_memcpy(&x, sb + p, 4);         /* the hop's load first, the record's store behind it (lz4_next_token_word) */
             asm volatile("" ::: "memory");
@@ -594,11 +653,57 @@ k_lz4_few_walk(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     ee[(blk << logS) + sw] = p;
 }
 
+/* which walkers lie on the true chain (k_lz4_index's phase 2 has the reasoning): one wave per block sweeps its up to 1 024
+ * walkers in order, 64 at a time; lp[walker] = 0x80000000 | predecessor for the walkers on the chain, 0 for the others */
+__global__ void __launch_bounds__(64)
+k_lz4_few_path(const uint32_t *__restrict__ src_size, const uint32_t logS, const uint32_t *__restrict__ ee, uint32_t *__restrict__ lp,
+               const uint32_t block_size)
+{
+    __shared__ uint32_t s_live[32];
+    __shared__ uint32_t s_pred[1024];
+    const uint64_t blk = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const FewGeom g = few_geom(src_size[blk], logS, block_size);
+    if (lane < 32u) s_live[lane] = (lane == 0u && g.indexed) ? 1u : 0u;
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    const uint32_t S = 1u << logS;
+    for (uint32_t u0 = 0; u0 < S; u0 += 64u) {
+        const uint32_t sw = u0 + lane;
+        const bool walker = g.indexed && sw < g.seff;
+        uint32_t nseg = 0xffffu; /* the segment this walker's chain enters (none: it is the last one, or it did not end on a token) */
+        if (walker && sw + 1u < g.seff) {
+            const uint32_t e = ee[(blk << logS) + sw], stop = (sw + 1u) * g.seglen;
+            if (e >= stop && e < g.cs) { const uint32_t t = e / g.seglen; nseg = t < g.seff ? t : g.seff - 1u; }
+        }
+        unsigned long long lm = (unsigned long long)uni(s_live[u0 >> 5]) | ((unsigned long long)uni(s_live[(u0 >> 5) + 1u]) << 32);
+        uint32_t pred = s_pred[sw]; /* written by an earlier group of 64, if this walker is on the chain */
+        for (uint32_t u = 0; u < 64u; u++) {
+            if ((lm >> u) & 1ull) {
+                const uint32_t tu = lane_get(nseg, u);
+                if (tu < g.seff) {
+                    if (tu - u0 < 64u) {
+                        lm |= 1ull << (tu - u0);
+                        pred = lane == tu - u0 ? u0 + u : pred;
+                    } else if (lane == 0u) {
+                        s_live[tu >> 5] |= 1u << (tu & 31u);
+                        s_pred[tu] = u0 + u;
+                    }
+                }
+            }
+        }
+        const bool live = walker && ((lm >> lane) & 1ull) != 0ull;
+        if (sw < S) lp[(blk << logS) + sw] = live ? (0x80000000u | pred) : 0u;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+    }
+}
+
 __global__ void __launch_bounds__(64)
 k_lz4_few_join(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off, const uint32_t *__restrict__ src_size,
                uint16_t *__restrict__ tbl, const uint32_t logS, const uint32_t cap_main, const uint32_t ext, const uint32_t cap,
-               const uint32_t *__restrict__ kk, const uint32_t *__restrict__ ee, uint32_t *__restrict__ failed,
-               uint2 *__restrict__ seg, const uint32_t block_size)
+               const uint32_t *__restrict__ kk, const uint32_t *__restrict__ ee, const uint32_t *__restrict__ lp,
+               uint32_t *__restrict__ failed, uint2 *__restrict__ seg, const uint32_t block_size)
 {
     const uint64_t blk = blockIdx.y;
     const uint32_t sw = blockIdx.x * 64u + threadIdx.x, cap_s = cap_main + ext;
@@ -608,14 +713,18 @@ k_lz4_few_join(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
     const uint32_t k = kk[(blk << logS) + sw], e = ee[(blk << logS) + sw];
     const uint32_t gstart = sw * g.seglen;
     const uint32_t stop = (walker && sw + 1u < g.seff) ? (sw + 1u) * g.seglen : g.cs;
-    /* this walker's own walk must have ended on a token behind its segment (an inner one) or behind the stream (the last) */
-    bool fail = walker && (e == 0xfffffffeu || (sw + 1u < g.seff && !(e >= stop && e < g.cs)));
+    /* only the walkers on the true chain describe anything (k_lz4_few_path); such a walker's own walk must have ended on a
+     * token behind its segment (an inner one) or behind the stream (the last) */
+    const uint32_t lpv = lp[(blk << logS) + sw];
+    const bool live = walker && (lpv >> 31) != 0u;
+    bool fail = live && (e == 0xfffffffeu || (sw + 1u < g.seff && !(e >= stop && e < g.cs)));
     uint32_t L = 0, j = 0;
-    if (walker && sw != 0u && !fail) {
+    if (live && sw != 0u && !fail) {
         const uint16_t *rec = tbl + blk * cap + sw * cap_s + ext; /* this walker's records: the first one is its guessed start */
         uint16_t *my_ext = tbl + blk * cap + sw * cap_s;          /* ... and the extension in front of them                 */
-        uint32_t pp = ee[(blk << logS) + sw - 1u], r = gstart;    /* the left neighbour's chain; record j of this walker    */
-        if (!(pp >= gstart && pp < g.cs)) fail = true;            /* the left neighbour did not end on a token in here (it reports that itself too) */
+        uint32_t pp = ee[(blk << logS) + (lpv & 0x7fffffffu)], r = gstart; /* where the chain enters this segment; record j of this walker */
+        if (k == 0u || !(pp >= gstart && pp < stop)) fail = true;           /* (a walker on the chain has records) */
+        else r = gstart + (((uint32_t)rec[0] - gstart) & 0xffffu);           /* its first record: at or behind the guessed start */
         while (!fail) {
             if (pp == r) break;
             if (pp < r) {
@@ -634,7 +743,7 @@ k_lz4_few_join(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
         fail = fail || j > 0xffffu;
     }
     if (fail) failed[blk] = 1u;
-    seg[(blk << logS) + sw] = (walker && !fail) ? make_uint2(L | (j << 16), k - j) : make_uint2(0u, 0u);
+    seg[(blk << logS) + sw] = (live && !fail) ? make_uint2(L | (j << 16), k - j) : make_uint2(0u, 0u);
 }
 
 /* ---- layout and launcher ---- */
@@ -678,13 +787,13 @@ Lz4IndexLayout lz4_index_layout_few(uint64_t n_blocks, uint32_t block_size)
     L.dummy_off = tbl_bytes;
     L.seg_off = (tbl_bytes + 64u * 32u + 255u) & ~(size_t)255u;
     /* behind the descriptors: record counts and end positions of the walkers (k_lz4_few_walk -> k_lz4_few_join), the blocks' flags */
-    L.bytes = L.seg_off + ((size_t)n_blocks << lg) * (sizeof(uint2) + 8u) + n_blocks * 4u + 256u;
+    L.bytes = L.seg_off + ((size_t)n_blocks << lg) * (sizeof(uint2) + 12u) + n_blocks * 4u + 256u;
     return L;
 }
 /* where the few-blocks index keeps "this block has no index" (the walkers' chains did not meet): one word per block */
 const uint32_t *lz4_index_few_failed(const void *d_workspace, const Lz4IndexLayout &L, uint64_t n_blocks)
 {
-    return reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(d_workspace) + L.seg_off + ((size_t)n_blocks << L.logS) * (sizeof(uint2) + 8u));
+    return reinterpret_cast<const uint32_t *>(static_cast<const uint8_t *>(d_workspace) + L.seg_off + ((size_t)n_blocks << L.logS) * (sizeof(uint2) + 12u));
 }
 
 hipError_t launch_lz4_index_few(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size,
@@ -697,10 +806,12 @@ hipError_t launch_lz4_index_few(hipStream_t s, const uint8_t *d_src, const uint6
     uint2 *seg = reinterpret_cast<uint2 *>(ws + L.seg_off);
     uint32_t *kk = reinterpret_cast<uint32_t *>(ws + L.seg_off + ((size_t)n_blocks << L.logS) * sizeof(uint2));
     uint32_t *ee = kk + ((size_t)n_blocks << L.logS);
-    uint32_t *failed = ee + ((size_t)n_blocks << L.logS);
+    uint32_t *lp = ee + ((size_t)n_blocks << L.logS);
+    uint32_t *failed = lp + ((size_t)n_blocks << L.logS);
     const dim3 grid(1u << (L.logS - 6u), (uint32_t)n_blocks);
     hipLaunchKernelGGL(k_lz4_few_walk, grid, dim3(64), 0, s, d_src, d_src_off, d_src_size, tbl, L.logS, L.cap_main, L.ext, L.cap, kk, ee, failed, block_size);
-    hipLaunchKernelGGL(k_lz4_few_join, grid, dim3(64), 0, s, d_src, d_src_off, d_src_size, tbl, L.logS, L.cap_main, L.ext, L.cap, kk, ee, failed, seg, block_size);
+    hipLaunchKernelGGL(k_lz4_few_path, dim3((uint32_t)n_blocks), dim3(64), 0, s, d_src_size, L.logS, ee, lp, block_size);
+    hipLaunchKernelGGL(k_lz4_few_join, grid, dim3(64), 0, s, d_src, d_src_off, d_src_size, tbl, L.logS, L.cap_main, L.ext, L.cap, kk, ee, lp, failed, seg, block_size);
     return hipGetLastError();
 }
 

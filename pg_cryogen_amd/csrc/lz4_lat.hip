@@ -68,7 +68,8 @@ __device__ inline void lat_segments(uint32_t cs, uint32_t logS, uint32_t &seff, 
 {
     const uint32_t kib = cs >> 10;
     const uint32_t lg = kib ? 31u - (uint32_t)__builtin_clz(kib) : 0u;
-    const uint32_t ls_ = lg < logS ? lg : logS;
+    const bool cs_small = lz4_index_one_walker(cs);
+    const uint32_t ls_ = cs_small ? 0u : (lg < logS ? lg : logS);
     seff = 1u << ls_;
     seglen = (cs + seff - 1u) >> ls_;
 }
@@ -95,8 +96,11 @@ __global__ void __launch_bounds__(1024) k_lat_segs(LatArgs A)
     lat_segments(A.src_size[blk], A.logS, seff, seglen);
     /* the walkers' chains did not all meet (the block's first lane walked all of it: positions more than 64 KiB from
      * the segment's start cannot be told from the 16-bit entries), or the block was left out of the index */
+    /* ... or its sequences are 64 bytes and more on average: runs -- the zero gap of narrow rows is ONE match of most of the
+     * block --, a memset for the batch decoder and a million-deep chain for pointer jumping (64 x 1 MiB `narrow`: 0.57 ms there,
+     * 2.7 ms here) */
     const bool plain = total != 0u && total <= A.nmax && (seff == 1u || s_later != 0u) && seglen < 0xF000u &&
-                       (A.ixfailed == nullptr || A.ixfailed[blk] == 0u);
+                       (A.ixfailed == nullptr || A.ixfailed[blk] == 0u) && (uint64_t)total * 64u >= A.B;
     if (threadIdx.x == 0u) {
         A.nseq[blk] = total;
         A.ok[blk] = plain ? 1u : 0u;
@@ -178,6 +182,9 @@ __global__ void __launch_bounds__(256) k_lat_parse(LatArgs A)
                     ml += 4u;
                     nx = ip;
                     if (of == 0u) good = false; /* liblz4 fills with zeros: the batch decoder's business */
+                    /* a block whose bytes are mostly ONE match (the zero gap of narrow rows) is a memset for the batch decoder
+                     * and a million-deep chain for pointer jumping: 64 x 1 MiB `narrow` 0.57 ms there, 2.7 ms here */
+                    if (ml >= (A.B >> 3)) good = false;
                 }
             }
         }

@@ -13,14 +13,17 @@
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 template <int NT>
-__global__ void __launch_bounds__(256) k_fill_regions(uint8_t *dst, uint32_t span, uint64_t nwaves, uint32_t v)
+__global__ void __launch_bounds__(256) k_fill_regions(uint8_t *dst, uint32_t span, uint64_t nwaves, uint32_t v, uint32_t rot)
 {
     const uint64_t w = (uint64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (w >= nwaves) return;
     const uint32_t lane = threadIdx.x & 63u;
     uint8_t *p = dst + w * span + lane * 16u;
     const uint4 x = make_uint4(v, v, v, v);
-    for (uint32_t o = 0; o < span; o += 1024u) {
+    const uint32_t start = rot ? (uint32_t)((w * 2654435761ull) % (span / 1024u)) * 1024u : 0u; /* F: every wave starts at another KiB of its region */
+    for (uint32_t i = 0; i < span; i += 1024u) {
+        uint32_t o = start + i;
+        if (o >= span) o -= span;
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
         const u32x4 y = {v, v, v, v};
         if (NT) __builtin_nontemporal_store(y, reinterpret_cast<u32x4 *>(p + o));
@@ -74,12 +77,28 @@ int main()
     hipStream_t s; CK(hipStreamCreate(&s));
     const int reps = 10;
     auto gbps = [&](double ms) { return bytes / (ms * 1e-3) / 1e9; };
-    for (int wpb : {1, 4, 8}) {
+    for (int wpb : {1, 4}) {
         const dim3 g((uint32_t)(nwaves / wpb)), b(64 * wpb);
-        double ms = time_ms(s, reps, [&] { hipLaunchKernelGGL(k_fill_regions<0>, g, b, 0, s, d, span, nwaves, 0u); });
+        double ms = time_ms(s, reps, [&] { hipLaunchKernelGGL(k_fill_regions<0>, g, b, 0, s, d, span, nwaves, 0u, 0u); });
         printf("A per-wave regions of 128 KiB, %d waves per workgroup, plain stores: %8.3f ms  %7.1f GB/s written\n", wpb, ms, gbps(ms));
-        ms = time_ms(s, reps, [&] { hipLaunchKernelGGL(k_fill_regions<1>, g, b, 0, s, d, span, nwaves, 0u); });
+        ms = time_ms(s, reps, [&] { hipLaunchKernelGGL(k_fill_regions<1>, g, b, 0, s, d, span, nwaves, 0u, 0u); });
         printf("B per-wave regions of 128 KiB, %d waves per workgroup, nt stores:    %8.3f ms  %7.1f GB/s written\n", wpb, ms, gbps(ms));
+    }
+    /* F: regions of 1 MiB (8 192 waves: the reference's block size), every wave from the start of its region / from a KiB of its own */
+    for (uint32_t big : {1u << 20, 1u << 18}) {
+        const uint64_t nw = bytes / big;
+        const dim3 g((uint32_t)(nw / 4)), b(256);
+        for (uint32_t rot : {0u, 1u}) {
+            double ms = time_ms(s, reps, [&] { hipLaunchKernelGGL(k_fill_regions<0>, g, b, 0, s, d, big, nw, 0u, rot); });
+            printf("F per-wave regions of %4u KiB, plain stores, %s: %8.3f ms  %7.1f GB/s written\n", big >> 10, rot ? "rotated start" : "from the start  ", ms, gbps(ms));
+            ms = time_ms(s, reps, [&] { hipLaunchKernelGGL(k_fill_regions<1>, g, b, 0, s, d, big, nw, 0u, rot); });
+            printf("F per-wave regions of %4u KiB, nt stores,    %s: %8.3f ms  %7.1f GB/s written\n", big >> 10, rot ? "rotated start" : "from the start  ", ms, gbps(ms));
+        }
+    }
+    for (uint32_t rot : {1u}) {
+        const dim3 g((uint32_t)(nwaves / 4)), b(256);
+        double ms = time_ms(s, reps, [&] { hipLaunchKernelGGL(k_fill_regions<1>, g, b, 0, s, d, span, nwaves, 0u, rot); });
+        printf("F per-wave regions of  128 KiB, nt stores,    rotated start: %8.3f ms  %7.1f GB/s written\n", ms, gbps(ms));
     }
     for (int blocks : {1024, 2048, 4096, 16384}) {
         double ms = time_ms(s, reps, [&] { hipLaunchKernelGGL(k_fill_stride, dim3(blocks), dim3(256), 0, s, reinterpret_cast<uint4 *>(d), bytes / 16, 0u); });
