@@ -365,6 +365,35 @@ def test_indexed_decoder_distributions_at_headline_sizes(codec, oracle, B, walke
         _decode_check(codec, comps, blocks, B, ("dist", B, walkers))
 
 
+@pytest.mark.parametrize("walkers", [4, 16, 64])
+def test_indexed_decoder_long_runs_across_segments(codec, oracle, walkers):
+    """Round 5: a chain may jump over whole index segments -- the match-length bytes of one long run (the zero gap of a cryo
+    block: 4 100 bytes of 255 for 1 MiB) span several 1 KiB segments, guessed starts fall inside them, and the walkers on the
+    true chain are found by a sweep (k_lz4_index phase 2, k_lz4_few_path).  Blocks of text, one run of 60 KB ... 900 KB at
+    varying places, text again; and two runs; through 4 / 16 / 64 walkers per block, both decoder forms, and the few-blocks
+    path (up to 1 024 walkers)."""
+    B = 1 << 20
+    text = oracle.synth(91, 0, B, 0)
+    rng = np.random.default_rng(91 + walkers)
+    blocks = []
+    for pre, run in ((1000, 900000), (30000, 500000), (200000, 60000), (517, 300000), (70001, 777777), (400000, 250000)):
+        b = text.copy()
+        b[pre:pre + run] = int(rng.integers(0, 256))
+        blocks.append(b)
+    b = text.copy()
+    b[5000:205000] = 0
+    b[600000:900000] = 0xFF                                            # a run of 255 DATA bytes: literal-free match, 255s in the match-length bytes only
+    blocks.append(b)
+    blocks.append(oracle.synth(91, 1, B, 1))                           # narrow rows
+    blocks.append(oracle.synth(91, 2, B, 2))                           # int4 rows: periodic stream, one walker (below 16 KiB)
+    comps = [oracle.lz4_compress(x, 1) for x in blocks]
+    with _indexed(codec, walkers):
+        _decode_check(codec, comps, blocks, B, ("runs", walkers))
+    with _few_blocks(codec):
+        _decode_check(codec, comps, blocks, B, ("runs-few", walkers))
+        _decode_check(codec, comps[1:2], blocks[1:2], B, ("runs-few-one", walkers))
+
+
 def test_indexed_decoder_two_walkers_on_1mib_blocks(codec, oracle):
     """Two walkers per 1 MiB block: a segment holds up to 81 984 records, more than the 16 bits in which a hand-over's skip
     count travels (lz4_index.hip: such a hand-over counts as a boundary that did not meet and the block is walked again by
