@@ -383,13 +383,16 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
      * reached memory for a 0.83 GB index -- the L2 does not hold 65 536 rows' open lines until they are full.  One
      * unconditional pair of stores per round (a lane with nothing to store writes its dummy slot), see the note on
      * the loads.  A macro, not a lambda: captured by a lambda, the packs lived in scratch memory. */
+#ifndef CRYO_IDX_NT_ROWS
+#define CRYO_IDX_NT_ROWS 0 /* experiment: the rows' 32-byte lines as non-temporal stores (profiles/r05_index_spread.txt) */
+#endif
 #define IDX_LINE_COPY(ps_, pd_)                                                                               \
     {                                                                                                        \
         const uint4 v0_ = *reinterpret_cast<const uint4 *>(ps_);                                             \
-        *reinterpret_cast<uint4 *>(pd_) = v0_;                                                               \
+        store16_out<CRYO_IDX_NT_ROWS != 0>(reinterpret_cast<uint8_t *>(pd_), v0_);                           \
         if (kIdxLine == 16u) {                                                                               \
             const uint4 v1_ = *reinterpret_cast<const uint4 *>((ps_) + 8);                                   \
-            *reinterpret_cast<uint4 *>((pd_) + 8) = v1_;                                                     \
+            store16_out<CRYO_IDX_NT_ROWS != 0>(reinterpret_cast<uint8_t *>((pd_) + 8), v1_);                 \
         }                                                                                                    \
     }
 #define IDX_PUT()                                                                                            \

@@ -26,6 +26,7 @@
  */
 #include "lz_common.h"
 #include "kernels.h"
+#include "lat_copy.h"
 
 namespace cryo {
 
@@ -37,31 +38,6 @@ namespace {
 constexpr uint32_t kLatMaxS = 1024;                   /* walkers per block of the index pass, at most */
 constexpr uint32_t kMFLimit = 12, kLastLiterals = 5; /* LZ4_decompress_safe's end-of-block rules (lz4.c) */
 
-struct LatArgs {
-    const uint8_t *src_base;
-    const uint64_t *src_off;
-    const uint32_t *src_size;
-    uint8_t *dst_base;
-    uint64_t dst_stride;
-    uint32_t B, n_blocks;
-    int32_t *status;
-    /* the index (lz4_index.hip) */
-    const uint16_t *tbl;
-    const uint2 *seg;
-    uint32_t tbl_cap, cap_s, ext, logS; /* S = 1 << logS walkers (descriptors) per block */
-    const uint32_t *ixfailed;           /* k_lz4_few_join: 1 = the block has no index (nullptr: k_lz4_index repairs its own) */
-    /* per block */
-    uint32_t nmax;      /* sequence slots per block */
-    uint32_t *segbase;  /* [n_blocks][S]: first sequence of segment s */
-    uint32_t *nseq;     /* [n_blocks] */
-    uint32_t *ok;       /* [n_blocks] 1: this path decodes the block */
-    uint32_t *done;     /* [n_blocks] 1: decoded here (the batch decoder skips it) */
-    uint32_t *pos, *opos, *ll, *lpos, *ml, *off, *nxt; /* [n_blocks][nmax] */
-    uint32_t *wgsum;    /* [n_blocks][nmax / 256] */
-    uint32_t *src;      /* [n_blocks][B rounded up to 16] */
-    uint32_t *changed;  /* [rounds + 1] */
-    uint32_t bpad;      /* B rounded up to 4096 */
-};
 
 /* segments of a block exactly as k_lz4_index cuts them (lz4_index.hip) */
 __device__ inline void lat_segments(uint32_t cs, uint32_t logS, uint32_t &seff, uint32_t &seglen)
@@ -201,24 +177,6 @@ __global__ void __launch_bounds__(256) k_lat_parse(LatArgs A)
     if (threadIdx.x == 0u) A.wgsum[blk * (A.nmax / 256u) + blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
 }
 
-/* a wave per block: exclusive scan of the workgroups' bytes (in place) */
-__global__ void __launch_bounds__(64) k_lat_scan(LatArgs A)
-{
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t blk = blockIdx.x;
-    if (uni(A.ok[blk]) == 0u) return;
-    const uint32_t nw = (uni(A.nseq[blk]) + 255u) / 256u;
-    uint32_t *w = A.wgsum + blk * (A.nmax / 256u);
-    uint32_t carry = 0;
-    for (uint32_t b0 = 0; b0 < nw; b0 += 64u) {
-        const uint32_t v = b0 + lane < nw ? w[b0 + lane] : 0u;
-        const uint32_t incl = scan64_incl(v);
-        if (b0 + lane < nw) w[b0 + lane] = carry + incl - v;
-        carry += lane_get(incl, 63);
-    }
-    if (carry != A.B && lane == 0u) A.ok[blk] = 0u; /* the block does not decode to B bytes */
-}
-
 /* a thread per sequence: output position, the checks that need it, the chain of tokens */
 __global__ void __launch_bounds__(256) k_lat_place(LatArgs A)
 {
@@ -258,109 +216,6 @@ __global__ void __launch_bounds__(256) k_lat_place(LatArgs A)
             good = good && ml == 0u && A.nxt[q] == cs && op + ll == A.B;
         }
         if (!good) A.ok[blk] = 0u;
-    }
-}
-
-/* a thread per 16 output bytes: literal bytes and where the match bytes come from */
-__global__ void __launch_bounds__(256) k_lat_fill(LatArgs A)
-{
-    const uint32_t blk = blockIdx.y;
-    if (A.ok[blk] == 0u) return;
-    const uint32_t b0 = (blockIdx.x * 256u + threadIdx.x) * 16u;
-    if (b0 >= A.B) return;
-    const uint32_t n = A.nseq[blk];
-    const uint64_t qb = (uint64_t)blk * A.nmax;
-    const uint32_t *opos = A.opos + qb;
-    /* the last sequence that starts at or before b0 */
-    uint32_t lo = 0, hi = n;
-    while (hi - lo > 1u) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (opos[mid] <= b0) lo = mid; else hi = mid;
-    }
-    uint32_t i = lo;
-    uint32_t so = opos[i], sl = A.ll[qb + i], sm = A.ml[qb + i], sf = A.off[qb + i], sp = A.lpos[qb + i];
-    const uint8_t *sb = A.src_base + A.src_off[blk];
-    uint32_t *srcb = A.src + (uint64_t)blk * A.bpad;
-    uint8_t *dst = A.dst_base + (uint64_t)blk * A.dst_stride;
-    uint32_t v[4] = {0, 0, 0, 0};
-    uint32_t sx[16];
-#pragma unroll
-    for (uint32_t k = 0; k < 16u; k++) {
-        const uint32_t b = b0 + k;
-        while (b >= so + sl + sm && i + 1u < n) {
-            i++;
-            so = opos[i]; sl = A.ll[qb + i]; sm = A.ml[qb + i]; sf = A.off[qb + i]; sp = A.lpos[qb + i];
-        }
-        uint32_t from = b;
-        if (b < A.B) {
-            if (b < so + sl) v[k >> 2] |= (uint32_t)sb[sp + (b - so)] << (8u * (k & 3u));
-            else from = b - sf;
-        }
-        sx[k] = from;
-    }
-    if (b0 + 16u <= A.B) *reinterpret_cast<uint4 *>(dst + b0) = make_uint4(v[0], v[1], v[2], v[3]);
-    else for (uint32_t k = 0; k < 16u && b0 + k < A.B; k++) dst[b0 + k] = (uint8_t)(v[k >> 2] >> (8u * (k & 3u)));
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; k++)
-        *reinterpret_cast<uint4 *>(srcb + b0 + 4u * k) = make_uint4(sx[4 * k], sx[4 * k + 1], sx[4 * k + 2], sx[4 * k + 3]);
-}
-
-/* one round of pointer jumping over every byte of every block this path decodes: THREE hops per round (round 5).  A source
- * only ever moves towards the literal byte it ends at, so a value another thread has already shortened is as good as the old
- * one -- the hops need no synchronisation between them, and a chain of depth d is at most ceil(d / 4) deep after a round:
- * half the launches of one hop per round (a launch costs ~4 us whatever it does, and a call is ~30 of them). */
-__global__ void __launch_bounds__(256) k_lat_jump(LatArgs A, uint32_t round)
-{
-    const uint32_t blk = blockIdx.y;
-    if (A.ok[blk] == 0u) return;
-    if (round != 0u && A.changed[round - 1u] == 0u) return; /* the round before changed nothing: done */
-    const uint32_t b0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
-    if (b0 >= A.B) return;
-    uint32_t *srcb = A.src + (uint64_t)blk * A.bpad;
-    uint4 s4 = *reinterpret_cast<const uint4 *>(srcb + b0);
-    uint32_t s[4] = {s4.x, s4.y, s4.z, s4.w};
-    uint32_t t[4];
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) t[k] = s[k];
-#pragma unroll
-    for (uint32_t hop = 0; hop < 3u; hop++) {
-        uint32_t u[4];
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; k++) u[k] = t[k] != b0 + k ? srcb[t[k]] : t[k]; /* a byte that points at itself is a literal */
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; k++) t[k] = u[k];
-    }
-    bool ch = false;
-#pragma unroll
-    for (uint32_t k = 0; k < 4u; k++) ch = ch || t[k] != s[k];
-    if (ch) *reinterpret_cast<uint4 *>(srcb + b0) = make_uint4(t[0], t[1], t[2], t[3]);
-    if (wave_any(ch) && (threadIdx.x & 63u) == 0u) A.changed[round] = 1u; /* a plain store: 65 000 atomics on one word took 0.3 ms a round */
-}
-
-/* match bytes from the literal bytes they come from */
-__global__ void __launch_bounds__(256) k_lat_gather(LatArgs A)
-{
-    const uint32_t blk = blockIdx.y;
-    if (A.ok[blk] == 0u) return;
-    const uint32_t b0 = (blockIdx.x * 256u + threadIdx.x) * 16u;
-    if (b0 < A.B) {
-        const uint32_t *srcb = A.src + (uint64_t)blk * A.bpad;
-        uint8_t *dst = A.dst_base + (uint64_t)blk * A.dst_stride;
-        uint32_t v[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (uint32_t k4 = 0; k4 < 4u; k4++) {
-            const uint4 s4 = *reinterpret_cast<const uint4 *>(srcb + b0 + 4u * k4);
-            const uint32_t s[4] = {s4.x, s4.y, s4.z, s4.w};
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; k++)
-                if (b0 + 4u * k4 + k < A.B) v[k4] |= (uint32_t)dst[s[k]] << (8u * k);
-        }
-        if (b0 + 16u <= A.B) *reinterpret_cast<uint4 *>(dst + b0) = make_uint4(v[0], v[1], v[2], v[3]);
-        else for (uint32_t k = 0; k < 16u && b0 + k < A.B; k++) dst[b0 + k] = (uint8_t)(v[k >> 2] >> (8u * (k & 3u)));
-    }
-    if (blockIdx.x == 0u && threadIdx.x == 0u) {
-        A.status[blk] = CRYO_ST_OK;
-        A.done[blk] = 1u;
     }
 }
 
@@ -437,7 +292,7 @@ hipError_t launch_lz4_decompress_latency(hipStream_t s, const uint8_t *d_src, co
 #else
     if (hipError_t e = launch_lz4_index(s, d_src, d_src_off, d_src_size, n_blocks, block_size, d_workspace, y.ix); e != hipSuccess) return e;
 #endif
-    LatArgs A;
+    LatArgs A = {};
     A.src_base = d_src; A.src_off = d_src_off; A.src_size = d_src_size;
     A.dst_base = d_dst; A.dst_stride = dst_stride; A.B = block_size; A.n_blocks = (uint32_t)n_blocks; A.status = d_status;
     A.tbl = reinterpret_cast<const uint16_t *>(ws);

@@ -32,6 +32,7 @@
 #include "zstd_common.h"
 #include "lz4_copy.h"
 #include "kernels.h"
+#include "lat_copy.h"
 #include <cstdio>
 #include <cstdlib>
 
@@ -94,6 +95,7 @@ struct ZPipe {
     uint32_t *mitems;  /* blocks whose symbols k_zmove moves (counters[60]) */
     uint32_t *irregular;
     uint32_t *sitems; /* blocks with sequences (f * nbmax + k) */
+    const uint32_t *done; /* few frames per call: frames the byte-parallel execution has decoded (k_zexec skips them); else nullptr */
 };
 
 struct PlanLds {
@@ -1874,6 +1876,7 @@ __global__ void __launch_bounds__(64, CRYO_ZEXEC_OCC) k_zexec(ZPipe P)
     const uint32_t f = blockIdx.x;
     const uint32_t flags = uni(P.frames[f].flags);
     if (flags & F_IRREG) return; /* the fused decoder writes this block and its status */
+    if (P.done != nullptr && uni(P.done[f]) != 0u) return; /* decoded, and its status written, by the few-frames path below */
     const uint64_t blk = P.first + f;
     if (flags & F_BAD) {
         if (lane == 0) P.status[blk] = CRYO_ST_CORRUPT;
@@ -1927,6 +1930,141 @@ __global__ void __launch_bounds__(64, CRYO_ZEXEC_OCC) k_zexec(ZPipe P)
     if (lane == 0) P.status[blk] = bad ? CRYO_ST_CORRUPT : CRYO_ST_OK;
 }
 
+/* ------------------------------------------------------------------------------------------- few frames per call
+ * k_zexec executes a frame's sequences on ONE wave: 800 batches for a 1 MiB frame, 3.8 of the 4.4 ms of that call -- and one
+ * frame per call is the reference's own read path (cache.c:178, default codec zstd, CRYO_BLCKSZ 1 MiB).  Once k_zmat has made
+ * the sequences explicit, executing them is the problem lz4_lat.hip solves for LZ4 blocks: output positions by a prefix sum,
+ * literal bytes placed and every match byte pointed at its source, pointer jumping, gather (lat_copy.h).  For calls of up
+ * to 64 frames and 64 MiB:
+ *   k_zlat_count  per frame: is it one this path takes (no checksum to verify, no RLE literals, it says B bytes), the
+ *                 place of every zstd block's sequences in the frame's flat list
+ *   k_zlat_build  per zstd block: its records -> ll / ml / offset / where the literals lie (input: raw literals, raw and
+ *                 RLE blocks; bit 31: the frame's pool of Huffman literals), by a scan of the literal lengths; the block's
+ *                 last literals as a sequence without a match; a raw block is one literal run, an RLE block one literal
+ *                 and a match at offset 1
+ *   k_zlat_sum / k_lat_scan / k_zlat_place  output positions; offsets inside the output so far; the frame decodes to B bytes
+ *   k_lat_fill / k_lat_jump / k_lat_gather  the bytes
+ * Whatever fails a check here is not marked done and k_zexec decodes it as before: verdicts and bytes are its. */
+namespace {
+
+__global__ void __launch_bounds__(64) k_zlat_count(ZPipe P, LatArgs A, uint32_t *zstart)
+{
+    const uint32_t f = blockIdx.x;
+    if (threadIdx.x != 0u) return;
+    const ZFrame fr = P.frames[f];
+    bool ok = (fr.flags & (F_IRREG | F_BAD | F_CK)) == 0u;
+    if ((fr.flags & F_FCS) && !(fr.fcs_hi == 0u && fr.fcs_lo == P.B)) ok = false;
+    uint32_t total = 0;
+    for (uint32_t k = 0; k < fr.nblk; k++) {
+        const ZBlk *d = P.blks + (uint64_t)f * P.nbmax + k;
+        zstart[f * P.nbmax + k] = total;
+        if (d->type == 2u) {
+            if (d->lit_mode == 1u && d->regen != 0u) ok = false; /* RLE literals: no stream to point at */
+            total += d->nseq + 1u;
+        } else total += 1u;
+    }
+    if (total == 0u || total > A.nmax) ok = false;
+    /* sequences of 64 bytes and more on average are runs (the zero gap of narrow rows: RLE blocks, one long match): a memset
+     * for k_zexec, a million-deep chain for pointer jumping (16 x 1 MiB `narrow`: 0.55 ms there, 0.98 here) */
+    if ((uint64_t)total * 64u < P.B) ok = false;
+    A.nseq[f] = total;
+    A.ok[f] = ok ? 1u : 0u;
+    A.done[f] = 0u;
+}
+
+__global__ void __launch_bounds__(256) k_zlat_build(ZPipe P, LatArgs A, const uint32_t *zstart)
+{
+    __shared__ uint32_t s_sum[4];
+    const uint32_t f = blockIdx.y, k = blockIdx.x;
+    if (A.ok[f] == 0u || k >= P.frames[f].nblk) return;
+    const ZBlk *d = P.blks + (uint64_t)f * P.nbmax + k;
+    const uint64_t q0 = (uint64_t)f * A.nmax + zstart[f * P.nbmax + k];
+    const uint32_t type = d->type;
+    if (type != 2u) {
+        if (threadIdx.x == 0u) {
+            const uint32_t bs = d->bsize;
+            if (type == 0u) { A.ll[q0] = bs; A.ml[q0] = 0u; A.off[q0] = 0u; A.lpos[q0] = d->src_off; }
+            else { A.ll[q0] = bs ? 1u : 0u; A.ml[q0] = bs ? bs - 1u : 0u; A.off[q0] = 1u; A.lpos[q0] = d->src_off; } /* RLE: the byte, then a match at distance 1 */
+        }
+        return;
+    }
+    const uint32_t nseq = d->nseq, regen = d->regen;
+    const uint32_t lbase = d->lit_mode == 2u ? (0x80000000u | d->lit_src) : d->lit_src; /* the pool / the frame's input */
+    const uint2 *seqs = P.seqs + d->seq_base;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    uint32_t carry = 0; /* literal bytes before this chunk of 256 sequences */
+    bool bad = false;
+    for (uint32_t i0 = 0; i0 < nseq; i0 += 256u) {
+        const uint32_t i = i0 + threadIdx.x;
+        uint32_t ll = 0, ml = 0, off = 0;
+        if (i < nseq) {
+            const uint2 r = seqs[i];
+            ll = (r.x >> 29) | ((r.y & 0x3FFFu) << 3);
+            ml = r.y >> 14;
+            off = r.x & 0x1FFFFFFFu;
+        }
+        const uint32_t incl = scan64_incl(ll);
+        __syncthreads(); /* (s_sum of the chunk before has been read) */
+        if (lane == 63u) s_sum[wv] = incl;
+        __syncthreads();
+        uint32_t before = carry;
+        for (uint32_t w = 0; w < wv; w++) before += s_sum[w];
+        if (i < nseq) {
+            const uint32_t lp = before + incl - ll;
+            if (lp + ll > regen || off == 0x1FFFFFFFu) bad = true; /* more literals than the block has; an offset beyond 29 bits */
+            A.ll[q0 + i] = ll; A.ml[q0 + i] = ml; A.off[q0 + i] = off; A.lpos[q0 + i] = lbase + lp;
+        }
+        carry += s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    }
+    if (carry > regen) bad = true;
+    if (threadIdx.x == 0u && carry <= regen) { /* the block's last literals */
+        A.ll[q0 + nseq] = regen - carry; A.ml[q0 + nseq] = 0u; A.off[q0 + nseq] = 0u; A.lpos[q0 + nseq] = lbase + carry;
+    }
+    if (bad) A.ok[f] = 0u;
+}
+
+/* bytes of every 256 flat sequences (k_lat_scan turns them into the workgroups' first output positions) */
+__global__ void __launch_bounds__(256) k_zlat_sum(LatArgs A)
+{
+    __shared__ uint32_t s_sum[4];
+    const uint32_t f = blockIdx.y, n = A.nseq[f];
+    if (A.ok[f] == 0u || blockIdx.x * 256u >= n) return;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const uint64_t q = (uint64_t)f * A.nmax + i;
+    const uint32_t len = i < n ? A.ll[q] + A.ml[q] : 0u;
+    const uint32_t incl = scan64_incl(len);
+    if ((threadIdx.x & 63u) == 63u) s_sum[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0u) A.wgsum[f * (A.nmax / 256u) + blockIdx.x] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+}
+
+/* a thread per sequence: output position; a match starts inside the output so far */
+__global__ void __launch_bounds__(256) k_zlat_place(LatArgs A)
+{
+    __shared__ uint32_t s_sum[4];
+    const uint32_t f = blockIdx.y, n = A.nseq[f];
+    if (A.ok[f] == 0u || blockIdx.x * 256u >= n) return;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool on = i < n;
+    const uint64_t q = (uint64_t)f * A.nmax + i;
+    uint32_t ll = 0, ml = 0;
+    if (on) { ll = A.ll[q]; ml = A.ml[q]; }
+    const uint32_t len = ll + ml, lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t incl = scan64_incl(len);
+    if (lane == 63u) s_sum[wv] = incl;
+    __syncthreads();
+    uint32_t before = A.wgsum[f * (A.nmax / 256u) + blockIdx.x];
+    for (uint32_t w = 0; w < wv; w++) before += s_sum[w];
+    const uint32_t op = before + incl - len;
+    if (on) {
+        A.opos[q] = op;
+        const uint32_t off = A.off[q];
+        if (ml != 0u && (off == 0u || off > op + ll)) A.ok[f] = 0u; /* k_zexec's rule: the offset may not reach before the output */
+    }
+}
+
+} // namespace
+
 /* ------------------------------------------------------------------------------------------- host */
 namespace {
 
@@ -1934,7 +2072,16 @@ struct Layout {
     uint32_t F, nbmax, litcap, seqcap;
     size_t htmp_stride;
     size_t o_frames, o_blks, o_huf, o_seqt, o_predef, o_lits, o_seqs, o_chain, o_cnt, o_hitems, o_hitems2, o_htmp, o_irreg, o_sitems, o_hsegs, o_mitems, o_fused, total;
+    /* few frames per call (k_zlat_*): sequence slots per frame, padded block size, jump rounds; 0 = the call is not one of those */
+    uint32_t lat_nmax, lat_bpad, lat_rounds;
+    size_t o_lat_nseq, o_lat_ok, o_lat_done, o_lat_zstart, o_lat_opos, o_lat_ll, o_lat_lpos, o_lat_ml, o_lat_off, o_lat_wgsum, o_lat_src, o_lat_changed;
 };
+
+/* calls the byte-parallel execution takes: what lz4_lat.hip takes (up to 64 blocks and 64 MiB per call) */
+inline bool zstd_few_frames(uint64_t n_blocks, uint32_t B)
+{
+    return n_blocks >= 1u && n_blocks <= 64u && B >= (32u << 10) && B <= (2u << 20) && n_blocks * (uint64_t)B <= (64ull << 20);
+}
 
 constexpr uint32_t kFusedGridForIrregular = 256;
 
@@ -1991,6 +2138,27 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     y.o_hsegs = o; o = al256(o + (size_t)y.F * y.nbmax * 64u * sizeof(uint4));
     y.o_mitems = o; o = al256(o + (size_t)y.F * y.nbmax * 4u);
     y.o_fused = o; o = al256(o + zstd_fused_workspace(kFusedGridForIrregular));
+    y.lat_nmax = 0; y.lat_bpad = 0; y.lat_rounds = 0;
+    if (zstd_few_frames(n_blocks, B) && y.F >= n_blocks) {
+        const size_t n = (size_t)n_blocks;
+        y.lat_nmax = (B / 4u + 2u * y.nbmax + 255u) & ~255u; /* the format allows B / 3 sequences: a frame beyond B / 4 stays with k_zexec */
+        y.lat_bpad = (B + 4095u) & ~4095u;
+        y.lat_rounds = 2;
+        while ((1ull << (2u * (y.lat_rounds - 1u))) < B) y.lat_rounds++;
+        const size_t per = n * y.lat_nmax * 4u;
+        y.o_lat_nseq = o; o = al256(o + n * 4u);
+        y.o_lat_ok = o; o = al256(o + n * 4u);
+        y.o_lat_done = o; o = al256(o + n * 4u);
+        y.o_lat_zstart = o; o = al256(o + n * y.nbmax * 4u);
+        y.o_lat_opos = o; o = al256(o + per);
+        y.o_lat_ll = o; o = al256(o + per);
+        y.o_lat_lpos = o; o = al256(o + per);
+        y.o_lat_ml = o; o = al256(o + per);
+        y.o_lat_off = o; o = al256(o + per);
+        y.o_lat_wgsum = o; o = al256(o + n * (y.lat_nmax / 256u) * 4u);
+        y.o_lat_src = o; o = al256(o + n * (size_t)y.lat_bpad * 4u);
+        y.o_lat_changed = o; o = al256(o + (y.lat_rounds + 1u) * 4u);
+    }
     y.total = o;
     return y;
 }
@@ -2058,6 +2226,7 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
     static const uint32_t seq_pad = cryo_tuning_env("CRYO_ZSEQ_PAD") ? (uint32_t)atoi(cryo_tuning_env("CRYO_ZSEQ_PAD")) : 0u;
     static const bool want_stats = cryo_tuning_env("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
     static const bool old_huf = cryo_tuning_env("CRYO_ZHUF_OLD") != nullptr;
+    static const bool skip_lat = cryo_tuning_env("CRYO_ZSTD_NO_FEW") != nullptr; /* A/B (debug builds): k_zexec for every frame */
     /* calls of at most this many zstd blocks (frames x blocks per frame) run a tile's two entropy stages side by side: 3-6 %
      * less time from 1 to 4 096 frames, 5 % MORE at a full tile of 12 288 (profiles/r05_zstd_fork.txt; tuning aid:
      * CRYO_ZSTD_FORK_ZBLOCKS) */
@@ -2089,6 +2258,7 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
         P.sitems = (uint32_t *)(ws + y.o_sitems);
         P.hsegs = (uint4 *)(ws + y.o_hsegs);
         P.mitems = (uint32_t *)(ws + y.o_mitems);
+        P.done = nullptr;
         const uint64_t left = n_blocks - first;
         P.first = first;
         P.F = (uint32_t)(left < y.F ? left : y.F);
@@ -2138,6 +2308,29 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
             if ((e = hipStreamWaitEvent(st, aux->seqs_done[l], 0)) != hipSuccess) return e;
         } else {
             seq_stage(st);
+        }
+        if (y.lat_nmax != 0u && !skip_lat) { /* few frames: every output byte in parallel; k_zexec takes what this leaves */
+            LatArgs A = {};
+            A.src_base = d_src; A.src_off = d_src_off + first; A.src_size = d_src_size + first;
+            A.dst_base = d_dst + first * dst_stride; A.dst_stride = dst_stride; A.B = block_size; A.n_blocks = P.F; A.status = d_status + first;
+            A.nmax = y.lat_nmax; A.bpad = y.lat_bpad;
+            A.nseq = (uint32_t *)(ws + y.o_lat_nseq); A.ok = (uint32_t *)(ws + y.o_lat_ok); A.done = (uint32_t *)(ws + y.o_lat_done);
+            A.opos = (uint32_t *)(ws + y.o_lat_opos); A.ll = (uint32_t *)(ws + y.o_lat_ll); A.lpos = (uint32_t *)(ws + y.o_lat_lpos);
+            A.ml = (uint32_t *)(ws + y.o_lat_ml); A.off = (uint32_t *)(ws + y.o_lat_off);
+            A.wgsum = (uint32_t *)(ws + y.o_lat_wgsum); A.src = (uint32_t *)(ws + y.o_lat_src); A.changed = (uint32_t *)(ws + y.o_lat_changed);
+            A.pool_base = P.lits; A.pool_stride = P.litcap;
+            uint32_t *zstart = (uint32_t *)(ws + y.o_lat_zstart);
+            if ((e = hipMemsetAsync(A.changed, 0, (y.lat_rounds + 1u) * 4u, st)) != hipSuccess) return e;
+            hipLaunchKernelGGL(k_zlat_count, dim3(P.F), dim3(64), 0, st, P, A, zstart);
+            hipLaunchKernelGGL(k_zlat_build, dim3(P.nbmax, P.F), dim3(256), 0, st, P, A, zstart);
+            hipLaunchKernelGGL(k_zlat_sum, dim3(y.lat_nmax / 256u, P.F), dim3(256), 0, st, A);
+            hipLaunchKernelGGL(k_lat_scan, dim3(P.F), dim3(64), 0, st, A);
+            hipLaunchKernelGGL(k_zlat_place, dim3(y.lat_nmax / 256u, P.F), dim3(256), 0, st, A);
+            hipLaunchKernelGGL(k_lat_fill, dim3((block_size + 4095u) / 4096u, P.F), dim3(256), 0, st, A);
+            for (uint32_t r = 0; r < y.lat_rounds; r++)
+                hipLaunchKernelGGL(k_lat_jump, dim3((block_size + 1023u) / 1024u, P.F), dim3(256), 0, st, A, r);
+            hipLaunchKernelGGL(k_lat_gather, dim3((block_size + 4095u) / 4096u, P.F), dim3(256), 0, st, A);
+            P.done = A.done;
         }
         hipLaunchKernelGGL(k_zexec, dim3(P.F), dim3(64), 0, st, P);
         const uint64_t fg = P.F < kFusedGridForIrregular ? P.F : kFusedGridForIrregular;
