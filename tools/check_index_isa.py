@@ -10,7 +10,12 @@ the slots are dead to the compiler and it hands their registers to something els
 In k_lz4_index either would only cost speed -- the decoder validates every index entry -- so no test of the output could see
 it.  This script compiles the kernels to assembly and requires that, from the loop that holds the assembly loads up to the
 drain behind it, a register written by one of those loads is touched by nothing but that load and the ds_write_b128 /
-ds_write_b64 that commits it."""
+ds_write_b64 that commits it.
+
+The counted waits themselves are checked too: `s_waitcnt vmcnt(N)` in front of a slot's commit is right only if
+at least N vector-memory operations are issued between that slot's loads and the wait, once around the loop -- vmcnt counts
+in issue order, so with fewer the slot's own loads are among the N that may still be in flight and stale ring bytes are
+committed (in k_zchain4: wrong sequences, not merely lost speed).  Operations a forward branch may skip do not count."""
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -95,6 +100,37 @@ def check(path, kernel):
                 break   # an unconditional branch backwards or beyond the drain: not the path to it
             else:
                 i += 1
+        # ---- the counted waits: at least N vector-memory operations between a slot's loads and the wait before its commit ----
+        VM = re.compile(r"^(global_|buffer_|scratch_|flat_)")
+        loop = list(range(first, back + 1))
+        skippable = set()
+        for i in loop:
+            m = re.match(r"\s*s_cbranch\S*\s+(\.LBB\d+_\d+)", body[i])
+            if m and m.group(1) in labels and i < labels[m.group(1)] <= back:
+                skippable |= set(range(i + 1, labels[m.group(1)]))
+        def is_vm(i):
+            return bool(VM.match(body[i].strip())) and i not in skippable
+        for ld in [i for i in grp if first <= i <= back]:
+            r = regs(body[ld].split()[1].rstrip(","))
+            order = [i for i in loop if i > ld] + [i for i in loop if i <= ld] # once around the loop, from behind the load
+            commit = next((i for i in order if (body[i].strip().startswith("ds_write_b128") or body[i].strip().startswith("ds_write_b64")) and
+                           (regs(re.findall(r"v\[\d+:\d+\]|v\d+", body[i].strip())[-1]) & r)), None)
+            if commit is None:
+                problems.append("no commit found for the assembly load at line %d" % (start + ld + 1))
+                continue
+            upto = order[:order.index(commit)]
+            waits = [i for i in upto if i in asm_lines and re.fullmatch(r"s_waitcnt vmcnt\(\d+\)", body[i].strip())]
+            if not waits:
+                problems.append("no counted wait between the assembly load at line %d and its commit" % (start + ld + 1))
+                continue
+            w = waits[-1]
+            n = int(re.search(r"\((\d+)\)", body[w]).group(1))
+            younger = sum(1 for i in upto[:upto.index(w)] if is_vm(i))
+            if os.environ.get("CRYO_ISA_VERBOSE"):
+                print("  %s: load at line %d, vmcnt(%d), %d vector-memory operations behind it" % (kernel, start + ld + 1, n, younger))
+            if younger < n:
+                problems.append("vmcnt(%d) at line %d: only %d vector-memory operations are issued behind the load at line %d" %
+                                (n, start + w + 1, younger, start + ld + 1))
         for i in path:
             s = body[i].strip()
             if not s or s.startswith(";") or s.startswith("."):
