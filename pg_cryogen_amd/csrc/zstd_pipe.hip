@@ -96,6 +96,8 @@ struct ZPipe {
     uint32_t *irregular;
     uint32_t *sitems; /* blocks with sequences (f * nbmax + k) */
     const uint32_t *done; /* few frames per call: frames the byte-parallel execution has decoded (k_zexec skips them); else nullptr */
+    uint32_t hufw_seglog; /* k_zhufw: a stream of T bits gets T >> this walkers (1 .. 16) */
+    uint32_t hufw_min; /* Huffman blocks of fewer literals than this go to k_zhuf (lane per stream) instead of k_zhufw's walkers */
 };
 
 struct PlanLds {
@@ -776,7 +778,7 @@ __device__ __attribute__((always_inline)) inline void zhufw_item(const ZPipe &P,
 #else
     auto fallback = [&](int = 0) { if (lane == 0u) P.hitems2[atomicAdd(&P.counters[61], 1u)] = it; };
 #endif
-    if (hlog > kHufL1 || hlog == 0u) { fallback(0); return; }
+    if (hlog > kHufL1 || hlog == 0u || regen < P.hufw_min) { fallback(0); return; }
     {
         /* the one-symbol table goes through the (still unused) rings */
         const uint16_t *g = P.huf + ((uint64_t)f * P.nbmax + uni(d->huf_slot)) * kHufTblWords;
@@ -819,7 +821,7 @@ __device__ __attribute__((always_inline)) inline void zhufw_item(const ZPipe &P,
     if (wave_any(sid < nstreams && !sok)) { fallback(1); return; } /* a stream without an end mark: k_zhuf says what it is */
     /* segments */
     const uint32_t T = sok ? (slen - 1u) * 8u + (31u - (uint32_t)__builtin_clz(last)) : 0u;
-    uint32_t se = T >> 11;
+    uint32_t se = T >> P.hufw_seglog;
     se = se < 1u ? 1u : (se > 16u ? 16u : se);
     const uint32_t Lb = (T + se - 1u) / se;
     const bool walker = sok && w < se;
@@ -2226,6 +2228,14 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
     static const uint32_t seq_pad = cryo_tuning_env("CRYO_ZSEQ_PAD") ? (uint32_t)atoi(cryo_tuning_env("CRYO_ZSEQ_PAD")) : 0u;
     static const bool want_stats = cryo_tuning_env("CRYO_ZSTD_STATS") != nullptr; /* debugging aid */
     static const bool old_huf = cryo_tuning_env("CRYO_ZHUF_OLD") != nullptr;
+    /* Huffman blocks of fewer than 4 KiB of literals (run-dominated frames: `int4` has ~1 KiB per block) are not worth the
+     * walkers' set-up (two-symbol table, marks, four phases): lane per stream decodes them, +8-12 % on `int4`, nothing lost
+     * elsewhere; from 12 KiB on the walkers win (`narrow`, 10 KiB: -14 % with everything on k_zhuf; profiles/r05_hufw_min.txt) */
+    static const uint32_t hufw_min = cryo_tuning_env("CRYO_ZHUFW_MIN") ? (uint32_t)atoi(cryo_tuning_env("CRYO_ZHUFW_MIN")) : 4096u;
+    /* walkers per stream: one per 2 048 bits; 1 024 / 512 / 256 measured the same within the noise on `narrow`, `int4` and
+     * level -5 streams, with the first blocks handed back for want of a meeting point (profiles/r05_hufw_seglog.txt) */
+    static const uint32_t hufw_seglog = cryo_tuning_env("CRYO_ZHUFW_SEGLOG") ? (uint32_t)atoi(cryo_tuning_env("CRYO_ZHUFW_SEGLOG")) : 11u;
+    static const uint32_t huf2_grid = cryo_tuning_env("CRYO_ZHUF2_GRID") ? (uint32_t)atoi(cryo_tuning_env("CRYO_ZHUF2_GRID")) : 512u;
     static const bool skip_lat = cryo_tuning_env("CRYO_ZSTD_NO_FEW") != nullptr; /* A/B (debug builds): k_zexec for every frame */
     /* calls of at most this many zstd blocks (frames x blocks per frame) run a tile's two entropy stages side by side: 3-6 %
      * less time from 1 to 4 096 frames, 5 % MORE at a full tile of 12 288 (profiles/r05_zstd_fork.txt; tuning aid:
@@ -2259,6 +2269,8 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
         P.hsegs = (uint4 *)(ws + y.o_hsegs);
         P.mitems = (uint32_t *)(ws + y.o_mitems);
         P.done = nullptr;
+        P.hufw_min = hufw_min;
+        P.hufw_seglog = hufw_seglog;
         const uint64_t left = n_blocks - first;
         P.first = first;
         P.F = (uint32_t)(left < y.F ? left : y.F);
@@ -2302,7 +2314,7 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
             hipLaunchKernelGGL(k_zmove, dim3(P.F * P.nbmax), dim3(64), 0, st, P);
             static const bool skip_fallbacks = cryo_tuning_env("CRYO_ZSTD_SKIP_FALLBACKS") != nullptr; /* timing experiment (debug builds): wrong if anything was handed back */
             if (!skip_fallbacks)
-            hipLaunchKernelGGL(k_zhuf, dim3((CRYO_GS & 1) && zhuf_all > 256u ? 256u : zhuf_all), dim3(64), 0, st, P, P.hitems2, 61u); /* the walkers' hand-backs: rarely any */
+            hipLaunchKernelGGL(k_zhuf, dim3((CRYO_GS & 1) && zhuf_all > huf2_grid ? huf2_grid : zhuf_all), dim3(64), 0, st, P, P.hitems2, 61u); /* the walkers' hand-backs: rarely any */
         }
         if (fork_stages) {
             if ((e = hipStreamWaitEvent(st, aux->seqs_done[l], 0)) != hipSuccess) return e;
