@@ -88,6 +88,39 @@ def test_zstd_decode_all_levels_live_library(codec, oracle, B, zstd_path):
         assert np.array_equal(o, raw)
 
 
+def test_zstd_decode_literal_sections_around_the_walker_threshold(codec, oracle, zstd_path):
+    """Huffman blocks of fewer than 4 KiB of literals are decoded lane per stream (k_zhuf), longer ones by k_zhufw's walkers
+    (zstd_pipe.hip, `hufw_min`): literal sections of 3 900 ... 4 300 bytes in one batch -- random hex that matches nothing, then a
+    zero gap --, short sections too (40 ... 1 100 bytes: raw, one Huffman stream, four); and
+    mutated copies whose verdicts and bytes must be the oracle's on either side of the threshold."""
+    rng = np.random.default_rng(4096)
+    hexd = np.frombuffer(b"0123456789abcdef", np.uint8)
+    B = 16384
+    blocks = []
+    for n in list(range(3900, 4300, 12)) + list(range(40, 260, 30)) + list(range(200, 1100, 60)) + [4095, 4096, 4097]:
+        b = np.zeros(B, np.uint8)
+        b[:n] = hexd[rng.integers(0, 16, n)]
+        blocks.append(b)
+    comps = [oracle.zstd_compress(b, 1) for b in blocks]
+    outs, st = codec.decompress_blocks(METHOD_ZSTD, comps, B)
+    assert (st == 0).all(), st
+    for i, (raw, o) in enumerate(zip(blocks, outs)):
+        assert np.array_equal(o, raw), i
+    from stress_gpu import mutate
+    items, expect = [], []
+    for it in range(60):
+        m = mutate(rng, comps[it % len(comps)])
+        r, out = oracle.zstd_decompress(m, B, fill=0xA5)
+        items.append(m)
+        expect.append(out.copy() if r == B else None)
+    outs, st = codec.decompress_blocks(METHOD_ZSTD, items, B)
+    for i, e in enumerate(expect):
+        if e is None:
+            assert st[i] != 0, i
+        else:
+            assert st[i] == 0 and np.array_equal(outs[i], e), i
+
+
 @pytest.mark.parametrize("B", [131072, 1 << 20])
 def test_zstd_decode_literals_of_one_code_length(codec, oracle, B, zstd_path):
     """Literal streams whose Huffman codes (nearly) all have one length -- hex digits, decimal digits, base64 -- are what
