@@ -259,8 +259,10 @@ __device__ bool plan_block(PlanLds &L, const ZPipe &P, PlanState &ps, const uint
         else {
             int hlog = 0;
             /* the decoding table is filled straight into the workspace (8 KiB less LDS: twice the workgroups per CU) */
-            /* the weights' bit reader reads the staged copy too (round 5: it read the stream in global memory, a dependent trip
-             * per eight bytes; the description is at most 1 + 127 bytes behind a header of at most 5: inside the window) */
+            /* the weights' bit reader reads the staged copy too (the description is at most 1 + 127 bytes behind a header of at
+             * most 5: inside the window).  It used to read the stream in global memory, a trip per eight bytes; that the phase
+             * took the same time either way (profiles/r05_zplan_lds_reader.txt) says k_zplan is bound by the ~14 K instructions
+             * of a frame's serial table work across its many resident waves, not by any one wave's trips */
             const int t = huf_read_table(L, P.huf + ((uint64_t)f * P.nbmax + k) * kHufTblWords, hs + hdr, hs + hdr, left, &hlog, lane);
             if (t < 0) return false;
             ps.huf_valid = true;
