@@ -1,5 +1,5 @@
 #!/bin/bash
-# the last collection of round 5 (after the zstd few-frames path): suite, smoke, zstd batch shapes, crossover, two ranks
+# the last collection of round 5 (after the zstd few-frames path; run again after the literal-section threshold): suite, smoke, zstd batch shapes, crossover, two ranks
 cd "$GRAFT_REPO_ROOT" && mkdir -p gpurun_out; ulimit -c 0; export HSA_ENABLE_COREDUMP=0
 T=r05
 out=gpurun_out/${T}_final_check.txt; : > $out
