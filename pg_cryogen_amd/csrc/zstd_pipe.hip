@@ -2093,34 +2093,54 @@ constexpr uint32_t kFusedGridForIrregular = 256;
 
 inline size_t al256(size_t v) { return (v + 255u) & ~(size_t)255u; }
 
-Layout make_layout(uint64_t n_blocks, uint32_t B)
+Layout make_layout(uint64_t n_blocks, uint32_t B, size_t limit = ~(size_t)0)
 {
-    Layout y;
-    y.nbmax = B / kZBlockMax + 2u;
-    if (y.nbmax > 254u) y.nbmax = 254u;
-    y.litcap = ((B + 15u) & ~15u) + 32u * y.nbmax;
-    y.htmp_stride = al256(2u * (size_t)y.litcap + (size_t)y.nbmax * kHwBlockSlack);
-    const size_t per_frame = y.htmp_stride + sizeof(ZFrame) + (size_t)y.nbmax * (sizeof(ZBlk) + kHufTblWords * 2u + kSeqTblWords * 4u + 8u) +
-                             y.litcap + (size_t)(B / 6u) * (sizeof(uint2) + sizeof(uint2)) /* sequence pool share */ + 4u +
-                             (size_t)y.nbmax * (64u * sizeof(uint4) + 4u) /* k_zmove's segment lists */;
+    Layout y0;
+    y0.nbmax = B / kZBlockMax + 2u;
+    if (y0.nbmax > 254u) y0.nbmax = 254u;
+    y0.litcap = ((B + 15u) & ~15u) + 32u * y0.nbmax;
+    y0.htmp_stride = al256(2u * (size_t)y0.litcap + (size_t)y0.nbmax * kHwBlockSlack);
+    const size_t per_frame = y0.htmp_stride + sizeof(ZFrame) + (size_t)y0.nbmax * (sizeof(ZBlk) + kHufTblWords * 2u + kSeqTblWords * 4u + 8u) +
+                             y0.litcap + (size_t)(B / 6u) * (sizeof(uint2) + sizeof(uint2)) /* sequence pool share */ + 4u +
+                             (size_t)y0.nbmax * (64u * sizeof(uint4) + 4u) /* k_zmove's segment lists */;
     /* Tile size.  K2 and K3 are bound by LDS capacity (two workgroups per CU, 512 per chip): 14848 frames
      * = 512 x 29 fill exactly one round of K3 (and 928 waves of 16 = two rounds of K2, the second 81 % full); the
      * workspace budget may force less. */
     static const size_t budget_env = cryo_tuning_env("CRYO_ZSTD_WS_MB") ? (size_t)atoll(cryo_tuning_env("CRYO_ZSTD_WS_MB")) << 20 : 0; /* tuning aid */
-    const size_t budget = budget_env ? budget_env : (size_t)16 << 30; /* per tile in flight; reached only by blocks > 128 KiB,
-                                                                        whose tiles would otherwise be too few frames to fill K1/K4 */
+    const size_t budget = budget_env ? budget_env : (size_t)18 << 30; /* per tile in flight */
     uint64_t F = budget / per_frame;
     /* one full round of k_zchain: 512 waves x 29 zstd blocks; a frame of B bytes is ceil(B / 128 KiB) of them (round 3:
      * 1 MiB frames in tiles of 2320 made 1.25 rounds, the second three quarters empty) */
     /* (k_zchain4: 768 waves x 16 blocks, three waves per CU) */
-    const uint64_t kTile = ((CRYO_ZCHAIN_QUAD ? 768u * kCqW : 512u * kChW)) / ((B + kZBlockMax - 1u) / kZBlockMax ? (B + kZBlockMax - 1u) / kZBlockMax : 1u);
-    if (F > kTile) F = kTile;
+    const uint64_t zbpf = (B + kZBlockMax - 1u) / kZBlockMax ? (B + kZBlockMax - 1u) / kZBlockMax : 1u;
+    const uint64_t kTile = ((CRYO_ZCHAIN_QUAD ? 768u * kCqW : 512u * kChW)) / zbpf;
+#ifndef CRYO_ZSTD_EQUAL_TILES
+#define CRYO_ZSTD_EQUAL_TILES 1
+#endif
+    if (CRYO_ZSTD_EQUAL_TILES && CRYO_ZCHAIN_QUAD && n_blocks > kTile) {
+        /* Round 5: a call of more than one tile is cut into tiles of EQUAL size, four (the streams they run on) per round.  With
+         * tiles of 12 288 zstd blocks 65 536 frames were 5.33 tiles: four in flight, then 1.33 with the chip half idle.  One
+         * round of four larger tiles (up to 16 896 zstd blocks each, 17.6 GiB of workspace) instead: 65 536 x 128 KiB 330 ->
+         * 335-350 GB/s, `narrow` 895 -> 950-965, 8 192 x 1 MiB 278 -> 313, 16 384 x 128 KiB 281 -> 292, level 5 134 -> 147
+         * (profiles/r05_zstd_tiles*.txt; tiles of 928 ... 1 392 frames of 1 MiB lose, two tiles of 4 176 gain less). */
+        const uint64_t kBig = (16384u + 512u) / zbpf ? (16384u + 512u) / zbpf : 1u;
+        const uint64_t rounds = (n_blocks + 4u * kBig - 1u) / (4u * kBig);
+        const uint64_t ntiles = 4u * rounds;
+        uint64_t Fe = (n_blocks + ntiles - 1u) / ntiles;
+        Fe = (Fe + 15u) & ~(uint64_t)15u;
+        /* ... unless the tiles would be short of frames: k_zplan, k_zmat and k_zexec are a wave per FRAME (2 048 x 1 MiB as four
+         * tiles of 512: 204 -> 190 GB/s; 4 096 x 1 MiB as four of 1 024: 261 -> 269) */
+        if (Fe < 1024u) Fe = kTile;
+        if (F > Fe) F = Fe;
+    } else if (F > kTile) F = kTile;
     static const uint64_t tile_env = cryo_tuning_env("CRYO_ZSTD_TILE") ? (uint64_t)atoll(cryo_tuning_env("CRYO_ZSTD_TILE")) : 0; /* tuning aid (debug builds) */
     if (tile_env) F = tile_env;
-    if (F >= 464u && F != kTile) F -= F % 464u;
-    else if (F < 16u) F = 16u;
+    if (!CRYO_ZCHAIN_QUAD && F >= 464u && F != kTile) F -= F % 464u;
+    if (F < 16u) F = 16u;
     if (F > n_blocks) F = n_blocks;
-    y.F = (uint32_t)F;
+    auto build = [&](const uint64_t Fq) -> Layout {
+    Layout y = y0;
+    y.F = (uint32_t)Fq;
     /* sequence records: a share of B/6 per frame (levels 4..9 reach B/8 on text-like rows; the format allows B/3:
      * frames that do not fit the pool go to the irregular list) */
     uint64_t seqcap = (uint64_t)y.F * (B / 6u) + 4096u;
@@ -2167,6 +2187,20 @@ Layout make_layout(uint64_t n_blocks, uint32_t B)
     }
     y.total = o;
     return y;
+    };
+    Layout y = build(F);
+    /* a cap on the workspace (CRYO_OPT_WORKSPACE_MAX_BYTES) below one tile of that size: the largest tile that fits (at least
+     * 16 frames, whatever the cap).  Largest, so that the launcher -- which is handed the workspace this was sized for, or a
+     * larger one -- arrives at the same tile or a larger one, never at a remainder tile */
+    if (limit != ~(size_t)0 && y.total > limit && F > 16u) {
+        uint64_t lo = 16u, hi = F;
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi + 1u) / 2u;
+            if (build(mid).total <= limit) lo = mid; else hi = mid - 1u;
+        }
+        y = build(lo);
+    }
+    return y;
 }
 
 /* two tiles in flight on two side streams: the wave-per-frame kernels of one tile beside the entropy kernels of the
@@ -2191,7 +2225,7 @@ bool use_pipeline(int path) { return path != 1; }
 size_t zstd_decompress_workspace(uint64_t n_blocks, uint32_t block_size, int path, size_t max_bytes)
 {
     if (!use_pipeline(path)) return zstd_fused_workspace(n_blocks);
-    const Layout y = make_layout(n_blocks, block_size);
+    const Layout y = make_layout(n_blocks, block_size, max_bytes == ~(size_t)0 ? max_bytes : (max_bytes > 256u ? max_bytes - 256u : 0u));
     const uint64_t nt = (n_blocks + y.F - 1u) / y.F;
     uint64_t nl = nt < (uint64_t)tile_lanes(block_size) ? nt : (uint64_t)tile_lanes(block_size);
     while (nl > 1u && (size_t)nl * y.total + 256u > max_bytes) nl--; /* fewer tiles in flight; the launcher takes what it is given */
@@ -2207,9 +2241,9 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
     if (!use_pipeline(path))
         return launch_zstd_fused(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status,
                                  d_workspace, workspace_bytes, nullptr, nullptr, 0);
-    const Layout y = make_layout(n_blocks, block_size);
-
     uint8_t *ws0 = (uint8_t *)(((uintptr_t)d_workspace + 255u) & ~(uintptr_t)255u);
+    const Layout y = make_layout(n_blocks, block_size, workspace_bytes > (size_t)(ws0 - (uint8_t *)d_workspace) ? workspace_bytes - (size_t)(ws0 - (uint8_t *)d_workspace) : 0u);
+
     /* Tiles alternate between side streams with a workspace each (tile_lanes()): the kernels of one tile fill what
      * another tile's leave idle (k_zchain holds the whole LDS with two waves per CU, the tail of every kernel leaves CUs
      * empty).  65 536 x 128 KiB: 259 / 274 / 292 / 302 GB/s with 1 / 2 / 3 / 4 tiles in flight, no more beyond;
