@@ -2090,6 +2090,7 @@ inline bool zstd_few_frames(uint64_t n_blocks, uint32_t B)
 }
 
 constexpr uint32_t kFusedGridForIrregular = 256;
+constexpr uint64_t kForkMaxZBlocks = 8192; /* calls of at most this many zstd blocks: one tile, its two entropy stages on two streams */
 
 inline size_t al256(size_t v) { return (v + 255u) & ~(size_t)255u; }
 
@@ -2117,12 +2118,14 @@ Layout make_layout(uint64_t n_blocks, uint32_t B, size_t limit = ~(size_t)0)
 #ifndef CRYO_ZSTD_EQUAL_TILES
 #define CRYO_ZSTD_EQUAL_TILES 1
 #endif
-    if (CRYO_ZSTD_EQUAL_TILES && CRYO_ZCHAIN_QUAD && n_blocks > kTile) {
+    if (CRYO_ZSTD_EQUAL_TILES && CRYO_ZCHAIN_QUAD && n_blocks * zbpf > kForkMaxZBlocks) {
         /* Round 5: a call of more than one tile is cut into tiles of EQUAL size, four (the streams they run on) per round.  With
          * tiles of 12 288 zstd blocks 65 536 frames were 5.33 tiles: four in flight, then 1.33 with the chip half idle.  One
          * round of four larger tiles (up to 16 896 zstd blocks each, 17.6 GiB of workspace) instead: 65 536 x 128 KiB 330 ->
          * 335-350 GB/s, `narrow` 895 -> 950-965, 8 192 x 1 MiB 278 -> 313, 16 384 x 128 KiB 281 -> 292, level 5 134 -> 147
-         * (profiles/r05_zstd_tiles*.txt; tiles of 928 ... 1 392 frames of 1 MiB lose, two tiles of 4 176 gain less). */
+         * (profiles/r05_zstd_tiles*.txt; tiles of 928 ... 1 392 frames of 1 MiB lose, two tiles of 4 176 gain less).  From 8 193
+         * zstd blocks on, i.e. where a call no longer runs its two entropy stages side by side (kForkMaxZBlocks; 12 288 frames as
+         * four tiles 283 -> 302 GB/s; below that one tile with the fork is best: 8 192 frames 251, as four tiles 192) */
         const uint64_t kBig = (16384u + 512u) / zbpf ? (16384u + 512u) / zbpf : 1u;
         const uint64_t rounds = (n_blocks + 4u * kBig - 1u) / (4u * kBig);
         const uint64_t ntiles = 4u * rounds;
@@ -2278,7 +2281,7 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
     /* calls of at most this many zstd blocks (frames x blocks per frame) run a tile's two entropy stages side by side: 3-6 %
      * less time from 1 to 4 096 frames, 5 % MORE at a full tile of 12 288 (profiles/r05_zstd_fork.txt; tuning aid:
      * CRYO_ZSTD_FORK_ZBLOCKS) */
-    static const uint64_t fork_max_zblocks = cryo_tuning_env("CRYO_ZSTD_FORK_ZBLOCKS") ? (uint64_t)atoll(cryo_tuning_env("CRYO_ZSTD_FORK_ZBLOCKS")) : 8192u;
+    static const uint64_t fork_max_zblocks = cryo_tuning_env("CRYO_ZSTD_FORK_ZBLOCKS") ? (uint64_t)atoll(cryo_tuning_env("CRYO_ZSTD_FORK_ZBLOCKS")) : kForkMaxZBlocks;
     uint64_t t = 0;
     for (uint64_t first = 0; first < n_blocks; first += y.F, t++) {
         const int l = (int)(t % (uint64_t)nl);
