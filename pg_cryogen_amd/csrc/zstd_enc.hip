@@ -866,15 +866,15 @@ __device__ uint32_t build_ctable(EncLds &L, uint8_t *dst, FseCt &ct, int fse_log
 struct SeqTabs { FseCt *prev; int rep[3]; int nrep[3]; bool built; /* this block built (or repeated) its three tables */ };
 
 /* literals + sequences -> compressed block body at dst; 0 = emit a raw block */
-__device__ uint32_t compress_sequences(EncLds &L, uint8_t *dst, uint8_t *ws, uint32_t nseq, uint32_t nlit,
+/* seqs / lits: what the match finder left (k_zstd_enc: in the workgroup's workspace; k_zent: in the block's slot);
+ * codes: 3 x kMaxSeq bytes of scratch for the LL / OF / ML codes */
+__device__ uint32_t compress_sequences(EncLds &L, uint8_t *dst, const uint2 *seqs, const uint8_t *lits, uint8_t *codes, uint32_t nseq, uint32_t nlit,
                                        uint32_t src_size, uint32_t long_pos, uint32_t long_kind, HufState &hs, SeqTabs &tb,
                                        bool disable_lit, uint32_t lane)
 {
     tb.nrep[0] = tb.rep[0]; tb.nrep[1] = tb.rep[1]; tb.nrep[2] = tb.rep[2];
     tb.built = false;
-    const uint2 *seqs = reinterpret_cast<const uint2 *>(ws + kWsSeq);
-    const uint8_t *lits = ws + kWsLit;
-    uint8_t *llc = ws + kWsLlc, *ofc = ws + kWsOfc, *mlc = ws + kWsMlc;
+    uint8_t *llc = codes, *ofc = codes + kMaxSeq, *mlc = codes + 2u * kMaxSeq;
     uint32_t op = compress_literals(L, dst, lits, nlit, hs, disable_lit, lane);
     if (lane == 0) {
         if (nseq < 128u) dst[op] = (uint8_t)nseq;
@@ -1107,8 +1107,89 @@ __device__ uint32_t block_fast(uint32_t *table, const CPar &cp, const uint8_t *b
 
 
 #include "zstd_dfast.h"
+#include "zstd_fastlds.h"
 #include "zstd_lazy.h"
 #include "zstd_opt.h"
+
+
+/* ------------------------------------------------------------ round 6: `fast` as two kernels (zstd_fastlds.h) */
+/* frame header of a one-segment or windowed frame of n bytes; returns its size */
+__device__ inline uint32_t write_frame_header(uint8_t *dst, uint32_t n, int wlog, uint32_t lane)
+{
+    const uint64_t wsize = 1ull << wlog;
+    const uint32_t single = wsize >= n ? 1u : 0u;
+    const uint32_t fcs = (n >= 256u) + (n >= 65536u + 256u);
+    uint32_t op = 5;
+    if (lane == 0) {
+        dst[0] = 0x28; dst[1] = 0xB5; dst[2] = 0x2F; dst[3] = 0xFD;
+        dst[4] = (uint8_t)((single << 5) + (fcs << 6));
+    }
+    if (!single) { if (lane == 0) dst[op] = (uint8_t)((wlog - 10) << 3); op++; }
+    if (fcs == 0u) { if (single) { if (lane == 0) dst[op] = (uint8_t)n; op++; } }
+    else if (fcs == 1u) { if (lane == 0) { dst[op] = (uint8_t)(n - 256u); dst[op + 1] = (uint8_t)((n - 256u) >> 8); } op += 2; }
+    else { if (lane == 0) { dst[op] = (uint8_t)n; dst[op + 1] = (uint8_t)(n >> 8); dst[op + 2] = (uint8_t)(n >> 16); dst[op + 3] = (uint8_t)(n >> 24); } op += 4; }
+    return op;
+}
+
+/* Match finder, 64 / LPB blocks per wave, persistent grid: block `first + i` -> slot i of the tile's workspace. */
+template <int LPB, bool PROF>
+__global__ void __launch_bounds__(64)
+k_zfind(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t first, uint32_t n_tile, int hlog, int mml,
+        int tlen, uint8_t *__restrict__ slots, uint64_t slot_stride, unsigned long long *stats)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t fl_lds[];
+    constexpr uint32_t kGroups = 64u / LPB;
+    const uint32_t lane = threadIdx.x & 63u;
+    FlGroup<LPB> g;
+    g.gl = lane & (LPB - 1u);
+    g.gbase = lane & ~(uint32_t)(LPB - 1u);
+    const uint32_t grp = lane / LPB;
+    lds8_t *lds = (lds8_t *)fl_lds + grp * ((fl_lds_bytes(hlog) + 15u) & ~15u);
+    const int mls = mml < 4 ? 4 : (mml > 7 ? 7 : mml);
+    const uint32_t step_size = (uint32_t)tlen + (tlen ? 0u : 1u) + 1u;
+    for (uint32_t i = blockIdx.x * kGroups + grp; i < n_tile; i += gridDim.x * kGroups)
+        fl_find_block<LPB, PROF>(lds, src_base + (first + i) * src_stride, n, hlog, mls, step_size, slots + (uint64_t)i * slot_stride, g, stats);
+}
+
+/* Entropy stage of one-block frames from what k_zfind left: one wave per frame, persistent grid; the code arrays live in
+ * the workgroup's own workspace. */
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4)))
+k_zent(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t first, uint32_t n_tile,
+       uint8_t *__restrict__ dst_base, uint64_t dst_stride, int wlog, int tlen, uint32_t *__restrict__ out_size,
+       int32_t *__restrict__ status, const uint8_t *__restrict__ slots, uint64_t slot_stride, uint8_t *wg_ws, uint64_t wg_stride)
+{
+    __shared__ __attribute__((aligned(16))) EncLds L;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint8_t *codes = wg_ws + (uint64_t)blockIdx.x * wg_stride;
+    for (uint32_t i = blockIdx.x; i < n_tile; i += gridDim.x) {
+        const uint64_t blk = first + i;
+        const uint8_t *src = src_base + blk * src_stride;
+        uint8_t *dst = dst_base + blk * dst_stride;
+        const uint8_t *slot = slots + (uint64_t)i * slot_stride;
+        uint32_t op = write_frame_header(dst, n, wlog, lane);
+        const FlHdr hd = *reinterpret_cast<const FlHdr *>(slot);
+        HufState hs;
+        hs.prev_valid = false; hs.next_new = false; hs.prof = nullptr; hs.t = 0; hs.strat = 1u;
+        SeqTabs tb;
+        tb.prev = reinterpret_cast<FseCt *>(codes + 3u * kMaxSeq); /* never read below `lazy` */
+        tb.rep[0] = tb.rep[1] = tb.rep[2] = 0;
+        const uint32_t csize = compress_sequences(L, dst + op + 3, reinterpret_cast<const uint2 *>(slot + kFlHdrBytes), slot + fl_lit_off(n), codes,
+                                                  uni(hd.nseq), uni(hd.nlit), n, uni(hd.long_pos), uni(hd.long_kind), hs, tb, tlen > 0, lane);
+        if (csize == 0u) {
+            const uint32_t h = 1u + (0u << 1) + (n << 3);
+            if (lane == 0) { dst[op] = (uint8_t)h; dst[op + 1] = (uint8_t)(h >> 8); dst[op + 2] = (uint8_t)(h >> 16); }
+            for (uint32_t k = lane; k < n; k += 64u) dst[op + 3u + k] = src[k];
+            op += 3u + n;
+        } else {
+            const uint32_t h = 1u + (2u << 1) + (csize << 3);
+            if (lane == 0) { dst[op] = (uint8_t)h; dst[op + 1] = (uint8_t)(h >> 8); dst[op + 2] = (uint8_t)(h >> 16); }
+            op += 3u + csize;
+        }
+        if (lane == 0) { out_size[blk] = op; status[blk] = CRYO_ST_OK; }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+constexpr size_t kZentWgBytes = (3u * (size_t)kMaxSeq + 3u * sizeof(FseCt) + 255u) & ~(size_t)255u;
 
 } // namespace
 
@@ -1246,7 +1327,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 ss.nlit += last_ll;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 if constexpr (PROF) hs.t = __builtin_amdgcn_s_memtime();
-                csize = compress_sequences(L, dst + op + 3, ws, ss.nseq, ss.nlit, bs, ss.long_pos, ss.long_kind, hs, tb,
+                csize = compress_sequences(L, dst + op + 3, reinterpret_cast<const uint2 *>(ws + kWsSeq), ws + kWsLit, ws + kWsLlc, ss.nseq, ss.nlit, bs, ss.long_pos, ss.long_kind, hs, tb,
                                            (finder == 0 || finder == 2) && tlen > 0 /* literals stay raw only for `fast` with a target length */, lane);
                 if constexpr (PROF) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_en += t - t_prev; t_prev = t; }
                 if (!first && csize < 25u) { /* RLE block for constant non-first blocks */
@@ -1356,12 +1437,48 @@ static size_t zstd_enc_stride(int hlog, int clog, bool two_tables, int strategy 
     return b;
 }
 
+/* round 6: `fast` with a table of at most 2^13 entries over one-block frames of at most 128 KiB runs as k_zfind + k_zent
+ * (zstd_fastlds.h).  A call is cut into tiles; a tile's blocks have a workspace slot each (sequences + literals). */
+struct FlPlan {
+    bool on = false;
+    int lpb = 64;
+    uint32_t tile = 0, find_grid = 0, ent_grid = 0, lds = 0;
+    size_t slot = 0, slots_bytes = 0, bytes = 0;
+};
+static FlPlan fl_plan(uint64_t n_blocks, uint32_t n, int strategy, int wlog, int hlog)
+{
+    FlPlan p;
+    static const bool off_env = cryo_tuning_env("CRYO_ZFL") && cryo_tuning_env("CRYO_ZFL")[0] == '0'; /* A/B aid: the one-kernel encoder */
+    if (off_env || strategy != 1 || hlog > (int)kFlMaxHlog || n > kFlMaxBlock || n < 4096u || (1ull << wlog) < n) return p;
+    static const int lpb_env = cryo_tuning_env("CRYO_ZFL_LPB") ? atoi(cryo_tuning_env("CRYO_ZFL_LPB")) : 0;
+    static const uint32_t tile_env = cryo_tuning_env("CRYO_ZFL_TILE") ? (uint32_t)atoi(cryo_tuning_env("CRYO_ZFL_TILE")) : 0u;
+    p.on = true;
+    p.lpb = lpb_env == 32 ? 32 : 64;
+    const uint32_t groups = 64u / (uint32_t)p.lpb;
+    p.lds = groups * ((fl_lds_bytes(hlog) + 15u) & ~15u);
+    uint32_t per_cu = (160u * 1024u) / ((p.lds + 511u) & ~511u);
+    if (per_cu * groups > 32u) per_cu = 32u / groups;
+    const uint32_t tile_cap = tile_env ? tile_env : 8192u;
+    p.tile = (uint32_t)(n_blocks < tile_cap ? n_blocks : tile_cap);
+    const uint32_t wgs = (p.tile + groups - 1u) / groups;
+    p.find_grid = wgs < 256u * per_cu ? wgs : 256u * per_cu;
+    p.ent_grid = p.tile < 4096u ? p.tile : 4096u;
+    p.slot = fl_slot_bytes(n);
+    p.slots_bytes = (size_t)p.tile * p.slot;
+    p.bytes = 2u * p.slots_bytes + (size_t)p.ent_grid * kZentWgBytes + 256u;
+    return p;
+}
+
 size_t zstd_compress_workspace(uint64_t n_blocks, int level, uint32_t block_size)
 {
     int wlog, hlog, mml, tlen, clog;
     bool dfast = false;
     int strategy = 1;
     if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast, &strategy)) return 256;
+    {
+        const FlPlan fp = fl_plan(n_blocks, block_size, strategy, wlog, hlog);
+        if (fp.on) return fp.bytes;
+    }
     const size_t stride = zstd_enc_stride(hlog, clog, strategy >= 2, strategy, mml, wlog);
     return (size_t)zstd_enc_grid(n_blocks, stride) * stride + 256;
 }
@@ -1381,6 +1498,54 @@ hipError_t launch_zstd_compress(hipStream_t s, const uint8_t *d_src, uint64_t sr
     bool dfast = false;
     int strategy = 1, slog = 0;
     if (!zstd_fast_cparams(level, block_size, &wlog, &hlog, &mml, &tlen, &clog, &dfast, &strategy, &slog)) return hipErrorNotSupported;
+    {
+        const FlPlan fp = fl_plan(n_blocks, block_size, strategy, wlog, hlog);
+        if (fp.on) {
+            if (workspace_bytes < fp.bytes) return hipErrorInvalidValue;
+            uint8_t *ws = (uint8_t *)d_workspace;
+            uint8_t *wg_ws = ws + 2u * fp.slots_bytes;
+            static const bool fl_stats_env = cryo_tuning_env("CRYO_ZFL_STATS") != nullptr; /* debugging aid */
+            unsigned long long *d_fst = nullptr;
+            if (fl_stats_env) {
+                if (hipMalloc((void **)&d_fst, 128) != hipSuccess) return hipErrorOutOfMemory;
+                (void)hipMemsetAsync(d_fst, 0, 128, s);
+            }
+            uint32_t t = 0;
+            for (uint64_t first = 0; first < n_blocks; first += fp.tile, t++) {
+                const uint32_t cnt = (uint32_t)(n_blocks - first < fp.tile ? n_blocks - first : fp.tile);
+                uint8_t *slots = ws + (t & 1u) * fp.slots_bytes;
+                const uint32_t groups = 64u / (uint32_t)fp.lpb;
+                const uint32_t wgs = (cnt + groups - 1u) / groups;
+                const uint32_t fgrid = wgs < fp.find_grid ? wgs : fp.find_grid;
+                if (fl_stats_env && fp.lpb == 32)
+                    hipLaunchKernelGGL((k_zfind<32, true>), dim3(fgrid), dim3(64), fp.lds, s, d_src, src_stride, block_size, first, cnt, hlog, mml, tlen,
+                                       slots, (uint64_t)fp.slot, d_fst);
+                else if (fl_stats_env)
+                    hipLaunchKernelGGL((k_zfind<64, true>), dim3(fgrid), dim3(64), fp.lds, s, d_src, src_stride, block_size, first, cnt, hlog, mml, tlen,
+                                       slots, (uint64_t)fp.slot, d_fst);
+                else if (fp.lpb == 32)
+                    hipLaunchKernelGGL((k_zfind<32, false>), dim3(fgrid), dim3(64), fp.lds, s, d_src, src_stride, block_size, first, cnt, hlog, mml, tlen,
+                                       slots, (uint64_t)fp.slot, d_fst);
+                else
+                    hipLaunchKernelGGL((k_zfind<64, false>), dim3(fgrid), dim3(64), fp.lds, s, d_src, src_stride, block_size, first, cnt, hlog, mml, tlen,
+                                       slots, (uint64_t)fp.slot, d_fst);
+                const uint32_t egrid = cnt < fp.ent_grid ? cnt : fp.ent_grid;
+                hipLaunchKernelGGL(k_zent, dim3(egrid), dim3(64), 0, s, d_src, src_stride, block_size, first, cnt, d_dst, dst_stride, wlog, tlen,
+                                   d_out_size, d_status, slots, (uint64_t)fp.slot, wg_ws, (uint64_t)kZentWgBytes);
+            }
+            if (fl_stats_env) {
+                unsigned long long h[16] = {0};
+                (void)hipMemcpyAsync(h, d_fst, 128, hipMemcpyDeviceToHost, s);
+                (void)hipStreamSynchronize(s);
+                (void)hipFree(d_fst);
+                fprintf(stderr, "[zfind] steps %llu, iterations %llu (%.2f per step), sequences %llu (%.2f steps per sequence)\n", h[0], h[1],
+                        h[0] ? (double)h[1] / h[0] : 0.0, h[2], h[2] ? (double)h[0] / h[2] : 0.0);
+                fprintf(stderr, "[zfind] cycles per sequence: input+hash %.0f  table+candidates %.0f  decide+commit %.0f  extension %.0f  literals+store %.0f  tail %.0f\n",
+                        (double)h[4] / h[2], (double)h[5] / h[2], (double)h[6] / h[2], (double)h[7] / h[2], (double)h[8] / h[2], (double)h[9] / h[2]);
+            }
+            return hipGetLastError();
+        }
+    }
     static const bool serial_only = cryo_tuning_env("CRYO_ZSTD_ENC") && cryo_tuning_env("CRYO_ZSTD_ENC")[0] == '1'; /* testing aid: the serial `fast` walk */
     const int finder = strategy >= 3 ? strategy : (dfast ? 1 : (serial_only ? 2 : 0)); /* 3 greedy, 4 lazy, 5 lazy2, 6 btlazy2 */
     /* search positions (dfast) / iterations (fast: two positions each) per step.  Measured on text-like rows, GB/s:
