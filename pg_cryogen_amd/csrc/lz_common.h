@@ -384,6 +384,38 @@ __device__ inline void stamp(Stats &st, int k)
 __device__ inline uint64_t ld64v(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ inline uint32_t ld32v(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
+/* Continuation of a forward match count from `done` bytes on: long matches (the zero gap of a cryo block is one match of
+ * ~110 KB) are compared 16 bytes per lane, two KiB per trip to memory, instead of one byte per lane (round 6:
+ * `zeros` 527 -> see profiles/r06_zstd_enc.txt); the last stretch in front of `end` goes 64 bytes per step. */
+__device__ inline uint32_t count_long(const uint8_t *fa, const uint8_t *fb, const uint8_t *end, uint32_t lane, uint32_t done)
+{
+    while (fa + done + 2048u <= end) {
+        uint4 a0, b0, a1, b1;
+        __builtin_memcpy(&a0, fa + done + 16u * lane, 16);
+        __builtin_memcpy(&b0, fb + done + 16u * lane, 16);
+        __builtin_memcpy(&a1, fa + done + 1024u + 16u * lane, 16);
+        __builtin_memcpy(&b1, fb + done + 1024u + 16u * lane, 16);
+        const uint32_t x0 = a0.x ^ b0.x, x1 = a0.y ^ b0.y, x2 = a0.z ^ b0.z, x3 = a0.w ^ b0.w;
+        const uint32_t y0 = a1.x ^ b1.x, y1 = a1.y ^ b1.y, y2 = a1.z ^ b1.z, y3 = a1.w ^ b1.w;
+        const unsigned long long m0 = wave_ballot((x0 | x1 | x2 | x3) != 0u), m1 = wave_ballot((y0 | y1 | y2 | y3) != 0u);
+        if (m0 | m1) {
+            const bool first = m0 != 0ull;
+            const uint32_t f = ctz64(first ? m0 : m1);
+            const uint32_t w0 = first ? x0 : y0, w1 = first ? x1 : y1, w2 = first ? x2 : y2, w3 = first ? x3 : y3;
+            const uint32_t fd = w0 ? ((uint32_t)__builtin_ctz(w0) >> 3) : (w1 ? 4u + ((uint32_t)__builtin_ctz(w1) >> 3) : (w2 ? 8u + ((uint32_t)__builtin_ctz(w2) >> 3) : 12u + ((uint32_t)__builtin_ctz(w3 | 0x80000000u) >> 3)));
+            return done + (first ? 0u : 1024u) + 16u * f + lane_get(fd, f);
+        }
+        done += 2048u;
+    }
+    for (;;) {
+        const bool inb = fa + done + lane < end;
+        const bool eq = inb && fa[done + lane] == fb[done + lane];
+        const unsigned long long neq = wave_ballot(!eq);
+        if (neq != 0ull) return done + ctz64(neq);
+        done += 64u;
+    }
+}
+
 /* forward and backward extension of a match in one trip to memory: bytes equal from fa/fb on (limited by
  * end) and bytes equal before ba/bb (at most blim: the library's catch-up loop); 64 bytes per step each */
 __device__ inline void count_both(const uint8_t *fa, const uint8_t *fb, const uint8_t *end, const uint8_t *ba,
@@ -396,16 +428,7 @@ __device__ inline void count_both(const uint8_t *fa, const uint8_t *fb, const ui
     const unsigned long long fne = wave_ballot(x0 != x1), bne = wave_ballot(y0 != y1);
     fwd = fne ? ctz64(fne) : 64u;
     back = bne ? ctz64(bne) : 64u;
-    if (!fne) {
-        uint32_t done = 64u;
-        for (;;) {
-            const bool inb = fa + done + lane < end;
-            const bool eq = inb && fa[done + lane] == fb[done + lane];
-            const unsigned long long neq = wave_ballot(!eq);
-            if (neq != 0ull) { fwd = done + ctz64(neq); break; }
-            done += 64u;
-        }
-    }
+    if (!fne) fwd = count_long(fa, fb, end, lane, 64u);
     if (!bne) {
         uint32_t done = 64u;
         for (;;) {

@@ -308,21 +308,27 @@ __device__ inline uint32_t distinct_prefix2(uint8_t *mark, uint32_t slot0, uint3
     return (w0 >= l && w1 >= l) ? l + 1u : l; /* the first loser stays when the lanes that won its slots come later */
 }
 
-/* ZSTD_compressBlock_fast over a table in global memory (hashLog > 14: level 2), many iterations of the search
- * loop per step -- the scheme of block_dfast_batch: an iteration looks at ip0 and ip1 = ip0 + 1 (reads both
- * slots, then writes both) and tests the repeat offset at ip0 + 2, then ip0, then ip1; no hit: both advance by
- * ((ip0 - anchor) >> 7) + stepSize.  (zstd_enc.hip's block_fast_batch does the same over an LDS table for
- * hashLog <= 14.) */
-/* TAB: uint32_t (the table in the workgroup's global workspace) or lds_u32_t (round 5 experiment: a 2^13-entry table in LDS,
- * k_zstd_enc<.., .., true>; profiles/r05_zstd_enc_lds.txt) */
-typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
-template <typename TAB>
-__device__ uint32_t block_fast_gbatch(TAB *table, uint8_t *mark, const CPar &cp, const uint8_t *base,
+/* ZSTD_compressBlock_fast over a table in global memory, many iterations of the search loop per step -- the scheme of
+ * block_dfast_batch: an iteration looks at ip0 and ip1 = ip0 + 1 (reads both slots, then writes both) and tests the repeat
+ * offset at ip0 + 2, then ip0, then ip1; no hit: both advance by ((ip0 - anchor) >> 7) + stepSize.
+ *
+ * Round 6: TWO trips to memory per sequence instead of three.  A table entry is index | tag << ib: the bits an index of
+ * this frame never uses hold a hash of the four bytes at that position (14 bits at 128 KiB, 11 at 1 MiB).  A candidate whose
+ * tag differs cannot match and is never read -- on `wide` a candidate is the last position that hashed to the slot, median
+ * age 6.9 KiB, and reading the bytes of 32 of them per step was a second trip and 45 % of the lines fetched
+ * (profiles/r06_zstd_enc.txt).  The repeat candidates' addresses do not depend on the table, so they ride with the slots
+ * (trip 1).  After it the first lane with a repeat hit (exact) or an equal tag (all but certain) is taken as the match and
+ * its verification word rides with the extension / tail loads (trip 2); a tag that lied (2^-14 per look-up) is struck out
+ * and the step is decided again.  A step that finds nothing is ONE trip. */
+__device__ inline bool wb_ok(uint32_t wb, uint32_t j, uint32_t iend) { return wb + 2u * j + 8u <= iend; }
+__device__ inline uint32_t fast_tag(uint32_t v4) { return v4 * 2654435761u; } /* its top bits are the tag */
+__device__ uint32_t block_fast_gbatch(uint32_t *table, uint8_t *mark, const CPar &cp, const uint8_t *base,
                                       const uint8_t *istart, uint32_t n, uint32_t *rep, uint8_t *ws, SeqStore &ss,
                                       uint32_t dict_limit, uint32_t lane, uint32_t W)
 {
     const int hlog = cp.hlog, mls = cp.mml < 4 ? 4 : (cp.mml > 7 ? 7 : cp.mml);
     const uint32_t step_size = (uint32_t)cp.tlen + (cp.tlen ? 0u : 1u) + 1u;
+    const uint32_t ib = (uint32_t)cp.ib, im = (1u << ib) - 1u; /* index bits of an entry; the tag lies above them */
     uint32_t ip = (uint32_t)(istart - base), anchor = ip;
     const uint32_t iend = ip + n, ilimit = iend - 8u;
     const uint32_t max_dist = 1u << cp.wlog;
@@ -347,56 +353,75 @@ __device__ uint32_t block_fast_gbatch(TAB *table, uint8_t *mark, const CPar &cp,
         have = false;
         const uint32_t h0 = hashs_v(v0, hlog, mls), h1 = hashs_v(v1, hlog, mls);
         valid = valid && lane < distinct_prefix2(mark, h0 & (kDfMark - 1u), h1 & (kDfMark - 1u), valid, lane);
-        const uint32_t mi0 = valid ? table[h0] : 0u, mi1 = valid ? table[h1] : 0u;
-        /* candidates in one trip; lanes without one read at ip.  rv: the byte in front of the repeat candidate, then its 4 bytes */
-        const bool rc = valid && off1 > 0u, c0 = valid && mi0 > prefix_idx, c1 = valid && mi1 > prefix_idx;
+        /* trip 1: the slots and the repeat candidates (rv: the byte in front of the repeat candidate, then its 4 bytes) */
+        const bool rc = valid && off1 > 0u;
+        const uint32_t e0 = valid ? table[h0] : 0u, e1 = valid ? table[h1] : 0u;
         const uint64_t rv = ld64v(base + (rc ? i0 + 1u - off1 : ip));
-        const uint32_t s0 = ld32v(base + (c0 ? mi0 : ip)), s1 = ld32v(base + (c1 ? mi1 : ip));
+        const uint32_t n0 = (i0 & im) | ((fast_tag((uint32_t)v0) >> ib) << ib), n1 = ((i0 + 1u) & im) | ((fast_tag((uint32_t)v1) >> ib) << ib);
+        const uint32_t mi0 = e0 & im, mi1 = e1 & im;
         const bool rephit = rc && (uint32_t)(rv >> 8) == (uint32_t)(v1 >> 8);
-        const bool hit0 = c0 && s0 == (uint32_t)v0, hit1 = c1 && s1 == (uint32_t)v1;
-        const unsigned long long repm = __ballot(rephit), m0m = __ballot(hit0);
-        const unsigned long long hitm = repm | m0m | __ballot(hit1);
-        const uint32_t T = hitm ? ctz64(hitm) : 63u;
-        const uint32_t ncommit = hitm ? T + 1u : (uint32_t)__builtin_popcountll(__ballot(valid));
-        if (lane < ncommit) table[h0] = i0;
-        asm volatile("" ::: "memory");
-        if (lane < ncommit) table[h1] = i0 + 1u;
-        if (!hitm) { ip += ncommit * st; continue; }
+        bool t0 = valid && mi0 > prefix_idx && ((e0 ^ n0) >> ib) == 0u, t1 = valid && mi1 > prefix_idx && ((e1 ^ n1) >> ib) == 0u;
+        const unsigned long long repm = __ballot(rephit);
+        const uint32_t nvalid = (uint32_t)__builtin_popcountll(__ballot(valid));
 
-        const uint32_t cur0 = __builtin_amdgcn_readlane(i0, T);
-        uint32_t mlen, offcode, m, known, blim;
-        if ((repm >> T) & 1ull) {
-            const uint32_t rlo = __builtin_amdgcn_readlane((uint32_t)rv, T), vlo = __builtin_amdgcn_readlane((uint32_t)v1, T);
-            const uint32_t b = ((rlo ^ vlo) & 0xFFu) == 0u ? 1u : 0u; /* ip2[-1] == repMatch[-1] */
-            ip = cur0 + 2u - b;
-            m = ip - off1;
-            known = 4u + b;
-            blim = 0;
-            offcode = 0;
-        } else {
-            if ((m0m >> T) & 1ull) { ip = cur0; m = __builtin_amdgcn_readlane(mi0, T); }
-            else { ip = cur0 + 1u; m = __builtin_amdgcn_readlane(mi1, T); }
-            off2 = off1;
-            off1 = ip - m;
-            offcode = off1 + 2u;
-            known = 4u;
-            const uint32_t la = ip - anchor, lm = m - prefix_idx;
-            blim = la < lm ? la : lm;
+        uint32_t T = 63u, cur0 = 0, mlen = 0, offcode = 0, m = 0, known = 0, blim = 0, fwd = 0, back = 0, r1s = 0, seq_ip = 0;
+        uint64_t A = 0, B = 0, vas = 0;
+        bool hit = false, isrep = false;
+        for (;;) { /* decided again only when a tag lied */
+            const unsigned long long m0m = __ballot(t0), m1m = __ballot(t1);
+            const unsigned long long hitm = repm | m0m | m1m;
+            if (!hitm) break;
+            T = ctz64(hitm);
+            cur0 = __builtin_amdgcn_readlane(i0, T);
+            uint32_t vword;
+            if ((repm >> T) & 1ull) {
+                const uint32_t rlo = __builtin_amdgcn_readlane((uint32_t)rv, T), vlo = __builtin_amdgcn_readlane((uint32_t)v1, T);
+                const uint32_t b = ((rlo ^ vlo) & 0xFFu) == 0u ? 1u : 0u; /* ip2[-1] == repMatch[-1] */
+                seq_ip = cur0 + 2u - b;
+                m = seq_ip - off1;
+                known = 4u + b;
+                blim = 0;
+                isrep = true;
+                vword = 0;
+            } else {
+                if ((m0m >> T) & 1ull) { seq_ip = cur0; m = __builtin_amdgcn_readlane(mi0, T); vword = __builtin_amdgcn_readlane((uint32_t)v0, T); }
+                else { seq_ip = cur0 + 1u; m = __builtin_amdgcn_readlane(mi1, T); vword = __builtin_amdgcn_readlane((uint32_t)v1, T); }
+                known = 4u;
+                const uint32_t la = seq_ip - anchor, lm = m - prefix_idx;
+                blim = la < lm ? la : lm;
+                isrep = false;
+            }
+            /* trip 2: the verification word with the match extension and everything the sequence's tail needs, whatever
+             * the match length turns out to be (below 64 bytes more): a window of the input behind the known part of
+             * the match -- lane j reads 8 bytes at wb + 2j (A) and wb + 2j + 1 (B), wb = ip + known - 2 -- serves the
+             * bytes at the end of the match (ip' - 2 for the complementary insertion, ip' for the immediate-repeat
+             * check), the next step's search input and the next literal run; lane j also reads the immediate-repeat
+             * candidate for a match ending at ip + known + j (the second offset after this sequence: off1 for a new
+             * offset, off2 for a repeat). */
+            const uint32_t o2 = isrep ? off2 : off1;
+            const uint32_t wb = seq_ip + known - 2u;
+            const bool win_a = wb + 2u * lane + 8u <= iend, win_b = wb + 2u * lane + 9u <= iend;
+            const uint32_t sver = ld32v(base + m);
+            A = ld64v(base + (win_a ? wb + 2u * lane : seq_ip));
+            B = ld64v(base + (win_b ? wb + 2u * lane + 1u : seq_ip));
+            r1s = ld32v(base + ((o2 > 0u && seq_ip + known + lane + 4u <= iend) ? seq_ip + known + lane - o2 : seq_ip));
+            vas = ld64v(base + cur0 + 2u);
+            count_both(base + seq_ip + known, base + m + known, base + iend, base + seq_ip, base + m, blim, lane, fwd, back);
+            if (isrep || uni(sver) == vword) { hit = true; break; }
+            /* the tag lied: strike this candidate out and decide again */
+            if (lane == T) { if ((m0m >> T) & 1ull) t0 = false; else t1 = false; }
         }
-        /* Match extension, and with it everything the sequence's tail needs, whatever the match length turns out to
-         * be (below 64 bytes more): a window of the input behind the known part of the match -- lane j reads 8 bytes
-         * at wb + 2j (A) and wb + 2j + 1 (B), wb = ip + known - 2 -- serves the bytes at the end of the match (ip' - 2
-         * for the complementary insertion, ip' for the immediate-repeat check), the next step's search input and
-         * the next literal run; lane j also reads the immediate-repeat candidate for a match ending at ip + known + j. */
-        const uint32_t wb = ip + known - 2u;
-        const bool win_a = wb + 2u * lane + 8u <= iend, win_b = wb + 2u * lane + 9u <= iend;
-        const uint64_t A = ld64v(base + (win_a ? wb + 2u * lane : ip)), B = ld64v(base + (win_b ? wb + 2u * lane + 1u : ip));
-        const uint32_t r1s = ld32v(base + ((off2 > 0u && ip + known + lane + 4u <= iend) ? ip + known + lane - off2 : ip));
-        const uint64_t vas = ld64v(base + cur0 + 2u);
-        uint32_t fwd, back;
-        count_both(base + ip + known, base + m + known, base + iend, base + ip, base + m, blim, lane, fwd, back);
+        {
+            const uint32_t ncommit = hit ? T + 1u : nvalid;
+            if (lane < ncommit) table[h0] = n0;
+            asm volatile("" ::: "memory");
+            if (lane < ncommit) table[h1] = n1;
+            if (!hit) { ip += ncommit * st; continue; }
+        }
+        if (isrep) offcode = 0;
+        else { off2 = off1; off1 = seq_ip - m; offcode = off1 + 2u; }
         mlen = known + fwd + back;
-        ip -= back;
+        ip = seq_ip - back;
         const uint32_t ll = ip - anchor, seq_anchor = anchor;
         ip += mlen;
         anchor = ip;
@@ -414,20 +439,23 @@ __device__ uint32_t block_fast_gbatch(TAB *table, uint8_t *mark, const CPar &cp,
             if (!(off2 > 0u && r0 == r1)) {
                 const uint64_t va = uni64(vas), vb = uni64(win64(fwd));
                 store_seq_pre(ws, ss, ll, litv, base + seq_anchor, offcode, mlen - 3u, lane);
-                if (lane == 0) { table[hashs_v(va, hlog, mls)] = cur0 + 2u; table[hashs_v(vb, hlog, mls)] = ip - 2u; }
+                if (lane == 0) {
+                    table[hashs_v(va, hlog, mls)] = ((cur0 + 2u) & im) | ((fast_tag((uint32_t)va) >> ib) << ib);
+                    table[hashs_v(vb, hlog, mls)] = ((ip - 2u) & im) | ((fast_tag((uint32_t)vb) >> ib) << ib);
+                }
                 /* next step: lane k looks at ip + k * step_size (and + 1) */
                 const bool nv = lane < W && ip + lane * step_size + 1u < ilimit;
-                const uint32_t t0 = te + lane * step_size;
-                const bool inw = t0 + 1u <= 127u;
-                v0n = win64(inw ? t0 : 0u);
-                v1n = win64(inw ? t0 + 1u : 0u);
+                const uint32_t t0w = te + lane * step_size;
+                const bool inw = t0w + 1u <= 127u;
+                v0n = win64(inw ? t0w : 0u);
+                v1n = win64(inw ? t0w + 1u : 0u);
                 if (nv && !inw) { v0n = ld64v(base + ip + lane * step_size); v1n = ld64v(base + ip + lane * step_size + 1u); }
                 if (!nv) { v0n = 0ull; v1n = 0ull; }
                 /* next literal run: byte at ip + lane = window position te + lane, inside A[j] for 2j <= t <= 2j + 7 */
                 {
                     const uint32_t t = te + lane, j = (t >> 1) < 63u ? (t >> 1) : 63u;
                     const uint64_t a = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(A >> 32), (int)j, 64) << 32) | (uint32_t)__shfl((int)(uint32_t)A, (int)j, 64);
-                    const bool ok = wb + 2u * j + 8u <= iend; /* lane j's A was a real window read */
+                    const bool ok = wb_ok(seq_ip + known - 2u, j, iend); /* lane j's A was a real window read */
                     uint32_t byte = (uint32_t)(a >> (8u * (t - 2u * j))) & 0xFFu;
                     if (!ok && ip + lane < iend) byte = base[ip + lane];
                     litv = ip + lane < iend ? byte : 0u;
@@ -449,7 +477,10 @@ __device__ uint32_t block_fast_gbatch(TAB *table, uint8_t *mark, const CPar &cp,
             if (first) {
                 const uint64_t va = uni64(vav), vb = uni64(vbv);
                 store_seq_pre(ws, ss, ll, litv, base + seq_anchor, offcode, mlen - 3u, lane);
-                if (lane == 0) { table[hashs_v(va, hlog, mls)] = cur0 + 2u; table[hashs_v(vb, hlog, mls)] = ip - 2u; }
+                if (lane == 0) {
+                    table[hashs_v(va, hlog, mls)] = ((cur0 + 2u) & im) | ((fast_tag((uint32_t)va) >> ib) << ib);
+                    table[hashs_v(vb, hlog, mls)] = ((ip - 2u) & im) | ((fast_tag((uint32_t)vb) >> ib) << ib);
+                }
                 first = false;
             }
             litv = litn;
@@ -458,7 +489,7 @@ __device__ uint32_t block_fast_gbatch(TAB *table, uint8_t *mark, const CPar &cp,
             const uint32_t t = off2; off2 = off1; off1 = t;
             {
                 const uint64_t v = ld64u(base + ip);
-                if (lane == 0) table[hashs_v(v, hlog, mls)] = ip;
+                if (lane == 0) table[hashs_v(v, hlog, mls)] = (ip & im) | ((fast_tag((uint32_t)v) >> ib) << ib);
             }
             store_seq_pre(ws, ss, 0, 0, base + anchor, 0, rlen - 3u, lane);
             ip += rlen;
