@@ -82,8 +82,11 @@ static int evictable_slots(void)
     return n;
 }
 
+/* iter: the scan's iterator -- pages of chains read or served from the cache are struck from it (reference cache.c:174,
+ * 235-242); ahead: entries from this index on strike theirs from `iter_ahead` instead (the read-ahead of cryo_read_data_rel
+ * looks ahead in a copy of the iterator: what the scan has not asked for yet stays in the scan's own set) */
 static CryoError load_blocks(CryoRel *rel, SeqScanIterator *iter, const BlockNumber *blocks, int k,
-                             CacheEntry *results, CryoError *errors)
+                             CacheEntry *results, CryoError *errors, int ahead, SeqScanIterator *iter_ahead)
 {
     /* gather the chains of every missing block, then ONE decompress call per method.
      *
@@ -109,6 +112,7 @@ static CryoError load_blocks(CryoRel *rel, SeqScanIterator *iter, const BlockNum
 
     for (i = 0; i < k; i++) {
         int s;
+        SeqScanIterator *it = i >= ahead ? iter_ahead : iter;
         slot_of[i] = pinned_by[i] = InvalidCacheEntry;
         errors[i] = CRYO_ERR_SUCCESS;
         if (rel->ops->nblocks(rel->handle) <= blocks[i] || blocks[i] == CRYO_META_PAGE) {
@@ -121,7 +125,7 @@ static CryoError load_blocks(CryoRel *rel, SeqScanIterator *iter, const BlockNum
             n_hits++; slots[s].ts = ++tick; results[i] = s;
             if (!slots[s].pinned) { slots[s].pinned = true; pinned_by[i] = s; }
             /* the cached block's pages must not be handed out again (cache.c:235-242,290-292) */
-            for (j = 0; j < slots[s].nblocks; j++) cryo_seqscan_iter_exclude(iter, slots[s].blocks[j], true);
+            for (j = 0; j < slots[s].nblocks; j++) cryo_seqscan_iter_exclude(it, slots[s].blocks[j], true);
             continue;
         }
         n_misses++;
@@ -139,7 +143,7 @@ static CryoError load_blocks(CryoRel *rel, SeqScanIterator *iter, const BlockNum
              * passes false here and its regression output pins the resulting internal error
              * (expected/pg_cryogen.out:166); a page the iterator already handed out is
              * harmless (it reads as WRONG_STARTING_BLOCK), so it is tolerated here */
-            for (j = 1; j < nb; j++) cryo_seqscan_iter_exclude(iter, tmp_blocks[j], true);
+            for (j = 1; j < nb; j++) cryo_seqscan_iter_exclude(it, tmp_blocks[j], true);
             csz[i] = (uint32_t)cs;
             /* claim the slot now (pinned for the duration of the batch so a later miss cannot evict it) */
             memcpy(sl->blocks, tmp_blocks, (size_t)nb * sizeof *tmp_blocks);
@@ -213,14 +217,104 @@ static CryoError load_blocks(CryoRel *rel, SeqScanIterator *iter, const BlockNum
 CryoError cryo_read_data_batch(CryoRel *rel, const BlockNumber *blocks, int k, CacheEntry *results, CryoError *errors)
 {
     if (k <= 0) return CRYO_ERR_SUCCESS;
-    return load_blocks(rel, NULL, blocks, k, results, errors);
+    return load_blocks(rel, NULL, blocks, k, results, errors, k, NULL);
 }
 
-CryoError cryo_read_data_rel(CryoRel *rel, void *iter, BlockNumber block, CacheEntry *result)
+/* strikes the continuation pages of the chain that starts at page b from `iter` (header looks only, no decode) */
+static void exclude_chain(CryoRel *rel, SeqScanIterator *iter, BlockNumber b, BlockNumber next)
 {
+    uint32 guard = 0;
+    while (BlockNumberIsValid(next) && next < rel->ops->nblocks(rel->handle) && guard++ < max_chain) {
+        const CryoPageHeader *q;
+        BlockNumber nn;
+        bool mine;
+        cryo_seqscan_iter_exclude(iter, next, true);
+        q = (const CryoPageHeader *)rel->ops->read_page(rel->handle, next);
+        if (!q) break;
+        mine = q->first == b;
+        nn = q->next;
+        if (rel->ops->release_page) rel->ops->release_page(rel->handle, next);
+        if (!mine) break;
+        next = nn;
+    }
+}
+
+/* pops page numbers from `iter` until `want` of them start a chain (cheap header looks); pages that are empty or belong to
+ * another chain are skipped, every chain's continuation pages are struck from `iter`.  *eof: the relation ended first. */
+static int next_block_starts(CryoRel *rel, SeqScanIterator *iter, int want, BlockNumber *cand, bool *eof)
+{
+    int nc = 0;
+    *eof = false;
+    while (nc < want) {
+        const BlockNumber b = cryo_seqscan_iter_next(iter);
+        const CryoPageHeader *pg;
+        BlockNumber first, next;
+        bool empty;
+        if (!BlockNumberIsValid(b) || b >= rel->ops->nblocks(rel->handle)) { *eof = true; break; }
+        pg = (const CryoPageHeader *)rel->ops->read_page(rel->handle, b);
+        if (!pg) continue;
+        empty = pg->base.pd_upper == 0; first = pg->first; next = pg->next;
+        if (rel->ops->release_page) rel->ops->release_page(rel->handle, b);
+        if (empty || first != b) continue; /* empty page / continuation page */
+        exclude_chain(rel, iter, b, next); /* now, so that they are not offered as candidates */
+        cand[nc++] = b;
+    }
+    return nc;
+}
+
+/*
+ * The reference's entry point (cache.c:244-297): one block per call, which is all the unchanged table AM ever asks for
+ * (pg_cryogen.c:262-265).  A device call pays off from a handful of blocks on (crossover table), so a
+ * MISS of a sequential scan -- the AM passes its iterator -- also loads the next block starts the scan is going to ask
+ * for, up to pg_cryogen.gpu_readahead_blocks in all (and never more than half the slots that may be evicted), with the ONE
+ * codec call load_blocks makes per method; the scan's next calls are hits.  The look-ahead walks a COPY of the iterator:
+ * the scan's own set changes exactly as it would without read-ahead (the block asked for loses its continuation pages,
+ * nothing else), and a scan that stops early (LIMIT) has wasted at most K - 1 decodes.
+ */
+CryoError cryo_read_data_rel(CryoRel *rel, void *iter_, BlockNumber block, CacheEntry *result)
+{
+    SeqScanIterator *iter = iter_;
     CryoError err = CRYO_ERR_SUCCESS;
+    int k = cryo_gpu_readahead_blocks_guc;
     *result = InvalidCacheEntry;
-    (void)load_blocks(rel, (SeqScanIterator *)iter, &block, 1, result, &err);
+    {
+        const int room = evictable_slots() / 2;
+        if (k > room) k = room;
+    }
+    if (iter && k > 1 && block != CRYO_META_PAGE && block < rel->ops->nblocks(rel->handle) &&
+        find_slot(rel->relid, block) == InvalidCacheEntry) {
+        const CryoPageHeader *pg = (const CryoPageHeader *)rel->ops->read_page(rel->handle, block);
+        BlockNumber first = InvalidBlockNumber, next = InvalidBlockNumber;
+        bool start = false;
+        if (pg) {
+            start = pg->base.pd_upper != 0 && pg->first == block;
+            first = pg->first; next = pg->next;
+            if (rel->ops->release_page) rel->ops->release_page(rel->handle, block);
+        }
+        (void)first;
+        if (start) {
+            SeqScanIterator *look = cryo_seqscan_iter_clone(iter);
+            BlockNumber *cand = malloc((size_t)k * sizeof *cand);
+            CacheEntry *res = malloc((size_t)k * sizeof *res);
+            CryoError *errs = malloc((size_t)k * sizeof *errs);
+            if (look && cand && res && errs) {
+                bool eof;
+                int nc = 1, i;
+                cand[0] = block;
+                exclude_chain(rel, look, block, next);
+                nc += next_block_starts(rel, look, k - 1, cand + 1, &eof);
+                (void)load_blocks(rel, iter, cand, nc, res, errs, 1, look);
+                /* what went wrong with a block nobody asked for yet is reported when it is asked for */
+                for (i = 1; i < nc; i++) (void)errs[i];
+                *result = res[0];
+                err = errs[0];
+                cryo_seqscan_iter_free(look); free(cand); free(res); free(errs);
+                return err;
+            }
+            cryo_seqscan_iter_free(look); free(cand); free(res); free(errs);
+        }
+    }
+    (void)load_blocks(rel, iter, &block, 1, result, &err, 1, NULL);
     return err;
 }
 
@@ -246,40 +340,12 @@ int cryo_scan_next_batch(CryoRel *rel, void *iter_, int k, BlockNumber *starts, 
         if (k > room) k = room > 0 ? room : 1;
     }
     while (got < k) {
-        int want = k - got, nc = 0, i;
-        /* candidates whose first page really starts a chain (cheap header look, no decode) */
-        while (nc < want) {
-            const BlockNumber b = cryo_seqscan_iter_next(iter);
-            const CryoPageHeader *pg;
-            if (!BlockNumberIsValid(b) || b >= rel->ops->nblocks(rel->handle)) { want = nc; break; }
-#define RELEASE(x) do { if (rel->ops->release_page) rel->ops->release_page(rel->handle, (x)); } while (0)
-            pg = (const CryoPageHeader *)rel->ops->read_page(rel->handle, b);
-            if (!pg) continue;
-            if (pg->base.pd_upper == 0 || pg->first != b) { RELEASE(b); continue; } /* empty page / continuation page */
-            {
-                /* exclude this chain's continuation pages now so they are not offered as candidates */
-                BlockNumber nb = pg->next;
-                uint32 guard = 0;
-                RELEASE(b);
-                while (BlockNumberIsValid(nb) && nb < rel->ops->nblocks(rel->handle) && guard++ < max_chain) {
-                    const CryoPageHeader *q;
-                    BlockNumber nn;
-                    bool mine;
-                    cryo_seqscan_iter_exclude(iter, nb, true);
-                    q = (const CryoPageHeader *)rel->ops->read_page(rel->handle, nb);
-                    if (!q) break;
-                    mine = q->first == b;
-                    nn = q->next;
-                    RELEASE(nb);
-                    if (!mine) break;
-                    nb = nn;
-                }
-            }
-#undef RELEASE
-            cand[nc++] = b;
-        }
+        int want = k - got, nc, i;
+        bool eof;
+        nc = next_block_starts(rel, iter, want, cand, &eof);
+        if (eof) want = nc;
         if (nc == 0) break;
-        (void)load_blocks(rel, iter, cand, nc, res, errs);
+        (void)load_blocks(rel, iter, cand, nc, res, errs, nc, NULL);
         for (i = 0; i < nc; i++) { starts[got] = cand[i]; entries[got] = res[i]; errors[got] = errs[i]; got++; }
         if (want < k - (got - nc)) break; /* hit the end of the relation */
     }

@@ -30,6 +30,7 @@ int cryo_gpu_device_guc = 0;
 int cryo_gpu_count_guc = 1;
 int cryo_gpu_pool_mb_guc = 0;
 int cryo_gpu_workspace_keep_mb_guc = 1024; /* device workspace a backend keeps between calls (-1: everything) */
+int cryo_gpu_readahead_blocks_guc = 8;    /* cryo blocks a sequential scan's cache miss decodes with one codec call (1: only the block asked for) */
 Size cryo_blcksz = (Size)1 << 20; /* CRYO_BLCKSZ, reference storage.h:18 */
 
 /* ---------------- codec binding ---------------- */
@@ -187,6 +188,9 @@ void cryo_define_compression_gucs(void)
                             NULL, &cryo_gpu_pool_mb_guc, 0, 0, 262144, PGC_USERSET, 0, NULL, NULL, NULL);
     DefineCustomIntVariable("pg_cryogen.gpu_workspace_keep_mb", "GPU workspace this backend keeps between codec calls (MiB; -1 = everything a call ever needed).",
                             NULL, &cryo_gpu_workspace_keep_mb_guc, 1024, -1, 262144, PGC_USERSET, 0, NULL, NULL, NULL);
+    DefineCustomIntVariable("pg_cryogen.gpu_readahead_blocks",
+                            "Cryo blocks a sequential scan's cache miss decodes with one codec call (1 = only the block asked for).",
+                            NULL, &cryo_gpu_readahead_blocks_guc, 8, 1, 64, PGC_USERSET, 0, NULL, NULL, NULL);
 #else
     /* no GUC machinery without PostgreSQL: the variables keep the reference's defaults */
     compression_method_guc = COMP_ZSTD;

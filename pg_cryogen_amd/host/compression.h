@@ -47,6 +47,7 @@ extern int cryo_gpu_count_guc;
 /* device-resident pool of decoded blocks, MiB over all GPUs of the backend (additive GUC pg_cryogen.gpu_pool_mb, default 0 = off) */
 extern int cryo_gpu_pool_mb_guc;
 extern int cryo_gpu_workspace_keep_mb_guc; /* pg_cryogen.gpu_workspace_keep_mb (default 1024, -1 = keep everything) */
+extern int cryo_gpu_readahead_blocks_guc;  /* pg_cryogen.gpu_readahead_blocks (default 8, 1 = off): host/cache.c, cryo_read_data_rel */
 /* bytes the codec moved towards the device / back, blocks served from the pool / decoded (0 when no GPU codec is bound) */
 void cryo_host_transfer_counters(uint64_t *h2d_bytes, uint64_t *d2h_bytes, uint64_t *pool_hits, uint64_t *pool_misses);
 

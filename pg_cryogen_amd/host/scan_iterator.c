@@ -77,3 +77,15 @@ bool cryo_seqscan_iter_exclude(SeqScanIterator *it, BlockNumber block, bool miss
 }
 
 int cryo_seqscan_iter_nranges(const SeqScanIterator *it) { return it->n; }
+
+SeqScanIterator *cryo_seqscan_iter_clone(const SeqScanIterator *it)
+{
+    SeqScanIterator *c = calloc(1, sizeof *c);
+    if (!c) return NULL;
+    c->cap = it->n > 8 ? it->n : 8;
+    c->r = malloc((size_t)c->cap * sizeof *c->r);
+    if (!c->r) { free(c); return NULL; }
+    memcpy(c->r, it->r, (size_t)it->n * sizeof *c->r);
+    c->n = it->n;
+    return c;
+}

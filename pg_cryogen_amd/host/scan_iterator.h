@@ -26,5 +26,7 @@ bool cryo_seqscan_iter_exclude(SeqScanIterator *iter, BlockNumber block, bool mi
  * do this, which its regression output pins as "LIMIT 3 returns 1 row" (expected/pg_cryogen.out:121-125) */
 void cryo_seqscan_iter_reset(SeqScanIterator *iter);
 int cryo_seqscan_iter_nranges(const SeqScanIterator *iter);
+/* addition: a copy of the set, for looking ahead without consuming (cache.c: the read-ahead inside cryo_read_data_rel) */
+SeqScanIterator *cryo_seqscan_iter_clone(const SeqScanIterator *iter);
 
 #endif

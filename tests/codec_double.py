@@ -16,6 +16,7 @@ class OracleCodecOps:
         self.stock = oracle_lib.StockLibs()
         self.compress_calls = 0
         self.decompress_calls = 0
+        self.blocks_decompressed = 0
         self._bound = host.BOUND_FN(self.bound)
         self._comp = host.COMPRESS_FN(self.compress)
         self._decomp = host.DECOMPRESS_FN(self.decompress)
@@ -40,6 +41,7 @@ class OracleCodecOps:
 
     def decompress(self, ctx, method, srcs, sizes, n, dst, bs, status):
         self.decompress_calls += 1
+        self.blocks_decompressed += n
         for i in range(n):
             comp = np.ctypeslib.as_array(C.cast(srcs[i], C.POINTER(C.c_uint8)), (sizes[i],))
             r, out = (self.ora.lz4_decompress if method == 0 else self.ora.zstd_decompress)(comp, bs)

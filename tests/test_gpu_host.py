@@ -61,6 +61,39 @@ def test_gpu_copy_10k_int4_lz4_roundtrip(HG, oracle):
     L.cryo_memrel_destroy(mem)
 
 
+def test_gpu_unchanged_am_scan_decodes_k_blocks_per_codec_call(HG, oracle):
+    """the reference's own scan loop (pg_cryogen.c:250-275) -- one iterator pop, one cryo_read_data
+    per block -- over the 35-block table of config 1.  A miss loads the next block starts with the same device call
+    (pg_cryogen.gpu_readahead_blocks): codec calls = ceil(35 / K), bytes of every block == what was written."""
+    L, errors = HG
+    rows = [struct.pack("<i", i) for i in range(1, 10001)]
+    mem, rel, blocks, firsts = _load(L, rows, 1, host.COMP_LZ4, batch=16)
+    assert len(blocks) == 35
+    guc = C.c_int.in_dll(L, "cryo_gpu_readahead_blocks_guc")
+    for k in (8, 1, 5):
+        L.cryo_cache_configure(16)                       # the reference's cache size (cache.c:17)
+        guc.value = k
+        it = L.cryo_seqscan_iter_create()
+        calls0 = L.cryo_cache_codec_calls()
+        got = []
+        while True:
+            b = L.cryo_seqscan_iter_next(it)
+            if L.cryo_memrel_nblocks(mem) <= b:
+                break
+            e = C.c_int(-1)
+            err = L.cryo_read_data(C.byref(rel), it, b, C.byref(e))
+            if err == host.CRYO_ERR_EMPTY_BLOCK:
+                continue
+            assert err == host.CRYO_ERR_SUCCESS, (b, err)
+            got.append(bytes(np.ctypeslib.as_array(C.cast(L.cryo_cache_get_data(e.value), C.POINTER(C.c_uint8)), (1 << 20,))))
+        L.cryo_seqscan_iter_free(it)
+        assert got == blocks
+        assert L.cryo_cache_codec_calls() - calls0 == -(-35 // k), k
+    guc.value = 8
+    assert not errors
+    L.cryo_memrel_destroy(mem)
+
+
 def test_gpu_reads_chains_written_by_stock_libraries(HG, oracle):
     """a stock pg_cryogen wrote these pages with liblz4 / libzstd; the GPU decoder reads them"""
     L, errors = HG

@@ -342,6 +342,95 @@ def test_seqscan_read_ahead_in_iterator_order(H):
     L.cryo_memrel_destroy(mem)
 
 
+def _mixed_chain_table(L, rng, relid=7):
+    """nine cryo blocks: multi-page chains interleaved with single-page ones, one reserved-but-unwritten page"""
+    mem = L.cryo_memrel_create()
+    rel = host.CryoRel()
+    L.cryo_memrel_bind(mem, relid, C.byref(rel))
+    all_rows, firsts = [], []
+    for b in range(9):
+        if b % 2:   # incompressible rows -> ~15-page chain
+            rows = [struct.pack("<i", 1000 * b + i) + rng.integers(0, 256, 400, dtype=np.uint8).tobytes() for i in range(290)]
+        else:
+            rows = [struct.pack("<i", 1000 * b + i) for i in range(290)]
+        blk = pack_rows(L, rows, 2 if b % 2 else 1, 131072)
+        assert len(blk) == 1
+        fb = (C.c_uint32 * 1)(L.cryo_memrel_reserve(mem))
+        assert L.cryo_stage_write_batch(C.byref(rel), blk[0], 1, host.COMP_LZ4, 5, fb) == 0
+        if b == 4:
+            L.cryo_memrel_reserve(mem)          # EMPTY_BLOCK in the middle
+        all_rows.append(rows)
+        firsts.append(fb[0])
+    return mem, rel, all_rows, firsts
+
+
+def _reference_seqscan(L, rel, mem, limit=None):
+    """the loop of reference pg_cryogen.c:250-275 (cryo_getnextslot): one iterator pop and one cryo_read_data per block"""
+    it = L.cryo_seqscan_iter_create()
+    popped, rows = [], []
+    while limit is None or len(rows) < limit:
+        b = L.cryo_seqscan_iter_next(it)
+        if L.cryo_memrel_nblocks(mem) <= b:
+            break
+        popped.append(b)
+        e = C.c_int(-1)
+        err = L.cryo_read_data(C.byref(rel), it, b, C.byref(e))
+        if err == host.CRYO_ERR_EMPTY_BLOCK:
+            continue
+        assert err == host.CRYO_ERR_SUCCESS, (b, err)
+        rows.append(fetch_rows(L, L.cryo_cache_get_data(e.value)))
+    nr = L.cryo_seqscan_iter_nranges(it)
+    L.cryo_seqscan_iter_free(it)
+    return popped, rows, nr
+
+
+def test_unchanged_am_scan_reaches_the_batch_path(H):
+    """the unmodified table AM asks for ONE block per call (reference pg_cryogen.c:262-265,
+    cache.c:244-297).  A miss of a sequential scan now also loads the next block starts with the same codec call
+    (pg_cryogen.gpu_readahead_blocks, never more than half the evictable slots); the scan's own iterator pops exactly
+    the pages it popped before, the rows are the same, and a scan that stops early wastes at most K - 1 decodes."""
+    L, dbl, errors = H
+    host.set_block_size(131072)
+    guc = C.c_int.in_dll(L, "cryo_gpu_readahead_blocks_guc")
+    assert guc.value == 8                                   # the default
+    rng = np.random.default_rng(2)
+    mem, rel, all_rows, firsts = _mixed_chain_table(L, rng)
+    runs = {}
+    for k in (1, 4, 8):
+        L.cryo_cache_configure(32)
+        guc.value = k
+        before = dbl.decompress_calls
+        popped, rows, nr = _reference_seqscan(L, rel, mem)
+        runs[k] = (popped, nr)
+        assert rows == all_rows
+        assert dbl.decompress_calls - before == -(-9 // k), k   # 9 chains: one codec call per K misses
+    assert runs[4] == runs[1] and runs[8] == runs[1]        # iterator order and exclusions unchanged by the read-ahead
+    assert [b for b in runs[1][0] if b in firsts] == firsts
+    # half the evictable slots bound K: 6 slots -> 3 blocks per call
+    L.cryo_cache_configure(6)
+    guc.value = 8
+    before = dbl.decompress_calls
+    popped, rows, _ = _reference_seqscan(L, rel, mem)
+    assert rows == all_rows and popped == runs[1][0]
+    assert dbl.decompress_calls - before == 3
+    # LIMIT 1: one codec call, at most K blocks decoded, and the look-ahead left the scan's iterator alone
+    L.cryo_cache_configure(32)
+    guc.value = 4
+    calls0, blocks0 = dbl.decompress_calls, dbl.blocks_decompressed
+    popped, rows, _ = _reference_seqscan(L, rel, mem, limit=1)
+    assert rows == all_rows[:1] and popped == runs[1][0][:1]
+    assert dbl.decompress_calls - calls0 == 1 and dbl.blocks_decompressed - blocks0 <= 4
+    # a scan without an iterator (bitmap and tid fetches pass NULL, reference pg_cryogen.c:423,873) never reads ahead
+    L.cryo_cache_configure(32)
+    calls0, blocks0 = dbl.decompress_calls, dbl.blocks_decompressed
+    e = C.c_int(-1)
+    assert L.cryo_read_data(C.byref(rel), None, firsts[0], C.byref(e)) == host.CRYO_ERR_SUCCESS
+    assert dbl.blocks_decompressed - blocks0 == 1
+    guc.value = 8
+    assert not errors
+    L.cryo_memrel_destroy(mem)
+
+
 def test_batch_larger_than_cache_never_aliases_slots(H):
     """A batch with more blocks than evictable slots: hits and earlier misses of the batch stay pinned, the
     surplus gets CACHE_IS_FULL, and every delivered entry holds its own block (round-1 advisor finding:
