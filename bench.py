@@ -53,6 +53,8 @@ def parse_args():
     ap.add_argument("--workload", default="lz4_decode", choices=["lz4_decode", "zstd_decode", "zstd", "lz4", "mixed"])
     ap.add_argument("--level", type=int, default=1, help="zstd level")
     ap.add_argument("--lz4-path", type=int, default=0, help="diagnostic: CRYO_OPT_LZ4_DECODE_PATH (0 auto, 1 in-wave parse, 2 indexed)")
+    ap.add_argument("--ref-gbps", type=float, default=0.0,
+                    help="one-GPU rate of the same per-GPU share: per_gpu_efficiency_vs_n1 = slowest rank's rate / this (N > 1)")
     ap.add_argument("--lz4-walkers", type=int, default=0, help="diagnostic: CRYO_OPT_LZ4_INDEX_WALKERS (0 auto)")
     ap.add_argument("--lz4-waves", type=int, default=0, help="diagnostic: CRYO_OPT_LZ4_DECODE_WAVES (0 auto, 1 one wave per block, 2 two)")
     return ap.parse_args()
@@ -245,11 +247,40 @@ def main():
         bufs.append(b)
         return b
 
+    rank_times = []   # every rank's own wall time of the timed region (filled by max_over_ranks)
+
     def max_over_ranks(x):
+        """MAX over the ranks (the contract's `value` uses it); also keeps every rank's own time: one aggregate hides a
+        straggler GPU, and north_star's ">= 0.9 x per-GPU efficiency at 8 GPUs" is a statement about the slowest rank."""
         t = torch.tensor([x], dtype=torch.float64)
+        del rank_times[:]
         if world > 1:
+            g = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(g, t)
+            rank_times.extend(float(v[0]) for v in g)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        else:
+            rank_times.append(x)
         return float(t[0])
+
+    def per_rank_fields(steps, per_rank_bytes):
+        """per_rank_ms_per_step, slowest_rank, the slowest rank's own rate and -- for N > 1 -- its ratio to the one-GPU rate of
+        the same per-GPU share (--ref-gbps, or the committed profiles/r05n_lz4_decode_bench.json for the configs[3] share)."""
+        ms = [round(t / steps * 1e3, 4) for t in rank_times]
+        slow = max(range(len(ms)), key=lambda i: ms[i])
+        rate = per_rank_bytes * steps / rank_times[slow] / 1e9
+        out = {"per_rank_ms_per_step": ms, "slowest_rank": slow, "slowest_rank_GBps": round(rate, 2)}
+        ref = a.ref_gbps
+        if not ref and world > 1 and a.workload == "lz4_decode" and n == CONFIG4_TOTAL_BLOCKS // 8 and B == 131072 and a.dist == "wide":
+            try:
+                with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05n_lz4_decode_bench.json")) as f:
+                    ref = float(json.load(f)["value"])
+            except (OSError, ValueError, KeyError):
+                ref = 0.0
+        if ref and world > 1:
+            out["per_gpu_efficiency_vs_n1"] = round(rate / ref, 4)
+            out["n1_reference_GBps"] = ref
+        return out
 
     def oracle_encode(method, param, k):
         raw = ora.synth(0, job_block(k), B, dist_id)
@@ -328,6 +359,7 @@ def main():
             value = n * world * B * a.steps / elapsed / 1e9
             out = dict(base, metric="%s_decompress_uncompressed_GBps" % mname, value=round(value, 2), unit="GB/s",
                        ms_per_step=round(elapsed / a.steps * 1e3, 4), per_gpu_GBps=round(value / world, 2))
+            out.update(per_rank_fields(a.steps, n * B))
             out["config"] = {"workload": "%s decompress %d x %d KiB synthetic cryo blocks per GPU" % (mname.upper(), n, B // 1024)
                              + (" (BASELINE configs[1])" if (world == 1 and n == 65536 and is_lz4) else "")
                              + (" (BASELINE configs[3]: 1 Mi blocks over 8 GPUs)" if (n * world == CONFIG4_TOTAL_BLOCKS and is_lz4) else ""),
@@ -399,6 +431,7 @@ def main():
             out = dict(base, steps=steps, metric="%s_compress_plus_decompress_uncompressed_GBps" % a.workload,
                        value=round(2 * n * world * B * steps / elapsed / 1e9, 2), unit="GB/s",
                        ms_per_step=round(elapsed / steps * 1e3, 3))
+            out.update(per_rank_fields(steps, 2 * n * B))
             out["config"] = {"workload": "%s param %d: compress + decompress %d x %d KiB synthetic cryo blocks per GPU (BASELINE configs[2] shape)"
                              % (a.workload, param, n, B // 1024), "distribution": a.dist, "blocks_per_gpu": n,
                              "compression_ratio": round(n * B / comp_bytes, 3),
@@ -482,6 +515,7 @@ def main():
             avg_ms = float(np.mean(ms))
             out = dict(base, steps=steps, metric="mixed_zstd22_lz4a50_decompress_uncompressed_GBps",
                        value=round(n * world * B * steps / elapsed / 1e9, 2), unit="GB/s", ms_per_step=round(elapsed / steps * 1e3, 3))
+            out.update(per_rank_fields(steps, n * B))
             out["config"] = {"workload": "BASELINE configs[4]: mixed batch of %d x %d KiB blocks per GPU, even = zstd level 22, odd = lz4 acceleration 50; decode of both"
                              % (n, B // 1024), "distribution": a.dist, "blocks_per_gpu": n,
                              "ratio_zstd22": round(ne * B / zbytes, 3), "ratio_lz4_a50": round(no * B / lbytes, 3),

@@ -28,13 +28,15 @@ WORKER = textwrap.dedent("""
         assert r == B and np.array_equal(out, raw)
         sums[i] = int.from_bytes(hashlib.sha256(out.tobytes()).digest()[:7], "little")
     dist.barrier(); el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    per_rank = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(per_rank, el)                             # bench.py: every rank's own time next to the MAX
     dist.all_reduce(el, op=dist.ReduceOp.MAX)
     owners = torch.zeros(N, dtype=torch.int64); owners[mine] = 1
     dist.all_reduce(owners); dist.all_reduce(sums)            # verification only, not the data path
     if rank == 0:
         exp = [int.from_bytes(hashlib.sha256(ora.synth(0, i, B, i %% 5).tobytes()).digest()[:7], "little") for i in range(N)]
         print(json.dumps({"covered_once": bool((owners == 1).all()), "sums_ok": sums.tolist() == exp,
-                          "elapsed_max": float(el[0]), "blocks": N}))
+                          "elapsed_max": float(el[0]), "per_rank": [float(v[0]) for v in per_rank], "blocks": N}))
     dist.destroy_process_group()
 """) % (ROOT, ROOT)
 
@@ -50,6 +52,7 @@ def test_round_robin_two_ranks_gloo(tmp_path):
     line = [l for l in out.splitlines() if l.startswith("{")][-1]
     r = json.loads(line)
     assert r["covered_once"] and r["sums_ok"] and r["elapsed_max"] > 0
+    assert len(r["per_rank"]) == 2 and max(r["per_rank"]) == r["elapsed_max"]
 
 
 def test_shard_partition_properties():

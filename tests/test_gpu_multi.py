@@ -29,6 +29,28 @@ def test_bench_two_ranks_share_one_gpu():
     r, c = j["roofline"], j["cpu_baseline"]
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and "traffic" in r
     assert c["unit"] == "GB/s" and c["value"] > 0 and c["cores"] == 1 and c["kind"] in ("reference", "port") and c["sample"]
+    # every rank's own time is on the line: one aggregate would hide a straggler GPU
+    assert len(j["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in j["per_rank_ms_per_step"])
+    assert j["slowest_rank"] in (0, 1) and j["ms_per_step"] == pytest.approx(max(j["per_rank_ms_per_step"]), rel=1e-3)
+    assert j["slowest_rank_GBps"] > 0
+
+
+def test_bench_eight_ranks_share_one_gpu():
+    """the driver's 8-GPU shape through self_launch on this box: eight processes, one rendezvous, MAX-reduce, one line
+    (8 x 1 024 blocks; --ref-gbps stands in for the one-GPU figure of the same share)"""
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+                          "--blocks", "1024", "--cpu-blocks", "64", "--ref-gbps", "100"], capture_output=True, text=True, timeout=900,
+                         env=env, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["config"]["total_blocks"] == 8192 and j["value"] > 0
+    assert len(j["per_rank_ms_per_step"]) == 8 and 0 <= j["slowest_rank"] < 8
+    assert j["per_gpu_efficiency_vs_n1"] == pytest.approx(j["slowest_rank_GBps"] / 100.0, rel=1e-2) and j["n1_reference_GBps"] == 100
 
 
 def test_bench_two_ranks_full_per_gpu_share():
