@@ -77,7 +77,8 @@ typedef enum {
     /* device-resident block pool (cryo_codec_decompress_blocks_keyed): capacity in bytes (0 = pool off, the default) */
     CRYO_OPT_POOL_BYTES = 4,
     /* zstd decode path: 0 = automatic (the four-kernel pipeline; the fused kernel for frames its planner does not take),
-     * 1 = the fused one-wave-per-frame kernel for everything, 2 = the pipeline */
+     * 1 = the fused one-wave-per-frame kernel for everything, 2 = the pipeline, 3 = the pipeline without the byte-parallel
+     * execution it uses for calls of up to 64 frames (k_zlat_* + lat_copy.h): one wave per frame (k_zexec) whatever the call */
     CRYO_OPT_ZSTD_DECODE_PATH = 5,
     /* device workspace kept between calls (the LZ4 sequence index: 2.1 GB for 65 536 x 128 KiB blocks; the zstd decode
      * tiles: up to 12.8 GiB each, four in flight): the host-buffer calls (cryo_codec_*_blocks*), which end synchronised,

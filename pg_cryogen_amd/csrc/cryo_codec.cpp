@@ -137,6 +137,7 @@ struct cryo_codec {
     bool have_aux = false;
     /* options (cryo_codec_set_option) */
     cryo::Lz4DecodeOpts lz4_opts = {};
+    bool lz4_side_failed = false; /* the optional side stream could not be created: not tried again */
     int zstd_path = 0;
     size_t pipe_min_bytes = (size_t)64 << 20;
     /* NUMA: the cpus of the node this GPU hangs on (sysfs local_cpulist of its PCI function, cut to what the process may
@@ -408,6 +409,11 @@ int cryo_codec_open(int device, cryo_codec **out)
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_off, sizeof(uint64_t));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_size, sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_status, sizeof(int32_t));
+    if (e == hipSuccess) { /* what one round of the LZ4 decoder holds depends on the device's compute units (a partition has fewer) */
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) c->lz4_opts.cus = cus;
+        else (void)hipGetLastError();
+    }
     if (e != hipSuccess) {
         cryo_codec_close(c);
         return CRYO_E_HIP;
@@ -507,7 +513,7 @@ int cryo_codec_set_option(cryo_codec *c, int option, int64_t value)
         c->pipe_min_bytes = (size_t)value;
         return CRYO_OK;
     case CRYO_OPT_ZSTD_DECODE_PATH:
-        if (value < 0 || value > 2) return CRYO_E_ARG;
+        if (value < 0 || value > 3) return CRYO_E_ARG;
         c->zstd_path = (int)value;
         return CRYO_OK;
     case CRYO_OPT_WORKSPACE_KEEP_BYTES:
@@ -668,12 +674,24 @@ int cryo_codec_decompress_batch(cryo_codec *c, int method, const void *d_src,
             int rc = ensure_ws(c, need);
             if (rc != CRYO_OK) return rc;
         }
-        if (!c->lz4_opts.side) { /* the side stream of the decoder's last round (lz4_dec2.hip): lowest priority, made once */
+        if (!c->lz4_opts.side && !c->lz4_side_failed) {
+            /* the side stream of the decoder's last round (lz4_dec2.hip): lowest priority, made once -- stream and both events or
+             * none of them: a handle that cannot have them decodes on one stream (an optimisation, never an error) */
             int least = 0, greatest = 0;
+            hipStream_t side = nullptr;
+            hipEvent_t fork = nullptr, join = nullptr;
             (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
-            HIP_TRY(c, hipStreamCreateWithPriority(&c->lz4_opts.side, hipStreamNonBlocking, least));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->lz4_opts.fork, hipEventDisableTiming));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->lz4_opts.join, hipEventDisableTiming));
+            if (hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least) == hipSuccess &&
+                hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
+                hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess) {
+                c->lz4_opts.side = side; c->lz4_opts.fork = fork; c->lz4_opts.join = join;
+            } else {
+                (void)hipGetLastError();
+                if (join) (void)hipEventDestroy(join);
+                if (fork) (void)hipEventDestroy(fork);
+                if (side) (void)hipStreamDestroy(side);
+                c->lz4_side_failed = true;
+            }
         }
         HIP_TRY(c, cryo::launch_lz4_decompress(c->stream, (const uint8_t *)d_src, d_src_off, d_src_size,
                                                (uint8_t *)d_dst, dst_stride, block_size, n_blocks,

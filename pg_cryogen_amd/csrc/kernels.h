@@ -59,6 +59,7 @@ struct Lz4DecodeOpts {
      * that fills the chip once or a few times is decoded there with two waves per block (lz4_dec2.hip, launch_dec_seq) */
     hipStream_t side = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
+    int cus = 0;     /* compute units of the handle's device (hipDeviceProp.multiProcessorCount; 0: an MI355X's 256) */
 };
 hipError_t launch_lz4_decompress(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
                                  const uint32_t *d_src_size, uint8_t *d_dst, uint64_t dst_stride,

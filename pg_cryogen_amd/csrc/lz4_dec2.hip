@@ -733,9 +733,9 @@ k_lz4_dec_dual(const uint8_t *__restrict__ src_base, const uint64_t *__restrict_
 }
 
 /* ---- launcher ---- */
-/* blocks one round of k_lz4_dec_seq holds: 24 waves per CU (LDS, 6 720 bytes per wave) on 256 CUs */
-constexpr uint64_t kSeqResident = 256u * 6u * kDecWpb;
-static void launch_dec_seq(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size, uint8_t *d_dst,
+/* blocks one round of k_lz4_dec_seq holds: 24 waves per CU (LDS, 6 720 bytes per wave) on the device's CUs (256 on an
+ * MI355X; a partitioned device has fewer: Lz4DecodeOpts::cus, filled by the handle from hipDeviceProp) */
+static hipError_t launch_dec_seq(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off, const uint32_t *d_src_size, uint8_t *d_dst,
                            uint64_t dst_stride, uint32_t block_size, uint64_t n_blocks, int32_t *d_status, const void *ws,
                            const Lz4IndexLayout &Lx, const uint32_t *d_done = nullptr, const int waves = 0, const Lz4DecodeOpts *opts = nullptr)
 {
@@ -749,7 +749,7 @@ static void launch_dec_seq(hipStream_t s, const uint8_t *d_src, const uint64_t *
 #if CRYO_DEC_DUAL
     if (waves == 2 || (waves == 0 && n_blocks <= kDualMaxBlocks)) { /* a batch that leaves most of the chip idle: two waves per block */
         dual(s, 0);
-        return;
+        return hipGetLastError();
     }
 #endif
     /* The last round (round 5).  A block is its wave's chain, so a batch of 1.33 rounds -- 8 192 blocks of 1 MiB, the reference's
@@ -761,16 +761,21 @@ static void launch_dec_seq(hipStream_t s, const uint8_t *d_src, const uint64_t *
      * a last round of at most 2 048 blocks. */
     uint64_t head = n_blocks;
 #if CRYO_DEC_DUAL
-    if (waves == 0 && opts != nullptr && opts->side != nullptr && n_blocks > kSeqResident && n_blocks <= 2u * kSeqResident) {
-        const uint64_t rest = n_blocks % kSeqResident;
-        if (rest != 0u && rest <= 2048u) head = n_blocks - rest;
+    if (waves == 0 && opts != nullptr && opts->side != nullptr && opts->fork != nullptr && opts->join != nullptr) {
+        const uint64_t resident = (uint64_t)(opts->cus > 0 ? opts->cus : 256) * 6u * kDecWpb;
+        if (n_blocks > resident && n_blocks <= 2u * resident) {
+            const uint64_t rest = n_blocks % resident;
+            if (rest != 0u && rest <= 2048u) head = n_blocks - rest;
+        }
     }
 #endif
-    const dim3 g((uint32_t)((head + kDecWpb - 1) / kDecWpb)), b(64 * kDecWpb);
-    if (head != n_blocks) {
-        (void)hipEventRecord(opts->fork, s); /* behind the index pass */
-        (void)hipStreamWaitEvent(opts->side, opts->fork, 0);
+    if (head != n_blocks) { /* behind the index pass; a fork that cannot be made means one stream for the whole batch */
+        if (hipEventRecord(opts->fork, s) != hipSuccess || hipStreamWaitEvent(opts->side, opts->fork, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            head = n_blocks;
+        }
     }
+    const dim3 g((uint32_t)((head + kDecWpb - 1) / kDecWpb)), b(64 * kDecWpb);
     /* (the first part's kernel is told where its blocks end by its grid: a workgroup's four blocks never straddle `head`,
      * a multiple of the residency) */
     if (Lx.logS != 0u)
@@ -781,9 +786,11 @@ static void launch_dec_seq(hipStream_t s, const uint8_t *d_src, const uint64_t *
                            d_status, nullptr, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, 0u, d_done, (uint64_t)0);
     if (head != n_blocks) {
         dual(opts->side, head);
-        (void)hipEventRecord(opts->join, opts->side);
-        (void)hipStreamWaitEvent(s, opts->join, 0);
+        /* the caller's stream must not run on (status copy, timer, the next call) before the side stream's blocks are done */
+        if (hipError_t e = hipEventRecord(opts->join, opts->side); e != hipSuccess) { (void)hipStreamSynchronize(opts->side); return e; }
+        if (hipError_t e = hipStreamWaitEvent(s, opts->join, 0); e != hipSuccess) { (void)hipStreamSynchronize(opts->side); return e; }
     }
+    return hipGetLastError();
 }
 
 /* the blocks the few-blocks path did not decode (lz4_lat.hip), with the index it built */
@@ -791,8 +798,7 @@ hipError_t launch_lz4_dec_seq_rest(hipStream_t s, const uint8_t *d_src, const ui
                                    uint8_t *d_dst, uint64_t dst_stride, uint32_t block_size, uint64_t n_blocks, int32_t *d_status,
                                    const void *ws, const Lz4IndexLayout &Lx, const uint32_t *d_done)
 {
-    launch_dec_seq(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, ws, Lx, d_done);
-    return hipGetLastError();
+    return launch_dec_seq(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, ws, Lx, d_done);
 }
 
 hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, const uint64_t *d_src_off,
@@ -835,7 +841,9 @@ hipError_t launch_lz4_decompress_indexed(hipStream_t s, const uint8_t *d_src, co
     }
 #endif
     (void)g; (void)b;
-    launch_dec_seq(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, d_workspace, Lx, nullptr, waves, opts);
+    if (hipError_t e = launch_dec_seq(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, d_workspace, Lx, nullptr, waves, opts);
+        e != hipSuccess)
+        return e;
     if (Lx.logS != 0u) /* the blocks the index and its decoder left out (almost all literals): the in-wave parser */
         return launch_lz4_dec_ring(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, true);
     return hipGetLastError();

@@ -2277,7 +2277,9 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
      * level -5 streams, with the first blocks handed back for want of a meeting point (profiles/r05_hufw_seglog.txt) */
     static const uint32_t hufw_seglog = cryo_tuning_env("CRYO_ZHUFW_SEGLOG") ? (uint32_t)atoi(cryo_tuning_env("CRYO_ZHUFW_SEGLOG")) : 11u;
     static const uint32_t huf2_grid = cryo_tuning_env("CRYO_ZHUF2_GRID") ? (uint32_t)atoi(cryo_tuning_env("CRYO_ZHUF2_GRID")) : 512u;
-    static const bool skip_lat = cryo_tuning_env("CRYO_ZSTD_NO_FEW") != nullptr; /* A/B (debug builds): k_zexec for every frame */
+    /* path 3 (CRYO_OPT_ZSTD_DECODE_PATH): the pipeline with k_zexec for every frame, i.e. without the few-frames execution
+     * below -- how the tests run one call shape through both */
+    const bool skip_lat = path == 3 || cryo_tuning_env("CRYO_ZSTD_NO_FEW") != nullptr;
     /* calls of at most this many zstd blocks (frames x blocks per frame) run a tile's two entropy stages side by side: 3-6 %
      * less time from 1 to 4 096 frames, 5 % MORE at a full tile of 12 288 (profiles/r05_zstd_fork.txt; tuning aid:
      * CRYO_ZSTD_FORK_ZBLOCKS) */

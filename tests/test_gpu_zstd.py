@@ -199,6 +199,76 @@ def test_zstd_decode_fuzz_matches_oracle(codec, oracle, zstd_path):
     assert n_ok > 30
 
 
+def _drop_content_size(c):
+    """the same frame without Frame_Content_Size: not single-segment, a window descriptor instead (what a streaming
+    compressor that was not told the size writes); the blocks are untouched"""
+    fhd = int(c[4])
+    fcs_flag, single, did = fhd >> 6, (fhd >> 5) & 1, fhd & 3
+    fcs_bytes = [1 if single else 0, 2, 4, 8][fcs_flag]
+    hdr = 5 + (0 if single else 1) + [0, 1, 2, 4][did] + fcs_bytes
+    wd = (21 - 10) << 3                                        # 2 MiB window: covers every block size used here
+    return np.concatenate([c[:4], np.array([fhd & 0x04, wd], np.uint8), c[hdr:]])   # keep only the checksum flag (0 here)
+
+
+@pytest.mark.parametrize("B", [131072, 1 << 20])
+def test_zstd_decode_few_frames_path_matches_oracle(codec, oracle, B):
+    """the byte-parallel execution that calls of up to 64 frames take by default (k_zlat_* + lat_copy.h) against
+    sequence-rich frames -- `wide` rows at levels 1 / 3 / 9, with and without content size, frames with raw and RLE blocks,
+    mutated copies -- at 1 .. 64 frames per call: verdicts and bytes == oracle, with the path on (automatic) and off
+    (CRYO_OPT_ZSTD_DECODE_PATH = 3: k_zexec for every frame)."""
+    from pg_cryogen_amd import codec as cc
+    stock = oracle_lib.StockLibs()
+    if stock.zstd is None:
+        pytest.skip("libzstd.so.1 not loadable")
+    rng = np.random.default_rng(77)
+    raws = [oracle.synth(9, i, B, 0) for i in range(4)]
+    if B > 131072:   # a frame of several zstd blocks, some of them raw (noise) and RLE (a run of one byte)
+        mix = oracle.synth(9, 9, B, 0).copy()
+        mix[131072:262144] = rng.integers(0, 256, 131072, dtype=np.uint8)
+        mix[393216:655360] = 0x5A
+        raws.append(mix)
+    frames = []
+    for lvl in (1, 3, 9):
+        for r in raws:
+            c = stock.zstd_compress(r, lvl)
+            frames += [c, _drop_content_size(c)]
+    assert any(int(f[4]) >> 6 == 0 and not (int(f[4]) >> 5) & 1 for f in frames)
+    muts = []
+    for c in frames[::3]:
+        for _ in range(6):
+            m = c.copy()
+            k = int(rng.integers(0, 3))
+            if k == 0:
+                m[int(rng.integers(8, len(m)))] ^= 1 << int(rng.integers(0, 8))
+            elif k == 1:
+                m = m[:int(rng.integers(len(m) // 2, len(m)))].copy()
+            else:
+                p = int(rng.integers(8, len(m) - 4))
+                m[p:p + 3] = rng.integers(0, 256, 3, dtype=np.uint8)
+            muts.append(m)
+    comps = frames + muts
+    expect = []
+    for m in comps:
+        r, out = oracle.zstd_decompress(m, B, fill=0xA5)
+        expect.append(out.copy() if r == B else None)
+    assert sum(e is not None for e in expect) >= len(frames)      # every unmutated frame decodes
+    sizes = (1, 3, 16, 64) if B == 131072 else (1, 5, 16)
+    try:
+        for path in (0, 3):
+            codec.set_option(cc.OPT_ZSTD_DECODE_PATH, path)
+            for k in sizes:
+                for first in range(0, len(comps), k):
+                    part, exp = comps[first:first + k], expect[first:first + k]
+                    outs, st = codec.decompress_blocks(METHOD_ZSTD, part, B)
+                    for i, e in enumerate(exp):
+                        if e is None:
+                            assert st[i] != 0, (path, k, first + i)
+                        else:
+                            assert st[i] == 0 and np.array_equal(outs[i], e), (path, k, first + i)
+    finally:
+        codec.set_option(cc.OPT_ZSTD_DECODE_PATH, 0)
+
+
 def test_zstd_single_block_host_api(codec, oracle):
     stock = oracle_lib.StockLibs()
     if stock.zstd is None:
