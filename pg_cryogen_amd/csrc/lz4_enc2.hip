@@ -28,32 +28,45 @@
  */
 #include "enc_ring.h"
 #include "kernels.h"
+#include <cstdio>
 #include <cstdlib>
 
 namespace cryo {
 
 namespace {
 
+constexpr bool kLz4EncTagsDefault = false; /* measured: profiles/r06_lz4_enc.txt */
 constexpr uint32_t kMfLimit = 12, kLastLiterals = 5, kMinLength = 13, kMaxDist = 65535, kSkipTrigger = 6;
 
-/* position table: u16 low halves + HB high bits per entry, packed and updated with LDS atomics when HB < 8:
- * HB = 1 (blocks up to 128 KiB) makes the table 8.5 KiB and 15 workgroups fit a CU instead of 11 (32.5 -> 41.5
- * GB/s on the headline blocks); HB = 4 (up to 1 MiB) 10 KiB, 13 per CU; HB = 8: a byte per entry (up to 16 MiB) */
-template <uint32_t kW, int HB>
+/* position table: u16 low halves + a byte plane per entry = the position's PB high bits (1 up to 128 KiB, 4 up to 1 MiB, 8
+ * up to 16 MiB) under a TAG of 8 - PB bits: a hash of the four bytes at that position.
+ *
+ * Round 6 (profiles/r06_lz4_enc.txt).  A candidate is the LAST position that hashed to the slot: on `wide` 80 % of them lie
+ * more than 1 KiB back, outside the ring, and 10.9 such candidates are probed before a sequence's hit
+ * (tests/sim_lz4_fast.py).  Their four bytes used to be read from memory in every step -- a trip to memory, with an
+ * s_waitcnt vmcnt(0) that also waits for the output stores still on their way --, then the match's extension read the far
+ * source again (backward: a second trip, forward: a third).  With the tag a far candidate is read only when its tag equals
+ * the probe's (1 in 128 for the accidents; the true match), and the FIRST such lane is taken as the match: its verification
+ * word, the 64 bytes before it and the 64 bytes behind its first four ride in ONE trip.  Two thirds of the matches on `wide`
+ * are near (median offset 440): those sequences never leave LDS.  (Rounds 1-5 packed the high bits -- 8.5 KiB tables, 15
+ * workgroups per CU instead of 11 now; the byte plane also ends the LDS atomics.) */
+/* TG: the byte plane with tags (4 KiB); !TG: the position's high bits packed (PB = 1: 512 bytes, 4: 2 KiB; updated with LDS
+ * atomics; the owner marks go to the low halves), no tags: every far candidate is read */
+template <uint32_t kW, int PB, bool TG>
 struct EncLds {
     uint8_t win[kW];
     uint16_t tlo[4096];
-    uint8_t thi[4096 * HB / 8];
+    uint8_t thi[TG ? 4096 : 4096 * PB / 8];
 };
 
-template <uint32_t kW, int HB>
-struct Enc : RingIn<kW> {
-    static constexpr bool BIT = HB < 8; /* owner marks go to the low halves */
-    EncLds<kW, HB> *L;
+template <uint32_t kW, uint32_t kStage, int PB, bool TG>
+struct Enc : RingIn<kW, kStage> {
+    static constexpr uint32_t TB = TG ? 8u - (uint32_t)PB : 0u, PM = (1u << PB) - 1u;
+    EncLds<kW, PB, TG> *L;
     uint8_t *dst;
     uint32_t op;
-    using RingIn<kW>::lane;
-    using RingIn<kW>::dw;
+    using RingIn<kW, kStage>::lane;
+    using RingIn<kW, kStage>::dw;
 
     /* LZ4_hash5 of the bytes at p (table log 12): ((v << 24) * 889523592379) >> 52, in 32-bit pieces */
     __device__ inline uint32_t hash(uint32_t p, uint32_t &first4) const
@@ -68,31 +81,30 @@ struct Enc : RingIn<kW> {
         const uint32_t top = __umulhi(x_lo, c_lo) + x_lo * c_hi + x_hi * c_lo;
         return top >> 20;
     }
-    __device__ inline uint32_t tab_get(uint32_t h) const
+    static __device__ inline uint32_t tag_of(uint32_t v4) { return TB ? (v4 * 2654435761u) >> (32u - TB) : 0u; }
+    /* the slot's high part: (TG) the plane's byte = high bits | tag << PB; (!TG) the packed high bits */
+    __device__ inline uint32_t hi_get(uint32_t h) const
     {
-        if constexpr (HB == 1) return (uint32_t)L->tlo[h] | (((reinterpret_cast<const uint32_t *>(L->thi)[h >> 5] >> (h & 31u)) & 1u) << 16);
-        else if constexpr (HB == 4) return (uint32_t)L->tlo[h] | (((reinterpret_cast<const uint32_t *>(L->thi)[h >> 3] >> (4u * (h & 7u))) & 15u) << 16);
-        else return (uint32_t)L->tlo[h] | ((uint32_t)L->thi[h] << 16);
+        if constexpr (TG) return L->thi[h];
+        else if constexpr (PB == 1) return (reinterpret_cast<const uint32_t *>(L->thi)[h >> 5] >> (h & 31u)) & 1u;
+        else if constexpr (PB == 4) return (reinterpret_cast<const uint32_t *>(L->thi)[h >> 3] >> (4u * (h & 7u))) & 15u;
+        else return L->thi[h];
     }
-    __device__ inline void tab_put(uint32_t h, uint32_t v)
+    __device__ inline void tab_put(uint32_t h, uint32_t v, uint32_t tag)
     {
         L->tlo[h] = (uint16_t)v;
-        if constexpr (HB == 1) {
+        if constexpr (TG || PB == 8) L->thi[h] = (uint8_t)(((v >> 16) & PM) | (tag << PB));
+        else if constexpr (PB == 1) {
             uint32_t *w = reinterpret_cast<uint32_t *>(L->thi) + (h >> 5);
             if ((v >> 16) & 1u) atomicOr(w, 1u << (h & 31u));
             else atomicAnd(w, ~(1u << (h & 31u)));
-        } else if constexpr (HB == 4) { /* other lanes of the step may update other nibbles of the word: clear, then set */
+        } else { /* other lanes of the step may update other nibbles of the word: clear, then set */
             uint32_t *w = reinterpret_cast<uint32_t *>(L->thi) + (h >> 3);
             const uint32_t sh = 4u * (h & 7u);
             atomicAnd(w, ~(15u << sh));
             atomicOr(w, ((v >> 16) & 15u) << sh);
-        } else L->thi[h] = (uint8_t)(v >> 16);
+        }
     }
-    /* owner marks for the in-step collision test: in the byte plane, or (BIT) in the low half, whose real value
-     * is in `cand` and comes back right after the test */
-    __device__ inline void mark(uint32_t h, uint32_t lane_id) { if constexpr (BIT) L->tlo[h] = (uint16_t)(0xFF00u | lane_id); else L->thi[h] = (uint8_t)lane_id; }
-    __device__ inline bool marked_by(uint32_t h, uint32_t lane_id) const { if constexpr (BIT) return L->tlo[h] == (uint16_t)(0xFF00u | lane_id); else return L->thi[h] == (uint8_t)lane_id; }
-    __device__ inline void unmark(uint32_t h, uint32_t cand) { if constexpr (BIT) L->tlo[h] = (uint16_t)cand; else L->thi[h] = (uint8_t)(cand >> 16); }
 
     /* 255-run length code */
     __device__ inline void put_len(uint32_t len)
@@ -104,38 +116,79 @@ struct Enc : RingIn<kW> {
     }
     __device__ inline void put_literals(uint32_t from, uint32_t lit)
     {
-        for (uint32_t i = lane; i < lit; i += 64u) dst[op + i] = (uint8_t)this->byte_any(from + i);
+        if (from >= this->lo_pos()) { /* the usual run: the ring holds it */
+            for (uint32_t i = lane; i < lit; i += 64u) dst[op + i] = (uint8_t)this->byte_ring(from + i);
+        } else {
+            uint32_t i = lane;
+            if (lit >= 2048u) { /* long runs (incompressible blocks are one literal run): 16 bytes per lane, memory to memory */
+                const uint32_t whole = lit & ~1023u;
+                for (uint32_t o = 16u * lane; o < whole; o += 1024u) {
+                    uint4 v;
+                    __builtin_memcpy(&v, this->src + from + o, 16);
+                    __builtin_memcpy(dst + op + o, &v, 16);
+                }
+                i += whole;
+            }
+            for (; i < lit; i += 64u) dst[op + i] = (uint8_t)this->byte_any(from + i);
+        }
         op += lit;
     }
 };
 
 } // namespace
 
-template <uint32_t kW, int HB>
+#ifdef CRYO_LZ4E_PROF /* phase stamps of the encoder (a variant build: profiles/scripts/r06_lz4e3.sh) */
+__device__ unsigned long long g_lz4e_prof[16];
+#define LZT(k) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); pt[k] += t_ - t0; t0 = t_; } while (0)
+#else
+#define LZT(k) do { } while (0)
+#endif
+
+template <uint32_t kW, int PB, bool TG>
 __global__ void __launch_bounds__(64)
 k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n, uint64_t n_blocks,
            uint8_t *__restrict__ dst_base, uint64_t dst_stride, int accel_in,
-           uint32_t *__restrict__ out_size, int32_t *__restrict__ status)
+           uint32_t *__restrict__ out_size, int32_t *__restrict__ status, uint32_t dbg)
 {
-    __shared__ __attribute__((aligned(16))) EncLds<kW, HB> L;
+    constexpr uint32_t kStage = kW >= 2048u ? kEncStage : kW / 2u; /* the ring's refill: half of it at most */
+    __shared__ __attribute__((aligned(16))) EncLds<kW, PB, TG> L;
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t blk = blockIdx.x;
     if (blk >= n_blocks) return;
 
-    Enc<kW, HB> e;
+    Enc<kW, kStage, PB, TG> e;
+    using E = Enc<kW, kStage, PB, TG>;
     e.L = &L;
     e.dst = dst_base + uni64(blk * dst_stride);
     e.op = 0;
     const uint32_t accel = accel_in < 1 ? 1u : (accel_in > 65537 ? 65537u : (uint32_t)accel_in);
+    const uint8_t *src = src_base + uni64(blk * src_stride);
 
     for (uint32_t i = lane; i < 512u; i += 64u) reinterpret_cast<uint4 *>(L.tlo)[i] = make_uint4(0, 0, 0, 0);
-    for (uint32_t i = lane; i < sizeof(L.thi) / 16u; i += 64u) reinterpret_cast<uint4 *>(L.thi)[i] = make_uint4(0, 0, 0, 0);
-    e.open(L.win, src_base + uni64(blk * src_stride), n, lane);
-    e.ensure(2u * kEncStage);
+    if constexpr (TG) {
+        /* an empty slot reads as position 0, which is a real candidate (liblz4 puts position 0 into its table before the
+         * first probe): every slot starts with the tag of the block's first four bytes */
+        uint32_t first4;
+        __builtin_memcpy(&first4, src, 4);
+        const uint32_t t0 = (E::tag_of(uni(first4)) << PB) & 0xFFu, t4 = t0 * 0x01010101u;
+        for (uint32_t i = lane; i < 256u; i += 64u) reinterpret_cast<uint4 *>(L.thi)[i] = make_uint4(t4, t4, t4, t4);
+    } else {
+        for (uint32_t i = lane; i < sizeof(L.thi) / 16u; i += 64u) reinterpret_cast<uint4 *>(L.thi)[i] = make_uint4(0, 0, 0, 0);
+    }
+    e.open(L.win, src, n, lane);
+    e.ensure(kW);
     __builtin_amdgcn_wave_barrier();
+    /* the owner marks (in the byte plane, or -- packed high bits -- in the low halves): every access is one the wave really
+     * makes (explicit LDS pointers: a volatile generic one becomes FLAT accesses with a wait behind each) */
+    volatile __attribute__((address_space(3))) uint8_t *vthi = (volatile __attribute__((address_space(3))) uint8_t *)L.thi;
+    volatile __attribute__((address_space(3))) uint16_t *vtlo = (volatile __attribute__((address_space(3))) uint16_t *)L.tlo;
+    constexpr bool kByteMarks = TG || PB == 8;
 
     const unsigned long long lt_mask = lane ? (~0ull >> (64u - lane)) : 0ull; /* lanes below this one */
     uint32_t anchor = 0;
+#ifdef CRYO_LZ4E_PROF
+    unsigned long long pt[8] = {0}, t0 = __builtin_amdgcn_s_memtime(), nseq_p = 0, nbatch_p = 0;
+#endif
 
     if (n >= kMinLength) {
         const uint32_t mflimit_p1 = n - kMfLimit + 1u;
@@ -143,140 +196,227 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         /* position 0 goes into the table as index 0: the table is zero already */
         uint32_t ip = 1;
         bool done = false, pre = false; /* pre: a match just ended at ip (table update at ip-2 and re-test at ip pending) */
+        uint32_t fwd = ip, step = 1, nb = accel << kSkipTrigger;
         while (!done) {
-            /* ================= search: batches of 64 probes =================
-             * After a match the serial code stores ip-2, then tests ip, then starts the search at ip+1: those
-             * two are simply lanes 0 and 1 of the first batch (lane order = time order), lane 0 never matching. */
-            uint32_t fwd = pre ? ip + 1u : ip, step = 1, nb = accel << kSkipTrigger;
-            uint32_t match = 0;
+            /* ================= a batch of 64 probes =================
+             * After a match the serial code stores ip-2, then tests ip, then starts the search at ip+1: those two are
+             * simply lanes 0 and 1 of the batch (lane order = time order), lane 0 never matching. */
+            if (pre) { fwd = ip + 1u; step = 1; nb = accel << kSkipTrigger; }
+            const uint32_t sh = pre ? 2u : 0u;
+            const uint32_t q = lane - sh;
+            const uint32_t sk = lane < sh ? 0u : (q == 0u ? step : (nb + q - 1u) >> kSkipTrigger);
+            const uint32_t inc = scan64_incl(sk);
+            uint32_t cur = fwd + inc - sk;
+            const uint32_t nxt = fwd + inc;
+            if (pre && lane < 2u) cur = lane == 0u ? ip - 2u : ip;
+            /* lanes of this batch: until the search would run off the block (prefix-closed: positions only grow), and
+             * only as far as the ring can hold next to the first position */
+            const bool ends = !(lane < sh || nxt <= mflimit_p1);
+            const uint32_t base = pre ? ip - 2u : fwd;
+            const bool fits = cur + 9u <= base + (kW - kStage);
+            const unsigned long long endm = __ballot(ends);
+            const unsigned long long stopm = endm | __ballot(!fits);
+            const uint32_t T = stopm ? ctz64(stopm) : 64u; /* lanes 0 .. T-1 take part */
+            const bool at_end = T < 64u && ((endm >> T) & 1ull); /* stopped by the block's end, not the ring */
+            const bool valid = lane < T;
+            if (T == 0u) { done = true; break; }
+            /* consecutive positions from lane 1 on (every probe one byte behind the last: the first 64 probes of a search at
+             * acceleration 1): what lies behind a match found in this batch can be served from it (below) */
+            const bool consecutive = accel == 1u && step == 1u && nb == (1u << kSkipTrigger) && !(dbg & 4u);
+            e.ensure(lane_get(cur, T - 1u) + 9u);
+            uint32_t own4 = 0, h = 0, cand = 0, ohi = 0;
+            bool lost = false;
+            if (valid) {
+                h = e.hash(cur, own4);
+                if constexpr (kByteMarks) {
+                    cand = L.tlo[h];
+                    ohi = vthi[h];
+                    vthi[h] = (uint8_t)lane; /* owner mark; what it overwrites is in ohi and comes back below */
+                    lost = vthi[h] != (uint8_t)lane; /* a lane that does not read its own mark back shares the slot */
+                    vthi[h] = (uint8_t)ohi;          /* all sharers hold the same old value */
+                } else {
+                    cand = vtlo[h];
+                    ohi = e.hi_get(h);
+                    vtlo[h] = (uint16_t)(0xFF00u | lane);
+                    lost = vtlo[h] != (uint16_t)(0xFF00u | lane);
+                    vtlo[h] = (uint16_t)cand;
+                }
+            }
+            cand |= (ohi & E::PM) << 16;
+            /* in-batch collisions: an earlier lane with the same hash is what the serial loop would read */
+            unsigned long long grouped = 0ull;
+            bool resolved = false;
+            {
+                unsigned long long losers = __ballot(lost);
+                while (losers) {
+                    const uint32_t j = ctz64(losers);
+                    const uint32_t hj = lane_get(h, j);
+                    const unsigned long long G = __ballot(valid && h == hj);
+                    const unsigned long long below = G & lt_mask;
+                    const uint32_t pred = below ? 63u - (uint32_t)__builtin_clzll(below) : lane;
+                    const uint32_t pc = (uint32_t)__shfl((int)cur, (int)pred, 64);
+                    if (((G >> lane) & 1ull) && below) { cand = pc; resolved = true; }
+                    grouped |= G;
+                    losers &= ~G;
+                }
+            }
+            /* candidates the ring still holds are compared there; an older one only if its tag says so and it could still
+             * be the first hit */
+            const uint32_t mytag = E::tag_of(own4);
+            const bool in_dist = valid && cand + kMaxDist >= cur;
+            const bool near = cand >= e.lo_pos();
+            const unsigned long long nearm = __ballot(in_dist && near && e.rd32(cand) == own4);
+            const unsigned long long farm = __ballot(in_dist && !near && (!TG || resolved || (ohi >> PB) == mytag || (dbg & 1u)));
+#ifdef CRYO_LZ4E_PROF
+            nbatch_p++;
+#endif
+            LZT(0);
+
+            /* ================= the sequences this batch holds =================
+             * L0: the lane that only stores its position (ip - 2 behind a match; none in a search that goes on);
+             * L1: the first lane that may match.  Lanes L0, L1 .. are the serial walk's next probes. */
+            uint32_t L0 = pre ? 0u : 64u, L1 = pre ? 1u : 0u;
+            bool next_batch_plain = false;
             for (;;) {
-                const uint32_t sh = pre ? 2u : 0u;
-                const uint32_t q = lane - sh;
-                const uint32_t sk = lane < sh ? 0u : (q == 0u ? step : (nb + q - 1u) >> kSkipTrigger);
-                const uint32_t inc = scan64_incl(sk);
-                uint32_t cur = fwd + inc - sk;
-                const uint32_t nxt = fwd + inc;
-                if (pre && lane < 2u) cur = lane == 0u ? ip - 2u : ip;
-                /* lanes of this batch: until the search would run off the block (prefix-closed: positions only
-                 * grow), and only as far as the ring can hold next to the first position */
-                const bool ends = !(lane < sh || nxt <= mflimit_p1);
-                const uint32_t base = pre ? ip - 2u : fwd;
-                const bool fits = cur + 9u <= base + (kW - kEncStage);
-                const unsigned long long stopm = __ballot(ends || !fits);
-                const uint32_t T = stopm ? ctz64(stopm) : 64u; /* lanes 0 .. T-1 take part */
-                const bool at_end = T < 64u && ((__ballot(ends) >> T) & 1ull); /* stopped by the block's end, not the ring */
-                const bool valid = lane < T;
-                if (T == 0u) { done = true; break; }
-                e.ensure(lane_get(cur, T - 1u) + 9u);
-                uint32_t own4 = 0, h = 0, cand = 0;
-                if (valid) {
-                    h = e.hash(cur, own4);
-                    cand = e.tab_get(h);
-                    e.mark(h, lane); /* owner mark; what it overwrites is in cand and comes back below */
-                }
-                /* in-batch collisions: an earlier lane with the same hash is what the serial loop would read.
-                 * Every lane marked its slot; a lane that does not read its own mark back shares the slot. */
-                unsigned long long grouped = 0ull;
-                {
-                    /* the read-back must see what the WAVE wrote, not be forwarded from this lane's own store */
-                    asm volatile("" ::: "memory");
-                    const bool lost = valid && !e.marked_by(h, lane);
-                    asm volatile("" ::: "memory");
-                    if (valid) e.unmark(h, cand); /* all sharers hold the same old value */
-                    unsigned long long losers = __ballot(lost);
-                    while (losers) {
-                        const uint32_t j = ctz64(losers);
-                        const uint32_t hj = lane_get(h, j);
-                        const unsigned long long G = __ballot(valid && h == hj);
-                        const unsigned long long below = G & lt_mask;
-                        const uint32_t pred = below ? 63u - (uint32_t)__builtin_clzll(below) : lane;
-                        const uint32_t pc = (uint32_t)__shfl((int)cur, (int)pred, 64);
-                        if (((G >> lane) & 1ull) && below) cand = pc;
-                        grouped |= G;
-                        losers &= ~G;
-                    }
-                }
-                /* candidates still in the ring first; the older ones only if they could be the first hit */
-                const bool testable = valid && !(pre && lane == 0u) && cand + kMaxDist >= cur;
-                const bool near = cand >= e.lo_pos();
-                unsigned long long hm = __ballot(testable && near && e.rd32(cand) == own4);
+                const unsigned long long from1 = L1 >= 64u ? 0ull : (~0ull << L1);
+                unsigned long long hm = nearm & from1;
+                bool have_win = false;
+                uint32_t wb = 0, wf = 0;
                 {
                     const uint32_t first = hm ? ctz64(hm) : 64u;
-                    const unsigned long long far = __ballot(testable && !near) & (first >= 64u ? ~0ull : ((1ull << first) - 1ull));
+                    const unsigned long long far = farm & from1 & (first >= 64u ? ~0ull : ((1ull << first) - 1ull));
                     if (far) {
-                        bool hf = false;
-                        if ((far >> lane) & 1ull) {
-                            uint32_t v;
-                            __builtin_memcpy(&v, e.src + cand, 4);
-                            hf = v == own4;
-                        }
-                        hm |= __ballot(hf);
+                        /* one trip: every such lane's four bytes, and for the first of them -- the match, unless its tag
+                         * lied -- the bytes its extension both ways starts with */
+                        const uint32_t P = ctz64(far);
+                        const uint32_t mP = lane_get(cand, P), ipP = lane_get(cur, P);
+                        const uint32_t room = ipP - anchor < mP ? ipP - anchor : mP;
+                        uint32_t v = 0, xb = 0, xf = 0;
+                        if ((far >> lane) & 1ull) __builtin_memcpy(&v, src + cand, 4);
+                        if (lane < room) xb = src[mP - 1u - lane];
+                        xf = src[mP + 4u + lane]; /* below ipP + 4 + lane: far candidates lie a ring's length back */
+                        const bool hf = ((far >> lane) & 1ull) && v == own4;
+                        const unsigned long long hfm = __ballot(hf);
+                        hm |= hfm;
+                        if (((hfm >> P) & 1ull) && !(dbg & 2u)) { have_win = true; wb = xb; wf = xf; }
                     }
                 }
                 const uint32_t K = hm ? ctz64(hm) + 1u : T;
-                /* commit probes 0 .. K-1: colliding ones one by one, ascending, so the last writer wins */
-                if (lane < K && !((grouped >> lane) & 1ull)) e.tab_put(h, cur);
+                LZT(1);
+                /* commit this search's probes up to K-1: colliding ones one by one, ascending, so the last writer wins */
                 {
-                    unsigned long long g = grouped & (K >= 64u ? ~0ull : ((1ull << K) - 1ull));
+                    const bool mine = lane < K && (lane >= L1 || lane == L0);
+                    if (mine && !((grouped >> lane) & 1ull)) e.tab_put(h, cur, mytag);
+                    unsigned long long g = grouped & __ballot(mine);
                     while (g) {
                         const uint32_t j = ctz64(g);
-                        if (lane == j) e.tab_put(h, cur);
+                        if (lane == j) e.tab_put(h, cur, mytag);
                         g &= g - 1ull;
                     }
                 }
-                if (hm) {
-                    ip = lane_get(cur, K - 1u);
-                    match = lane_get(cand, K - 1u);
+                LZT(2);
+                if (!hm) {
+                    if (at_end) { done = true; break; }
+                    /* the search goes on behind the batch: the probes counted are the ones behind L1 (or all of a plain batch) */
+                    const uint32_t counted = L0 < 64u ? (T > L1 + 1u ? T - L1 - 1u : 0u) : T;
+                    fwd = lane_get(nxt, T - 1u);
+                    if (counted) { step = (nb + counted - 1u) >> kSkipTrigger; nb += counted; }
+                    next_batch_plain = true;
                     break;
                 }
-                if (at_end) { done = true; break; }
-                fwd = lane_get(nxt, T - 1u);
-                if (T > sh) { step = (nb + (T - sh) - 1u) >> kSkipTrigger; nb += T - sh; }
-                pre = false;
-            }
-            if (done) break;
+                ip = lane_get(cur, K - 1u);
+                uint32_t match = lane_get(cand, K - 1u);
 
-            /* ================= extend backwards ================= */
-            {
-                uint32_t room = ip - anchor < match ? ip - anchor : match;
-                while (room) {
-                    const bool in = lane < room;
-                    const bool eq = in && e.byte_any(ip - 1u - lane) == e.byte_any(match - 1u - lane);
-                    const unsigned long long neq = __ballot(!eq);
-                    const uint32_t c = neq ? ctz64(neq) : 64u;
-                    ip -= c; match -= c;
-                    if (c < 64u) break;
-                    room -= 64u;
+                /* ================= extend backwards ================= */
+                const bool ring_ok = anchor >= e.lo_pos();     /* the literal run lies in the ring */
+                const bool near_m = match >= e.lo_pos() + 64u; /* ... and so do the candidate and the 64 bytes before it */
+                const uint32_t ip_hit = ip;
+                {
+                    uint32_t room = ip - anchor < match ? ip - anchor : match;
+                    bool first = true;
+                    while (room) {
+                        const bool in = lane < room;
+                        uint32_t x, y;
+                        if (ring_ok) x = e.byte_ring(ip - 1u - lane); else x = in ? e.byte_any(ip - 1u - lane) : 0u;
+                        if (have_win && first) y = wb;
+                        else if (near_m && first) y = e.byte_ring(match - 1u - lane);
+                        else y = in ? e.byte_any(match - 1u - lane) : 1u;
+                        const bool eq = in && x == y;
+                        const unsigned long long neq = __ballot(!eq);
+                        const uint32_t c = neq ? ctz64(neq) : 64u;
+                        ip -= c; match -= c;
+                        if (c < 64u) break;
+                        room -= 64u;
+                        first = false;
+                    }
+                }
+
+                const uint32_t lit = ip - anchor;
+                LZT(3);
+                /* ================= extend forwards: 64 bytes per step, then 2 KiB per step =================
+                 * from the four bytes the search compared (what the backward extension added in front of them is equal
+                 * already): lane l of the far trip's window is the byte l behind the candidate's first four */
+                uint32_t a = ip_hit + 4u, b = match + (ip_hit - ip) + 4u;
+                {
+                    bool first = true;
+                    for (;;) {
+                        e.ensure(a + 64u);
+                        const bool inb = a + lane < matchlimit;
+                        const uint32_t x = e.byte_ring(a + lane); /* a is a probed position or behind one: the ring holds it */
+                        uint32_t y;
+                        if (have_win && first) y = wf;
+                        else if (b >= e.lo_pos()) y = e.byte_ring(b + lane); /* (staging may have pushed the candidate out since) */
+                        else y = inb ? e.byte_any(b + lane) : 1u;
+                        const bool eq = inb && x == y;
+                        const unsigned long long neq = __ballot(!eq);
+                        if (neq) { a += ctz64(neq); break; }
+                        a += 64u; b += 64u;
+                        first = false;
+                        if (a + 2048u + 64u <= matchlimit) { /* a long match: 16 bytes per lane straight from memory */
+                            a += count_long(src + a, src + b, src + matchlimit, lane, 0u);
+                            break;
+                        }
+                    }
+                }
+                const uint32_t ml = a - (ip + 4u);
+                LZT(4);
+                /* ================= emit: token, literal length, literals, offset, match length ================= */
+                if (lane == 0) e.dst[e.op] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (ml < 15u ? ml : 15u));
+                e.op++;
+                if (lit >= 15u) e.put_len(lit - 15u);
+                e.put_literals(anchor, lit);
+                if (lane == 0) {
+                    e.dst[e.op] = (uint8_t)(ip - match);
+                    e.dst[e.op + 1] = (uint8_t)((ip - match) >> 8);
+                }
+                e.op += 2u;
+                if (ml >= 15u) e.put_len(ml - 15u);
+                ip = a;
+                anchor = ip;
+#ifdef CRYO_LZ4E_PROF
+                nseq_p++;
+#endif
+                LZT(5);
+                if (ip >= mflimit_p1) { done = true; break; }
+                pre = true;
+                /* The serial walk now stores ip - 2, tests ip and searches on from ip + 1.  If this batch holds those
+                 * positions -- consecutive probes, lane = position - (position of lane 1) + 1 -- their hashes, candidates
+                 * and comparisons are done already.  A candidate resolved inside the batch assumed that EVERY earlier lane
+                 * stores its position; the lanes inside the match and the one at ip - 1 do not: if any of those shares a
+                 * slot with another lane, the batch is not used further. */
+                if (!consecutive) break;
+                {
+                    const uint32_t p1 = lane_get(cur, 1u); /* position of lane 1; lane l >= 1 holds p1 + l - 1 */
+                    if (ip < p1 + 2u) break;               /* (ip - 2 must be a lane >= 1) */
+                    const uint32_t n1 = ip - p1 + 1u, n0 = n1 - 2u;
+                    if (n1 >= T) break;
+                    const unsigned long long skipped = (((1ull << n0) - 1ull) & ~((1ull << K) - 1ull)) | (1ull << (n1 - 1u));
+                    if (grouped & skipped) break;
+                    L0 = n0; L1 = n1;
                 }
             }
-
-            const uint32_t lit = ip - anchor;
-            /* ================= extend forwards: 64 bytes per step ================= */
-            uint32_t a = ip + 4u, b = match + 4u;
-            for (;;) {
-                e.ensure(a + 64u);
-                const bool inb = a + lane < matchlimit;
-                const bool eq = inb && e.byte_any(a + lane) == e.byte_any(b + lane); /* after a backward extension even ip may precede the ring */
-                const unsigned long long neq = __ballot(!eq);
-                if (neq) { a += ctz64(neq); break; }
-                a += 64u; b += 64u;
-            }
-            const uint32_t ml = a - (ip + 4u);
-            /* ================= emit: token, literal length, literals, offset, match length ================= */
-            if (lane == 0) e.dst[e.op] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (ml < 15u ? ml : 15u));
-            e.op++;
-            if (lit >= 15u) e.put_len(lit - 15u);
-            e.put_literals(anchor, lit);
-            if (lane == 0) {
-                e.dst[e.op] = (uint8_t)(ip - match);
-                e.dst[e.op + 1] = (uint8_t)((ip - match) >> 8);
-            }
-            e.op += 2u;
-            if (ml >= 15u) e.put_len(ml - 15u);
-            ip = a;
-            anchor = ip;
-            if (ip >= mflimit_p1) break;
-            pre = true;
+            if (done) break;
+            if (next_batch_plain) pre = false;
         }
     }
     /* ================= last literals ================= */
@@ -289,6 +429,9 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         e.put_literals(anchor, lit);
     }
     if (lane == 0) { out_size[blk] = e.op; status[blk] = CRYO_ST_OK; }
+#ifdef CRYO_LZ4E_PROF
+    if (lane == 0) { for (int k = 0; k < 6; k++) atomicAdd(&g_lz4e_prof[k], pt[k]); atomicAdd(&g_lz4e_prof[8], nseq_p); atomicAdd(&g_lz4e_prof[9], nbatch_p); }
+#endif
 }
 
 hipError_t launch_lz4_compress_batch64(hipStream_t s, const uint8_t *d_src, uint64_t src_stride,
@@ -296,32 +439,50 @@ hipError_t launch_lz4_compress_batch64(hipStream_t s, const uint8_t *d_src, uint
                                        uint64_t dst_stride, int accel, uint32_t *d_out_size, int32_t *d_status)
 {
     if (n_blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    static const uint32_t dbg = cryo_tuning_env("CRYO_LZ4_ENC_DBG") ? (uint32_t)atoi(cryo_tuning_env("CRYO_LZ4_ENC_DBG")) : 0u; /* bisecting aid */
     static const int wkb = cryo_tuning_env("CRYO_LZ4_ENC_WINDOW") ? atoi(cryo_tuning_env("CRYO_LZ4_ENC_WINDOW")) : 2; /* KiB; tuning aid */
     const dim3 grid((uint32_t)n_blocks), wg(64);
     if (wkb >= 64)
-        hipLaunchKernelGGL((k_lz4_enc2<65536, 8>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
-                           accel, d_out_size, d_status);
+        hipLaunchKernelGGL((k_lz4_enc2<65536, 8, true>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
+                           accel, d_out_size, d_status, dbg);
     else if (wkb >= 32)
-        hipLaunchKernelGGL((k_lz4_enc2<32768, 8>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
-                           accel, d_out_size, d_status);
+        hipLaunchKernelGGL((k_lz4_enc2<32768, 8, true>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
+                           accel, d_out_size, d_status, dbg);
     else if (wkb >= 16)
-        hipLaunchKernelGGL((k_lz4_enc2<16384, 8>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
-                           accel, d_out_size, d_status);
+        hipLaunchKernelGGL((k_lz4_enc2<16384, 8, true>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
+                           accel, d_out_size, d_status, dbg);
     else if (wkb >= 8)
-        hipLaunchKernelGGL((k_lz4_enc2<8192, 8>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
-                           accel, d_out_size, d_status);
+        hipLaunchKernelGGL((k_lz4_enc2<8192, 8, true>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
+                           accel, d_out_size, d_status, dbg);
     else if (wkb >= 4)
-        hipLaunchKernelGGL((k_lz4_enc2<4096, 8>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
-                           accel, d_out_size, d_status);
-    else if (block_size <= (128u << 10))
-        hipLaunchKernelGGL((k_lz4_enc2<2048, 1>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
-                           accel, d_out_size, d_status);
-    else if (block_size <= (1u << 20))
-        hipLaunchKernelGGL((k_lz4_enc2<2048, 4>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
-                           accel, d_out_size, d_status);
-    else
-        hipLaunchKernelGGL((k_lz4_enc2<2048, 8>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
-                           accel, d_out_size, d_status);
+        hipLaunchKernelGGL((k_lz4_enc2<4096, 8, true>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride,
+                           accel, d_out_size, d_status, dbg);
+    else {
+        /* 1 KiB ring; tags (12 workgroups per CU at 128 KiB) or packed high bits without tags (16 per CU): tuning aid CRYO_LZ4_ENC_TAGS */
+#define LZ4E_LAUNCH(KW, PBV, TGV) hipLaunchKernelGGL((k_lz4_enc2<KW, PBV, TGV>), grid, wg, 0, s, d_src, src_stride, block_size, n_blocks, d_dst, dst_stride, accel, d_out_size, d_status, dbg)
+        static const int tags_env = cryo_tuning_env("CRYO_LZ4_ENC_TAGS") ? atoi(cryo_tuning_env("CRYO_LZ4_ENC_TAGS")) : -1;
+        const bool tags = tags_env >= 0 ? tags_env != 0 : kLz4EncTagsDefault;
+        const bool ring2k = wkb >= 2 && cryo_tuning_env("CRYO_LZ4_ENC_WINDOW") != nullptr;
+        if (block_size <= (128u << 10)) {
+            if (ring2k) { if (tags) LZ4E_LAUNCH(2048, 1, true); else LZ4E_LAUNCH(2048, 1, false); }
+            else { if (tags) LZ4E_LAUNCH(1024, 1, true); else LZ4E_LAUNCH(1024, 1, false); }
+        } else if (block_size <= (1u << 20)) {
+            if (ring2k) { if (tags) LZ4E_LAUNCH(2048, 4, true); else LZ4E_LAUNCH(2048, 4, false); }
+            else { if (tags) LZ4E_LAUNCH(1024, 4, true); else LZ4E_LAUNCH(1024, 4, false); }
+        } else LZ4E_LAUNCH(2048, 8, true);
+#undef LZ4E_LAUNCH
+    }
+#ifdef CRYO_LZ4E_PROF
+    {
+        unsigned long long h[16];
+        (void)hipStreamSynchronize(s);
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lz4e_prof), sizeof h);
+        fprintf(stderr, "[lz4 enc] %llu sequences, %llu batches (%.2f sequences per batch); cycles per sequence: batch set-up %.0f  decide + far trip %.0f  commit %.0f  backward %.0f  forward %.0f  emit %.0f\n",
+                h[8], h[9], (double)h[8] / h[9], (double)h[0] / h[8], (double)h[1] / h[8], (double)h[2] / h[8], (double)h[3] / h[8], (double)h[4] / h[8], (double)h[5] / h[8]);
+        unsigned long long z[16] = {0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lz4e_prof), z, sizeof z);
+    }
+#endif
     return hipGetLastError();
 }
 
