@@ -53,6 +53,11 @@ def parse_args():
     ap.add_argument("--workload", default="lz4_decode", choices=["lz4_decode", "zstd_decode", "zstd", "lz4", "mixed"])
     ap.add_argument("--level", type=int, default=1, help="zstd level")
     ap.add_argument("--lz4-path", type=int, default=0, help="diagnostic: CRYO_OPT_LZ4_DECODE_PATH (0 auto, 1 in-wave parse, 2 indexed)")
+    ap.add_argument("--flush", choices=["auto", "on", "off"], default="auto",
+                    help="decode workloads: sweep a 512 MiB scratch buffer before every timed step, so that a small batch does not "
+                         "find its input and output in the 256 MiB Infinity Cache (SURVEY.md 8d); auto = on when the batch's "
+                         "buffers are below 2 GiB.  With the flush on, value is the rate of the timed steps (HIP events), the "
+                         "flushes lie outside them")
     ap.add_argument("--ref-gbps", type=float, default=0.0,
                     help="one-GPU rate of the same per-GPU share: per_gpu_efficiency_vs_n1 = slowest rank's rate / this (N > 1)")
     ap.add_argument("--lz4-walkers", type=int, default=0, help="diagnostic: CRYO_OPT_LZ4_INDEX_WALKERS (0 auto)")
@@ -336,17 +341,20 @@ def main():
         barrier()
         t0 = time.perf_counter()
         kernel_ms = []
-        touch = os.environ.get("CRYO_BENCH_TOUCH")   # diagnostic: another kernel sweeps 17 GB of other buffers between the steps
+        # cache flush: re-decoding the same small batch would read its input from, and write its output to, the
+        # 256 MiB Infinity Cache; a 512 MiB memset between the steps (outside the timed launches) evicts both
+        flush = a.flush == "on" or (a.flush == "auto" and n * (stride + ostride) < (2 << 30))
+        d_flush = alloc(512 << 20) if flush else None
         for _ in range(a.steps):
-            if touch:
-                codec.compare_batch(d_raw, B, d_raw, B, B, n, d_mis)
+            if flush:
+                d_flush.memset(0x5A)
                 codec.sync()
             codec.timer_start()          # HIP events on the codec's own stream
             step()
             kernel_ms.append(codec.timer_stop())
         codec.sync()
         barrier()
-        elapsed = max_over_ranks(time.perf_counter() - t0)
+        elapsed = max_over_ranks((sum(kernel_ms) * 1e-3) if flush else (time.perf_counter() - t0))
         verify_all()
         if rank == 0 and os.environ.get("CRYO_BENCH_TRACE"):   # diagnostic: the per-step times, ten per line
             print("[bench trace] device pointers: comp %#x out %#x raw %#x" % tuple(int(getattr(x, "ptr", 0) or 0) for x in (d_comp, d_out, d_raw)), file=sys.stderr)
@@ -367,7 +375,8 @@ def main():
                              "blocks_per_gpu": n, "total_blocks": n * world, "sharding": "block i -> rank i mod N, no collective",
                              "compression_ratio": round(n * B / comp_bytes, 3),
                              "bit_exact": "encode == oracle on %d sampled blocks; decode == original on all %d blocks" % (len(sample_idx), n),
-                             "setup_encode_GBps": round(n * B / (enc_ms * 1e-3) / 1e9, 2)}
+                             "setup_encode_GBps": round(n * B / (enc_ms * 1e-3) / 1e9, 2),
+                             "cache_flush": "512 MiB memset before every timed step; value = rate of the timed steps (HIP events)" if flush else "none (buffers >= 2 GiB)"}
             traffic, traffic_src = lookup_traffic(mname, n, B, a.dist, param)
             out["roofline"] = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,

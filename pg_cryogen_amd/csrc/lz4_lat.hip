@@ -267,8 +267,12 @@ LatLayout lat_layout(uint64_t n, uint32_t B)
 
 bool lz4_latency_eligible(uint64_t n_blocks, uint32_t block_size)
 {
-    return n_blocks >= 1u && n_blocks <= 64u && block_size >= (32u << 10) && block_size <= (2u << 20) &&
-           n_blocks * (uint64_t)block_size <= (64ull << 20);
+    /* tuning aid (debug builds): up to CRYO_LZ4_FEW_MAX blocks / 4 x that many MiB -- where the byte-parallel form stops paying
+     * was measured with it (profiles/r06_lz4_decode_batch_shapes.txt) */
+    static const uint64_t max_env = cryo_tuning_env("CRYO_LZ4_FEW_MAX") ? (uint64_t)atoll(cryo_tuning_env("CRYO_LZ4_FEW_MAX")) : 0u;
+    const uint64_t max_blocks = max_env ? max_env : 64u, max_bytes = max_env ? (max_env << 22) : (64ull << 20);
+    return n_blocks >= 1u && n_blocks <= max_blocks && block_size >= (32u << 10) && block_size <= (2u << 20) &&
+           n_blocks * (uint64_t)block_size <= max_bytes;
 }
 
 size_t lz4_latency_workspace(uint64_t n_blocks, uint32_t block_size) { return lat_layout(n_blocks, block_size).bytes; }
