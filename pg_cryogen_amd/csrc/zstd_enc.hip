@@ -923,16 +923,31 @@ __device__ uint32_t compress_sequences(EncLds &L, uint8_t *dst, const uint2 *seq
     if (lane == 0) dst[seq_head] = (uint8_t)((tll << 6) + (tof << 4) + (tml << 2));
     __builtin_amdgcn_wave_barrier();
     zprof(hs, 6);
-    /* interleaved bitstream, last sequence first.  The state recurrences are serial, but nothing in the loop
-     * touches memory except the three state tables in LDS: the lanes fetch 64 sequences at a time (codes,
-     * values, per-symbol table entries) and the loop reads them with v_readlane. */
+    /* Interleaved bitstream, last sequence first.  Round 6: what is serial -- the three state recurrences -- runs on THREE LANES
+     * at once (lane 0 offsets, 1 match lengths, 2 literal lengths: the order their state bits are written in), 64 sequences
+     * per batch: a lane's step is code -> (deltaNbBits, deltaFindState) -> bits out, next state; the bits a state gives up are
+     * left in LDS.  Everything else is per sequence: lane j then assembles sequence j's up to 90 bits (three state fields, then
+     * the literal-length, match-length and offset extra bits), a scan of the bit counts places them, and they are OR-ed into a
+     * staging buffer in LDS whose whole dwords go out coalesced.  (Before: one sequence at a time with every value broadcast
+     * from its lane and nine 64-bit shifts into a bit accumulator -- ~150 wave instructions per sequence, half of the entropy
+     * stage.)  The LDS used lies over what this stage no longer needs: the code histogram (staging), the table-building cells
+     * (the batch's codes) and the weights / normalised counts / cumulated counts (the states' bits). */
     {
-        BitW b;
         /* a block of many short matches at far offsets can cost more than it covers: the library's writer stops at the end of
-         * its buffer and the block goes out raw; here nothing is written beyond the block's own size (+ the slack every
-         * output slot has), and the size test below gives the same verdict */
-        b.init(dst + op, src_size + 32u > op ? src_size + 32u - op : 0u);
-        uint32_t sm = 0, so = 0, sl = 0;
+         * its buffer and the block goes out raw; here nothing is written beyond the block's own size (+ the slack every output
+         * slot has), and the size test below gives the same verdict */
+        const uint32_t cap = src_size + 32u > op ? src_size + 32u - op : 0u;
+        uint8_t *out = dst + op;
+        uint32_t *stage = L.hist;                                    /* 256 dwords */
+        uint8_t *bcodes = L.cell;                                    /* [64][3]: offset, match-length, literal-length code */
+        uint16_t *recs = reinterpret_cast<uint16_t *>(L.wts);        /* [64][3]: bits out | count << 10 (wts + norm + cumul: 648 bytes) */
+        static_assert(offsetof(EncLds, cell) - offsetof(EncLds, wts) >= 64u * 3u * 2u, "the states' bits need 384 bytes behind wts");
+        for (uint32_t i = lane; i < 256u; i += 64u) stage[i] = 0;
+        const FseCt *ct = lane == 0u ? &L.of : (lane == 1u ? &L.ml : &L.ll);
+        uint32_t state = 0;       /* lanes 0..2 */
+        uint32_t basebit = 0;     /* bit position of stage[0] in the stream (a multiple of 32) */
+        uint32_t bits_total = 0;  /* bits produced so far */
+        __builtin_amdgcn_wave_barrier();
         for (uint32_t c1 = nseq; c1 > 0u;) {
             const uint32_t cnt = c1 < 64u ? c1 : 64u;
             const uint32_t idx = lane < cnt ? c1 - 1u - lane : 0u; /* lane j holds sequence c1-1-j */
@@ -940,38 +955,86 @@ __device__ uint32_t compress_sequences(EncLds &L, uint8_t *dst, const uint2 *seq
             const uint2 q = seqs[idx];
             const uint32_t llv = q.y & 0xFFFFu, mlv = q.y >> 16, ofv = q.x;
             const uint32_t llb = kELLBits[lc], mlb = kEMLBits[mc];
-            const uint32_t l_dnb = L.ll.dnb[lc], o_dnb = L.of.dnb[oc], m_dnb = L.ml.dnb[mc];
-            const int32_t l_df = L.ll.dfind[lc], o_df = L.of.dfind[oc], m_df = L.ml.dfind[mc];
-            uint32_t j = 0;
-            if (c1 == nseq) { /* the last sequence starts the states */
-                sm = fse_init_state(L.ml, lane_get(mc, 0));
-                so = fse_init_state(L.of, lane_get(oc, 0));
-                sl = fse_init_state(L.ll, lane_get(lc, 0));
-                b.add(lane_get(llv, 0), lane_get(llb, 0));
-                b.add(lane_get(mlv, 0), lane_get(mlb, 0));
-                b.add(lane_get(ofv, 0), lane_get(oc, 0));
-                j = 1;
+            bcodes[lane * 3u + 0u] = (uint8_t)oc; bcodes[lane * 3u + 1u] = (uint8_t)mc; bcodes[lane * 3u + 2u] = (uint8_t)lc;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool first = c1 == nseq;
+            if (lane < 3u) {
+                uint32_t j = 0;
+                if (first) { /* the last sequence starts the states and gives up no bits */
+                    state = fse_init_state(*ct, bcodes[lane]);
+                    recs[lane] = 0;
+                    j = 1;
+                }
+                for (; j < cnt; j++) {
+                    const uint32_t sym = bcodes[j * 3u + lane];
+                    const uint32_t nb = (state + ct->dnb[sym]) >> 16;
+                    recs[j * 3u + lane] = (uint16_t)((state & ((1u << nb) - 1u)) | (nb << 10));
+                    state = ct->state[(int32_t)(state >> nb) + ct->dfind[sym]];
+                }
             }
-            for (; j < cnt; j++) {
-                uint32_t nb = (so + lane_get(o_dnb, j)) >> 16;
-                b.add(so, nb);
-                so = uni(L.of.state[(int32_t)(so >> nb) + (int32_t)lane_get((uint32_t)o_df, j)]);
-                nb = (sm + lane_get(m_dnb, j)) >> 16;
-                b.add(sm, nb);
-                sm = uni(L.ml.state[(int32_t)(sm >> nb) + (int32_t)lane_get((uint32_t)m_df, j)]);
-                nb = (sl + lane_get(l_dnb, j)) >> 16;
-                b.add(sl, nb);
-                sl = uni(L.ll.state[(int32_t)(sl >> nb) + (int32_t)lane_get((uint32_t)l_df, j)]);
-                b.add(lane_get(llv, j), lane_get(llb, j));
-                b.add(lane_get(mlv, j), lane_get(mlb, j));
-                b.add(lane_get(ofv, j), lane_get(oc, j));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            /* lane j: sequence j's bits, least significant first: offset / match-length / literal-length state bits, then the
+             * literal-length, match-length and offset extra bits */
+            uint64_t lo = 0, hi = 0;
+            uint32_t tb = 0;
+            if (lane < cnt) {
+                auto put = [&](uint32_t v, uint32_t nb) {
+                    if (nb == 0u) return;
+                    const uint64_t x = (uint64_t)v & ((1ull << nb) - 1ull);
+                    if (tb < 64u) { lo |= x << tb; if (tb + nb > 64u) hi |= x >> (64u - tb); }
+                    else hi |= x << (tb - 64u);
+                    tb += nb;
+                };
+                const uint32_t r0 = recs[lane * 3u + 0u], r1 = recs[lane * 3u + 1u], r2 = recs[lane * 3u + 2u];
+                put(r0 & 1023u, r0 >> 10); put(r1 & 1023u, r1 >> 10); put(r2 & 1023u, r2 >> 10);
+                put(llv, llb); put(mlv, mlb); put(ofv, oc);
             }
+            const uint32_t incl = scan64_incl(tb);
+            const uint32_t rel = bits_total - basebit + (incl - tb); /* this lane's first bit inside the staging buffer */
+            if (tb != 0u) {
+                const uint32_t w = rel >> 5, sh = rel & 31u;
+                const uint32_t d0 = (uint32_t)(lo << sh), d1 = (uint32_t)((lo >> 1) >> (31u - sh)), d2 = (uint32_t)(((lo >> 33) >> (31u - sh)) | (hi << sh)),
+                               d3 = (uint32_t)((hi >> 1) >> (31u - sh));
+                atomicOr(&stage[w], d0);
+                if (d1) atomicOr(&stage[w + 1u], d1);
+                if (d2) atomicOr(&stage[w + 2u], d2);
+                if (d3) atomicOr(&stage[w + 3u], d3);
+            }
+            bits_total += lane_get(incl, 63);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            /* whole dwords out, the partial one to the front */
+            const uint32_t ndw = (bits_total - basebit) >> 5;
+            uint32_t carry = 0;
+            for (uint32_t i = lane; i < ndw; i += 64u) {
+                const uint32_t v = stage[i];
+                const uint32_t bo = (basebit >> 3) + 4u * i;
+                if (bo + 4u <= cap) __builtin_memcpy(out + bo, &v, 4);
+            }
+            carry = stage[ndw];
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("" ::: "memory");
+            for (uint32_t i = lane; i <= ndw; i += 64u) stage[i] = i == 0u ? carry : 0u;
+            if (ndw == 0u && lane == 0u) stage[0] = carry;
+            basebit += 32u * ndw;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
             c1 -= cnt;
         }
-        b.add(sm, (uint32_t)L.ml.log);
-        b.add(so, (uint32_t)L.of.log);
-        b.add(sl, (uint32_t)L.ll.log);
-        op += b.close();
+        /* the final states (match lengths, offsets, literal lengths), the end mark, the last bytes */
+        {
+            const uint32_t sm = lane_get(state, 1), so = lane_get(state, 0), sl = lane_get(state, 2);
+            uint64_t acc = uni(stage[0]);
+            uint32_t nacc = bits_total - basebit;
+            auto add = [&](uint32_t v, uint32_t nb) { if (nb) { acc |= ((uint64_t)v & ((1ull << nb) - 1ull)) << nacc; nacc += nb; } };
+            add(sm, (uint32_t)uni((uint32_t)L.ml.log)); add(so, (uint32_t)uni((uint32_t)L.of.log)); add(sl, (uint32_t)uni((uint32_t)L.ll.log));
+            add(1u, 1u);
+            const uint32_t nbytes = (nacc + 7u) >> 3, bo = basebit >> 3;
+            if (lane < nbytes && bo + lane < cap) out[bo + lane] = (uint8_t)(acc >> (8u * lane));
+            op += bo + nbytes;
+        }
         zprof(hs, 7);
         if (last_ncount != 0xFFFFFFFFu && op - last_ncount < 4u) return 0;
     }
