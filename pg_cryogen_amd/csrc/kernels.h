@@ -44,12 +44,7 @@ hipError_t launch_gather_blocks(hipStream_t s, const uint8_t *d_pool, const Gath
                                 uint32_t block_size, uint32_t first);
 
 /* LZ4 block format */
-#ifndef CRYO_IDX_V2
-#define CRYO_IDX_V2 0 /* index pass geometry (lz4_index.hip): 0 = 512-byte rings, 128-byte chunks, four waves per CU; 1 = the round-4
-                       * experiment (256-byte rings, 64-byte chunks, eight waves per CU, twice the walkers): slower, see lz4_index.hip */
-#endif
-/* walker lanes that are resident at once: 256 CUs x waves per CU x 64 */
-constexpr uint32_t kLz4IndexResidentLanes = CRYO_IDX_V2 ? 131072u : 65536u;
+constexpr uint32_t kLz4IndexResidentLanes = 65536u;
 /* per-handle options (include/cryo_codec.h: CRYO_OPT_LZ4_DECODE_PATH, CRYO_OPT_LZ4_INDEX_WALKERS); 0 = automatic */
 struct Lz4DecodeOpts {
     int path = 0;    /* 1: in-wave parse kernel, 2: sequence index + indexed decoder, 3: few blocks, every output byte in parallel (lz4_lat.hip) */

@@ -22,9 +22,6 @@ namespace cryo {
 namespace {
 
 #define LDS_FENCE() asm volatile("" ::: "memory")
-#ifndef CRYO_ABL
-#define CRYO_ABL 0 /* timing experiments only (profiles/scripts/r02_ablate3.sh): parts of the copy engine compiled out, wrong bytes */
-#endif
 
 template <uint32_t R, uint32_t TMAX>
 struct CopyLds {
@@ -89,12 +86,6 @@ __device__ inline void lane_runs(uint8_t *ring, const uint8_t *sbase, uint32_t r
     }
 }
 
-#ifndef CRYO_COPY_V2
-#define CRYO_COPY_V2 0 /* round 4 experiment: all lane-run reads of a batch before its first write (loses 6 %, profiles/r04_lz4_decode_ab.txt) */
-#endif
-#ifndef CRYO_MS_V2
-#define CRYO_MS_V2 0   /* round 4 experiment: match space resolved four chunks at a time by fixed-point rounds (loses: chains are deep) */
-#endif
 
 /* the 8/4/2/1-byte pieces of a run shorter than 16 bytes, from registers (exact to the byte) */
 template <uint32_t R>
@@ -204,7 +195,7 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
     const unsigned long long depm = wave_ballot(dep);
     const uint32_t drank = __builtin_amdgcn_mbcnt_hi((uint32_t)(depm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)depm, 0u));
 
-    if (!(CRYO_ABL & 128)) {
+    {
     if (lane < kBmW) L.mbm[lane] = 0u;
     LDS_FENCE();
     if (dep) {
@@ -223,16 +214,9 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
     {
         uint32_t spill = 0; /* bytes this lane wrote beyond the ring's end */
         const uint4 z = make_uint4(0, 0, 0, 0);
-#if CRYO_COPY_V2
-        (void)z;
-        lane_copies_v2<R>(L.ring, L.in, act ? ll : 0u, lpos, op0 + ostart, indep ? ml : 0u, op0 + mrel - off, op0 + mrel, isfar, xfa, xfb, spill);
-#else
-        if (!(CRYO_ABL & 8) && !NOLIT)
-        lane_runs<R, kInMask>(L.ring, L.in, act ? ll : 0u, lpos, op0 + ostart, false, z, z, spill);
+        if (!NOLIT) lane_runs<R, kInMask>(L.ring, L.in, act ? ll : 0u, lpos, op0 + ostart, false, z, z, spill);
         /* (the 16 bytes behind the ring mirror its first 16 for reads that start in its last 15: lz4_seq_batch) */
-        if (!(CRYO_ABL & 16))
         lane_runs<R, R - 1u>(L.ring, L.ring, indep ? ml : 0u, op0 + mrel - off, op0 + mrel, isfar, xfa, xfb, spill);
-#endif
         /* a batch crosses the ring's end at most once: fold the bytes that ran over back to the start */
         const unsigned long long sm = wave_ballot(spill != 0u);
         if (sm != 0ull) {
@@ -243,7 +227,7 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
     }
     LDS_FENCE();
     stamp(st, 5);
-    if (!(CRYO_ABL & 128)) {
+    {
         /* bits before each match-space chunk */
         static_assert(kNc <= 64, "one lane per chunk");
         uint32_t cnt = 0;
@@ -258,7 +242,7 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
 
     /* ---- match space: chunks in order ---- */
     {
-        const uint32_t nM = (CRYO_ABL & 32) ? 0u : (MT + 63u) >> 6;
+        const uint32_t nM = (MT + 63u) >> 6;
         constexpr uint32_t U = 4;
         for (uint32_t c0 = 0; c0 < nM; c0 += U) {
             uint32_t da[U], ra[U];
@@ -290,42 +274,6 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
                     pmv[u] = wave_ballot(a) & wave_ballot(ge);
                 }
             }
-#if CRYO_MS_V2
-            /* The group's four chunks together (round 4).  Taken one after the other, each chunk cost a trip for its
-             * first copy and one per frontier round (1.94): twelve trips per batch.  Now: one copy of all 256 bytes,
-             * then the bytes whose source lies inside the group's own span are copied again, all of them, until a round
-             * changes nothing.  Sources lie strictly below their destinations, so after round r every byte whose chain
-             * of sources is r links deep is final and stays so, and a round without a change is the fixed point: rounds
-             * = the deepest chain inside the group + 1, whatever the chunk boundaries. */
-            {
-                const uint32_t D0 = uni(da[0]);
-                uint8_t *dp[U];
-                const uint8_t *sp[U];
-                uint32_t x[U];
-                bool pend[U];
-#pragma unroll
-                for (uint32_t u = 0; u < U; u++) {
-                    dp[u] = &L.ring[da[u] & (R - 1u)];
-                    sp[u] = &L.ring[ra[u] & (R - 1u)];
-                    pend[u] = actv[u] && ra[u] >= D0;
-                    if ((c0 + u) * 64u < MT) st.chunks++;
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < U; u++) x[u] = *sp[u];
-#pragma unroll
-                for (uint32_t u = 0; u < U; u++) if (actv[u]) *dp[u] = (uint8_t)x[u];
-                bool more = pend[0] | pend[1] | pend[2] | pend[3];
-                while (wave_any(more)) {
-                    st.rounds++;
-                    uint32_t y[U];
-#pragma unroll
-                    for (uint32_t u = 0; u < U; u++) { y[u] = x[u]; if (pend[u]) y[u] = *sp[u]; }
-                    more = (y[0] != x[0]) | (y[1] != x[1]) | (y[2] != x[2]) | (y[3] != x[3]);
-#pragma unroll
-                    for (uint32_t u = 0; u < U; u++) { if (pend[u]) *dp[u] = (uint8_t)y[u]; x[u] = y[u]; }
-                }
-            }
-#else
 #pragma unroll
             for (uint32_t u = 0; u < U; u++) {
                 if ((c0 + u) * 64u < MT) {
@@ -350,7 +298,6 @@ __device__ inline void seq_copy(Wave<R> &w, const CopyLds<R, TMAX> &L, const uin
                     }
                 }
             }
-#endif
         }
     }
     stamp(st, 6);

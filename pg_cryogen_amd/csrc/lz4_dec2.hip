@@ -28,18 +28,6 @@
 #include <cstdio>
 #include <cstdlib>
 
-#ifndef CRYO_DEC_R
-#define CRYO_DEC_R 4096   /* output ring of a decoding wave */
-#endif
-#ifndef CRYO_DEC_WPB
-#define CRYO_DEC_WPB 4    /* waves (blocks) per workgroup */
-#endif
-#ifndef CRYO_DEC_OCC
-#define CRYO_DEC_OCC 6
-#endif
-#ifndef CRYO_DEC_DUAL
-#define CRYO_DEC_DUAL 1   /* batches of at most kDualMaxBlocks blocks: two waves per block (k_lz4_dec_dual) */
-#endif
 namespace cryo {
 
 /* ---------------------------------------------------------------------------------------------
@@ -200,8 +188,7 @@ __device__ inline uint32_t lz4_seq_batch(Wave<R> &w, const CopyLds<R, kT2> &L, u
         atomicAdd(&stop_hist[why], 1ull);
     }
     stamp(st, 1);
-    if (!(st.ablate & 2u) && !(CRYO_ABL & 64)) w.flush();   /* what earlier batches produced; far sources below are read back from it */
-    else if (CRYO_ABL & 64) w.flushed = w.op & ~(kChunk - 1u);
+    if (!(st.ablate & 2u)) w.flush();   /* what earlier batches produced; far sources below are read back from it */
     else w.flushed = w.op & ~(kChunk - 1u);
     stamp(st, 2);
     if (!(st.ablate & 4u)) w.top_up(); else w.nstale = 0;
@@ -335,10 +322,12 @@ __device__ inline uint32_t lz4_general_seq(Wave<R> &w, uint32_t &vp, const uint3
     return 0u;
 }
 
-constexpr uint32_t kDecR = CRYO_DEC_R, kDecWpb = CRYO_DEC_WPB;
+constexpr uint32_t kDecR = 4096;   /* output ring of a decoding wave */
+constexpr uint32_t kDecWpb = 4;   /* waves (blocks) per workgroup */
+constexpr int kDecOcc = 6;        /* workgroups per CU the register allocator aims at */
 
 template <uint32_t R, bool STATS, uint32_t WPB, bool MULTI>
-__global__ void __launch_bounds__(64 * WPB, CRYO_DEC_OCC)
+__global__ void __launch_bounds__(64 * WPB, kDecOcc)
 k_lz4_dec_seq(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ src_off,
               const uint32_t *__restrict__ src_size, uint8_t *dst_base, uint64_t dst_stride, uint32_t B,
               uint64_t n_blocks, int32_t *__restrict__ status, unsigned long long *stats,
@@ -746,12 +735,10 @@ static hipError_t launch_dec_seq(hipStream_t s, const uint8_t *d_src, const uint
         hipLaunchKernelGGL(k_lz4_dec_dual, dim3((uint32_t)(n_blocks - first)), dim3(128), 0, q, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size,
                            n_blocks, d_status, tbl, Lx.cap, seg, Lx.logS, Lx.cap_main + Lx.ext, Lx.ext, heavy, d_done, first);
     };
-#if CRYO_DEC_DUAL
     if (waves == 2 || (waves == 0 && n_blocks <= kDualMaxBlocks)) { /* a batch that leaves most of the chip idle: two waves per block */
         dual(s, 0);
         return hipGetLastError();
     }
-#endif
     /* The last round (round 5).  A block is its wave's chain, so a batch of 1.33 rounds -- 8 192 blocks of 1 MiB, the reference's
      * block size -- takes two rounds' time: the last 2 048 blocks run on a chip that is two thirds empty at the pace of a full
      * one.  Those blocks go to a low-priority side stream with two waves each (1.4-1.7 x per block, k_lz4_dec_dual): its
@@ -760,7 +747,6 @@ static hipError_t launch_dec_seq(hipStream_t s, const uint8_t *d_src, const uint
      * it loses 1-6 % (the two-wave workgroups wait for LDS the one-wave ones hold): only between one and two rounds, and for
      * a last round of at most 2 048 blocks. */
     uint64_t head = n_blocks;
-#if CRYO_DEC_DUAL
     if (waves == 0 && opts != nullptr && opts->side != nullptr && opts->fork != nullptr && opts->join != nullptr) {
         const uint64_t resident = (uint64_t)(opts->cus > 0 ? opts->cus : 256) * 6u * kDecWpb;
         if (n_blocks > resident && n_blocks <= 2u * resident) {
@@ -768,7 +754,6 @@ static hipError_t launch_dec_seq(hipStream_t s, const uint8_t *d_src, const uint
             if (rest != 0u && rest <= 2048u) head = n_blocks - rest;
         }
     }
-#endif
     if (head != n_blocks) { /* behind the index pass; a fork that cannot be made means one stream for the whole batch */
         if (hipEventRecord(opts->fork, s) != hipSuccess || hipStreamWaitEvent(opts->side, opts->fork, 0) != hipSuccess) {
             (void)hipGetLastError();

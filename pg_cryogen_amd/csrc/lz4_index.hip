@@ -34,30 +34,21 @@
 
 namespace cryo {
 
-#ifndef CRYO_IDX_RING
-#define CRYO_IDX_RING (CRYO_IDX_V2 ? 256 : 512)
-#endif
-#ifndef CRYO_IDX_DIST
-#define CRYO_IDX_DIST 2 /* rounds between the request of a chunk and its store into the ring (1 or 2) */
-#endif
-/* Geometry.  A chunk is what one walker is fed at a time: kIdxLpw lanes x 16 bytes.  A turn issues two loads, each serving
- * 64 / kIdxLpw walkers; a round is four turns.  Production (CRYO_IDX_V2 = 0): 128-byte chunks (a cache line) into 512-byte
- * rings, every walker served once per round -- 39 KB of LDS per wave, one wave per SIMD.
- * Round 4 tried to get two waves per SIMD (CRYO_IDX_V2 = 1: 64-byte chunks, every walker served twice per round, 256-byte
- * rings, one shared trash slot, positions buffered in lines of 8: 19.5 KB per wave, and two walkers per block on a full
- * batch so that all of them are resident).  It loses (profiles/r04_lz4_decode_ab.txt, r04_ab9: 2.24 -> 3.09 ms; 2.87 with
- * one walker per block): a walker uses 0 .. 70 bytes of its stream per turn, and with 256 bytes of ring minus what is in
- * flight it runs dry where 512 bytes carry it through; smaller rings with 128-byte chunks starve outright (r04_ab6).  The
- * ring a walker needs is set by the variance of its appetite, not by the latency to cover: LDS per walker does not shrink
- * with more waves per SIMD. */
-constexpr uint32_t kIdxLanes = 64, kIdxRing = CRYO_IDX_RING;
-constexpr uint32_t kIdxLpw = CRYO_IDX_V2 ? 4u : 8u;          /* lanes that load one walker's chunk */
-constexpr uint32_t kIdxChunk = kIdxLpw * 16u;                /* 64 / 128 bytes */
-constexpr uint32_t kIdxWpl = kIdxLanes / kIdxLpw;            /* walkers per load: 16 / 8 */
-constexpr uint32_t kIdxGroups = kIdxLanes / (2u * kIdxWpl);  /* walker groups, one per turn in rotation: 2 / 4 */
-constexpr uint32_t kIdxLine = CRYO_IDX_V2 ? 8u : 16u;        /* positions per stored line (16 / 32 bytes) */
+constexpr uint32_t kIdxDist = 2; /* rounds between the request of a chunk and its store into the ring (one round of distance: no faster, profiles/r03_variants_ab.txt) */
+/* Geometry.  A chunk is what one walker is fed at a time: kIdxLpw lanes x 16 bytes = a cache line.  A turn issues two loads,
+ * each serving 64 / kIdxLpw walkers; a round is four turns; 512-byte rings, every walker served once per round -- 39 KB of
+ * LDS per wave, one wave per SIMD.  (Round 4 tried two waves per SIMD with 64-byte chunks and 256-byte rings: 2.24 -> 3.09 ms
+ * -- a walker uses 0 .. 70 bytes of its stream per turn and runs dry on 256 bytes; the ring a walker needs is set by the
+ * variance of its appetite, not by the latency to cover.  profiles/r04_lz4_decode_ab.txt; the variant is
+ * profiles/scripts/r06_removed_variants.patch.) */
+constexpr uint32_t kIdxLanes = 64, kIdxRing = 512;
+constexpr uint32_t kIdxLpw = 8u;                             /* lanes that load one walker's chunk */
+constexpr uint32_t kIdxChunk = kIdxLpw * 16u;                /* 128 bytes */
+constexpr uint32_t kIdxWpl = kIdxLanes / kIdxLpw;            /* walkers per load: 8 */
+constexpr uint32_t kIdxGroups = kIdxLanes / (2u * kIdxWpl);  /* walker groups, one per turn in rotation: 4 */
+constexpr uint32_t kIdxLine = 16u;                           /* positions per stored line (32 bytes) */
 constexpr uint32_t kIdxPutStores = kIdxLine / 8u;            /* 16-byte stores of IDX_PUT per round */
-constexpr uint32_t kIdxTrashPerLane = CRYO_IDX_V2 ? 0u : 1u; /* v1: a trash slot per lane; v2: one for the wave */
+constexpr uint32_t kIdxTrashPerLane = 1u;                    /* a trash slot per lane */
 constexpr uint32_t kIdxStride = kIdxRing + 16u; /* bank skew between rings */
 
 __device__ inline uint32_t bperm(uint32_t v, uint32_t src_lane)
@@ -204,9 +195,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
 #define IDX_SRC(q) const uint64_t saoff##q = ((uint64_t)bperm((uint32_t)(aoff >> 32), kIdxWpl * q + wil) << 32) | bperm((uint32_t)aoff, kIdxWpl * q + wil); \
                    const uint32_t svend##q = bperm(vend, kIdxWpl * q + wil);
     IDX_SRC(0) IDX_SRC(1) IDX_SRC(2) IDX_SRC(3)
-#if !CRYO_IDX_V2
     IDX_SRC(4) IDX_SRC(5) IDX_SRC(6) IDX_SRC(7)
-#endif
 #undef IDX_SRC
     const uint32_t rb = lane * kIdxStride; /* this lane's ring inside s_ring */
 
@@ -224,9 +213,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
     const uint32_t mytrash = kTrash + (kIdxTrashPerLane ? lane * 16u : 0u);
 #define IDX_SLOT(n) u32x4 fd##n = {0, 0, 0, 0}, fe##n = fd##n; uint32_t fa##n = mytrash, fb##n = fa##n; /* nothing requested yet */
     IDX_SLOT(0) IDX_SLOT(1) IDX_SLOT(2) IDX_SLOT(3)
-#if CRYO_IDX_DIST == 2
     IDX_SLOT(4) IDX_SLOT(5) IDX_SLOT(6) IDX_SLOT(7)
-#endif
 #undef IDX_SLOT
 
     /* a chunk's size while a chunk of this lane is on its way, else 0: per slot set (A / B) and per visit of the round
@@ -241,7 +228,7 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
          * && / || / if the compiler built exec-mask branches around one- and two-instruction bodies, 450 scalar mask
          * instructions per round of 1160; a lone wave per SIMD issues one instruction per four cycles whatever its kind,
          * so the pass is as long as its instruction count (round 3: 3.06 -> 2.4 ms for the headline batch). */
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((8 + kIdxPutStores) * (CRYO_IDX_DIST - 1) + 6 + kIdxPutStores) : "memory");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((8 + kIdxPutStores) * (kIdxDist - 1) + 6 + kIdxPutStores) : "memory");
         *reinterpret_cast<u32x4 *>(s_ring + fa) = fd;
         *reinterpret_cast<u32x4 *>(s_ring + fb) = fe;
         {
@@ -271,13 +258,8 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
              * commits (vmcnt(N)); a conditional load made it drain the queue once per round (2.3 us a round) */
             const uint8_t *g1 = src_base + (soff + ((p1 & (o1 < sve)) ? o1 : 0u));
             const uint8_t *g2 = src_base + (soff2 + ((p2 & (o2 < sve2)) ? o2 : 0u));
-#if CRYO_NT_LOADS
-            asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(fd) : "v"(g1));
-            asm volatile("global_load_dwordx4 %0, %1, off nt" : "+v"(fe) : "v"(g2));
-#else
             asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(fd) : "v"(g1)); /* "+": the slot keeps its registers round after round (see above) */
             asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(fe) : "v"(g2));
-#endif
         }
         /* ---- one hop, branch-free for the two common states (token, match-length extension) ---- */
         {
@@ -383,16 +365,13 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
      * reached memory for a 0.83 GB index -- the L2 does not hold 65 536 rows' open lines until they are full.  One
      * unconditional pair of stores per round (a lane with nothing to store writes its dummy slot), see the note on
      * the loads.  A macro, not a lambda: captured by a lambda, the packs lived in scratch memory. */
-#ifndef CRYO_IDX_NT_ROWS
-#define CRYO_IDX_NT_ROWS 0 /* experiment: the rows' 32-byte lines as non-temporal stores (profiles/r05_index_spread.txt) */
-#endif
 #define IDX_LINE_COPY(ps_, pd_)                                                                               \
     {                                                                                                        \
         const uint4 v0_ = *reinterpret_cast<const uint4 *>(ps_);                                             \
-        store16_out<CRYO_IDX_NT_ROWS != 0>(reinterpret_cast<uint8_t *>(pd_), v0_);                           \
+        store16_out<false>(reinterpret_cast<uint8_t *>(pd_), v0_);                           \
         if (kIdxLine == 16u) {                                                                               \
             const uint4 v1_ = *reinterpret_cast<const uint4 *>((ps_) + 8);                                   \
-            store16_out<CRYO_IDX_NT_ROWS != 0>(reinterpret_cast<uint8_t *>((pd_) + 8), v1_);                 \
+            store16_out<false>(reinterpret_cast<uint8_t *>((pd_) + 8), v1_);                 \
         }                                                                                                    \
     }
 #define IDX_PUT()                                                                                            \
@@ -416,30 +395,16 @@ k_lz4_index(const uint8_t *__restrict__ src_base, const uint64_t *__restrict__ s
         }                                                                                                    \
     }
 #define IDX_TURN(j, n, o, sa, sb) turn(j, fd##n, fe##n, fa##n, fb##n, o, saoff##sa, svend##sa, saoff##sb, svend##sb);
-#if CRYO_IDX_V2
-#define IDX_ROUND(a, b, c, d, o0, o1)                           \
-    IDX_PUT()                                                   \
-    IDX_TURN(0, a, o0, 0, 1) IDX_TURN(1, b, o0, 2, 3) IDX_TURN(2, c, o1, 0, 1) IDX_TURN(3, d, o1, 2, 3)
-#else
 #define IDX_ROUND(a, b, c, d, o0, o1)                           \
     IDX_PUT()                                                   \
     IDX_TURN(0, a, o0, 0, 1) IDX_TURN(1, b, o0, 2, 3) IDX_TURN(2, c, o0, 4, 5) IDX_TURN(3, d, o0, 6, 7)
-#endif
-#if CRYO_IDX_DIST == 2
 #define IDX_ROUNDS() IDX_ROUND(0, 1, 2, 3, outA0, outA1) IDX_ROUND(4, 5, 6, 7, outB0, outB1)
-#else
-#define IDX_ROUNDS() IDX_ROUND(0, 1, 2, 3, outA0, outA1)
-#endif
     /* (the compiler does not see the assembly loads: nothing it generates behind a walk may meet one still in flight.  The
      * drain names every slot: their registers are dead to the compiler once the loop is left, and without the operands it
      * may hand them to something else in FRONT of the drain -- k_zchain4 of zstd_pipe.hip did, and a late load overwrote
      * an address) */
-#if CRYO_IDX_DIST == 2
 #define IDX_DRAIN() asm volatile("s_waitcnt vmcnt(0)" : "+v"(fd0), "+v"(fe0), "+v"(fd1), "+v"(fe1), "+v"(fd2), "+v"(fe2), "+v"(fd3), "+v"(fe3), \
                                  "+v"(fd4), "+v"(fe4), "+v"(fd5), "+v"(fe5), "+v"(fd6), "+v"(fe6), "+v"(fd7), "+v"(fe7) : : "memory");
-#else
-#define IDX_DRAIN() asm volatile("s_waitcnt vmcnt(0)" : "+v"(fd0), "+v"(fe0), "+v"(fd1), "+v"(fe1), "+v"(fd2), "+v"(fe2), "+v"(fd3), "+v"(fe3) : : "memory");
-#endif
 #define IDX_WALK()                                              \
     if (wave_any(!done)) {                                         \
         do {                                                    \

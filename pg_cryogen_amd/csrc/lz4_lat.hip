@@ -32,9 +32,6 @@ namespace cryo {
 
 namespace {
 
-#ifndef CRYO_LAT_FEW
-#define CRYO_LAT_FEW 1 /* 1: k_lz4_index_few (up to 1 024 walkers per block, direct loads; round 5), 0: k_lz4_index with 64 */
-#endif
 constexpr uint32_t kLatMaxS = 1024;                   /* walkers per block of the index pass, at most */
 constexpr uint32_t kMFLimit = 12, kLastLiterals = 5; /* LZ4_decompress_safe's end-of-block rules (lz4.c) */
 
@@ -230,16 +227,11 @@ inline size_t al256(size_t v) { return (v + 255u) & ~(size_t)255u; }
 LatLayout lat_layout(uint64_t n, uint32_t B)
 {
     LatLayout y;
-#if CRYO_LAT_FEW
     y.ix = lz4_index_layout_few(n, B);
     {   /* sequence slots per block: what the rows hold, and no more than a block of B bytes can have (three bytes a sequence) */
         const uint64_t rows = ((uint64_t)y.ix.cap_main + y.ix.ext) << y.ix.logS, most = (uint64_t)B / 3u + 256u;
         y.nmax = (uint32_t)(((rows < most ? rows : most) + 255u) & ~(uint64_t)255u);
     }
-#else
-    y.ix = lz4_index_layout(n, B, 64u);
-    y.nmax = (64u * (y.ix.cap_main + y.ix.ext) + 255u) & ~255u;
-#endif
     y.bpad = (B + 4095u) & ~4095u;
     y.rounds = 2;
     while ((1ull << (2u * (y.rounds - 1u))) < B) y.rounds++; /* a chain is at most B hops long and shrinks four times per round (k_lat_jump) */
@@ -291,22 +283,14 @@ hipError_t launch_lz4_decompress_latency(hipStream_t s, const uint8_t *d_src, co
     const LatLayout y = lat_layout(n_blocks, block_size);
     if (workspace_bytes < y.bytes) return hipErrorInvalidValue;
     uint8_t *ws = static_cast<uint8_t *>(d_workspace);
-#if CRYO_LAT_FEW
     if (hipError_t e = launch_lz4_index_few(s, d_src, d_src_off, d_src_size, n_blocks, block_size, d_workspace, y.ix); e != hipSuccess) return e;
-#else
-    if (hipError_t e = launch_lz4_index(s, d_src, d_src_off, d_src_size, n_blocks, block_size, d_workspace, y.ix); e != hipSuccess) return e;
-#endif
     LatArgs A = {};
     A.src_base = d_src; A.src_off = d_src_off; A.src_size = d_src_size;
     A.dst_base = d_dst; A.dst_stride = dst_stride; A.B = block_size; A.n_blocks = (uint32_t)n_blocks; A.status = d_status;
     A.tbl = reinterpret_cast<const uint16_t *>(ws);
     A.seg = reinterpret_cast<const uint2 *>(ws + y.ix.seg_off);
     A.tbl_cap = y.ix.cap; A.cap_s = y.ix.cap_main + y.ix.ext; A.ext = y.ix.ext; A.logS = y.ix.logS;
-#if CRYO_LAT_FEW
     A.ixfailed = lz4_index_few_failed(d_workspace, y.ix, n_blocks);
-#else
-    A.ixfailed = nullptr;
-#endif
     A.nmax = y.nmax;
     A.segbase = reinterpret_cast<uint32_t *>(ws + y.o_segbase);
     A.nseq = reinterpret_cast<uint32_t *>(ws + y.o_nseq);
@@ -333,16 +317,9 @@ hipError_t launch_lz4_decompress_latency(hipStream_t s, const uint8_t *d_src, co
     for (uint32_t r = 0; r < y.rounds; r++)
         hipLaunchKernelGGL(k_lat_jump, dim3((block_size + 1023u) / 1024u, nb), dim3(256), 0, s, A, r);
     hipLaunchKernelGGL(k_lat_gather, dim3((block_size + 4095u) / 4096u, nb), dim3(256), 0, s, A);
-#if CRYO_LAT_FEW
     /* what was left (a failed check, offset 0, an index the walkers could not complete, blocks of almost only literals): the
      * decoder that parses in the wave -- it needs no index, and verdicts and bytes are its */
     return launch_lz4_dec_ring(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, false, A.done);
-#else
-    /* what was left: the batch decoder with the same index, the in-wave parser for blocks of almost only literals */
-    if (hipError_t e = launch_lz4_dec_seq_rest(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status,
-                                               d_workspace, y.ix, A.done); e != hipSuccess) return e;
-    return launch_lz4_dec_ring(s, d_src, d_src_off, d_src_size, d_dst, dst_stride, block_size, n_blocks, d_status, true);
-#endif
 }
 
 } // namespace cryo

@@ -51,12 +51,6 @@ __device__ inline uint32_t ctz64(unsigned long long m) { return (uint32_t)__buil
 #ifndef CRYO_NT_FLUSH
 #define CRYO_NT_FLUSH 0
 #endif
-#ifndef CRYO_STREAM_ROT
-#define CRYO_STREAM_ROT 0 /* experiment: wave_stream_pattern starts every block's run at another KiB (profiles/r05_stream_rot.txt) */
-#endif
-#ifndef CRYO_NT_LOADS
-#define CRYO_NT_LOADS 0 /* experiment: the compressed input (read once) with non-temporal loads: no gain (profiles/r05_nt_ab.txt) */
-#endif
 template <bool NT>
 __device__ inline void store16_out(uint8_t *p, const uint4 v)
 {
@@ -92,12 +86,7 @@ struct Wave {
     {
         const uint32_t o = at + lane * 8u;
         uint2 v = make_uint2(0, 0);
-#if CRYO_NT_LOADS
-        typedef uint32_t u32x2_ __attribute__((ext_vector_type(2)));
-        if (o < vend) { const u32x2_ y = __builtin_nontemporal_load(reinterpret_cast<const u32x2_ *>(abase + o)); v = make_uint2(y.x, y.y); }
-#else
         if (o < vend) v = *reinterpret_cast<const uint2 *>(abase + o);
-#endif
         return v;
     }
     __device__ inline void prefetch()
@@ -264,18 +253,7 @@ __device__ inline bool wave_stream_pattern(Wave<R> &w, uint32_t &rem, bool zero)
 #pragma unroll
     for (uint32_t k = 0; k < R / kChunk; k++) *reinterpret_cast<uint4 *>(w.ring + ((k * kChunk + w.lane * 16u) & (R - 1))) = v;
     const uint32_t nch = rem / kChunk;
-#if CRYO_STREAM_ROT
-    /* every block starts its run at another KiB of it: thousands of waves that reach their long run at the same moment would
-     * otherwise sweep the same address bits -- the same memory channels -- in step (the order of the stores is free: every
-     * position holds pattern[x mod 16]) */
-    uint32_t c0 = (uint32_t)(((reinterpret_cast<uintptr_t>(w.dst) >> 12) * 2654435761ull) >> 7) % nch;
-    for (uint32_t i = 0; i < nch; i++) {
-        store16_out<CRYO_NT_STREAM != 0>(w.dst + w.op + c0 * kChunk + w.lane * 16u, v);
-        c0 = c0 + 1u == nch ? 0u : c0 + 1u;
-    }
-#else
     for (uint32_t c = 0; c < nch; c++) store16_out<CRYO_NT_STREAM != 0>(w.dst + w.op + c * kChunk + w.lane * 16u, v);
-#endif
     w.op += nch * kChunk;
     w.flushed = w.op;
     rem -= nch * kChunk;

@@ -14,8 +14,9 @@
  *   K2  k_zhufw   wave per block   Huffman literals, 16 walkers per stream from guessed bit positions (a prefix code
  *                                  resynchronises), two symbols per lookup; k_zhuf (lane per stream, 16 blocks' tables
  *                                  in LDS) takes what the walkers hand back
- *   K3  k_zchain  lane per block   the serial part of the FSE sequence stream only: 29 blocks' tables (16-bit entries)
- *                                  in LDS, 8 bytes per sequence out (bit position, the three states)
+ *   K3  k_zchain4 quad per block   the serial part of the FSE sequence stream only (the three states on three lanes of a
+ *                                  quad): 16 blocks' tables (16-bit entries) in LDS, 8 bytes per sequence out (bit
+ *                                  position, the three states)
  *   K3' k_zmat    wave per frame   values (base + extra bits) and repeat offsets of 512 sequences per round: the offset
  *                                  history by a scan over "history transforms"
  *   K4  k_zexec   wave per frame   sequence execution with the shared LZ copy engine (lz_common.h): 8-byte records
@@ -1129,7 +1130,7 @@ __device__ inline uint32_t ml_xbits(uint32_t sym)
 }
 
 /* ------------------------------------------------------------------------------------------------ K3' */
-/* k_zchain + k_zmat: the sequence stage split by what is serial in it.
+/* k_zchain4 + k_zmat: the sequence stage split by what is serial in it.
  *
  * Round 2's k_zseq did everything for a sequence on the one lane that owns the block: 321 instructions, and a lone wave per
  * SIMD (LDS capacity: the decoding tables) issues one instruction every ~4.7 cycles -- the stage is as long as its
@@ -1139,241 +1140,14 @@ __device__ inline uint32_t ml_xbits(uint32_t sym)
  * function of (bit position, three symbols) per sequence and are computed afterwards, 64 sequences at a time, by a
  * wave per frame (k_zmat) -- the history by a parallel scan over "history transforms".
  *
- * k_zchain, lane per block as before, 29 blocks' tables in LDS: per sequence it stores an 8-byte record (unread
+ * The chain kernel (round 3: k_zchain, a lane per block, 29 blocks' tables in LDS; since round 4 k_zchain4 below -- the lane-
+ * per-block kernel is profiles/scripts/r06_removed_variants.patch) stores an 8-byte record per sequence (unread
  * bits before the sequence | the three symbols), takes the state bits out of ONE 8-byte window read from the
  * lane's ring (unaligned ds_read_b64; the rare sequence with more than 57 bits re-reads) and looks the next entries
  * up: one LDS round trip and ~100 instructions per sequence.  The rings (128 bytes per lane, contiguous, first 8 bytes
  * mirrored behind the end) are fed cooperatively like the LZ4 index pass's: in turn J the wave's 64 lanes load one
  * 16-byte piece each for 16 walkers (4 lanes x 16 B = half a cache line per walker) that have room, and store it
  * four turns later; every per-lane condition is evaluated eagerly. */
-#ifndef CRYO_ZCHAIN_PER_WAVE
-#define CRYO_ZCHAIN_PER_WAVE 29
-#endif
-#ifndef CRYO_ZCHAIN_QUAD
-#define CRYO_ZCHAIN_QUAD 1 /* round 4: a quad of lanes per block (k_zchain4); 0: a lane per block (k_zchain) */
-#endif
-constexpr uint32_t kChW = CRYO_ZCHAIN_PER_WAVE;
-static_assert(kChW <= 32, "two groups of 16 walkers");
-
-struct ChainLds {
-    uint16_t tab[kChW][kSeqTblWords];
-    uint8_t ring[32 * kChStride + 64 * 16]; /* + a 16-byte trash slot per lane */
-};
-
-struct ChainLane {
-    /* stream, in virtual byte positions (offset in the frame + delta, so that half-lines are 64-byte aligned in memory) */
-    int32_t s0;        /* first byte of the bitstream */
-    int32_t pos;       /* unread bits */
-    int32_t cb;        /* s0 + ((pos - 1) >> 3): the byte the top unread bit is in */
-    int32_t lowh, fillh; /* lowest half-line requested / in the ring */
-    uint32_t pend;     /* bit J: a request of this lane is in slot J */
-    uint32_t sl, so, sm;
-    uint32_t i, nseq;
-    uint32_t el, eo, em, sh;
-    uint64_t raw;
-    bool rd_ok;
-};
-
-template <int J, bool FEED>
-__device__ inline void chain_turn(uint8_t *ring, const uint16_t *tab, ChainLane &z, const uint32_t lane, const bool mygroup,
-                                  uint4 &fd, uint32_t &fa, uint32_t &fm, const uint8_t *gsrc, const uint32_t svend,
-                                  const uint32_t srv_lane, const uint32_t srv_ring, uint2 *out, uint2 *trash,
-                                  const int32_t cl, const int32_t co, const int32_t cm, const uint32_t myring, bool &bad)
-{
-    /* Order matters: a lone wave has nothing else to run while it waits, so everything that is not on the chain
-     * entries -> bit counts -> state bits -> next entries sits between the issue of the next entries' reads and their use. */
-    /* ---- the ring feed, first half: ask for the next half-line of the walkers of this turn's group ---- */
-    uint32_t wi = 0, m = 0;
-    if (FEED) { /* every other sequence: 64 bytes per eight sequences per walker, a sequence takes 3 on tuple data (11 at most: the lane waits) */
-        const bool want = mygroup & (z.i < z.nseq) & (z.cb < 64 * (z.lowh + 1)) & (64 * z.lowh > z.s0);
-        wi = want ? 1u : 0u;
-        z.lowh -= (int32_t)wi;
-        m = bperm32((uint32_t)z.lowh | (wi << 31), srv_lane);
-    }
-    /* ---- one sequence (entries and window were requested at the end of the previous turn) ---- */
-    uint2 rec;
-    bool go;
-    {
-        const bool on = z.i < z.nseq;
-        go = on & z.rd_ok;
-        const uint32_t el = z.el, eo = z.eo, em = z.em;
-        const uint32_t X = (el >> 11) + (eo >> 11) + (em >> 11); /* extra bits of the three codes */
-        const uint32_t vl = el & 1023u, vm = em & 1023u, vo = eo & 1023u;
-        const uint32_t nl = (uint32_t)(__builtin_clz(vl) + cl), nm = (uint32_t)(__builtin_clz(vm) + cm), no = (uint32_t)(__builtin_clz(vo) + co);
-        const uint32_t N = nl + nm + no;
-        const uint64_t win = z.raw << z.sh;
-        uint32_t W = (uint32_t)((win << X) >> 32);
-        const bool ovf = go & (X + N > 57u);
-        if (wave_any(ovf)) { /* more bits than one window holds: the state bits come from a second read */
-            if (ovf) {
-                const int32_t p2 = z.pos - (int32_t)X;
-                const int32_t cb2 = z.s0 + ((p2 - 1) >> 3);
-                uint64_t r2;
-                __builtin_memcpy(&r2, ring + myring + ((uint32_t)(cb2 - 7) & (kChRing - 1u)), 8);
-                W = (uint32_t)((r2 << (7u - ((uint32_t)(p2 - 1) & 7u))) >> 32);
-            }
-        }
-        const uint32_t bl = __builtin_amdgcn_ubfe(W, 32u - nl, nl), bm = __builtin_amdgcn_ubfe(W, 32u - nl - nm, nm),
-                       bo = __builtin_amdgcn_ubfe(W, 32u - N, no);
-        const uint32_t nsl = (vl << nl) - (1u << (cl + 31)) + bl;
-        const uint32_t nsm = (vm << nm) - (1u << (cm + 31)) + bm;
-        const uint32_t nso = (vo << no) - (1u << (co + 31)) + bo;
-        const int32_t npos = z.pos - (int32_t)(X + N);
-        rec = make_uint2((uint32_t)z.pos | (z.sl << 20), z.so | (z.sm << 8));
-        z.sl = go ? nsl : z.sl;
-        z.sm = go ? nsm : z.sm;
-        z.so = go ? nso : z.so;
-        z.pos = go ? npos : z.pos;
-        const bool neg = go & (npos < 0); /* read past the start of the stream */
-        bad = bad | neg;
-        z.nseq = neg ? 0u : z.nseq;
-    }
-    /* ---- the next sequence's entries and window go out now ---- */
-    z.cb = z.s0 + ((z.pos - 1) >> 3);
-    z.sh = 7u - ((uint32_t)(z.pos - 1) & 7u);
-    z.rd_ok = (z.cb - 16 >= 64 * z.fillh) | (64 * z.fillh <= z.s0); /* what the window reads is in the ring */
-    __builtin_memcpy(&z.raw, ring + myring + ((uint32_t)(z.cb - 7) & (kChRing - 1u)), 8);
-    z.el = tab[z.sl]; z.eo = tab[1024u + z.so]; z.em = tab[512u + z.sm];
-    /* ---- while they are on their way: the record, the piece slot J's load brought, the new request ---- */
-    *(go ? out + z.i : trash) = rec;
-    z.i += go ? 1u : 0u;
-    if (!FEED) return;
-    *reinterpret_cast<uint4 *>(ring + fa) = fd;
-    *reinterpret_cast<uint2 *>(ring + fm) = make_uint2(fd.x, fd.y);
-    {
-        const uint32_t got = (z.pend >> J) & 1u;
-        z.fillh -= (int32_t)got;
-        z.pend = (z.pend & ~(1u << J)) | (wi << J);
-    }
-    {
-        const bool p = (m >> 31) != 0u;
-        const uint32_t o = ((m & 0x7FFFFFFFu) << 6) + (lane & 3u) * 16u;
-        const uint32_t slot = srv_ring + (o & (kChRing - 1u));
-        const uint32_t tr = 32u * kChStride + lane * 16u;
-        fa = p ? slot : tr;
-        fm = (p & ((o & (kChRing - 1u)) == 0u)) ? srv_ring + kChRing : tr;
-        /* always one load per turn (a lane with nothing to fetch re-reads its stream's first piece): a fixed number of
-         * vector-memory operations per turn lets the compiler wait for exactly the piece it commits */
-        fd = *reinterpret_cast<const uint4 *>(gsrc + ((p & (o < svend)) ? o : 0u));
-    }
-}
-
-__global__ void __launch_bounds__(64) k_zchain(ZPipe P)
-{
-    __shared__ __attribute__((aligned(16))) ChainLds L;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t nitems = uni(P.counters[3]);
-    const uint32_t i0 = blockIdx.x * kChW;
-    if (i0 >= nitems) return;
-    for (uint32_t j = 0; j < kChW && i0 + j < nitems; j++) {
-        const uint32_t it = uni(P.sitems[i0 + j]);
-        const uint32_t fj = it / P.nbmax;
-        const ZBlk *d = P.blks + it;
-        const uint32_t slots = uni(d->slots), logs = uni(d->logs);
-#pragma unroll
-        for (int kind = 0; kind < 3; kind++) {
-            const uint32_t slot = (slots >> (8 * kind)) & 255u, lg = (logs >> (8 * kind)) & 255u;
-            const uint32_t goff = kind == 0 ? 0u : (kind == 1 ? 1024u : 512u);
-            const uint32_t *g = (slot == kPredefSlot ? P.predef : P.seqt + ((uint64_t)fj * P.nbmax + slot) * kSeqTblWords) + goff;
-            for (uint32_t q = lane; q < (1u << lg); q += 64u) { /* 25-bit workspace entry -> 16 bits: extra-bit count (5) | v (10) */
-                const uint32_t e = g[q], nb = (e >> 10) & 15u;
-                L.tab[j][goff + q] = (uint16_t)((((e >> 20) & 31u) << 11) | (1u << (lg - nb)) | ((e & 1023u) >> nb));
-            }
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-
-    bool act = lane < kChW && i0 + lane < nitems;
-    const uint32_t it = act ? P.sitems[i0 + lane] : P.sitems[i0];
-    const uint32_t f = it / P.nbmax;
-    const ZBlk *d = P.blks + it;
-    if (act && (P.frames[f].flags & (F_BAD | F_IRREG))) act = false;
-    const uint64_t fo = P.src_off[P.first + f];
-    const uint64_t aoff = fo & ~(uint64_t)63;
-    const uint32_t delta = (uint32_t)(fo & 63u);
-    const uint32_t vend = delta + P.src_size[P.first + f];
-    const uint32_t logs = d->logs;
-    const uint32_t sq_off = d->sq_off, sq_len = d->sq_len;
-    const uint8_t *gmine = P.src_base + aoff;
-    const uint32_t myring = (lane & 31u) * kChStride;
-    ChainLane z;
-    z.s0 = (int32_t)(delta + sq_off);
-    z.pos = 0; z.cb = z.s0; z.lowh = 0; z.fillh = 0; z.pend = 0; z.sl = z.so = z.sm = 0; z.i = 0; z.nseq = 0;
-    z.el = z.eo = z.em = 0; z.sh = 0; z.raw = 0;
-    bool bad = false;
-    bool opened = act && sq_len >= 1u;
-    uint32_t last = 0;
-    if (opened) last = gmine[delta + sq_off + sq_len - 1u];
-    if (last == 0u) opened = false;
-    if (act && !opened) bad = true;
-    const uint16_t *tab = L.tab[lane < kChW ? lane : 0u];
-    const int32_t cl = (int32_t)(logs & 255u) - 31, co = (int32_t)((logs >> 8) & 255u) - 31, cm = (int32_t)((logs >> 16) & 255u) - 31;
-    if (opened) {
-        /* the stream's top two half-lines, loaded by the lane itself */
-        const int32_t s1 = z.s0 + (int32_t)sq_len;
-        const int32_t ht = (s1 - 1) >> 6;
-        const int32_t hl = ht >= 1 ? ht - 1 : 0;
-        for (int32_t h = hl; h <= ht; h++)
-            for (uint32_t q = 0; q < 4u; q++) {
-                const uint32_t o = (uint32_t)h * 64u + q * 16u;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (o < vend) v = *reinterpret_cast<const uint4 *>(gmine + o);
-                *reinterpret_cast<uint4 *>(L.ring + myring + (o & (kChRing - 1u))) = v;
-                if ((o & (kChRing - 1u)) == 0u) *reinterpret_cast<uint2 *>(L.ring + myring + kChRing) = make_uint2(v.x, v.y);
-            }
-        z.lowh = z.fillh = hl;
-        z.nseq = d->nseq - 1u; /* the turns take every sequence that is followed by state bits; the block's last one after the loop */
-        z.pos = (int32_t)(sq_len - 1u) * 8 + (31 - __builtin_clz(last));
-        /* initial states: LL, OF, ML from the top of the stream (<= 26 bits) */
-        const int32_t cb = z.s0 + ((z.pos - 1) >> 3);
-        uint64_t r;
-        __builtin_memcpy(&r, L.ring + myring + ((uint32_t)(cb - 7) & (kChRing - 1u)), 8);
-        const uint32_t W = (uint32_t)((r << (7u - ((uint32_t)(z.pos - 1) & 7u))) >> 32);
-        const uint32_t lgl = logs & 255u, lgo = (logs >> 8) & 255u, lgm = (logs >> 16) & 255u;
-        z.sl = __builtin_amdgcn_ubfe(W, 32u - lgl, lgl);
-        z.so = __builtin_amdgcn_ubfe(W, 32u - lgl - lgo, lgo);
-        z.sm = __builtin_amdgcn_ubfe(W, 32u - lgl - lgo - lgm, lgm);
-        z.pos -= (int32_t)(lgl + lgo + lgm);
-        if (z.pos < 0) { bad = true; z.nseq = 0; z.pos = 0; opened = false; }
-    }
-    __builtin_amdgcn_wave_barrier();
-    z.cb = z.s0 + ((z.pos - 1) >> 3);
-    z.sh = 7u - ((uint32_t)(z.pos - 1) & 7u);
-    z.rd_ok = true; /* the top of the stream is in the ring */
-    __builtin_memcpy(&z.raw, L.ring + myring + ((uint32_t)(z.cb - 7) & (kChRing - 1u)), 8);
-    z.el = tab[z.sl]; z.eo = tab[1024u + z.so]; z.em = tab[512u + z.sm];
-
-    /* what this lane serves: group g = J & 1, walker 16 g + (lane >> 2), piece lane & 3 */
-    const uint32_t w0 = lane >> 2, w1 = 16u + (lane >> 2);
-    const uint64_t a0 = ((uint64_t)bperm32((uint32_t)(aoff >> 32), w0) << 32) | bperm32((uint32_t)aoff, w0);
-    const uint64_t a1 = ((uint64_t)bperm32((uint32_t)(aoff >> 32), w1) << 32) | bperm32((uint32_t)aoff, w1);
-    const uint32_t ve0 = bperm32(vend, w0), ve1 = bperm32(vend, w1);
-    const uint8_t *g0 = P.src_base + a0, *g1 = P.src_base + a1;
-    const uint32_t r0 = w0 * kChStride, r1 = w1 * kChStride;
-    const bool grp0 = lane < 16u, grp1 = (lane >> 4) == 1u;
-    uint2 *out = P.chain + (opened ? d->seq_base : 0u);
-    uint2 *trash = P.chain + P.seqcap + lane;
-    const uint32_t tr = 32u * kChStride + lane * 16u;
-    uint4 fd0 = make_uint4(0, 0, 0, 0), fd1 = fd0, fd2 = fd0, fd3 = fd0;
-    uint32_t fa0 = tr, fa1 = tr, fa2 = tr, fa3 = tr, fm0 = tr, fm1 = tr, fm2 = tr, fm3 = tr;
-    while (wave_any(z.i < z.nseq)) {
-        chain_turn<0, true>(L.ring, tab, z, lane, grp0, fd0, fa0, fm0, g0, ve0, w0, r0, out, trash, cl, co, cm, myring, bad);
-        chain_turn<0, false>(L.ring, tab, z, lane, grp0, fd0, fa0, fm0, g0, ve0, w0, r0, out, trash, cl, co, cm, myring, bad);
-        chain_turn<1, true>(L.ring, tab, z, lane, grp1, fd1, fa1, fm1, g1, ve1, w1, r1, out, trash, cl, co, cm, myring, bad);
-        chain_turn<1, false>(L.ring, tab, z, lane, grp1, fd1, fa1, fm1, g1, ve1, w1, r1, out, trash, cl, co, cm, myring, bad);
-        chain_turn<2, true>(L.ring, tab, z, lane, grp0, fd2, fa2, fm2, g0, ve0, w0, r0, out, trash, cl, co, cm, myring, bad);
-        chain_turn<2, false>(L.ring, tab, z, lane, grp0, fd2, fa2, fm2, g0, ve0, w0, r0, out, trash, cl, co, cm, myring, bad);
-        chain_turn<3, true>(L.ring, tab, z, lane, grp1, fd3, fa3, fm3, g1, ve1, w1, r1, out, trash, cl, co, cm, myring, bad);
-        chain_turn<3, false>(L.ring, tab, z, lane, grp1, fd3, fa3, fm3, g1, ve1, w1, r1, out, trash, cl, co, cm, myring, bad);
-    }
-    if (opened && !bad) { /* the last sequence: its extra bits, no state bits */
-        const uint32_t X = (z.el >> 11) + (z.eo >> 11) + (z.em >> 11);
-        out[z.i] = make_uint2((uint32_t)z.pos | (z.sl << 20), z.so | (z.sm << 8));
-        z.pos -= (int32_t)X;
-    }
-    if (opened && z.pos != 0) bad = true; /* the bitstream must be consumed exactly */
-    if (bad) atomicOr(&P.frames[f].flags, F_BAD);
-}
 
 /* k_zchain4 (round 4): the same chain with a QUAD of lanes per block -- lane 0 the literal-length state, lane 1 the match-
  * length state, lane 2 the offset state, lane 3 none (it helps with the ring and holds its tongue).  With a lane per block a
@@ -2114,11 +1888,11 @@ Layout make_layout(uint64_t n_blocks, uint32_t B, size_t limit = ~(size_t)0)
      * 1 MiB frames in tiles of 2320 made 1.25 rounds, the second three quarters empty) */
     /* (k_zchain4: 768 waves x 16 blocks, three waves per CU) */
     const uint64_t zbpf = (B + kZBlockMax - 1u) / kZBlockMax ? (B + kZBlockMax - 1u) / kZBlockMax : 1u;
-    const uint64_t kTile = ((CRYO_ZCHAIN_QUAD ? 768u * kCqW : 512u * kChW)) / zbpf;
+    const uint64_t kTile = (768u * kCqW) / zbpf;
 #ifndef CRYO_ZSTD_EQUAL_TILES
 #define CRYO_ZSTD_EQUAL_TILES 1
 #endif
-    if (CRYO_ZSTD_EQUAL_TILES && CRYO_ZCHAIN_QUAD && n_blocks * zbpf > kForkMaxZBlocks) {
+    if (CRYO_ZSTD_EQUAL_TILES && n_blocks * zbpf > kForkMaxZBlocks) {
         /* Round 5: a call of more than one tile is cut into tiles of EQUAL size, four (the streams they run on) per round.  With
          * tiles of 12 288 zstd blocks 65 536 frames were 5.33 tiles: four in flight, then 1.33 with the chip half idle.  One
          * round of four larger tiles (up to 16 896 zstd blocks each, 17.6 GiB of workspace) instead: 65 536 x 128 KiB 330 ->
@@ -2138,7 +1912,6 @@ Layout make_layout(uint64_t n_blocks, uint32_t B, size_t limit = ~(size_t)0)
     } else if (F > kTile) F = kTile;
     static const uint64_t tile_env = cryo_tuning_env("CRYO_ZSTD_TILE") ? (uint64_t)atoll(cryo_tuning_env("CRYO_ZSTD_TILE")) : 0; /* tuning aid (debug builds) */
     if (tile_env) F = tile_env;
-    if (!CRYO_ZCHAIN_QUAD && F >= 464u && F != kTile) F -= F % 464u;
     if (F < 16u) F = 16u;
     if (F > n_blocks) F = n_blocks;
     auto build = [&](const uint64_t Fq) -> Layout {
@@ -2336,12 +2109,8 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
 #endif
         /* ---- sequence stage (its own stream when forked; issued first so that it is not queued behind the Huffman kernels) ---- */
         auto seq_stage = [&](hipStream_t q) {
-#if CRYO_ZCHAIN_QUAD
             const uint32_t zc_all = (P.F * P.nbmax + kCqW - 1u) / kCqW;
             hipLaunchKernelGGL(k_zchain4, dim3((CRYO_GS & 4) && zc_all > 768u ? 768u : zc_all), dim3(64), seq_pad, q, P);
-#else
-            hipLaunchKernelGGL(k_zchain, dim3((P.F * P.nbmax + kChW - 1u) / kChW), dim3(64), seq_pad, q, P);
-#endif
             hipLaunchKernelGGL(k_zmat, dim3(P.F), dim3(64), 0, q, P);
         };
         if (fork_stages) {
