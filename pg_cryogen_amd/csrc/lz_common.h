@@ -82,8 +82,56 @@ struct Wave {
     bool dst_aligned;
     uint32_t lane;
 
-    __device__ inline uint2 fetch(uint32_t at) const
+    /* A SEGMENTED stream (zstd decode, round 6): the stream's bytes lie in up to 64 pieces of a scratch area, in order --
+     * what the Huffman walkers of k_zhufw leave: piece j = s_src bytes into sbase, the stream's positions [s_end - length,
+     * s_end); lane j holds piece j.  Reading them in place takes the copy into a contiguous pool (k_zmove: 3 GB read and
+     * 5.4 GB written per call of 65 536 frames) out of the pipeline.  Every piece that is not empty has at least 8 bytes
+     * (the producer sees to it), and up to 15 bytes behind a piece's last may be read. */
+    bool seg_on = false;
+    const uint8_t *sbase = nullptr;
+    uint32_t s_src = 0, s_end = 0, s_dst = 0, s_nxt = 0; /* per lane: piece j; s_nxt: s_src of the next piece that is not empty */
+    uint32_t cs = 0;                                     /* first piece that ends behind the last fetch's position */
+
+    __device__ inline uint2 fetch_seg(uint32_t at)
     {
+        const uint32_t o = at + lane * 8u;
+        uint2 v = make_uint2(0, 0);
+        if (at >= vend) return v;
+        while (cs < 63u && (uint32_t)__builtin_amdgcn_readlane((int)s_end, (int)cs) <= at) cs++;
+        const uint32_t e0 = (uint32_t)__builtin_amdgcn_readlane((int)s_end, (int)cs);
+        uint32_t so, eseg, nx;
+        if (e0 >= at + kInChunk || cs >= 63u) { /* the whole chunk lies in one piece */
+            so = (uint32_t)__builtin_amdgcn_readlane((int)s_src, (int)cs) + (o - (uint32_t)__builtin_amdgcn_readlane((int)s_dst, (int)cs));
+            eseg = e0;
+            nx = (uint32_t)__builtin_amdgcn_readlane((int)s_nxt, (int)cs);
+        } else {
+            uint32_t seg = cs;
+            for (uint32_t k = cs; k < 63u; k++) {
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)s_end, (int)k);
+                if (e >= at + kInChunk) break;
+                seg += o >= e ? 1u : 0u;
+            }
+            const int a = (int)(seg << 2);
+            so = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)s_src) + (o - (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)s_dst));
+            eseg = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)s_end);
+            nx = (uint32_t)__builtin_amdgcn_ds_bpermute(a, (int)s_nxt);
+        }
+        if (o < vend) {
+            __builtin_memcpy(&v, sbase + so, 8);
+            if (o + 8u > eseg && eseg < vend) { /* the piece ends inside these 8 bytes: the rest is the head of the next one */
+                uint2 t;
+                __builtin_memcpy(&t, sbase + nx, 8);
+                const uint32_t r = 8u * (eseg - o); /* bits that are this piece's */
+                const uint64_t a64 = ((uint64_t)v.y << 32) | v.x, b64 = ((uint64_t)t.y << 32) | t.x;
+                const uint64_t m = (a64 & ((1ull << r) - 1ull)) | (b64 << r);
+                v = make_uint2((uint32_t)m, (uint32_t)(m >> 32));
+            }
+        }
+        return v;
+    }
+    __device__ inline uint2 fetch(uint32_t at)
+    {
+        if (seg_on) return fetch_seg(at);
         const uint32_t o = at + lane * 8u;
         uint2 v = make_uint2(0, 0);
         if (o < vend) v = *reinterpret_cast<const uint2 *>(abase + o);
@@ -196,7 +244,7 @@ __device__ inline uint32_t lane_mod(uint32_t lane, uint32_t m)
 template <uint32_t R>
 __device__ inline bool wave_stream_literals(Wave<R> &w, uint32_t &p, uint32_t &rem)
 {
-    if (rem < 2u * R || w.flushed != w.op || !w.dst_aligned) return false;
+    if (rem < 2u * R || w.flushed != w.op || !w.dst_aligned || w.seg_on /* pieces: through the ring */) return false;
     const uint32_t nch = rem / kChunk;
     for (uint32_t c = 0; c < nch; c++) {
         uint4 v;

@@ -542,6 +542,7 @@ __device__ uint64_t xxh64_dev(const uint8_t *p, uint32_t len)
 template <uint32_t R>
 __device__ inline uint32_t stream_open(Wave<R> &w, const uint8_t *ptr, uint32_t size)
 {
+    w.seg_on = false;
     w.delta = (uint32_t)(reinterpret_cast<uintptr_t>(ptr) & 15u);
     w.abase = ptr - w.delta;
     w.vend = w.delta + size;
@@ -549,6 +550,30 @@ __device__ inline uint32_t stream_open(Wave<R> &w, const uint8_t *ptr, uint32_t 
     w.prefetch();
     if (size) { w.refill(); if (w.in_hi < w.vend) w.refill(); }
     return w.delta; /* virtual position of the first byte */
+}
+
+/* ... at a stream that lies in pieces (Wave::fetch_seg): lane j's piece = (offset into base, bytes, stream position) */
+template <uint32_t R>
+__device__ inline uint32_t stream_open_seg(Wave<R> &w, const uint8_t *base, uint4 piece, uint32_t size)
+{
+    w.seg_on = true;
+    w.sbase = base;
+    w.s_src = piece.x; w.s_dst = piece.z; w.s_end = piece.z + piece.y;
+    {
+        /* the next piece that is not empty (for the 8 bytes that straddle a piece's end) */
+        const unsigned long long ne = __builtin_amdgcn_ballot_w64(piece.y != 0u);
+        const unsigned long long later = w.lane >= 63u ? 0ull : (ne & (~0ull << (w.lane + 1u)));
+        const uint32_t nl = later ? (uint32_t)__builtin_ctzll(later) : w.lane;
+        w.s_nxt = (uint32_t)__shfl((int)piece.x, (int)nl, 64);
+    }
+    w.cs = 0;
+    w.delta = 0;
+    w.abase = base;
+    w.vend = size;
+    w.in_hi = 0;
+    w.prefetch();
+    if (size) { w.refill(); if (w.in_hi < w.vend) w.refill(); }
+    return 0;
 }
 
 template <uint32_t R>

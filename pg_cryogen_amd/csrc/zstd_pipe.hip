@@ -61,7 +61,8 @@ struct ZBlk { /* one zstd block of a frame; 128 bytes */
     uint32_t slots;          /* table slots: ll | of << 8 | ml << 16 */
     uint32_t logs;           /* table logs, same packing */
     uint32_t seq_base;       /* first record in the sequence pool */
-    uint32_t pad[9];
+    uint32_t segd;           /* Huffman literals: 1 = they lie in the walkers' pieces of scratch (ZPipe::hsegs), k_zexec reads them in place */
+    uint32_t pad[8];
 };
 static_assert(sizeof(ZBlk) == 128, "descriptor size");
 
@@ -92,7 +93,8 @@ struct ZPipe {
     uint32_t *hitems2; /* blocks k_zhufw hands back to k_zhuf (counters[61]) */
     uint8_t *htmp;     /* k_zhufw's scratch: the walkers' symbols before they are moved to the literal pool */
     uint64_t htmp_stride;
-    uint4 *hsegs;      /* per block 64 entries, one per walker: scratch offset of its true symbols, their count, pool offset (k_zmove) */
+    uint4 *hsegs;      /* per block 64 entries, one per walker: scratch offset of its true symbols, their count, pool offset (k_zmove / k_zexec) */
+    uint32_t in_place; /* 1: k_zexec reads the walkers' pieces where they lie (no k_zmove) unless a block has a piece shorter than 8 bytes */
     uint32_t *mitems;  /* blocks whose symbols k_zmove moves (counters[60]) */
     uint32_t *irregular;
     uint32_t *sitems; /* blocks with sequences (f * nbmax + k) */
@@ -1041,7 +1043,12 @@ __device__ __attribute__((always_inline)) inline void zhufw_item(const ZPipe &P,
         const uint32_t srcp = (uint32_t)(tmp - tbase) + myskip;
         const uint32_t dstp = oofs + (incl - ntrue);
         P.hsegs[(uint64_t)it * 64u + lane] = make_uint4(srcp, ntrue, dstp, 0u);
-        if (lane == 0u) P.mitems[atomicAdd(&P.counters[60], 1u)] = it;
+        /* read in place by k_zexec (Wave::fetch_seg) when every piece that is not empty has 8 bytes; moved to the pool otherwise */
+        const bool in_place = P.in_place != 0u && wave_all(ntrue == 0u || ntrue >= 8u);
+        if (lane == 0u) {
+            if (in_place) P.blks[it].segd = 1u;
+            else P.mitems[atomicAdd(&P.counters[60], 1u)] = it;
+        }
     }
     HW_STAMP(62);
 }
@@ -1562,7 +1569,13 @@ __device__ bool exec_block(ExecLds &L, Wave<kZR> &w, const ZPipe &P, const ZBlk 
     const uint32_t rle_byte = lit_src;
     uint32_t lit_pos = 0, lvp = 0;
     if (lit_mode == 0) lvp = stream_open(w, src + lit_src, regen);
-    else if (lit_mode == 2) lvp = stream_open(w, P.lits + (uint64_t)f * P.litcap + lit_src, regen);
+    else if (lit_mode == 2) {
+        if (uni(d->segd)) { /* the walkers' pieces, where k_zhufw left them */
+            const uint32_t it = (uint32_t)(d - P.blks), kblk = it - f * P.nbmax;
+            const uint8_t *tbase = P.htmp + (uint64_t)f * P.htmp_stride + ((2u * (uint64_t)lit_src + 127u) & ~(uint64_t)127) + (uint64_t)kblk * kHwBlockSlack;
+            lvp = stream_open_seg(w, tbase, P.hsegs[(uint64_t)it * 64u + lane], regen);
+        } else lvp = stream_open(w, P.lits + (uint64_t)f * P.litcap + lit_src, regen);
+    }
     const bool streamed = lit_mode != 1;
 
     const uint2 *seqs = P.seqs + uni(d->seq_base);
@@ -2083,6 +2096,11 @@ hipError_t launch_zstd_decompress(hipStream_t s, const uint8_t *d_src, const uin
         P.irregular = (uint32_t *)(ws + y.o_irreg);
         P.sitems = (uint32_t *)(ws + y.o_sitems);
         P.hsegs = (uint4 *)(ws + y.o_hsegs);
+        {
+            /* the few-frames execution below reads Huffman literals from the pool: the move stays for such calls */
+            static const bool move_env = cryo_tuning_env("CRYO_ZSTD_MOVE") != nullptr; /* A/B aid: k_zmove for every block */
+            P.in_place = (move_env || (y.lat_nmax != 0u && !skip_lat)) ? 0u : 1u;
+        }
         P.mitems = (uint32_t *)(ws + y.o_mitems);
         P.done = nullptr;
         P.hufw_min = hufw_min;
