@@ -670,11 +670,10 @@ __global__ void __launch_bounds__(64) k_zhuf(ZPipe P, const uint32_t *__restrict
 }
 
 /* per-lane input rings fed cooperatively by the wave (k_zhufw, k_zchain) */
-#ifndef CRYO_ZEXEC_OCC
-#define CRYO_ZEXEC_OCC 6 /* waves per SIMD the register allocator aims at: k_zexec takes 94 registers = 5 waves without a hint; with 80
-                          * (32 bytes of scratch) 1.91 -> 1.82 ms per tile, the call 1 % (profiles/r04_zstd_decode_ab.txt); k_zmove at 8
-                          * waves (64 registers, 92 bytes of scratch) and k_zmat at 7 / 8 (72 / 64 registers) lose */
-#endif
+/* waves per SIMD the register allocator aims at for k_zexec: 5 (96 registers).  Round 4 ran it at 6 (80 registers, 32 bytes of
+ * scratch: 1 % on the call); with the segmented literal stream of round 6 (Wave::fetch_seg keeps a piece per lane) 6 waves mean
+ * 108 bytes of scratch and 5 are faster on every shape (profiles/r06_zstd_decode.txt) */
+constexpr int kZexecOcc = 5;
 constexpr uint32_t kChRing = 128, kChStride = 144; /* ring + 8-byte mirror + pad */
 __device__ inline uint32_t bperm32(uint32_t v, uint32_t src_lane)
 {
@@ -1662,7 +1661,7 @@ __device__ bool exec_block(ExecLds &L, Wave<kZR> &w, const ZPipe &P, const ZBlk 
 
 } // namespace
 
-__global__ void __launch_bounds__(64, CRYO_ZEXEC_OCC) k_zexec(ZPipe P)
+__global__ void __launch_bounds__(64, kZexecOcc) k_zexec(ZPipe P)
 {
     __shared__ __attribute__((aligned(16))) ExecLds L;
     const uint32_t lane = threadIdx.x & 63u;
