@@ -175,8 +175,10 @@ cryo_cache_allocate(Relation rel, BlockNumber blockno)
 }
 
 /*
- * Beyond the drop-in: how the table AM would call the BATCH staging (sketch of two further call-site changes a
- * maintainer may make; nothing else of pg_cryogen.c changes):
+ * Beyond the drop-in.  Reads need nothing: cryo_read_data() above reaches cryo_read_data_rel(), whose miss path reads
+ * ahead in a copy of the scan's iterator (pg_cryogen.gpu_readahead_blocks), so the unchanged cryo_getnextslot
+ * (reference pg_cryogen.c:262-277) decodes K blocks per codec call.  Writes: one call-site change a maintainer may make
+ * (nothing else of pg_cryogen.c changes):
  *
  *   write-behind, replacing the per-block cryo_preserve() of cryo_multi_insert (reference pg_cryogen.c:603-663):
  *       keep K full cryo blocks (state->data) in a backend-local array instead of compressing each when it
@@ -184,9 +186,5 @@ cryo_cache_allocate(Relation rel, BlockNumber blockno)
  *           CryoPgRel s; CryoRel r; cryo_pg_bind(rel, &s, &r);
  *           cryo_stage_write_batch(&r, blocks, K, compression_method_guc, GetCurrentTransactionId(), first_blocks);
  *       then the metapage update of reference pg_cryogen.c:807-821 once for the batch.
- *
- *   read-ahead, replacing cryo_read_data() in cryo_getnextslot (reference pg_cryogen.c:262-277):
- *           n = cryo_scan_next_batch(&r, scan->iterator, K, starts, entries, errors);
- *       and serve tuples from entries[0..n) before asking again.
  */
 #endif /* CRYO_HAVE_POSTGRES */

@@ -24,7 +24,7 @@ constexpr uint32_t kInChunk = 512;  /* bytes per input refill: 64 lanes x 8 B (l
 __device__ inline uint32_t uni(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 /* votes: HIP's __ballot / __any turn the predicate into 0/1 in a register and compare that again (v_cndmask + v_cmp per vote);
  * the builtin takes the compare's lane mask as it stands.  The decoders are bound by vector instruction issue at full
- * occupancy (k_lz4_dec_seq: 88 % of the SIMDs' cycles), and a batch holds some twenty votes. */
+ * occupancy (k_lz4_dec_seq: 88 % of the SIMDs' cycles, NOTEBOOK.md 4.1), and a batch holds some twenty votes. */
 __device__ inline unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ inline bool wave_any(bool p) { return __builtin_amdgcn_ballot_w64(p) != 0ull; }
 __device__ inline bool wave_all(bool p) { return __builtin_amdgcn_ballot_w64(!p) == 0ull; }

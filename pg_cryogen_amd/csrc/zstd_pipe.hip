@@ -1153,7 +1153,7 @@ __device__ inline uint32_t ml_xbits(uint32_t sym)
  * up: one LDS round trip and ~100 instructions per sequence.  The rings (128 bytes per lane, contiguous, first 8 bytes
  * mirrored behind the end) are fed cooperatively like the LZ4 index pass's: in turn J the wave's 64 lanes load one
  * 16-byte piece each for 16 walkers (4 lanes x 16 B = half a cache line per walker) that have room, and store it
- * four turns later; every per-lane condition is evaluated eagerly. */
+ * four turns later; every per-lane condition is evaluated eagerly (NOTEBOOK.md 4.1). */
 
 /* k_zchain4 (round 4): the same chain with a QUAD of lanes per block -- lane 0 the literal-length state, lane 1 the match-
  * length state, lane 2 the offset state, lane 3 none (it helps with the ring and holds its tongue).  With a lane per block a
