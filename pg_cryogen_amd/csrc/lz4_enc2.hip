@@ -190,6 +190,83 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
     unsigned long long pt[8] = {0}, t0 = __builtin_amdgcn_s_memtime(), nseq_p = 0, nbatch_p = 0;
 #endif
 
+    /* ---- the sequences found wait in a queue, one per lane (literal run's start, the probe that hit, its candidate, the
+     * match's end), and are written out 64 at a time.  Nothing the search does next depends on a sequence's bytes in the
+     * output, nor on how far its match reaches BACK (the next anchor is the match's end): so the backward extension and the
+     * emission leave the block's dependent chain -- they were 1 100 of its 3 850 cycles per sequence on `wide`, wave-uniform
+     * work on one sequence -- and are done lane per sequence: 8 bytes before probe and candidate compared at a time; sizes;
+     * a scan gives every sequence its place in the output; token, lengths and offset as byte stores, the literals 16 / 8 / 4 /
+     * 2 / 1 bytes at a time exact to the byte (memory to memory: the ring has moved on).  A sequence with a long literal run
+     * or a very long match is written by the whole wave. ---- */
+    uint32_t q_anchor = 0, q_ip = 0, q_match = 0, q_end = 0, qn = 0;
+    auto emit_queue = [&]() __attribute__((always_inline)) {
+        const bool on = lane < qn;
+        uint32_t back = 0;
+        if (on) {
+            uint32_t room = q_ip - q_anchor < q_match ? q_ip - q_anchor : q_match;
+            while (room) {
+                if (q_match - back >= 8u) {
+                    uint64_t x, y;
+                    __builtin_memcpy(&x, src + q_ip - back - 8u, 8);
+                    __builtin_memcpy(&y, src + q_match - back - 8u, 8);
+                    const uint64_t d = x ^ y;
+                    uint32_t c = d ? (uint32_t)__builtin_clzll(d) >> 3 : 8u;
+                    c = c < room ? c : room;
+                    back += c; room -= c;
+                    if (d) break;
+                } else {
+                    if (src[q_ip - back - 1u] != src[q_match - back - 1u]) break;
+                    back++; room--;
+                }
+            }
+        }
+        const uint32_t mstart = q_ip - back;
+        const uint32_t lit = on ? mstart - q_anchor : 0u, ml = on ? q_end - (mstart + 4u) : 0u, off = q_ip - q_match;
+        const uint32_t nl = lit >= 15u ? (lit - 15u) / 255u + 1u : 0u, nm = ml >= 15u ? (ml - 15u) / 255u + 1u : 0u;
+        const uint32_t size = on ? 1u + nl + lit + 2u + nm : 0u;
+        const uint32_t incl = scan64_incl(size);
+        const uint32_t o0 = e.op + incl - size;
+        const bool big = on && (lit > 64u || nm > 4u);
+        if (on && !big) {
+            uint8_t *d = e.dst + o0;
+            *d++ = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (ml < 15u ? ml : 15u));
+            if (nl) { /* lit <= 64: one byte */
+                *d++ = (uint8_t)(lit - 15u);
+            }
+            const uint8_t *sp = src + q_anchor;
+            uint32_t r = lit;
+            while (r >= 16u) { uint4 v; __builtin_memcpy(&v, sp, 16); __builtin_memcpy(d, &v, 16); sp += 16; d += 16; r -= 16u; }
+            if (r & 8u) { uint2 v; __builtin_memcpy(&v, sp, 8); __builtin_memcpy(d, &v, 8); sp += 8; d += 8; }
+            if (r & 4u) { uint32_t v; __builtin_memcpy(&v, sp, 4); __builtin_memcpy(d, &v, 4); sp += 4; d += 4; }
+            if (r & 2u) { uint16_t v; __builtin_memcpy(&v, sp, 2); __builtin_memcpy(d, &v, 2); sp += 2; d += 2; }
+            if (r & 1u) *d++ = *sp;
+            d[0] = (uint8_t)off;
+            d[1] = (uint8_t)(off >> 8);
+            d += 2;
+            if (nm) {
+                uint32_t x = ml - 15u;
+                for (uint32_t k = 1; k < nm; k++) { *d++ = 255; x -= 255u; }
+                *d = (uint8_t)x;
+            }
+        }
+        unsigned long long bm = __ballot(big);
+        const uint32_t total = lane_get(incl, 63u);
+        while (bm) {
+            const uint32_t j = ctz64(bm);
+            bm &= bm - 1ull;
+            const uint32_t lj = lane_get(lit, j), mj = lane_get(ml, j), oj = lane_get(off, j), aj = lane_get(q_anchor, j);
+            e.op = lane_get(o0, j);
+            if (lane == 0) e.dst[e.op] = (uint8_t)(((lj < 15u ? lj : 15u) << 4) | (mj < 15u ? mj : 15u));
+            e.op++;
+            if (lj >= 15u) e.put_len(lj - 15u);
+            e.put_literals(aj, lj);
+            if (lane == 0) { e.dst[e.op] = (uint8_t)oj; e.dst[e.op + 1] = (uint8_t)(oj >> 8); }
+            e.op += 2u;
+            if (mj >= 15u) e.put_len(mj - 15u);
+        }
+        e.op = lane_get(o0, 0u) + total;
+    };
+
     if (n >= kMinLength) {
         const uint32_t mflimit_p1 = n - kMfLimit + 1u;
         const uint32_t matchlimit = n - kLastLiterals;
@@ -281,7 +358,7 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 const unsigned long long from1 = L1 >= 64u ? 0ull : (~0ull << L1);
                 unsigned long long hm = nearm & from1;
                 bool have_win = false;
-                uint32_t wb = 0, wf = 0;
+                uint32_t wf = 0;
                 {
                     const uint32_t first = hm ? ctz64(hm) : 64u;
                     const unsigned long long far = farm & from1 & (first >= 64u ? ~0ull : ((1ull << first) - 1ull));
@@ -289,16 +366,14 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                         /* one trip: every such lane's four bytes, and for the first of them -- the match, unless its tag
                          * lied -- the bytes its extension both ways starts with */
                         const uint32_t P = ctz64(far);
-                        const uint32_t mP = lane_get(cand, P), ipP = lane_get(cur, P);
-                        const uint32_t room = ipP - anchor < mP ? ipP - anchor : mP;
-                        uint32_t v = 0, xb = 0, xf = 0;
+                        const uint32_t mP = lane_get(cand, P);
+                        uint32_t v = 0, xf = 0;
                         if ((far >> lane) & 1ull) __builtin_memcpy(&v, src + cand, 4);
-                        if (lane < room) xb = src[mP - 1u - lane];
                         xf = src[mP + 4u + lane]; /* below ipP + 4 + lane: far candidates lie a ring's length back */
                         const bool hf = ((far >> lane) & 1ull) && v == own4;
                         const unsigned long long hfm = __ballot(hf);
                         hm |= hfm;
-                        if (((hfm >> P) & 1ull) && !(dbg & 2u)) { have_win = true; wb = xb; wf = xf; }
+                        if (((hfm >> P) & 1ull) && !(dbg & 2u)) { have_win = true; wf = xf; }
                     }
                 }
                 const uint32_t K = hm ? ctz64(hm) + 1u : T;
@@ -327,36 +402,12 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 ip = lane_get(cur, K - 1u);
                 uint32_t match = lane_get(cand, K - 1u);
 
-                /* ================= extend backwards ================= */
-                const bool ring_ok = anchor >= e.lo_pos();     /* the literal run lies in the ring */
-                const bool near_m = match >= e.lo_pos() + 64u; /* ... and so do the candidate and the 64 bytes before it */
                 const uint32_t ip_hit = ip;
-                {
-                    uint32_t room = ip - anchor < match ? ip - anchor : match;
-                    bool first = true;
-                    while (room) {
-                        const bool in = lane < room;
-                        uint32_t x, y;
-                        if (ring_ok) x = e.byte_ring(ip - 1u - lane); else x = in ? e.byte_any(ip - 1u - lane) : 0u;
-                        if (have_win && first) y = wb;
-                        else if (near_m && first) y = e.byte_ring(match - 1u - lane);
-                        else y = in ? e.byte_any(match - 1u - lane) : 1u;
-                        const bool eq = in && x == y;
-                        const unsigned long long neq = __ballot(!eq);
-                        const uint32_t c = neq ? ctz64(neq) : 64u;
-                        ip -= c; match -= c;
-                        if (c < 64u) break;
-                        room -= 64u;
-                        first = false;
-                    }
-                }
-
-                const uint32_t lit = ip - anchor;
                 LZT(3);
                 /* ================= extend forwards: 64 bytes per step, then 2 KiB per step =================
                  * from the four bytes the search compared (what the backward extension added in front of them is equal
                  * already): lane l of the far trip's window is the byte l behind the candidate's first four */
-                uint32_t a = ip_hit + 4u, b = match + (ip_hit - ip) + 4u;
+                uint32_t a = ip_hit + 4u, b = match + 4u;
                 {
                     bool first = true;
                     for (;;) {
@@ -378,19 +429,11 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                         }
                     }
                 }
-                const uint32_t ml = a - (ip + 4u);
                 LZT(4);
-                /* ================= emit: token, literal length, literals, offset, match length ================= */
-                if (lane == 0) e.dst[e.op] = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (ml < 15u ? ml : 15u));
-                e.op++;
-                if (lit >= 15u) e.put_len(lit - 15u);
-                e.put_literals(anchor, lit);
-                if (lane == 0) {
-                    e.dst[e.op] = (uint8_t)(ip - match);
-                    e.dst[e.op + 1] = (uint8_t)((ip - match) >> 8);
-                }
-                e.op += 2u;
-                if (ml >= 15u) e.put_len(ml - 15u);
+                /* ================= the sequence joins the queue: written out 64 at a time (emit_queue) ================= */
+                if (lane == qn) { q_anchor = anchor; q_ip = ip_hit; q_match = match; q_end = a; }
+                qn++;
+                if (qn == 64u) { emit_queue(); qn = 0; }
                 ip = a;
                 anchor = ip;
 #ifdef CRYO_LZ4E_PROF
@@ -419,6 +462,7 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
             if (next_batch_plain) pre = false;
         }
     }
+    if (qn) { emit_queue(); qn = 0; }
     /* ================= last literals ================= */
     {
         const uint32_t lit = n - anchor;
