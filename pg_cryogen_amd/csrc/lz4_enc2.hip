@@ -201,10 +201,45 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
     uint32_t q_anchor = 0, q_ip = 0, q_match = 0, q_end = 0, qn = 0;
     auto emit_queue = [&]() __attribute__((always_inline)) {
         const bool on = lane < qn;
+        /* ONE trip to memory: the 8 bytes before the probe and before its candidate, and the literal run's first 64 bytes
+         * (its start does not depend on the backward extension, only its length does) */
+        const uint32_t lmax = on ? q_ip - q_anchor : 0u;
+        uint64_t bx = 0, by = 1;
+        const bool b8 = on && lmax != 0u && q_match >= 8u;
+        if (b8) { __builtin_memcpy(&bx, src + q_ip - 8u, 8); __builtin_memcpy(&by, src + q_match - 8u, 8); }
+        uint4 lv0 = make_uint4(0, 0, 0, 0), lv1 = lv0, lv2 = lv0, lv3 = lv0;
+        {
+            const uint8_t *sp = src + q_anchor;
+            const bool whole = on && q_anchor + 64u <= n; /* (16-byte loads may reach behind the run, never behind the block) */
+            if (whole && lmax > 0u) __builtin_memcpy(&lv0, sp, 16);
+            if (whole && lmax > 16u) __builtin_memcpy(&lv1, sp + 16, 16);
+            if (whole && lmax > 32u) __builtin_memcpy(&lv2, sp + 32, 16);
+            if (whole && lmax > 48u) __builtin_memcpy(&lv3, sp + 48, 16);
+            if (on && !whole) { /* the block's last bytes: byte by byte (once per block at most) */
+                uint32_t w[16];
+#pragma unroll
+                for (uint32_t k = 0; k < 16u; k++) w[k] = 0;
+                const uint32_t m = lmax < 64u ? lmax : 64u;
+#pragma unroll 1
+                for (uint32_t k = 0; k < m; k++) {
+                    const uint32_t b = (uint32_t)sp[k] << (8u * (k & 3u));
+#pragma unroll
+                    for (uint32_t j = 0; j < 16u; j++) w[j] |= (k >> 2) == j ? b : 0u;
+                }
+                lv0 = make_uint4(w[0], w[1], w[2], w[3]); lv1 = make_uint4(w[4], w[5], w[6], w[7]);
+                lv2 = make_uint4(w[8], w[9], w[10], w[11]); lv3 = make_uint4(w[12], w[13], w[14], w[15]);
+            }
+        }
         uint32_t back = 0;
-        if (on) {
-            uint32_t room = q_ip - q_anchor < q_match ? q_ip - q_anchor : q_match;
-            while (room) {
+        if (on && lmax != 0u) {
+            uint32_t room = lmax < q_match ? lmax : q_match;
+            if (b8) {
+                const uint64_t d = bx ^ by;
+                uint32_t c = d ? (uint32_t)__builtin_clzll(d) >> 3 : 8u;
+                c = c < room ? c : room;
+                back = c; room = d ? 0u : room - c;
+            }
+            while (room) { /* rare: more than 8 bytes, or a candidate in the block's first 8 bytes */
                 if (q_match - back >= 8u) {
                     uint64_t x, y;
                     __builtin_memcpy(&x, src + q_ip - back - 8u, 8);
@@ -230,16 +265,17 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
         if (on && !big) {
             uint8_t *d = e.dst + o0;
             *d++ = (uint8_t)(((lit < 15u ? lit : 15u) << 4) | (ml < 15u ? ml : 15u));
-            if (nl) { /* lit <= 64: one byte */
-                *d++ = (uint8_t)(lit - 15u);
-            }
-            const uint8_t *sp = src + q_anchor;
+            if (nl) *d++ = (uint8_t)(lit - 15u); /* lit <= 64: one byte */
+            /* the run's bytes from the registers, exact to the byte */
             uint32_t r = lit;
-            while (r >= 16u) { uint4 v; __builtin_memcpy(&v, sp, 16); __builtin_memcpy(d, &v, 16); sp += 16; d += 16; r -= 16u; }
-            if (r & 8u) { uint2 v; __builtin_memcpy(&v, sp, 8); __builtin_memcpy(d, &v, 8); sp += 8; d += 8; }
-            if (r & 4u) { uint32_t v; __builtin_memcpy(&v, sp, 4); __builtin_memcpy(d, &v, 4); sp += 4; d += 4; }
-            if (r & 2u) { uint16_t v; __builtin_memcpy(&v, sp, 2); __builtin_memcpy(d, &v, 2); sp += 2; d += 2; }
-            if (r & 1u) *d++ = *sp;
+            if (r >= 16u) { __builtin_memcpy(d, &lv0, 16); d += 16; r -= 16u; lv0 = lv1; lv1 = lv2; lv2 = lv3; }
+            if (r >= 16u) { __builtin_memcpy(d, &lv0, 16); d += 16; r -= 16u; lv0 = lv1; lv1 = lv2; }
+            if (r >= 16u) { __builtin_memcpy(d, &lv0, 16); d += 16; r -= 16u; lv0 = lv1; }
+            if (r >= 16u) { __builtin_memcpy(d, &lv0, 16); d += 16; r -= 16u; }
+            if (r & 8u) { __builtin_memcpy(d, &lv0.x, 8); d += 8; lv0.x = lv0.z; lv0.y = lv0.w; }
+            if (r & 4u) { __builtin_memcpy(d, &lv0.x, 4); d += 4; lv0.x = lv0.y; }
+            if (r & 2u) { const uint16_t h2 = (uint16_t)lv0.x; __builtin_memcpy(d, &h2, 2); d += 2; lv0.x >>= 16; }
+            if (r & 1u) *d++ = (uint8_t)lv0.x;
             d[0] = (uint8_t)off;
             d[1] = (uint8_t)(off >> 8);
             d += 2;
@@ -320,6 +356,14 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 }
             }
             cand |= (ohi & E::PM) << 16;
+            /* candidates older than the ring: their four bytes are asked for NOW, before the collisions are sorted out and the
+             * near candidates compared -- two LDS round trips the trip to memory hides behind.  (A candidate that the
+             * resolution below replaces is a position of this batch, which the ring holds: a far candidate stays what it is.
+             * One load per lane and batch serves every search the batch holds.) */
+            const uint32_t mytag = E::tag_of(own4);
+            uint32_t vfar = 0;
+            if (valid && cand + kMaxDist >= cur && cand < e.lo_pos() && (!TG || (ohi >> PB) == mytag || (dbg & 1u)))
+                __builtin_memcpy(&vfar, src + cand, 4);
             /* in-batch collisions: an earlier lane with the same hash is what the serial loop would read */
             unsigned long long grouped = 0ull;
             bool resolved = false;
@@ -339,7 +383,6 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
             }
             /* candidates the ring still holds are compared there; an older one only if its tag says so and it could still
              * be the first hit */
-            const uint32_t mytag = E::tag_of(own4);
             const bool in_dist = valid && cand + kMaxDist >= cur;
             const bool near = cand >= e.lo_pos();
             const unsigned long long nearm = __ballot(in_dist && near && e.rd32(cand) == own4);
@@ -362,21 +405,15 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 {
                     const uint32_t first = hm ? ctz64(hm) : 64u;
                     const unsigned long long far = farm & from1 & (first >= 64u ? ~0ull : ((1ull << first) - 1ull));
-                    if (far) {
-                        /* one trip: every such lane's four bytes, and for the first of them -- the match, unless its tag
-                         * lied -- the bytes its extension both ways starts with */
-                        const uint32_t P = ctz64(far);
-                        const uint32_t mP = lane_get(cand, P);
-                        uint32_t v = 0, xf = 0;
-                        if ((far >> lane) & 1ull) __builtin_memcpy(&v, src + cand, 4);
-                        xf = src[mP + 4u + lane]; /* below ipP + 4 + lane: far candidates lie a ring's length back */
-                        const bool hf = ((far >> lane) & 1ull) && v == own4;
-                        const unsigned long long hfm = __ballot(hf);
-                        hm |= hfm;
-                        if (((hfm >> P) & 1ull) && !(dbg & 2u)) { have_win = true; wf = xf; }
-                    }
+                    if (far) hm |= __ballot(((far >> lane) & 1ull) && vfar == own4);
                 }
                 const uint32_t K = hm ? ctz64(hm) + 1u : T;
+                /* a far candidate won: the 64 bytes behind its first four (the forward extension's first round) are on their
+                 * way while the probes are committed */
+                if (hm && ((farm >> (K - 1u)) & 1ull) && !(dbg & 2u)) {
+                    have_win = true;
+                    wf = src[lane_get(cand, K - 1u) + 4u + lane]; /* below ip + 4 + lane: a far candidate lies a ring's length back */
+                }
                 LZT(1);
                 /* commit this search's probes up to K-1: colliding ones one by one, ascending, so the last writer wins */
                 {
@@ -433,7 +470,7 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 /* ================= the sequence joins the queue: written out 64 at a time (emit_queue) ================= */
                 if (lane == qn) { q_anchor = anchor; q_ip = ip_hit; q_match = match; q_end = a; }
                 qn++;
-                if (qn == 64u) { emit_queue(); qn = 0; }
+                if (qn == 64u) { LZT(5); emit_queue(); qn = 0; LZT(6); }
                 ip = a;
                 anchor = ip;
 #ifdef CRYO_LZ4E_PROF
@@ -474,7 +511,7 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
     }
     if (lane == 0) { out_size[blk] = e.op; status[blk] = CRYO_ST_OK; }
 #ifdef CRYO_LZ4E_PROF
-    if (lane == 0) { for (int k = 0; k < 6; k++) atomicAdd(&g_lz4e_prof[k], pt[k]); atomicAdd(&g_lz4e_prof[8], nseq_p); atomicAdd(&g_lz4e_prof[9], nbatch_p); }
+    if (lane == 0) { for (int k = 0; k < 7; k++) atomicAdd(&g_lz4e_prof[k], pt[k]); atomicAdd(&g_lz4e_prof[8], nseq_p); atomicAdd(&g_lz4e_prof[9], nbatch_p); }
 #endif
 }
 
@@ -521,8 +558,8 @@ hipError_t launch_lz4_compress_batch64(hipStream_t s, const uint8_t *d_src, uint
         unsigned long long h[16];
         (void)hipStreamSynchronize(s);
         (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_lz4e_prof), sizeof h);
-        fprintf(stderr, "[lz4 enc] %llu sequences, %llu batches (%.2f sequences per batch); cycles per sequence: batch set-up %.0f  decide + far trip %.0f  commit %.0f  backward %.0f  forward %.0f  emit %.0f\n",
-                h[8], h[9], (double)h[8] / h[9], (double)h[0] / h[8], (double)h[1] / h[8], (double)h[2] / h[8], (double)h[3] / h[8], (double)h[4] / h[8], (double)h[5] / h[8]);
+        fprintf(stderr, "[lz4 enc] %llu sequences, %llu batches (%.2f sequences per batch); cycles per sequence: batch set-up %.0f  decide + far trip %.0f  commit %.0f  queue %.0f  forward %.0f  rest %.0f  write-out %.0f\n",
+                h[8], h[9], (double)h[8] / h[9], (double)h[0] / h[8], (double)h[1] / h[8], (double)h[2] / h[8], (double)h[3] / h[8], (double)h[4] / h[8], (double)h[5] / h[8], (double)h[6] / h[8]);
         unsigned long long z[16] = {0};
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lz4e_prof), z, sizeof z);
     }
