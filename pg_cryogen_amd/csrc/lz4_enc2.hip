@@ -69,13 +69,15 @@ struct Enc : RingIn<kW, kStage> {
     using RingIn<kW, kStage>::dw;
 
     /* LZ4_hash5 of the bytes at p (table log 12): ((v << 24) * 889523592379) >> 52, in 32-bit pieces */
-    __device__ inline uint32_t hash(uint32_t p, uint32_t &first4) const
+    /* ... and the 8 bytes behind the first four (next8: what a match's forward extension starts with) */
+    __device__ inline uint32_t hash(uint32_t p, uint32_t &first4, uint64_t &next8) const
     {
-        const uint32_t d0 = dw(p, 0), d1 = dw(p, 1);
+        const uint32_t d0 = dw(p, 0), d1 = dw(p, 1), d2 = dw(p, 2), d3 = dw(p, 3);
         const uint32_t s = p & 3u;
         const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, s);
         const uint32_t b4 = __builtin_amdgcn_ubfe(d1, 8u * s, 8u);
         first4 = lo;
+        next8 = (uint64_t)__builtin_amdgcn_alignbyte(d2, d1, s) | ((uint64_t)__builtin_amdgcn_alignbyte(d3, d2, s) << 32);
         const uint32_t x_lo = lo << 24, x_hi = (lo >> 8) | (b4 << 24);
         const uint32_t c_lo = 0x1BBCDCBBu, c_hi = 0xCFu;
         const uint32_t top = __umulhi(x_lo, c_lo) + x_lo * c_hi + x_hi * c_lo;
@@ -326,7 +328,7 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
              * only as far as the ring can hold next to the first position */
             const bool ends = !(lane < sh || nxt <= mflimit_p1);
             const uint32_t base = pre ? ip - 2u : fwd;
-            const bool fits = cur + 9u <= base + (kW - kStage);
+            const bool fits = cur + 12u <= base + (kW - kStage);
             const unsigned long long endm = __ballot(ends);
             const unsigned long long stopm = endm | __ballot(!fits);
             const uint32_t T = stopm ? ctz64(stopm) : 64u; /* lanes 0 .. T-1 take part */
@@ -336,11 +338,12 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
             /* consecutive positions from lane 1 on (every probe one byte behind the last: the first 64 probes of a search at
              * acceleration 1): what lies behind a match found in this batch can be served from it (below) */
             const bool consecutive = accel == 1u && step == 1u && nb == (1u << kSkipTrigger) && !(dbg & 4u);
-            e.ensure(lane_get(cur, T - 1u) + 9u);
+            e.ensure(lane_get(cur, T - 1u) + 12u);
             uint32_t own4 = 0, h = 0, cand = 0, ohi = 0;
+            uint64_t own8 = 0;
             bool lost = false;
             if (valid) {
-                h = e.hash(cur, own4);
+                h = e.hash(cur, own4, own8);
                 if constexpr (kByteMarks) {
                     cand = L.tlo[h];
                     ohi = vthi[h];
@@ -361,9 +364,9 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
              * resolution below replaces is a position of this batch, which the ring holds: a far candidate stays what it is.
              * One load per lane and batch serves every search the batch holds.) */
             const uint32_t mytag = E::tag_of(own4);
-            uint32_t vfar = 0;
+            uint4 vfar = make_uint4(0, 0, 0, 0); /* 12 of the 16 bytes are used: the four compared, and the eight behind them */
             if (valid && cand + kMaxDist >= cur && cand < e.lo_pos() && (!TG || (ohi >> PB) == mytag || (dbg & 1u)))
-                __builtin_memcpy(&vfar, src + cand, 4);
+                __builtin_memcpy(&vfar, src + cand, 16);
             /* in-batch collisions: an earlier lane with the same hash is what the serial loop would read */
             unsigned long long grouped = 0ull;
             bool resolved = false;
@@ -385,7 +388,19 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
              * be the first hit */
             const bool in_dist = valid && cand + kMaxDist >= cur;
             const bool near = cand >= e.lo_pos();
-            const unsigned long long nearm = __ballot(in_dist && near && e.rd32(cand) == own4);
+            /* the candidate's twelve bytes from the ring (whatever a far candidate's lane reads here is not used): four to
+             * compare, eight that tell how far a match reaches -- most matches of `wide` end inside them, and need no
+             * forward extension of their own */
+            uint32_t c4, fq_near;
+            {
+                const uint32_t c0 = e.dw(cand, 0), c1 = e.dw(cand, 1), c2 = e.dw(cand, 2), c3 = e.dw(cand, 3);
+                const uint32_t sc = cand & 3u;
+                c4 = __builtin_amdgcn_alignbyte(c1, c0, sc);
+                const uint64_t m8 = (uint64_t)__builtin_amdgcn_alignbyte(c2, c1, sc) | ((uint64_t)__builtin_amdgcn_alignbyte(c3, c2, sc) << 32);
+                const uint64_t d8 = m8 ^ own8;
+                fq_near = d8 ? (uint32_t)__builtin_ctzll(d8) >> 3 : 8u;
+            }
+            const unsigned long long nearm = __ballot(in_dist && near && c4 == own4);
             const unsigned long long farm = __ballot(in_dist && !near && (!TG || resolved || (ohi >> PB) == mytag || (dbg & 1u)));
 #ifdef CRYO_LZ4E_PROF
             nbatch_p++;
@@ -405,14 +420,23 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 {
                     const uint32_t first = hm ? ctz64(hm) : 64u;
                     const unsigned long long far = farm & from1 & (first >= 64u ? ~0ull : ((1ull << first) - 1ull));
-                    if (far) hm |= __ballot(((far >> lane) & 1ull) && vfar == own4);
+                    if (far) hm |= __ballot(((far >> lane) & 1ull) && vfar.x == own4);
                 }
                 const uint32_t K = hm ? ctz64(hm) + 1u : T;
-                /* a far candidate won: the 64 bytes behind its first four (the forward extension's first round) are on their
-                 * way while the probes are committed */
-                if (hm && ((farm >> (K - 1u)) & 1ull) && !(dbg & 2u)) {
-                    have_win = true;
-                    wf = src[lane_get(cand, K - 1u) + 4u + lane]; /* below ip + 4 + lane: a far candidate lies a ring's length back */
+                /* how far the match reaches in the eight bytes behind the four compared (8: further) */
+                uint32_t fq = 0;
+                if (hm) {
+                    if ((farm >> (K - 1u)) & 1ull) {
+                        const uint64_t y = (uint64_t)lane_get(vfar.y, K - 1u) | ((uint64_t)lane_get(vfar.z, K - 1u) << 32);
+                        const uint64_t x = (uint64_t)lane_get((uint32_t)own8, K - 1u) | ((uint64_t)lane_get((uint32_t)(own8 >> 32), K - 1u) << 32);
+                        const uint64_t d8 = x ^ y;
+                        fq = d8 ? (uint32_t)__builtin_ctzll(d8) >> 3 : 8u;
+                        /* a long match on a far candidate: the next 64 bytes are on their way while the probes are committed */
+                        if (fq == 8u && !(dbg & 2u)) {
+                            have_win = true;
+                            wf = src[lane_get(cand, K - 1u) + 12u + lane]; /* below ip + 12 + lane: a far candidate lies a ring's length back */
+                        }
+                    } else fq = lane_get(fq_near, K - 1u);
                 }
                 LZT(1);
                 /* commit this search's probes up to K-1: colliding ones one by one, ascending, so the last writer wins */
@@ -444,8 +468,9 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 /* ================= extend forwards: 64 bytes per step, then 2 KiB per step =================
                  * from the four bytes the search compared (what the backward extension added in front of them is equal
                  * already): lane l of the far trip's window is the byte l behind the candidate's first four */
-                uint32_t a = ip_hit + 4u, b = match + 4u;
-                {
+                uint32_t a = ip_hit + 4u + fq, b = match + 12u;
+                if (fq < 8u) { if (a > matchlimit) a = matchlimit; } /* (the last five bytes of a block are literals) */
+                else {
                     bool first = true;
                     for (;;) {
                         e.ensure(a + 64u);
