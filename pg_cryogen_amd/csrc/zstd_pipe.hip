@@ -905,6 +905,13 @@ __device__ __attribute__((always_inline)) inline void zhufw_item(const ZPipe &P,
         if (phase == MAIN && z.pos - bound > 88 && hw_ready(z)) {
             if (n + 24u > cap) { phase = DONE; okw = false; }
             else {
+                /* ONE 16-byte store per turn (two halves of 4 .. 8 symbols each).  The walkers' stores are scattered -- 64 lines
+                 * per instruction -- and it is the number of such requests, not their bytes, that bounds this kernel: with an
+                 * 8-byte store per half a tile took 7.0 ms, with this 5.9 (profiles/r06_zstd_decode.txt; the input ring
+                 * replaced by a window in registers, twelve waves per CU instead of seven, but a load per lane and turn:
+                 * 10.4 ms, profiles/scripts/r06_zhufw_regwin.patch) */
+                uint64_t acc2[2];
+                uint32_t k2[2];
 #pragma unroll
                 for (int half = 0; half < 2; half++) {
                     uint64_t c = hw_window(L.ring, z, myring);
@@ -920,8 +927,16 @@ __device__ __attribute__((always_inline)) inline void zhufw_item(const ZPipe &P,
                         k += 1u + (e >> 24);
                     }
                     z.cb = z.s0 + ((z.pos - 1) >> 3);
-                    __builtin_memcpy(tmp + n, &acc, 8);
-                    n += k;
+                    acc2[half] = acc;
+                    k2[half] = k;
+                }
+                {
+                    const uint32_t sh = 8u * k2[0]; /* 32 .. 64; bytes k .. 7 of a half's word are zero */
+                    const uint64_t lo = acc2[0] | (sh < 64u ? acc2[1] << sh : 0ull);
+                    const uint64_t hi = sh < 64u ? acc2[1] >> (64u - sh) : acc2[1];
+                    const uint4 v = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+                    __builtin_memcpy(tmp + n, &v, 16);
+                    n += k2[0] + k2[1];
                 }
                 if (mark) { /* every fourth turn: 15 marks over ~4 000 bits */
                     tc++;
