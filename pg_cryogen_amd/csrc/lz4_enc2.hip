@@ -469,8 +469,8 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                  * from the four bytes the search compared (what the backward extension added in front of them is equal
                  * already): lane l of the far trip's window is the byte l behind the candidate's first four */
                 uint32_t a = ip_hit + 4u + fq, b = match + 12u;
-                if (fq < 8u) { if (a > matchlimit) a = matchlimit; } /* (the last five bytes of a block are literals) */
-                else {
+                if (a >= matchlimit) a = matchlimit; /* (the last five bytes of a block are literals) */
+                else if (fq == 8u) {
                     bool first = true;
                     for (;;) {
                         e.ensure(a + 64u);

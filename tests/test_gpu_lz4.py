@@ -193,6 +193,31 @@ def test_lz4_encode_batch_kernel_corners(codec, oracle):
                 assert np.array_equal(got[i], exp), (n, accel, i, len(got[i]), len(exp))
 
 
+def test_lz4_encode_last_match_runs_into_the_block_end(codec, oracle):
+    """the last five bytes of a block are literals (liblz4's matchlimit): a match whose bytes go on being equal up to
+    the block's end stops there -- for every distance of the last match's start from the end (the encoder knows the
+    first twelve bytes of a match from the search itself: matches that end inside them, at them and behind them), near
+    and far candidates, with and without literals in front"""
+    rng = np.random.default_rng(29)
+    words = [rng.integers(0, 256, int(rng.integers(5, 13)), dtype=np.uint8) for _ in range(300)]
+    for n in (65547, 70000, 131072):
+        blocks = []
+        for tail in range(6, 40):
+            for dist in (8, 300, 5000):
+                # text of 300 words: matches all along, so the search is still taking every position when it gets to the end
+                a = np.concatenate([words[int(k)] for k in rng.integers(0, 300, n // 5)])[:n].copy()
+                a[n - tail:] = a[n - tail - dist:n - dist]    # the block's last `tail` bytes repeat what lies `dist` back
+                blocks.append(a)
+                b = a.copy()
+                b[n - tail - 1] ^= 0x55                        # ... with a mismatch right in front of them
+                blocks.append(b)
+        for accel in (1, 4):
+            got = codec.compress_blocks(METHOD_LZ4, accel, blocks)
+            for i, b in enumerate(blocks):
+                exp = oracle.lz4_compress(b, accel)
+                assert np.array_equal(got[i], exp), (n, accel, i, len(got[i]), len(exp))
+
+
 def test_lz4_golden_cells_on_gpu(codec, oracle):
     """tests/golden/vectors.json (liblz4 1.9.3 called as reference compression.c:70-72): the device encoder's
     bytes hash to the golden comp_sha256 for every LZ4 cell, all sizes incl. 128 KiB and 1 MiB, and the device
