@@ -319,8 +319,14 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
             if (pre) { fwd = ip + 1u; step = 1; nb = accel << kSkipTrigger; }
             const uint32_t sh = pre ? 2u : 0u;
             const uint32_t q = lane - sh;
-            const uint32_t sk = lane < sh ? 0u : (q == 0u ? step : (nb + q - 1u) >> kSkipTrigger);
-            const uint32_t inc = scan64_incl(sk);
+            /* (the first 64 probes of a search at acceleration 1 are consecutive positions: no scan) */
+            const bool fresh = accel == 1u && step == 1u && nb == (1u << kSkipTrigger);
+            uint32_t sk, inc;
+            if (fresh) { sk = lane < sh ? 0u : 1u; inc = lane < sh ? 0u : q + 1u; }
+            else {
+                sk = lane < sh ? 0u : (q == 0u ? step : (nb + q - 1u) >> kSkipTrigger);
+                inc = scan64_incl(sk);
+            }
             uint32_t cur = fwd + inc - sk;
             const uint32_t nxt = fwd + inc;
             if (pre && lane < 2u) cur = lane == 0u ? ip - 2u : ip;
@@ -337,7 +343,7 @@ k_lz4_enc2(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
             if (T == 0u) { done = true; break; }
             /* consecutive positions from lane 1 on (every probe one byte behind the last: the first 64 probes of a search at
              * acceleration 1): what lies behind a match found in this batch can be served from it (below) */
-            const bool consecutive = accel == 1u && step == 1u && nb == (1u << kSkipTrigger) && !(dbg & 4u);
+            const bool consecutive = fresh && !(dbg & 4u);
             e.ensure(lane_get(cur, T - 1u) + 12u);
             uint32_t own4 = 0, h = 0, cand = 0, ohi = 0;
             uint64_t own8 = 0;
