@@ -108,3 +108,6 @@ timeout 300 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2 |
 timeout 400 python3 tests/stress_gpu.py 150 61 2>&1 | tail -3 | tee -a $out
 timeout 400 python3 tests/stress_gpu.py fuzz 100 62 2>&1 | tail -3 | tee -a $out
 timeout 900 python3 bench.py --gpus 2 --steps 20 2>/dev/null | tail -1 | cut -c1-900 | tee -a $out
+# LZ4 encoder's instruction mix, the crossover table of INTEGRATION.md with this round's encoders
+timeout 600 bash profiles/scripts/pmc_sq.sh ${T}_lz4_enc lz4 > gpurun_out/${T}_collect_sq_enc.log 2>&1; tail -n 3 gpurun_out/${T}_collect_sq_enc.log | cut -c1-600
+timeout 900 python3 profiles/crossover.py 2>&1 | grep -v "^W2026\|amdgpu.ids" > gpurun_out/${T}_crossover.txt; tail -40 gpurun_out/${T}_crossover.txt
