@@ -18,13 +18,20 @@
  *     that lane's position as its candidate instead -- exactly what the serial loop would have read.
  *     Such collisions are detected by marking the slot's high byte with the lane number and reading it
  *     back, and resolved per colliding hash value (rare);
- *   - the first lane with a valid match ends the batch; only the probes up to and including it are
- *     committed to the table, colliding ones in ascending order;
- *   - backward / forward match extension compare 64 bytes per step; literal runs are copied 64 bytes
- *     per step straight to the output.
- * The kernel is latency bound (serial chain of LDS round trips per sequence), so what matters is waves
- * per CU, i.e. LDS per wave: the position table is 4096 x (u16 low | 1, 4 or 8 high bits) = 8.5-12 KiB and the ring only
- * 2 KiB (measured on 64k x 128 KiB "wide" blocks: 64 KiB ring 8.6 GB/s, 16 KiB 19, 8 KiB 25.6, 2 KiB 29).
+ *   - the first lane with a valid match ends the search; only the probes up to and including it are
+ *     committed to the table, colliding ones in ascending order; what the serial walk does behind the match
+ *     (store ip - 2, test ip, search on from ip + 1) are further lanes of the same batch when the probes are
+ *     consecutive positions: several sequences per batch;
+ *   - every probe and candidate is known twelve bytes deep (the four compared and the eight behind them): a match
+ *     that ends inside them needs no extension; longer ones go on 64 bytes per step, then 2 KiB per trip;
+ *   - what the search does not need is not on its chain: a found sequence (literal run's start, probe, candidate,
+ *     match end) waits in a queue, one per lane, and 64 at a time are extended backwards, sized, placed by a scan
+ *     and written out lane per sequence (emit_queue).
+ * The kernel is latency bound (a block's chain of LDS round trips, and the part of the far candidates' trip to memory
+ * that the batch set-up does not cover), so what matters is how short that chain is and how many blocks a CU's LDS
+ * holds: the position table is 4096 x (u16 low | 1, 4 or 8 high bits) = 8.5-12 KiB and the ring 1 KiB (measured on
+ * 64k x 128 KiB "wide" blocks, round 2: 64 KiB ring 8.6 GB/s, 16 KiB 19, 8 KiB 25.6, 2 KiB 29; round 6:
+ * profiles/r06_lz4_enc.txt, 43 -> 68 GB/s).
  */
 #include "enc_ring.h"
 #include "kernels.h"
