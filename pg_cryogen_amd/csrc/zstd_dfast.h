@@ -344,10 +344,26 @@ __device__ uint32_t block_fast_gbatch(uint32_t *table, uint8_t *mark, const CPar
     uint32_t litv = anchor + lane < iend ? base[anchor + lane] : 0u;
     uint64_t v0n = 0, v1n = 0;
     bool have = false;
+    /* iterations per step: W behind a match; twice as many after every step that found nothing, up to the wave's 64 (a step
+     * is a trip to memory whatever its width; rows of hex digits or random bytes are mostly steps without a hit) */
+    uint32_t Wc = W;
     while (ip + 1u < ilimit) { /* ip is the walk's ip0; ip1 = ip0 + 1 */
         const uint32_t st = ((ip - anchor) >> 7) + step_size;
-        const uint32_t i0 = ip + lane * st;
-        bool valid = lane < W && i0 + 1u < ilimit && ((i0 - anchor) >> 7) + step_size == st;
+        uint32_t i0 = ip + lane * st, inext = i0 + st, nk = Wc;
+        if ((((ip + (Wc - 1u) * st) - anchor) >> 7) + step_size != st) {
+            /* the walk's stride grows with the literal run (every 128 bytes of it): the lanes' positions are the walk's own
+             * recurrence, lane by lane -- a few hundred scalar instructions against a trip to memory per lane group (an
+             * incompressible block was one iteration per step from stride 64 on) */
+            uint32_t pos = ip;
+            nk = 0;
+            for (uint32_t k = 0; k < Wc && pos + 1u < ilimit; k++) {
+                const uint32_t sk = ((pos - anchor) >> 7) + step_size;
+                if (lane == k) { i0 = pos; inext = pos + sk; }
+                pos += sk;
+                nk = k + 1u;
+            }
+        }
+        bool valid = lane < nk && i0 + 1u < ilimit;
         const uint64_t v0 = have ? v0n : (valid ? ld64v(base + i0) : 0ull);
         const uint64_t v1 = have ? v1n : (valid ? ld64v(base + i0 + 1u) : 0ull);
         have = false;
@@ -416,7 +432,8 @@ __device__ uint32_t block_fast_gbatch(uint32_t *table, uint8_t *mark, const CPar
             if (lane < ncommit) table[h0] = n0;
             asm volatile("" ::: "memory");
             if (lane < ncommit) table[h1] = n1;
-            if (!hit) { ip += ncommit * st; continue; }
+            if (!hit) { ip = (uint32_t)__builtin_amdgcn_readlane(inext, ncommit - 1u); Wc = Wc * 2u < 64u ? Wc * 2u : 64u; continue; }
+            Wc = W;
         }
         if (isrep) offcode = 0;
         else { off2 = off1; off1 = seq_ip - m; offcode = off1 + 2u; }
