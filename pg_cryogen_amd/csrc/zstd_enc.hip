@@ -625,6 +625,30 @@ __device__ inline void zprof(HufState &hs, int k)
     if (hs.prof) { const unsigned long long now = __builtin_amdgcn_s_memtime(); if (threadIdx.x == 0) atomicAdd(&hs.prof[k], now - hs.t); hs.t = now; }
 }
 
+/* n bytes from one place in memory to another by the wave: 16 bytes per lane, four such loads in flight (a byte per lane and
+ * trip, 2 048 trips for an incompressible block's literals, raw block and last literals, was most of what `random` cost) */
+__device__ inline void wave_copy_bytes(uint8_t *dst, const uint8_t *src, uint32_t n, uint32_t lane)
+{
+    uint32_t o = 0;
+    for (; o + 4096u <= n; o += 4096u) {
+        uint4 a, b, c, d;
+        __builtin_memcpy(&a, src + o + 16u * lane, 16);
+        __builtin_memcpy(&b, src + o + 1024u + 16u * lane, 16);
+        __builtin_memcpy(&c, src + o + 2048u + 16u * lane, 16);
+        __builtin_memcpy(&d, src + o + 3072u + 16u * lane, 16);
+        __builtin_memcpy(dst + o + 16u * lane, &a, 16);
+        __builtin_memcpy(dst + o + 1024u + 16u * lane, &b, 16);
+        __builtin_memcpy(dst + o + 2048u + 16u * lane, &c, 16);
+        __builtin_memcpy(dst + o + 3072u + 16u * lane, &d, 16);
+    }
+    for (; o + 1024u <= n; o += 1024u) {
+        uint4 a;
+        __builtin_memcpy(&a, src + o + 16u * lane, 16);
+        __builtin_memcpy(dst + o + 16u * lane, &a, 16);
+    }
+    for (uint32_t i = o + lane; i < n; i += 64u) dst[i] = src[i];
+}
+
 /* ZSTD_compressLiterals; returns the literals-section size.  Updates hs.next_new. */
 __device__ uint32_t compress_literals(EncLds &L, uint8_t *dst, const uint8_t *src, uint32_t n, HufState &hs,
                                       bool disable, uint32_t lane)
@@ -637,7 +661,7 @@ __device__ uint32_t compress_literals(EncLds &L, uint8_t *dst, const uint8_t *sr
             else if (fl == 2u) { const uint32_t h = 0u + (1u << 2) + (n << 4); dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); }
             else { const uint32_t h = 0u + (3u << 2) + (n << 4); dst[0] = (uint8_t)h; dst[1] = (uint8_t)(h >> 8); dst[2] = (uint8_t)(h >> 16); }
         }
-        for (uint32_t i = lane; i < n; i += 64u) dst[fl + i] = src[i];
+        wave_copy_bytes(dst + fl, src, n, lane);
         return fl + n;
     };
     if (disable || n <= 63u) return raw();
@@ -646,7 +670,33 @@ __device__ uint32_t compress_literals(EncLds &L, uint8_t *dst, const uint8_t *sr
     /* histogram */
     for (uint32_t i = lane; i < 256u; i += 64u) L.hist[i] = 0;
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t i = lane; i < n; i += 64u) atomicAdd(&L.hist[src[i]], 1u);
+    {   /* 16 bytes per lane and load, four loads in flight (a byte per lane and trip: 2 048 trips for 128 KiB of literals) */
+        auto add16 = [&](const uint4 v) {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                atomicAdd(&L.hist[w[k] & 255u], 1u);
+                atomicAdd(&L.hist[(w[k] >> 8) & 255u], 1u);
+                atomicAdd(&L.hist[(w[k] >> 16) & 255u], 1u);
+                atomicAdd(&L.hist[w[k] >> 24], 1u);
+            }
+        };
+        uint32_t o = 0;
+        for (; o + 4096u <= n; o += 4096u) {
+            uint4 a, b, c, d;
+            __builtin_memcpy(&a, src + o + 16u * lane, 16);
+            __builtin_memcpy(&b, src + o + 1024u + 16u * lane, 16);
+            __builtin_memcpy(&c, src + o + 2048u + 16u * lane, 16);
+            __builtin_memcpy(&d, src + o + 3072u + 16u * lane, 16);
+            add16(a); add16(b); add16(c); add16(d);
+        }
+        for (; o + 1024u <= n; o += 1024u) {
+            uint4 a;
+            __builtin_memcpy(&a, src + o + 16u * lane, 16);
+            add16(a);
+        }
+        for (uint32_t i = o + lane; i < n; i += 64u) atomicAdd(&L.hist[src[i]], 1u);
+    }
     __builtin_amdgcn_wave_barrier();
     uint32_t max_sym = 255, largest = 0;
     while (!L.hist[max_sym]) max_sym--;
@@ -1303,7 +1353,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 else if (finder == 0) last_ll = block_fast_gbatch(table, df_mark, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane, width);
                 else last_ll = block_fast(table, cp, base, src + ip, bs, nrep, ws, ss, dict_limit, lane);
                 if constexpr (PROF) { const unsigned long long t = __builtin_amdgcn_s_memtime(); t_mf += t - t_prev; t_prev = t; }
-                for (uint32_t i = lane; i < last_ll; i += 64u) (ws + kWsLit)[ss.nlit + i] = src[ip + bs - last_ll + i];
+                wave_copy_bytes(ws + kWsLit + ss.nlit, src + ip + bs - last_ll, last_ll, lane);
                 ss.nlit += last_ll;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 if constexpr (PROF) hs.t = __builtin_amdgcn_s_memtime();
@@ -1313,7 +1363,16 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
                 if (!first && csize < 25u) { /* RLE block for constant non-first blocks */
                     const uint32_t b0 = uni(src[ip]);
                     bool diff = false;
-                    for (uint32_t i = lane; i < bs; i += 64u) diff |= (src[ip + i] != b0);
+                    {
+                        const uint32_t b4 = b0 * 0x01010101u;
+                        uint32_t o = 0;
+                        for (; o + 1024u <= bs; o += 1024u) {
+                            uint4 v;
+                            __builtin_memcpy(&v, src + ip + o + 16u * lane, 16);
+                            diff |= ((v.x ^ b4) | (v.y ^ b4) | (v.z ^ b4) | (v.w ^ b4)) != 0u;
+                        }
+                        for (uint32_t i = o + lane; i < bs; i += 64u) diff |= (src[ip + i] != b0);
+                    }
                     if (__ballot(diff) == 0ull) { csize = 1; if (lane == 0) dst[op + 3] = (uint8_t)b0; }
                 }
                 if (csize > 1u) {
@@ -1336,7 +1395,7 @@ k_zstd_enc(const uint8_t *__restrict__ src_base, uint64_t src_stride, uint32_t n
             if (csize == 0u) {
                 const uint32_t h = last + (0u << 1) + (bs << 3);
                 if (lane == 0) { dst[op] = (uint8_t)h; dst[op + 1] = (uint8_t)(h >> 8); dst[op + 2] = (uint8_t)(h >> 16); }
-                for (uint32_t i = lane; i < bs; i += 64u) dst[op + 3u + i] = src[ip + i];
+                wave_copy_bytes(dst + op + 3u, src + ip, bs, lane);
                 op += 3u + bs;
             } else {
                 const uint32_t h = csize == 1u ? last + (1u << 1) + (bs << 3) : last + (2u << 1) + (csize << 3);
